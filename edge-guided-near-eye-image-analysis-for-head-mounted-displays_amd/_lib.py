@@ -1,0 +1,107 @@
+"""ctypes binding of the C-ABI in ``include/egne_hip.h`` (``csrc/libegne_hip.so``).
+
+There is no fallback: :func:`lib` raises ``RuntimeError`` when the shared library has not been
+built (``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C .../csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libegne_hip.so")
+
+MAXSEG, MAXGROUP = 8, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+c_fp = C.c_void_p  # device pointers travel as integers
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", c_fp), ("pix_stride", C.c_int64), ("ch_off", C.c_int32), ("Cp", C.c_int32),
+                ("scale", c_fp), ("shift", c_fp), ("act_in", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
+                ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("pad_mode", C.c_int32),
+                ("ngroups", C.c_int32), ("dil", C.c_int32 * MAXGROUP),
+                ("nseg", C.c_int32), ("seg", Seg * MAXSEG),
+                ("Ktot", C.c_int32), ("CoutP", C.c_int32),
+                ("w", c_fp), ("bias", c_fp), ("act", C.c_int32),
+                ("post_scale", c_fp), ("post_shift", c_fp),
+                ("residual", c_fp), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
+                ("out", c_fp), ("out_pix_stride", C.c_int64), ("out_ch_off", C.c_int32),
+                ("Cout_store", C.c_int32)]
+
+
+class BdcnTailDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("s", c_fp * 5), ("s1", c_fp * 5), ("h", C.c_int32 * 5), ("w", C.c_int32 * 5),
+                ("stride", C.c_int32 * 5), ("crop", C.c_int32 * 5), ("up", c_fp * 5),
+                ("fuse_w", c_fp), ("fuse_b", c_fp), ("out", c_fp * 11), ("edge_thres", C.c_int32)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("logits", c_fp), ("pix_stride", C.c_int64), ("ch_off", C.c_int32),
+                ("target", c_fp), ("spatWts", c_fp), ("distMap", c_fp), ("cond", c_fp),
+                ("pupil_center", c_fp), ("elNorm", c_fp), ("elOut", c_fp), ("alpha", C.c_float),
+                ("grid_x", c_fp), ("grid_y", c_fp),
+                ("partials", c_fp), ("out_terms", c_fp), ("pred_c", c_fp), ("elPred", c_fp),
+                ("mask", c_fp), ("op_nchw", c_fp)]
+
+
+# name -> (restype, argtypes); every symbol include/egne_hip.h declares
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SIGNATURES = {
+    "egne_conv2d_fwd": (i32, [C.POINTER(ConvDesc), vp]),
+    "egne_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
+    "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "egne_norm_stats": (i32, [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
+    "egne_affine_inplace": (i32, [vp, i64, i32, i32, i64, vp, vp, vp]),
+    "egne_avgpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_maxpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "egne_upsample2x": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_nchw_to_nhwc": (i32, [vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
+    "egne_nhwc_to_nchw": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, vp]),
+    "egne_bdcn_stage_scores": (i32, [C.POINTER(vp), i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egne_bdcn_tail": (i32, [C.POINTER(BdcnTailDesc), vp]),
+    "egne_loss_workspace_floats": (i64, [i32, i32, i32]),
+    "egne_loss_fwd": (i32, [C.POINTER(LossDesc), vp]),
+    "egne_ellipse_head_act": (i32, [vp, i32, i32, vp]),
+    "egne_selu_inplace": (i32, [vp, i64, vp]),
+    "egne_spatial_mean": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
+    "egne_ellipse_fit": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "egne_last_error": (C.c_char_p, []),
+    "egne_version": (i32, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises RuntimeError if it is missing -- by design."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "HIP extension not built: %s is missing (run __graft_entry__.build()). "
+                "This package has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().egne_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what or "egne call", status, (msg or b"").decode()))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,284 @@
+// Implicit-GEMM convolution for gfx950: fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32.
+//
+// GEMM view:  M = B*Ho*Wo output pixels (flat, so odd sizes such as 29x39 or 15x20 waste nothing),
+//             N = Cout, K = taps * sum(channels of the input slices).
+// A (pixels x K) is gathered on the fly from up to EGNE_MAXSEG NHWC channel slices -- this is how
+// torch.cat disappears -- with zero / reflect padding and an optional per-(n,c) affine + LeakyReLU
+// fused into the load (InstanceNorm / Transition_down).  B (Cout x K) is the pre-packed weight
+// [group][tap][CoutP][Ktot], K contiguous, so both operands are "row x contiguous-k" LDS tiles read
+// with ds_read_b128: lane (i = lane&31, h = lane>>5) fetches k = 8*s + 4*h .. +3 of row i and feeds
+// four 32x32x2 MFMAs (the k pairing (j, 4+j) is the same for A and B, and the K order is free).
+// LDS rows are padded to 36 floats: ds_read_b128 lane groups then hit 16 distinct 16-B slots.
+//
+// Staging is global -> registers -> LDS with the loads of step s+1 issued before the MFMAs of
+// step s (one LDS buffer, two barriers per step, 2 workgroups per CU hide each other's barriers).
+// `ngroups`=3 runs the three dilated 3x3 convs of a BDCN MSBlock back to back on one accumulator
+// set and sums relu(conv_g) in registers; the block's first conv output is added as `residual`.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32;        // K (channels) per step
+constexpr int LDK = KC + 4;   // LDS row pitch in floats (144 B)
+
+struct KState {
+  int g, seg, c0, tap, kofs;  // group, slice, first channel of the step, tap, K offset of the slice
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == EGNE_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EGNE_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+template <int WM, int WN, bool GROUPED>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p) {
+  constexpr int BM = 128 * WM, BN = 32 * WN;
+  constexpr int AR = BM / 32;  // A rows staged per thread
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDK];
+  float* As = lds;
+  float* Bs = lds + BM * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int T = p.kh * p.kw;
+
+  // ---- loader coordinates: thread (rbase, col4) stages rows rbase+32*i, floats col4*4..+3 ----
+  const int col4 = tid & 7, rbase = tid >> 3;
+  int pb[AR], py[AR], px[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    long long m = m0 + rbase + 32 * i;
+    if (m < M) {
+      int hw = p.Ho * p.Wo;
+      int b = (int)(m / hw);
+      int r = (int)(m - (long long)b * hw);
+      int oy = r / p.Wo;
+      pb[i] = b;
+      py[i] = oy * p.stride;
+      px[i] = (r - oy * p.Wo) * p.stride;
+    } else {
+      pb[i] = -1; py[i] = 0; px[i] = 0;
+    }
+  }
+
+  f32x4 ra[AR];
+  f32x4 rb[WN];
+
+  auto advance = [&](KState& s) {
+    if (++s.tap < T) return;
+    s.tap = 0;
+    s.c0 += KC;
+    if (s.c0 < p.seg[s.seg].Cp) return;
+    s.c0 = 0;
+    s.kofs += p.seg[s.seg].Cp;
+    if (++s.seg < p.nseg) return;
+    s.seg = 0; s.kofs = 0;
+    ++s.g;
+  };
+
+  auto load_step = [&](const KState& s) {
+    const egne_seg sg = p.seg[s.seg];
+    const int dil = p.dil[s.g];
+    const int ky = s.tap / p.kw, kx = s.tap - ky * p.kw;
+    const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+    const int c = s.c0 + col4 * 4;
+    const bool cok = c < sg.Cp;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      int iy = py[i] + dy, ix = px[i] + dx;
+      bool ok = cok && pb[i] >= 0;
+      if (p.pad_mode == 1) {
+        iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+      } else {
+        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      }
+      if (ok) {
+        const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c;
+        v = *(const f32x4*)src;
+        if (sg.scale) {
+          const f32x4 sc = *(const f32x4*)(sg.scale + (long long)pb[i] * sg.Cp + c);
+          const f32x4 sh = *(const f32x4*)(sg.shift + (long long)pb[i] * sg.Cp + c);
+          v = v * sc + sh;
+        }
+        if (sg.act_in == EGNE_ACT_LEAKY) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        } else if (sg.act_in == EGNE_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+      }
+      ra[i] = v;
+    }
+    const float* wbase = p.w + ((long long)(s.g * T + s.tap) * p.CoutP + n0 + rbase) * p.Ktot + s.kofs + c;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cok) v = *(const f32x4*)(wbase + (long long)(32 * j) * p.Ktot);
+      rb[j] = v;
+    }
+  };
+
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = ra[i];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) *(f32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
+  };
+
+  f32x16 acc[WM][WN];
+  f32x16 res[GROUPED ? WM : 1][GROUPED ? WN : 1];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      acc[a][b] = (f32x16)(0.f);
+      if (GROUPED) res[a][b] = (f32x16)(0.f);
+    }
+
+  // total number of K steps
+  int steps_per_group = 0;
+  for (int s = 0; s < p.nseg; ++s) steps_per_group += ((p.seg[s].Cp + KC - 1) / KC) * T;
+  const int nsteps = steps_per_group * p.ngroups;
+
+  KState cur = {0, 0, 0, 0, 0};
+  load_step(cur);
+  store_step();
+  __syncthreads();
+
+  const float* arow = &As[(wave * 32 * WM + li) * LDK + lh * 4];
+  const float* brow = &Bs[li * LDK + lh * 4];
+
+  for (int step = 0; step < nsteps; ++step) {
+    KState nxt = cur;
+    advance(nxt);
+    const bool more = step + 1 < nsteps;
+    if (more) load_step(nxt);
+
+    int rem = p.seg[cur.seg].Cp - cur.c0;
+    const int nk8 = rem >= KC ? KC / 8 : (rem >> 3);
+    for (int s = 0; s < nk8; ++s) {
+      f32x4 a[WM], b[WN];
+#pragma unroll
+      for (int tm = 0; tm < WM; ++tm) a[tm] = *(const f32x4*)(arow + tm * 32 * LDK + s * 8);
+#pragma unroll
+      for (int tn = 0; tn < WN; ++tn) b[tn] = *(const f32x4*)(brow + tn * 32 * LDK + s * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+
+    if (GROUPED && (!more || nxt.g != cur.g)) {
+      // end of a dilation group: res += act(acc + bias_g)
+#pragma unroll
+      for (int tn = 0; tn < WN; ++tn) {
+        const int n = n0 + tn * 32 + li;
+        const float bv = p.bias ? p.bias[cur.g * p.CoutP + n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) res[tm][tn][r] += act_apply(acc[tm][tn][r] + bv, p.act);
+          acc[tm][tn] = (f32x16)(0.f);
+        }
+      }
+    }
+
+    __syncthreads();
+    if (more) store_step();
+    __syncthreads();
+    cur = nxt;
+  }
+
+  // ---- epilogue: lane holds column n of 16 rows: row = (r&3) + 8*(r>>2) + 4*lh ----
+#pragma unroll
+  for (int tn = 0; tn < WN; ++tn) {
+    const int n = n0 + tn * 32 + li;
+    const bool nok = n < p.Cout_store;
+    float bv = 0.f, ps = 1.f, pt = 0.f;
+    if (!GROUPED && p.bias) bv = p.bias[n];
+    if (p.post_scale) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+#pragma unroll
+    for (int tm = 0; tm < WM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + wave * 32 * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nok && m < M) {
+          float v = GROUPED ? res[tm][tn][r] : act_apply(acc[tm][tn][r] + bv, p.act);
+          if (p.post_scale) v = v * ps + pt;
+          if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
+          p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN>
+int launch(const egne_conv_desc& d, hipStream_t st) {
+  constexpr int BM = 128 * WM, BN = 32 * WN;
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / BN));
+  if (d.ngroups > 1)
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, true>), grid, dim3(256), 0, st, d);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false>), grid, dim3(256), 0, st, d);
+  return egne::check_launch("egne_conv2d_fwd");
+}
+
+}  // namespace
+
+extern "C" int egne_conv2d_fwd(const egne_conv_desc* dp, void* stream) {
+  EGNE_REQUIRE(dp != nullptr, "conv: null descriptor");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0, "conv: bad shape %dx%dx%d -> %dx%d", d.B, d.H, d.W, d.Ho, d.Wo);
+  EGNE_REQUIRE(d.kh > 0 && d.kw > 0 && d.stride > 0, "conv: bad kernel %dx%d stride %d", d.kh, d.kw, d.stride);
+  EGNE_REQUIRE(d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP, "conv: ngroups %d", d.ngroups);
+  EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG, "conv: nseg %d", d.nseg);
+  EGNE_REQUIRE(d.pad_mode == 0 || d.pad_mode == 1, "conv: pad_mode %d", d.pad_mode);
+  int ktot = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr != nullptr, "conv: seg %d null", s);
+    EGNE_REQUIRE(g.Cp > 0 && g.Cp % 8 == 0, "conv: seg %d Cp=%d not a multiple of 8", s, g.Cp);
+    EGNE_REQUIRE(g.ch_off % 4 == 0 && g.pix_stride % 4 == 0, "conv: seg %d offset/stride not 16-B aligned", s);
+    EGNE_REQUIRE(g.ch_off + g.Cp <= g.pix_stride, "conv: seg %d exceeds pixel stride", s);
+    EGNE_REQUIRE(((uintptr_t)g.ptr & 15) == 0, "conv: seg %d pointer not 16-B aligned", s);
+    EGNE_REQUIRE((g.scale == nullptr) == (g.shift == nullptr), "conv: seg %d scale/shift mismatch", s);
+    ktot += g.Cp;
+  }
+  EGNE_REQUIRE(ktot == d.Ktot, "conv: Ktot %d != sum of slices %d", d.Ktot, ktot);
+  EGNE_REQUIRE(d.CoutP > 0 && d.CoutP % 32 == 0, "conv: CoutP %d", d.CoutP);
+  EGNE_REQUIRE(d.Cout_store > 0 && d.Cout_store <= d.CoutP, "conv: Cout_store %d", d.Cout_store);
+  EGNE_REQUIRE(d.w != nullptr && d.out != nullptr, "conv: null weight/output");
+  EGNE_REQUIRE(((uintptr_t)d.w & 15) == 0, "conv: weight pointer not 16-B aligned");
+  EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv: output slice exceeds pixel stride");
+  EGNE_REQUIRE((d.post_scale == nullptr) == (d.post_shift == nullptr), "conv: post affine mismatch");
+  for (int g = 0; g < d.ngroups; ++g) EGNE_REQUIRE(d.dil[g] >= 1, "conv: dilation");
+  if (d.pad_mode == 1)
+    EGNE_REQUIRE(d.pad_h < d.H && d.pad_w < d.W, "conv: reflect pad larger than input");
+  // output size must match the convolution arithmetic for every group (pad scales with dilation)
+  for (int g = 0; g < d.ngroups; ++g) {
+    int ho = (d.H + 2 * d.pad_h * d.dil[g] - d.dil[g] * (d.kh - 1) - 1) / d.stride + 1;
+    int wo = (d.W + 2 * d.pad_w * d.dil[g] - d.dil[g] * (d.kw - 1) - 1) / d.stride + 1;
+    EGNE_REQUIRE(ho == d.Ho && wo == d.Wo, "conv: output %dx%d inconsistent with geometry (%dx%d)", d.Ho, d.Wo, ho, wo);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice: the widest N tile that does not add padding beyond the 32-multiple
+  const int c = d.CoutP;
+  if (c % 128 == 0) return launch<1, 4>(d, st);
+  if (c % 64 == 0) return launch<2, 2>(d, st);
+  return launch<2, 1>(d, st);
+}

@@ -1,0 +1,319 @@
+// HBM-bound helper kernels on NHWC channel slices: normalisation statistics, pooling, bilinear
+// upsampling, layout conversion, small activations.  All loads/stores are 16 B per lane along the
+// channel axis (slices are 16-B aligned and padded to multiples of 8 channels).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm / BatchNorm statistics: two deterministic stages, fp64 accumulation.
+//   stage 1: grid (nchunk, ceil(Cp/32), Bn); block = 8 channel-vectors x 32 pixel rows
+//   stage 2: one thread per (n, c)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_stats_partial(const float* __restrict__ x, long long pix_stride,
+                                                          int ch_off, int Cp, long long npix_per_n, int nchunk,
+                                                          double* __restrict__ ws) {
+  const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
+  const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
+  const int c = cg * 32 + v * 4;
+  const long long per = (npix_per_n + nchunk - 1) / nchunk;
+  const long long p0 = (long long)chunk * per;
+  const long long p1 = p0 + per < npix_per_n ? p0 + per : npix_per_n;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (c < Cp) {
+    const float* base = x + (long long)n * npix_per_n * pix_stride + ch_off + c;
+    for (long long p = p0 + row; p < p1; p += 32) {
+      const f32x4 t = *(const f32x4*)(base + p * pix_stride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += t[e]; q[e] += (double)t[e] * t[e]; }
+    }
+  }
+  __shared__ double sh[32][8][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sh[row][v][e] = s[e]; sh[row][v][4 + e] = q[e]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int vv = threadIdx.x >> 3, e = threadIdx.x & 7;  // e<4: sum of channel e, else sumsq
+    double a = 0;
+    for (int r = 0; r < 32; ++r) a += sh[r][vv][e];
+    const int cc = cg * 32 + vv * 4 + (e & 3);
+    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + (e >> 2)] = a;
+  }
+}
+
+__global__ void norm_stats_final(const double* __restrict__ ws, int Cp, int Bn, int nchunk, long long npix_per_n,
+                                 float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                 float* __restrict__ mean_out, float* __restrict__ var_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bn * Cp) return;
+  const int n = i / Cp, c = i - n * Cp;
+  double s = 0, q = 0;
+  for (int k = 0; k < nchunk; ++k) {
+    const double* w = ws + (((long long)n * nchunk + k) * Cp + c) * 2;
+    s += w[0]; q += w[1];
+  }
+  const double mean = s / (double)npix_per_n;
+  double var = q / (double)npix_per_n - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  scale[i] = rstd;
+  shift[i] = (float)(-mean) * rstd;
+  if (mean_out) mean_out[i] = (float)mean;
+  if (var_out) var_out[i] = (float)var;
+}
+
+__global__ void affine_inplace_k(float* __restrict__ x, long long pix_stride, int ch_off, int Cp, long long npix,
+                                 const float* __restrict__ scale, const float* __restrict__ shift) {
+  const int nv = Cp >> 2;
+  const long long total = npix * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / nv;
+    const int c = (int)(i - p * nv) * 4;
+    f32x4* ptr = (f32x4*)(x + p * pix_stride + ch_off + c);
+    f32x4 v = *ptr;
+    const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+    *ptr = v * sc + sh;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void avgpool2_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
+                           int yo, int B, int H, int W, int Cp) {
+  const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
+  const long long total = (long long)B * Ho * Wo * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const float* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
+    const f32x4 a = *(const f32x4*)s, bb = *(const f32x4*)(s + xs);
+    const f32x4 cc = *(const f32x4*)(s + (long long)W * xs), d = *(const f32x4*)(s + (long long)W * xs + xs);
+    f32x4 r = ((a + bb) + cc) + d;  // row-major accumulation order of ATen's avg_pool2d
+    r = r * 0.25f;
+    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+  }
+}
+
+__global__ void maxpool2_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
+                           int yo, int B, int H, int W, int Ho, int Wo, int stride, int Cp) {
+  const int nv = Cp >> 2;
+  const long long total = (long long)B * Ho * Wo * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int y0 = oy * stride, x0 = ox * stride;
+    const int y1 = y0 + 1 < H ? y0 + 1 : y0, x1 = x0 + 1 < W ? x0 + 1 : x0;  // ceil_mode: clipped window
+    const float* s = x + ((long long)b * H * W) * xs + xo + c;
+    const f32x4 a = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
+    const f32x4 bb = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
+    const f32x4 cc = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
+    const f32x4 d = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(a[e], bb[e]), fmaxf(cc[e], d[e]));
+    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+  }
+}
+
+__global__ void upsample2x_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
+                             int yo, int B, int H, int W, int Cp) {
+  const int Ho = 2 * H, Wo = 2 * W, nv = Cp >> 2;
+  const long long total = (long long)B * Ho * Wo * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    // ATen area_pixel_compute_source_index(scale=0.5, align_corners=false): max(0.5*(d+0.5)-0.5, 0)
+    float sy = 0.5f * (oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = 0.5f * (ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* s = x + ((long long)b * H * W) * xs + xo + c;
+    const f32x4 a = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
+    const f32x4 bb = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
+    const f32x4 cc = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
+    const f32x4 d = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
+    const f32x4 r = hy * (hx * a + lx * bb) + ly * (hx * cc + lx * d);
+    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+  }
+}
+
+__global__ void nchw_to_nhwc_k(const float* __restrict__ x, int B, int C, int H, int W, float* __restrict__ y,
+                               long long ys, int yo, int Cp) {
+  const long long HW = (long long)H * W, total = (long long)B * HW;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+    const long long b = p / HW, r = p - b * HW;
+    float* dst = y + p * ys + yo;
+    for (int c = 0; c < Cp; ++c) dst[c] = c < C ? x[(b * C + c) * HW + r] : 0.f;
+  }
+}
+
+__global__ void nhwc_to_nchw_k(const float* __restrict__ x, long long xs, int xo, int B, int C, int H, int W,
+                               float* __restrict__ y) {
+  const long long HW = (long long)H * W, total = (long long)B * HW;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+    const long long b = p / HW, r = p - b * HW;
+    const float* src = x + p * xs + xo;
+    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + r] = src[c];
+  }
+}
+
+__global__ void ellipse_head_act_k(float* __restrict__ x, int B, int ld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 10) return;
+  const int b = i / 10, j = i - b * 10, k = j % 5;
+  float v = x[(long long)b * ld + j];
+  if (k < 2) v = tanhf(v);
+  else if (k < 4) v = 1.f / (1.f + expf(-v));
+  x[(long long)b * ld + j] = v;
+}
+
+__global__ void selu_k(float* __restrict__ x, long long n) {
+  const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    x[i] = scale * (v > 0.f ? v : alpha * (expf(v) - 1.f));
+  }
+}
+
+// one block per sample; thread = channel; fp32 pairwise-ish (per-thread serial over <= a few hundred px)
+__global__ void spatial_mean_k(const float* __restrict__ x, long long pix_stride, int ch_off, int C, int HW,
+                               float* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* s = x + (long long)b * HW * pix_stride + ch_off + c;
+    double a = 0;
+    for (int p = 0; p < HW; ++p) a += s[(long long)p * pix_stride];
+    out[(long long)b * C + c] = (float)(a / HW);
+  }
+}
+
+inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline bool slice_ok(const void* p, long long stride, int off, int Cp) {
+  return p && ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && off % 4 == 0 && Cp > 0 && Cp % 4 == 0 && off + Cp <= stride;
+}
+
+}  // namespace
+
+static int norm_nchunk(int Bn, long long npix, int Cp) {
+  const int cgroups = (Cp + 31) / 32;
+  long long want = 2048 / ((long long)Bn * cgroups);
+  if (want < 1) want = 1;
+  long long maxchunk = npix / 64 > 0 ? npix / 64 : 1;
+  long long n = want < maxchunk ? want : maxchunk;
+  return (int)(n > 256 ? 256 : n);
+}
+
+extern "C" int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int per_sample) {
+  const int Bn = per_sample ? B : 1;
+  const long long npix = per_sample ? HW : (long long)B * HW;
+  return (int64_t)Bn * norm_nchunk(Bn, npix, Cp) * Cp * 2 * sizeof(double);
+}
+
+extern "C" int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample,
+                               float eps, float* scale, float* shift, float* mean_out, float* var_out, void* ws,
+                               void* stream) {
+  EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp), "norm_stats: bad slice (stride %lld off %d Cp %d)", (long long)pix_stride, ch_off, Cp);
+  EGNE_REQUIRE(B > 0 && HW > 0 && scale && shift && ws, "norm_stats: bad arguments");
+  const int Bn = per_sample ? B : 1;
+  const long long npix = per_sample ? HW : (long long)B * HW;
+  const int cgroups = (Cp + 31) / 32;
+  const int nchunk = norm_nchunk(Bn, npix, Cp);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(norm_stats_partial, dim3(nchunk, cgroups, Bn), dim3(256), 0, st, x, (long long)pix_stride, ch_off,
+                     Cp, npix, nchunk, (double*)ws);
+  const int tot = Bn * Cp;
+  hipLaunchKernelGGL(norm_stats_final, dim3((tot + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk,
+                     npix, eps, scale, shift, mean_out, var_out);
+  return egne::check_launch("egne_norm_stats");
+}
+
+extern "C" int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, const float* scale,
+                                   const float* shift, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp) && scale && shift && npix > 0, "affine_inplace: bad arguments");
+  hipLaunchKernelGGL(affine_inplace_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)pix_stride, ch_off, Cp, (long long)npix, scale, shift);
+  return egne::check_launch("egne_affine_inplace");
+}
+
+extern "C" int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
+                             int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "avgpool2: bad slices");
+  EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2, "avgpool2: bad shape");
+  hipLaunchKernelGGL(avgpool2_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, (long long)xs, xo, y, (long long)ys, yo, B, H, W, Cp);
+  return egne::check_launch("egne_avgpool2");
+}
+
+extern "C" int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
+                             int Ho, int Wo, int stride, int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "maxpool2: bad slices");
+  EGNE_REQUIRE(stride == 1 || stride == 2, "maxpool2: stride %d", stride);
+  // ceil_mode output size; the last window must start inside the input
+  auto osz = [&](int n) { int o = (n - 2 + stride - 1) / stride + 1; if ((o - 1) * stride >= n) --o; return o; };
+  EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2 && Ho == osz(H) && Wo == osz(W), "maxpool2: output %dx%d != %dx%d", Ho, Wo, osz(H), osz(W));
+  hipLaunchKernelGGL(maxpool2_k, dim3(grid_for((long long)B * Ho * Wo * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)xs, xo, y, (long long)ys, yo, B, H, W, Ho, Wo, stride, Cp);
+  return egne::check_launch("egne_maxpool2");
+}
+
+extern "C" int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
+                               int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "upsample2x: bad slices");
+  EGNE_REQUIRE(B > 0 && H > 0 && W > 0, "upsample2x: bad shape");
+  hipLaunchKernelGGL(upsample2x_k, dim3(grid_for((long long)B * 4 * H * W * (Cp / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, (long long)xs, xo, y, (long long)ys, yo, B, H, W, Cp);
+  return egne::check_launch("egne_upsample2x");
+}
+
+extern "C" int egne_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int64_t ys, int yo, int Cp,
+                                 void* stream) {
+  EGNE_REQUIRE(x && y && B > 0 && C > 0 && C <= Cp && yo + Cp <= ys, "nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_k, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B, C, H,
+                     W, y, (long long)ys, yo, Cp);
+  return egne::check_launch("egne_nchw_to_nhwc");
+}
+
+extern "C" int egne_nhwc_to_nchw(const float* x, int64_t xs, int xo, int B, int C, int H, int W, float* y,
+                                 void* stream) {
+  EGNE_REQUIRE(x && y && B > 0 && C > 0 && xo + C <= xs, "nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_k, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)xs, xo, B, C, H, W, y);
+  return egne::check_launch("egne_nhwc_to_nchw");
+}
+
+extern "C" int egne_ellipse_head_act(float* x, int B, int ld, void* stream) {
+  EGNE_REQUIRE(x && B > 0 && ld >= 10, "ellipse_head_act: bad arguments");
+  hipLaunchKernelGGL(ellipse_head_act_k, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, B, ld);
+  return egne::check_launch("egne_ellipse_head_act");
+}
+
+extern "C" int egne_selu_inplace(float* x, int64_t n, void* stream) {
+  EGNE_REQUIRE(x && n > 0, "selu: bad arguments");
+  hipLaunchKernelGGL(selu_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n);
+  return egne::check_launch("egne_selu_inplace");
+}
+
+extern "C" int egne_spatial_mean(const float* x, int64_t pix_stride, int ch_off, int C, int B, int HW, float* out,
+                                 void* stream) {
+  EGNE_REQUIRE(x && out && B > 0 && HW > 0 && C > 0 && ch_off + C <= pix_stride, "spatial_mean: bad arguments");
+  hipLaunchKernelGGL(spatial_mean_k, dim3(B), dim3(256), 0, (hipStream_t)stream, x, (long long)pix_stride, ch_off, C, HW,
+                     out);
+  return egne::check_launch("egne_spatial_mean");
+}

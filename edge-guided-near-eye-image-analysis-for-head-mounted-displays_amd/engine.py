@@ -1,0 +1,256 @@
+"""Host-side execution engine: NHWC slices, packed conv layers and replayable launch plans.
+
+PyTorch is used for device memory and streams only.  A *plan* is built once per
+(network, batch, height, width, mode): it owns every activation buffer and a flat list of
+prepared C-ABI calls (ctypes descriptors with raw device pointers), so running the network is a
+loop of ``fn(desc, stream)`` calls with no tensor allocation, no torch.cat and no host sync.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
+
+
+def pad8(c):
+    return (int(c) + 7) // 8 * 8
+
+
+def pad32(c):
+    return (int(c) + 31) // 32 * 32
+
+
+def _ptr(t, elem_off=0):
+    return t.data_ptr() + 4 * int(elem_off)
+
+
+class Piece:
+    """A channel slice [off, off+Cp) of an NHWC fp32 buffer (optionally starting at sample n0)."""
+
+    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in")
+
+    def __init__(self, buf, off, C_, Cp=None, n0=0):
+        self.buf, self.off, self.C, self.Cp, self.n0 = buf, int(off), int(C_), int(Cp or pad8(C_)), int(n0)
+        self.scale = self.shift = None
+        self.act_in = ACT_NONE
+        assert self.off % 4 == 0 and self.Cp % 8 == 0 and self.off + self.Cp <= buf.shape[-1]
+
+    @property
+    def stride(self):
+        return self.buf.shape[-1]
+
+    @property
+    def ptr(self):
+        hw = self.buf.shape[1] * self.buf.shape[2]
+        return self.buf.data_ptr() + 4 * (self.n0 * hw * self.stride)
+
+    def with_norm(self, scale, shift, act_in=ACT_NONE):
+        p = Piece(self.buf, self.off, self.C, self.Cp, self.n0)
+        p.scale, p.shift, p.act_in = scale, shift, act_in
+        return p
+
+    def samples(self, n0):
+        return Piece(self.buf, self.off, self.C, self.Cp, n0)
+
+
+class ConvLayer:
+    """A convolution whose weights live in torch Parameters (OIHW) and are packed for the kernel.
+
+    ``in_layout`` lists the (C, Cp) of the input slices in concat order; ``weights`` / ``biases``
+    hold one tensor per group (three for the fused dilated branch of an MSBlock).
+    """
+
+    def __init__(self, weights, biases, in_layout, stride=1, pad=(0, 0), dils=(1,), act=ACT_NONE, pad_mode=0,
+                 kernel_hw=None, cout_pad=None):
+        self.weights = list(weights)
+        self.biases = list(biases) if biases is not None else None
+        self.in_layout = [(int(c), int(cp)) for c, cp in in_layout]
+        w0 = self.weights[0]
+        self.Cout = w0.shape[0]
+        self.Cin = sum(c for c, _ in self.in_layout)
+        self.kh, self.kw = kernel_hw if kernel_hw else (w0.shape[2], w0.shape[3])
+        assert w0.numel() == self.Cout * self.Cin * self.kh * self.kw, (tuple(w0.shape), self.Cin, self.kh, self.kw)
+        self.stride, self.pad, self.dils, self.act, self.pad_mode = stride, pad, tuple(dils), act, pad_mode
+        self.Ktot = sum(cp for _, cp in self.in_layout)
+        self.CoutP = pad32(self.Cout)
+        self.Cout_store = cout_pad if cout_pad else pad8(self.Cout)
+        self.G = len(self.weights)
+        self.wp = None
+        self.bp = None
+        self._versions = None
+        self.post = None  # (scale, shift) tensors [CoutP] for a folded eval-mode BatchNorm
+
+    def _kinv(self, dev):
+        k, c0 = [], 0
+        for c, cp in self.in_layout:
+            k += list(range(c0, c0 + c)) + [-1] * (cp - c)
+            c0 += c
+        return torch.tensor(k, dtype=torch.int32, device=dev)
+
+    def ensure_packed(self, dev):
+        vers = tuple(w._version for w in self.weights) + tuple(
+            (b._version if b is not None else -1) for b in (self.biases or []))
+        if self.wp is not None and vers == self._versions and self.wp.device == dev:
+            return
+        L = _lib.lib()
+        T = self.kh * self.kw
+        if self.wp is None or self.wp.device != dev:
+            self.wp = torch.empty(self.G * T * self.CoutP * self.Ktot, dtype=torch.float32, device=dev)
+            self.bp = torch.zeros(self.G * self.CoutP, dtype=torch.float32, device=dev)
+            self.kinv = self._kinv(dev)
+        st = _lib.stream_ptr()
+        for g, w in enumerate(self.weights):
+            wd = w.detach()
+            assert wd.is_cuda and wd.dtype == torch.float32
+            wd = wd.contiguous()
+            _lib.check(L.egne_pack_conv_weight(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw,
+                                               self.kinv.data_ptr(), self.CoutP, self.Ktot,
+                                               _ptr(self.wp, g * T * self.CoutP * self.Ktot), st), "pack_conv_weight")
+            if self.biases is not None and self.biases[g] is not None:
+                self.bp[g * self.CoutP: g * self.CoutP + self.Cout].copy_(self.biases[g].detach())
+        self._versions = vers
+
+    def out_hw(self, H, W):
+        d = self.dils[0]
+        ho = (H + 2 * self.pad[0] * d - d * (self.kh - 1) - 1) // self.stride + 1
+        wo = (W + 2 * self.pad[1] * d - d * (self.kw - 1) - 1) // self.stride + 1
+        return ho, wo
+
+
+class Plan:
+    """Buffers + prepared launches for one network at one shape."""
+
+    def __init__(self, device):
+        self.device = device
+        self.calls = []     # (fn, desc_or_args tuple, name)
+        self.keep = []      # tensors / descriptors that must outlive the plan's calls
+        self.layers = []    # ConvLayers to (re)pack before running
+        self.pre = []       # python callables run before the launches (BN folding etc.)
+        self.L = _lib.lib()
+
+    # ---- memory ------------------------------------------------------------------------------
+    def buf(self, B, H, W, Ctot):
+        t = torch.zeros((B, H, W, int(Ctot)), dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def vec(self, *shape, dtype=torch.float32):
+        t = torch.zeros(shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    # ---- launches ----------------------------------------------------------------------------
+    def _add(self, fn, args, name):
+        self.calls.append((fn, args, name))
+
+    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv"):
+        """pieces: input Pieces in concat order; dst: output Piece.  Returns (Ho, Wo)."""
+        assert len(pieces) == len(layer.in_layout) and len(pieces) <= _lib.MAXSEG, name
+        for p, (c, cp) in zip(pieces, layer.in_layout):
+            assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
+        if layer not in self.layers:
+            self.layers.append(layer)
+            layer.ensure_packed(self.device)
+        Ho, Wo = layer.out_hw(H, W)
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
+        d.kh, d.kw, d.stride = layer.kh, layer.kw, layer.stride
+        d.pad_h, d.pad_w, d.pad_mode = layer.pad[0], layer.pad[1], layer.pad_mode
+        d.ngroups = layer.G
+        for g in range(_lib.MAXGROUP):
+            d.dil[g] = layer.dils[g] if g < layer.G else 1
+        d.nseg = len(pieces)
+        for i, p in enumerate(pieces):
+            s = d.seg[i]
+            s.ptr, s.pix_stride, s.ch_off, s.Cp = p.ptr, p.stride, p.off, p.Cp
+            s.scale = p.scale.data_ptr() if p.scale is not None else None
+            s.shift = p.shift.data_ptr() if p.shift is not None else None
+            s.act_in = p.act_in
+        d.Ktot, d.CoutP = layer.Ktot, layer.CoutP
+        d.w = layer.wp.data_ptr()
+        d.bias = layer.bp.data_ptr() if layer.biases is not None else None
+        d.act = layer.act
+        if layer.post is not None:
+            d.post_scale, d.post_shift = layer.post[0].data_ptr(), layer.post[1].data_ptr()
+        if residual is not None:
+            d.residual, d.res_pix_stride, d.res_ch_off = residual.ptr, residual.stride, residual.off
+        d.out, d.out_pix_stride, d.out_ch_off = dst.ptr, dst.stride, dst.off
+        d.Cout_store = min(layer.Cout_store, dst.Cp)
+        assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
+        self.keep.append(d)
+        self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name)
+        return Ho, Wo
+
+    def norm_stats(self, piece, B, HW, per_sample=True, eps=1e-5, want_moments=False, name="norm_stats"):
+        Bn = B if per_sample else 1
+        scale, shift = self.vec(Bn, piece.Cp), self.vec(Bn, piece.Cp)
+        mean = var = None
+        if want_moments:
+            mean, var = self.vec(Bn, piece.Cp), self.vec(Bn, piece.Cp)
+        nbytes = self.L.egne_norm_stats_workspace_bytes(B, HW, piece.Cp, 1 if per_sample else 0)
+        ws = self.vec((nbytes + 7) // 8, dtype=torch.float64)
+        self._add(self.L.egne_norm_stats,
+                  (piece.ptr, piece.stride, piece.off, piece.Cp, B, HW, 1 if per_sample else 0, eps,
+                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr() if want_moments else None,
+                   var.data_ptr() if want_moments else None, ws.data_ptr()), name)
+        return scale, shift, mean, var
+
+    def affine_inplace(self, piece, npix, scale, shift, name="affine"):
+        self._add(self.L.egne_affine_inplace, (piece.ptr, piece.stride, piece.off, piece.Cp, npix,
+                                               scale.data_ptr(), shift.data_ptr()), name)
+
+    def avgpool2(self, src, dst, B, H, W, name="avgpool"):
+        assert src.Cp == dst.Cp
+        self._add(self.L.egne_avgpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name)
+
+    def maxpool2(self, src, dst, B, H, W, stride, name="maxpool"):
+        o = lambda n: min((n - 2 + stride - 1) // stride + 1, (n - 1) // stride + 1)  # noqa: E731
+        Ho, Wo = o(H), o(W)
+        assert src.Cp == dst.Cp
+        self._add(self.L.egne_maxpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, Ho, Wo,
+                                         stride, src.Cp), name)
+        return Ho, Wo
+
+    def upsample2x(self, src, dst, B, H, W, name="upsample"):
+        assert src.Cp == dst.Cp
+        self._add(self.L.egne_upsample2x, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name)
+
+    def raw(self, fn, args, name):
+        self._add(fn, args, name)
+
+    # ---- execution ---------------------------------------------------------------------------
+    def run(self):
+        for layer in self.layers:
+            layer.ensure_packed(self.device)
+        for f in self.pre:
+            f()
+        st = _lib.stream_ptr()
+        for fn, args, name in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                _lib.check(rc, name)
+
+
+class VersionGuard:
+    """Runs ``fn`` only when one of ``tensors`` was modified in place since the last run
+    (load_state_dict, optimizer step): keeps tiny host-side refreshes off the steady-state path."""
+
+    def __init__(self, tensors, fn):
+        self.tensors, self.fn, self.seen = list(tensors), fn, None
+
+    def __call__(self):
+        v = tuple((t._version, t.data_ptr()) for t in self.tensors)
+        if v != self.seen:
+            with torch.no_grad():
+                self.fn()
+            self.seen = v
+
+
+def maxpool_out(n, stride):
+    return min((n - 2 + stride - 1) // stride + 1, (n - 1) // stride + 1)
+
+
+def require_cuda(t, what):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise RuntimeError("%s must be a CUDA (ROCm) tensor: this package has no CPU path" % what)

@@ -1,0 +1,306 @@
+"""Launch-plan builder for ESF-Net (``DenseNet2D``), shared by models/RITnet_v2.py and
+models/RITnet_concat.py.
+
+Data flow follows models/RITnet_v2.py:261-354 but is laid out for the GPU:
+
+* the shared encoder runs ONCE on a 2B batch (image frames then edge maps; the weights are the
+  same and InstanceNorm is per sample; in training mode the two BatchNorm passes still use
+  their own batch statistics, RITnet_v2.py:281,285);
+* every torch.cat of the reference is a channel slice of a shared NHWC buffer
+  (``[out | x | x1 | x22]`` per down block, ``[up(x) | x1]`` per up block); the 1x1 convs read
+  up to 6 slices directly, the 3x3 convs write into their slice;
+* InstanceNorm is never materialised: a statistics kernel produces per-(n,c) scale/shift that
+  the consuming conv applies while loading (Transition_down's LeakyReLU included);
+* eval-mode BatchNorm is folded into the producing conv's epilogue.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import ACT_LEAKY, ACT_NONE, ConvLayer, Piece, Plan, VersionGuard, pad8, pad32
+
+
+def enc_sizes(chz, growth=1.2, blks=4):
+    """models/RITnet_v2.py:15-29 getSizes (encoder part)."""
+    inter = [chz * (i + 1) for i in range(blks)]
+    op = [int(growth * chz * (i + 1)) for i in range(blks)]
+    ip = [chz] + op[:-1]
+    return dict(inter=inter, op=op, ip=ip)
+
+
+def dec_sizes(chz, growth, add_edge, variant):
+    """Decoder widths: RITnet_v2.py:177-190 / RITnet_concat.py:160-169, generalised in chz
+    (exact at chz=32; other widths have no reference)."""
+    e = enc_sizes(chz, growth)
+    skip = [e["ip"][::-1][i] + e["inter"][::-1][i] for i in range(4)]
+    fc = e["op"][-1]
+    plain_ip = e["op"][::-1]
+    plain_op = e["op"][::-1][1:] + [chz]
+    if variant == "concat":
+        return dict(ip=[2 * fc] + plain_op[:-1], op=plain_op, skip=[2 * s for s in skip])
+    if add_edge:
+        d = [int(round(chz * f)) for f in (5.625, 3.125, 1.9375)]
+        return dict(ip=[2 * fc] + d, op=d + [chz], skip=skip)
+    return dict(ip=plain_ip, op=plain_op, skip=skip)
+
+
+def _cl(conv, layout, pad=(0, 0), act=ACT_NONE, **kw):
+    return ConvLayer([conv.weight], [conv.bias] if conv.bias is not None else None, layout, pad=pad, act=act, **kw)
+
+
+def _lay(pieces):
+    return [(p.C, p.Cp) for p in pieces]
+
+
+class _BNFold:
+    """Eval-mode BatchNorm2d folded to per-channel (scale, shift) after the activation."""
+
+    def __init__(self, bn, CoutP, dev):
+        self.bn = bn
+        self.scale = torch.zeros(CoutP, device=dev)
+        self.shift = torch.zeros(CoutP, device=dev)
+        self.guard = VersionGuard([bn.weight, bn.bias, bn.running_mean, bn.running_var], self._fold)
+
+    def _fold(self):
+        bn, c = self.bn, self.bn.num_features
+        s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        self.scale[:c].copy_(s)
+        self.shift[:c].copy_(bn.bias.detach() - bn.running_mean * s)
+
+
+def _train_bn(pl, bn, piece, n0, B, HW, name):
+    """Training-mode BatchNorm2d over samples [n0, n0+B) of ``piece`` (utils.py:1049):
+    batch statistics -> y = (x-mean)*rstd*gamma + beta in place, running stats updated."""
+    p = piece.samples(n0)
+    rstd, nshift, mean, var = pl.norm_stats(p, B, HW, per_sample=False, eps=bn.eps, want_moments=True, name=name + ".stats")
+    sc, sh = pl.vec(piece.Cp), pl.vec(piece.Cp)
+    c = bn.num_features
+    n = B * HW
+
+    def finish(rstd=rstd, nshift=nshift, mean=mean, var=var, sc=sc, sh=sh):
+        # tiny [C]-sized bookkeeping on the stream (no sync): affine coefficients + running stats
+        with torch.no_grad():
+            g = bn.weight.detach()
+            sc[:c].copy_(rstd[0, :c] * g)
+            sh[:c].copy_(nshift[0, :c] * g + bn.bias.detach())
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(mean[0, :c], alpha=m)
+            bn.running_var.mul_(1 - m).add_(var[0, :c] * (n / max(n - 1, 1)), alpha=m)
+            bn.num_batches_tracked.add_(1)
+    pl.raw(_PyCall(finish), (), name + ".coef")
+    pl.affine_inplace(p, n, sc, sh, name + ".apply")
+
+
+class _PyCall:
+    """Adapter so that a python callable can sit in a plan's launch list."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        self.fn()
+        return 0
+
+
+def build_forward_plan(model, B, H, W, dev, training):
+    st = model.setting
+    variant = model.variant
+    chz, growth = model.chz, model.growth
+    add_edge = variant == "concat" or st["add_edge"] == 1
+    in_c = 2 if (variant == "v2" and st["input_concat"] == 1) else 1
+    only_edge = variant == "v2" and st["only_edge"] == 1
+    NB = 2 * B if add_edge else B
+    es = enc_sizes(chz, growth)
+    ds = dec_sizes(chz, growth, add_edge, variant)
+    fc = es["op"][-1]
+    pl = Plan(dev)
+    L = pl.L
+
+    # ---- inputs (persistent; forward() copies the caller's tensors in) -----------------------------
+    pl.in_img = pl.vec(B, 1, H, W)
+    pl.in_edge = pl.vec(B, 1, H, W)
+    xin = pl.buf(NB, H, W, 8)
+    first = pl.in_edge if only_edge else pl.in_img
+    pl.raw(L.egne_nchw_to_nhwc, (first.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 0, 8), "in.img")
+    if in_c == 2:
+        pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 1, 1), "in.edge_ch")
+    if add_edge:
+        pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr() + 4 * B * H * W * 8, 8, 0, 8),
+               "in.edge")
+
+    # ---- encoder on NB samples -------------------------------------------------------------------
+    enc = model.enc
+    blocks = [enc.down_block1, enc.down_block2, enc.down_block3, enc.down_block4, enc.bottleneck]
+    ins = es["ip"] + [es["op"][3]]
+    inters = es["inter"] + [es["inter"][3]]
+    outs = es["op"] + [es["op"][3]]
+    pools = [2, 2, 2, 2, 0]
+    res = [(H >> i, W >> i) for i in range(5)]
+
+    def dbuf(i):
+        h, w = res[i]
+        it, ic = pad8(inters[i]), pad8(ins[i])
+        b = pl.buf(NB, h, w, it + ic + 2 * it)
+        return dict(out=Piece(b, 0, inters[i]), x=Piece(b, it, ins[i]), x1=Piece(b, it + ic, inters[i]),
+                    x22=Piece(b, it + ic + it, inters[i]))
+    D = [dbuf(i) for i in range(5)]
+
+    t0 = pl.buf(NB, H, W, pad8(chz))
+    l = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
+    pl.conv(l, [Piece(xin, 0, in_c, 8)], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
+    l = _cl(enc.head.conv2, [(chz, pad8(chz))], pad=(1, 1), act=ACT_LEAKY)
+    if not training:
+        fold = _BNFold(enc.head.bn, l.CoutP, dev)
+        pl.pre.append(fold.guard)
+        l.post = (fold.scale, fold.shift)
+    pl.conv(l, [Piece(t0, 0, chz)], D[0]["x"], NB, H, W, name="enc.head.conv2")
+    if training:
+        _train_bn(pl, enc.head.bn, D[0]["x"], 0, B, H * W, "enc.head.bn")
+        if add_edge:
+            _train_bn(pl, enc.head.bn, D[0]["x"], B, B, H * W, "enc.head.bn.edge")
+
+    bott = pl.buf(NB, res[4][0], res[4][1], pad8(fc))
+    for i, blk in enumerate(blocks):
+        h, w = res[i]
+        d = D[i]
+        nm = "enc.b%d" % i
+        sc, sh, _, _ = pl.norm_stats(d["x"], NB, h * w, name=nm + ".in_x")
+        l = _cl(blk.conv1, _lay([d["x"]]), pad=(1, 1), act=ACT_LEAKY)
+        pl.conv(l, [d["x"].with_norm(sc, sh)], d["x1"], NB, h, w, name=nm + ".conv1")
+        tmp = pl.buf(NB, h, w, pad8(inters[i]))
+        tp = Piece(tmp, 0, inters[i])
+        l = _cl(blk.conv21, _lay([d["x"], d["x1"]]))
+        pl.conv(l, [d["x"], d["x1"]], tp, NB, h, w, name=nm + ".conv21")
+        l = _cl(blk.conv22, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
+        pl.conv(l, [tp], d["x22"], NB, h, w, name=nm + ".conv22")
+        l = _cl(blk.conv31, _lay([d["x"], d["x1"], d["x22"]]))
+        pl.conv(l, [d["x"], d["x1"], d["x22"]], tp, NB, h, w, name=nm + ".conv31")
+        l = _cl(blk.conv32, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
+        pl.conv(l, [tp], d["out"], NB, h, w, name=nm + ".conv32")
+        sc2, sh2, _, _ = pl.norm_stats(d["out"], NB, h * w, name=nm + ".in_out")
+        tdl = _cl(blk.TD.conv, _lay([d["out"], d["x"]]))
+        tin = [d["out"].with_norm(sc2, sh2, ACT_LEAKY), d["x"].with_norm(sc, sh, ACT_LEAKY)]
+        if pools[i]:
+            td = pl.buf(NB, h, w, pad8(outs[i]))
+            pl.conv(tdl, tin, Piece(td, 0, outs[i]), NB, h, w, name=nm + ".TD")
+            pl.avgpool2(Piece(td, 0, outs[i]), D[i + 1]["x"], NB, h, w, name=nm + ".pool")
+        else:
+            pl.conv(tdl, tin, Piece(bott, 0, fc), NB, h, w, name=nm + ".TD")
+
+    # latent = mean over H*W of the image pass' bottleneck (RITnet_v2.py:282)
+    hb, wb = res[4]
+    pl.latent = pl.vec(B, fc)
+    pl.raw(L.egne_spatial_mean, (bott.data_ptr(), bott.shape[-1], 0, fc, B, hb * wb, pl.latent.data_ptr()), "latent")
+
+    # ---- decoder on B samples ---------------------------------------------------------------------
+    xb = [Piece(bott, 0, fc)] + ([Piece(bott, 0, fc, n0=B)] if add_edge else [])
+    prev, ph, pw = xb, hb, wb
+    dec = model.dec
+    ups = [dec.up_block4, dec.up_block3, dec.up_block2, dec.up_block1]
+    for k, ub in enumerate(ups):
+        lvl = 3 - k                      # encoder level whose skip is used
+        h, w = res[lvl]
+        oc = ds["op"][k]
+        nm = "dec.up%d" % (4 - k)
+        upw = sum(p.Cp for p in prev)
+        U = pl.buf(B, h, w, upw + pad8(oc))
+        up_pieces, off = [], 0
+        for p in prev:
+            q = Piece(U, off, p.C, p.Cp)
+            pl.upsample2x(p, q, B, ph, pw, name=nm + ".up")
+            up_pieces.append(q)
+            off += p.Cp
+        x1 = Piece(U, off, oc)
+        skip = [D[lvl]["out"], D[lvl]["x"]]
+        if variant == "concat":
+            skip = skip + [D[lvl]["out"].samples(B), D[lvl]["x"].samples(B)]
+        cat = up_pieces + skip
+        t = pl.buf(B, h, w, pad8(oc))
+        tp = Piece(t, 0, oc)
+        l = _cl(ub.conv11, _lay(cat))
+        pl.conv(l, cat, tp, B, h, w, name=nm + ".conv11")
+        l = _cl(ub.conv12, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
+        pl.conv(l, [tp], x1, B, h, w, name=nm + ".conv12")
+        l = _cl(ub.conv21, _lay(cat + [x1]))
+        pl.conv(l, cat + [x1], tp, B, h, w, name=nm + ".conv21")
+        y = pl.buf(B, h, w, pad8(oc))
+        l = _cl(ub.conv22, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
+        pl.conv(l, [tp], Piece(y, 0, oc), B, h, w, name=nm + ".conv22")
+        prev, ph, pw = [Piece(y, 0, oc)], h, w
+
+    tf = pl.buf(B, H, W, pad8(chz))
+    l = _cl(dec.final.conv1, _lay(prev), pad=(1, 1), act=ACT_LEAKY)
+    pl.conv(l, prev, Piece(tf, 0, chz), B, H, W, name="dec.final.conv1")
+    opb = pl.buf(B, H, W, 8)
+    l = _cl(dec.final.conv2, [(chz, pad8(chz))], pad=(1, 1), act=ACT_LEAKY)
+    if not training:
+        fold = _BNFold(dec.final.bn, l.CoutP, dev)
+        pl.pre.append(fold.guard)
+        l.post = (fold.scale, fold.shift)
+    pl.conv(l, [Piece(tf, 0, chz)], Piece(opb, 0, 3), B, H, W, name="dec.final.conv2")
+    if training:
+        _train_bn(pl, dec.final.bn, Piece(opb, 0, 3), 0, B, H * W, "dec.final.bn")
+
+    if variant == "v2" and st["add_seg"] == 1:
+        raise NotImplementedError("AdaIN fusion path (add_seg=1) is not built yet")
+
+    # ---- regression module (utils.py:983-1037) ------------------------------------------------------
+    rg = model.elReg
+    l = _cl(rg.c1, _lay(xb), act=ACT_LEAKY)
+    h1, w1 = l.out_hw(hb, wb)
+    r1 = pl.buf(B, h1, w1, 128)
+    pl.conv(l, xb, Piece(r1, 0, 128), B, hb, wb, name="elReg.c1")
+    r2 = pl.buf(B, h1 // 2, w1 // 2, 128)
+    pl.avgpool2(Piece(r1, 0, 128), Piece(r2, 0, 128), B, h1, w1, name="elReg.pool")
+    l = _cl(rg.c2, [(128, 128)], act=ACT_LEAKY)
+    h3, w3 = l.out_hw(h1 // 2, w1 // 2)
+    r3 = pl.buf(B, h3, w3, 128)
+    pl.conv(l, [Piece(r2, 0, 128)], Piece(r3, 0, 128), B, h1 // 2, w1 // 2, name="elReg.c2")
+    l = _cl(rg.c3, [(128, 128)], act=ACT_LEAKY)
+    h4, w4 = l.out_hw(h3, w3)
+    r4 = pl.buf(B, h4, w4, 32)
+    pl.conv(l, [Piece(r3, 0, 128)], Piece(r4, 0, 32), B, h3, w3, name="elReg.c3")
+    if 32 * h4 * w4 != rg.l1.weight.shape[1]:
+        raise ValueError("regressionModule expects a %d-feature map, got 32x%dx%d (input must be 240x320)"
+                         % (rg.l1.weight.shape[1], h4, w4))
+    l = ConvLayer([rg.l1.weight], [rg.l1.bias], [(32, 32)], kernel_hw=(h4, w4))
+    r5 = pl.buf(B, 1, 1, 256)
+    pl.conv(l, [Piece(r4, 0, 32)], Piece(r5, 0, 256), B, h4, w4, name="elReg.l1")
+    pl.raw(L.egne_selu_inplace, (r5.data_ptr(), B * 256), "elReg.selu")
+    l = ConvLayer([rg.l2.weight], [rg.l2.bias], [(256, 256)], kernel_hw=(1, 1))
+    r6 = pl.buf(B, 1, 1, 16)
+    pl.conv(l, [Piece(r5, 0, 256)], Piece(r6, 0, 10, 16), B, 1, 1, name="elReg.l2")
+    pl.raw(L.egne_ellipse_head_act, (r6.data_ptr(), B, 16), "elReg.act")
+    pl.elOut = pl.vec(B, 10)
+    pl.raw(_PyCall(lambda: pl.elOut.copy_(r6.view(B, 16)[:, :10])), (), "elOut.copy")
+
+    # ---- loss head -----------------------------------------------------------------------------------
+    ld = _lib.LossDesc()
+    pl.t_target = pl.vec(B, H, W, dtype=torch.int64)
+    pl.t_spat = pl.vec(B, H, W)
+    pl.t_dist = pl.vec(B, 3, H, W)
+    pl.t_cond = pl.vec(B, 4)
+    pl.t_pc = pl.vec(B, 2)
+    pl.t_eln = pl.vec(B, 2, 5)
+    pl.terms = pl.vec(8)
+    pl.pred_c = pl.vec(B, 2, 2)
+    pl.elPred = pl.vec(B, 10)
+    pl.op = pl.vec(B, 3, H, W)
+    pl.mask = pl.vec(B, H, W, dtype=torch.int64)
+    part = pl.vec(int(L.egne_loss_workspace_floats(B, H, W)))
+    gx = torch.linspace(-1, 1, W).to(dev)   # create_meshgrid (utils.py:27-60) builds the axes this way
+    gy = torch.linspace(-1, 1, H).to(dev)
+    pl.keep += [gx, gy]
+    ld.B, ld.H, ld.W = B, H, W
+    ld.logits, ld.pix_stride, ld.ch_off = opb.data_ptr(), 8, 0
+    ld.target, ld.spatWts, ld.distMap = pl.t_target.data_ptr(), pl.t_spat.data_ptr(), pl.t_dist.data_ptr()
+    ld.cond, ld.pupil_center, ld.elNorm = pl.t_cond.data_ptr(), pl.t_pc.data_ptr(), pl.t_eln.data_ptr()
+    ld.elOut = pl.elOut.data_ptr()
+    ld.alpha = 0.0
+    ld.grid_x, ld.grid_y = gx.data_ptr(), gy.data_ptr()
+    ld.partials, ld.out_terms, ld.pred_c, ld.elPred = part.data_ptr(), pl.terms.data_ptr(), pl.pred_c.data_ptr(), pl.elPred.data_ptr()
+    ld.mask, ld.op_nchw = pl.mask.data_ptr(), pl.op.data_ptr()
+    pl.loss_desc = ld
+    pl.raw(L.egne_loss_fwd, (C.byref(ld),), "loss")
+    return pl

@@ -1,0 +1,194 @@
+"""ESF-Net (``DenseNet2D``) on the HIP path -- drop-in for the reference's ``models/RITnet_v2.py``.
+
+Same constructor arguments, attributes (``selfCorr``, ``disentangle``, ``toggle``,
+``setDatasetInfo``), ``state_dict`` keys and ``forward`` signature / return tuple
+(models/RITnet_v2.py:204-354).  The modules below only hold parameters under the reference's
+names; execution is a launch plan built by ``esf_engine`` (no torch ops on the compute path).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..esf_engine import build_forward_plan, dec_sizes, enc_sizes
+from ..engine import require_cuda
+from ..utils import Conv2dBlock, LinearBlock, convBlock, linStack, regressionModule
+
+
+def getSizes(chz, growth, blks=4):
+    """models/RITnet_v2.py:15-29 (same dict layout)."""
+    e = enc_sizes(chz, growth, blks)
+    sizes = {"enc": {"inter": np.array(e["inter"]), "ip": np.array(e["ip"]), "op": np.array(e["op"])},
+             "dec": {}}
+    sizes["dec"]["skip"] = sizes["enc"]["ip"][::-1] + sizes["enc"]["inter"][::-1]
+    sizes["dec"]["ip"] = sizes["enc"]["op"][::-1]
+    sizes["dec"]["op"] = np.append(sizes["enc"]["op"][::-1][1:], chz)
+    return sizes
+
+
+class Transition_down(nn.Module):
+    def __init__(self, in_c, out_c, down_size, norm=None, actfunc=None):
+        super().__init__()
+        self.conv = nn.Conv2d(in_c, out_c, kernel_size=1, padding=0)
+        self.down_size = down_size
+
+
+class DenseNet2D_down_block(nn.Module):
+    def __init__(self, in_c, inter_c, op_c, down_size, norm=None, actfunc=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_c, inter_c, kernel_size=3, padding=1)
+        self.conv21 = nn.Conv2d(in_c + inter_c, inter_c, kernel_size=1, padding=0)
+        self.conv22 = nn.Conv2d(inter_c, inter_c, kernel_size=3, padding=1)
+        self.conv31 = nn.Conv2d(in_c + 2 * inter_c, inter_c, kernel_size=1, padding=0)
+        self.conv32 = nn.Conv2d(inter_c, inter_c, kernel_size=3, padding=1)
+        self.TD = Transition_down(inter_c + in_c, op_c, down_size, norm, actfunc)
+
+
+class DenseNet2D_up_block(nn.Module):
+    def __init__(self, skip_c, in_c, out_c, up_stride, actfunc=None):
+        super().__init__()
+        self.conv11 = nn.Conv2d(skip_c + in_c, out_c, kernel_size=1, padding=0)
+        self.conv12 = nn.Conv2d(out_c, out_c, kernel_size=3, padding=1)
+        self.conv21 = nn.Conv2d(skip_c + in_c + out_c, out_c, kernel_size=1, padding=0)
+        self.conv22 = nn.Conv2d(out_c, out_c, kernel_size=3, padding=1)
+        self.up_stride = up_stride
+
+
+class StyleEncoder(nn.Module):
+    """models/RITnet_v2.py:91-107."""
+
+    def __init__(self, n_downsample, input_dim, dim, style_dim, norm, activ, pad_type):
+        super().__init__()
+        m = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(2):
+            m += [Conv2dBlock(dim, 2 * dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+            dim *= 2
+        for _ in range(n_downsample - 2):
+            m += [Conv2dBlock(dim, dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+        m += [nn.AdaptiveAvgPool2d(1)]
+        m += [nn.Conv2d(dim, style_dim, 1, 1, 0)]
+        self.model = nn.Sequential(*m)
+        self.output_dim = dim
+
+
+class MLP(nn.Module):
+    """models/RITnet_v2.py:110-121."""
+
+    def __init__(self, input_dim, output_dim, dim, n_blk, norm="none", activ="relu"):
+        super().__init__()
+        m = [LinearBlock(input_dim, dim, norm=norm, activation=activ)]
+        for _ in range(n_blk - 2):
+            m += [LinearBlock(dim, dim, norm=norm, activation=activ)]
+        m += [LinearBlock(dim, output_dim, norm="none", activation="none")]
+        self.model = nn.Sequential(*m)
+
+
+class DenseNet_encoder(nn.Module):
+    def __init__(self, in_c=1, chz=32, actfunc=None, growth=1.5, norm=None):
+        super().__init__()
+        s = enc_sizes(chz, growth)
+        self.head = convBlock(in_c=in_c, inter_c=chz, out_c=chz, actfunc=actfunc)
+        for i in range(4):
+            setattr(self, "down_block%d" % (i + 1),
+                    DenseNet2D_down_block(s["ip"][i], s["inter"][i], s["op"][i], 2, norm, actfunc))
+        self.bottleneck = DenseNet2D_down_block(s["op"][3], s["inter"][3], s["op"][3], 0, norm, actfunc)
+
+
+class DenseNet_decoder(nn.Module):
+    def __init__(self, setting, chz, out_c, growth, actfunc=None, norm=None, variant="v2"):
+        super().__init__()
+        d = dec_sizes(chz, growth, setting["add_edge"] == 1, variant)
+        for k in range(4):
+            setattr(self, "up_block%d" % (4 - k), DenseNet2D_up_block(d["skip"][k], d["ip"][k], d["op"][k], 2, actfunc))
+        self.final = convBlock(chz, chz, out_c, actfunc)
+
+
+class DenseNet2D(nn.Module):
+    variant = "v2"
+
+    def __init__(self, setting, chz=32, growth=1.2, actfunc=None, norm=None, selfCorr=False, disentangle=False):
+        super().__init__()
+        self.sizes = getSizes(chz, growth)
+        self.chz, self.growth = chz, growth
+        self.toggle = True
+        self.selfCorr = selfCorr
+        self.disentangle = disentangle
+        self.disentangle_alpha = 2
+        self.setting = setting
+        input_channels = 2 if (self.variant == "v2" and setting["input_concat"] == 1) else 1
+        self.enc = DenseNet_encoder(in_c=input_channels, chz=chz, actfunc=actfunc, growth=growth, norm=norm)
+        self.dec = DenseNet_decoder(setting, chz=chz, out_c=3, actfunc=actfunc, growth=growth, norm=norm,
+                                    variant=self.variant)
+        fc_enc = int(self.sizes["enc"]["op"][-1])
+        feature_channels = setting["feature_channels"] if chz == 32 else fc_enc
+        if self.variant == "concat" or setting["add_edge"] == 1:
+            feature_channels *= 2
+            # reference: assert feature_channels == 306 (RITnet_v2.py:227-230), i.e. 2 * enc.op[-1]
+            assert feature_channels == 2 * fc_enc, "feature_channels must equal the encoder width"
+        if self.variant == "v2" and setting["add_seg"] == 1:
+            style_dim = setting["style_dim"]
+            self.seg_encoder = StyleEncoder(4, 3, 64, style_dim, norm="none", activ="relu", pad_type="reflect")
+            self.mlp = MLP(style_dim, feature_channels * 2, 256, 3, norm="none", activ="relu")
+        self.elReg = regressionModule(feature_channels)
+        self._initialize_weights()
+        self._plans = {}
+
+    def setDatasetInfo(self, numSets=2):
+        """models/RITnet_v2.py:240-249."""
+        self.numSets = numSets
+        self.dsIdentify_lin = linStack(num_layers=2, in_dim=int(self.sizes["enc"]["op"][-1]), hidden_dim=64,
+                                       out_dim=numSets, bias=True, actBool=False, dp=0.0)
+
+    def _initialize_weights(self):
+        """models/RITnet_v2.py:356-369."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, np.sqrt(2. / n))
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+    # ------------------------------------------------------------------------------------------
+    def _plan(self, B, H, W, dev):
+        key = (B, H, W, dev, bool(self.training))
+        if key not in self._plans:
+            self._plans[key] = build_forward_plan(self, B, H, W, dev, bool(self.training))
+        return self._plans[key]
+
+    def forward(self, x, x_edge, target, pupil_center, elNorm, spatWts, distMap, cond, ID, alpha):
+        """models/RITnet_v2.py:261-354.  Returns (op, elPred, latent, loss[1], elOut)."""
+        if self.variant == "v2":
+            assert (self.setting["input_concat"] + self.setting["add_edge"] < 2), "edge can use only 1 time!"
+        else:
+            assert self.setting["add_edge"] == 1
+        require_cuda(x, "x")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("backward of the HIP path is not built yet; call under torch.no_grad()")
+        if self.selfCorr:
+            raise NotImplementedError("selfCorr is disabled in the reference pipeline (--selfCorr 0, args.py:41)")
+        B, _, H, W = x.shape
+        pl = self._plan(B, H, W, x.device)
+        pl.in_img.copy_(x)
+        pl.in_edge.copy_(x_edge)
+        pl.t_target.copy_(target)
+        pl.t_pc.copy_(pupil_center)
+        pl.t_eln.copy_(elNorm)
+        pl.t_spat.copy_(spatWts)
+        pl.t_dist.copy_(distMap)
+        pl.t_cond.copy_(cond)
+        pl.loss_desc.alpha = float(alpha)
+        pl.run()
+        loss = pl.terms[0:1].clone()
+        if self.disentangle:
+            raise NotImplementedError("dataset-confusion head is not built yet")
+        return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), loss, pl.elOut.clone()
+
+    def predictions(self):
+        """Argmax mask [B,H,W] int64 of the last forward (device-side get_predictions, utils.py:65-81)."""
+        last = next(reversed(self._plans.values()))
+        return last.mask

@@ -1,0 +1,221 @@
+/*
+ * egne_hip.h -- C-ABI of the MI355X (gfx950) hot path of edge-guided near-eye segmentation.
+ *
+ * The reference (zhaoyuhsin/Edge-Guided-Near-Eye-Image-Analysis-for-Head-Mounted-Displays) has no
+ * FFI layer of its own: its hot path is a chain of PyTorch ATen calls made from Python
+ * (SURVEY.md section 2.3).  Each entry point below therefore names the reference call site(s)
+ * whose ATen op(s) it replaces (file:line under /root/reference).  The Python host in
+ * edge-guided-near-eye-image-analysis-for-head-mounted-displays_amd/ binds these with ctypes
+ * (_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative egne_status otherwise; egne_last_error()
+ *     returns a message for the calling thread;
+ *   - all pointers are DEVICE pointers owned by the caller, nothing is allocated or freed here;
+ *   - activations are fp32 NHWC; a tensor is addressed as (base pointer, floats per pixel,
+ *     first channel, channel count) so that torch.cat never has to materialise: producers write
+ *     into channel slices of a shared buffer and consumers read up to EGNE_MAXSEG slices;
+ *   - channel counts of slices are padded to a multiple of 8 with zero weights / zero data;
+ *   - `stream` is a hipStream_t passed as void*; kernels are asynchronous on it.
+ */
+#ifndef EGNE_HIP_H
+#define EGNE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGNE_MAXSEG 8
+#define EGNE_MAXGROUP 3
+
+typedef enum {
+  EGNE_OK = 0,
+  EGNE_ERR_ARG = -1,     /* shape / alignment / range check failed on the host side */
+  EGNE_ERR_LAUNCH = -2,  /* hipLaunchKernel or a runtime call failed */
+  EGNE_ERR_NODEVICE = -3
+} egne_status;
+
+typedef enum { EGNE_ACT_NONE = 0, EGNE_ACT_RELU = 1, EGNE_ACT_LEAKY = 2 } egne_act;
+
+/* One input slice of a convolution (a piece of a would-be torch.cat). */
+typedef struct {
+  const float* ptr;     /* NHWC base of the buffer that holds the slice */
+  int64_t pix_stride;   /* floats per pixel of that buffer */
+  int32_t ch_off;       /* first channel of the slice (multiple of 4) */
+  int32_t Cp;           /* padded channel count of the slice (multiple of 8) */
+  const float* scale;   /* optional per-(n,c) affine applied while loading: x*scale+shift  */
+  const float* shift;   /*   ([B][Cp], used to fuse InstanceNorm / BatchNorm into the consumer) */
+  int32_t act_in;       /* egne_act applied after the affine (LeakyReLU of Transition_down) */
+  int32_t reserved;
+} egne_seg;
+
+/*
+ * Implicit-GEMM convolution, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ * Replaces F.conv2d at: vgg16_c.py:66-78 (3x3, dilation 1/2), bdcn_new.py:50-53 (3x3 + three
+ * dilated 3x3 of MSBlock, fused as `ngroups`=3 with the 4-way sum of :54 as `residual`),
+ * utils.py:1047-1048 (convBlock), models/RITnet_v2.py:57-62,41 (down block 3x3 / concat-free
+ * 1x1 / Transition_down), :85-87 (up block), utils.py:1016-1019 (regressionModule convs),
+ * utils.py:1020-1021 (its Linear layers, as 1x1 convs), models/RITnet_v2.py:91-121 (StyleEncoder
+ * with reflect padding, MLP).
+ */
+typedef struct {
+  int32_t B, H, W;            /* input batch / height / width */
+  int32_t Ho, Wo;             /* output height / width */
+  int32_t kh, kw, stride;
+  int32_t pad_h, pad_w;       /* padding for dilation 1; group g pads by pad*dil[g] */
+  int32_t pad_mode;           /* 0 zero, 1 reflect */
+  int32_t ngroups;            /* 1, or 3 for the fused MSBlock dilated branch */
+  int32_t dil[EGNE_MAXGROUP];
+  int32_t nseg;
+  egne_seg seg[EGNE_MAXSEG];
+  int32_t Ktot;               /* sum of seg[i].Cp */
+  int32_t CoutP;              /* rows of the packed weight, multiple of 32 */
+  const float* w;             /* packed [group][tap][CoutP][Ktot], zero padded */
+  const float* bias;          /* [group][CoutP], zero padded (may be NULL) */
+  int32_t act;                /* egne_act applied to (acc + bias) of every group */
+  const float* post_scale;    /* optional per-channel affine after act (eval BatchNorm) [CoutP] */
+  const float* post_shift;
+  const float* residual;      /* optional tensor added last (same pixels as the output) */
+  int64_t res_pix_stride;
+  int32_t res_ch_off;
+  float* out;
+  int64_t out_pix_stride;
+  int32_t out_ch_off;
+  int32_t Cout_store;         /* channels written (logical Cout rounded up to the slice's padding) */
+} egne_conv_desc;
+
+int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
+
+/* OIHW (torch layout) -> packed [tap][CoutP][Ktot].  kinv[k] (device int32, k < Ktot) names the
+ * input channel stored at padded K position k, or -1 for a padding column; rows Cout..CoutP-1 are
+ * zero.  Used at load_state_dict / after optimizer steps. */
+int egne_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw,
+                          const int32_t* kinv, int CoutP, int Ktot, float* w_packed, void* stream);
+
+/* Per-(n,c) mean / inverse std over H*W of an NHWC slice -> scale = rstd, shift = -mean*rstd
+ * ([B][Cp]).  F.instance_norm at models/RITnet_v2.py:40,57 (eps 1e-5, biased variance).  With
+ * per_sample=0 the statistics run over (B,H,W): training-mode BatchNorm2d of utils.py:1049 and
+ * the result is [1][Cp]; mean/var (biased) are also written when the pointers are non-NULL.
+ * Two deterministic stages with fp64 partial sums in `ws` (egne_norm_stats_workspace_bytes). */
+int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int per_sample);
+int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW,
+                    int per_sample, float eps, float* scale, float* shift,
+                    float* mean_out, float* var_out, void* ws, void* stream);
+
+/* y = x*scale[c] + shift[c] in place over an NHWC slice (training-mode BatchNorm apply). */
+int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix,
+                        const float* scale, const float* shift, void* stream);
+
+/* nn.AvgPool2d(2) (models/RITnet_v2.py:36,43; utils.py:1017) on an NHWC slice. */
+int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
+                  int B, int H, int W, int Cp, void* stream);
+
+/* nn.MaxPool2d(2, stride, ceil_mode=True) (vgg16_c.py:15,20,27,34) on an NHWC slice. */
+int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
+                  int B, int H, int W, int Ho, int Wo, int stride, int Cp, void* stream);
+
+/* F.interpolate(bilinear, scale_factor=2, align_corners=False) (models/RITnet_v2.py:80-83). */
+int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
+                    int B, int H, int W, int Cp, void* stream);
+
+/* NCHW [B,C,H,W] -> NHWC slice (zero fills channels C..Cp-1) and back. */
+int egne_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int64_t ys, int yo,
+                      int Cp, void* stream);
+int egne_nhwc_to_nchw(const float* x, int64_t xs, int xo, int B, int C, int H, int W, float* y,
+                      void* stream);
+
+/*
+ * BDCN side outputs of one stage (bdcn_new.py:118-164): the 1x1 `convK_j_down` (32->21) of every
+ * MSBlock output of the stage are summed and the two 1x1 score heads (21->1) applied; writes the two
+ * low-resolution score maps s (score_dsnK) and s1 (score_dsnK_1), each [B,h,w].
+ * ms is a HOST array of nblk device pointers to NHWC 32-channel tensors; wd [nblk][21][32], bd [nblk][21]; ws/ws1 [21], bs/bs1 scalars
+ * passed by pointer (device).
+ */
+int egne_bdcn_stage_scores(const float* const* ms, int nblk, int64_t ms_pix_stride, int64_t npix,
+                           const float* wd, const float* bd, const float* ws, const float* bs,
+                           const float* ws1, const float* bs1, float* s, float* s1, void* stream);
+
+/*
+ * BDCN tail (bdcn_new.py:127-191): ConvTranspose2d upsampling (k=2*stride, weights from the
+ * checkpoint) + crop of stages 2..5, the two deep-supervision cascades, the 1x1 fuse over the 10
+ * maps and the sigmoids.  s[k]/s1[k] are the stage score maps [B,h_k,w_k]; up[k] the k_k x k_k
+ * upsampling kernels (up[0] unused).  out[0..10] are [B,1,H,W] maps (any may be NULL to skip it;
+ * calc_edge only needs out[10], the fused edge map).
+ */
+typedef struct {
+  int32_t B, H, W;
+  const float* s[5];
+  const float* s1[5];
+  int32_t h[5], w[5];
+  int32_t stride[5], crop[5];
+  const float* up[5];
+  const float* fuse_w;   /* [10] */
+  const float* fuse_b;   /* [1]  */
+  float* out[11];
+  int32_t edge_thres;    /* utils.py:653-655: out[10] >= 0.1 -> 1 */
+} egne_bdcn_tail_desc;
+int egne_bdcn_tail(const egne_bdcn_tail_desc* d, void* stream);
+
+/*
+ * Loss head (models/RITnet_v2.py:372-432, loss.py:16-137) in two launches and no host sync.
+ * Pass 1 reads the logits once (NHWC slice, 3 classes) and writes per-block partial sums;
+ * pass 2 (one block per sample + one finishing block) reduces them to
+ *   out_terms[0..7] = total, l_seg2pt, l_seg, l_pt, l_ellipse, n_mask_present, bad_sample_flag, 0
+ *   pred_c[B][2][2] = (iris, pupil) soft-argmax centres (iris = elOut[:,5:7] when no mask in batch)
+ *   mask[B][H][W]   = argmax over the 3 classes (int64, first max on ties; utils.py:65-81), optional
+ *   op_nchw         = logits transposed to [B,3,H,W], optional
+ */
+typedef struct {
+  int32_t B, H, W;
+  const float* logits; int64_t pix_stride; int32_t ch_off;
+  const int64_t* target;       /* [B,H,W] */
+  const float* spatWts;        /* [B,H,W] */
+  const float* distMap;        /* [B,3,H,W] */
+  const float* cond;           /* [B,4], 0 = annotation present */
+  const float* pupil_center;   /* [B,2] pixels */
+  const float* elNorm;         /* [B,2,5] */
+  const float* elOut;          /* [B,10] */
+  float alpha;
+  const float* grid_x;         /* optional [W] / [H] mesh axes (torch.linspace(-1,1,.)); NULL = closed form */
+  const float* grid_y;
+  float* partials;             /* workspace, egne_loss_workspace_floats(B,H,W) floats */
+  float* out_terms;            /* [8] */
+  float* pred_c;               /* [B,2,2] */
+  float* elPred;               /* [B,10] = (c_iris, elOut[2:5], c_pupil, elOut[7:10]) */
+  int64_t* mask;               /* optional */
+  float* op_nchw;              /* optional */
+} egne_loss_desc;
+int64_t egne_loss_workspace_floats(int B, int H, int W);
+int egne_loss_fwd(const egne_loss_desc* d, void* stream);
+
+/* regressionModule output activations (utils.py:1023-1036): tanh / sigmoid / identity split of the
+ * 10 raw outputs, in place over [B,10] (row stride `ld`). */
+int egne_ellipse_head_act(float* x, int B, int ld, void* stream);
+/* torch.selu in place over n floats (utils.py:1021). */
+int egne_selu_inplace(float* x, int64_t n, void* stream);
+/* latent = mean over H*W of an NHWC slice -> [B][C] (models/RITnet_v2.py:282). */
+int egne_spatial_mean(const float* x, int64_t pix_stride, int ch_off, int C, int B, int HW,
+                      float* out, void* stream);
+
+/*
+ * Ellipse fit of evaluate.py (utils.py:450-486 search_proper_parameter_iou_for_our_data with
+ * calc_ell_iou utils.py:176-204 and the conic algebra of helperfunctions.py:13-63,102-129):
+ * one workgroup per (frame, class) runs the whole coordinate search on the device.
+ * mask [frames][H][W] int64 class maps, frame_of[n] / cls[n] the frame and class id of each fit,
+ * xs[W] / ys[H] the float32 mesh axes exactly as torch.linspace(-1,1,.) produces them (utils.py:27-60
+ * create_meshgrid; passed in because ATen's vectorised linspace is not a closed formula),
+ * init [n][5] (cx,cy,a,b,theta) pixels, out [n][5] doubles, evals[n] IoU evaluation count (optional).
+ */
+int egne_ellipse_fit(const int64_t* mask, const int32_t* frame_of, const int32_t* cls, int n,
+                     int H, int W, const float* xs, const float* ys, const double* init, double* out,
+                     int32_t* evals, void* stream);
+
+const char* egne_last_error(void);
+int egne_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

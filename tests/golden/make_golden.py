@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REFERENCE itself (CPU) in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Needs /root/reference (read-only) -- it therefore only runs in the container, never on the GPU
+box; the .npz files it writes are committed.  Fixtures hold data only (inputs' checksums and
+expected outputs); weights and inputs are regenerated from seeds on the consuming side with
+``egne_amd.synth`` (the same generator is used here to load the reference modules).
+"""
+import contextlib
+import hashlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_shim  # noqa: E402
+import egne_amd  # noqa: E402,F401
+from egne_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+REF = _ref_shim.reference_modules()
+CFG_DIR = os.path.join(ROOT, egne_amd.PKG_DIRNAME if hasattr(egne_amd, "PKG_DIRNAME") else
+                       "edge-guided-near-eye-image-analysis-for-head-mounted-displays_amd", "configs")
+
+
+def sha(t):
+    a = t.detach().cpu().contiguous().numpy() if torch.is_tensor(t) else np.ascontiguousarray(t)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-34s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def load_setting(name):
+    with open(os.path.join(CFG_DIR, name + ".yaml")) as f:
+        return yaml.safe_load(f)
+
+
+def ref_bdcn(seed=0):
+    m = quiet(REF["bdcn_new"].BDCN)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=seed, kind="bdcn"))
+    return m.eval()
+
+
+def ref_esf(setting, variant="v2", seed=0, disentangle=False, nsets=4):
+    mod = REF["RITnet_v2"] if variant == "v2" else REF["RITnet_concat"]
+    m = quiet(mod.DenseNet2D, dict(setting))
+    if disentangle:
+        m.disentangle = True
+        m.setDatasetInfo(nsets)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=seed, kind="esf"))
+    return m
+
+
+def batch_args(b, edge):
+    return (b["img"], edge, b["label"], b["pupil_center"], b["elNorm"], b["spatWts"],
+            b["distMap"], b["cond"], b["ID"], b["alpha"])
+
+
+# ------------------------------------------------------------------------------------------
+def gold_bdcn():
+    bd = ref_bdcn()
+    b = synth.make_batch(2, seed=1234)
+    x = b["img"]
+    with torch.no_grad():
+        x3 = torch.cat((x, x, x), 1)
+        outs = bd(x3)
+        feats = bd.features(x3)
+    arrs = dict(img_sha=sha(x), fuse=npy(outs[-1]))
+    for i, o in enumerate(outs[:-1]):
+        arrs["map%d_sub" % i] = npy(o[:, :, ::8, ::8])
+        arrs["map%d_sum" % i] = npy(o.double().sum((1, 2, 3)))
+    arrs["feat_mean"] = np.array([f.double().mean().item() for f in feats])
+    arrs["feat_absmax"] = np.array([f.abs().max().item() for f in feats])
+    save("bdcn_b2_240x320", **arrs)
+
+    # odd size + genuinely 3-channel input: exercises ceil_mode pools and crop offsets
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 3, 100, 100, generator=g)
+    with torch.no_grad():
+        outs = bd(x)
+    save("bdcn_b1_100x100", x=npy(x), **{"map%d" % i: npy(o) for i, o in enumerate(outs)})
+    return bd
+
+
+def esf_case(name, cfg, variant, b, edge, full_op, train=True, disentangle=False):
+    setting = load_setting(cfg)
+    m = ref_esf(setting, variant, disentangle=disentangle)
+    args = batch_args(b, edge)
+    m.eval()
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut = quiet(m, *args)
+    arrs = dict(cfg=cfg, variant=variant, B=b["img"].shape[0],
+                img_sha=sha(b["img"]), edge_sha=sha(edge), dist_sha=sha(b["distMap"]),
+                elOut=npy(elOut), elPred=npy(elPred), latent=npy(latent), loss=npy(loss),
+                op_sum=npy(op.double().sum((2, 3))), op_abs=npy(op.double().abs().sum((2, 3))),
+                mask=np.packbits(npy(op.max(1)[1]).astype(np.uint8) == 1),
+                mask2=np.packbits(npy(op.max(1)[1]).astype(np.uint8) == 2))
+    arrs["op"] = npy(op) if full_op else npy(op[:, :, ::4, ::4])
+    # top-2 logit gap, to list near-tie pixels where argmax may legitimately differ
+    srt = op.sort(dim=1, descending=True)[0]
+    arrs["gap_lt_2e3"] = np.array(int(((srt[:, 0] - srt[:, 1]) < 2e-3).sum()))
+    if train:
+        m.train()
+        m.zero_grad()
+        op, elPred, latent, loss, elOut = quiet(m, *args)
+        loss.sum().backward()
+        arrs.update(t_loss=npy(loss), t_elOut=npy(elOut), t_latent=npy(latent),
+                    t_op_sub=npy(op[:, :, ::4, ::4]),
+                    t_head_rm=npy(m.enc.head.bn.running_mean), t_head_rv=npy(m.enc.head.bn.running_var),
+                    t_final_rm=npy(m.dec.final.bn.running_mean), t_final_rv=npy(m.dec.final.bn.running_var))
+        names, gsum, gl2 = [], [], []
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            gsum.append(p.grad.double().sum().item())
+            gl2.append(p.grad.double().norm().item())
+        arrs.update(grad_names=np.array(names), grad_sum=np.array(gsum), grad_l2=np.array(gl2))
+        for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight",
+                  "enc.down_block1.conv21.weight", "dec.up_block4.conv11.bias"):
+            arrs["grad::" + k] = npy(dict(m.named_parameters())[k].grad)
+        # one Adam step as train.py:148,285-287 (lr 5e-4, defaults); dsIdentify params excluded
+        opt = torch.optim.Adam([p for n, p in m.named_parameters() if "dsIdentify" not in n], lr=5e-4)
+        opt.step()
+        arrs["adam_names"] = np.array([n for n, _ in m.named_parameters()])
+        arrs["adam_sum"] = np.array([p.double().sum().item() for _, p in m.named_parameters()])
+        arrs["adam::enc.head.conv1.weight"] = npy(m.enc.head.conv1.weight)
+    save(name, **arrs)
+
+
+def gold_esf(bd):
+    b = synth.make_batch(2, seed=1234)
+    with torch.no_grad():
+        edge = bd(torch.cat((b["img"],) * 3, 1))[-1]
+    esf_case("esf_edge_b2", "baseline_edge", "v2", b, edge, True)
+    esf_case("esf_adain_edge_b2", "baseline_adain_edge", "v2", b, edge, False)
+    esf_case("esf_baseline_b2", "baseline", "v2", b, edge, False)
+    esf_case("esf_adain_b2", "baseline_adain", "v2", b, edge, False, train=False)
+    esf_case("esf_input_concat_b2", "baseline_input_concat", "v2", b, edge, False, train=False)
+    esf_case("esf_only_edge_b2", "baseline_only_edge", "v2", b, edge, False, train=False)
+    esf_case("esf_concat_b2", "baseline_edge", "concat", b, edge, False)
+    esf_case("esf_edge_disent_b2", "baseline_edge", "v2", b, edge, False, disentangle=True)
+    # mask-absent sample in the batch (cond[:,1:4]=1 for sample 1) and an all-absent batch
+    b2 = synth.make_batch(2, seed=4321, mask_absent_every=2)
+    with torch.no_grad():
+        e2 = bd(torch.cat((b2["img"],) * 3, 1))[-1]
+    esf_case("esf_edge_b2_absent1", "baseline_edge", "v2", b2, e2, False)
+    b3 = synth.make_batch(2, seed=99, mask_absent_every=1)
+    with torch.no_grad():
+        e3 = bd(torch.cat((b3["img"],) * 3, 1))[-1]
+    esf_case("esf_edge_b2_absent_all", "baseline_edge", "v2", b3, e3, False)
+    # B=1 exactly as evaluate.py:112-131 builds its arguments
+    b1 = synth.make_batch(1, seed=555)
+    H, W = b1["img"].shape[-2:]
+    lab = torch.zeros((1, H, W))
+    lab[..., 0, 2] = 1
+    lab[..., 2, 2] = 2
+    b1.update(label=lab.long(), pupil_center=torch.zeros(1, 2), elNorm=torch.zeros(1, 2, 5),
+              spatWts=torch.zeros(1, H, W), distMap=torch.zeros(1, 3, H, W), cond=torch.zeros(1, 4),
+              ID=0, alpha=0)
+    with torch.no_grad():
+        e1 = bd(torch.cat((b1["img"],) * 3, 1))[-1]
+    esf_case("esf_edge_b1_eval", "baseline_edge", "v2", b1, e1, False, train=False)
+
+
+def gold_losses():
+    L = REF["loss"]
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 4, 48, 64
+    op = 2 * torch.randn(B, 3, H, W, generator=g)
+    tgt = torch.randint(0, 3, (B, H, W), generator=g)
+    tgt[1][tgt[1] == 2] = 1          # sample 1: pupil class absent
+    tgt[2][tgt[2] == 0] = 2          # sample 2: background absent
+    sw = 1 + 20 * (torch.rand(B, H, W, generator=g) > 0.9).float()
+    dist = torch.randn(B, 3, H, W, generator=g)
+    gt = torch.rand(B, 2, generator=g) * 2 - 1
+    arrs = dict(op=npy(op), tgt=npy(tgt).astype(np.uint8), sw=npy(sw), dist=npy(dist), gt=npy(gt))
+    l, p = L.get_seg2ptLoss(op[:, 2], gt, temperature=4)
+    arrs.update(s2p_loss=npy(l), s2p_pts=npy(p))
+    l, p = L.get_seg2ptLoss(-op[:, 0], gt, temperature=4)
+    arrs.update(s2p_iri_loss=npy(l), s2p_iri_pts=npy(p))
+    arrs["surface"] = np.array([L.SurfaceLoss(op[i:i + 1], dist[i:i + 1]).item() for i in range(B)])
+    arrs["gdice"] = np.array([L.GDiceLoss(op[i:i + 1], tgt[i:i + 1], torch.nn.functional.softmax).item()
+                              for i in range(B)])
+    arrs["wce"] = np.array([L.wCE(op[i], tgt[i], sw[i]).item() for i in range(B)])
+    for nm, cond in (("all", [1, 1, 1, 1]), ("some", [1, 0, 1, 0]), ("none", [0, 0, 0, 0])):
+        c = torch.tensor(cond, dtype=torch.float32)
+        v = L.get_segLoss(op, tgt, sw, dist, c, 0.3)
+        arrs["segloss_" + nm] = np.array(float(v))
+        v = L.get_ptLoss(op[:, :, 0, 0:10].reshape(B, -1)[:, :10], dist[:, 0, 0, :10], c)
+        arrs["ptloss_" + nm] = np.array(float(v))
+    x = torch.randn(6, 4, generator=g)
+    arrs["conf_in"] = npy(x)
+    arrs["conf_true"] = np.array(L.conf_Loss(x, torch.tensor([0, 1, 2, 3, 0, 1]), True).item())
+    arrs["conf_false"] = np.array(L.conf_Loss(x, torch.tensor([0, 1, 2, 3, 0, 1]), False).item())
+    save("loss_cases", **arrs)
+
+
+def gold_fit():
+    U = REF["utils"]
+    rng = np.random.RandomState(3)
+    H, W = 240, 320
+    masks, inits, outs = [], [], []
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in range(24):
+        cx, cy = rng.uniform(90, 230), rng.uniform(70, 170)
+        a, b = rng.uniform(12, 70), rng.uniform(12, 70)
+        th = rng.uniform(-1.4, 1.4)
+        X = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        Y = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        m = (X / a) ** 2 + (Y / b) ** 2 <= 1
+        if i % 4 == 1:   # occlude the top (eyelid)
+            m[: int(cy - 0.4 * b)] = False
+        if i % 4 == 2:   # speckle
+            m ^= rng.rand(H, W) > 0.995
+        if i == 23:      # empty mask -> nan scores, search must stop after one sweep
+            m[:] = False
+        init = np.array([cx + rng.uniform(-3, 3), cy + rng.uniform(-3, 3), a * rng.uniform(0.8, 1.25),
+                         b * rng.uniform(0.8, 1.25), th + rng.uniform(-0.3, 0.3)])
+        res = U.search_proper_parameter_iou_for_our_data(torch.from_numpy(m), init.copy())
+        masks.append(np.packbits(m))
+        inits.append(init)
+        outs.append(res)
+    # calc_ell_iou scores for a few raw evaluations (pins the IoU map itself)
+    mesh = U.create_meshgrid(H, W, normalized_coordinates=True)
+    m0 = np.unpackbits(masks[0]).reshape(H, W).astype(bool)
+    sc = []
+    for i in range(8):
+        el = np.concatenate([inits[i][:4], [inits[i][4] * 180. / 3.14159]])
+        sc.append(U.calc_ell_iou(torch.from_numpy(m0), el.copy(), mesh, False, True))
+    save("fit_cases", masks=np.stack(masks), inits=np.stack(inits), outs=np.stack(outs),
+         iou0=np.array(sc))
+    # my_ellipse.transform on its own (evaluate.py:141-146 un-normalisation)
+    Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
+    prm = np.stack([[rng.uniform(-.5, .5), rng.uniform(-.5, .5), rng.uniform(.1, .5), rng.uniform(.1, .5),
+                     rng.uniform(-1.5, 1.5)] for _ in range(16)])
+    tr = np.stack([REF["hf"].my_ellipse(p).transform(Hm)[0][:-1] for p in prm])
+    save("ellipse_transform", params=prm, out=tr)
+
+
+def gold_metrics():
+    U = REF["utils"]
+    rng = np.random.RandomState(11)
+    B, H, W = 4, 60, 80
+    yt = rng.randint(0, 3, (B, H, W))
+    yp = np.where(rng.rand(B, H, W) < 0.8, yt, rng.randint(0, 3, (B, H, W)))
+    yt[2][yt[2] == 2] = 1
+    cond = np.array([0, 0, 0, 1], dtype=np.float32)
+    miou, pc, sl = U.getSeg_metrics(yt, yp, cond)
+    a = rng.rand(B, 2) * 100
+    p = rng.rand(B, 2) * 2 - 1
+    d, dv = U.getPoint_metric(a, p, cond, (H, W), True)
+    d2, dv2 = U.getPoint_metric(a, a + 1.5, cond, (H, W), False)
+    logits = rng.randn(B, 3, H, W).astype(np.float32)
+    logits[0, :, 0, 0] = 1.0  # exact tie -> first index wins
+    pred = U.get_predictions(torch.from_numpy(logits)).numpy()
+    save("metrics", yt=yt.astype(np.uint8), yp=yp.astype(np.uint8), cond=cond, miou=np.array(miou), perclass=pc,
+         scorelist=sl, pts_true=a, pts_pred=p, pdist=np.array(d), pdist_v=dv, pdist2=np.array(d2), pdist2_v=dv2,
+         logits=logits, pred=pred.astype(np.uint8),
+         norm=U.normPts(torch.from_numpy(a.astype(np.float32)), (H, W)).numpy(),
+         unnorm=U.unnormPts(p.astype(np.float32), (H, W)))
+
+
+def gold_keys():
+    """Checkpoint key schema (name -> shape) of every reference module on the path."""
+    import json
+    out = {"bdcn": {k: list(v.shape) for k, v in ref_bdcn().state_dict().items()}}
+    for cfg in ("baseline", "baseline_edge", "baseline_adain", "baseline_adain_edge", "baseline_input_concat"):
+        m = ref_esf(load_setting(cfg))
+        out["v2:" + cfg] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    m = ref_esf(load_setting("baseline_edge"), disentangle=True, nsets=4)
+    out["v2:baseline_edge:disentangle4"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    m = ref_esf(load_setting("baseline_edge"), variant="concat")
+    out["concat:baseline_edge"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(HERE, "state_keys.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote state_keys.json")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["bdcn", "esf", "loss", "fit", "metrics", "keys"]
+    bd = None
+    if "bdcn" in what:
+        bd = gold_bdcn()
+    if "esf" in what:
+        gold_esf(bd or ref_bdcn())
+    if "loss" in what:
+        gold_losses()
+    if "fit" in what:
+        gold_fit()
+    if "metrics" in what:
+        gold_metrics()
+    if "keys" in what:
+        gold_keys()

