@@ -116,6 +116,7 @@ def build_forward_plan(model, B, H, W, dev, training):
     fc = es["op"][-1]
     pl = Plan(dev)
     L = pl.L
+    pl.dbg = {}
 
     # ---- inputs (persistent; forward() copies the caller's tensors in) -----------------------------
     pl.in_img = pl.vec(B, 1, H, W)
@@ -161,6 +162,7 @@ def build_forward_plan(model, B, H, W, dev, training):
             _train_bn(pl, enc.head.bn, D[0]["x"], B, B, H * W, "enc.head.bn.edge")
 
     bott = pl.buf(NB, res[4][0], res[4][1], pad8(fc))
+    pl.dbg.update(D=D, bott=bott, t0=t0)
     for i, blk in enumerate(blocks):
         h, w = res[i]
         d = D[i]
@@ -228,6 +230,7 @@ def build_forward_plan(model, B, H, W, dev, training):
         l = _cl(ub.conv22, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
         pl.conv(l, [tp], Piece(y, 0, oc), B, h, w, name=nm + ".conv22")
         prev, ph, pw = [Piece(y, 0, oc)], h, w
+        pl.dbg[nm] = prev[0]
 
     tf = pl.buf(B, H, W, pad8(chz))
     l = _cl(dec.final.conv1, _lay(prev), pad=(1, 1), act=ACT_LEAKY)

@@ -62,7 +62,10 @@ def seeded_state_dict(template, seed=0, kind="esf", gain=1.0):
                         std *= 0.15  # keeps the side outputs inside the sigmoid's useful range
                     t = std * torch.randn(shape, generator=g)
             else:
-                std = gain * math.sqrt(2.0 / (kh * kw * o))
+                # fan-in scaling: the reference's own fan-out init (RITnet_v2.py:356-369) lets the
+                # un-trained logits grow to O(1e4), where the 1e-3 absolute tolerance of the north
+                # star is below fp32 round-off; a trained net has O(10) logits, which this mimics
+                std = gain * math.sqrt(2.0 / (i * kh * kw))
                 t = std * torch.randn(shape, generator=g)
         elif len(shape) == 2:  # linear weight [out, in]
             t = torch.randn(shape, generator=g) / math.sqrt(shape[1])

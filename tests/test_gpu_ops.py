@@ -1,0 +1,241 @@
+"""-m gpu: every C-ABI op against the CPU oracle / plain torch fp32 on seeded inputs.
+
+Tolerances: fp32 MFMA accumulates a k-ordered fmaf chain (exact fp32), the CPU reference sums in a
+different order -> relative 1e-5 of the output scale for convs; byte-exact for argmax / fit.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(g, *shape):
+    return torch.randn(*shape, generator=g)
+
+
+def _close(a, b, rel=2e-5):
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+@pytest.fixture(scope="module")
+def G():
+    from gpu_util import conv_hip  # noqa: F401  (imports torch.cuda)
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.Generator().manual_seed(2024)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,d,act", [
+    (2, 3, 64, 29, 39, 1, 1),      # VGG first layer shape class, odd spatial, M tail
+    (1, 64, 64, 24, 40, 1, 1),
+    (2, 38, 38, 30, 40, 2, 2),     # odd channels -> padded K and N, dilation 2 (VGG conv5 class)
+    (1, 128, 256, 15, 20, 1, 0),   # wide N tile (128), no activation
+    (3, 32, 3, 16, 24, 1, 2),      # Cout=3 (final conv)
+    (1, 512, 512, 9, 11, 2, 1),    # deep K
+])
+def test_conv3x3(G, B, Cin, Cout, H, W, d, act):
+    from gpu_util import conv_hip
+    x, w, b = _rand(G, B, Cin, H, W), _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    ref = F.conv2d(x, w, b, padding=d, dilation=d)
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref) if act == 2 else ref)
+    _close(conv_hip([x], [w], [b], pad=(1, 1), dils=(d,), act=act), ref)
+
+
+def test_conv1x1_concat_free_with_fused_instancenorm(G):
+    """1x1 conv reading three slices (would-be torch.cat), InstanceNorm + LeakyReLU fused on load."""
+    from gpu_util import conv_hip
+    B, H, W = 2, 17, 23
+    xs = [_rand(G, B, 38, H, W) * 2 + 1, _rand(G, B, 32, H, W), _rand(G, B, 64, H, W)]
+    w, b = _rand(G, 76, 134, 1, 1) / 11, _rand(G, 76)
+    mean = xs[0].mean((2, 3))
+    rstd = 1 / torch.sqrt(xs[0].var((2, 3), unbiased=False) + 1e-5)
+    xin = torch.cat([F.leaky_relu(F.instance_norm(xs[0])), xs[1], xs[2]], 1)
+    ref = F.conv2d(xin, w, b)
+    got = conv_hip(xs, [w], [b], norm={0: (rstd, -mean * rstd, 2)})
+    _close(got, ref, 5e-5)
+
+
+def test_msblock_fused_dilated_group(G):
+    """bdcn_new.py:49-55: o + relu(conv_d4(o)) + relu(conv_d8(o)) + relu(conv_d12(o)) in one launch."""
+    from gpu_util import conv_hip
+    B, H, W = 2, 31, 45
+    o = F.relu(_rand(G, B, 32, H, W))
+    ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+    bs = [_rand(G, 32) for _ in range(3)]
+    ref = o.clone()
+    for w, b, d in zip(ws, bs, (4, 8, 12)):
+        ref = ref + F.relu(F.conv2d(o, w, b, padding=d, dilation=d))
+    _close(conv_hip([o], ws, bs, pad=(1, 1), dils=(4, 8, 12), act=1, residual=o), ref)
+
+
+def test_conv_misc_geometries(G):
+    from gpu_util import conv_hip
+    # regressionModule c1: 2x3 kernel, no padding, two slices (utils.py:991-994)
+    xa, xb = _rand(G, 2, 153, 15, 20), _rand(G, 2, 153, 15, 20)
+    w, b = _rand(G, 128, 306, 2, 3) / 40, _rand(G, 128)
+    _close(conv_hip([xa, xb], [w], [b], act=2), F.leaky_relu(F.conv2d(torch.cat([xa, xb], 1), w, b)))
+    # StyleEncoder: reflect pad 3 + 7x7, then reflect pad 1 + 4x4 stride 2 (RITnet_v2.py:95-101)
+    x = _rand(G, 2, 3, 20, 28)
+    w, b = _rand(G, 64, 3, 7, 7) / 12, _rand(G, 64)
+    _close(conv_hip([x], [w], [b], pad=(3, 3), act=1, pad_mode=1), F.relu(F.conv2d(F.pad(x, (3,) * 4, mode="reflect"), w, b)))
+    x = _rand(G, 2, 64, 20, 28)
+    w, b = _rand(G, 128, 64, 4, 4) / 32, _rand(G, 128)
+    _close(conv_hip([x], [w], [b], stride=2, pad=(1, 1), act=1, pad_mode=1),
+           F.relu(F.conv2d(F.pad(x, (1,) * 4, mode="reflect"), w, b, stride=2)))
+    # Linear(480,256) as a 3x5 "valid" conv over the NHWC map (utils.py:1020)
+    x = _rand(G, 4, 32, 3, 5)
+    wl, bl = _rand(G, 256, 480) / 22, _rand(G, 256)
+    got = conv_hip([x], [wl], [bl], kernel_hw=(3, 5))
+    _close(got.reshape(4, 256), F.linear(x.reshape(4, -1), wl, bl))
+    # eval-mode BatchNorm folded behind the activation (utils.py:1047-1049)
+    x = _rand(G, 2, 32, 12, 16)
+    w, b = _rand(G, 3, 32, 3, 3) / 17, _rand(G, 3)
+    ps, pt = torch.rand(3, generator=G) + 0.5, _rand(G, 3)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1)) * ps[None, :, None, None] + pt[None, :, None, None]
+    _close(conv_hip([x], [w], [b], pad=(1, 1), act=2, post=(ps, pt)), ref)
+
+
+def test_norm_pool_upsample(G):
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import Piece, Plan
+    B, C, H, W = 3, 38, 30, 40
+    x = _rand(G, B, C, H, W) * 3 + 0.5
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    sc, sh, _, _ = pl.norm_stats(px, B, H * W)
+    bsc, bsh, bm, bv = pl.norm_stats(px, B, H * W, per_sample=False, want_moments=True)
+    ap = pl.buf(B, H // 2, W // 2, px.Cp)
+    pl.avgpool2(px, Piece(ap, 0, C), B, H, W)
+    mp2 = pl.buf(B, 15, 20, px.Cp)
+    pl.maxpool2(px, Piece(mp2, 0, C), B, H, W, 2)
+    mp1 = pl.buf(B, 29, 39, px.Cp)
+    pl.maxpool2(px, Piece(mp1, 0, C), B, H, W, 1)
+    up = pl.buf(B, 2 * H, 2 * W, px.Cp)
+    pl.upsample2x(px, Piece(up, 0, C), B, H, W)
+    pl.run()
+    torch.cuda.synchronize()
+    nchw = lambda t: t.cpu()[..., :C].permute(0, 3, 1, 2)  # noqa: E731
+    mean, var = x.mean((2, 3)), x.var((2, 3), unbiased=False)
+    np.testing.assert_allclose(sc.cpu()[:, :C], 1 / torch.sqrt(var + 1e-5), rtol=1e-5)
+    np.testing.assert_allclose(sh.cpu()[:, :C], -mean / torch.sqrt(var + 1e-5), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(bm.cpu()[0, :C], x.mean((0, 2, 3)), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bv.cpu()[0, :C], x.var((0, 2, 3), unbiased=False), rtol=1e-5)
+    np.testing.assert_allclose(nchw(ap), F.avg_pool2d(x, 2), rtol=1e-6, atol=1e-6)
+    assert torch.equal(nchw(mp2), F.max_pool2d(x, 2, 2, ceil_mode=True))
+    assert torch.equal(nchw(mp1), F.max_pool2d(x, 2, 1, ceil_mode=True))
+    np.testing.assert_allclose(nchw(up), F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False),
+                               rtol=1e-5, atol=1e-6)
+    # odd sizes: ceil_mode windows hanging over the border (vgg16_c.py pools at 25 -> 13)
+    x2 = _rand(G, 1, 8, 25, 13)
+    pl2 = Plan(torch.device(DEV))
+    (p2,) = to_nhwc_buf(pl2, [x2], 1, 25, 13)
+    o2 = pl2.buf(1, 13, 7, 8)
+    pl2.maxpool2(p2, Piece(o2, 0, 8), 1, 25, 13, 2)
+    pl2.run()
+    assert torch.equal(o2.cpu().permute(0, 3, 1, 2), F.max_pool2d(x2, 2, 2, ceil_mode=True))
+
+
+@pytest.mark.parametrize("H,W,absent", [(48, 64, "none"), (240, 320, "some"), (30, 40, "all")])
+def test_loss_head_vs_oracle(G, H, W, absent):
+    import ctypes as C
+    from gpu_util import DEV
+    from egne_amd import _lib
+    from oracle import losses as oloss
+    B = 5
+    op = 2 * _rand(G, B, 3, H, W)
+    tgt = torch.randint(0, 3, (B, H, W), generator=G)
+    tgt[1][tgt[1] == 2] = 1           # a sample without pupil pixels (one class absent)
+    sw = 1 + 20 * (torch.rand(B, H, W, generator=G) > 0.9).float()
+    dist = _rand(G, B, 3, H, W)
+    pc = torch.rand(B, 2, generator=G) * torch.tensor([W, H])
+    eln = torch.rand(B, 2, 5, generator=G) * 2 - 1
+    elOut = torch.rand(B, 10, generator=G) * 2 - 1
+    cond = torch.zeros(B, 4)
+    if absent == "some":
+        cond[2, 1:] = 1
+        cond[4, 1:] = 1
+    elif absent == "all":
+        cond[:, 1:] = 1
+    alpha = 0.3
+    total, pred_c, terms = oloss.all_loss(op, elOut, tgt, pc, eln, sw, dist, cond, alpha)
+    L = _lib.lib()
+    d = _lib.LossDesc()
+    t = {k: v.to(DEV).contiguous() for k, v in dict(tgt=tgt, sw=sw, dist=dist, pc=pc, eln=eln, elOut=elOut, cond=cond).items()}
+    logits = torch.zeros(B, H, W, 8, device=DEV)
+    logits[..., :3] = op.permute(0, 2, 3, 1).to(DEV)
+    part = torch.zeros(int(L.egne_loss_workspace_floats(B, H, W)), device=DEV)
+    out_terms, pcd, elp = torch.zeros(8, device=DEV), torch.zeros(B, 2, 2, device=DEV), torch.zeros(B, 10, device=DEV)
+    mask = torch.zeros(B, H, W, dtype=torch.int64, device=DEV)
+    opn = torch.zeros(B, 3, H, W, device=DEV)
+    gx, gy = torch.linspace(-1, 1, W).to(DEV), torch.linspace(-1, 1, H).to(DEV)
+    d.B, d.H, d.W = B, H, W
+    d.logits, d.pix_stride, d.ch_off = logits.data_ptr(), 8, 0
+    d.target, d.spatWts, d.distMap, d.cond = t["tgt"].data_ptr(), t["sw"].data_ptr(), t["dist"].data_ptr(), t["cond"].data_ptr()
+    d.pupil_center, d.elNorm, d.elOut, d.alpha = t["pc"].data_ptr(), t["eln"].data_ptr(), t["elOut"].data_ptr(), alpha
+    d.grid_x, d.grid_y = gx.data_ptr(), gy.data_ptr()
+    d.partials, d.out_terms, d.pred_c, d.elPred = part.data_ptr(), out_terms.data_ptr(), pcd.data_ptr(), elp.data_ptr()
+    d.mask, d.op_nchw = mask.data_ptr(), opn.data_ptr()
+    _lib.check(L.egne_loss_fwd(C.byref(d), _lib.stream_ptr()), "loss")
+    torch.cuda.synchronize()
+    ot = out_terms.cpu().numpy()
+    np.testing.assert_allclose(ot[0], float(total), rtol=2e-5)
+    for i, k in enumerate(["l_seg2pt", "l_seg", "l_pt", "l_ellipse"]):
+        np.testing.assert_allclose(ot[1 + i], float(terms[k]), rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(pcd.cpu().numpy(), pred_c.numpy(), atol=2e-6)
+    assert torch.equal(mask.cpu(), op.max(1)[1]), "argmax mask must be identical (first max on ties)"
+    assert torch.equal(opn.cpu(), op)
+    ref_elp = torch.cat([pred_c[:, 0], elOut[:, 2:5], pred_c[:, 1], elOut[:, 7:10]], 1)
+    np.testing.assert_allclose(elp.cpu().numpy(), ref_elp.numpy(), atol=2e-6)
+
+
+def test_loss_two_absent_classes_flag(G):
+    """wCE raises in the reference when two classes are absent (loss.py:132); the device path cannot
+    raise without a sync, it reports the sample count in out_terms[6] instead."""
+    import ctypes as C
+    from gpu_util import DEV
+    from egne_amd import _lib
+    B, H, W = 1, 16, 16
+    L = _lib.lib()
+    d = _lib.LossDesc()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+    logits, tgt = z(B, H, W, 8), z(B, H, W, dt=torch.int64)
+    bufs = [z(B, H, W), z(B, 3, H, W), z(B, 4), z(B, 2), z(B, 2, 5), z(B, 10), z(int(L.egne_loss_workspace_floats(B, H, W))),
+            z(8), z(B, 2, 2), z(B, 10)]
+    d.B, d.H, d.W, d.logits, d.pix_stride, d.ch_off, d.target = B, H, W, logits.data_ptr(), 8, 0, tgt.data_ptr()
+    (d.spatWts, d.distMap, d.cond, d.pupil_center, d.elNorm, d.elOut, d.partials, d.out_terms, d.pred_c,
+     d.elPred) = [b.data_ptr() for b in bufs]
+    _lib.check(L.egne_loss_fwd(C.byref(d), _lib.stream_ptr()), "loss")
+    torch.cuda.synchronize()
+    assert bufs[7][6].item() == 1.0
+
+
+def test_fit_bit_exact_vs_golden(G):
+    """Device ellipse fit == reference search (fixtures from utils.py:450-486 run on CPU)."""
+    from common import gold
+    from gpu_util import DEV
+    from egne_amd.utils import fit_ellipses, search_proper_parameter_iou_for_our_data
+    g = gold("fit_cases")
+    H, W = 240, 320
+    n = len(g["masks"])
+    masks = np.stack([np.unpackbits(m).reshape(H, W) for m in g["masks"]]).astype(np.int64)
+    out, ev = fit_ellipses(torch.from_numpy(masks).to(DEV), list(range(n)), [1] * n, g["inits"], return_evals=True)
+    bad = [i for i in range(n) if not np.array_equal(out[i], g["outs"][i])]
+    assert not bad, "fit differs from the reference for cases %s" % bad
+    one = search_proper_parameter_iou_for_our_data(torch.from_numpy(masks[3] == 1).to(DEV), g["inits"][3])
+    np.testing.assert_array_equal(one, g["outs"][3])
+
+
+def test_errors_are_reported(G):
+    """Host-side validation returns an error code + message instead of launching."""
+    import ctypes as C
+    from egne_amd import _lib
+    L = _lib.lib()
+    d = _lib.ConvDesc()
+    rc = L.egne_conv2d_fwd(C.byref(d), None)
+    assert rc == -1 and b"conv" in L.egne_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "conv")
