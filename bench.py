@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (BASELINE.json): eye-frames/s at 320x240.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch that is already resident in HBM:
+frozen BDCN edge extractor -> ESF-Net (baseline_edge, chz=32) -> loss head + argmax mask
+(BASELINE.json configs[1]: inference, batch 64 per GPU, fp32).  For N>1 the driver launches one
+process per GPU (torch.distributed.run); frames shard across ranks with no data-path collective
+(inference replicas), so scaling is weak: every rank processes its own 64 frames.
+
+The JSON line also carries
+  roofline     -- the dominant kernel family (implicit-GEMM conv on fp32 MFMA): algorithmic conv FLOPs
+                  of one step / the summed duration of its conv launches, measured with HIP events
+                  on the launch stream inside the timed region, against the 157.3 TFLOP/s fp32 MFMA peak;
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's PyTorch path) timed on the host
+                  cores on a bounded sample (B=2, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(setting, bd_sd, net_sd, B, iters):
+    """The oracle (CPU port of the reference path: edge + seg + loss, eval, no_grad) on host cores."""
+    import torch
+    import egne_amd  # noqa: F401
+    from egne_amd import synth
+    from oracle import bdcn as obdcn, esfnet as oesf
+    torch.set_num_threads(os.cpu_count() or 1)
+    b = synth.make_batch(B, seed=1234)
+    times = []
+    with torch.no_grad():
+        for i in range(iters + 1):
+            t0 = time.perf_counter()
+            e = obdcn.calc_edge(bd_sd, b["img"])
+            oesf.esf_forward(net_sd, setting, b["img"], e, b["label"], b["pupil_center"], b["elNorm"], b["spatWts"],
+                             b["distMap"], b["cond"], b["ID"], b["alpha"])
+            if i > 0:  # first iteration is warm-up
+                times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 4), "unit": "eye-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "B=%d edge+seg+loss fp32 eval, %d timed iterations (median), torch CPU %d threads of %s logical cores"
+                      % (B, iters, torch.get_num_threads(), os.cpu_count())}
+
+
+def main():
+    a = parse()
+    import torch
+    import yaml
+    import egne_amd  # noqa: F401
+    from egne_amd import _lib, synth
+    from egne_amd.bdcn_new import BDCN
+    from egne_amd.models.RITnet_v2 import DenseNet2D
+    from egne_amd.utils import calc_edge
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    _lib.lib()  # fail loudly if the HIP extension is missing
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    with open(os.path.join(os.path.dirname(egne_amd.__file__), "configs", "baseline_edge.yaml")) as f:
+        setting = yaml.safe_load(f)
+    bd = BDCN()
+    bd.load_state_dict(synth.seeded_state_dict(bd.state_dict(), kind="bdcn"))
+    net = DenseNet2D(dict(setting))
+    net.load_state_dict(synth.seeded_state_dict(net.state_dict(), kind="esf"))
+    bd_sd = {k: v.clone() for k, v in bd.state_dict().items()}
+    net_sd = {k: v.clone() for k, v in net.state_dict().items()}
+    bd, net = bd.to(dev).eval(), net.to(dev).eval()
+
+    B = a.batch
+    # synthetic TEyeD-shaped batch: render 8 distinct frames on the host, tile to B
+    base = synth.make_batch(min(B, 8), seed=1234 + rank)
+    rep = (B + base["img"].shape[0] - 1) // base["img"].shape[0]
+    t = {k: (torch.cat([v] * rep)[:B].to(dev) if torch.is_tensor(v) else v) for k, v in base.items()}
+    args = types.SimpleNamespace(prec=torch.float32, edge_thres=0)
+
+    def step():
+        with torch.no_grad():
+            edge = calc_edge(args, t["img"], bd, dev)
+            return net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
+                       t["ID"], t["alpha"])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    events = []
+    bd._events = net._events = events
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    bd._events = net._events = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    assert torch.isfinite(out[3]).all()
+
+    # per-kernel-family time from the HIP events recorded on the launch stream during the timed steps
+    fam = {}
+    for kind, flops, e0, e1 in events:
+        d = fam.setdefault(kind, [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1) * 1e-3
+        d[1] += flops
+        d[2] += 1
+    conv_t, conv_f, conv_n = fam.get("conv_igemm", [0.0, 0.0, 0])
+    frames = B * a.steps * world
+    res = None
+    if rank == 0:
+        achieved = conv_f / conv_t / 1e12 if conv_t > 0 else 0.0
+        res = {
+            "metric": "eye-frames/sec (320x240) inference edge+seg (BDCN -> ESF-Net -> loss/argmax)",
+            "value": round(frames / dt, 2), "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: baseline_edge.yaml (chz=32) inference, batch=%d/GPU, fp32, "
+                                   "240x320 synthetic IR frames, seeded random-init weights" % B,
+                       "frames_per_gpu_per_step": B, "parallelism": "replicas x%d (frames sharded, no collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2, all tile variants)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": conv_n // max(a.steps, 1),
+                         "avg_launch_ms": round(1e3 * conv_t / max(conv_n, 1), 4),
+                         "algorithmic_gflop_per_frame": round(conv_f / a.steps / B / 1e9, 2)},
+            "kernel_time_share": {k: round(v[0] / max(sum(x[0] for x in fam.values()), 1e-9), 4) for k, v in sorted(fam.items())},
+            "gpu_busy_frac": round(sum(x[0] for x in fam.values()) / dt, 4),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(setting, bd_sd, net_sd, a.cpu_batch, a.cpu_iters)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,7 @@ class BDCN(nn.Module):
         self.fuse = nn.Conv2d(10, 1, 1, stride=1)
         self._initialize_weights()
         self._plans = {}
+        self._events = None  # bench.py: list collecting per-launch HIP events
         self.edge_thres = 0  # set by utils.calc_edge to fuse the >=0.1 -> 1 threshold into the tail
 
     def _initialize_weights(self, logger=None):
@@ -237,5 +238,5 @@ class BDCN(nn.Module):
         """Only the fused edge map (what utils.calc_edge consumes, utils.py:648)."""
         pl = self._plan(x, only_fuse=True, edge_thres=edge_thres)
         pl.x_in.copy_(x.to(torch.float32))
-        pl.run()
+        pl.run(self._events)
         return pl.outs[10].clone()

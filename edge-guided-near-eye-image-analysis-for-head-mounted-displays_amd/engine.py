@@ -127,6 +127,7 @@ class Plan:
         self.keep = []      # tensors / descriptors that must outlive the plan's calls
         self.layers = []    # ConvLayers to (re)pack before running
         self.pre = []       # python callables run before the launches (BN folding etc.)
+        self.meta = []      # per call: (kernel family, algorithmic FLOPs) for bench.py's roofline
         self.L = _lib.lib()
 
     # ---- memory ------------------------------------------------------------------------------
@@ -141,8 +142,9 @@ class Plan:
         return t
 
     # ---- launches ----------------------------------------------------------------------------
-    def _add(self, fn, args, name):
+    def _add(self, fn, args, name, flops=0.0, kind=None):
         self.calls.append((fn, args, name))
+        self.meta.append((kind or name.split(".")[0], flops))
 
     def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv"):
         """pieces: input Pieces in concat order; dst: output Piece.  Returns (Ho, Wo)."""
@@ -179,7 +181,8 @@ class Plan:
         d.Cout_store = min(layer.Cout_store, dst.Cp)
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
-        self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name)
+        flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
+        self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
         return Ho, Wo
 
     def norm_stats(self, piece, B, HW, per_sample=True, eps=1e-5, want_moments=False, name="norm_stats"):
@@ -193,43 +196,56 @@ class Plan:
         self._add(self.L.egne_norm_stats,
                   (piece.ptr, piece.stride, piece.off, piece.Cp, B, HW, 1 if per_sample else 0, eps,
                    scale.data_ptr(), shift.data_ptr(), mean.data_ptr() if want_moments else None,
-                   var.data_ptr() if want_moments else None, ws.data_ptr()), name)
+                   var.data_ptr() if want_moments else None, ws.data_ptr()), name, kind="norm_stats")
         return scale, shift, mean, var
 
     def affine_inplace(self, piece, npix, scale, shift, name="affine"):
         self._add(self.L.egne_affine_inplace, (piece.ptr, piece.stride, piece.off, piece.Cp, npix,
-                                               scale.data_ptr(), shift.data_ptr()), name)
+                                               scale.data_ptr(), shift.data_ptr()), name, kind="affine_inplace")
 
     def avgpool2(self, src, dst, B, H, W, name="avgpool"):
         assert src.Cp == dst.Cp
-        self._add(self.L.egne_avgpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name)
+        self._add(self.L.egne_avgpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name, kind="avgpool2")
 
     def maxpool2(self, src, dst, B, H, W, stride, name="maxpool"):
         o = lambda n: min((n - 2 + stride - 1) // stride + 1, (n - 1) // stride + 1)  # noqa: E731
         Ho, Wo = o(H), o(W)
         assert src.Cp == dst.Cp
         self._add(self.L.egne_maxpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, Ho, Wo,
-                                         stride, src.Cp), name)
+                                         stride, src.Cp), name, kind="maxpool2")
         return Ho, Wo
 
     def upsample2x(self, src, dst, B, H, W, name="upsample"):
         assert src.Cp == dst.Cp
-        self._add(self.L.egne_upsample2x, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name)
+        self._add(self.L.egne_upsample2x, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name, kind="upsample2x")
 
     def raw(self, fn, args, name):
-        self._add(fn, args, name)
+        self._add(fn, args, name, kind=getattr(fn, "__name__", None) or "host")
 
     # ---- execution ---------------------------------------------------------------------------
-    def run(self):
+    def run(self, events=None):
+        """Replay the launches on torch's current stream.  ``events`` (a list) receives one
+        (kernel family, flops, start_event, end_event) per launch -- HIP events recorded on the
+        launch stream, used by bench.py to time individual kernels inside the timed region."""
         for layer in self.layers:
             layer.ensure_packed(self.device)
         for f in self.pre:
             f()
         st = _lib.stream_ptr()
-        for fn, args, name in self.calls:
+        if events is None:
+            for fn, args, name in self.calls:
+                rc = fn(*args, st)
+                if rc != 0:
+                    _lib.check(rc, name)
+            return
+        for (fn, args, name), (kind, flops) in zip(self.calls, self.meta):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             rc = fn(*args, st)
+            e1.record()
             if rc != 0:
                 _lib.check(rc, name)
+            events.append((kind, flops, e0, e1))
 
 
 class VersionGuard:

@@ -131,6 +131,7 @@ class DenseNet2D(nn.Module):
         self.elReg = regressionModule(feature_channels)
         self._initialize_weights()
         self._plans = {}
+        self._events = None  # bench.py: list collecting per-launch HIP events
 
     def setDatasetInfo(self, numSets=2):
         """models/RITnet_v2.py:240-249."""
@@ -182,7 +183,7 @@ class DenseNet2D(nn.Module):
         pl.t_dist.copy_(distMap)
         pl.t_cond.copy_(cond)
         pl.loss_desc.alpha = float(alpha)
-        pl.run()
+        pl.run(self._events)
         loss = pl.terms[0:1].clone()
         if self.disentangle:
             raise NotImplementedError("dataset-confusion head is not built yet")
