@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--layers", action="store_true", help="print a per-launch time / TFLOP/s table to stderr")
     return ap.parse_args()
 
 
@@ -47,7 +48,9 @@ def cpu_baseline(setting, bd_sd, net_sd, B, iters):
     import egne_amd  # noqa: F401
     from egne_amd import synth
     from oracle import bdcn as obdcn, esfnet as oesf
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the box exposes 256 logical cores but over-subscribing torch's intra-op pool is pathologically slow
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(min(ncores, 32))
     b = synth.make_batch(B, seed=1234)
     times = []
     with torch.no_grad():
@@ -133,12 +136,19 @@ def main():
 
     # per-kernel-family time from the HIP events recorded on the launch stream during the timed steps
     fam = {}
-    for kind, flops, e0, e1 in events:
+    per_layer = {}
+    for kind, flops, e0, e1, lname in events:
         d = fam.setdefault(kind, [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1) * 1e-3
         d[1] += flops
         d[2] += 1
+        pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
+        pl_[0] += e0.elapsed_time(e1) * 1e-3 / a.steps
     conv_t, conv_f, conv_n = fam.get("conv_igemm", [0.0, 0.0, 0])
+    if a.layers and rank == 0:
+        for lname, (sec, fl, kind) in per_layer.items():
+            print("%-26s %-18s %9.1f us %8.2f GFLOP %7.1f TFLOP/s" % (lname, kind, sec * 1e6, fl / 1e9, fl / sec / 1e12 if sec > 0 else 0),
+                  file=sys.stderr)
     frames = B * a.steps * world
     res = None
     if rank == 0:

@@ -245,7 +245,7 @@ class Plan:
             e1.record()
             if rc != 0:
                 _lib.check(rc, name)
-            events.append((kind, flops, e0, e1))
+            events.append((kind, flops, e0, e1, name))
 
 
 class VersionGuard:
