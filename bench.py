@@ -144,7 +144,7 @@ def main():
         d[2] += 1
         pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
         pl_[0] += e0.elapsed_time(e1) * 1e-3 / a.steps
-    conv_t, conv_f, conv_n = fam.get("conv_igemm", [0.0, 0.0, 0])
+    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in ("conv_igemm", "conv3x3_halo")) for i in range(3)]
     if a.layers and rank == 0:
         for lname, (sec, fl, kind) in per_layer.items():
             print("%-26s %-18s %9.1f us %8.2f GFLOP %7.1f TFLOP/s" % (lname, kind, sec * 1e6, fl / 1e9, fl / sec / 1e12 if sec > 0 else 0),
@@ -161,7 +161,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: baseline_edge.yaml (chz=32) inference, batch=%d/GPU, fp32, "
                                    "240x320 synthetic IR frames, seeded random-init weights" % B,
                        "frames_per_gpu_per_step": B, "parallelism": "replicas x%d (frames sharded, no collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2, all tile variants)",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (implicit-GEMM conv, fp32 MFMA 32x32x2, all tile variants)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                          "launches_per_step": conv_n // max(a.steps, 1),

@@ -13,6 +13,13 @@ from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
 
 
+import os
+
+HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
+HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "60"))
+HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "64"))  # wider layers: flat kernel is faster (measured)
+
+
 def pad8(c):
     return (int(c) + 7) // 8 * 8
 
@@ -77,6 +84,9 @@ class ConvLayer:
         self.Cout_store = cout_pad if cout_pad else pad8(self.Cout)
         self.G = len(self.weights)
         self.wp = None
+        self.wf = None          # fragment-order pack for the LDS-halo 3x3 kernel
+        self.need_flat = False
+        self.need_frag = False
         self.bp = None
         self._versions = None
         self.post = None  # (scale, shift) tensors [CoutP] for a folded eval-mode BatchNorm
@@ -91,22 +101,30 @@ class ConvLayer:
     def ensure_packed(self, dev):
         vers = tuple(w._version for w in self.weights) + tuple(
             (b._version if b is not None else -1) for b in (self.biases or []))
-        if self.wp is not None and vers == self._versions and self.wp.device == dev:
+        have = (self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+        if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
         L = _lib.lib()
         T = self.kh * self.kw
-        if self.wp is None or self.wp.device != dev:
-            self.wp = torch.empty(self.G * T * self.CoutP * self.Ktot, dtype=torch.float32, device=dev)
+        n = self.G * T * self.CoutP * self.Ktot
+        if self.bp is None or self.bp.device != dev:
             self.bp = torch.zeros(self.G * self.CoutP, dtype=torch.float32, device=dev)
             self.kinv = self._kinv(dev)
+            self.wp = self.wf = None
+        if self.need_flat and self.wp is None:
+            self.wp = torch.empty(n, dtype=torch.float32, device=dev)
+        if self.need_frag and self.wf is None:
+            self.wf = torch.empty(n, dtype=torch.float32, device=dev)
         st = _lib.stream_ptr()
         for g, w in enumerate(self.weights):
             wd = w.detach()
             assert wd.is_cuda and wd.dtype == torch.float32
             wd = wd.contiguous()
-            _lib.check(L.egne_pack_conv_weight(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw,
-                                               self.kinv.data_ptr(), self.CoutP, self.Ktot,
-                                               _ptr(self.wp, g * T * self.CoutP * self.Ktot), st), "pack_conv_weight")
+            for need, buf, fn in ((self.need_flat, self.wp, L.egne_pack_conv_weight),
+                                  (self.need_frag, self.wf, L.egne_pack_conv_weight_frag)):
+                if need:
+                    _lib.check(fn(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.kinv.data_ptr(),
+                                  self.CoutP, self.Ktot, _ptr(buf, g * T * self.CoutP * self.Ktot), st), "pack_conv_weight")
             if self.biases is not None and self.biases[g] is not None:
                 self.bp[g * self.CoutP: g * self.CoutP + self.Cout].copy_(self.biases[g].detach())
         self._versions = vers
@@ -151,10 +169,17 @@ class Plan:
         assert len(pieces) == len(layer.in_layout) and len(pieces) <= _lib.MAXSEG, name
         for p, (c, cp) in zip(pieces, layer.in_layout):
             assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
+        Ho, Wo = layer.out_hw(H, W)
+        halo = (HALO_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
+                and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] <= 2
+                and W >= HALO_MIN_W and layer.CoutP <= HALO_MAX_COUTP and H * W * pieces[0].stride < 2 ** 31)
+        if halo:
+            layer.need_frag = True
+        else:
+            layer.need_flat = True
         if layer not in self.layers:
             self.layers.append(layer)
-            layer.ensure_packed(self.device)
-        Ho, Wo = layer.out_hw(H, W)
+        layer.ensure_packed(self.device)
         d = _lib.ConvDesc()
         d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
         d.kh, d.kw, d.stride = layer.kh, layer.kw, layer.stride
@@ -170,7 +195,7 @@ class Plan:
             s.shift = p.shift.data_ptr() if p.shift is not None else None
             s.act_in = p.act_in
         d.Ktot, d.CoutP = layer.Ktot, layer.CoutP
-        d.w = layer.wp.data_ptr()
+        d.w = layer.wf.data_ptr() if halo else layer.wp.data_ptr()
         d.bias = layer.bp.data_ptr() if layer.biases is not None else None
         d.act = layer.act
         if layer.post is not None:
@@ -182,7 +207,10 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
+        if halo:
+            self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
+        else:
+            self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
         return Ho, Wo
 
     def norm_stats(self, piece, B, HW, per_sample=True, eps=1e-5, want_moments=False, name="norm_stats"):

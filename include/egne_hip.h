@@ -88,6 +88,18 @@ typedef struct {
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
 
+/*
+ * Fast path for the 3x3 / stride 1 / "same" / dilation<=2 / single-slice convolutions (most of
+ * vgg16_c.py:66-78, utils.py:1047-1048 and the 3x3s of models/RITnet_v2.py:57-62,85-87): the input halo
+ * tile is staged once per 32 channels in LDS and all 9 taps run from it.  Same descriptor as
+ * egne_conv2d_fwd, except that `w` must be the FRAGMENT-order pack of egne_pack_conv_weight_frag
+ * ([tap][Ktot/8][CoutP/32][lane][4], each wave's B fragment is one coalesced 1-KiB load).
+ */
+int egne_conv3x3_halo_supported(const egne_conv_desc* d);
+int egne_conv3x3_halo_fwd(const egne_conv_desc* d, void* stream);
+int egne_pack_conv_weight_frag(const float* w_oihw, int Cout, int Cin, int kh, int kw,
+                               const int32_t* kinv, int CoutP, int Ktot, float* w_packed, void* stream);
+
 /* OIHW (torch layout) -> packed [tap][CoutP][Ktot].  kinv[k] (device int32, k < Ktot) names the
  * input channel stored at padded K position k, or -1 for a padding column; rows Cout..CoutP-1 are
  * zero.  Used at load_state_dict / after optimizer steps. */

@@ -36,6 +36,12 @@ def G():
     (1, 128, 256, 15, 20, 1, 0),   # wide N tile (128), no activation
     (3, 32, 3, 16, 24, 1, 2),      # Cout=3 (final conv)
     (1, 512, 512, 9, 11, 2, 1),    # deep K
+    # W >= 60 -> LDS-halo kernel (conv_halo.hip): ragged tiles in x and y, padded K/N, dilation 2, deep K
+    (2, 32, 32, 21, 70, 1, 2),
+    (1, 64, 128, 16, 96, 1, 1),
+    (1, 38, 64, 13, 64, 2, 0),
+    (2, 3, 64, 19, 100, 1, 1),
+    (1, 160, 100, 9, 65, 1, 2),
 ])
 def test_conv3x3(G, B, Cin, Cout, H, W, d, act):
     from gpu_util import conv_hip
@@ -57,6 +63,17 @@ def test_conv1x1_concat_free_with_fused_instancenorm(G):
     ref = F.conv2d(xin, w, b)
     got = conv_hip(xs, [w], [b], norm={0: (rstd, -mean * rstd, 2)})
     _close(got, ref, 5e-5)
+
+
+def test_conv3x3_halo_with_fused_instancenorm(G):
+    """Down-block conv1(IN(x)) on the halo path: zero padding applies AFTER the normalisation."""
+    from gpu_util import conv_hip
+    B, C, H, W = 2, 38, 18, 72
+    x = _rand(G, B, C, H, W) * 2 + 1
+    w, b = _rand(G, 64, C, 3, 3) / 18, _rand(G, 64)
+    mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+    ref = F.leaky_relu(F.conv2d(F.instance_norm(x), w, b, padding=1))
+    _close(conv_hip([x], [w], [b], pad=(1, 1), act=2, norm={0: (rstd, -mean * rstd, 0)}), ref, 5e-5)
 
 
 def test_msblock_fused_dilated_group(G):
