@@ -74,6 +74,9 @@ SIGNATURES = {
     "egne_ellipse_head_act": (i32, [vp, i32, i32, vp]),
     "egne_selu_inplace": (i32, [vp, i64, vp]),
     "egne_spatial_mean": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
+    "egne_softmax3": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp]),
+    "egne_adain": (i32, [vp, i64, i32, i32, vp, vp, i64, i32, vp, i64, i32, i32, i32, f32, vp]),
+    "egne_conf_loss": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp]),
     "egne_ellipse_fit": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "egne_last_error": (C.c_char_p, []),
     "egne_version": (i32, []),

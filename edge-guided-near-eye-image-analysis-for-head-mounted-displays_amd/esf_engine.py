@@ -192,8 +192,10 @@ def build_forward_plan(model, B, H, W, dev, training):
 
     # latent = mean over H*W of the image pass' bottleneck (RITnet_v2.py:282)
     hb, wb = res[4]
-    pl.latent = pl.vec(B, fc)
-    pl.raw(L.egne_spatial_mean, (bott.data_ptr(), bott.shape[-1], 0, fc, B, hb * wb, pl.latent.data_ptr()), "latent")
+    fcp = pad8(fc)
+    pl.latent_p = pl.buf(B, 1, 1, fcp)   # padded row stride so that it can feed a 1x1 conv directly
+    pl.raw(L.egne_spatial_mean, (bott.data_ptr(), bott.shape[-1], 0, fcp, B, hb * wb, pl.latent_p.data_ptr()), "latent")
+    pl.latent = pl.latent_p.view(B, fcp)[:, :fc]
 
     # ---- decoder on B samples ---------------------------------------------------------------------
     xb = [Piece(bott, 0, fc)] + ([Piece(bott, 0, fc, n0=B)] if add_edge else [])
@@ -246,7 +248,49 @@ def build_forward_plan(model, B, H, W, dev, training):
         _train_bn(pl, dec.final.bn, Piece(opb, 0, 3), 0, B, H * W, "dec.final.bn")
 
     if variant == "v2" and st["add_seg"] == 1:
-        raise NotImplementedError("AdaIN fusion path (add_seg=1) is not built yet")
+        # ---- AdaIN fusion (RITnet_v2.py:289-308): softmax(op) -> StyleEncoder -> MLP -> modulate bottleneck ----
+        from .engine import ACT_RELU
+        sm = pl.buf(B, H, W, 8)
+        pl.raw(L.egne_softmax3, (opb.data_ptr(), 8, 0, sm.data_ptr(), 8, 0, 8, B * H * W), "adain.softmax")
+        se = model.seg_encoder.model
+        cur, cc, ch, cw = Piece(sm, 0, 3), 3, H, W
+        for i in range(5):
+            blk = se[i]
+            k = blk.conv.kernel_size[0]
+            l = ConvLayer([blk.conv.weight], [blk.conv.bias], [(cc, pad8(cc))], stride=blk.conv.stride[0],
+                          pad=(blk.padding, blk.padding), act=ACT_RELU, pad_mode=1)
+            oh, ow = l.out_hw(ch, cw)
+            ob = pl.buf(B, oh, ow, pad8(l.Cout))
+            pl.conv(l, [cur], Piece(ob, 0, l.Cout), B, ch, cw, name="adain.enc%d" % i)
+            cur, cc, ch, cw = Piece(ob, 0, l.Cout), l.Cout, oh, ow
+        gap = pl.buf(B, 1, 1, pad8(cc))
+        pl.raw(L.egne_spatial_mean, (cur.ptr, cur.stride, cur.off, cur.Cp, B, ch * cw, gap.data_ptr()), "adain.gap")
+        l = ConvLayer([se[6].weight], [se[6].bias], [(cc, pad8(cc))])
+        sty = pl.buf(B, 1, 1, pad8(l.Cout))
+        pl.conv(l, [Piece(gap, 0, cc)], Piece(sty, 0, l.Cout), B, 1, 1, name="adain.style")
+        cur, cc = Piece(sty, 0, l.Cout), l.Cout
+        mlp = model.mlp.model
+        for i in range(len(mlp)):
+            fcm = mlp[i].fc
+            l = ConvLayer([fcm.weight], [fcm.bias], [(cc, pad8(cc))], kernel_hw=(1, 1),
+                          act=ACT_RELU if mlp[i].activation_name == "relu" else ACT_NONE)
+            ob = pl.buf(B, 1, 1, pad8(l.Cout))
+            pl.conv(l, [cur], Piece(ob, 0, l.Cout), B, 1, 1, name="adain.mlp%d" % i)
+            cur, cc = Piece(ob, 0, l.Cout), l.Cout
+        nfc = fc * len(xb)
+        assert cc == 2 * nfc, (cc, nfc)
+        xa = pl.buf(B, hb, wb, pad8(fc) * len(xb))
+        mod = []
+        for j, pc in enumerate(xb):
+            q = Piece(xa, j * pad8(fc), fc)
+            pl.raw(L.egne_adain, (pc.ptr, pc.stride, pc.off, fc, cur.ptr, cur.ptr, cur.stride, 0, q.ptr, q.stride, q.off,
+                                  B, hb * wb, 1e-5), "adain.apply")
+            # gamma = adain_params[:,0] (first nfc), beta = adain_params[:,1] (next nfc)
+            fn, args, nm = pl.calls[-1]
+            pl.calls[-1] = (fn, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.ptr + 4 * (nfc + j * fc),
+                                 cur.stride, 0, q.ptr, q.stride, q.off, B, hb * wb, 1e-5), nm)
+            mod.append(q)
+        xb = mod
 
     # ---- regression module (utils.py:983-1037) ------------------------------------------------------
     rg = model.elReg
@@ -306,4 +350,17 @@ def build_forward_plan(model, B, H, W, dev, training):
     ld.mask, ld.op_nchw = pl.mask.data_ptr(), pl.op.data_ptr()
     pl.loss_desc = ld
     pl.raw(L.egne_loss_fwd, (C.byref(ld),), "loss")
+
+    # ---- dataset-confusion head (RITnet_v2.py:343-350; loss.py:139-157) -------------------------------
+    pl.t_id = pl.vec(B, dtype=torch.int64)
+    if model.disentangle and variant == "v2":
+        lins = model.dsIdentify_lin.layersLin
+        cur, cc = Piece(pl.latent_p, 0, fc), fc
+        for i, lin in enumerate(lins):   # actBool=False, dropout 0: plain linear stack (utils.py:953-981)
+            l = ConvLayer([lin.weight], [lin.bias] if lin.bias is not None else None, [(cc, pad8(cc))], kernel_hw=(1, 1))
+            ob = pl.buf(B, 1, 1, pad8(l.Cout))
+            pl.conv(l, [cur], Piece(ob, 0, l.Cout), B, 1, 1, name="dsIdentify.lin%d" % i)
+            cur, cc = Piece(ob, 0, l.Cout), l.Cout
+        pl.raw(L.egne_conf_loss, (cur.ptr, cur.stride, pl.t_id.data_ptr(), B, cc, 1 if model.toggle else 0,
+                                  float(model.disentangle_alpha), pl.terms.data_ptr()), "conf_loss")
     return pl

@@ -156,7 +156,7 @@ class DenseNet2D(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _plan(self, B, H, W, dev):
-        key = (B, H, W, dev, bool(self.training))
+        key = (B, H, W, dev, bool(self.training), bool(self.disentangle), bool(self.toggle))
         if key not in self._plans:
             self._plans[key] = build_forward_plan(self, B, H, W, dev, bool(self.training))
         return self._plans[key]
@@ -183,10 +183,10 @@ class DenseNet2D(nn.Module):
         pl.t_dist.copy_(distMap)
         pl.t_cond.copy_(cond)
         pl.loss_desc.alpha = float(alpha)
+        if self.disentangle and torch.is_tensor(ID):
+            pl.t_id.copy_(ID.to(torch.long))
         pl.run(self._events)
         loss = pl.terms[0:1].clone()
-        if self.disentangle:
-            raise NotImplementedError("dataset-confusion head is not built yet")
         return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), loss, pl.elOut.clone()
 
     def predictions(self):

@@ -211,6 +211,23 @@ int egne_selu_inplace(float* x, int64_t n, void* stream);
 int egne_spatial_mean(const float* x, int64_t pix_stride, int ch_off, int C, int B, int HW,
                       float* out, void* stream);
 
+/* AdaIN fusion path (models/RITnet_v2.py:289-308).  egne_softmax3: nn.Softmax(dim=1) over the 3 logits
+ * of every pixel into an NHWC slice of Cp_out channels (zero padded) that feeds the StyleEncoder.
+ * egne_adain: calc_mean_std (:251-259, UNBIASED variance + eps) and
+ * x' = (x-mean)/std * gamma[n][c] + beta[n][c]; gamma/beta are rows of the MLP output
+ * (element [n*gb_stride + gb_off + c]). */
+int egne_softmax3(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp_out,
+                  int64_t npix, void* stream);
+int egne_adain(const float* x, int64_t xs, int xo, int C, const float* gamma, const float* beta,
+               int64_t gb_stride, int gb_off, float* y, int64_t ys, int yo, int B, int HW, float eps,
+               void* stream);
+
+/* conf_Loss (loss.py:139-157) on pred [B,C] (row stride ld).  flag=1: conf = mean|softmax - 1/C| and
+ * terms[0] += weight*conf (RITnet_v2.py:345-347); flag=0: conf = cross-entropy(pred, gt) and
+ * terms[0] = conf (:348-350).  terms[7] = conf.  Runs after egne_loss_fwd on the same stream. */
+int egne_conf_loss(const float* pred, int ld, const int64_t* gt, int B, int C, int flag, float weight,
+                   float* terms, void* stream);
+
 /*
  * Ellipse fit of evaluate.py (utils.py:450-486 search_proper_parameter_iou_for_our_data with
  * calc_ell_iou utils.py:176-204 and the conic algebra of helperfunctions.py:13-63,102-129):

@@ -76,7 +76,7 @@ def test_calc_edge_threshold(bdcn):
 
 
 ESF_GPU_CASES = ["esf_edge_b2", "esf_baseline_b2", "esf_input_concat_b2", "esf_only_edge_b2", "esf_concat_b2",
-                 "esf_edge_b2_absent1", "esf_edge_b2_absent_all"]
+                 "esf_edge_b2_absent1", "esf_edge_b2_absent_all", "esf_adain_edge_b2", "esf_adain_b2"]
 
 
 @pytest.mark.parametrize("name", ESF_GPU_CASES)
@@ -121,6 +121,28 @@ def test_esf_b1_as_evaluate_calls_it(bdcn):
     assert np.abs(op.cpu()[:, :, ::4, ::4].numpy() - g["op"]).max() < TOL
     np.testing.assert_allclose(elPred.cpu().numpy().reshape(g["elPred"].shape), g["elPred"], atol=TOL)
     np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-3)
+
+
+def test_esf_disentangle_conf_loss(edge_of):
+    """--disentangle 1 (train.py default): loss += 2*conf_Loss(dsIdentify_lin(latent)); and the
+    toggle=False branch where the loss IS the cross-entropy of the dataset head."""
+    from common import batch_args, esf_module, gold, setting
+    from oracle import esfnet as oesf
+    import torch.nn.functional as F
+    g = gold("esf_edge_disent_b2")
+    b, edge = edge_of(B=2, seed=1234)
+    m = esf_module("baseline_edge", disentangle=True).to(DEV).eval()
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    with torch.no_grad():
+        out = m(*args)
+        np.testing.assert_allclose(out[3].cpu().numpy(), g["loss"], rtol=1e-3)
+        m.toggle = False
+        out2 = m(*args)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    lat = out2[2].cpu()
+    pd = F.linear(F.linear(lat, sd["dsIdentify_lin.layersLin.0.weight"], sd["dsIdentify_lin.layersLin.0.bias"]),
+                  sd["dsIdentify_lin.layersLin.1.weight"], sd["dsIdentify_lin.layersLin.1.bias"])
+    np.testing.assert_allclose(out2[3].item(), F.cross_entropy(pd, b["ID"]).item(), rtol=1e-3)
 
 
 def test_esf_vs_oracle_fresh_seed(edge_of):
