@@ -48,7 +48,7 @@ class LossDesc(C.Structure):
                 ("pupil_center", c_fp), ("elNorm", c_fp), ("elOut", c_fp), ("alpha", C.c_float),
                 ("grid_x", c_fp), ("grid_y", c_fp),
                 ("partials", c_fp), ("out_terms", c_fp), ("pred_c", c_fp), ("elPred", c_fp),
-                ("mask", c_fp), ("op_nchw", c_fp)]
+                ("mask", c_fp), ("op_nchw", c_fp), ("coef", c_fp)]
 
 
 # name -> (restype, argtypes); every symbol include/egne_hip.h declares
@@ -62,6 +62,7 @@ SIGNATURES = {
     "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "egne_norm_stats": (i32, [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "egne_affine_inplace": (i32, [vp, i64, i32, i32, i64, vp, vp, vp]),
+    "egne_affine": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_avgpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_maxpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
@@ -77,6 +78,22 @@ SIGNATURES = {
     "egne_softmax3": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp]),
     "egne_adain": (i32, [vp, i64, i32, i32, vp, vp, i64, i32, vp, i64, i32, i32, i32, f32, vp]),
     "egne_conf_loss": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp]),
+    "egne_loss_bwd": (i32, [C.POINTER(LossDesc), vp, vp, i64, i32, vp, vp]),
+    "egne_act_bwd_bias_workspace_bytes": (i64, [i64, i32]),
+    "egne_act_bwd_bias": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp]),
+    "egne_norm_bwd_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "egne_norm_bwd": (i32, [vp, i64, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp,
+                            i32, vp, vp]),
+    "egne_avgpool2_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_upsample2x_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_ellipse_head_act_bwd": (i32, [vp, vp, i32, i32, vp]),
+    "egne_selu_bwd": (i32, [vp, vp, i64, vp]),
+    "egne_spatial_mean_bwd": (i32, [vp, i32, vp, i64, i32, i32, i32, i32, vp]),
+    "egne_conf_loss_bwd": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, i32, vp]),
+    "egne_conv2d_wgrad_splits": (i32, [C.POINTER(ConvDesc)]),
+    "egne_conv2d_wgrad_workspace_bytes": (i64, [C.POINTER(ConvDesc)]),
+    "egne_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, i64, i32, i32, i32, vp, C.POINTER(vp), vp, vp]),
+    "egne_pack_conv_weight_dgrad": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "egne_ellipse_fit": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "egne_last_error": (C.c_char_p, []),
     "egne_version": (i32, []),

@@ -1,0 +1,648 @@
+// Backward kernels of ESF-Net (BDCN is frozen: train.py:129, utils.py:646).  Data gradients of the
+// convolutions reuse the forward MFMA kernels with flipped / transposed weight packs
+// (egne_pack_conv_weight_dgrad); this file holds the weight-gradient GEMM, the loss-head gradient
+// and the HBM-bound elementwise / reduction backward ops.  Everything is deterministic (two-stage
+// reductions, no atomics).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss head backward (models/RITnet_v2.py:372-432, loss.py:16-137): d total / d logits, d total / d elOut
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
+
+__global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const float* __restrict__ gscale_p,
+                                                  float* __restrict__ g_logits, long long gs, int go,
+                                                  float* __restrict__ g_elOut) {
+  const float gscale = gscale_p[0];
+  const int b = blockIdx.y;
+  const int HW = d.H * d.W;
+  const float* cf = d.coef + b * 32;
+  const float nmask = d.out_terms[5];
+  const float mp = cf[0];
+  const float segw = (mp == 1.f && nmask > 0.f) ? 20.f * gscale / nmask : 0.f;
+  const float A = cf[4], Bq = cf[5], dact = cf[6], msw = cf[7];
+  const float cpx = cf[8], cpy = cf[9], cix = cf[10], ciy = cf[11];
+  const float pm = cf[12], ps = cf[13], im = cf[14], is = cf[15];
+  const float spx = sgn(cpx - cf[16]), spy = sgn(cpy - cf[17]);
+  const float six = sgn(cix - d.elNorm[b * 10 + 0]), siy = sgn(ciy - d.elNorm[b * 10 + 1]);
+  const float kp = gscale * 0.5f / (2.f * (float)d.B) * 4.f;
+  const float ki = (nmask > 0.f) ? gscale * 0.5f * mp / (2.f * nmask) * (-4.f) : 0.f;
+  const float fHW = (float)HW;
+  const long long base = (long long)b * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const float* lp = d.logits + (base + p) * d.pix_stride + d.ch_off;
+    const float l0 = lp[0], l1 = lp[1], l2 = lp[2];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (segw != 0.f) {
+      const int t = (int)d.target[base + p];
+      const float mx = fmaxf(l0, fmaxf(l1, l2));
+      const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+      const float inv = 1.f / (e0 + e1 + e2);
+      const float pr[3] = {e0 * inv, e1 * inv, e2 * inv};
+      float u[3], dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float tc = (t == c) ? 1.f : 0.f;
+        u[c] = d.alpha * d.distMap[((long long)b * 3 + c) * HW + p] / (3.f * fHW)
+             - (1.f - d.alpha) * dact * 2.f * cf[1 + c] * (tc * Bq - A) / (Bq * Bq);
+        dot += pr[c] * u[c];
+      }
+      const float ce = msw / fHW;
+      g0 = segw * (pr[0] * (u[0] - dot) + ce * (pr[0] - (t == 0 ? 1.f : 0.f)));
+      g1 = segw * (pr[1] * (u[1] - dot) + ce * (pr[1] - (t == 1 ? 1.f : 0.f)));
+      g2 = segw * (pr[2] * (u[2] - dot) + ce * (pr[2] - (t == 2 ? 1.f : 0.f)));
+    }
+    const int y = p / d.W, x = p - y * d.W;
+    const float gx = d.grid_x[x], gy = d.grid_y[y];
+    const float wp = expf(4.f * l2 - pm) / ps;
+    g2 += kp * wp * (spx * (gx - cpx) + spy * (gy - cpy));
+    if (ki != 0.f) {
+      const float wi = expf(-4.f * l0 - im) / is;
+      g0 += ki * wi * (six * (gx - cix) + siy * (gy - ciy));
+    }
+    float* o = g_logits + (base + p) * gs + go;
+    o[0] = g0; o[1] = g1; o[2] = g2;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 10) {
+    const int j = threadIdx.x;
+    const float nabs = (float)d.B - nmask;
+    float g = 0.f;
+    if (mp == 1.f) {
+      if (nmask > 0.f) g = gscale * sgn(d.elOut[b * 10 + j] - d.elNorm[b * 10 + j]) / nmask;   // 10 * (1/10) / nmask
+    } else if (j == 5 || j == 6) {
+      g = 10.f * gscale * sgn(d.elOut[b * 10 + j] - cf[16 + (j - 5)]) / (2.f * nabs);
+    }
+    g_elOut[b * 10 + j] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gz = gy * act'(y) in place + bias gradient (sum over pixels), two deterministic stages
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ g, long long gs, int go,
+                                                            const float* __restrict__ y, long long ys, int yo, int act,
+                                                            int Cp, long long npix, int nchunk, double* __restrict__ ws) {
+  const int chunk = blockIdx.x, cg = blockIdx.y;
+  const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
+  const int c = cg * 32 + v * 4;
+  const long long per = (npix + nchunk - 1) / nchunk;
+  const long long p0 = (long long)chunk * per, p1 = p0 + per < npix ? p0 + per : npix;
+  double s[4] = {0, 0, 0, 0};
+  if (c < Cp) {
+    for (long long p = p0 + row; p < p1; p += 32) {
+      f32x4* gp = (f32x4*)(g + p * gs + go + c);
+      f32x4 t = *gp;
+      if (act != EGNE_ACT_NONE) {
+        const f32x4 yy = *(const f32x4*)(y + p * ys + yo + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = yy[e] > 0.f ? t[e] : (act == EGNE_ACT_LEAKY ? 0.01f * t[e] : 0.f);
+        *gp = t;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += t[e];
+    }
+  }
+  __shared__ double sh[32][8][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sh[row][v][e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int vv = threadIdx.x >> 2, e = threadIdx.x & 3;
+    double a = 0;
+    for (int r = 0; r < 32; ++r) a += sh[r][vv][e];
+    const int cc = cg * 32 + vv * 4 + e;
+    if (cc < Cp) ws[(long long)chunk * Cp + cc] = a;
+  }
+}
+
+__global__ void reduce_chunks_k(const double* __restrict__ ws, int stride, int n, int nchunk, float* __restrict__ out,
+                                int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int k = 0; k < nchunk; ++k) s += ws[(long long)k * stride + i];
+  out[i] = accumulate ? out[i] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm / BatchNorm backward.  xh = x*scale + shift (scale = rstd, shift = -mean*rstd);
+// g = gy * act'(xh) [* gamma];  gx += rstd * (g - mean(g) - xh * mean(g*xh));  dgamma = sum gy*xh, dbeta = sum gy
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_bwd_partial(const float* __restrict__ x, long long xs, int xo,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ gy, long long gs, int go, int act_in,
+                                                        int Cp, long long npix_per_n, int nchunk, int per_sample,
+                                                        double* __restrict__ ws) {
+  const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
+  const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
+  const int c = cg * 32 + v * 4;
+  const long long per = (npix_per_n + nchunk - 1) / nchunk;
+  const long long p0 = (long long)chunk * per, p1 = p0 + per < npix_per_n ? p0 + per : npix_per_n;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (c < Cp) {
+    const f32x4 sc = *(const f32x4*)(scale + (long long)(per_sample ? n : 0) * Cp + c);
+    const f32x4 sh = *(const f32x4*)(shift + (long long)(per_sample ? n : 0) * Cp + c);
+    const long long nb = (long long)n * npix_per_n;
+    for (long long p = p0 + row; p < p1; p += 32) {
+      const f32x4 xv = *(const f32x4*)(x + (nb + p) * xs + xo + c);
+      f32x4 g = *(const f32x4*)(gy + (nb + p) * gs + go + c);
+      const f32x4 xh = xv * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
+        else if (act_in == EGNE_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+        s1[e] += g[e]; s2[e] += (double)g[e] * xh[e];
+      }
+    }
+  }
+  __shared__ double sh_[32][8][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sh_[row][v][e] = s1[e]; sh_[row][v][4 + e] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int vv = threadIdx.x >> 3, e = threadIdx.x & 7;
+    double a = 0;
+    for (int r = 0; r < 32; ++r) a += sh_[r][vv][e];
+    const int cc = cg * 32 + vv * 4 + (e & 3);
+    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + (e >> 2)] = a;
+  }
+}
+
+__global__ void norm_bwd_final(const double* __restrict__ ws, int Cp, int Bn, int nchunk, float* __restrict__ sums,
+                               float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bn * Cp) return;
+  const int n = i / Cp, c = i - n * Cp;
+  double a = 0, b = 0;
+  for (int k = 0; k < nchunk; ++k) {
+    const double* w = ws + (((long long)n * nchunk + k) * Cp + c) * 2;
+    a += w[0]; b += w[1];
+  }
+  sums[2 * i] = (float)a; sums[2 * i + 1] = (float)b;
+  if (dgamma && c < C) { dgamma[c] += (float)b; dbeta[c] += (float)a; }   // Bn == 1 for BatchNorm
+}
+
+__global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
+                               const float* __restrict__ shift, const float* __restrict__ gamma,
+                               const float* __restrict__ gy, long long gs, int go, int act_in, int Cp,
+                               long long npix_per_n, int Bn, int per_sample, const float* __restrict__ sums,
+                               float* __restrict__ gx, long long gxs, int gxo) {
+  const int nv = Cp >> 2;
+  const long long total = (long long)Bn * npix_per_n * nv;
+  const float invN = 1.f / (float)npix_per_n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    const long long pp = i / nv;               // global pixel index over (n, p)
+    const int n = per_sample ? (int)(pp / npix_per_n) : 0;
+    const f32x4 sc = *(const f32x4*)(scale + (long long)n * Cp + c);
+    const f32x4 sh = *(const f32x4*)(shift + (long long)n * Cp + c);
+    const f32x4 xv = *(const f32x4*)(x + pp * xs + xo + c);
+    f32x4 g = *(const f32x4*)(gy + pp * gs + go + c);
+    const f32x4 xh = xv * sc + sh;
+    f32x4* dst = (f32x4*)(gx + pp * gxs + gxo + c);
+    f32x4 o = *dst;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
+      else if (act_in == EGNE_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+      const float gm = gamma ? gamma[c + e] : 1.f;
+      const float m1 = sums[2 * ((long long)n * Cp + c + e)] * invN, m2 = sums[2 * ((long long)n * Cp + c + e) + 1] * invN;
+      o[e] += sc[e] * gm * (g[e] - m1 - xh[e] * m2);
+    }
+    *dst = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void avgpool2_bwd_k(const float* __restrict__ gy, long long gs, int go, float* __restrict__ gx, long long xs,
+                               int xo, int B, int H, int W, int Cp) {
+  const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
+  const long long total = (long long)B * Ho * Wo * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    f32x4 g = *(const f32x4*)(gy + (((long long)b * Ho + oy) * Wo + ox) * gs + go + c);
+    g = g * 0.25f;
+    float* d = gx + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
+    *(f32x4*)d += g; *(f32x4*)(d + xs) += g;
+    *(f32x4*)(d + (long long)W * xs) += g; *(f32x4*)(d + (long long)W * xs + xs) += g;
+  }
+}
+
+// transpose of F.interpolate(bilinear, x2, align_corners=False): gather over the <=4x4 output pixels
+__device__ __forceinline__ int up_taps(int y, int H, int* oy, float* w) {
+  int n = 0;
+  if (y >= 1) { oy[n] = 2 * y - 1; w[n++] = 0.25f; }
+  oy[n] = 2 * y; w[n++] = (y == 0) ? 1.0f : 0.75f;
+  oy[n] = 2 * y + 1; w[n++] = (y == H - 1) ? 1.0f : 0.75f;
+  if (y + 1 <= H - 1) { oy[n] = 2 * y + 2; w[n++] = 0.25f; }
+  return n;
+}
+__global__ void upsample2x_bwd_k(const float* __restrict__ gy, long long gs, int go, float* __restrict__ gx, long long xs,
+                                 int xo, int B, int H, int W, int Cp) {
+  const int nv = Cp >> 2, Wo = 2 * W, Ho = 2 * H;
+  const long long total = (long long)B * H * W * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    int oys[4], oxs[4]; float wy[4], wx[4];
+    const int ny = up_taps(y, H, oys, wy), nx = up_taps(x, W, oxs, wx);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+      for (int q = 0; q < nx; ++q)
+        acc += (wy[a] * wx[q]) * *(const f32x4*)(gy + (((long long)b * Ho + oys[a]) * Wo + oxs[q]) * gs + go + c);
+    *(f32x4*)(gx + (((long long)b * H + y) * W + x) * xs + xo + c) += acc;
+  }
+}
+
+__global__ void head_act_bwd_k(float* __restrict__ g, const float* __restrict__ y, int B, int ld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 10) return;
+  const int b = i / 10, j = i - b * 10, k = j % 5;
+  const float v = y[(long long)b * ld + j];
+  float d = 1.f;
+  if (k < 2) d = 1.f - v * v; else if (k < 4) d = v * (1.f - v);
+  g[(long long)b * ld + j] *= d;
+}
+
+__global__ void selu_bwd_k(float* __restrict__ g, const float* __restrict__ y, long long n) {
+  const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    g[i] *= y[i] > 0.f ? scale : y[i] + scale * alpha;
+}
+
+__global__ void spatial_mean_bwd_k(const float* __restrict__ g, int gld, float* __restrict__ gx, long long xs, int xo,
+                                   int C, int HW) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / (float)HW;
+  for (long long i = threadIdx.x; i < (long long)HW * C; i += blockDim.x) {
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    gx[((long long)b * HW + p) * xs + xo + c] += g[(long long)b * gld + c] * inv;
+  }
+}
+
+// d(weight * mean|softmax(x) - 1/C|)/dx  (loss.py:150) or d CE/dx (:153)
+__global__ void conf_loss_bwd_k(const float* __restrict__ x, int ld, const long long* __restrict__ gt, int B, int C, int flag,
+                                const float* __restrict__ gscale_p, float* __restrict__ gx, int gld) {
+  const float gscale = gscale_p[0];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* r = x + (long long)b * ld;
+  float m = -INFINITY;
+  for (int k = 0; k < C; ++k) m = fmaxf(m, r[k]);
+  float se = 0.f;
+  for (int k = 0; k < C; ++k) se += expf(r[k] - m);
+  if (flag) {
+    float dot = 0.f;
+    for (int k = 0; k < C; ++k) { const float p = expf(r[k] - m) / se; dot += p * sgn(p - 1.0f / C); }
+    for (int k = 0; k < C; ++k) {
+      const float p = expf(r[k] - m) / se;
+      gx[(long long)b * gld + k] = gscale / (float)(B * C) * p * (sgn(p - 1.0f / C) - dot);
+    }
+  } else {
+    for (int k = 0; k < C; ++k)
+      gx[(long long)b * gld + k] = gscale / (float)B * (expf(r[k] - m) / se - (gt[b] == k ? 1.f : 0.f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[tap][co][k] = sum over pixels gz[m][co] * xin[m shifted by tap][k]  (k over the padded
+// concatenated input channels, with the same fused load transform as the forward conv).
+// One workgroup = one 32(co) x 32(k) tile over a pixel range; the 4 waves split each 32-pixel chunk
+// (K-split) and are reduced through LDS at the end.  Partials go to ws[split][tap][CoutP][Ktot].
+// ------------------------------------------------------------------------------------------------
+constexpr int WPX = 32;   // pixels per chunk
+constexpr int WLD = 33;   // LDS row pitch (floats): lanes read consecutive floats of one pixel row
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p, const float* __restrict__ gz, long long gzs,
+                                                         int gzo, int nsplit, float* __restrict__ ws) {
+  __shared__ float As[WPX * WLD];   // gz chunk   [pixel][co]
+  __shared__ float Bs[WPX * WLD];   // x chunk    [pixel][k]
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int T = p.kh * p.kw;
+  // column tile -> (group, tap, segment, c0)
+  int ct = blockIdx.z;
+  int seg = 0, kofs = 0, g = 0, tap = 0, c0 = 0;
+  {
+    int per_tap = 0;
+    for (int s = 0; s < p.nseg; ++s) per_tap += (p.seg[s].Cp + 31) / 32;
+    g = ct / (per_tap * T); ct -= g * per_tap * T;
+    tap = ct / per_tap; ct -= tap * per_tap;
+    for (seg = 0; seg < p.nseg; ++seg) {
+      const int n = (p.seg[seg].Cp + 31) / 32;
+      if (ct < n) break;
+      ct -= n; kofs += p.seg[seg].Cp;
+    }
+    c0 = ct * 32;
+  }
+  const egne_seg sg = p.seg[seg];
+  const int co0 = blockIdx.y * 32;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long per = ((M + nsplit - 1) / nsplit + WPX - 1) / WPX * WPX;
+  const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
+  const int dil = p.dil[g];
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+
+  // loader: thread -> (pixel row = tid>>3, float4 column = tid&7) of both 32x32 tiles
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
+  f32x16 acc = (f32x16)(0.f);
+  for (long long mc = m_begin; mc < m_end; mc += WPX) {
+    const long long m = mc + lr;
+    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+    if (m < m_end) {
+      if (co0 + lc < p.Cout_store) av = *(const f32x4*)(gz + m * gzs + gzo + co0 + lc);
+      const int hw = p.Ho * p.Wo;
+      const int b = (int)(m / hw);
+      const int r = (int)(m - (long long)b * hw);
+      const int oy = r / p.Wo, ox = r - oy * p.Wo;
+      int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
+      bool ok = c0 + lc < sg.Cp;
+      if (p.pad_mode == 1) {
+        iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+      } else {
+        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      }
+      if (ok) {
+        bv = *(const f32x4*)(sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + lc);
+        if (sg.scale) {
+          const f32x4 sc = *(const f32x4*)(sg.scale + (long long)b * sg.Cp + c0 + lc);
+          const f32x4 sh = *(const f32x4*)(sg.shift + (long long)b * sg.Cp + c0 + lc);
+          bv = bv * sc + sh;
+        }
+        if (sg.act_in == EGNE_ACT_LEAKY) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = bv[e] > 0.f ? bv[e] : 0.01f * bv[e];
+        } else if (sg.act_in == EGNE_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = fmaxf(bv[e], 0.f);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { As[lr * WLD + lc + e] = av[e]; Bs[lr * WLD + lc + e] = bv[e]; }
+    __syncthreads();
+    // wave w consumes pixel pairs 4w..4w+3 of the chunk: D[co][k] += A[co][px] * B[px][k]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int px = (wave * 4 + s) * 2 + lh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[px * WLD + li], Bs[px * WLD + li], acc, 0, 0, 0);
+    }
+  }
+  // cross-wave reduction; lane holds column k = li of rows co = (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+    float* dst = ws + (((long long)blockIdx.x * p.ngroups + g) * T + tap) * (long long)p.CoutP * p.Ktot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int k = c0 + li;
+      if (k < sg.Cp) dst[(long long)co * p.Ktot + kofs + k] = v;
+    }
+  }
+}
+
+// sum the split partials and add into the OIHW gradient of group g
+__global__ void wgrad_reduce_k(const float* __restrict__ ws, int nsplit, int G, int g, int T, int Cout, int Cin,
+                               const int* __restrict__ kinv, int CoutP, int Ktot, float* __restrict__ gw) {
+  const long long total = (long long)T * CoutP * Ktot;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Ktot);
+    long long q = i / Ktot;
+    const int n = (int)(q % CoutP);
+    const int t = (int)(q / CoutP);
+    const int ci = kinv[k];
+    if (n >= Cout || ci < 0) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += ws[((long long)sp * G + g) * total + i];
+    gw[((long long)n * Cin + ci) * T + t] += s;
+  }
+}
+
+// dgrad pack: forward OIHW w -> weights of the transposed conv for input channels [ci0, ci0+Cpiece):
+// out[tap'][n = ci - ci0][k = co] = w[co][ci][T-1-tap'], flat ([tap][CoutP'][Ktot']) or fragment order.
+__global__ void pack_weight_dgrad_k(const float* __restrict__ w, int Cout, int Cin, int T, int ci0, int Cpiece, int CoutPp,
+                                    int Ktotp, int frag, float* __restrict__ out) {
+  const long long total = (long long)T * CoutPp * Ktotp;
+  const int NT = CoutPp >> 5;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int t, n, k;
+    if (frag) {
+      const int e = (int)(i & 3), nn = (int)((i >> 2) & 31), h = (int)((i >> 7) & 1);
+      long long q = i >> 8;
+      const int nt = (int)(q % NT); q /= NT;
+      const int kg = (int)(q % (Ktotp >> 3));
+      t = (int)(q / (Ktotp >> 3));
+      n = nt * 32 + nn; k = kg * 8 + h * 4 + e;
+    } else {
+      k = (int)(i % Ktotp);
+      long long q = i / Ktotp;
+      n = (int)(q % CoutPp); t = (int)(q / CoutPp);
+    }
+    out[i] = (n < Cpiece && k < Cout) ? w[((long long)k * Cin + ci0 + n) * T + (T - 1 - t)] : 0.f;
+  }
+}
+
+inline bool slice_ok(const void* p, long long stride, int off, int Cp) {
+  return p && ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && off % 4 == 0 && Cp > 0 && Cp % 4 == 0 && off + Cp <= stride;
+}
+int chunks_for(long long npix, int Cp, int Bn) {
+  const int cgroups = (Cp + 31) / 32;
+  long long want = 2048 / ((long long)Bn * cgroups);
+  if (want < 1) want = 1;
+  long long maxchunk = npix / 64 > 0 ? npix / 64 : 1;
+  long long n = want < maxchunk ? want : maxchunk;
+  return (int)(n > 256 ? 256 : n);
+}
+
+}  // namespace
+
+extern "C" int egne_loss_bwd(const egne_loss_desc* dp, const float* gscale, float* g_logits, int64_t gs, int go, float* g_elOut,
+                             void* stream) {
+  EGNE_REQUIRE(dp && g_logits && g_elOut && gscale, "loss_bwd: null pointer");
+  const egne_loss_desc& d = *dp;
+  EGNE_REQUIRE(d.coef && d.grid_x && d.grid_y && d.out_terms, "loss_bwd: forward state (coef/grid) missing");
+  EGNE_REQUIRE(go + 3 <= gs, "loss_bwd: bad gradient slice");
+  const int HW = d.H * d.W;
+  int gx = (HW + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(loss_bwd_k, dim3(gx, d.B), dim3(256), 0, (hipStream_t)stream, d, gscale, g_logits, (long long)gs, go,
+                     g_elOut);
+  return egne::check_launch("egne_loss_bwd");
+}
+
+extern "C" int64_t egne_act_bwd_bias_workspace_bytes(int64_t npix, int Cp) {
+  return (int64_t)chunks_for(npix, Cp, 1) * Cp * sizeof(double);
+}
+
+extern "C" int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
+                                 int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream) {
+  EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && npix > 0 && ws, "act_bwd_bias: bad gradient slice");
+  EGNE_REQUIRE(act == EGNE_ACT_NONE || slice_ok(y, ys, yo, Cp), "act_bwd_bias: bad output slice");
+  const int nchunk = chunks_for(npix, Cp, 1);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(act_bwd_bias_partial, dim3(nchunk, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, y,
+                     (long long)ys, yo, act, Cp, (long long)npix, nchunk, (double*)ws);
+  if (dbias)
+    hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
+                       nchunk, dbias, accumulate);
+  return egne::check_launch("egne_act_bwd_bias");
+}
+
+extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_sample) {
+  const int Bn = per_sample ? B : 1;
+  const long long npix = per_sample ? HW : (long long)B * HW;
+  return (int64_t)Bn * chunks_for(npix, Cp, Bn) * Cp * 2 * sizeof(double);
+}
+
+extern "C" int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                             const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                             int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                             int C, void* ws, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(gy, gs, go, Cp) && slice_ok(gx, gxs, gxo, Cp), "norm_bwd: bad slices");
+  EGNE_REQUIRE(scale && shift && sums && ws && B > 0 && HW > 0, "norm_bwd: null pointer");
+  EGNE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || !per_sample), "norm_bwd: dgamma/dbeta only for batch statistics");
+  const int Bn = per_sample ? B : 1;
+  const long long npix = per_sample ? HW : (long long)B * HW;
+  const int nchunk = chunks_for(npix, Cp, Bn);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(norm_bwd_partial, dim3(nchunk, (Cp + 31) / 32, Bn), dim3(256), 0, st, x, (long long)xs, xo, scale, shift,
+                     gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws);
+  hipLaunchKernelGGL(norm_bwd_final, dim3((Bn * Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
+                     dgamma, dbeta, C);
+  hipLaunchKernelGGL(norm_bwd_apply, dim3(grid_for((long long)Bn * npix * (Cp / 4))), dim3(256), 0, st, x, (long long)xs, xo,
+                     scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,
+                     gxo);
+  return egne::check_launch("egne_norm_bwd");
+}
+
+extern "C" int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
+                                 int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(gy, gs, go, Cp) && slice_ok(gx, xs, xo, Cp) && B > 0 && H >= 2 && W >= 2, "avgpool2_bwd: bad arguments");
+  hipLaunchKernelGGL(avgpool2_bwd_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+                     (hipStream_t)stream, gy, (long long)gs, go, gx, (long long)xs, xo, B, H, W, Cp);
+  return egne::check_launch("egne_avgpool2_bwd");
+}
+
+extern "C" int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
+                                   int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(gy, gs, go, Cp) && slice_ok(gx, xs, xo, Cp) && B > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
+  hipLaunchKernelGGL(upsample2x_bwd_k, dim3(grid_for((long long)B * H * W * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, gy,
+                     (long long)gs, go, gx, (long long)xs, xo, B, H, W, Cp);
+  return egne::check_launch("egne_upsample2x_bwd");
+}
+
+extern "C" int egne_ellipse_head_act_bwd(float* g, const float* y, int B, int ld, void* stream) {
+  EGNE_REQUIRE(g && y && B > 0 && ld >= 10, "head_act_bwd: bad arguments");
+  hipLaunchKernelGGL(head_act_bwd_k, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, y, B, ld);
+  return egne::check_launch("egne_ellipse_head_act_bwd");
+}
+
+extern "C" int egne_selu_bwd(float* g, const float* y, int64_t n, void* stream) {
+  EGNE_REQUIRE(g && y && n > 0, "selu_bwd: bad arguments");
+  hipLaunchKernelGGL(selu_bwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, (long long)n);
+  return egne::check_launch("egne_selu_bwd");
+}
+
+extern "C" int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo, int C, int B, int HW,
+                                     void* stream) {
+  EGNE_REQUIRE(g && gx && C > 0 && xo + C <= xs && gld >= C && B > 0 && HW > 0, "spatial_mean_bwd: bad arguments");
+  hipLaunchKernelGGL(spatial_mean_bwd_k, dim3(B), dim3(256), 0, (hipStream_t)stream, g, gld, gx, (long long)xs, xo, C, HW);
+  return egne::check_launch("egne_spatial_mean_bwd");
+}
+
+extern "C" int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag, const float* gscale,
+                                  float* gpred, int gld, void* stream) {
+  EGNE_REQUIRE(pred && gpred && gscale && B > 0 && C > 0 && ld >= C && gld >= C && (flag || gt), "conf_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(conf_loss_bwd_k, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, ld,
+                     (const long long*)gt, B, C, flag, gscale, gpred, gld);
+  return egne::check_launch("egne_conf_loss_bwd");
+}
+
+extern "C" int egne_conv2d_wgrad_splits(const egne_conv_desc* dp) {
+  if (!dp) return 0;
+  const egne_conv_desc& d = *dp;
+  int per_tap = 0;
+  for (int s = 0; s < d.nseg; ++s) per_tap += (d.seg[s].Cp + 31) / 32;
+  const long long tiles = (long long)(d.CoutP / 32) * per_tap * d.kh * d.kw * d.ngroups;
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  long long ns = 4096 / (tiles > 0 ? tiles : 1);
+  if (ns < 1) ns = 1;
+  const long long mx = (M + 1023) / 1024;
+  if (ns > mx) ns = mx;
+  if (ns > 512) ns = 512;
+  return (int)ns;
+}
+
+extern "C" int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* dp) {
+  if (!dp) return 0;
+  const egne_conv_desc& d = *dp;
+  return (int64_t)egne_conv2d_wgrad_splits(dp) * d.ngroups * d.kh * d.kw * d.CoutP * d.Ktot * sizeof(float);
+}
+
+// gz: gradient w.r.t. the pre-activation output (Cout_store channels).  gw[g]: OIHW gradient tensors,
+// accumulated into.  kinv as in egne_pack_conv_weight.  ws: egne_conv2d_wgrad_workspace_bytes.
+extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,
+                                 const int32_t* kinv, float* const* gw, void* ws, void* stream) {
+  EGNE_REQUIRE(dp && gz && kinv && gw && ws, "wgrad: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP, "wgrad: bad descriptor");
+  EGNE_REQUIRE(slice_ok(gz, gzs, gzo, d.Cout_store), "wgrad: bad gz slice");
+  int ktot = 0, per_tap = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 && ((uintptr_t)g.ptr & 15) == 0, "wgrad: seg %d", s);
+    ktot += g.Cp; per_tap += (g.Cp + 31) / 32;
+  }
+  EGNE_REQUIRE(ktot == d.Ktot && d.CoutP % 32 == 0 && Cout <= d.CoutP && Cin <= d.Ktot, "wgrad: inconsistent sizes");
+  const int T = d.kh * d.kw, nsplit = egne_conv2d_wgrad_splits(dp);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bytes = (size_t)nsplit * d.ngroups * T * d.CoutP * d.Ktot * sizeof(float);
+  if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
+  dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+  for (int g = 0; g < d.ngroups; ++g) {
+    EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
+    const long long total = (long long)T * d.CoutP * d.Ktot;
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(total)), dim3(256), 0, st, (const float*)ws, nsplit, d.ngroups, g, T, Cout,
+                       Cin, kinv, d.CoutP, d.Ktot, gw[g]);
+  }
+  return egne::check_launch("egne_conv2d_wgrad");
+}
+
+extern "C" int egne_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int kh, int kw, int ci0, int Cpiece,
+                                           int CoutPp, int Ktotp, int frag, float* out, void* stream) {
+  EGNE_REQUIRE(w_oihw && out, "pack_dgrad: null pointer");
+  EGNE_REQUIRE(ci0 >= 0 && Cpiece > 0 && ci0 + Cpiece <= Cin && CoutPp >= Cpiece && CoutPp % 32 == 0 && Ktotp >= Cout && Ktotp % 8 == 0,
+               "pack_dgrad: bad sizes");
+  const long long total = (long long)kh * kw * CoutPp * Ktotp;
+  hipLaunchKernelGGL(pack_weight_dgrad_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kh * kw,
+                     ci0, Cpiece, CoutPp, Ktotp, frag, out);
+  return egne::check_launch("egne_pack_conv_weight_dgrad");
+}

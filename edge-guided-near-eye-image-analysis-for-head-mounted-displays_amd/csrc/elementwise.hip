@@ -64,17 +64,16 @@ __global__ void norm_stats_final(const double* __restrict__ ws, int Cp, int Bn, 
   if (var_out) var_out[i] = (float)var;
 }
 
-__global__ void affine_inplace_k(float* __restrict__ x, long long pix_stride, int ch_off, int Cp, long long npix,
-                                 const float* __restrict__ scale, const float* __restrict__ shift) {
+__global__ void affine_k(const float* x, long long pix_stride, int ch_off, float* y, long long ys, int yo, int Cp,
+                         long long npix, const float* __restrict__ scale, const float* __restrict__ shift) {
   const int nv = Cp >> 2;
   const long long total = npix * nv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long p = i / nv;
     const int c = (int)(i - p * nv) * 4;
-    f32x4* ptr = (f32x4*)(x + p * pix_stride + ch_off + c);
-    f32x4 v = *ptr;
+    const f32x4 v = *(const f32x4*)(x + p * pix_stride + ch_off + c);
     const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
-    *ptr = v * sc + sh;
+    *(f32x4*)(y + p * ys + yo + c) = v * sc + sh;
   }
 }
 
@@ -247,9 +246,17 @@ extern "C" int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, i
 extern "C" int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, const float* scale,
                                    const float* shift, void* stream) {
   EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp) && scale && shift && npix > 0, "affine_inplace: bad arguments");
-  hipLaunchKernelGGL(affine_inplace_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x,
-                     (long long)pix_stride, ch_off, Cp, (long long)npix, scale, shift);
+  hipLaunchKernelGGL(affine_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)pix_stride, ch_off, x, (long long)pix_stride, ch_off, Cp, (long long)npix, scale, shift);
   return egne::check_launch("egne_affine_inplace");
+}
+
+extern "C" int egne_affine(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix,
+                           const float* scale, const float* shift, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp) && scale && shift && npix > 0, "affine: bad arguments");
+  hipLaunchKernelGGL(affine_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x, (long long)xs, xo, y,
+                     (long long)ys, yo, Cp, (long long)npix, scale, shift);
+  return egne::check_launch("egne_affine");
 }
 
 extern "C" int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,

@@ -146,6 +146,12 @@ __global__ __launch_bounds__(256) void loss_final_k(const egne_loss_desc d, int 
     bt[1] += mp;
     d.pred_c[b * 4 + 0] = cix; d.pred_c[b * 4 + 1] = ciy;  // iris first (provisional, see below)
     d.pred_c[b * 4 + 2] = cpx; d.pred_c[b * 4 + 3] = cpy;
+    float* cf = d.coef ? d.coef + b * 32 : nullptr;   // per-sample state for egne_loss_bwd
+    if (cf) {
+      cf[0] = mp; cf[1] = cf[2] = cf[3] = 0.f; cf[4] = 0.f; cf[5] = 1.f; cf[6] = 0.f; cf[7] = a[13] / fHW;
+      cf[8] = cpx; cf[9] = cpy; cf[10] = cix; cf[11] = ciy;
+      cf[12] = pup.m; cf[13] = pup.s; cf[14] = iri.m; cf[15] = iri.s; cf[16] = gpx; cf[17] = gpy;
+    }
     if (mp == 1.f) {
       // SurfaceLoss (loss.py:86-92)
       const float l_sl = ((a[0] / fHW + a[1] / fHW) + a[2] / fHW) / 3.f;
@@ -159,6 +165,10 @@ __global__ __launch_bounds__(256) void loss_final_k(const egne_loss_desc d, int 
         Bq += w * (a[9 + c] + a[3 + c]);
       }
       const float l_gd = 1.f - fmaxf(2.f * A / Bq, 1e-5f);
+      if (cf) {
+        for (int c = 0; c < 3; ++c) cf[1 + c] = a[3 + c] > 0.f ? 1.f / fmaxf(a[3 + c] * a[3 + c], 1e-5f) : 0.f;
+        cf[4] = A; cf[5] = Bq; cf[6] = (2.f * A / Bq > 1e-5f) ? 1.f : 0.f;
+      }
       // wCE (loss.py:123-137): mean(spatWts) * CE_mean; ignore_index is the absent class, which by
       // construction labels no pixel, so CE_mean is the plain mean
       const float l_ce = (a[13] / fHW) * (a[12] / fHW);

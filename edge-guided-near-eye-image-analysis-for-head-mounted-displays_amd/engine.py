@@ -35,12 +35,13 @@ def _ptr(t, elem_off=0):
 class Piece:
     """A channel slice [off, off+Cp) of an NHWC fp32 buffer (optionally starting at sample n0)."""
 
-    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in")
+    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd")
 
     def __init__(self, buf, off, C_, Cp=None, n0=0):
         self.buf, self.off, self.C, self.Cp, self.n0 = buf, int(off), int(C_), int(Cp or pad8(C_)), int(n0)
         self.scale = self.shift = None
         self.act_in = ACT_NONE
+        self.nograd = False
         assert self.off % 4 == 0 and self.Cp % 8 == 0 and self.off + self.Cp <= buf.shape[-1]
 
     @property
@@ -54,7 +55,7 @@ class Piece:
 
     def with_norm(self, scale, shift, act_in=ACT_NONE):
         p = Piece(self.buf, self.off, self.C, self.Cp, self.n0)
-        p.scale, p.shift, p.act_in = scale, shift, act_in
+        p.scale, p.shift, p.act_in, p.nograd = scale, shift, act_in, self.nograd
         return p
 
     def samples(self, n0):
@@ -136,11 +137,59 @@ class ConvLayer:
         return ho, wo
 
 
+class DgradLayer(ConvLayer):
+    """Data gradient of ``fwd`` w.r.t. its input slice ``idx`` as a forward convolution: the weights
+    are the flipped / transposed pack of egne_pack_conv_weight_dgrad, the input is the gradient
+    w.r.t. the pre-activation output (Cout_store channels)."""
+
+    def __init__(self, fwd, idx):
+        assert fwd.stride == 1 and fwd.pad_mode == 0 and fwd.G == 1, "dgrad: stride-1 zero-padded convs only"
+        self.fwd, self.idx = fwd, idx
+        self.ci0 = sum(c for c, _ in fwd.in_layout[:idx])
+        C_, Cp_ = fwd.in_layout[idx]
+        self.weights, self.biases = fwd.weights, None
+        self.in_layout = [(fwd.Cout, fwd.Cout_store)]
+        self.Cout, self.Cin = C_, fwd.Cout
+        self.kh, self.kw = fwd.kh, fwd.kw
+        self.stride, self.pad_mode, self.act = 1, 0, ACT_NONE
+        self.pad = (fwd.kh - 1 - fwd.pad[0], fwd.kw - 1 - fwd.pad[1])
+        self.dils = fwd.dils
+        self.Ktot, self.CoutP, self.Cout_store, self.G = fwd.Cout_store, pad32(C_), Cp_, 1
+        self.wp = self.wf = self.bp = None
+        self.need_flat = self.need_frag = False
+        self._versions, self.post = None, None
+
+    def ensure_packed(self, dev):
+        w = self.weights[0]
+        vers = (w._version, w.data_ptr())
+        have = (self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+        if have and vers == self._versions:
+            return
+        L = _lib.lib()
+        n = self.kh * self.kw * self.CoutP * self.Ktot
+        st = _lib.stream_ptr()
+        wd = w.detach().contiguous()
+        if self.need_flat:
+            if self.wp is None:
+                self.wp = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(L.egne_pack_conv_weight_dgrad(wd.data_ptr(), self.fwd.Cout, self.fwd.Cin, self.kh, self.kw, self.ci0,
+                                                     self.Cout, self.CoutP, self.Ktot, 0, self.wp.data_ptr(), st), "pack_dgrad")
+        if self.need_frag:
+            if self.wf is None:
+                self.wf = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(L.egne_pack_conv_weight_dgrad(wd.data_ptr(), self.fwd.Cout, self.fwd.Cin, self.kh, self.kw, self.ci0,
+                                                     self.Cout, self.CoutP, self.Ktot, 1, self.wf.data_ptr(), st), "pack_dgrad")
+        self._versions = vers
+
+
 class Plan:
     """Buffers + prepared launches for one network at one shape."""
 
-    def __init__(self, device):
+    def __init__(self, device, train=False):
         self.device = device
+        self.train = train  # record a tape of backward emitters while the forward plan is built
+        self.tape = []
+        self.gtwins = {}    # id(forward buffer) -> gradient buffer of the same shape
         self.calls = []     # (fn, desc_or_args tuple, name)
         self.keep = []      # tensors / descriptors that must outlive the plan's calls
         self.layers = []    # ConvLayers to (re)pack before running
@@ -158,6 +207,32 @@ class Plan:
         t = torch.zeros(shape, dtype=dtype, device=self.device)
         self.keep.append(t)
         return t
+
+    # ---- gradients (training plans) ------------------------------------------------------------
+    def gbuf(self, buf):
+        t = self.gtwins.get(id(buf))
+        if t is None:
+            t = torch.zeros_like(buf)
+            self.gtwins[id(buf)] = t
+            self.keep.append(buf)
+        return t
+
+    def gp(self, piece):
+        return Piece(self.gbuf(piece.buf), piece.off, piece.C, piece.Cp, piece.n0)
+
+    def build_backward(self):
+        """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
+        bw = Plan(self.device)
+        bw.fwd = self
+        for emit in reversed(self.tape):
+            emit(bw)
+        self.bw = bw
+        return bw
+
+    def zero_grads(self):
+        ts = list(self.gtwins.values())
+        if ts:
+            torch._foreach_zero_(ts)
 
     # ---- launches ----------------------------------------------------------------------------
     def _add(self, fn, args, name, flops=0.0, kind=None):
@@ -211,7 +286,46 @@ class Plan:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
+        if self.train:
+            self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, d, B, H, W, Ho, Wo, name))
         return Ho, Wo
+
+    def _bw_conv(self, bw, layer, pieces, dst, d, B, H, W, Ho, Wo, name):
+        """Backward of y = act(conv(pieces) + b): mask + bias grad, weight grad, data grads."""
+        L = self.L
+        gy = self.gp(dst)
+        Cs = int(d.Cout_store)
+        npix = B * Ho * Wo
+        ws = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(npix, Cs)) + 7) // 8, dtype=torch.float64)
+        bias = layer.biases[0] if layer.biases is not None else None
+        bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
+                                     bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr()),
+               name + ".act_bwd")
+        w = layer.weights[0]
+        assert layer.G == 1 and w.grad is not None and w.grad.is_contiguous()
+        gw = (C.c_void_p * 1)(w.grad.data_ptr())
+        wsw = bw.vec((int(L.egne_conv2d_wgrad_workspace_bytes(C.byref(d))) + 3) // 4)
+        bw.keep.append(gw)
+        flops = 2.0 * npix * layer.Cout * layer.Cin * layer.kh * layer.kw
+        bw._add(L.egne_conv2d_wgrad, (C.byref(d), gy.ptr, gy.stride, gy.off, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
+                                      gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad")
+        gin = Piece(gy.buf, gy.off, layer.Cout, Cs, gy.n0)
+        for i, pc in enumerate(pieces):
+            if pc.nograd:
+                continue
+            dl = DgradLayer(layer, i)
+            tgt = self.gp(pc)
+            if pc.scale is None:
+                bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=tgt, name=name + ".dgrad%d" % i)
+            else:
+                tmp = bw.buf(B, H, W, pc.Cp)
+                bw.conv(dl, [gin], Piece(tmp, 0, pc.C, pc.Cp), B, Ho, Wo, name=name + ".dgrad%d" % i)
+                sums = bw.vec(B * pc.Cp * 2)
+                wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, H * W, pc.Cp, 1)) + 7) // 8, dtype=torch.float64)
+                bw.raw(L.egne_norm_bwd, (pc.ptr, pc.stride, pc.off, pc.scale.data_ptr(), pc.shift.data_ptr(), None,
+                                         tmp.data_ptr(), tmp.shape[-1], 0, pc.act_in, pc.Cp, B, H * W, 1,
+                                         tgt.ptr, tgt.stride, tgt.off, sums.data_ptr(), None, None, 0, wsn.data_ptr()),
+                       name + ".in_bwd%d" % i)
 
     def norm_stats(self, piece, B, HW, per_sample=True, eps=1e-5, want_moments=False, name="norm_stats"):
         Bn = B if per_sample else 1
@@ -234,6 +348,12 @@ class Plan:
     def avgpool2(self, src, dst, B, H, W, name="avgpool"):
         assert src.Cp == dst.Cp
         self._add(self.L.egne_avgpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name, kind="avgpool2")
+        if self.train:
+            def emit(bw, src=src, dst=dst):
+                gs, gd = self.gp(src), self.gp(dst)
+                bw.raw(self.L.egne_avgpool2_bwd, (gd.ptr, gd.stride, gd.off, gs.ptr, gs.stride, gs.off, B, H, W, src.Cp),
+                       name + ".bwd")
+            self.tape.append(emit)
 
     def maxpool2(self, src, dst, B, H, W, stride, name="maxpool"):
         o = lambda n: min((n - 2 + stride - 1) // stride + 1, (n - 1) // stride + 1)  # noqa: E731
@@ -246,6 +366,12 @@ class Plan:
     def upsample2x(self, src, dst, B, H, W, name="upsample"):
         assert src.Cp == dst.Cp
         self._add(self.L.egne_upsample2x, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name, kind="upsample2x")
+        if self.train:
+            def emit(bw, src=src, dst=dst):
+                gs, gd = self.gp(src), self.gp(dst)
+                bw.raw(self.L.egne_upsample2x_bwd, (gd.ptr, gd.stride, gd.off, gs.ptr, gs.stride, gs.off, B, H, W, src.Cp),
+                       name + ".bwd")
+            self.tape.append(emit)
 
     def raw(self, fn, args, name):
         self._add(fn, args, name, kind=getattr(fn, "__name__", None) or "host")

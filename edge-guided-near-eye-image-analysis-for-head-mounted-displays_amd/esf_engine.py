@@ -69,12 +69,13 @@ class _BNFold:
         self.shift[:c].copy_(bn.bias.detach() - bn.running_mean * s)
 
 
-def _train_bn(pl, bn, piece, n0, B, HW, name):
-    """Training-mode BatchNorm2d over samples [n0, n0+B) of ``piece`` (utils.py:1049):
-    batch statistics -> y = (x-mean)*rstd*gamma + beta in place, running stats updated."""
-    p = piece.samples(n0)
+def _train_bn(pl, bn, pre, dst, n0, B, HW, name):
+    """Training-mode BatchNorm2d over samples [n0, n0+B) (utils.py:1049): batch statistics of ``pre``
+    (the activated conv output, kept for backward) -> dst = (pre-mean)*rstd*gamma + beta; running
+    statistics updated as torch does (momentum 0.1, unbiased variance)."""
+    p, q = pre.samples(n0), dst.samples(n0)
     rstd, nshift, mean, var = pl.norm_stats(p, B, HW, per_sample=False, eps=bn.eps, want_moments=True, name=name + ".stats")
-    sc, sh = pl.vec(piece.Cp), pl.vec(piece.Cp)
+    sc, sh, gpad = pl.vec(pre.Cp), pl.vec(pre.Cp), pl.vec(pre.Cp)
     c = bn.num_features
     n = B * HW
 
@@ -82,6 +83,7 @@ def _train_bn(pl, bn, piece, n0, B, HW, name):
         # tiny [C]-sized bookkeeping on the stream (no sync): affine coefficients + running stats
         with torch.no_grad():
             g = bn.weight.detach()
+            gpad[:c].copy_(g)
             sc[:c].copy_(rstd[0, :c] * g)
             sh[:c].copy_(nshift[0, :c] * g + bn.bias.detach())
             m = bn.momentum
@@ -89,7 +91,19 @@ def _train_bn(pl, bn, piece, n0, B, HW, name):
             bn.running_var.mul_(1 - m).add_(var[0, :c] * (n / max(n - 1, 1)), alpha=m)
             bn.num_batches_tracked.add_(1)
     pl.raw(_PyCall(finish), (), name + ".coef")
-    pl.affine_inplace(p, n, sc, sh, name + ".apply")
+    pl.raw(pl.L.egne_affine, (p.ptr, p.stride, p.off, q.ptr, q.stride, q.off, pre.Cp, n, sc.data_ptr(), sh.data_ptr()),
+           name + ".apply")
+    if pl.train:
+        def emit(bw):
+            L = pl.L
+            gq, gpre = pl.gp(q), pl.gp(p)
+            sums = bw.vec(pre.Cp * 2)
+            ws = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, HW, pre.Cp, 0)) + 7) // 8, dtype=torch.float64)
+            bw.raw(L.egne_norm_bwd, (p.ptr, p.stride, p.off, rstd.data_ptr(), nshift.data_ptr(), gpad.data_ptr(),
+                                     gq.ptr, gq.stride, gq.off, 0, pre.Cp, B, HW, 0, gpre.ptr, gpre.stride, gpre.off,
+                                     sums.data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), c, ws.data_ptr()),
+                   name + ".bwd")
+        pl.tape.append(emit)
 
 
 class _PyCall:
@@ -114,7 +128,7 @@ def build_forward_plan(model, B, H, W, dev, training):
     es = enc_sizes(chz, growth)
     ds = dec_sizes(chz, growth, add_edge, variant)
     fc = es["op"][-1]
-    pl = Plan(dev)
+    pl = Plan(dev, train=training)
     L = pl.L
     pl.dbg = {}
 
@@ -149,17 +163,22 @@ def build_forward_plan(model, B, H, W, dev, training):
 
     t0 = pl.buf(NB, H, W, pad8(chz))
     l = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
-    pl.conv(l, [Piece(xin, 0, in_c, 8)], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
+    xin_p = Piece(xin, 0, in_c, 8)
+    xin_p.nograd = True
+    pl.conv(l, [xin_p], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
     l = _cl(enc.head.conv2, [(chz, pad8(chz))], pad=(1, 1), act=ACT_LEAKY)
     if not training:
         fold = _BNFold(enc.head.bn, l.CoutP, dev)
         pl.pre.append(fold.guard)
         l.post = (fold.scale, fold.shift)
-    pl.conv(l, [Piece(t0, 0, chz)], D[0]["x"], NB, H, W, name="enc.head.conv2")
-    if training:
-        _train_bn(pl, enc.head.bn, D[0]["x"], 0, B, H * W, "enc.head.bn")
+    if not training:
+        pl.conv(l, [Piece(t0, 0, chz)], D[0]["x"], NB, H, W, name="enc.head.conv2")
+    else:
+        pre = pl.buf(NB, H, W, pad8(chz))
+        pl.conv(l, [Piece(t0, 0, chz)], Piece(pre, 0, chz), NB, H, W, name="enc.head.conv2")
+        _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn")
         if add_edge:
-            _train_bn(pl, enc.head.bn, D[0]["x"], B, B, H * W, "enc.head.bn.edge")
+            _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], B, B, H * W, "enc.head.bn.edge")
 
     bott = pl.buf(NB, res[4][0], res[4][1], pad8(fc))
     pl.dbg.update(D=D, bott=bott, t0=t0)
@@ -176,6 +195,8 @@ def build_forward_plan(model, B, H, W, dev, training):
         pl.conv(l, [d["x"], d["x1"]], tp, NB, h, w, name=nm + ".conv21")
         l = _cl(blk.conv22, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
         pl.conv(l, [tp], d["x22"], NB, h, w, name=nm + ".conv22")
+        if training:   # backward needs both 1x1 outputs: no buffer reuse
+            tp = Piece(pl.buf(NB, h, w, pad8(inters[i])), 0, inters[i])
         l = _cl(blk.conv31, _lay([d["x"], d["x1"], d["x22"]]))
         pl.conv(l, [d["x"], d["x1"], d["x22"]], tp, NB, h, w, name=nm + ".conv31")
         l = _cl(blk.conv32, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
@@ -196,6 +217,11 @@ def build_forward_plan(model, B, H, W, dev, training):
     pl.latent_p = pl.buf(B, 1, 1, fcp)   # padded row stride so that it can feed a 1x1 conv directly
     pl.raw(L.egne_spatial_mean, (bott.data_ptr(), bott.shape[-1], 0, fcp, B, hb * wb, pl.latent_p.data_ptr()), "latent")
     pl.latent = pl.latent_p.view(B, fcp)[:, :fc]
+    if training:
+        def emit_latent(bw):
+            gl, gb = pl.gbuf(pl.latent_p), pl.gbuf(bott)
+            bw.raw(L.egne_spatial_mean_bwd, (gl.data_ptr(), fcp, gb.data_ptr(), gb.shape[-1], 0, fcp, B, hb * wb), "latent.bwd")
+        pl.tape.append(emit_latent)
 
     # ---- decoder on B samples ---------------------------------------------------------------------
     xb = [Piece(bott, 0, fc)] + ([Piece(bott, 0, fc, n0=B)] if add_edge else [])
@@ -226,6 +252,8 @@ def build_forward_plan(model, B, H, W, dev, training):
         pl.conv(l, cat, tp, B, h, w, name=nm + ".conv11")
         l = _cl(ub.conv12, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
         pl.conv(l, [tp], x1, B, h, w, name=nm + ".conv12")
+        if training:
+            tp = Piece(pl.buf(B, h, w, pad8(oc)), 0, oc)
         l = _cl(ub.conv21, _lay(cat + [x1]))
         pl.conv(l, cat + [x1], tp, B, h, w, name=nm + ".conv21")
         y = pl.buf(B, h, w, pad8(oc))
@@ -243,9 +271,12 @@ def build_forward_plan(model, B, H, W, dev, training):
         fold = _BNFold(dec.final.bn, l.CoutP, dev)
         pl.pre.append(fold.guard)
         l.post = (fold.scale, fold.shift)
-    pl.conv(l, [Piece(tf, 0, chz)], Piece(opb, 0, 3), B, H, W, name="dec.final.conv2")
-    if training:
-        _train_bn(pl, dec.final.bn, Piece(opb, 0, 3), 0, B, H * W, "dec.final.bn")
+    if not training:
+        pl.conv(l, [Piece(tf, 0, chz)], Piece(opb, 0, 3), B, H, W, name="dec.final.conv2")
+    else:
+        pre = pl.buf(B, H, W, 8)
+        pl.conv(l, [Piece(tf, 0, chz)], Piece(pre, 0, 3), B, H, W, name="dec.final.conv2")
+        _train_bn(pl, dec.final.bn, Piece(pre, 0, 3), Piece(opb, 0, 3), 0, B, H * W, "dec.final.bn")
 
     if variant == "v2" and st["add_seg"] == 1:
         # ---- AdaIN fusion (RITnet_v2.py:289-308): softmax(op) -> StyleEncoder -> MLP -> modulate bottleneck ----
@@ -315,12 +346,20 @@ def build_forward_plan(model, B, H, W, dev, training):
     r5 = pl.buf(B, 1, 1, 256)
     pl.conv(l, [Piece(r4, 0, 32)], Piece(r5, 0, 256), B, h4, w4, name="elReg.l1")
     pl.raw(L.egne_selu_inplace, (r5.data_ptr(), B * 256), "elReg.selu")
+    if training:
+        pl.tape.append(lambda bw: bw.raw(L.egne_selu_bwd, (pl.gbuf(r5).data_ptr(), r5.data_ptr(), B * 256), "elReg.selu.bwd"))
     l = ConvLayer([rg.l2.weight], [rg.l2.bias], [(256, 256)], kernel_hw=(1, 1))
     r6 = pl.buf(B, 1, 1, 16)
     pl.conv(l, [Piece(r5, 0, 256)], Piece(r6, 0, 10, 16), B, 1, 1, name="elReg.l2")
     pl.raw(L.egne_ellipse_head_act, (r6.data_ptr(), B, 16), "elReg.act")
     pl.elOut = pl.vec(B, 10)
     pl.raw(_PyCall(lambda: pl.elOut.copy_(r6.view(B, 16)[:, :10])), (), "elOut.copy")
+    if training:
+        pl.g_elOut = pl.vec(B, 10)
+        pl.tape.append(lambda bw: bw.raw(L.egne_ellipse_head_act_bwd, (pl.gbuf(r6).data_ptr(), r6.data_ptr(), B, 16),
+                                         "elReg.act.bwd"))
+        pl.tape.append(lambda bw: bw.raw(_PyCall(lambda: pl.gbuf(r6).view(B, 16)[:, :10].copy_(pl.g_elOut)), (),
+                                         "elOut.copy.bwd"))
 
     # ---- loss head -----------------------------------------------------------------------------------
     ld = _lib.LossDesc()
@@ -349,7 +388,17 @@ def build_forward_plan(model, B, H, W, dev, training):
     ld.partials, ld.out_terms, ld.pred_c, ld.elPred = part.data_ptr(), pl.terms.data_ptr(), pl.pred_c.data_ptr(), pl.elPred.data_ptr()
     ld.mask, ld.op_nchw = pl.mask.data_ptr(), pl.op.data_ptr()
     pl.loss_desc = ld
+    if training:
+        pl.coef = pl.vec(B, 32)
+        ld.coef = pl.coef.data_ptr()
+        pl.gscale = pl.vec(1)
     pl.raw(L.egne_loss_fwd, (C.byref(ld),), "loss")
+    if training:
+        def emit_loss(bw):
+            go = pl.gbuf(opb)
+            bw.raw(L.egne_loss_bwd, (C.byref(ld), pl.gscale.data_ptr(), go.data_ptr(), go.shape[-1], 0,
+                                     pl.g_elOut.data_ptr()), "loss.bwd")
+        pl.tape.append(emit_loss)
 
     # ---- dataset-confusion head (RITnet_v2.py:343-350; loss.py:139-157) -------------------------------
     pl.t_id = pl.vec(B, dtype=torch.int64)
@@ -363,4 +412,21 @@ def build_forward_plan(model, B, H, W, dev, training):
             cur, cc = Piece(ob, 0, l.Cout), l.Cout
         pl.raw(L.egne_conf_loss, (cur.ptr, cur.stride, pl.t_id.data_ptr(), B, cc, 1 if model.toggle else 0,
                                   float(model.disentangle_alpha), pl.terms.data_ptr()), "conf_loss")
+        if training:
+            if not model.toggle:
+                raise NotImplementedError("toggle=False (secondary dataset loss) has no backward here: the reference "
+                                          "never steps that optimizer (train.py:182-186)")
+            pred = cur
+
+            def emit_conf(bw):
+                gpd = pl.gp(pred)
+                tmp = bw.vec(1)
+                # conf enters the total as alpha*conf; its gradient scale is gscale*alpha
+                bw.raw(_PyCall(lambda: tmp.copy_(pl.gscale * float(model.disentangle_alpha))), (), "conf.scale")
+                bw.raw(L.egne_conf_loss_bwd, (pred.ptr, pred.stride, pl.t_id.data_ptr(), B, cc, 1, tmp.data_ptr(),
+                                                gpd.ptr, gpd.stride), "conf_loss.bwd")
+            # tape order: the conf-loss emitter must run BEFORE the linear layers' backward, i.e. be appended last
+            pl.tape.append(emit_conf)
+    if training:
+        pl.build_backward()
     return pl

@@ -102,6 +102,33 @@ class DenseNet_decoder(nn.Module):
         self.final = convBlock(chz, chz, out_c, actfunc)
 
 
+class _ESFFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward replays the launch plan, backward replays the
+    reversed tape.  Parameter gradients are written straight into ``p.grad`` (views of one flat
+    arena, ready for a single RCCL all-reduce), so nothing is returned for them."""
+
+    @staticmethod
+    def forward(ctx, model, pl, dummy):
+        ctx.set_materialize_grads(False)
+        ctx.model, ctx.pl = model, pl
+        pl.run(model._events)
+        return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), pl.terms[0:1].clone(), pl.elOut.clone()
+
+    @staticmethod
+    def backward(ctx, g_op, g_elPred, g_latent, g_loss, g_elOut):
+        if any(g is not None for g in (g_op, g_elPred, g_latent, g_elOut)):
+            raise NotImplementedError("the HIP path back-propagates the returned loss only (train.py:285-286 calls "
+                                      "loss.backward()); gradients w.r.t. op / elPred / latent / elOut are not built")
+        if g_loss is None:
+            return None, None, None
+        model, pl = ctx.model, ctx.pl
+        model._ensure_grad_arena()
+        pl.zero_grads()
+        pl.gscale.copy_(g_loss.reshape(1))
+        pl.bw.run(model._events)
+        return None, None, None
+
+
 class DenseNet2D(nn.Module):
     variant = "v2"
 
@@ -155,6 +182,26 @@ class DenseNet2D(nn.Module):
                 m.bias.data.zero_()
 
     # ------------------------------------------------------------------------------------------
+    def _ensure_grad_arena(self):
+        """All parameter gradients live in ONE flat fp32 buffer (``self._grad_flat``); ``p.grad`` are views.
+        Re-attaches views dropped by ``optimizer.zero_grad(set_to_none=True)`` (zeroing them first)."""
+        params = [p for p in self.parameters()]
+        dev = params[0].device
+        sig = tuple((id(p), p.numel()) for p in params) + (dev,)
+        if getattr(self, "_grad_sig", None) != sig:
+            self._grad_flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            self._grad_views, o = [], 0
+            for p in params:
+                self._grad_views.append(self._grad_flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
+            self._grad_sig = sig
+            self._plans = {k: v for k, v in self._plans.items() if not k[4]}  # training plans hold grad pointers
+        for p, v in zip(params, self._grad_views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                v.zero_()
+                p.grad = v
+        return self._grad_flat
+
     def _plan(self, B, H, W, dev):
         key = (B, H, W, dev, bool(self.training), bool(self.disentangle), bool(self.toggle))
         if key not in self._plans:
@@ -168,8 +215,12 @@ class DenseNet2D(nn.Module):
         else:
             assert self.setting["add_edge"] == 1
         require_cuda(x, "x")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("backward of the HIP path is not built yet; call under torch.no_grad()")
+        want_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
+        if want_grad:
+            if self.variant == "v2" and self.setting["add_seg"] == 1:
+                raise NotImplementedError("backward through the AdaIN fusion path (stride-2 reflect-padded StyleEncoder) "
+                                          "is not built yet")
+            self._ensure_grad_arena()
         if self.selfCorr:
             raise NotImplementedError("selfCorr is disabled in the reference pipeline (--selfCorr 0, args.py:41)")
         B, _, H, W = x.shape
@@ -185,6 +236,10 @@ class DenseNet2D(nn.Module):
         pl.loss_desc.alpha = float(alpha)
         if self.disentangle and torch.is_tensor(ID):
             pl.t_id.copy_(ID.to(torch.long))
+        if want_grad:
+            if getattr(self, "_dummy", None) is None or self._dummy.device != x.device:
+                self._dummy = torch.zeros(1, device=x.device, requires_grad=True)
+            return _ESFFunction.apply(self, pl, self._dummy)
         pl.run(self._events)
         loss = pl.terms[0:1].clone()
         return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), loss, pl.elOut.clone()

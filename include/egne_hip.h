@@ -120,6 +120,10 @@ int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int 
 int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix,
                         const float* scale, const float* shift, void* stream);
 
+/* y = x*scale[c] + shift[c], out of place (training-mode BatchNorm keeps its input for backward). */
+int egne_affine(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix,
+                const float* scale, const float* shift, void* stream);
+
 /* nn.AvgPool2d(2) (models/RITnet_v2.py:36,43; utils.py:1017) on an NHWC slice. */
 int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
                   int B, int H, int W, int Cp, void* stream);
@@ -198,6 +202,7 @@ typedef struct {
   float* elPred;               /* [B,10] = (c_iris, elOut[2:5], c_pupil, elOut[7:10]) */
   int64_t* mask;               /* optional */
   float* op_nchw;              /* optional */
+  float* coef;                 /* optional [B][32]: per-sample state kept for egne_loss_bwd */
 } egne_loss_desc;
 int64_t egne_loss_workspace_floats(int B, int H, int W);
 int egne_loss_fwd(const egne_loss_desc* d, void* stream);
@@ -227,6 +232,54 @@ int egne_adain(const float* x, int64_t xs, int xo, int C, const float* gamma, co
  * terms[0] = conf (:348-350).  terms[7] = conf.  Runs after egne_loss_fwd on the same stream. */
 int egne_conf_loss(const float* pred, int ld, const int64_t* gt, int B, int C, int flag, float weight,
                    float* terms, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of ESF-Net (loss.backward() of train.py:286; BDCN is frozen and has no backward).
+ * Data gradients of convolutions are forward convolutions with the weight pack of
+ * egne_pack_conv_weight_dgrad (flipped taps, in/out channels swapped, restricted to one input slice),
+ * accumulated into the slice's gradient through `residual`.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* d total_loss * gscale / d logits (written to an NHWC slice, 3 channels) and / d elOut [B,10].
+ * Needs the descriptor of the matching egne_loss_fwd call with `coef`, `grid_x`, `grid_y` set. */
+int egne_loss_bwd(const egne_loss_desc* d, const float* gscale /* device, 1 float */, float* g_logits,
+                  int64_t gs, int go, float* g_elOut, void* stream);
+
+/* In place g <- g * act'(y) over an NHWC slice (y = forward output of the conv) and the bias gradient
+ * dbias[c] (+)= sum over pixels of the masked g, c < C. */
+int64_t egne_act_bwd_bias_workspace_bytes(int64_t npix, int Cp);
+int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
+                      int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream);
+
+/* Backward of the normalisation that the forward fused into a conv's load (InstanceNorm, per_sample=1)
+ * or of training-mode BatchNorm (per_sample=0, gamma/dgamma/dbeta given): xh = x*scale+shift,
+ * g = gy*act_in'(xh), gx += scale*gamma*(g - mean(g) - xh*mean(g*xh)).  sums: [Bn][Cp][2] scratch. */
+int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_sample);
+int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                  const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                  int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                  int C, void* ws, void* stream);
+
+int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo,
+                      int B, int H, int W, int Cp, void* stream);       /* gx += ; H,W = input size */
+int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo,
+                        int B, int H, int W, int Cp, void* stream);     /* gx += ; H,W = input size */
+int egne_ellipse_head_act_bwd(float* g, const float* y, int B, int ld, void* stream);
+int egne_selu_bwd(float* g, const float* y, int64_t n, void* stream);
+int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo, int C, int B, int HW,
+                          void* stream);
+int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag,
+                       const float* gscale /* device, 1 float */, float* gpred, int gld, void* stream);
+
+/* Weight gradient of the convolution described by `d` (same descriptor as the forward call):
+ * gw[g][co][ci][kh][kw] += sum_pixels gz[pixel][co] * input[pixel + tap][ci], gz = gradient w.r.t. the
+ * pre-activation output.  gw is a HOST array of ngroups device pointers (OIHW, torch layout). */
+int egne_conv2d_wgrad_splits(const egne_conv_desc* d);
+int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* d);
+int egne_conv2d_wgrad(const egne_conv_desc* d, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,
+                      const int32_t* kinv, float* const* gw, void* ws, void* stream);
+int egne_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int kh, int kw, int ci0, int Cpiece,
+                                int CoutPp, int Ktotp, int frag, float* out, void* stream);
 
 /*
  * Ellipse fit of evaluate.py (utils.py:450-486 search_proper_parameter_iou_for_our_data with
