@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 64 infer / 32 train)")
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
+                    help="infer: BASELINE.json configs[1] (headline); train: fwd+bwd+all-reduce+Adam step (fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -98,8 +100,14 @@ def main():
     bd_sd = {k: v.clone() for k, v in bd.state_dict().items()}
     net_sd = {k: v.clone() for k, v in net.state_dict().items()}
     bd, net = bd.to(dev).eval(), net.to(dev).eval()
+    train = a.mode == "train"
+    if train:
+        from egne_amd import parallel
+        net.train()
+        parallel.broadcast_state(net)
+        opt = torch.optim.Adam([p for n, p in net.named_parameters() if "dsIdentify" not in n], lr=5e-4)
 
-    B = a.batch
+    B = a.batch or (32 if train else 64)
     # synthetic TEyeD-shaped batch: render 8 distinct frames on the host, tile to B
     base = synth.make_batch(min(B, 8), seed=1234 + rank)
     rep = (B + base["img"].shape[0] - 1) // base["img"].shape[0]
@@ -107,6 +115,15 @@ def main():
     args = types.SimpleNamespace(prec=torch.float32, edge_thres=0)
 
     def step():
+        if train:   # train.py:262-287: frozen edge net, forward, loss.backward(), (DP) gradient all-reduce, Adam
+            edge = calc_edge(args, t["img"], bd, dev)
+            opt.zero_grad(set_to_none=False)
+            out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
+                      t["ID"], t["alpha"])
+            out[3].backward()
+            parallel.allreduce_grads(net)
+            opt.step()
+            return [o.detach() for o in out]
         with torch.no_grad():
             edge = calc_edge(args, t["img"], bd, dev)
             return net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
@@ -144,7 +161,8 @@ def main():
         d[2] += 1
         pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
         pl_[0] += e0.elapsed_time(e1) * 1e-3 / a.steps
-    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in ("conv_igemm", "conv3x3_halo")) for i in range(3)]
+    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in ("conv_igemm", "conv3x3_halo", "conv_wgrad"))
+                              for i in range(3)]
     if a.layers and rank == 0:
         for lname, (sec, fl, kind) in per_layer.items():
             print("%-26s %-18s %9.1f us %8.2f GFLOP %7.1f TFLOP/s" % (lname, kind, sec * 1e6, fl / 1e9, fl / sec / 1e12 if sec > 0 else 0),
@@ -154,14 +172,19 @@ def main():
     if rank == 0:
         achieved = conv_f / conv_t / 1e12 if conv_t > 0 else 0.0
         res = {
-            "metric": "eye-frames/sec (320x240) inference edge+seg (BDCN -> ESF-Net -> loss/argmax)",
+            "metric": ("eye-frames/sec (320x240) train step: edge fwd + ESF-Net fwd+bwd + grad all-reduce + Adam" if train else
+                       "eye-frames/sec (320x240) inference edge+seg (BDCN -> ESF-Net -> loss/argmax)"),
             "value": round(frames / dt, 2), "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: baseline_edge.yaml (chz=32) inference, batch=%d/GPU, fp32, "
-                                   "240x320 synthetic IR frames, seeded random-init weights" % B,
-                       "frames_per_gpu_per_step": B, "parallelism": "replicas x%d (frames sharded, no collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (implicit-GEMM conv, fp32 MFMA 32x32x2, all tile variants)",
+            "config": {"workload": ("baseline_edge.yaml (chz=32) TRAIN step (BASELINE.json configs[2] shape, but fp32 and "
+                                    "batch=%d/GPU), 240x320 synthetic TEyeD-shaped batch, seeded random-init weights" % B) if train
+                       else ("BASELINE.json configs[1]: baseline_edge.yaml (chz=32) inference, batch=%d/GPU, fp32, "
+                             "240x320 synthetic IR frames, seeded random-init weights" % B),
+                       "frames_per_gpu_per_step": B,
+                       "parallelism": ("dp%d (one flat RCCL all-reduce of 13.45 MB per step)" % world) if train
+                       else "replicas x%d (frames sharded, no collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (+ conv_wgrad_kernel in train mode): implicit-GEMM conv, fp32 MFMA 32x32x2, all tile variants",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                          "launches_per_step": conv_n // max(a.steps, 1),
@@ -170,7 +193,7 @@ def main():
             "kernel_time_share": {k: round(v[0] / max(sum(x[0] for x in fam.values()), 1e-9), 4) for k, v in sorted(fam.items())},
             "gpu_busy_frac": round(sum(x[0] for x in fam.values()) / dt, 4),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not train:
             res["cpu_baseline"] = cpu_baseline(setting, bd_sd, net_sd, a.cpu_batch, a.cpu_iters)
         print(json.dumps(res), flush=True)
     if world > 1:

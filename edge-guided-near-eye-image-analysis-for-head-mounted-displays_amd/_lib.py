@@ -97,6 +97,7 @@ SIGNATURES = {
     "egne_ellipse_fit": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "egne_last_error": (C.c_char_p, []),
     "egne_version": (i32, []),
+    "egne_sizeof": (i32, [i32]),
 }
 
 _lib = None

@@ -296,6 +296,7 @@ int egne_ellipse_fit(const int64_t* mask, const int32_t* frame_of, const int32_t
 
 const char* egne_last_error(void);
 int egne_version(void);
+int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,190 @@
+"""CPU (-m "not gpu"): host logic, key schemas, C-ABI surface, DP collectives over gloo."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLD, ROOT, bdcn_module, esf_module, gold
+
+
+def test_state_dict_schema_matches_reference():
+    """Checkpoint key names / shapes must round-trip unchanged."""
+    import yaml
+    import egne_amd
+    from egne_amd.models.RITnet_v2 import DenseNet2D
+    from egne_amd.models.RITnet_concat import DenseNet2D as DC
+    ref = json.load(open(os.path.join(GOLD, "state_keys.json")))
+    cfgd = os.path.join(os.path.dirname(egne_amd.__file__), "configs")
+    got = {k: list(v.shape) for k, v in bdcn_module().state_dict().items()}
+    assert got == ref["bdcn"]
+    for key, want in ref.items():
+        if key == "bdcn":
+            continue
+        parts = key.split(":")
+        st = yaml.safe_load(open(os.path.join(cfgd, parts[1] + ".yaml")))
+        m = (DenseNet2D if parts[0] == "v2" else DC)(st)
+        if len(parts) > 2:
+            m.setDatasetInfo(4)
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == want, key
+
+
+def test_param_counts():
+    """ESF edge 3 363 494, adain_edge 6 353 810, baseline 2 608 965, BDCN 16 302 120."""
+    n = lambda m: sum(p.numel() for p in m.parameters())  # noqa: E731
+    assert n(esf_module("baseline_edge")) == 3363494
+    assert n(esf_module("baseline_adain_edge")) == 6353810
+    assert n(esf_module("baseline")) == 2608965
+    assert n(bdcn_module()) == 16302120
+
+
+def test_width_generalisation_builds():
+    """chz != 32 crashes in the reference; here the widths follow section 8a-note."""
+    from common import setting
+    from egne_amd.models.RITnet_v2 import DenseNet2D
+    from egne_amd.esf_engine import dec_sizes
+    assert dec_sizes(32, 1.2, True, "v2") == dict(ip=[306, 180, 100, 62], op=[180, 100, 62, 32], skip=[243, 172, 102, 64])
+    assert dec_sizes(32, 1.2, False, "v2")["ip"] == [153, 115, 76, 38]
+    assert dec_sizes(32, 1.2, True, "concat") == dict(ip=[306, 115, 76, 38], op=[115, 76, 38, 32], skip=[486, 344, 204, 128])
+    for chz in (16, 64):
+        m = DenseNet2D(dict(setting("baseline_edge")), chz=chz)
+        assert m.elReg.c1.weight.shape[1] == 2 * int(1.2 * chz * 4)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads (no GPU needed) and exports exactly what include/egne_hip.h declares."""
+    from egne_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "egne_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(egne_[a-z0-9_]+)\s*\(", hdr))
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "header declares %s but the library does not export it" % name
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert L.egne_version() >= 100
+    # struct layouts agree between ctypes and the C compiler
+    assert L.egne_sizeof(0) == __import__("ctypes").sizeof(_lib.ConvDesc)
+    assert L.egne_sizeof(1) == __import__("ctypes").sizeof(_lib.LossDesc)
+    assert L.egne_sizeof(2) == __import__("ctypes").sizeof(_lib.BdcnTailDesc)
+
+
+def test_no_cpu_fallback_and_loud_failure():
+    from egne_amd import synth
+    m = esf_module("baseline_edge")
+    b = synth.make_batch(1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(b["img"], b["img"], b["label"], b["pupil_center"], b["elNorm"], b["spatWts"], b["distMap"], b["cond"], b["ID"], 0.5)
+    with pytest.raises(RuntimeError):
+        bdcn_module()(torch.zeros(1, 3, 32, 32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "edge-guided-near-eye-image-analysis-for-head-mounted-displays_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_metrics_match_reference():
+    """utils.getSeg_metrics / getPoint_metric / get_predictions / normPts / unnormPts (host side)."""
+    from egne_amd import utils as U
+    g = gold("metrics")
+    miou, pc, sl = U.getSeg_metrics(g["yt"].astype(np.int64), g["yp"].astype(np.int64), g["cond"])
+    np.testing.assert_allclose(miou, g["miou"], rtol=1e-12)
+    np.testing.assert_allclose(pc, g["perclass"], rtol=1e-12)
+    np.testing.assert_allclose(sl, g["scorelist"], rtol=1e-12, equal_nan=True)
+    H, W = g["yt"].shape[1:]
+    d, dv = U.getPoint_metric(g["pts_true"], g["pts_pred"], g["cond"], (H, W), True)
+    np.testing.assert_allclose(d, g["pdist"], rtol=1e-6)
+    np.testing.assert_allclose(dv, g["pdist_v"], rtol=1e-6, atol=1e-9)
+    d2, _ = U.getPoint_metric(g["pts_true"], g["pts_true"] + 1.5, g["cond"], (H, W), False)
+    np.testing.assert_allclose(d2, g["pdist2"], rtol=1e-6)
+    pred = U.get_predictions(torch.from_numpy(g["logits"])).numpy()
+    assert np.array_equal(pred.astype(np.uint8), g["pred"])
+    np.testing.assert_allclose(U.normPts(torch.from_numpy(g["pts_true"].astype(np.float32)), (H, W)).numpy(), g["norm"])
+    np.testing.assert_allclose(U.unnormPts(g["pts_pred"].astype(np.float32), (H, W)), g["unnorm"])
+    mg = U.create_meshgrid(5, 7)
+    assert tuple(mg.shape) == (1, 5, 7, 2) and mg[0, 0, 0, 0] == -1 and mg[0, 4, 6, 1] == 1
+
+
+def test_seeded_weights_are_deterministic():
+    from egne_amd import synth
+    m = esf_module("baseline_edge")
+    a = synth.seeded_state_dict(m.state_dict(), seed=3)
+    b = synth.seeded_state_dict(m.state_dict(), seed=3)
+    c = synth.seeded_state_dict(m.state_dict(), seed=4)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["enc.head.conv1.weight"], c["enc.head.conv1.weight"])
+
+
+def test_grad_arena_views():
+    """p.grad are views of one flat buffer; zero_grad(set_to_none=True) is survived."""
+    m = esf_module("baseline_edge")
+    flat = m._ensure_grad_arena()
+    assert flat.numel() == sum(p.numel() for p in m.parameters())
+    p = m.enc.head.conv1.weight
+    p.grad.fill_(2.0)
+    assert flat[:p.numel()].eq(2.0).all()
+    for q in m.parameters():
+        q.grad = None
+    flat2 = m._ensure_grad_arena()
+    assert flat2.data_ptr() == flat.data_ptr() and p.grad.data_ptr() == flat.data_ptr() and flat.eq(0).all()
+
+
+_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import torch, torch.distributed as dist
+from common import esf_module
+from egne_amd import parallel
+rank, world = parallel.init('gloo')
+assert world == 2
+m = esf_module('baseline_edge', seed=rank)            # ranks start different on purpose
+parallel.broadcast_state(m)
+ref = esf_module('baseline_edge', seed=0)
+assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))
+flat = m._ensure_grad_arena()
+g = torch.Generator().manual_seed(100 + rank)
+flat.copy_(torch.randn(flat.numel(), generator=g))
+mine = flat.clone()
+parallel.allreduce_grads(m)
+# expected: mean of both ranks' gradients, visible through every p.grad view
+g0 = torch.randn(flat.numel(), generator=torch.Generator().manual_seed(100))
+g1 = torch.randn(flat.numel(), generator=torch.Generator().manual_seed(101))
+assert torch.allclose(flat, (g0 + g1) / 2, atol=1e-6)
+w = m.dec.final.conv2.weight
+off = sum(p.numel() for p in list(m.parameters())[:[id(q) for q in m.parameters()].index(id(w))])
+assert torch.allclose(w.grad.reshape(-1), ((g0 + g1) / 2)[off:off + w.numel()], atol=1e-6)
+# async form + loss averaging + sharding
+work, fin = parallel.allreduce_grads(m, async_op=True); work.wait(); fin()
+l = parallel.mean_loss(torch.tensor([float(rank + 1)]))
+assert abs(l.item() - 1.5) < 1e-6
+lo, hi = parallel.shard(10)
+assert (lo, hi) == (rank * 5, rank * 5 + 5)
+# one SGD step from identical weights + averaged grads keeps the replicas identical
+opt = torch.optim.SGD(m.parameters(), lr=0.1); opt.step()
+chk = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().reshape(1)
+both = [torch.zeros_like(chk) for _ in range(2)]
+dist.all_gather(both, chk)
+assert torch.equal(both[0], both[1])
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok')
+"""
+
+
+def test_data_parallel_collectives_gloo_world2(tmp_path):
+    """N>1 path on CPU: two processes over gloo -- broadcast, flat-arena all-reduce(avg), shard, step."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "ok" in o, "rank %d failed:\n%s" % (r, o[-3000:])
