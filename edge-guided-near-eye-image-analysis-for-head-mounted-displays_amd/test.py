@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Evaluation entry point -- the reference's test.py (calc_acc :31-252, main :255-298) on the HIP path.
+
+    python test.py --curObj LPW --path2data ... --loadfile ... --setting configs/baseline_edge.yaml
+    python test.py --synthetic 16 --batchsize 8 --setting configs/baseline_edge.yaml      # no data needed
+"""
+import os
+import pickle
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import egne_amd  # noqa: E402,F401
+from egne_amd import _entry  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from torch.utils.data import DataLoader  # noqa: E402
+
+from egne_amd.args import parse_args  # noqa: E402
+from egne_amd.utils import calc_edge, getPoint_metric, getSeg_metrics  # noqa: E402
+
+
+def calc_acc(args, testloader, model, edge_model, device):
+    """test.py:31-252 without the visualisation: per batch edge -> model -> argmax -> metrics."""
+    ious, dists_pupil_latent, dists_pupil_seg, dists_iris_latent, dists_iris_seg, losses = [], [], [], [], [], []
+    model.eval()
+    for bt, batch in enumerate(testloader):
+        if args.test_normal and bt > 20:       # test.py:76
+            break
+        img, labels, spatialWeights, distMap, pupil_center, iris_center, elNorm, cond, imInfo = batch
+        with torch.no_grad():
+            img_edge = calc_edge(args, img.to(device), edge_model, device)
+            op, elPred, _, loss, elOut = model(img.to(device).to(args.prec), img_edge, labels.to(device).long(),
+                                               pupil_center.to(device).to(args.prec), elNorm.to(device).to(args.prec),
+                                               spatialWeights.to(device).to(args.prec), distMap.to(device).to(args.prec),
+                                               cond.to(device).to(args.prec), imInfo[:, 2].to(device).to(torch.long), 0.5)
+        predict = model.predictions().cpu().numpy()          # device argmax == get_predictions(op) (utils.py:65-81)
+        cnp = cond.numpy().astype(np.float32)
+        iou, _, _ = getSeg_metrics(labels.numpy(), predict, cnp[:, 1])
+        H, W = labels.shape[1:]
+        lat_p, _ = getPoint_metric(pupil_center.numpy(), elOut[:, 5:7].cpu().numpy(), cnp[:, 0], (H, W), True)
+        seg_p, _ = getPoint_metric(pupil_center.numpy(), elPred[:, 5:7].cpu().numpy(), cnp[:, 0], (H, W), True)
+        lat_i, _ = getPoint_metric(iris_center.numpy(), elOut[:, 0:2].cpu().numpy(), cnp[:, 1], (H, W), True)
+        seg_i, _ = getPoint_metric(iris_center.numpy(), elPred[:, 0:2].cpu().numpy(), cnp[:, 1], (H, W), True)
+        ious.append(iou)
+        dists_pupil_latent.append(lat_p); dists_pupil_seg.append(seg_p)
+        dists_iris_latent.append(lat_i); dists_iris_seg.append(seg_i)
+        losses.append(loss.mean().item())
+    ious = np.nanmean(np.stack(ious)) if ious else np.nan
+    print('mIoU: {}'.format(ious))
+    print('Latent space PUPIL dist. Med: {}, STD: {}'.format(np.nanmedian(dists_pupil_latent), np.nanstd(dists_pupil_latent)))
+    print('Segmentation PUPIL dist. Med: {}, STD: {}'.format(np.nanmedian(dists_pupil_seg), np.nanstd(dists_pupil_seg)))
+    print('Latent space IRIS dist. Med: {}, STD: {}'.format(np.nanmedian(dists_iris_latent), np.nanstd(dists_iris_latent)))
+    print('Segmentation IRIS dist. Med: {}, STD: {}'.format(np.nanmedian(dists_iris_seg), np.nanstd(dists_iris_seg)))
+    return ious, np.nanmedian(dists_pupil_seg), np.nanmedian(dists_iris_seg), float(np.mean(losses))
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    setting = _entry.load_setting(args.setting)
+    device = torch.device("cuda")
+    if args.synthetic:
+        testObj = _entry.SyntheticEyes(args.synthetic)
+        edge_net, model = _entry.seeded_networks(setting, args.model)
+    else:
+        from egne_amd.bdcn_new import BDCN
+        from egne_amd.modelSummary import get_model
+        with open(os.path.join(args.path2data, 'baseline', 'cond_' + args.curObj + '.pkl'), 'rb') as f:
+            _, _, testObj = pickle.load(f)                     # test.py:271-274
+        edge_net = BDCN()
+        edge_net.load_state_dict(torch.load('gen_00000016.pt', map_location='cpu')['a'])   # test.py:280-283
+        model = get_model(args.model, setting)
+        model.load_state_dict(torch.load(args.loadfile, map_location='cpu')['state_dict'], strict=False)
+    loader = DataLoader(testObj, batch_size=args.batchsize, shuffle=False, num_workers=args.workers, drop_last=True)
+    edge_net, model = edge_net.to(device).eval(), model.to(device).to(args.prec)
+    return calc_acc(args, loader, model, edge_net, device)
+
+
+if __name__ == '__main__':
+    main()

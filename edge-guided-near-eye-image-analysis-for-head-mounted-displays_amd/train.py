@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Training entry point -- the reference's train.py loop (:246-488) on the HIP path, data-parallel over
+one process per GPU (torchrun) instead of nn.DataParallel.
+
+    python train.py --synthetic 32 --batchsize 8 --epochs 2 --setting configs/baseline_edge.yaml
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --curObj ... --setting ...
+"""
+import os
+import pickle
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import egne_amd  # noqa: E402,F401
+from egne_amd import _entry, parallel  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from torch.utils.data import DataLoader  # noqa: E402
+
+from egne_amd.args import parse_args  # noqa: E402
+from egne_amd.utils import calc_edge, getSeg_metrics  # noqa: E402
+
+
+class EarlyStopping:
+    """pytorchtools.py:11-67 ('max' mode as train.py:197-203 uses it): stop after `patience` epochs
+    without an improvement of more than `delta`; saves the best model to `path`."""
+
+    def __init__(self, patience=10, delta=0.001, path=None):
+        self.patience, self.delta, self.path = patience, delta, path
+        self.best, self.counter, self.early_stop = None, 0, False
+
+    def __call__(self, metric, ckpt):
+        if self.best is None or metric > self.best + self.delta:
+            self.best, self.counter = metric, 0
+            if self.path:
+                torch.save(ckpt, self.path)
+        else:
+            self.counter += 1
+            self.early_stop = self.counter >= self.patience
+
+
+def lossandaccuracy(args, loader, model, edge_model, alpha, device):
+    """utils.py:658-760 (the shipped version dies in np.stack([])): validation loss + mIoU."""
+    model.eval()
+    losses, ious = [], []
+    for bt, batch in enumerate(loader):
+        if args.test_normal and bt > 20:
+            break
+        img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
+        with torch.no_grad():
+            edge = calc_edge(args, img.to(device), edge_model, device)
+            out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
+                        dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
+        losses.append(out[3].mean().item())
+        ious.append(getSeg_metrics(labels.numpy(), model.predictions().cpu().numpy(), cond.numpy().astype(np.float32)[:, 1])[0])
+    model.train()
+    return float(np.mean(losses)) if losses else float('nan'), float(np.nanmean(ious)) if ious else float('nan')
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank, world = parallel.init()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.manual_seed(0)                                      # train.py:34-36
+    setting = _entry.load_setting(args.setting)
+    if args.synthetic:
+        trainObj = _entry.SyntheticEyes(args.synthetic, seed=1234 + rank)
+        validObj = _entry.SyntheticEyes(max(args.batchsize, 4), seed=99)
+        edge_net, model = _entry.seeded_networks(setting, args.model, bool(args.disentangle))
+    else:
+        from egne_amd.bdcn_new import BDCN
+        from egne_amd.modelSummary import get_model
+        with open(os.path.join(args.path2data, 'baseline', 'cond_' + args.curObj + '.pkl'), 'rb') as f:
+            trainObj, validObj, _ = pickle.load(f)            # train.py:86-92
+        edge_net = BDCN()
+        edge_net.load_state_dict(torch.load('gen_00000016.pt', map_location='cpu')['a'])   # train.py:124-129
+        model = get_model(args.model, setting)
+        if args.disentangle:                                   # train.py:182-186
+            model.disentangle = True
+            model.setDatasetInfo(int(torch.unique(trainObj.imList[:, 2]).numel()))
+        if args.resume and os.path.exists(args.loadfile):
+            model.load_state_dict(torch.load(args.loadfile, map_location='cpu')['state_dict'], strict=False)
+    model.selfCorr = bool(args.selfCorr)
+    edge_net, model = edge_net.to(device).eval(), model.to(device).to(args.prec).train()
+    parallel.broadcast_state(model)
+    params = [p for n, p in model.named_parameters() if 'dsIdentify' not in n]     # train.py:146-148
+    optimizer = torch.optim.Adam(params, lr=args.lr)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'max', patience=5, factor=0.1)   # train.py:192
+    logdir = os.path.join('logs', args.model, args.expname)
+    os.makedirs(os.path.join(logdir, 'weights'), exist_ok=True)
+    stopper = EarlyStopping(patience=10, delta=0.001, path=os.path.join(logdir, 'checkpoint.pt') if rank == 0 else None)
+    # each rank loads its own shard (DataParallel scatter equivalent); synthetic sets are per-rank already
+    trainloader = DataLoader(trainObj, batch_size=args.batchsize, shuffle=True, num_workers=args.workers, drop_last=True)
+    validloader = DataLoader(validObj, batch_size=args.batchsize, shuffle=False, num_workers=args.workers, drop_last=True)
+    for epoch in range(args.epochs):
+        alpha = epoch / args.epochs                                                 # helperfunctions.linVal, train.py:248
+        t_edge = t_net = 0.0
+        t0 = time.time()
+        for bt, batch in enumerate(trainloader):
+            if (args.overfit and bt >= args.overfit) or (args.test_normal and bt > 20):
+                break
+            img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
+            torch.cuda.synchronize(); ta = time.time()
+            edge = calc_edge(args, img.to(device), edge_net, device)               # frozen, no_grad (train.py:266)
+            torch.cuda.synchronize(); tb = time.time()
+            optimizer.zero_grad(set_to_none=False)
+            out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
+                        dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
+            loss = out[3].mean()                                                   # train.py:285
+            loss.backward()
+            parallel.allreduce_grads(model)
+            optimizer.step()
+            torch.cuda.synchronize(); tc = time.time()
+            t_edge += tb - ta; t_net += tc - tb
+            if rank == 0 and bt % 30 == 0:
+                print('Epoch:{} [{}/{}], Loss: {:.3f} edge {:.3f}s net {:.3f}s'.format(epoch, bt, len(trainloader),
+                                                                                  parallel.mean_loss(loss.detach()).item(), t_edge, t_net))
+            elif world > 1 and bt % 30 == 0:
+                parallel.mean_loss(loss.detach())
+        vloss, viou = lossandaccuracy(args, validloader, model, edge_net, alpha, device)
+        if rank == 0:
+            print('Epoch {} done in {:.1f}s: valid loss {:.4f} mIoU {:.4f}'.format(epoch, time.time() - t0, vloss, viou))
+            ckpt = _entry.checkpoint_dict(model, epoch)
+            torch.save(ckpt, os.path.join(logdir, 'weights', '{}_{}.pkl'.format(args.model, epoch)))   # train.py:486-488
+            stopper(viou if viou == viou else -vloss, ckpt)
+        scheduler.step(viou if viou == viou else -vloss)
+        stop = torch.tensor([1.0 if stopper.early_stop else 0.0], device=device)
+        if world > 1:
+            torch.distributed.broadcast(stop, src=0)
+        if stop.item() > 0:
+            break
+    return model
+
+
+if __name__ == '__main__':
+    main()

@@ -188,3 +188,29 @@ def test_data_parallel_collectives_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "ok" in o, "rank %d failed:\n%s" % (r, o[-3000:])
+
+
+def test_ellipse_transform_matches_reference():
+    from egne_amd import ellipse
+    g = gold("ellipse_transform")
+    Hm = np.array([[160.0, 0, 160.0], [0, 120.0, 120.0], [0, 0, 1]])
+    for p, ref in zip(g["params"], g["out"]):
+        np.testing.assert_allclose(ellipse.transform(p, Hm), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_entry_args_and_checkpoint_format():
+    from egne_amd import _entry
+    from egne_amd.args import parse_args, parse_precision
+    a = parse_args(["--synthetic", "4", "--setting", "configs/baseline_edge.yaml"])
+    assert a.lr == 5e-4 and a.batchsize == 12 and a.epochs == 40 and a.disentangle == 1 and a.prec == torch.float32
+    assert parse_precision(64) == torch.float32 and parse_precision(16) == torch.float16
+    with pytest.raises(SystemExit):
+        parse_args([])
+    st = _entry.load_setting("configs/baseline_edge.yaml")
+    assert st["add_edge"] == 1 and st["feature_channels"] == 153
+    m = esf_module("baseline_edge", disentangle=True)
+    ck = _entry.checkpoint_dict(m, 3)
+    assert ck["epoch"] == 3 and not any("dsIdentify" in k for k in ck["state_dict"]) and "enc.head.conv1.weight" in ck["state_dict"]
+    ds = _entry.SyntheticEyes(2)
+    s = ds[1]
+    assert len(s) == 9 and tuple(s[0].shape) == (1, 240, 320) and s[7].dtype == torch.bool and tuple(s[8].shape) == (3,)
