@@ -285,6 +285,45 @@ def gold_metrics():
          unnorm=U.unnormPts(p.astype(np.float32), (H, W)))
 
 
+def gold_evaluate(bd):
+    """evaluate.py:112-166 on REAL frames of videos/example1.avi (two eyes of two frames), seeded weights:
+    z-scored frame -> edge -> logits -> argmax -> un-normalised ellipses -> fitted ellipses."""
+    import io as _io
+    from PIL import Image
+    U, HF = REF["utils"], REF["hf"]
+    data = open("/root/reference/videos/example1.avi", "rb").read()
+    frames, pos = [], 0
+    while len(frames) < 120:
+        a = data.find(b"\xff\xd8\xff", pos)
+        b = data.find(b"\xff\xd9", a)
+        pos = b + 2
+        frames.append(np.asarray(Image.open(_io.BytesIO(data[a:b + 2])).convert("L")))
+    eyes = np.stack([frames[j][:, 320 * i: 320 * (i + 1)] for j in (0, 119) for i in (0, 1)])   # [4,240,320] uint8
+    m = ref_esf(load_setting("baseline_edge")).eval()
+    H, W = 240, 320
+    Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
+    masks, inits, fits, ops = [], [], [], []
+    for e in eyes:
+        img = e.astype(np.float64)
+        img = (img - img.mean()) / img.std()                      # evaluate.py:102
+        x = torch.from_numpy(img).unsqueeze(0).to(torch.float32).unsqueeze(0)
+        with torch.no_grad():
+            edge = bd(torch.cat((x, x, x), 1))[-1]
+            lab = torch.zeros((1, H, W)); lab[..., 0, 2] = 1; lab[..., 2, 2] = 2
+            out = quiet(m, x, edge, lab.long(), torch.zeros(1, 2), torch.zeros(1, 2, 5), torch.zeros(1, H, W),
+                        torch.zeros(1, 3, H, W), torch.zeros(1, 4), 0, 0)
+        seg = U.get_predictions(out[0]).squeeze()
+        elp = out[1].squeeze().numpy()
+        ini_p = HF.my_ellipse(elp[5:10]).transform(Hm)[0][:-1]
+        ini_i = HF.my_ellipse(elp[0:5]).transform(Hm)[0][:-1]
+        fit_i = U.search_proper_parameter_iou_for_our_data(seg == 1, ini_i.copy())
+        fit_p = U.search_proper_parameter_iou_for_our_data(seg == 2, ini_p.copy())
+        masks.append(np.packbits(seg.numpy().astype(np.uint8) == 1)); masks.append(np.packbits(seg.numpy().astype(np.uint8) == 2))
+        inits.append(np.stack([ini_i, ini_p])); fits.append(np.stack([fit_i, fit_p])); ops.append(npy(out[0][0, :, ::4, ::4]))
+    save("evaluate_real_frames", eyes=eyes, masks=np.stack(masks), inits=np.stack(inits), fits=np.stack(fits),
+         op_sub=np.stack(ops))
+
+
 def gold_keys():
     """Checkpoint key schema (name -> shape) of every reference module on the path."""
     import json
@@ -302,7 +341,7 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "loss", "fit", "metrics", "keys"]
+    what = sys.argv[1:] or ["bdcn", "esf", "loss", "fit", "metrics", "keys", "evaluate"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
@@ -316,3 +355,5 @@ if __name__ == "__main__":
         gold_metrics()
     if "keys" in what:
         gold_keys()
+    if "evaluate" in what:
+        gold_evaluate(bd or ref_bdcn())

@@ -36,3 +36,38 @@ def test_evaluate_py_synthetic():
     from egne_amd import evaluate as E
     pup, iri = E.main(["--synthetic", "2"])
     assert pup.shape == (2, 5) and iri.shape == (2, 5) and np.isfinite(pup).all() and np.isfinite(iri).all()
+
+
+def test_evaluate_on_real_video_frames():
+    """Real frames of the reference's videos/example1.avi (fixture: 4 eye crops) through the evaluate
+    path: logits within 1e-3 of the reference, identical masks, and -- given the same (mask, initial
+    ellipse) -- a bit-identical fit.  Fitted ellipses of the full pipeline agree whenever the mask and
+    the network's initial ellipse agree (the search is a discontinuous hill climb)."""
+    import types
+    from common import bdcn_module, esf_module, gold
+    from egne_amd import evaluate as E
+    from egne_amd.utils import fit_ellipses
+    g = gold("evaluate_real_frames")
+    dev = "cuda:0"
+    bd, net = bdcn_module().to(dev), esf_module("baseline_edge").to(dev).eval()
+    xs = torch.stack([E.preprocess_frame(e, (240, 320), True)[0] for e in g["eyes"]]).to(dev)
+    edge, seg, pup, iri = E.evaluate_ellseg_on_image(xs, net, bd)
+    H, W = 240, 320
+    for k in range(4):
+        m1 = np.packbits(seg[k].astype(np.uint8) == 1)
+        m2 = np.packbits(seg[k].astype(np.uint8) == 2)
+        assert np.array_equal(m1, g["masks"][2 * k]) and np.array_equal(m2, g["masks"][2 * k + 1]), "mask %d differs" % k
+    # fit stage alone: reference masks + reference initial ellipses -> bit-identical result
+    masks = np.stack([np.unpackbits(g["masks"][2 * k]).reshape(H, W).astype(np.int64)
+                      + 2 * np.unpackbits(g["masks"][2 * k + 1]).reshape(H, W).astype(np.int64) for k in range(4)])
+    init = g["inits"].reshape(8, 5)
+    fit = fit_ellipses(torch.from_numpy(masks).to(dev), [0, 0, 1, 1, 2, 2, 3, 3], [1, 2] * 4, init)
+    np.testing.assert_array_equal(fit, g["fits"].reshape(8, 5))
+    # end to end: initial ellipses come from the network (1e-3 parity), so the climb may take another path;
+    # centres are never moved by the search and must match to 1e-3 * image size
+    np.testing.assert_allclose(iri[:, :2], g["fits"][:, 0, :2], atol=0.35)
+    np.testing.assert_allclose(pup[:, :2], g["fits"][:, 1, :2], atol=0.35)
+    same = sum(np.allclose(iri[k], g["fits"][k, 0], atol=1e-2) for k in range(4)) + \
+        sum(np.allclose(pup[k], g["fits"][k, 1], atol=1e-2) for k in range(4))
+    print("end-to-end fitted ellipses equal to the reference's within 1e-2: %d / 8" % same)
+    assert same >= 6
