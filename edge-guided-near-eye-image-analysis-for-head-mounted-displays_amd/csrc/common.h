@@ -5,6 +5,11 @@
 #include <cstdio>
 #include "../../include/egne_hip.h"
 
+// 256 bytes of zeros in device memory: invalid (out-of-image / padded-channel) lanes load from here with
+// an UNCONDITIONAL load (pointer select) instead of a conditional load -- hipcc otherwise branches around
+// each load and waits vmcnt(0) per element, which serialises the whole staging phase.
+static __device__ __attribute__((aligned(256), used)) float egne_zero_page[64] = {0};
+
 namespace egne {
 
 char* err_buf();  // thread-local 512-byte buffer (defined in api.hip)
@@ -25,6 +30,9 @@ inline int check_launch(const char* what) {
 
 #define EGNE_REQUIRE(cond, ...) \
   do { if (!(cond)) return ::egne::fail(EGNE_ERR_ARG, __VA_ARGS__); } while (0)
+
+bool halo3_supported(const egne_conv_desc& d);   // conv_halo3.hip
+int halo3_launch(const egne_conv_desc& d, hipStream_t st);
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -11,6 +11,7 @@
 // [tap][k/8][n/32][lane][4] so that each wave fetches its B fragment with one fully coalesced
 // 1-KiB global load (L2/L1 resident, prefetched one k-step ahead).
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,35 +79,44 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
   };
 
   f32x4 st[NI_MAX];
+  // load phase: unconditional loads only (invalid lanes read the zero page); the fused affine /
+  // activation and the zero padding are applied in the store phase, after the MFMAs of the current chunk.
+  f32x4 st_sc = {1.f, 1.f, 1.f, 1.f}, st_sh = {0.f, 0.f, 0.f, 0.f};
+  bool st_cok = true;
   auto load_chunk = [&](int c0) {
     const bool cok = c0 + c4 * 4 < Cp;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (sg.scale && cok) {
-      sc = *(const f32x4*)(sg.scale + (long long)stage_b * Cp + c0 + c4 * 4);
-      sh = *(const f32x4*)(sg.shift + (long long)stage_b * Cp + c0 + c4 * 4);
+    st_cok = cok;
+    if (sg.scale) {
+      const float* sp = cok ? sg.scale + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page;
+      const float* hp = cok ? sg.shift + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page;
+      st_sc = *(const f32x4*)sp;
+      st_sh = *(const f32x4*)hp;
     }
 #pragma unroll
     for (int i = 0; i < NI_MAX; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (goff[i] >= 0 && cok) {
-        v = *(const f32x4*)(src + goff[i] + c0);
-        if (sg.scale) v = v * sc + sh;
-        if (sg.act_in == EGNE_ACT_LEAKY) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-        } else if (sg.act_in == EGNE_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-      }
-      st[i] = v;
+      const float* q = (goff[i] >= 0 && cok) ? src + goff[i] + c0 : egne_zero_page;
+      st[i] = *(const f32x4*)q;
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NI_MAX; ++i) {
       const int item = tid + 256 * i;
-      if (item < nitems) *(f32x4*)&lds[(item >> 3) * LDK + c4 * 4] = st[i];
+      if (item < nitems) {
+        f32x4 v = st[i];
+        if (sg.scale) {
+          v = v * st_sc + st_sh;
+          if (sg.act_in == EGNE_ACT_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+          } else if (sg.act_in == EGNE_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (!(goff[i] >= 0 && st_cok)) v = (f32x4)(0.f);   // zero padding AFTER the normalisation
+        }
+        *(f32x4*)&lds[(item >> 3) * LDK + c4 * 4] = v;
+      }
     }
   };
 
@@ -313,6 +323,8 @@ extern "C" int egne_conv3x3_halo_fwd(const egne_conv_desc* dp, void* stream) {
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride < (1ll << 31), "conv_halo: frame too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
   const int c = d.CoutP;
+  static const int gen = [] { const char* e = getenv("EGNE_HALO_V"); return e ? atoi(e) : 2; }();   // generation 3 (conv_halo3.hip) is opt-in: measured slower so far
+  if (gen >= 3 && egne::halo3_supported(d)) return egne::halo3_launch(d, st);
   if (d.dil[0] == 1) {
     if (c % 128 == 0) return launch_halo<2, 4, 1>(d, d.w, st);
     if (c % 64 == 0) return launch_halo<2, 2, 1>(d, d.w, st);

@@ -83,6 +83,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     ++s.g;
   };
 
+  // Staging is split in two so that NOTHING consumes a loaded register before the MFMAs of the current
+  // step have been issued: load_step only issues unconditional loads (invalid lanes read the zero page),
+  // store_step applies the fused affine / activation, zeroes the padding and writes LDS.
+  unsigned okmask = 0;       // bit i: row i of the staged step is inside the image
+  int st_seg = 0, st_c = 0;  // slice / first channel of the staged step (for the deferred affine)
   auto load_step = [&](const KState& s) {
     const egne_seg sg = p.seg[s.seg];
     const int dil = p.dil[s.g];
@@ -90,9 +95,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
     const int c = s.c0 + col4 * 4;
     const bool cok = c < sg.Cp;
+    okmask = 0;
+    st_seg = s.seg; st_c = c;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       int iy = py[i] + dy, ix = px[i] + dx;
       bool ok = cok && pb[i] >= 0;
       if (p.pad_mode == 1) {
@@ -101,14 +107,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
       } else {
         ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       }
-      if (ok) {
-        const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c;
-        v = *(const f32x4*)src;
-        if (sg.scale) {
-          const f32x4 sc = *(const f32x4*)(sg.scale + (long long)pb[i] * sg.Cp + c);
-          const f32x4 sh = *(const f32x4*)(sg.shift + (long long)pb[i] * sg.Cp + c);
-          v = v * sc + sh;
-        }
+      const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c;
+      src = ok ? src : egne_zero_page;
+      ra[i] = *(const f32x4*)src;
+      okmask |= (ok ? 1u : 0u) << i;
+    }
+    const float* wbase = p.w + ((long long)(s.g * T + s.tap) * p.CoutP + n0 + rbase) * p.Ktot + s.kofs + c;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const float* src = cok ? wbase + (long long)(32 * j) * p.Ktot : egne_zero_page;
+      rb[j] = *(const f32x4*)src;
+    }
+  };
+
+  auto store_step = [&]() {
+    const egne_seg sg = p.seg[st_seg];
+    if (sg.scale) {
+      // per-(n,c) affine of the fused InstanceNorm / BatchNorm (+ activation); padding stays exactly zero
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = (okmask >> i) & 1u;
+        const float* sp = ok ? sg.scale + (long long)pb[i] * sg.Cp + st_c : egne_zero_page;
+        const float* hp = ok ? sg.shift + (long long)pb[i] * sg.Cp + st_c : egne_zero_page;
+        const f32x4 sc = *(const f32x4*)sp, sh = *(const f32x4*)hp;
+        f32x4 v = ra[i] * sc + sh;
         if (sg.act_in == EGNE_ACT_LEAKY) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
@@ -116,19 +138,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        ra[i] = v;
       }
-      ra[i] = v;
     }
-    const float* wbase = p.w + ((long long)(s.g * T + s.tap) * p.CoutP + n0 + rbase) * p.Ktot + s.kofs + c;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cok) v = *(const f32x4*)(wbase + (long long)(32 * j) * p.Ktot);
-      rb[j] = v;
-    }
-  };
-
-  auto store_step = [&]() {
 #pragma unroll
     for (int i = 0; i < AR; ++i) *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = ra[i];
 #pragma unroll

@@ -17,7 +17,7 @@ import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "60"))
-HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "64"))  # wider layers: flat kernel is faster (measured)
+HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "32"))  # wider layers: flat kernel is faster (measured)
 
 
 def pad8(c):
