@@ -64,6 +64,7 @@ SIGNATURES = {
     "egne_affine_inplace": (i32, [vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_affine": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_avgpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_norm_act_pool2": (i32, [vp, i64, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_maxpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_nchw_to_nhwc": (i32, [vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),

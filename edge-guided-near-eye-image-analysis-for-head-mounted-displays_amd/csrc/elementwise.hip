@@ -97,6 +97,35 @@ __global__ void avgpool2_k(const float* __restrict__ x, long long xs, int xo, fl
   }
 }
 
+// avgpool2(act(x*scale+shift)): Transition_down with the pooling commuted in front of its 1x1 conv
+// (both are linear, models/RITnet_v2.py:40-44), which quarters the conv's work and traffic.
+__global__ void norm_act_pool2_k(const float* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, int act, float* __restrict__ y, long long ys, int yo,
+                                 int B, int H, int W, int Cp) {
+  const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
+  const long long total = (long long)B * Ho * Wo * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const f32x4 sc = *(const f32x4*)(scale + (long long)b * Cp + c), sh = *(const f32x4*)(shift + (long long)b * Cp + c);
+    const float* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
+    f32x4 v[4] = {*(const f32x4*)s, *(const f32x4*)(s + xs), *(const f32x4*)(s + (long long)W * xs),
+                  *(const f32x4*)(s + (long long)W * xs + xs)};
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 t = v[k] * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = act == EGNE_ACT_LEAKY ? (t[e] > 0.f ? t[e] : 0.01f * t[e]) : (act == EGNE_ACT_RELU ? fmaxf(t[e], 0.f) : t[e]);
+      r += t;
+    }
+    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r * 0.25f;
+  }
+}
+
 __global__ void maxpool2_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
                            int yo, int B, int H, int W, int Ho, int Wo, int stride, int Cp) {
   const int nv = Cp >> 2;
@@ -266,6 +295,15 @@ extern "C" int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64
   hipLaunchKernelGGL(avgpool2_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
                      (hipStream_t)stream, x, (long long)xs, xo, y, (long long)ys, yo, B, H, W, Cp);
   return egne::check_launch("egne_avgpool2");
+}
+
+extern "C" int egne_norm_act_pool2(const float* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
+                                   float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp) && scale && shift, "norm_act_pool2: bad slices");
+  EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2, "norm_act_pool2: bad shape");
+  hipLaunchKernelGGL(norm_act_pool2_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, (long long)xs, xo, scale, shift, act, y, (long long)ys, yo, B, H, W, Cp);
+  return egne::check_launch("egne_norm_act_pool2");
 }
 
 extern "C" int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,

@@ -204,7 +204,15 @@ def build_forward_plan(model, B, H, W, dev, training):
         sc2, sh2, _, _ = pl.norm_stats(d["out"], NB, h * w, name=nm + ".in_out")
         tdl = _cl(blk.TD.conv, _lay([d["out"], d["x"]]))
         tin = [d["out"].with_norm(sc2, sh2, ACT_LEAKY), d["x"].with_norm(sc, sh, ACT_LEAKY)]
-        if pools[i]:
+        if pools[i] and not training:
+            # eval plans: pool first, then the 1x1 conv at quarter resolution (linear ops commute)
+            pb_ = pl.buf(NB, h // 2, w // 2, d["out"].Cp + d["x"].Cp)
+            q_out, q_x = Piece(pb_, 0, d["out"].C, d["out"].Cp), Piece(pb_, d["out"].Cp, d["x"].C, d["x"].Cp)
+            for src, dstp, (a_, b_) in ((d["out"], q_out, (sc2, sh2)), (d["x"], q_x, (sc, sh))):
+                pl.raw(L.egne_norm_act_pool2, (src.ptr, src.stride, src.off, a_.data_ptr(), b_.data_ptr(), ACT_LEAKY,
+                                               dstp.ptr, dstp.stride, dstp.off, NB, h, w, src.Cp), nm + ".TDpool")
+            pl.conv(tdl, [q_out, q_x], D[i + 1]["x"], NB, h // 2, w // 2, name=nm + ".TD")
+        elif pools[i]:
             td = pl.buf(NB, h, w, pad8(outs[i]))
             pl.conv(tdl, tin, Piece(td, 0, outs[i]), NB, h, w, name=nm + ".TD")
             pl.avgpool2(Piece(td, 0, outs[i]), D[i + 1]["x"], NB, h, w, name=nm + ".pool")

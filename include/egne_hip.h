@@ -128,6 +128,11 @@ int egne_affine(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo
 int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
                   int B, int H, int W, int Cp, void* stream);
 
+/* avgpool2(act(x*scale[n][c] + shift[n][c])): Transition_down (models/RITnet_v2.py:32-44) with the
+ * AvgPool2d commuted in front of its 1x1 conv (both linear; rounding-level difference only). */
+int egne_norm_act_pool2(const float* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
+                        float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);
+
 /* nn.MaxPool2d(2, stride, ceil_mode=True) (vgg16_c.py:15,20,27,34) on an NHWC slice. */
 int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
                   int B, int H, int W, int Ho, int Wo, int stride, int Cp, void* stream);
