@@ -161,7 +161,7 @@ def main():
         d[2] += 1
         pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
         pl_[0] += e0.elapsed_time(e1) * 1e-3 / a.steps
-    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in ("conv_igemm", "conv3x3_halo", "conv_wgrad"))
+    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad"))
                               for i in range(3)]
     if a.layers and rank == 0:
         for lname, (sec, fl, kind) in per_layer.items():

@@ -252,6 +252,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   }
 }
 
+// First layers (Cin <= 4: grey frame / 3 replicated channels): 27..36 MACs per output, so the layer is a
+// pure 128-256 B/pixel store stream.  Direct VALU kernel: lane = output channel (weights in registers),
+// a few pixel slots per workgroup; the <= 36 input values of a pixel are wave-uniform broadcast loads.
+template <int CG>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const egne_conv_desc p, int cin) {
+  constexpr int SLOTS = 256 / CG;
+  const int c = threadIdx.x % CG, slot = threadIdx.x / CG;
+  float w[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[t][k] = (k < cin && c < p.CoutP) ? p.w[((long long)t * p.CoutP + c) * p.Ktot + k] : 0.f;
+  const float bv = (p.bias && c < p.CoutP) ? p.bias[c] : 0.f;
+  const float ps = p.post_scale ? p.post_scale[c] : 1.f, pt = p.post_scale ? p.post_shift[c] : 0.f;
+  const egne_seg sg = p.seg[0];
+  const long long M = (long long)p.B * p.H * p.W;
+  const bool cok = c < p.Cout_store;
+  for (long long m = (long long)blockIdx.x * SLOTS + slot; m < M; m += (long long)gridDim.x * SLOTS) {
+    const int hw = p.H * p.W;
+    const int b = (int)(m / hw);
+    const int r = (int)(m - (long long)b * hw);
+    const int y = r / p.W, x = r - y * p.W;
+    float acc = bv;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const float* src = ok ? sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off : egne_zero_page;
+      const f32x4 v = *(const f32x4*)src;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = fmaf(v[k], w[t][k], acc);
+    }
+    if (cok) {
+      float v = act_apply(acc, p.act);
+      if (p.post_scale) v = v * ps + pt;
+      p.out[m * p.out_pix_stride + p.out_ch_off + c] = v;
+    }
+  }
+}
+
 template <int WM, int WN>
 int launch(const egne_conv_desc& d, hipStream_t st) {
   constexpr int BM = 128 * WM, BN = 32 * WN;
@@ -265,6 +305,28 @@ int launch(const egne_conv_desc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+// 3x3 / stride 1 / pad 1 / one slice / logical Cin <= 4 / Cout_store <= 64 (vgg16_c.py conv1_1, convBlock head conv1)
+extern "C" int egne_conv3x3_smallcin_fwd(const egne_conv_desc* dp, int cin, void* stream) {
+  EGNE_REQUIRE(dp != nullptr, "conv_smallcin: null descriptor");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_h == 1 && d.pad_w == 1 && d.pad_mode == 0 && d.ngroups == 1 &&
+               d.dil[0] == 1 && d.nseg == 1 && d.Ho == d.H && d.Wo == d.W, "conv_smallcin: geometry not supported");
+  EGNE_REQUIRE(cin >= 1 && cin <= 4 && d.seg[0].Cp >= 4 && d.seg[0].scale == nullptr, "conv_smallcin: Cin %d / fused affine not supported", cin);
+  EGNE_REQUIRE(d.Cout_store <= 64 && d.CoutP % 32 == 0 && d.w && d.out && d.residual == nullptr, "conv_smallcin: Cout");
+  EGNE_REQUIRE(((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0, "conv_smallcin: alignment");
+  EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv_smallcin: output slice exceeds pixel stride");
+  const long long M = (long long)d.B * d.H * d.W;
+  hipStream_t st = (hipStream_t)stream;
+  if (d.Cout_store <= 32) {
+    long long g = (M + 8 * 16 - 1) / (8 * 16); if (g > 16384) g = 16384;
+    hipLaunchKernelGGL((conv3x3_smallcin_kernel<32>), dim3((unsigned)g), dim3(256), 0, st, d, cin);
+  } else {
+    long long g = (M + 4 * 16 - 1) / (4 * 16); if (g > 16384) g = 16384;
+    hipLaunchKernelGGL((conv3x3_smallcin_kernel<64>), dim3((unsigned)g), dim3(256), 0, st, d, cin);
+  }
+  return egne::check_launch("egne_conv3x3_smallcin_fwd");
+}
 
 extern "C" int egne_conv2d_fwd(const egne_conv_desc* dp, void* stream) {
   EGNE_REQUIRE(dp != nullptr, "conv: null descriptor");

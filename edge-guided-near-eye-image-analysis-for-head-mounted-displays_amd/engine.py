@@ -16,6 +16,7 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
 import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
+SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "0") != "0"   # opt-in: measured slower than the MFMA path so far
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "60"))
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "32"))  # wider layers: flat kernel is faster (measured)
 
@@ -248,6 +249,11 @@ class Plan:
         halo = (HALO_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                 and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] <= 2
                 and W >= HALO_MIN_W and layer.CoutP <= HALO_MAX_COUTP and H * W * pieces[0].stride < 2 ** 31)
+        smallcin = (SMALLCIN_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
+                    and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] == 1
+                    and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None)
+        if smallcin:
+            halo = False
         if halo:
             layer.need_frag = True
         else:
@@ -282,7 +288,9 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if halo:
+        if smallcin:
+            self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.Cin), name, flops=flops, kind="conv3x3_smallcin")
+        elif halo:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")

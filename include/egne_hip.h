@@ -100,6 +100,11 @@ int egne_conv3x3_halo_fwd(const egne_conv_desc* d, void* stream);
 int egne_pack_conv_weight_frag(const float* w_oihw, int Cout, int Cin, int kh, int kw,
                                const int32_t* kinv, int CoutP, int Ktot, float* w_packed, void* stream);
 
+/* First layers (vgg16_c.py:66 conv1_1 on 3 channels, utils.py:1047 convBlock conv1 on 1-2 channels):
+ * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  27-36 MACs per output make this a pure store
+ * stream, so it runs as a direct VALU kernel (flat weight pack of egne_pack_conv_weight). */
+int egne_conv3x3_smallcin_fwd(const egne_conv_desc* d, int cin, void* stream);
+
 /* OIHW (torch layout) -> packed [tap][CoutP][Ktot].  kinv[k] (device int32, k < Ktot) names the
  * input channel stored at padded K position k, or -1 for a padding column; rows Cout..CoutP-1 are
  * zero.  Used at load_state_dict / after optimizer steps. */
