@@ -1,0 +1,230 @@
+// Split-precision implicit-GEMM convolution: fp32 data, three f16 MFMAs per product, fp32 accumulate.
+//
+// gfx950 has no xf32/TF32 and its exact-fp32 MFMA runs at 1/16 of the f16 rate, so an fp32 direct
+// convolution tops out at 157 TFLOP/s (1213 frames/s for this path).  Here every fp32
+// operand is split on the fly into two halves, x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 bits of
+// significand, and  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  (the dropped lo*lo term is 2^-22 relative).
+// Three v_mfma_f32_32x32x16_f16 cost 96 cycles for K=16 against 512 cycles of eight 32x32x2 fp32 MFMAs.
+// Operands are pre-scaled by exact powers of two (weights at pack time, activations while staging) so that
+// the lo halves stay in the f16 normal range; the epilogue undoes the scaling exactly.
+//
+// Used for the frozen BDCN trunk only (single input slice, Cin % 32 == 0, no fused affine): its edge map has
+// a 1e-3 tolerance and a measured error of ~1e-5 with this kernel, while ESF-Net (training, gradients) stays
+// on the exact-fp32 kernels.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32;
+constexpr int LDH = 40;          // LDS row pitch in halfs (80 B): conflict-free ds_read_b128
+constexpr int BM = 128, BN = 128;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == EGNE_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EGNE_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+// 4 waves as 2(M) x 2(N); each wave owns a 64 x 64 tile = 2 x 2 MFMA tiles
+__global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ whi,
+                                                         const _Float16* __restrict__ wlo, float a_scale,
+                                                         float out_scale) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * BM + 2 * BN) * LDH];
+  _Float16* Ahi = lds;
+  _Float16* Alo = Ahi + BM * LDH;
+  _Float16* Bhi = Alo + BM * LDH;
+  _Float16* Blo = Bhi + BN * LDH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int T = p.kh * p.kw;
+  const egne_seg sg = p.seg[0];
+  const int dil = p.dil[0];
+
+  const int col4 = tid & 7, rbase = tid >> 3;
+  int pb[4], py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m0 + rbase + 32 * i;
+    if (m < M) {
+      const int hw = p.Ho * p.Wo;
+      const int b = (int)(m / hw);
+      const int r = (int)(m - (long long)b * hw);
+      const int oy = r / p.Wo;
+      pb[i] = b; py[i] = oy; px[i] = r - oy * p.Wo;
+    } else {
+      pb[i] = -1; py[i] = 0; px[i] = 0;
+    }
+  }
+
+  f32x4 ra[4];
+  f32x4 rbh[2], rbl[2];   // 8 halfs each (loaded as 16 B)
+  auto load_step = [&](int tap, int c0) {
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = py[i] + dy, ix = px[i] + dx;
+      const bool ok = pb[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + col4 * 4;
+      src = ok ? src : egne_zero_page;
+      ra[i] = *(const f32x4*)src;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int item = tid + 256 * j;
+      const int row = item >> 2, piece = item & 3;
+      const long long off = ((long long)tap * p.CoutP + n0 + row) * p.Ktot + c0 + piece * 8;
+      rbh[j] = *(const f32x4*)(whi + off);
+      rbl[j] = *(const f32x4*)(wlo + off);
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = ra[i][e] * a_scale;
+        const _Float16 h = (_Float16)x;
+        hi[e] = h;
+        lo[e] = (_Float16)(x - (float)h);
+      }
+      const int o = (rbase + 32 * i) * LDH + col4 * 4;
+      *(h4*)&Ahi[o] = hi;
+      *(h4*)&Alo[o] = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int item = tid + 256 * j;
+      const int o = (item >> 2) * LDH + (item & 3) * 8;
+      *(f32x4*)&Bhi[o] = rbh[j];
+      *(f32x4*)&Blo[o] = rbl[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16)(0.f);
+
+  const int nchunk = sg.Cp / KC;
+  const int nsteps = T * nchunk;
+  int tap = 0, c0 = 0;
+  load_step(0, 0);
+  store_step();
+  __syncthreads();
+
+  const int arow = (wm * 64 + li) * LDH + lh * 8;
+  const int brow = (wn * 64 + li) * LDH + lh * 8;
+  for (int step = 0; step < nsteps; ++step) {
+    int ntap = tap + 1, nc0 = c0;
+    if (ntap == T) { ntap = 0; nc0 += KC; }
+    const bool more = step + 1 < nsteps;
+    if (more) load_step(ntap, nc0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *(const h8*)&Ahi[arow + t * 32 * LDH + ks * 16];
+        al[t] = *(const h8*)&Alo[arow + t * 32 * LDH + ks * 16];
+        bh[t] = *(const h8*)&Bhi[brow + t * 32 * LDH + ks * 16];
+        bl[t] = *(const h8*)&Blo[brow + t * 32 * LDH + ks * 16];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) store_step();
+    __syncthreads();
+    tap = ntap; c0 = nc0;
+  }
+
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = n0 + wn * 64 + tn * 32 + li;
+    const bool nok = n < p.Cout_store;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nok && m < M) p.out[m * p.out_pix_stride + p.out_ch_off + n] = act_apply(acc[tm][tn][r] * out_scale + bv, p.act);
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> two f16 arrays [tap][CoutP][Ktot] holding hi / lo of w * wscale (zero padded)
+__global__ void pack_weight_f16x2_k(const float* __restrict__ w, int Cout, int Cin, int T, int CoutP, int Ktot,
+                                    float wscale, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  const long long total = (long long)T * CoutP * Ktot;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Ktot);
+    long long q = i / Ktot;
+    const int n = (int)(q % CoutP);
+    const int t = (int)(q / CoutP);
+    float v = (n < Cout && k < Cin) ? w[((long long)n * Cin + k) * T + t] * wscale : 0.f;
+    const _Float16 h = (_Float16)v;
+    hi[i] = h;
+    lo[i] = (_Float16)(v - (float)h);
+  }
+}
+
+}  // namespace
+
+extern "C" int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot,
+                                           float wscale, void* whi, void* wlo, void* stream) {
+  EGNE_REQUIRE(w_oihw && whi && wlo && Cout > 0 && Cin > 0 && CoutP >= Cout && CoutP % 128 == 0 && Ktot >= Cin && Ktot % 32 == 0,
+               "pack_f16x2: bad sizes Cout %d Cin %d CoutP %d Ktot %d", Cout, Cin, CoutP, Ktot);
+  long long total = (long long)kh * kw * CoutP * Ktot, g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pack_weight_f16x2_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kh * kw, CoutP,
+                     Ktot, wscale, (_Float16*)whi, (_Float16*)wlo);
+  return egne::check_launch("egne_pack_conv_weight_f16x2");
+}
+
+// Same descriptor as egne_conv2d_fwd (d->w unused).  Requirements: one input slice without fused affine,
+// Cp % 32 == 0, stride 1, zero padding, ngroups 1, CoutP % 128 == 0 (pack pads), no post affine / residual.
+// a_scale / w_scale are the power-of-two pre-scales of activations / weights (w_scale must match the pack).
+extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, const void* wlo, float a_scale,
+                                     float w_scale, void* stream) {
+  EGNE_REQUIRE(dp && whi && wlo, "conv_f16x3: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.nseg == 1 && d.ngroups == 1 && d.stride == 1 && d.pad_mode == 0 && d.seg[0].scale == nullptr &&
+               d.post_scale == nullptr && d.residual == nullptr, "conv_f16x3: unsupported descriptor");
+  EGNE_REQUIRE(d.seg[0].Cp % 32 == 0 && d.seg[0].Cp == d.Ktot && d.CoutP % 128 == 0, "conv_f16x3: Cp %d CoutP %d", d.seg[0].Cp, d.CoutP);
+  EGNE_REQUIRE(d.seg[0].ptr && ((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0,
+               "conv_f16x3: input alignment");
+  EGNE_REQUIRE(((uintptr_t)whi & 15) == 0 && ((uintptr_t)wlo & 15) == 0 && d.out && d.Cout_store <= d.CoutP &&
+               d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv_f16x3: weights / output");
+  EGNE_REQUIRE(a_scale > 0.f && w_scale > 0.f, "conv_f16x3: scales");
+  {
+    const int dd = d.dil[0];
+    const int ho = d.H + 2 * d.pad_h * dd - dd * (d.kh - 1), wo = d.W + 2 * d.pad_w * dd - dd * (d.kw - 1);
+    EGNE_REQUIRE(ho == d.Ho && wo == d.Wo, "conv_f16x3: output %dx%d inconsistent with geometry", d.Ho, d.Wo);
+  }
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / BN));
+  hipLaunchKernelGGL(conv_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, (const _Float16*)whi, (const _Float16*)wlo,
+                     a_scale, 1.0f / (a_scale * w_scale));
+  return egne::check_launch("egne_conv2d_f16x3_fwd");
+}

@@ -16,6 +16,8 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
 import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
+F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
+F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "0") != "0"   # opt-in: measured slower than the MFMA path so far
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "60"))
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "32"))  # wider layers: flat kernel is faster (measured)
@@ -87,6 +89,10 @@ class ConvLayer:
         self.G = len(self.weights)
         self.wp = None
         self.wf = None          # fragment-order pack for the LDS-halo 3x3 kernel
+        self.split = False      # allow the split-f16 (f16x3) kernel for this layer (frozen nets only)
+        self.need_split = False
+        self.whi = self.wlo = None
+        self.w_scale = 1.0
         self.need_flat = False
         self.need_frag = False
         self.bp = None
@@ -103,7 +109,8 @@ class ConvLayer:
     def ensure_packed(self, dev):
         vers = tuple(w._version for w in self.weights) + tuple(
             (b._version if b is not None else -1) for b in (self.biases or []))
-        have = (self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+        have = ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+                and (self.whi is not None or not self.need_split))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
         L = _lib.lib()
@@ -129,6 +136,19 @@ class ConvLayer:
                                   self.CoutP, self.Ktot, _ptr(buf, g * T * self.CoutP * self.Ktot), st), "pack_conv_weight")
             if self.biases is not None and self.biases[g] is not None:
                 self.bp[g * self.CoutP: g * self.CoutP + self.Cout].copy_(self.biases[g].detach())
+        if self.need_split:
+            # power-of-two scale that puts max|w| in [1024, 2048): hi and lo halves both stay f16-normal
+            import math
+            wd = self.weights[0].detach().contiguous()
+            mx = float(wd.abs().max())          # host sync, at (re)pack time only
+            self.w_scale = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
+            cp128 = (self.Cout + 127) // 128 * 128
+            nh = T * cp128 * self.Ktot
+            if self.whi is None:
+                self.whi = torch.empty(nh, dtype=torch.float16, device=dev)
+                self.wlo = torch.empty(nh, dtype=torch.float16, device=dev)
+            _lib.check(L.egne_pack_conv_weight_f16x2(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, cp128, self.Ktot,
+                                                     self.w_scale, self.whi.data_ptr(), self.wlo.data_ptr(), st), "pack_f16x2")
         self._versions = vers
 
     def out_hw(self, H, W):
@@ -158,6 +178,9 @@ class DgradLayer(ConvLayer):
         self.Ktot, self.CoutP, self.Cout_store, self.G = fwd.Cout_store, pad32(C_), Cp_, 1
         self.wp = self.wf = self.bp = None
         self.need_flat = self.need_frag = False
+        self.split = self.need_split = False
+        self.whi = self.wlo = None
+        self.w_scale = 1.0
         self._versions, self.post = None, None
 
     def ensure_packed(self, dev):
@@ -252,9 +275,14 @@ class Plan:
         smallcin = (SMALLCIN_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                     and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] == 1
                     and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None)
-        if smallcin:
+        split = (F16X3_ENABLED and layer.split and layer.G == 1 and layer.stride == 1 and layer.pad_mode == 0
+                 and len(pieces) == 1 and pieces[0].scale is None and pieces[0].Cp % 32 == 0 and layer.Ktot == pieces[0].Cp
+                 and layer.Cin == pieces[0].Cp and residual is None and layer.post is None)
+        if smallcin or split:
             halo = False
-        if halo:
+        if split:
+            layer.need_split = True
+        elif halo:
             layer.need_frag = True
         else:
             layer.need_flat = True
@@ -275,8 +303,8 @@ class Plan:
             s.scale = p.scale.data_ptr() if p.scale is not None else None
             s.shift = p.shift.data_ptr() if p.shift is not None else None
             s.act_in = p.act_in
-        d.Ktot, d.CoutP = layer.Ktot, layer.CoutP
-        d.w = layer.wf.data_ptr() if halo else layer.wp.data_ptr()
+        d.Ktot, d.CoutP = layer.Ktot, ((layer.Cout + 127) // 128 * 128 if split else layer.CoutP)
+        d.w = layer.whi.data_ptr() if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
         d.bias = layer.bp.data_ptr() if layer.biases is not None else None
         d.act = layer.act
         if layer.post is not None:
@@ -288,7 +316,10 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if smallcin:
+        if split:
+            self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
+                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3")
+        elif smallcin:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.Cin), name, flops=flops, kind="conv3x3_smallcin")
         elif halo:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")

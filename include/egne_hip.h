@@ -100,6 +100,19 @@ int egne_conv3x3_halo_fwd(const egne_conv_desc* d, void* stream);
 int egne_pack_conv_weight_frag(const float* w_oihw, int Cout, int Cin, int kh, int kw,
                                const int32_t* kinv, int CoutP, int Ktot, float* w_packed, void* stream);
 
+/*
+ * Split-precision convolution for the FROZEN edge extractor (vgg16_c.py:66-78, bdcn_new.py:50): fp32 tensors,
+ * every operand split into two f16 halves (22-bit significand), three v_mfma_f32_32x32x16_f16 per product,
+ * fp32 accumulation -- 5.3x the matrix rate of the exact-fp32 MFMA.  Same descriptor as egne_conv2d_fwd
+ * (`w` unused; CoutP must be the 128-padded row count of the f16 pack).  One input slice without fused
+ * affine, Cp % 32 == 0, stride 1, zero padding.  a_scale / w_scale: exact power-of-two pre-scales that keep
+ * the low halves in the f16 normal range (w_scale is baked into the pack).
+ */
+int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot,
+                                float wscale, void* whi, void* wlo, void* stream);
+int egne_conv2d_f16x3_fwd(const egne_conv_desc* d, const void* whi, const void* wlo, float a_scale,
+                          float w_scale, void* stream);
+
 /* First layers (vgg16_c.py:66 conv1_1 on 3 channels, utils.py:1047 convBlock conv1 on 1-2 channels):
  * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  27-36 MACs per output make this a pure store
  * stream, so it runs as a direct VALU kernel (flat weight pack of egne_pack_conv_weight). */

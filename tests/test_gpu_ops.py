@@ -256,3 +256,30 @@ def test_errors_are_reported(G):
     assert rc == -1 and b"conv" in L.egne_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc, "conv")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,d", [(2, 64, 64, 33, 47, 1), (1, 128, 256, 20, 24, 1), (1, 512, 512, 9, 13, 2)])
+def test_conv_f16x3_split_precision(G, B, Cin, Cout, H, W, d):
+    """Split-f16 MFMA convolution (conv_f16x3.hip): error against a float64 convolution must be at the fp32
+    level (the fp32 CPU conv is measured against the same truth for comparison)."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = F.relu(_rand(G, B, Cin, H, W)) * 3          # post-ReLU activations, O(1-10)
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    truth = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=d, dilation=d))
+    ref32 = F.relu(F.conv2d(x, w, b, padding=d, dilation=d))
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1),
+                      dils=(d,), act=1)
+    layer.split = True
+    out = pl.buf(B, H, W, Cout)
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+    assert pl.meta[-1][0] == "conv_f16x3"
+    pl.run()
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    scale = truth.abs().max().item()
+    e_split, e_f32 = (got - truth).abs().max().item() / scale, (ref32.double() - truth).abs().max().item() / scale
+    print("f16x3 err %.2e  (fp32 CPU conv err %.2e)" % (e_split, e_f32))
+    assert e_split < 2e-6
