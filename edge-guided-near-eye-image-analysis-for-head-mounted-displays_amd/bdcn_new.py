@@ -157,6 +157,7 @@ class BDCN(nn.Module):
                 fi += 1
                 mb = getattr(self, "msblock" + b)
                 l0 = ConvLayer([mb.conv.weight], [mb.conv.bias], [(c_in, pad8(c_in))], pad=(1, 1), act=ACT_RELU)
+                l0.split = True
                 o = Piece(o_buf, 0, 32)
                 pl.conv(l0, [src], o, B, hh, ww, name="ms%s.conv" % b)
                 r = self.rate
@@ -164,6 +165,7 @@ class BDCN(nn.Module):
                 lg = ConvLayer([mb.conv1.weight, mb.conv2.weight, mb.conv3.weight],
                                [mb.conv1.bias, mb.conv2.bias, mb.conv3.bias], [(32, 32)], pad=(1, 1), dils=dil,
                                act=ACT_RELU)
+                lg.split = True
                 msb = pl.buf(B, hh, ww, 32)
                 pl.conv(lg, [o], Piece(msb, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b)
                 ms_bufs.append(msb)

@@ -137,19 +137,25 @@ class ConvLayer:
             if self.biases is not None and self.biases[g] is not None:
                 self.bp[g * self.CoutP: g * self.CoutP + self.Cout].copy_(self.biases[g].detach())
         if self.need_split:
-            # power-of-two scale that puts max|w| in [1024, 2048): hi and lo halves both stay f16-normal
+            # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
-            wd = self.weights[0].detach().contiguous()
-            mx = float(wd.abs().max())          # host sync, at (re)pack time only
+            ws = [w.detach().contiguous() for w in self.weights]
+            mx = max(float(w.abs().max()) for w in ws)          # host sync, at (re)pack time only
             self.w_scale = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
-            cp128 = (self.Cout + 127) // 128 * 128
-            nh = T * cp128 * self.Ktot
+            cps = self.split_coutp()
+            per = T * cps * self.Ktot
             if self.whi is None:
-                self.whi = torch.empty(nh, dtype=torch.float16, device=dev)
-                self.wlo = torch.empty(nh, dtype=torch.float16, device=dev)
-            _lib.check(L.egne_pack_conv_weight_f16x2(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, cp128, self.Ktot,
-                                                     self.w_scale, self.whi.data_ptr(), self.wlo.data_ptr(), st), "pack_f16x2")
+                self.whi = torch.empty(self.G * per, dtype=torch.float16, device=dev)
+                self.wlo = torch.empty(self.G * per, dtype=torch.float16, device=dev)
+            for g, wd in enumerate(ws):
+                _lib.check(L.egne_pack_conv_weight_f16x2(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, cps, self.Ktot,
+                                                         self.w_scale, self.whi.data_ptr() + 2 * g * per,
+                                                         self.wlo.data_ptr() + 2 * g * per, st), "pack_f16x2")
         self._versions = vers
+
+    def split_coutp(self):
+        """Row count of the f16 pack: 128-padded for wide layers (128x128 tile), 32-padded otherwise (256x32 tile)."""
+        return (self.Cout + 127) // 128 * 128 if (self.Cout >= 64 and self.G == 1) else self.CoutP
 
     def out_hw(self, H, W):
         d = self.dils[0]
@@ -275,9 +281,9 @@ class Plan:
         smallcin = (SMALLCIN_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                     and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] == 1
                     and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None)
-        split = (F16X3_ENABLED and layer.split and layer.G == 1 and layer.stride == 1 and layer.pad_mode == 0
+        split = (F16X3_ENABLED and layer.split and layer.stride == 1 and layer.pad_mode == 0
                  and len(pieces) == 1 and pieces[0].scale is None and pieces[0].Cp % 32 == 0 and layer.Ktot == pieces[0].Cp
-                 and layer.Cin == pieces[0].Cp and residual is None and layer.post is None)
+                 and layer.Cin == pieces[0].Cp and layer.post is None)
         if smallcin or split:
             halo = False
         if split:
@@ -303,7 +309,7 @@ class Plan:
             s.scale = p.scale.data_ptr() if p.scale is not None else None
             s.shift = p.shift.data_ptr() if p.shift is not None else None
             s.act_in = p.act_in
-        d.Ktot, d.CoutP = layer.Ktot, ((layer.Cout + 127) // 128 * 128 if split else layer.CoutP)
+        d.Ktot, d.CoutP = layer.Ktot, (layer.split_coutp() if split else layer.CoutP)
         d.w = layer.whi.data_ptr() if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
         d.bias = layer.bp.data_ptr() if layer.biases is not None else None
         d.act = layer.act

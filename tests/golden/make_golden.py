@@ -302,7 +302,7 @@ def gold_evaluate(bd):
     m = ref_esf(load_setting("baseline_edge")).eval()
     H, W = 240, 320
     Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
-    masks, inits, fits, ops = [], [], [], []
+    masks, inits, fits, ops, gaps = [], [], [], [], []
     for e in eyes:
         img = e.astype(np.float64)
         img = (img - img.mean()) / img.std()                      # evaluate.py:102
@@ -313,6 +313,8 @@ def gold_evaluate(bd):
             out = quiet(m, x, edge, lab.long(), torch.zeros(1, 2), torch.zeros(1, 2, 5), torch.zeros(1, H, W),
                         torch.zeros(1, 3, H, W), torch.zeros(1, 4), 0, 0)
         seg = U.get_predictions(out[0]).squeeze()
+        srt = out[0].sort(dim=1, descending=True)[0]
+        gaps.append(int(((srt[:, 0] - srt[:, 1]) < 2e-3).sum()))
         elp = out[1].squeeze().numpy()
         ini_p = HF.my_ellipse(elp[5:10]).transform(Hm)[0][:-1]
         ini_i = HF.my_ellipse(elp[0:5]).transform(Hm)[0][:-1]
@@ -321,7 +323,7 @@ def gold_evaluate(bd):
         masks.append(np.packbits(seg.numpy().astype(np.uint8) == 1)); masks.append(np.packbits(seg.numpy().astype(np.uint8) == 2))
         inits.append(np.stack([ini_i, ini_p])); fits.append(np.stack([fit_i, fit_p])); ops.append(npy(out[0][0, :, ::4, ::4]))
     save("evaluate_real_frames", eyes=eyes, masks=np.stack(masks), inits=np.stack(inits), fits=np.stack(fits),
-         op_sub=np.stack(ops))
+         op_sub=np.stack(ops), gap_lt_2e3=np.array(gaps))
 
 
 def gold_keys():

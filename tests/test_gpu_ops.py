@@ -283,3 +283,30 @@ def test_conv_f16x3_split_precision(G, B, Cin, Cout, H, W, d):
     e_split, e_f32 = (got - truth).abs().max().item() / scale, (ref32.double() - truth).abs().max().item() / scale
     print("f16x3 err %.2e  (fp32 CPU conv err %.2e)" % (e_split, e_f32))
     assert e_split < 2e-6
+
+
+def test_conv_f16x3_grouped_msblock(G):
+    """Split-f16 kernel, 256x32 tile, fused dilated group (bdcn_new.py:49-55) against float64."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    B, H, W = 2, 37, 53
+    o = F.relu(_rand(G, B, 32, H, W)) * 2
+    ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+    bs = [_rand(G, 32) for _ in range(3)]
+    truth = o.double()
+    for w, b, d in zip(ws, bs, (4, 8, 12)):
+        truth = truth + F.relu(F.conv2d(o.double(), w.double(), b.double(), padding=d, dilation=d))
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [o], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV)) for w in ws], [torch.nn.Parameter(b.to(DEV)) for b in bs], [(32, 32)],
+                      pad=(1, 1), dils=(4, 8, 12), act=1)
+    layer.split = True
+    out = pl.buf(B, H, W, 32)
+    pl.conv(layer, [px], Piece(out, 0, 32), B, H, W, residual=px)
+    assert pl.meta[-1][0] == "conv_f16x3"
+    pl.run()
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    err = (got - truth).abs().max().item() / truth.abs().max().item()
+    print("grouped f16x3 err %.2e" % err)
+    assert err < 2e-6

