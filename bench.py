@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"; the split kernel issues 3 MFMAs per product
 
 
 def parse():
@@ -161,8 +162,9 @@ def main():
         d[2] += 1
         pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
         pl_[0] += e0.elapsed_time(e1) * 1e-3 / a.steps
-    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad"))
-                              for i in range(3)]
+    FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad")
+    conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in FP32_FAM) for i in range(3)]
+    sp_t, sp_f, sp_n = fam.get("conv_f16x3", [0.0, 0.0, 0])
     if a.layers and rank == 0:
         for lname, (sec, fl, kind) in per_layer.items():
             print("%-26s %-18s %9.1f us %8.2f GFLOP %7.1f TFLOP/s" % (lname, kind, sec * 1e6, fl / 1e9, fl / sec / 1e12 if sec > 0 else 0),
@@ -184,12 +186,21 @@ def main():
                        "frames_per_gpu_per_step": B,
                        "parallelism": ("dp%d (one flat RCCL all-reduce of 13.45 MB per step)" % world) if train
                        else "replicas x%d (frames sharded, no collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (+ conv_wgrad_kernel in train mode): implicit-GEMM conv, fp32 MFMA 32x32x2, all tile variants",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (+ conv_wgrad_kernel in train mode): exact-fp32 implicit-GEMM conv on v_mfma_f32_32x32x2_f32 (ESF-Net and the BDCN layers not on the split kernel); dominant family by time",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                          "launches_per_step": conv_n // max(a.steps, 1),
                          "avg_launch_ms": round(1e3 * conv_t / max(conv_n, 1), 4),
-                         "algorithmic_gflop_per_frame": round(conv_f / a.steps / B / 1e9, 2)},
+                         "algorithmic_gflop_per_frame": round(conv_f / a.steps / B / 1e9, 2),
+                         "time_share": round(conv_t / max(sum(x[0] for x in fam.values()), 1e-9), 4)},
+            "roofline_split_f16": {"bound": "mfma", "kernel": "conv_f16x3_kernel (frozen BDCN: fp32 data, 3 f16 MFMAs per product, fp32 accumulate)",
+                                   "achieved": round(sp_f / sp_t / 1e12, 2) if sp_t > 0 else 0.0,
+                                   "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s (algorithmic fp32-equivalent; peak = 2500 dense f16 / 3)",
+                                   "frac": round(sp_f / sp_t / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3), 4) if sp_t > 0 else 0.0,
+                                   "traffic": None, "launches_per_step": sp_n // max(a.steps, 1),
+                                   "algorithmic_gflop_per_frame": round(sp_f / a.steps / B / 1e9, 2),
+                                   "time_share": round(sp_t / max(sum(x[0] for x in fam.values()), 1e-9), 4)},
+            "algorithmic_gflop_per_frame_total": round((conv_f + sp_f) / a.steps / B / 1e9, 2),
             "kernel_time_share": {k: round(v[0] / max(sum(x[0] for x in fam.values()), 1e-9), 4) for k, v in sorted(fam.items())},
             "gpu_busy_frac": round(sum(x[0] for x in fam.values()) / dt, 4),
         }
