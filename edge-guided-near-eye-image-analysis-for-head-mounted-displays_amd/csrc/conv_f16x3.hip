@@ -12,6 +12,7 @@
 // float64 convolution 4e-7..2e-6 (the fp32 CPU convolution: 2e-7..3e-7), edge map within 3e-6 of the reference;
 // ESF-Net (training, gradients) stays on the exact-fp32 kernels.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -72,17 +73,23 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 
   f32x4 ra[AR];
   f32x4 rbh[BI], rbl[BI];   // 8 halfs each (loaded as 16 B)
+  unsigned okmask = 0;
+  int st_c = 0;
   auto load_step = [&](int g, int tap, int c0) {
     const int dil = p.dil[g];
     const int ky = tap / p.kw, kx = tap - ky * p.kw;
     const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+    const bool cok = c0 + col4 * 4 < sg.Cp;     // channel tail of a slice whose width is not a multiple of 32
+    okmask = 0;
+    st_c = c0 + col4 * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int iy = py[i] + dy, ix = px[i] + dx;
-      const bool ok = pb[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const bool ok = cok && pb[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + col4 * 4;
       src = ok ? src : egne_zero_page;
       ra[i] = *(const f32x4*)src;
+      okmask |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -95,6 +102,30 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
     }
   };
   auto store_step = [&]() {
+    if (sg.scale) {   // fused InstanceNorm affine (+ activation) of the consumer, zero padding applied after it
+      const bool same = pb[0] == pb[AR - 1] && pb[0] >= 0 && st_c < sg.Cp;
+      f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
+      if (same) {
+        sc0 = *(const f32x4*)(sg.scale + (long long)pb[0] * sg.Cp + st_c);
+        sh0 = *(const f32x4*)(sg.shift + (long long)pb[0] * sg.Cp + st_c);
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = (okmask >> i) & 1u;
+        f32x4 sc = sc0, sh = sh0;
+        if (!same) {
+          sc = *(const f32x4*)(ok ? sg.scale + (long long)pb[i] * sg.Cp + st_c : egne_zero_page);
+          sh = *(const f32x4*)(ok ? sg.shift + (long long)pb[i] * sg.Cp + st_c : egne_zero_page);
+        } else if (!ok) {
+          sc = (f32x4)(0.f); sh = (f32x4)(0.f);
+        }
+        f32x4 v = ra[i] * sc + sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = sg.act_in == EGNE_ACT_LEAKY ? (v[e] > 0.f ? v[e] : 0.01f * v[e]) : (sg.act_in == EGNE_ACT_RELU ? fmaxf(v[e], 0.f) : v[e]);
+        ra[i] = v;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       h4 hi, lo;
@@ -130,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
       if (GROUPED) res[a][b] = (f32x16)(0.f);
     }
 
-  const int nchunk = sg.Cp / KC;
+  const int nchunk = (sg.Cp + KC - 1) / KC;
   const int nsteps = T * nchunk * p.ngroups;
   int g = 0, tap = 0, c0 = 0;
   load_step(0, 0, 0);
@@ -197,6 +228,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
         const long long m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (nok && m < M) {
           float v = GROUPED ? res[tm][tn][r] : act_apply(acc[tm][tn][r] * out_scale + bv, p.act);
+          if (p.post_scale) v = v * p.post_scale[n] + p.post_shift[n];
           if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
           p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
         }
@@ -243,8 +275,9 @@ extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, 
   EGNE_REQUIRE(dp && whi && wlo, "conv_f16x3: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.nseg == 1 && d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP && d.stride == 1 && d.pad_mode == 0 &&
-               d.seg[0].scale == nullptr && d.post_scale == nullptr, "conv_f16x3: unsupported descriptor");
-  EGNE_REQUIRE(d.seg[0].Cp % 32 == 0 && d.seg[0].Cp == d.Ktot && d.CoutP % 32 == 0, "conv_f16x3: Cp %d CoutP %d", d.seg[0].Cp, d.CoutP);
+               (d.seg[0].scale == nullptr) == (d.seg[0].shift == nullptr), "conv_f16x3: unsupported descriptor");
+  EGNE_REQUIRE(d.seg[0].Cp % 8 == 0 && (d.seg[0].Cp + 31) / 32 * 32 == d.Ktot && d.CoutP % 32 == 0,
+               "conv_f16x3: Cp %d Ktot %d (must be Cp rounded up to 32) CoutP %d", d.seg[0].Cp, d.Ktot, d.CoutP);
   EGNE_REQUIRE(d.seg[0].ptr && ((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0,
                "conv_f16x3: input alignment");
   EGNE_REQUIRE(((uintptr_t)whi & 15) == 0 && ((uintptr_t)wlo & 15) == 0 && d.out && d.Cout_store <= d.CoutP &&
@@ -261,9 +294,16 @@ extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, 
   hipStream_t st = (hipStream_t)stream;
   const _Float16* h = (const _Float16*)whi;
   const _Float16* l = (const _Float16*)wlo;
-  if (d.CoutP % 128 == 0 && d.ngroups == 1) {
+  static const int big = [] { const char* e = getenv("EGNE_SPLIT_BIG"); return e ? atoi(e) : 0; }();
+  if (d.CoutP % 128 == 0 && d.ngroups == 1 && big && M >= 256 * 512) {
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)(d.CoutP / 128));
+    hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
+  } else if (d.CoutP % 128 == 0 && d.ngroups == 1) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)(d.CoutP / 128));
     hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
+  } else if (d.CoutP % 64 == 0 && d.ngroups == 1) {
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)(d.CoutP / 64));
+    hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
   } else {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)(d.CoutP / 32));
     if (d.ngroups > 1) hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 1, true>), grid, dim3(256), 0, st, d, h, l, a_scale, os);

@@ -46,7 +46,13 @@ def dec_sizes(chz, growth, add_edge, variant):
 
 
 def _cl(conv, layout, pad=(0, 0), act=ACT_NONE, **kw):
-    return ConvLayer([conv.weight], [conv.bias] if conv.bias is not None else None, layout, pad=pad, act=act, **kw)
+    l = ConvLayer([conv.weight], [conv.bias] if conv.bias is not None else None, layout, pad=pad, act=act, **kw)
+    from . import engine
+    l.split = engine.ESF_SPLIT and _cl.eval_plan and (l.kh > 1 or l.kw > 1)
+    return l
+
+
+_cl.eval_plan = False
 
 
 def _lay(pieces):
@@ -131,6 +137,7 @@ def build_forward_plan(model, B, H, W, dev, training):
     pl = Plan(dev, train=training)
     L = pl.L
     pl.dbg = {}
+    _cl.eval_plan = not training
 
     # ---- inputs (persistent; forward() copies the caller's tensors in) -----------------------------
     pl.in_img = pl.vec(B, 1, H, W)

@@ -104,8 +104,8 @@ int egne_pack_conv_weight_frag(const float* w_oihw, int Cout, int Cin, int kh, i
  * Split-precision convolution for the FROZEN edge extractor (vgg16_c.py:66-78, bdcn_new.py:50): fp32 tensors,
  * every operand split into two f16 halves (22-bit significand), three v_mfma_f32_32x32x16_f16 per product,
  * fp32 accumulation -- 5.3x the matrix rate of the exact-fp32 MFMA.  Same descriptor as egne_conv2d_fwd
- * (`w` unused; CoutP must be the 128-padded row count of the f16 pack).  One input slice without fused
- * affine, Cp % 32 == 0, stride 1, zero padding.  a_scale / w_scale: exact power-of-two pre-scales that keep
+ * (`w` unused; CoutP = row count of the f16 pack, Ktot = slice width rounded up to 32).  One input slice
+ * (fused affine allowed), stride 1, zero padding; ngroups = 3 fuses the MSBlock dilated branch.  a_scale / w_scale: exact power-of-two pre-scales that keep
  * the low halves in the f16 normal range (w_scale is baked into the pack).
  */
 int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot,
