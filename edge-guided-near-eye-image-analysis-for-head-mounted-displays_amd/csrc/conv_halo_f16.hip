@@ -1,0 +1,297 @@
+// 3x3 "same" convolution with an LDS-resident halo tile on the split-f16 MFMA path (fp32 tensors, three
+// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; see conv_f16x3.hip for the numerics).
+//
+// With the matrix work 5x cheaper, the narrow (Cout = 32 / 64) full-resolution layers of ESF-Net and of the
+// BDCN MSBlocks are bound by re-gathering their input 9 times from L2.  As in conv_halo.hip a workgroup owns
+// an 8 x 32 block of output pixels: the (8+2d) x (32+2d) halo is fetched ONCE per 32 channels, converted to
+// hi/lo halves while it is written to LDS (80-B pixel pitch, conflict-free ds_read_b128), and the 9 taps
+// are address offsets into it.  Weight fragments ([tap][k/16][n/32][lane][8 halfs], hi and lo) come from L2
+// through a 4-slot register ring; workgroups walk tiles grid-stride with the next halo prefetched.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32, LDH = 40, TW = 32;
+
+__device__ __forceinline__ float act1(float v, int act) {
+  if (act == EGNE_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EGNE_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+template <int WM, int WN, int D>
+__global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
+                                                               const _Float16* __restrict__ flo, float a_scale,
+                                                               float out_scale, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int TH = 4 * WM;
+  constexpr int d = D;
+  constexpr int HWd = TW + 2 * d, HHd = TH + 2 * d, npx = HHd * HWd;
+  constexpr int nitems = npx * 8;
+  constexpr int NI = (nitems + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+  _Float16* Ahi = ldsh;
+  _Float16* Alo = ldsh + npx * LDH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nt0 = blockIdx.y * WN;
+  const int NT = p.CoutP >> 5, KT16 = p.Ktot >> 4;
+  const egne_seg sg = p.seg[0];
+  const int Cp = sg.Cp;
+  const int c4 = tid & 7;
+
+  struct Tile { int b, y0, x0; };
+  auto tile_of = [&](int t) {
+    Tile r;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    r.b = t / tiles_y; r.y0 = ty * TH; r.x0 = tx * TW;
+    return r;
+  };
+
+  int goff[NI];
+  const float* src = sg.ptr;
+  int stage_b = 0;
+  auto map_tile = [&](const Tile& tl) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + 256 * i;
+      goff[i] = -1;
+      if (item < nitems) {
+        const int px = item >> 3;
+        const int hy = px / HWd, hx = px - hy * HWd;
+        const int iy = tl.y0 - d + hy, ix = tl.x0 - d + hx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+          goff[i] = (int)((((long long)iy * p.W + ix) * sg.pix_stride) + sg.ch_off + c4 * 4);
+      }
+    }
+    src = sg.ptr + (long long)tl.b * p.H * p.W * sg.pix_stride;
+    stage_b = tl.b;
+  };
+
+  f32x4 st[NI];
+  f32x4 st_sc = {1.f, 1.f, 1.f, 1.f}, st_sh = {0.f, 0.f, 0.f, 0.f};
+  bool st_cok = true;
+  auto load_chunk = [&](int c0) {
+    const bool cok = c0 + c4 * 4 < Cp;
+    st_cok = cok;
+    if (sg.scale) {
+      st_sc = *(const f32x4*)(cok ? sg.scale + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page);
+      st_sh = *(const f32x4*)(cok ? sg.shift + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float* q = (goff[i] >= 0 && cok) ? src + goff[i] + c0 : egne_zero_page;
+      st[i] = *(const f32x4*)q;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + 256 * i;
+      if (item < nitems) {
+        f32x4 v = st[i];
+        if (sg.scale) {
+          v = v * st_sc + st_sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = sg.act_in == EGNE_ACT_LEAKY ? (v[e] > 0.f ? v[e] : 0.01f * v[e]) : (sg.act_in == EGNE_ACT_RELU ? fmaxf(v[e], 0.f) : v[e]);
+          if (!(goff[i] >= 0 && st_cok)) v = (f32x4)(0.f);
+        }
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[e] * a_scale;
+          const _Float16 h = (_Float16)x;
+          hi[e] = h;
+          lo[e] = (_Float16)(x - (float)h);
+        }
+        const int o = (item >> 3) * LDH + c4 * 4;
+        *(h4*)&Ahi[o] = hi;
+        *(h4*)&Alo[o] = lo;
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
+
+  // fragment-order weights: element ((tap*KT16 + k16)*NT + nt)*512 + lane*8 (halfs)
+  const long long stride_k16 = (long long)NT * 512, stride_tap = (long long)KT16 * NT * 512;
+  const long long wlane = (long long)nt0 * 512 + lane * 8;
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  Tile cur = tile_of(t);
+  map_tile(cur);
+  load_chunk(0);
+  int c0 = 0;
+  const int abase = (wave * WM * HWd + li) * LDH + lh * 8;
+  while (true) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    const bool last_chunk = c0 + KC >= Cp;
+    const int tnext = t + gridDim.x;
+    if (!last_chunk) {
+      load_chunk(c0 + KC);
+    } else if (tnext < ntiles) {
+      const Tile nx = tile_of(tnext);
+      map_tile(nx);
+      load_chunk(0);
+    }
+    const long long wchunk = wlane + (long long)(c0 >> 4) * stride_k16;
+    // 4-slot ring: slot = (tap & 1) * 2 + ks holds the fragments of (tap, ks); refilled two taps ahead
+    f32x4 qh[4][WN], ql[4][WN];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int tn = 0; tn < WN; ++tn) {
+        const long long o = wchunk + (long long)(s >> 1) * stride_tap + (long long)(s & 1) * stride_k16 + tn * 512;
+        qh[s][tn] = *(const f32x4*)(fhi + o);
+        ql[s][tn] = *(const f32x4*)(flo + o);
+      }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int aoff = abase + (ky * d * HWd + kx * d) * LDH;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = (tap & 1) * 2 + ks;
+        h8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm) {
+          ah[tm] = *(const h8*)&Ahi[aoff + tm * HWd * LDH + ks * 16];
+          al[tm] = *(const h8*)&Alo[aoff + tm * HWd * LDH + ks * 16];
+        }
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn) {
+          bh[tn] = __builtin_bit_cast(h8, qh[slot][tn]);
+          bl[tn] = __builtin_bit_cast(h8, ql[slot][tn]);
+        }
+        if (tap + 2 < 9) {
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn) {
+            const long long o = wchunk + (long long)(tap + 2) * stride_tap + (long long)ks * stride_k16 + tn * 512;
+            qh[slot][tn] = *(const f32x4*)(fhi + o);
+            ql[slot][tn] = *(const f32x4*)(flo + o);
+          }
+        }
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+    }
+    if (!last_chunk) { c0 += KC; continue; }
+
+#pragma unroll
+    for (int tn = 0; tn < WN; ++tn) {
+      const int n = (nt0 + tn) * 32 + li;
+      const bool nok = n < p.Cout_store;
+      const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+      float ps = 1.f, pt = 0.f;
+      if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+#pragma unroll
+      for (int tm = 0; tm < WM; ++tm) {
+        const int y = cur.y0 + wave * WM + tm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (nok && y < p.H && x < p.W) {
+            const long long m = ((long long)cur.b * p.H + y) * p.W + x;
+            float v = act1(acc[tm][tn][r] * out_scale + bv, p.act);
+            if (p.post_scale) v = v * ps + pt;
+            if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
+            p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
+          }
+        }
+        acc[tm][tn] = (f32x16)(0.f);
+      }
+    }
+    t = tnext;
+    if (t >= ntiles) break;
+    cur = tile_of(t);
+    c0 = 0;
+  }
+}
+
+// OIHW fp32 -> hi / lo f16 in fragment order [tap][Ktot/16][CoutP/32][lane = h*32 + n%32][8]: k = 16*k16 + 8*h + j
+__global__ void pack_weight_f16frag_k(const float* __restrict__ w, int Cout, int Cin, int T, int CoutP, int Ktot, float wscale,
+                                      _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  const long long total = (long long)T * CoutP * Ktot;
+  const int NT = CoutP >> 5;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), nn = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    long long q = i >> 9;
+    const int nt = (int)(q % NT); q /= NT;
+    const int k16 = (int)(q % (Ktot >> 4));
+    const int t = (int)(q / (Ktot >> 4));
+    const int n = nt * 32 + nn, k = k16 * 16 + h * 8 + j;
+    const float v = (n < Cout && k < Cin) ? w[((long long)n * Cin + k) * T + t] * wscale : 0.f;
+    const _Float16 hh = (_Float16)v;
+    hi[i] = hh;
+    lo[i] = (_Float16)(v - (float)hh);
+  }
+}
+
+template <int WM, int WN, int D>
+int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
+  constexpr int TH = 4 * WM;
+  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+  const size_t lds = (size_t)2 * (TH + 2 * D) * (TW + 2 * D) * LDH * sizeof(_Float16);
+  const int ntiles = tiles_x * tiles_y * d.B, ny = d.CoutP / (32 * WN);
+  int gx = (256 * 2 + ny - 1) / ny;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
+                     tiles_y, ntiles);
+  return egne::check_launch("egne_conv3x3_halo_f16_fwd");
+}
+
+}  // namespace
+
+extern "C" int egne_pack_conv_weight_f16frag(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot,
+                                             float wscale, void* fhi, void* flo, void* stream) {
+  EGNE_REQUIRE(w_oihw && fhi && flo && Cout > 0 && Cin > 0 && CoutP >= Cout && CoutP % 32 == 0 && Ktot >= Cin && Ktot % 32 == 0,
+               "pack_f16frag: bad sizes Cout %d Cin %d CoutP %d Ktot %d", Cout, Cin, CoutP, Ktot);
+  long long total = (long long)kh * kw * CoutP * Ktot, g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pack_weight_f16frag_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kh * kw, CoutP,
+                     Ktot, wscale, (_Float16*)fhi, (_Float16*)flo);
+  return egne::check_launch("egne_pack_conv_weight_f16frag");
+}
+
+// 3x3 / stride 1 / pad 1 / dilation 1-2 / one input slice (fused affine allowed) / CoutP 32 or 64; Ktot = slice
+// width rounded up to 32; weights in the fragment order of egne_pack_conv_weight_f16frag.
+extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale,
+                                         float w_scale, void* stream) {
+  EGNE_REQUIRE(dp && fhi && flo, "conv_halo_f16: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_mode == 0 && d.ngroups == 1 && d.nseg == 1 && d.pad_h == 1 &&
+               d.pad_w == 1 && d.dil[0] >= 1 && d.dil[0] <= 2 && d.Ho == d.H && d.Wo == d.W, "conv_halo_f16: geometry not supported");
+  const egne_seg& g = d.seg[0];
+  EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
+               ((uintptr_t)g.ptr & 15) == 0 && (g.scale == nullptr) == (g.shift == nullptr), "conv_halo_f16: input slice");
+  EGNE_REQUIRE((d.CoutP == 32 || d.CoutP == 64) && d.Cout_store <= d.CoutP && d.out && d.out_ch_off + d.Cout_store <= d.out_pix_stride,
+               "conv_halo_f16: CoutP %d", d.CoutP);
+  EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv_halo_f16: weights / scales");
+  EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride < (1ll << 31), "conv_halo_f16: frame too large for 32-bit offsets");
+  const float os = 1.0f / (a_scale * w_scale);
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16* h = (const _Float16*)fhi;
+  const _Float16* l = (const _Float16*)flo;
+  if (d.dil[0] == 1) return d.CoutP == 64 ? launch_hf<2, 2, 1>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1>(d, h, l, a_scale, os, st);
+  return d.CoutP == 64 ? launch_hf<2, 2, 2>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2>(d, h, l, a_scale, os, st);
+}

@@ -17,6 +17,7 @@ import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
+HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))
@@ -93,7 +94,9 @@ class ConvLayer:
         self.wf = None          # fragment-order pack for the LDS-halo 3x3 kernel
         self.split = False      # allow the split-f16 (f16x3) kernel for this layer (frozen nets only)
         self.need_split = False
+        self.need_sfrag = False  # fragment-order f16 pack for the split-f16 halo kernel
         self.whi = self.wlo = None
+        self.fhi = self.flo = None
         self.w_scale = 1.0
         self.need_flat = False
         self.need_frag = False
@@ -112,7 +115,7 @@ class ConvLayer:
         vers = tuple(w._version for w in self.weights) + tuple(
             (b._version if b is not None else -1) for b in (self.biases or []))
         have = ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
-                and (self.whi is not None or not self.need_split))
+                and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
         L = _lib.lib()
@@ -138,7 +141,7 @@ class ConvLayer:
                                   self.CoutP, self.Ktot, _ptr(buf, g * T * self.CoutP * self.Ktot), st), "pack_conv_weight")
             if self.biases is not None and self.biases[g] is not None:
                 self.bp[g * self.CoutP: g * self.CoutP + self.Cout].copy_(self.biases[g].detach())
-        if self.need_split:
+        if self.need_split or self.need_sfrag:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
             ws = [w.detach().contiguous() for w in self.weights]
@@ -147,13 +150,21 @@ class ConvLayer:
             cps = self.split_coutp()
             kts = pad32(self.Ktot)           # single slice: logical channels first, zero columns up to a multiple of 32
             per = T * cps * kts
-            if self.whi is None:
-                self.whi = torch.empty(self.G * per, dtype=torch.float16, device=dev)
-                self.wlo = torch.empty(self.G * per, dtype=torch.float16, device=dev)
-            for g, wd in enumerate(ws):
-                _lib.check(L.egne_pack_conv_weight_f16x2(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, cps, kts,
-                                                         self.w_scale, self.whi.data_ptr() + 2 * g * per,
-                                                         self.wlo.data_ptr() + 2 * g * per, st), "pack_f16x2")
+            if self.need_split:
+                if self.whi is None:
+                    self.whi = torch.empty(self.G * per, dtype=torch.float16, device=dev)
+                    self.wlo = torch.empty(self.G * per, dtype=torch.float16, device=dev)
+                for g, wd in enumerate(ws):
+                    _lib.check(L.egne_pack_conv_weight_f16x2(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, cps, kts,
+                                                             self.w_scale, self.whi.data_ptr() + 2 * g * per,
+                                                             self.wlo.data_ptr() + 2 * g * per, st), "pack_f16x2")
+            if self.need_sfrag:
+                perf = T * self.CoutP * kts
+                if self.fhi is None:
+                    self.fhi = torch.empty(perf, dtype=torch.float16, device=dev)
+                    self.flo = torch.empty(perf, dtype=torch.float16, device=dev)
+                _lib.check(L.egne_pack_conv_weight_f16frag(ws[0].data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.CoutP, kts,
+                                                           self.w_scale, self.fhi.data_ptr(), self.flo.data_ptr(), st), "pack_f16frag")
         self._versions = vers
 
     def split_coutp(self):
@@ -187,8 +198,8 @@ class DgradLayer(ConvLayer):
         self.Ktot, self.CoutP, self.Cout_store, self.G = fwd.Cout_store, pad32(C_), Cp_, 1
         self.wp = self.wf = self.bp = None
         self.need_flat = self.need_frag = False
-        self.split = self.need_split = False
-        self.whi = self.wlo = None
+        self.split = self.need_split = self.need_sfrag = False
+        self.whi = self.wlo = self.fhi = self.flo = None
         self.w_scale = 1.0
         self._versions, self.post = None, None
 
@@ -284,10 +295,19 @@ class Plan:
         smallcin = (SMALLCIN_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                     and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] == 1
                     and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None)
-        split = (F16X3_ENABLED and layer.split and layer.stride == 1 and layer.pad_mode == 0 and len(pieces) == 1)
+        split = (F16X3_ENABLED and layer.split and layer.stride == 1 and layer.pad_mode == 0 and len(pieces) == 1
+                 and pieces[0].Cp >= 32 and layer.Cout >= 8)
+        # narrow 3x3 layers on wide images: split-f16 arithmetic AND the LDS halo (input fetched once for 9 taps)
+        shalo = (split and HALO_F16_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.G == 1 and layer.pad == (1, 1)
+                 and layer.dils[0] <= 2 and W >= HALO_MIN_W and layer.CoutP in (32, 64) and residual is None
+                 and H * W * pieces[0].stride < 2 ** 31)
+        if split and not shalo and halo and pieces[0].scale is not None:
+            split = False            # fused-affine layers: the fp32 halo kernel beats the flat split kernel
         if smallcin or split:
             halo = False
-        if split:
+        if shalo:
+            layer.need_sfrag = True
+        elif split:
             layer.need_split = True
         elif halo:
             layer.need_frag = True
@@ -311,7 +331,9 @@ class Plan:
             s.shift = p.shift.data_ptr() if p.shift is not None else None
             s.act_in = p.act_in
         d.Ktot, d.CoutP = (pad32(layer.Ktot), layer.split_coutp()) if split else (layer.Ktot, layer.CoutP)
-        d.w = layer.whi.data_ptr() if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
+        if shalo:
+            d.CoutP = layer.CoutP
+        d.w = (layer.fhi.data_ptr() if shalo else layer.whi.data_ptr()) if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
         d.bias = layer.bp.data_ptr() if layer.biases is not None else None
         d.act = layer.act
         if layer.post is not None:
@@ -323,7 +345,10 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if split:
+        if shalo:
+            self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
+                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3")
+        elif split:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
                                                      layer.w_scale), name, flops=flops, kind="conv_f16x3")
         elif smallcin:

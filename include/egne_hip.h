@@ -113,6 +113,14 @@ int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Cin, int kh, 
 int egne_conv2d_f16x3_fwd(const egne_conv_desc* d, const void* whi, const void* wlo, float a_scale,
                           float w_scale, void* stream);
 
+/* Split-f16 variant of the LDS-halo 3x3 kernel (narrow full-resolution layers: Cout 32 / 64, dilation <= 2, one
+ * input slice, fused affine allowed).  Weights: hi / lo f16 in MFMA-fragment order
+ * [tap][Ktot/16][CoutP/32][lane][8], Ktot = slice width rounded up to 32. */
+int egne_pack_conv_weight_f16frag(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot,
+                                  float wscale, void* fhi, void* flo, void* stream);
+int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
+                              float w_scale, void* stream);
+
 /* First layers (vgg16_c.py:66 conv1_1 on 3 channels, utils.py:1047 convBlock conv1 on 1-2 channels):
  * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  27-36 MACs per output make this a pure store
  * stream, so it runs as a direct VALU kernel (flat weight pack of egne_pack_conv_weight). */
