@@ -59,7 +59,7 @@ SIGNATURES = {
     "egne_pack_conv_weight_frag": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     "egne_conv3x3_halo_supported": (i32, [C.POINTER(ConvDesc)]),
     "egne_conv3x3_halo_fwd": (i32, [C.POINTER(ConvDesc), vp]),
-    "egne_conv3x3_smallcin_fwd": (i32, [C.POINTER(ConvDesc), i32, vp]),
+    "egne_conv3x3_smallcin_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
     "egne_pack_conv_weight_f16x2": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "egne_conv2d_f16x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_pack_conv_weight_f16frag": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -252,42 +252,81 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   }
 }
 
-// First layers (Cin <= 4: grey frame / 3 replicated channels): 27..36 MACs per output, so the layer is a
-// pure 128-256 B/pixel store stream.  Direct VALU kernel: lane = output channel (weights in registers),
-// a few pixel slots per workgroup; the <= 36 input values of a pixel are wave-uniform broadcast loads.
-template <int CG>
-__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const egne_conv_desc p, int cin) {
-  constexpr int SLOTS = 256 / CG;
-  const int c = threadIdx.x % CG, slot = threadIdx.x / CG;
-  float w[9][4];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w[t][k] = (k < cin && c < p.CoutP) ? p.w[((long long)t * p.CoutP + c) * p.Ktot + k] : 0.f;
-  const float bv = (p.bias && c < p.CoutP) ? p.bias[c] : 0.f;
-  const float ps = p.post_scale ? p.post_scale[c] : 1.f, pt = p.post_scale ? p.post_shift[c] : 0.f;
-  const egne_seg sg = p.seg[0];
+// First layers (Cin <= 4: grey frame / 3 replicated channels).  With 8..32 useful K per tap the tap-by-tap
+// implicit GEMM spends its time in 9 staging rounds; here the 9 taps are folded INTO K: one pixel row of the
+// A tile is [tap0 c0..c3 | tap1 c0..c3 | ... | tap8 c0..c3 | 0 0 0 0] (K = 40), staged once, one barrier, 20
+// fp32 MFMAs per 32x32 tile.  The layer is then a pure store stream (128-256 B per pixel).
+constexpr int C4K = 40, C4LD = 44;
+template <int WN>
+__global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p, const float* __restrict__ w40) {
+  __shared__ __attribute__((aligned(16))) float As[256 * C4LD];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * WN * C4LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
   const long long M = (long long)p.B * p.H * p.W;
-  const bool cok = c < p.Cout_store;
-  for (long long m = (long long)blockIdx.x * SLOTS + slot; m < M; m += (long long)gridDim.x * SLOTS) {
+  const long long m0 = (long long)blockIdx.x * 256;
+  const egne_seg sg = p.seg[0];
+  {
+    const long long m = m0 + tid;
     const int hw = p.H * p.W;
-    const int b = (int)(m / hw);
-    const int r = (int)(m - (long long)b * hw);
+    const int b = m < M ? (int)(m / hw) : 0;
+    const int r = m < M ? (int)(m - (long long)b * hw) : 0;
     const int y = r / p.W, x = r - y * p.W;
-    float acc = bv;
+    f32x4 v[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const bool ok = m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const float* src = ok ? sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off : egne_zero_page;
-      const f32x4 v = *(const f32x4*)src;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc = fmaf(v[k], w[t][k], acc);
+      v[t] = *(const f32x4*)src;
     }
-    if (cok) {
-      float v = act_apply(acc, p.act);
-      if (p.post_scale) v = v * ps + pt;
-      p.out[m * p.out_pix_stride + p.out_ch_off + c] = v;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *(f32x4*)&As[tid * C4LD + t * 4] = v[t];
+    *(f32x4*)&As[tid * C4LD + 36] = (f32x4)(0.f);
+    for (int i = tid; i < 32 * WN * 10; i += 256) {
+      const int n = i / 10, q = i - n * 10;
+      *(f32x4*)&Bs[n * C4LD + q * 4] = *(const f32x4*)(w40 + (long long)n * C4K + q * 4);
+    }
+  }
+  __syncthreads();
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    f32x4 a[2], bq[WN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const f32x4*)&As[(wave * 64 + tm * 32 + li) * C4LD + s * 8 + lh * 4];
+#pragma unroll
+    for (int tn = 0; tn < WN; ++tn) bq[tn] = *(const f32x4*)&Bs[(tn * 32 + li) * C4LD + s * 8 + lh * 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], bq[tn][j], acc[tm][tn], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tn = 0; tn < WN; ++tn) {
+    const int n = tn * 32 + li;
+    const bool nok = n < p.Cout_store;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+    float ps = 1.f, pt = 0.f;
+    if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nok && m < M) {
+          float v = act_apply(acc[tm][tn][r] + bv, p.act);
+          if (p.post_scale) v = v * ps + pt;
+          p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
+        }
+      }
     }
   }
 }
@@ -306,25 +345,23 @@ int launch(const egne_conv_desc& d, hipStream_t st) {
 
 }  // namespace
 
-// 3x3 / stride 1 / pad 1 / one slice / logical Cin <= 4 / Cout_store <= 64 (vgg16_c.py conv1_1, convBlock head conv1)
-extern "C" int egne_conv3x3_smallcin_fwd(const egne_conv_desc* dp, int cin, void* stream) {
-  EGNE_REQUIRE(dp != nullptr, "conv_smallcin: null descriptor");
+// 3x3 / stride 1 / pad 1 / one slice / logical Cin <= 4 / Cout_store <= 64 (vgg16_c.py conv1_1, convBlock head conv1).
+// w40: [CoutP][40] fp32, column tap*4 + c (zero padded) -- packed by the host at load time.
+extern "C" int egne_conv3x3_smallcin_fwd(const egne_conv_desc* dp, const float* w40, void* stream) {
+  EGNE_REQUIRE(dp != nullptr && w40 != nullptr, "conv_smallcin: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_h == 1 && d.pad_w == 1 && d.pad_mode == 0 && d.ngroups == 1 &&
                d.dil[0] == 1 && d.nseg == 1 && d.Ho == d.H && d.Wo == d.W, "conv_smallcin: geometry not supported");
-  EGNE_REQUIRE(cin >= 1 && cin <= 4 && d.seg[0].Cp >= 4 && d.seg[0].scale == nullptr, "conv_smallcin: Cin %d / fused affine not supported", cin);
-  EGNE_REQUIRE(d.Cout_store <= 64 && d.CoutP % 32 == 0 && d.w && d.out && d.residual == nullptr, "conv_smallcin: Cout");
-  EGNE_REQUIRE(((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0, "conv_smallcin: alignment");
+  EGNE_REQUIRE(d.seg[0].Cp >= 4 && d.seg[0].scale == nullptr, "conv_smallcin: fused affine not supported");
+  EGNE_REQUIRE(d.Cout_store <= 64 && d.out && d.residual == nullptr, "conv_smallcin: Cout");
+  EGNE_REQUIRE(((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0 && ((uintptr_t)w40 & 15) == 0,
+               "conv_smallcin: alignment");
   EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv_smallcin: output slice exceeds pixel stride");
   const long long M = (long long)d.B * d.H * d.W;
   hipStream_t st = (hipStream_t)stream;
-  if (d.Cout_store <= 32) {
-    long long g = (M + 8 * 16 - 1) / (8 * 16); if (g > 16384) g = 16384;
-    hipLaunchKernelGGL((conv3x3_smallcin_kernel<32>), dim3((unsigned)g), dim3(256), 0, st, d, cin);
-  } else {
-    long long g = (M + 4 * 16 - 1) / (4 * 16); if (g > 16384) g = 16384;
-    hipLaunchKernelGGL((conv3x3_smallcin_kernel<64>), dim3((unsigned)g), dim3(256), 0, st, d, cin);
-  }
+  dim3 grid((unsigned)((M + 255) / 256));
+  if (d.Cout_store <= 32) hipLaunchKernelGGL((conv3x3_c4_kernel<1>), grid, dim3(256), 0, st, d, w40);
+  else hipLaunchKernelGGL((conv3x3_c4_kernel<2>), grid, dim3(256), 0, st, d, w40);
   return egne::check_launch("egne_conv3x3_smallcin_fwd");
 }
 

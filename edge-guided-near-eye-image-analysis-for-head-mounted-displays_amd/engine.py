@@ -21,7 +21,7 @@ HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))
-SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "0") != "0"   # opt-in: measured slower than the MFMA path so far
+SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "60"))
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "32"))  # wider layers: flat kernel is faster (measured)
 
@@ -114,7 +114,7 @@ class ConvLayer:
     def ensure_packed(self, dev):
         vers = tuple(w._version for w in self.weights) + tuple(
             (b._version if b is not None else -1) for b in (self.biases or []))
-        have = ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+        have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
@@ -141,6 +141,14 @@ class ConvLayer:
                                   self.CoutP, self.Ktot, _ptr(buf, g * T * self.CoutP * self.Ktot), st), "pack_conv_weight")
             if self.biases is not None and self.biases[g] is not None:
                 self.bp[g * self.CoutP: g * self.CoutP + self.Cout].copy_(self.biases[g].detach())
+        if getattr(self, "need_c4", False):
+            # [CoutP][40] fp32, column tap*4 + c (taps folded into K for the Cin <= 4 first layers); tiny host-side pack
+            n32 = 32 if self.Cout_store <= 32 else 64
+            if getattr(self, "w40", None) is None:
+                self.w40 = torch.zeros(n32, 40, dtype=torch.float32, device=dev)
+            wd = self.weights[0].detach()
+            self.w40.zero_()
+            self.w40[:self.Cout, :36].view(self.Cout, 9, 4)[:, :, :self.Cin].copy_(wd.permute(0, 2, 3, 1).reshape(self.Cout, 9, self.Cin))
         if self.need_split or self.need_sfrag:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
@@ -296,16 +304,21 @@ class Plan:
                     and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] == 1
                     and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None)
         split = (F16X3_ENABLED and layer.split and layer.stride == 1 and layer.pad_mode == 0 and len(pieces) == 1
-                 and pieces[0].Cp >= 32 and layer.Cout >= 8)
+                 and pieces[0].Cp >= 32)
         # narrow 3x3 layers on wide images: split-f16 arithmetic AND the LDS halo (input fetched once for 9 taps)
         shalo = (split and HALO_F16_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.G == 1 and layer.pad == (1, 1)
                  and layer.dils[0] <= 2 and W >= HALO_MIN_W and layer.CoutP in (32, 64) and residual is None
                  and H * W * pieces[0].stride < 2 ** 31)
         if split and not shalo and halo and pieces[0].scale is not None:
             split = False            # fused-affine layers: the fp32 halo kernel beats the flat split kernel
+        if smallcin:
+            split = shalo = False
         if smallcin or split:
             halo = False
-        if shalo:
+        if smallcin:
+            layer.need_c4 = True
+            layer.need_flat = True   # the generic pack is still what the backward (wgrad) paths index with kinv
+        elif shalo:
             layer.need_sfrag = True
         elif split:
             layer.need_split = True
@@ -352,7 +365,7 @@ class Plan:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
                                                      layer.w_scale), name, flops=flops, kind="conv_f16x3")
         elif smallcin:
-            self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.Cin), name, flops=flops, kind="conv3x3_smallcin")
+            self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif halo:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
         else:

@@ -122,9 +122,9 @@ int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* d, const void* fhi, const vo
                               float w_scale, void* stream);
 
 /* First layers (vgg16_c.py:66 conv1_1 on 3 channels, utils.py:1047 convBlock conv1 on 1-2 channels):
- * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  27-36 MACs per output make this a pure store
- * stream, so it runs as a direct VALU kernel (flat weight pack of egne_pack_conv_weight). */
-int egne_conv3x3_smallcin_fwd(const egne_conv_desc* d, int cin, void* stream);
+ * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  The 9 taps are folded into K (one 40-wide K step,
+ * exact fp32 MFMA), so the layer is a pure store stream.  w40: [32 or 64][40] fp32, column tap*4 + c. */
+int egne_conv3x3_smallcin_fwd(const egne_conv_desc* d, const float* w40, void* stream);
 
 /* OIHW (torch layout) -> packed [tap][CoutP][Ktot].  kinv[k] (device int32, k < Ktot) names the
  * input channel stored at padded K position k, or -1 for a padding column; rows Cout..CoutP-1 are

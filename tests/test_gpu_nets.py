@@ -249,21 +249,24 @@ def test_esf_train_step_vs_reference(name, edge_of_exact):
     ref = g["grad_l2"]
     rel = np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max())
     worst = int(np.argmax(rel))
-    assert rel.max() < 1e-2, "grad L2 of %s: %.6e vs %.6e" % (names[worst], got[worst], ref[worst])
+    # the all-masks-absent batch leaves only the centre terms: its deepest gradients are cancellation dominated and
+    # the reference's own fp32 result is ~1e-2 away from float64 there (test_gradients_vs_float64_truth prints it)
+    tol = 3e-2 if name.endswith("absent_all") else 1e-2
+    assert rel.max() < tol, "grad L2 of %s: %.6e vs %.6e" % (names[worst], got[worst], ref[worst])
     for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight", "enc.down_block1.conv21.weight",
               "dec.up_block4.conv11.bias"):
         r = g["grad::" + k]
         e = np.abs(params[k].grad.cpu().numpy() - r).max()
-        assert e <= 1.5e-2 * np.abs(r).max() + 1e-7, "%s: max err %.3e (scale %.3e)" % (k, e, np.abs(r).max())
+        assert e <= 1.5 * tol * np.abs(r).max() + 1e-7, "%s: max err %.3e (scale %.3e)" % (k, e, np.abs(r).max())
 
 
-def test_gradients_vs_float64_truth(bdcn):
+@pytest.mark.parametrize("name", ["esf_edge_b2_absent1", "esf_edge_b2_absent_all"])
+def test_gradients_vs_float64_truth(bdcn, name):
     """The oracle evaluated in float64 is the truth; the HIP fp32 gradients must be at least as close to
     it as the reference's fp32 gradients are (x2 slack), for every parameter tensor."""
     from common import ESF_CASES, batch_args, esf_module, gold, setting
     from egne_amd import synth
     from oracle import bdcn as obdcn, esfnet as oesf
-    name = "esf_edge_b2_absent1"
     cfg, variant, kw = ESF_CASES[name]
     kw = dict(kw)
     g = gold(name)
@@ -283,7 +286,7 @@ def test_gradients_vs_float64_truth(bdcn):
     r, h = g["grad_l2"], np.array([params[n].grad.double().norm().item() for n in names])
     keep = t > 1e-6 * t.max()
     ref_dev, hip_dev = (np.abs(r - t) / t)[keep].max(), (np.abs(h - t) / t)[keep].max()
-    print("grad L2 deviation from float64: reference fp32 %.2e, HIP fp32 %.2e" % (ref_dev, hip_dev))
+    print("%s: grad L2 deviation from float64: reference fp32 %.2e, HIP fp32 %.2e" % (name, ref_dev, hip_dev))
     assert hip_dev < max(2 * ref_dev, 2e-3)
 
 
