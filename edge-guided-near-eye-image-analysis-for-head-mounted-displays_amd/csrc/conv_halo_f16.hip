@@ -24,7 +24,11 @@ __device__ __forceinline__ float act1(float v, int act) {
   return v;
 }
 
-template <int WM, int WN, int D>
+// LAT = true: "lattice" mode for large dilations.  A dilation-S conv is S*S independent ordinary 3x3 convs on
+// the sub-lattices (phase_y + S*i, phase_x + S*j); a tile is 8 x 32 LATTICE points, its halo is one lattice
+// step wide (D = 1), so a dilation-12 conv stages the same 340-pixel halo as a dilation-1 conv.  Pixels are
+// 128-B channel vectors, so the strided gather still moves full cache lines.
+template <int WM, int WN, int D, bool LAT>
 __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
@@ -45,12 +49,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
   const int Cp = sg.Cp;
   const int c4 = tid & 7;
 
-  struct Tile { int b, y0, x0; };
+  const int S = LAT ? p.dil[0] : 1;          // lattice step
+  struct Tile { int b, y0, x0, py, px; };    // y0/x0 in lattice units, (py, px) = lattice phase
   auto tile_of = [&](int t) {
     Tile r;
     const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    r.b = t / tiles_y; r.y0 = ty * TH; r.x0 = tx * TW;
+    const int ty = t % tiles_y; t /= tiles_y;
+    r.py = 0; r.px = 0;
+    if (LAT) { r.px = t % S; t /= S; r.py = t % S; t /= S; }
+    r.b = t; r.y0 = ty * TH; r.x0 = tx * TW;
     return r;
   };
 
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
       if (item < nitems) {
         const int px = item >> 3;
         const int hy = px / HWd, hx = px - hy * HWd;
-        const int iy = tl.y0 - d + hy, ix = tl.x0 - d + hx;
+        const int iy = tl.py + S * (tl.y0 - d + hy), ix = tl.px + S * (tl.x0 - d + hx);
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
           goff[i] = (int)((((long long)iy * p.W + ix) * sg.pix_stride) + sg.ch_off + c4 * 4);
       }
@@ -206,16 +213,25 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
       if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
 #pragma unroll
       for (int tm = 0; tm < WM; ++tm) {
-        const int y = cur.y0 + wave * WM + tm;
+        const int y = cur.py + S * (cur.y0 + wave * WM + tm);
+        // all residual loads of the tile row first (one wait), then the stores
+        float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int x = cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int x = cur.px + S * (cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+          const bool ok = p.residual && nok && y < p.H && x < p.W;
+          const long long m = ((long long)cur.b * p.H + y) * p.W + x;
+          const float* q = ok ? p.residual + m * p.res_pix_stride + p.res_ch_off + n : egne_zero_page;
+          rv[r] = *q;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = cur.px + S * (cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
           if (nok && y < p.H && x < p.W) {
             const long long m = ((long long)cur.b * p.H + y) * p.W + x;
             float v = act1(acc[tm][tn][r] * out_scale + bv, p.act);
             if (p.post_scale) v = v * ps + pt;
-            if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
-            p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
+            p.out[m * p.out_pix_stride + p.out_ch_off + n] = v + rv[r];
           }
         }
         acc[tm][tn] = (f32x16)(0.f);
@@ -247,15 +263,17 @@ __global__ void pack_weight_f16frag_k(const float* __restrict__ w, int Cout, int
   }
 }
 
-template <int WM, int WN, int D>
+template <int WM, int WN, int D, bool LAT>
 int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   constexpr int TH = 4 * WM;
-  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+  const int S = LAT ? d.dil[0] : 1;
+  const int lw = (d.W + S - 1) / S, lh_ = (d.H + S - 1) / S;     // lattice extent (largest phase)
+  const int tiles_x = (lw + TW - 1) / TW, tiles_y = (lh_ + TH - 1) / TH;
   const size_t lds = (size_t)2 * (TH + 2 * D) * (TW + 2 * D) * LDH * sizeof(_Float16);
-  const int ntiles = tiles_x * tiles_y * d.B, ny = d.CoutP / (32 * WN);
+  const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN);
   int gx = (256 * 2 + ny - 1) / ny;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
+  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
                      tiles_y, ntiles);
   return egne::check_launch("egne_conv3x3_halo_f16_fwd");
 }
@@ -280,7 +298,7 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   EGNE_REQUIRE(dp && fhi && flo, "conv_halo_f16: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_mode == 0 && d.ngroups == 1 && d.nseg == 1 && d.pad_h == 1 &&
-               d.pad_w == 1 && d.dil[0] >= 1 && d.dil[0] <= 2 && d.Ho == d.H && d.Wo == d.W, "conv_halo_f16: geometry not supported");
+               d.pad_w == 1 && d.dil[0] >= 1 && d.dil[0] <= 32 && d.Ho == d.H && d.Wo == d.W, "conv_halo_f16: geometry not supported");
   const egne_seg& g = d.seg[0];
   EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
                ((uintptr_t)g.ptr & 15) == 0 && (g.scale == nullptr) == (g.shift == nullptr), "conv_halo_f16: input slice");
@@ -292,6 +310,8 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   hipStream_t st = (hipStream_t)stream;
   const _Float16* h = (const _Float16*)fhi;
   const _Float16* l = (const _Float16*)flo;
-  if (d.dil[0] == 1) return d.CoutP == 64 ? launch_hf<2, 2, 1>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1>(d, h, l, a_scale, os, st);
-  return d.CoutP == 64 ? launch_hf<2, 2, 2>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2>(d, h, l, a_scale, os, st);
+  if (d.dil[0] == 1) return d.CoutP == 64 ? launch_hf<2, 2, 1, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false>(d, h, l, a_scale, os, st);
+  if (d.dil[0] == 2) return d.CoutP == 64 ? launch_hf<2, 2, 2, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2, false>(d, h, l, a_scale, os, st);
+  // larger dilations: lattice mode (the dilation-S conv as S*S ordinary convs on sub-lattices)
+  return d.CoutP == 64 ? launch_hf<2, 2, 1, true>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, true>(d, h, l, a_scale, os, st);
 }

@@ -17,6 +17,8 @@ import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
+LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
+LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
@@ -169,10 +171,12 @@ class ConvLayer:
             if self.need_sfrag:
                 perf = T * self.CoutP * kts
                 if self.fhi is None:
-                    self.fhi = torch.empty(perf, dtype=torch.float16, device=dev)
-                    self.flo = torch.empty(perf, dtype=torch.float16, device=dev)
-                _lib.check(L.egne_pack_conv_weight_f16frag(ws[0].data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.CoutP, kts,
-                                                           self.w_scale, self.fhi.data_ptr(), self.flo.data_ptr(), st), "pack_f16frag")
+                    self.fhi = torch.empty(self.G * perf, dtype=torch.float16, device=dev)
+                    self.flo = torch.empty(self.G * perf, dtype=torch.float16, device=dev)
+                for g, wd in enumerate(ws):
+                    _lib.check(L.egne_pack_conv_weight_f16frag(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.CoutP, kts,
+                                                               self.w_scale, self.fhi.data_ptr() + 2 * g * perf,
+                                                               self.flo.data_ptr() + 2 * g * perf, st), "pack_f16frag")
         self._versions = vers
 
     def split_coutp(self):
@@ -309,6 +313,12 @@ class Plan:
         shalo = (split and HALO_F16_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.G == 1 and layer.pad == (1, 1)
                  and layer.dils[0] <= 2 and W >= HALO_MIN_W and layer.CoutP in (32, 64) and residual is None
                  and H * W * pieces[0].stride < 2 ** 31)
+        # fused dilated group of an MSBlock: three lattice-halo launches (out = o + sum_g relu(conv_g(o)))
+        lattice = (split and LATTICE_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)
+                   and layer.CoutP in (32, 64) and residual is not None and pieces[0].scale is None
+                   and min(W // d_ for d_ in layer.dils) >= LATTICE_MIN_W and H * W * pieces[0].stride < 2 ** 31)
+        if lattice:
+            shalo = True
         if split and not shalo and halo and pieces[0].scale is not None:
             split = False            # fused-affine layers: the fp32 halo kernel beats the flat split kernel
         if smallcin:
@@ -358,7 +368,21 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if shalo:
+        if lattice:
+            perf = 9 * layer.CoutP * pad32(layer.Ktot)
+            for g in range(3):
+                dg = _lib.ConvDesc()
+                C.memmove(C.byref(dg), C.byref(d), C.sizeof(_lib.ConvDesc))
+                dg.ngroups = 1
+                dg.dil[0] = layer.dils[g]
+                dg.bias = layer.bp.data_ptr() + 4 * g * layer.CoutP if layer.biases is not None else None
+                if g > 0:   # accumulate onto the running sum
+                    dg.residual, dg.res_pix_stride, dg.res_ch_off = dst.ptr, dst.stride, dst.off
+                self.keep.append(dg)
+                self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(dg), layer.fhi.data_ptr() + 2 * g * perf,
+                                                             layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
+                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3")
+        elif shalo:
             self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
                                                          layer.w_scale), name, flops=flops, kind="conv_f16x3")
         elif split:
