@@ -208,6 +208,16 @@ def main():
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": None,
                    "launches_per_step": sp_n // max(a.steps, 1), "avg_launch_ms": round(1e3 * sp_t / max(sp_n, 1), 4),
                    "algorithmic_gflop_per_frame": round(sp_f / a.steps / B / 1e9, 2), "time_share": round(sp_t / tot_t, 4)}
+        # HBM traffic per launch from the committed PMC run (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE);
+        # inference plans only -- bench.py cannot run the PMC passes itself
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                tr = json.load(f)["families"]
+            if not train and B == 64:
+                r_split["traffic"] = tr["split_f16"]["hbm_bytes_per_launch"]
+                r_fp32["traffic"] = tr["fp32_conv"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         res["roofline"], res["roofline_secondary"] = (r_split, r_fp32) if sp_t > conv_t else (r_fp32, r_split)
         if world == 1 and not a.no_cpu_baseline and not train:
             res["cpu_baseline"] = cpu_baseline(setting, bd_sd, net_sd, a.cpu_batch, a.cpu_iters)
