@@ -302,7 +302,7 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   const egne_seg& g = d.seg[0];
   EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
                ((uintptr_t)g.ptr & 15) == 0 && (g.scale == nullptr) == (g.shift == nullptr), "conv_halo_f16: input slice");
-  EGNE_REQUIRE((d.CoutP == 32 || d.CoutP == 64) && d.Cout_store <= d.CoutP && d.out && d.out_ch_off + d.Cout_store <= d.out_pix_stride,
+  EGNE_REQUIRE(d.CoutP % 32 == 0 && d.Cout_store <= d.CoutP && d.out && d.out_ch_off + d.Cout_store <= d.out_pix_stride,
                "conv_halo_f16: CoutP %d", d.CoutP);
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv_halo_f16: weights / scales");
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride < (1ll << 31), "conv_halo_f16: frame too large for 32-bit offsets");
@@ -310,8 +310,9 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   hipStream_t st = (hipStream_t)stream;
   const _Float16* h = (const _Float16*)fhi;
   const _Float16* l = (const _Float16*)flo;
-  if (d.dil[0] == 1) return d.CoutP == 64 ? launch_hf<2, 2, 1, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false>(d, h, l, a_scale, os, st);
-  if (d.dil[0] == 2) return d.CoutP == 64 ? launch_hf<2, 2, 2, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2, false>(d, h, l, a_scale, os, st);
+  const bool w2 = d.CoutP % 64 == 0;   // wider layers: several 64-wide N tiles along grid.y, each re-stages the halo
+  if (d.dil[0] == 1) return w2 ? launch_hf<2, 2, 1, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false>(d, h, l, a_scale, os, st);
+  if (d.dil[0] == 2) return w2 ? launch_hf<2, 2, 2, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2, false>(d, h, l, a_scale, os, st);
   // larger dilations: lattice mode (the dilation-S conv as S*S ordinary convs on sub-lattices)
-  return d.CoutP == 64 ? launch_hf<2, 2, 1, true>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, true>(d, h, l, a_scale, os, st);
+  return w2 ? launch_hf<2, 2, 1, true>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, true>(d, h, l, a_scale, os, st);
 }

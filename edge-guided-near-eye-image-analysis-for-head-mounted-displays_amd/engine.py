@@ -17,6 +17,7 @@ import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
+HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "64"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
@@ -311,7 +312,7 @@ class Plan:
                  and pieces[0].Cp >= 32)
         # narrow 3x3 layers on wide images: split-f16 arithmetic AND the LDS halo (input fetched once for 9 taps)
         shalo = (split and HALO_F16_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.G == 1 and layer.pad == (1, 1)
-                 and layer.dils[0] <= 2 and W >= HALO_MIN_W and layer.CoutP in (32, 64) and residual is None
+                 and layer.dils[0] <= 2 and W >= HALO_MIN_W and layer.CoutP <= HALO_F16_MAX_COUTP and residual is None
                  and H * W * pieces[0].stride < 2 ** 31)
         # fused dilated group of an MSBlock: three lattice-halo launches (out = o + sum_g relu(conv_g(o)))
         lattice = (split and LATTICE_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)
