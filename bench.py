@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--fit", action="store_true", help="inference: also run the ellipse-fit stage of evaluate.py (2 fits per frame)")
     ap.add_argument("--layers", action="store_true", help="print a per-launch time / TFLOP/s table to stderr")
     return ap.parse_args()
 
@@ -127,8 +128,17 @@ def main():
             return [o.detach() for o in out]
         with torch.no_grad():
             edge = calc_edge(args, t["img"], bd, dev)
-            return net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
-                       t["ID"], t["alpha"])
+            out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
+                      t["ID"], t["alpha"])
+            if a.fit:   # evaluate.py:135-151: un-normalise the predicted ellipses (host, float64) and fit both on the device
+                import numpy as np
+                from egne_amd import ellipse
+                from egne_amd.utils import fit_ellipses
+                ep = out[1].cpu().numpy().astype(np.float64)
+                Hm = np.array([[160.0, 0, 160.0], [0, 120.0, 120.0], [0, 0, 1]])
+                init = np.stack([ellipse.transform(ep[i, k:k + 5], Hm) for i in range(B) for k in (0, 5)])
+                fit_ellipses(net.predictions(), [i for i in range(B) for _ in (0, 1)], [1, 2] * B, init)
+            return out
 
     def barrier():
         if world > 1:
@@ -183,7 +193,7 @@ def main():
                                     "batch=%d/GPU), 240x320 synthetic TEyeD-shaped batch, seeded random-init weights" % B) if train
                        else ("BASELINE.json configs[1]: baseline_edge.yaml (chz=32) inference, batch=%d/GPU, fp32, "
                              "240x320 synthetic IR frames, seeded random-init weights" % B),
-                       "frames_per_gpu_per_step": B,
+                       "frames_per_gpu_per_step": B, "ellipse_fit_stage": bool(a.fit),
                        "arithmetic": "fp32 tensors everywhere; training: exact fp32 MFMA; inference: split-f16 MFMA products "
                                      "(22-bit significand) with fp32 accumulation where eligible, exact fp32 elsewhere",
                        "parallelism": ("dp%d (one flat RCCL all-reduce of 13.45 MB per step)" % world) if train

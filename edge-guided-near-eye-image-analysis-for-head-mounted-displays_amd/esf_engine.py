@@ -329,12 +329,9 @@ def build_forward_plan(model, B, H, W, dev, training):
         mod = []
         for j, pc in enumerate(xb):
             q = Piece(xa, j * pad8(fc), fc)
-            pl.raw(L.egne_adain, (pc.ptr, pc.stride, pc.off, fc, cur.ptr, cur.ptr, cur.stride, 0, q.ptr, q.stride, q.off,
-                                  B, hb * wb, 1e-5), "adain.apply")
-            # gamma = adain_params[:,0] (first nfc), beta = adain_params[:,1] (next nfc)
-            fn, args, nm = pl.calls[-1]
-            pl.calls[-1] = (fn, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.ptr + 4 * (nfc + j * fc),
-                                 cur.stride, 0, q.ptr, q.stride, q.off, B, hb * wb, 1e-5), nm)
+            # gamma = adain_params[:,0] (first nfc values of the MLP row), beta = adain_params[:,1] (next nfc)
+            pl.raw(L.egne_adain, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.ptr + 4 * (nfc + j * fc),
+                                  cur.stride, 0, q.ptr, q.stride, q.off, B, hb * wb, 1e-5), "adain.apply")
             mod.append(q)
         xb = mod
 
