@@ -94,6 +94,9 @@ SIGNATURES = {
     "egne_upsample2x_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_ellipse_head_act_bwd": (i32, [vp, vp, i32, i32, vp]),
     "egne_selu_bwd": (i32, [vp, vp, i64, vp]),
+    "egne_softmax3_bwd": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i64, vp]),
+    "egne_adain_bwd": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, vp, i64, i32, vp, vp, i64, i32, i32, i32, f32, vp]),
+    "egne_reflect_pad_bwd": (i32, [vp, i64, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_spatial_mean_bwd": (i32, [vp, i32, vp, i64, i32, i32, i32, i32, vp]),
     "egne_conf_loss_bwd": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, i32, vp]),
     "egne_conv2d_wgrad_splits": (i32, [C.POINTER(ConvDesc)]),

@@ -78,6 +78,105 @@ __global__ void conf_loss_k(const float* __restrict__ x, int ld, const long long
   }
 }
 
+
+// ---- backward of the AdaIN fusion path -------------------------------------------------------------
+// softmax: gx[c] += y[c] * (gy[c] - sum_k gy[k] y[k])
+__global__ void softmax3_bwd_k(const float* __restrict__ y, long long ys, int yo, const float* __restrict__ gy, long long gs,
+                               int go, float* __restrict__ gx, long long xs, int xo, long long npix) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const float* a = y + p * ys + yo;
+    const float* g = gy + p * gs + go;
+    const float dot = g[0] * a[0] + g[1] * a[1] + g[2] * a[2];
+    float* d = gx + p * xs + xo;
+    d[0] += a[0] * (g[0] - dot); d[1] += a[1] * (g[1] - dot); d[2] += a[2] * (g[2] - dot);
+  }
+}
+
+// y = gamma * xhat + beta, xhat = (x - mean) / sqrt(var_unbiased + eps):
+//   ggamma += sum gy xhat, gbeta += sum gy, gx += gamma/std * (gy - mean(gy) - xhat * sum(gy xhat) / (HW-1))
+__global__ __launch_bounds__(256) void adain_bwd_k(const float* __restrict__ x, long long xs, int xo, int C,
+                                                   const float* __restrict__ gamma, long long gb_stride, int gb_off,
+                                                   const float* __restrict__ gy, long long gys, int gyo,
+                                                   float* __restrict__ gx, long long gxs, int gxo,
+                                                   float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                   long long gg_stride, int gg_off, int HW, float eps) {
+  const int n = blockIdx.y, cg = blockIdx.x;
+  const int cl = threadIdx.x & 31, c = cg * 32 + cl, row = threadIdx.x >> 5;
+  const bool ok = c < C;
+  const float* src = x + (long long)n * HW * xs + xo + c;
+  const float* gsrc = gy + (long long)n * HW * gys + gyo + c;
+  __shared__ double sh[2][8][32];
+  double s = 0, q = 0;
+  if (ok)
+    for (int p = row; p < HW; p += 8) { const float v = src[(long long)p * xs]; s += v; q += (double)v * v; }
+  sh[0][row][cl] = s; sh[1][row][cl] = q;
+  __syncthreads();
+  double ts = 0, tq = 0;
+  for (int r = 0; r < 8; ++r) { ts += sh[0][r][cl]; tq += sh[1][r][cl]; }
+  __syncthreads();
+  const double mean = ts / HW;
+  double var = (tq - ts * mean) / (HW - 1);
+  if (var < 0) var = 0;
+  const float fm = (float)mean, fs = sqrtf((float)var + eps);
+  double sg = 0, sgx = 0;
+  if (ok)
+    for (int p = row; p < HW; p += 8) {
+      const float g = gsrc[(long long)p * gys];
+      sg += g; sgx += (double)g * ((src[(long long)p * xs] - fm) / fs);
+    }
+  sh[0][row][cl] = sg; sh[1][row][cl] = sgx;
+  __syncthreads();
+  double tg = 0, tgx = 0;
+  for (int r = 0; r < 8; ++r) { tg += sh[0][r][cl]; tgx += sh[1][r][cl]; }
+  if (!ok) return;
+  if (row == 0) {
+    ggamma[(long long)n * gg_stride + gg_off + c] += (float)tgx;
+    gbeta[(long long)n * gg_stride + gg_off + c] += (float)tg;
+  }
+  const float gm = gamma[(long long)n * gb_stride + gb_off + c] / fs;
+  const float mg = (float)(tg / HW), kx = (float)(tgx / (HW - 1));
+  float* dst = gx + (long long)n * HW * gxs + gxo + c;
+  for (int p = row; p < HW; p += 8) {
+    const float xh = (src[(long long)p * xs] - fm) / fs;
+    dst[(long long)p * gxs] += gm * (gsrc[(long long)p * gys] - mg - xh * kx);
+  }
+}
+
+// Backward of ReflectionPad2d(P): gx[b,iy,ix,:] += sum of gpad over every padded position that reflects onto
+// (iy,ix).  gpad is either dense [B,H+2P,W+2P,Cp] (phase=0) or the phase-packed output of the stride-2
+// transposed conv: [B,(H+2P)/2,(W+2P)/2,4*Cp] with channel block (py&1)*2+(px&1) (phase=1).
+__global__ void reflect_pad_bwd_k(const float* __restrict__ gp, long long gs, int go, int phase, int Cp,
+                                  float* __restrict__ gx, long long xs, int xo, int B, int H, int W, int P) {
+  const int c4 = Cp >> 2;
+  const long long total = (long long)B * H * W * c4;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    long long q = i / c4;
+    const int ix = (int)(q % W); q /= W;
+    const int iy = (int)(q % H);
+    const int b = (int)(q / H);
+    int pys[3], pxs[3], ny = 0, nx = 0;
+    pys[ny++] = iy + P;
+    if (iy >= 1 && iy <= P) pys[ny++] = P - iy;
+    if (iy <= H - 2 && iy >= H - 1 - P) pys[ny++] = P + 2 * (H - 1) - iy;
+    pxs[nx++] = ix + P;
+    if (ix >= 1 && ix <= P) pxs[nx++] = P - ix;
+    if (ix <= W - 2 && ix >= W - 1 - P) pxs[nx++] = P + 2 * (W - 1) - ix;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+      for (int e = 0; e < nx; ++e) {
+        const int py = pys[a], px = pxs[e];
+        const float* s;
+        if (phase) s = gp + (((long long)b * (Hp >> 1) + (py >> 1)) * (Wp >> 1) + (px >> 1)) * gs + go + ((py & 1) * 2 + (px & 1)) * Cp + c;
+        else       s = gp + (((long long)b * Hp + py) * Wp + px) * gs + go + c;
+        acc += *(const f32x4*)s;
+      }
+    f32x4* d = (f32x4*)(gx + (((long long)b * H + iy) * W + ix) * xs + xo + c);
+    *d += acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int egne_softmax3(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp_out, int64_t npix,
@@ -105,4 +204,39 @@ extern "C" int egne_conf_loss(const float* pred, int ld, const int64_t* gt, int 
   hipLaunchKernelGGL(conf_loss_k, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, ld, (const long long*)gt, B, C, flag,
                      weight, terms);
   return egne::check_launch("egne_conf_loss");
+}
+
+extern "C" int egne_softmax3_bwd(const float* y, int64_t ys, int yo, const float* gy, int64_t gs, int go, float* gx,
+                                 int64_t xs, int xo, int64_t npix, void* stream) {
+  EGNE_REQUIRE(y && gy && gx && yo + 3 <= ys && go + 3 <= gs && xo + 3 <= xs && npix > 0, "softmax3_bwd: bad arguments");
+  long long g = (npix + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(softmax3_bwd_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, (long long)ys, yo, gy,
+                     (long long)gs, go, gx, (long long)xs, xo, (long long)npix);
+  return egne::check_launch("egne_softmax3_bwd");
+}
+
+extern "C" int egne_adain_bwd(const float* x, int64_t xs, int xo, int C, const float* gamma, int64_t gb_stride, int gb_off,
+                              const float* gy, int64_t gys, int gyo, float* gx, int64_t gxs, int gxo, float* ggamma,
+                              float* gbeta, int64_t gg_stride, int gg_off, int B, int HW, float eps, void* stream) {
+  EGNE_REQUIRE(x && gamma && gy && gx && ggamma && gbeta && C > 0 && xo + C <= xs && gyo + C <= gys && gxo + C <= gxs &&
+               B > 0 && HW > 1, "adain_bwd: bad arguments");
+  hipLaunchKernelGGL(adain_bwd_k, dim3((C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, x, (long long)xs, xo, C, gamma,
+                     (long long)gb_stride, gb_off, gy, (long long)gys, gyo, gx, (long long)gxs, gxo, ggamma, gbeta,
+                     (long long)gg_stride, gg_off, HW, eps);
+  return egne::check_launch("egne_adain_bwd");
+}
+
+extern "C" int egne_reflect_pad_bwd(const float* gpad, int64_t gs, int go, int phase, int Cp, float* gx, int64_t xs, int xo,
+                                    int B, int H, int W, int P, void* stream) {
+  EGNE_REQUIRE(gpad && gx && Cp > 0 && Cp % 4 == 0 && gs % 4 == 0 && go % 4 == 0 && xs % 4 == 0 && xo % 4 == 0 &&
+               ((uintptr_t)gpad & 15) == 0 && ((uintptr_t)gx & 15) == 0, "reflect_pad_bwd: alignment");
+  EGNE_REQUIRE(B > 0 && P >= 0 && H > P && W > P && xo + Cp <= xs && go + (phase ? 4 : 1) * Cp <= gs, "reflect_pad_bwd: shape");
+  EGNE_REQUIRE(!phase || ((H + 2 * P) % 2 == 0 && (W + 2 * P) % 2 == 0), "reflect_pad_bwd: phase layout needs even padded sizes");
+  const long long total = (long long)B * H * W * (Cp / 4);
+  long long g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(reflect_pad_bwd_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, gpad, (long long)gs, go, phase, Cp,
+                     gx, (long long)xs, xo, B, H, W, P);
+  return egne::check_launch("egne_reflect_pad_bwd");
 }

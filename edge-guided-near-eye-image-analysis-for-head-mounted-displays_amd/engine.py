@@ -239,6 +239,44 @@ class DgradLayer(ConvLayer):
         self._versions = vers
 
 
+class TransposedLayer(ConvLayer):
+    """Data gradient of a reflect-padded and / or stride-2 convolution w.r.t. its PADDED input, as an ordinary
+    zero-padded stride-1 convolution over the output gradient with weights derived from the forward ones:
+
+    * stride 1, k x k:  W'[ci][co][j][i] = w[co][ci][k-1-j][k-1-i], pad k-1 -> dense [B,H+2P,W+2P,Cin]
+    * stride 2, 4 x 4, P = 1 (the StyleEncoder's down-sampling blocks, utils.py:96-103): the padded position
+      py = 2m + a receives gy[m - t] * w[ky = a + 2t], t in {0,1} -- one 2x2 convolution per phase (a, b); the four
+      phases are the channel blocks of ONE launch: W'[(a,b,ci)][co][j][i] = w[co][ci][a+2(1-j)][b+2(1-i)], pad 1,
+      output [B,Ho+1,Wo+1,4*Cp] which egne_reflect_pad_bwd un-shuffles and folds.
+
+    ``refresh`` recomputes the derived tensor (a handful of torch ops) whenever the forward weight changed."""
+
+    def __init__(self, fwd, idx, dev):
+        assert fwd.G == 1 and len(fwd.in_layout) == 1 and idx == 0
+        w = fwd.weights[0]
+        C_, Cp_ = fwd.in_layout[0]
+        self.fwd, self.phase = fwd, 0
+        if fwd.stride == 1:
+            shape, khw, pad, cout_pad = (C_, fwd.Cout, fwd.kh, fwd.kw), (fwd.kh, fwd.kw), (fwd.kh - 1, fwd.kw - 1), Cp_
+        elif fwd.stride == 2 and (fwd.kh, fwd.kw) == (4, 4) and fwd.pad == (1, 1):
+            assert C_ == Cp_, "phase-packed dgrad: input slice must not be channel padded"
+            shape, khw, pad, cout_pad, self.phase = (4 * C_, fwd.Cout, 2, 2), (2, 2), (1, 1), 4 * Cp_, 1
+        else:
+            raise NotImplementedError("dgrad of a %dx%d stride-%d convolution" % (fwd.kh, fwd.kw, fwd.stride))
+        self.derived = torch.zeros(shape, dtype=torch.float32, device=dev)
+        super().__init__([self.derived], None, [(fwd.Cout, fwd.Cout_store)], stride=1, pad=pad, kernel_hw=khw, cout_pad=cout_pad)
+        self.guard = VersionGuard([w], self.refresh)
+
+    def refresh(self):
+        w = self.fwd.weights[0].detach()
+        if self.phase:
+            Co, Ci = w.shape[:2]
+            v = w.view(Co, Ci, 2, 2, 2, 2).flip(2).flip(4)            # [co][ci][j][a][i][b], j = 1 - t
+            self.derived.copy_(v.permute(3, 5, 1, 0, 2, 4).reshape(4 * Ci, Co, 2, 2))
+        else:
+            self.derived.copy_(w.flip(2).flip(3).transpose(0, 1))
+
+
 class Plan:
     """Buffers + prepared launches for one network at one shape."""
 
@@ -421,6 +459,24 @@ class Plan:
         gin = Piece(gy.buf, gy.off, layer.Cout, Cs, gy.n0)
         for i, pc in enumerate(pieces):
             if pc.nograd:
+                continue
+            if layer.stride != 1 or layer.pad_mode == 1:
+                # reflect-padded / strided blocks: gradient w.r.t. the padded input, then fold the padding back
+                assert pc.scale is None and layer.pad_mode == 1 and layer.pad[0] == layer.pad[1]
+                tl = TransposedLayer(layer, i, self.device)
+                self.pre.append(tl.guard)            # forward plan: refreshed before the backward plan re-packs
+                hp, wp = tl.out_hw(Ho, Wo)
+                P = layer.pad[0]
+                if tl.phase:
+                    if (H + 2 * P) % 2 or (W + 2 * P) % 2 or (hp, wp) != ((H + 2 * P) // 2, (W + 2 * P) // 2):
+                        raise NotImplementedError("stride-2 dgrad needs even input sizes, got %dx%d" % (H, W))
+                else:
+                    assert (hp, wp) == (H + 2 * P, W + 2 * P), (hp, wp, H, W, P)
+                tmp = bw.buf(B, hp, wp, tl.Cout_store)
+                bw.conv(tl, [gin], Piece(tmp, 0, tl.Cout, tl.Cout_store), B, Ho, Wo, name=name + ".dgrad_pad")
+                tgt = self.gp(pc)
+                bw.raw(L.egne_reflect_pad_bwd, (tmp.data_ptr(), tmp.shape[-1], 0, tl.phase, pc.Cp, tgt.ptr, tgt.stride, tgt.off,
+                                                B, H, W, P), name + ".pad_bwd")
                 continue
             dl = DgradLayer(layer, i)
             tgt = self.gp(pc)

@@ -300,6 +300,14 @@ def build_forward_plan(model, B, H, W, dev, training):
         pl.raw(L.egne_softmax3, (opb.data_ptr(), 8, 0, sm.data_ptr(), 8, 0, 8, B * H * W), "adain.softmax")
         se = model.seg_encoder.model
         cur, cc, ch, cw = Piece(sm, 0, 3), 3, H, W
+        if st.get("seg_detach", 0):
+            cur.nograd = True            # softmx(op.detach()), RITnet_v2.py:291-292
+        elif training:
+            def emit_softmax(bw):
+                gs, go = pl.gbuf(sm), pl.gbuf(opb)
+                bw.raw(L.egne_softmax3_bwd, (sm.data_ptr(), 8, 0, gs.data_ptr(), 8, 0, go.data_ptr(), 8, 0, B * H * W),
+                       "adain.softmax.bwd")
+            pl.tape.append(emit_softmax)
         for i in range(5):
             blk = se[i]
             k = blk.conv.kernel_size[0]
@@ -311,6 +319,12 @@ def build_forward_plan(model, B, H, W, dev, training):
             cur, cc, ch, cw = Piece(ob, 0, l.Cout), l.Cout, oh, ow
         gap = pl.buf(B, 1, 1, pad8(cc))
         pl.raw(L.egne_spatial_mean, (cur.ptr, cur.stride, cur.off, cur.Cp, B, ch * cw, gap.data_ptr()), "adain.gap")
+        if training:
+            def emit_gap(bw, cur=cur, n=ch * cw):
+                gg, gc = pl.gbuf(gap), pl.gp(cur)
+                bw.raw(L.egne_spatial_mean_bwd, (gg.data_ptr(), gg.shape[-1], gc.ptr, gc.stride, gc.off, cur.Cp, B, n),
+                       "adain.gap.bwd")
+            pl.tape.append(emit_gap)
         l = ConvLayer([se[6].weight], [se[6].bias], [(cc, pad8(cc))])
         sty = pl.buf(B, 1, 1, pad8(l.Cout))
         pl.conv(l, [Piece(gap, 0, cc)], Piece(sty, 0, l.Cout), B, 1, 1, name="adain.style")
@@ -332,6 +346,14 @@ def build_forward_plan(model, B, H, W, dev, training):
             # gamma = adain_params[:,0] (first nfc values of the MLP row), beta = adain_params[:,1] (next nfc)
             pl.raw(L.egne_adain, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.ptr + 4 * (nfc + j * fc),
                                   cur.stride, 0, q.ptr, q.stride, q.off, B, hb * wb, 1e-5), "adain.apply")
+            if training:
+                def emit_adain(bw, pc=pc, q=q, j=j, cur=cur):
+                    gq, gx, gm = pl.gp(q), pl.gp(pc), pl.gp(cur)
+                    bw.raw(L.egne_adain_bwd, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.stride, 0,
+                                              gq.ptr, gq.stride, gq.off, gx.ptr, gx.stride, gx.off,
+                                              gm.ptr + 4 * (j * fc), gm.ptr + 4 * (nfc + j * fc), gm.stride, 0,
+                                              B, hb * wb, 1e-5), "adain.apply.bwd")
+                pl.tape.append(emit_adain)
             mod.append(q)
         xb = mod
 

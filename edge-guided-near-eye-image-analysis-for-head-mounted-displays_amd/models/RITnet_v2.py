@@ -217,9 +217,6 @@ class DenseNet2D(nn.Module):
         require_cuda(x, "x")
         want_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         if want_grad:
-            if self.variant == "v2" and self.setting["add_seg"] == 1:
-                raise NotImplementedError("backward through the AdaIN fusion path (stride-2 reflect-padded StyleEncoder) "
-                                          "is not built yet")
             self._ensure_grad_arena()
         if self.selfCorr:
             raise NotImplementedError("selfCorr is disabled in the reference pipeline (--selfCorr 0, args.py:41)")

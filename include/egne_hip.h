@@ -297,6 +297,20 @@ int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t 
                         int B, int H, int W, int Cp, void* stream);     /* gx += ; H,W = input size */
 int egne_ellipse_head_act_bwd(float* g, const float* y, int B, int ld, void* stream);
 int egne_selu_bwd(float* g, const float* y, int64_t n, void* stream);
+/* Backward of the AdaIN fusion path (models/RITnet_v2.py:289-308); every output is ACCUMULATED (+=).
+ * egne_softmax3_bwd: gx[c] += y[c]*(gy[c] - sum_k gy[k]y[k]) over the 3 logits of a pixel.
+ * egne_adain_bwd: gradients of x' = gamma*(x-mean)/sqrt(var_unbiased+eps) + beta w.r.t. x (gx), gamma and beta
+ *   (rows of the MLP output gradient: element [n*gg_stride + gg_off + c]).
+ * egne_reflect_pad_bwd: backward of nn.ReflectionPad2d(P) in front of a Conv2dBlock (utils.py:1099-1100,1144):
+ *   gx += fold of the padded-input gradient; phase=1 reads the phase-packed [B,(H+2P)/2,(W+2P)/2,4*Cp] output of the
+ *   stride-2 transposed convolution (channel block (py&1)*2+(px&1)). */
+int egne_softmax3_bwd(const float* y, int64_t ys, int yo, const float* gy, int64_t gs, int go, float* gx,
+                      int64_t xs, int xo, int64_t npix, void* stream);
+int egne_adain_bwd(const float* x, int64_t xs, int xo, int C, const float* gamma, int64_t gb_stride, int gb_off,
+                   const float* gy, int64_t gys, int gyo, float* gx, int64_t gxs, int gxo, float* ggamma,
+                   float* gbeta, int64_t gg_stride, int gg_off, int B, int HW, float eps, void* stream);
+int egne_reflect_pad_bwd(const float* gpad, int64_t gs, int go, int phase, int Cp, float* gx, int64_t xs, int xo,
+                         int B, int H, int W, int P, void* stream);
 int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo, int C, int B, int HW,
                           void* stream);
 int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag,

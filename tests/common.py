@@ -19,8 +19,14 @@ def gold(name):
 
 
 def setting(name):
+    """``name`` is a config file stem, optionally followed by ``+key=int`` overrides."""
+    name, *ov = name.split("+")
     with open(os.path.join(CFG, name + ".yaml")) as f:
-        return yaml.safe_load(f)
+        st = yaml.safe_load(f)
+    for kv in ov:
+        k, v = kv.split("=")
+        st[k] = int(v)
+    return st
 
 
 def sha(t):
@@ -62,6 +68,8 @@ ESF_CASES = {
     "esf_concat_b2": ("baseline_edge", "concat", dict(B=2, seed=1234)),
     "esf_adain_edge_b2": ("baseline_adain_edge", "v2", dict(B=2, seed=1234)),
     "esf_adain_b2": ("baseline_adain", "v2", dict(B=2, seed=1234)),
+    "esf_adain_b2_train": ("baseline_adain", "v2", dict(B=2, seed=1234)),
+    "esf_adain_edge_detach_b2": ("baseline_adain_edge+seg_detach=1", "v2", dict(B=2, seed=1234)),
     "esf_edge_b2_absent1": ("baseline_edge", "v2", dict(B=2, seed=4321, mask_absent_every=2)),
     "esf_edge_b2_absent_all": ("baseline_edge", "v2", dict(B=2, seed=99, mask_absent_every=1)),
 }

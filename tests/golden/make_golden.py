@@ -106,8 +106,9 @@ def gold_bdcn():
     return bd
 
 
-def esf_case(name, cfg, variant, b, edge, full_op, train=True, disentangle=False):
+def esf_case(name, cfg, variant, b, edge, full_op, train=True, disentangle=False, overrides=None):
     setting = load_setting(cfg)
+    setting.update(overrides or {})
     m = ref_esf(setting, variant, disentangle=disentangle)
     args = batch_args(b, edge)
     m.eval()
@@ -185,6 +186,16 @@ def gold_esf(bd):
     with torch.no_grad():
         e1 = bd(torch.cat((b1["img"],) * 3, 1))[-1]
     esf_case("esf_edge_b1_eval", "baseline_edge", "v2", b1, e1, False, train=False)
+
+
+def gold_esf_adain_train(bd):
+    """Training fixtures of the AdaIN fusion path: image-only AdaIN (baseline_adain) and the seg_detach switch
+    (RITnet_v2.py:291-292).  Separate target so that the other fixtures need no regeneration."""
+    b = synth.make_batch(2, seed=1234)
+    with torch.no_grad():
+        edge = bd(torch.cat((b["img"],) * 3, 1))[-1]
+    esf_case("esf_adain_b2_train", "baseline_adain", "v2", b, edge, False)
+    esf_case("esf_adain_edge_detach_b2", "baseline_adain_edge", "v2", b, edge, False, overrides={"seg_detach": 1})
 
 
 def gold_losses():
@@ -343,12 +354,14 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "loss", "fit", "metrics", "keys", "evaluate"]
+    what = sys.argv[1:] or ["bdcn", "esf", "adain", "loss", "fit", "metrics", "keys", "evaluate"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
     if "esf" in what:
         gold_esf(bd or ref_bdcn())
+    if "adain" in what:
+        gold_esf_adain_train(bd or ref_bdcn())
     if "loss" in what:
         gold_losses()
     if "fit" in what:

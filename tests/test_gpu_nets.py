@@ -219,7 +219,8 @@ def test_no_cpu_fallback():
 # training: forward in train mode (batch-stat BatchNorm, two encoder passes) + backward
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["esf_edge_b2", "esf_baseline_b2", "esf_concat_b2", "esf_edge_b2_absent1",
-                                  "esf_edge_b2_absent_all"])
+                                  "esf_edge_b2_absent_all", "esf_adain_edge_b2", "esf_adain_b2_train",
+                                  "esf_adain_edge_detach_b2"])
 def test_esf_train_step_vs_reference(name, edge_of_exact):
     edge_of = edge_of_exact
     """loss.backward() on the HIP path against the reference's autograd (fixtures: per-parameter grad

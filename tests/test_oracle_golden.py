@@ -100,7 +100,7 @@ def test_esf_disentangle(edges):
     np.testing.assert_allclose(out[3].numpy(), g["loss"], rtol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["esf_edge_b2", "esf_concat_b2", "esf_edge_b2_absent1"])
+@pytest.mark.parametrize("name", ["esf_edge_b2", "esf_concat_b2", "esf_edge_b2_absent1", "esf_adain_edge_detach_b2"])
 def test_esf_train_mode_and_grads(name, edges):
     """Training-mode forward (batch-stat BatchNorm, two encoder passes) and backward via autograd."""
     cfg, variant, kw = ESF_CASES[name]
