@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--config", default="baseline_edge", help="configs/<name>.yaml (baseline_adain_edge = BASELINE.json configs[3])")
     ap.add_argument("--fit", action="store_true", help="inference: also run the ellipse-fit stage of evaluate.py (2 fits per frame)")
     ap.add_argument("--layers", action="store_true", help="print a per-launch time / TFLOP/s table to stderr")
     return ap.parse_args()
@@ -93,7 +94,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    with open(os.path.join(os.path.dirname(egne_amd.__file__), "configs", "baseline_edge.yaml")) as f:
+    with open(os.path.join(os.path.dirname(egne_amd.__file__), "configs", a.config + ".yaml")) as f:
         setting = yaml.safe_load(f)
     bd = BDCN()
     bd.load_state_dict(synth.seeded_state_dict(bd.state_dict(), kind="bdcn"))
@@ -189,11 +190,12 @@ def main():
             "value": round(frames / dt, 2), "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("baseline_edge.yaml (chz=32) TRAIN step (BASELINE.json configs[2] shape, but fp32 and "
+            "config": {"workload": (a.config + ".yaml (chz=32) TRAIN step (BASELINE.json configs[2] shape, but fp32 and "
                                     "batch=%d/GPU), 240x320 synthetic TEyeD-shaped batch, seeded random-init weights" % B) if train
-                       else ("BASELINE.json configs[1]: baseline_edge.yaml (chz=32) inference, batch=%d/GPU, fp32, "
-                             "240x320 synthetic IR frames, seeded random-init weights" % B),
-                       "frames_per_gpu_per_step": B, "ellipse_fit_stage": bool(a.fit),
+                       else ("BASELINE.json configs[1]: %s.yaml (chz=32) inference, batch=%d/GPU, fp32, "
+                             "240x320 synthetic IR frames, seeded random-init weights" % (a.config, B)),
+                       "frames_per_gpu_per_step": B, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       "ellipse_fit_stage": bool(a.fit),
                        "arithmetic": "fp32 tensors everywhere; training: exact fp32 MFMA; inference: split-f16 MFMA products "
                                      "(22-bit significand) with fp32 accumulation where eligible, exact fp32 elsewhere",
                        "parallelism": ("dp%d (one flat RCCL all-reduce of 13.45 MB per step)" % world) if train

@@ -28,6 +28,22 @@ __device__ __forceinline__ float act1(float v, int act) {
 // the sub-lattices (phase_y + S*i, phase_x + S*j); a tile is 8 x 32 LATTICE points, its halo is one lattice
 // step wide (D = 1), so a dilation-12 conv stages the same 340-pixel halo as a dilation-1 conv.  Pixels are
 // 128-B channel vectors, so the strided gather still moves full cache lines.
+//
+// Instruction budget: the matrix work of a tile is only 54 MFMAs per 32x32 block, so every VALU / SALU
+// instruction around it counts (PMC: the first version issued 12 VALU + 6 SALU per MFMA and ran VALU-bound).
+// All global traffic therefore goes through BUFFER instructions on per-frame resources: the halo gather, the
+// weight ring, the residual and the output use 32-bit byte offsets that are tile-independent per lane plus one
+// scalar per tile, and out-of-image / padded lanes carry the offset 0x80000000, which the range check of the
+// buffer unit turns into a zero load or a dropped store -- no per-lane 64-bit address math and no selects.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
 template <int WM, int WN, int D, bool LAT>
 __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
@@ -37,6 +53,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
   constexpr int HWd = TW + 2 * d, HHd = TH + 2 * d, npx = HHd * HWd;
   constexpr int nitems = npx * 8;
   constexpr int NI = (nitems + 255) / 256;
+  static_assert(HWd >= 32, "one wrap per 32-pixel step");
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* Ahi = ldsh;
   _Float16* Alo = ldsh + npx * LDH;
@@ -48,8 +65,27 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
   const egne_seg sg = p.seg[0];
   const int Cp = sg.Cp;
   const int c4 = tid & 7;
-
   const int S = LAT ? p.dil[0] : 1;          // lattice step
+  const unsigned frame_in = (unsigned)p.H * p.W * (unsigned)sg.pix_stride * 4u;
+  const unsigned frame_out = (unsigned)p.H * p.W * (unsigned)p.out_pix_stride * 4u;
+  const unsigned frame_res = (unsigned)p.H * p.W * (unsigned)p.res_pix_stride * 4u;
+
+  // tile-independent per-item constants: halo coordinates (in image pixels, lattice step applied) and byte offset
+  int hyx[NI], roff[NI];
+  {
+    int px = tid >> 3;
+    int hy = px / HWd, hx = px - hy * HWd;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool in = tid + 256 * i < nitems;
+      hyx[i] = in ? ((S * hy) << 16) | (S * hx) : 0x7fff7fff;
+      roff[i] = ((S * hy * p.W + S * hx) * (int)sg.pix_stride + c4 * 4) * 4;
+      hx += 32;
+      if (hx >= HWd) { hx -= HWd; ++hy; }
+    }
+  }
+  const int lofs0 = (tid >> 3) * LDH + c4 * 4;   // LDS slot of item 0; item i is 32 pixels further
+
   struct Tile { int b, y0, x0, py, px; };    // y0/x0 in lattice units, (py, px) = lattice phase
   auto tile_of = [&](int t) {
     Tile r;
@@ -61,64 +97,59 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
     return r;
   };
 
-  int goff[NI];
-  const float* src = sg.ptr;
+  unsigned goff[NI];
+  __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr, 0);
   int stage_b = 0;
   auto map_tile = [&](const Tile& tl) {
+    const int ybase = tl.py + S * (tl.y0 - d), xbase = tl.px + S * (tl.x0 - d);
+    const int tbase = ((ybase * p.W + xbase) * (int)sg.pix_stride + sg.ch_off) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int item = tid + 256 * i;
-      goff[i] = -1;
-      if (item < nitems) {
-        const int px = item >> 3;
-        const int hy = px / HWd, hx = px - hy * HWd;
-        const int iy = tl.py + S * (tl.y0 - d + hy), ix = tl.px + S * (tl.x0 - d + hx);
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-          goff[i] = (int)((((long long)iy * p.W + ix) * sg.pix_stride) + sg.ch_off + c4 * 4);
-      }
+      const unsigned iy = (unsigned)(ybase + (hyx[i] >> 16)), ix = (unsigned)(xbase + (hyx[i] & 0xffff));
+      goff[i] = (iy < (unsigned)p.H && ix < (unsigned)p.W) ? (unsigned)(tbase + roff[i]) : OOB;
     }
-    src = sg.ptr + (long long)tl.b * p.H * p.W * sg.pix_stride;
+    rin = make_rsrc(sg.ptr + (long long)tl.b * p.H * p.W * sg.pix_stride, frame_in);
     stage_b = tl.b;
   };
 
-  f32x4 st[NI];
+  u32x4 st[NI];
   f32x4 st_sc = {1.f, 1.f, 1.f, 1.f}, st_sh = {0.f, 0.f, 0.f, 0.f};
-  bool st_cok = true;
+  unsigned st_cmask = 0;
   auto load_chunk = [&](int c0) {
     const bool cok = c0 + c4 * 4 < Cp;
-    st_cok = cok;
+    st_cmask = cok ? 0u : OOB;
     if (sg.scale) {
       st_sc = *(const f32x4*)(cok ? sg.scale + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page);
       st_sh = *(const f32x4*)(cok ? sg.shift + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page);
     }
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const float* q = (goff[i] >= 0 && cok) ? src + goff[i] + c0 : egne_zero_page;
-      st[i] = *(const f32x4*)q;
-    }
+    for (int i = 0; i < NI; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(goff[i] | st_cmask), c0 * 4, 0);
   };
+  // activations as max(v, slope*v): slope 0 = ReLU, 0.01 = LeakyReLU, 1 = identity (no per-element branches)
+  const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   auto store_chunk = [&]() {
+    if (sg.scale) {     // fused InstanceNorm affine (+ activation) of the consumer; zero padding applied after it
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        f32x4 v = __builtin_bit_cast(f32x4, st[i]) * st_sc + st_sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
+        if ((goff[i] | st_cmask) & OOB) v = (f32x4)(0.f);
+        st[i] = __builtin_bit_cast(u32x4, v);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int item = tid + 256 * i;
-      if (item < nitems) {
-        f32x4 v = st[i];
-        if (sg.scale) {
-          v = v * st_sc + st_sh;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = sg.act_in == EGNE_ACT_LEAKY ? (v[e] > 0.f ? v[e] : 0.01f * v[e]) : (sg.act_in == EGNE_ACT_RELU ? fmaxf(v[e], 0.f) : v[e]);
-          if (!(goff[i] >= 0 && st_cok)) v = (f32x4)(0.f);
-        }
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = v[e] * a_scale;
-          const _Float16 h = (_Float16)x;
-          hi[e] = h;
-          lo[e] = (_Float16)(x - (float)h);
-        }
-        const int o = (item >> 3) * LDH + c4 * 4;
+      if (i < NI - 1 || tid + 256 * i < nitems) {
+        const f32x4 v = __builtin_bit_cast(f32x4, st[i]);
+        // x*a_scale = hi + lo, two elements per (packed) instruction
+        const f32x2 x0 = {v[0] * a_scale, v[1] * a_scale}, x1 = {v[2] * a_scale, v[3] * a_scale};
+        const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
+        const h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x2), h2);
+        const h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x2), h2);
+        const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+        const int o = lofs0 + i * 32 * LDH;
         *(h4*)&Ahi[o] = hi;
         *(h4*)&Alo[o] = lo;
       }
@@ -131,9 +162,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
 
-  // fragment-order weights: element ((tap*KT16 + k16)*NT + nt)*512 + lane*8 (halfs)
-  const long long stride_k16 = (long long)NT * 512, stride_tap = (long long)KT16 * NT * 512;
-  const long long wlane = (long long)nt0 * 512 + lane * 8;
+  // fragment-order weights: element ((tap*KT16 + k16)*NT + nt)*512 + lane*8 (halfs); byte offsets below
+  const unsigned wbytes = 9u * (unsigned)p.Ktot * (unsigned)p.CoutP * 2u;
+  const __amdgpu_buffer_rsrc_t rwh = make_rsrc(fhi, wbytes), rwl = make_rsrc(flo, wbytes);
+  const int stride_k16 = NT * 1024, stride_tap = KT16 * NT * 1024;
+  const int wlane = lane * 16;
+
+  // epilogue constants: lane -> channel n, first x of the lane inside a tile row
+  const int out_step = S * (int)p.out_pix_stride * 4, res_step = S * (int)p.res_pix_stride * 4;
 
   int t = blockIdx.x;
   if (t >= ntiles) return;
@@ -155,16 +191,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
       map_tile(nx);
       load_chunk(0);
     }
-    const long long wchunk = wlane + (long long)(c0 >> 4) * stride_k16;
+    const int wchunk = nt0 * 1024 + (c0 >> 4) * stride_k16;
     // 4-slot ring: slot = (tap & 1) * 2 + ks holds the fragments of (tap, ks); refilled two taps ahead
-    f32x4 qh[4][WN], ql[4][WN];
+    u32x4 qh[4][WN], ql[4][WN];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
-        const long long o = wchunk + (long long)(s >> 1) * stride_tap + (long long)(s & 1) * stride_k16 + tn * 512;
-        qh[s][tn] = *(const f32x4*)(fhi + o);
-        ql[s][tn] = *(const f32x4*)(flo + o);
+        const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
+        qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
+        ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
       }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -187,9 +223,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
         if (tap + 2 < 9) {
 #pragma unroll
           for (int tn = 0; tn < WN; ++tn) {
-            const long long o = wchunk + (long long)(tap + 2) * stride_tap + (long long)ks * stride_k16 + tn * 512;
-            qh[slot][tn] = *(const f32x4*)(fhi + o);
-            ql[slot][tn] = *(const f32x4*)(flo + o);
+            const int o = wchunk + (tap + 2) * stride_tap + ks * stride_k16 + tn * 1024;
+            qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
+            ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
           }
         }
 #pragma unroll
@@ -204,37 +240,46 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
     }
     if (!last_chunk) { c0 += KC; continue; }
 
+    // ---- epilogue: lane holds channel n of 16 pixels x = x_lane + S*c_r, c_r = (r&3) + 8*(r>>2), of tile row tm ----
+    {
+      const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + (long long)cur.b * p.H * p.W * p.out_pix_stride, frame_out);
+      const __amdgpu_buffer_rsrc_t rres =
+          make_rsrc(p.residual ? p.residual + (long long)cur.b * p.H * p.W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
+      const int xl = cur.px + S * (cur.x0 + 4 * lh);
+      const int cmax = xl < p.W ? (p.W - xl + S - 1) / S : 0;      // c_r < cmax  <=>  x < W
 #pragma unroll
-    for (int tn = 0; tn < WN; ++tn) {
-      const int n = (nt0 + tn) * 32 + li;
-      const bool nok = n < p.Cout_store;
-      const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-      float ps = 1.f, pt = 0.f;
-      if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+      for (int tn = 0; tn < WN; ++tn) {
+        const int n = (nt0 + tn) * 32 + li;
+        const bool nok = n < p.Cout_store;
+        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+        float ps = 1.f, pt = 0.f;
+        if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
 #pragma unroll
-      for (int tm = 0; tm < WM; ++tm) {
-        const int y = cur.py + S * (cur.y0 + wave * WM + tm);
-        // all residual loads of the tile row first (one wait), then the stores
-        float rv[16];
+        for (int tm = 0; tm < WM; ++tm) {
+          const int y = cur.py + S * (cur.y0 + wave * WM + tm);
+          const int cm = (nok && y < p.H) ? cmax : 0;
+          const int pix = y * p.W + xl;
+          const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
+          float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int x = cur.px + S * (cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-          const bool ok = p.residual && nok && y < p.H && x < p.W;
-          const long long m = ((long long)cur.b * p.H + y) * p.W + x;
-          const float* q = ok ? p.residual + m * p.res_pix_stride + p.res_ch_off + n : egne_zero_page;
-          rv[r] = *q;
-        }
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+          if (p.residual) {     // all residual loads of the tile row first (one wait), then the stores
+            const unsigned r0 = (unsigned)((pix * (int)p.res_pix_stride + p.res_ch_off + n) * 4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int x = cur.px + S * (cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-          if (nok && y < p.H && x < p.W) {
-            const long long m = ((long long)cur.b * p.H + y) * p.W + x;
-            float v = act1(acc[tm][tn][r] * out_scale + bv, p.act);
-            if (p.post_scale) v = v * ps + pt;
-            p.out[m * p.out_pix_stride + p.out_ch_off + n] = v + rv[r];
+            for (int r = 0; r < 16; ++r) {
+              const int c = (r & 3) + 8 * (r >> 2);
+              rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0));
+            }
           }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            float v = acc[tm][tn][r] * out_scale + bv;
+            v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+          }
+          acc[tm][tn] = (f32x16)(0.f);
         }
-        acc[tm][tn] = (f32x16)(0.f);
       }
     }
     t = tnext;
@@ -305,7 +350,8 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   EGNE_REQUIRE(d.CoutP % 32 == 0 && d.Cout_store <= d.CoutP && d.out && d.out_ch_off + d.Cout_store <= d.out_pix_stride,
                "conv_halo_f16: CoutP %d", d.CoutP);
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv_halo_f16: weights / scales");
-  EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride < (1ll << 31), "conv_halo_f16: frame too large for 32-bit offsets");
+  EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
+               (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv_halo_f16: frame too large for 32-bit byte offsets");
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16* h = (const _Float16*)fhi;
