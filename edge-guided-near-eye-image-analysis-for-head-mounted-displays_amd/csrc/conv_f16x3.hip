@@ -30,9 +30,24 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// 4 waves arranged WGM x WGN, each wave owns TM x TN MFMA tiles (32x32).  Two shapes are instantiated:
-//   <2,2,2,2>  128 x 128  wide layers (VGG trunk)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// 4 waves arranged WGM x WGN, each wave owns TM x TN MFMA tiles (32x32).  Shapes instantiated:
+//   <2,2,2,2>  128 x 128  wide layers (VGG trunk)          <4,1,2,2>  256 x 64
 //   <4,1,2,1>  256 x  32  the 32-channel MSBlock convs; GROUPED fuses its three dilated convs + 4-way sum
+//
+// Addressing (PMC: the first version issued 8.5 VALU + 4.6 SALU per MFMA, as much issue time as the MFMAs): every
+// staged row keeps ONE byte offset relative to the first frame of the tile and a bit mask of the taps that fall
+// inside the image; a K-step adds a scalar tap offset and selects 0x80000000 for padded lanes, which the
+// buffer unit's range check turns into zeros.  Weights, residual and output use buffer instructions with
+// lane-constant offsets and scalar step offsets as well.
 template <int WGM, int WGN, int TM, int TN, bool GROUPED>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ whi,
                                                          const _Float16* __restrict__ wlo, float a_scale,
@@ -54,53 +69,78 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   const int n0 = blockIdx.y * BN;
   const int T = p.kh * p.kw;
   const egne_seg sg = p.seg[0];
+  const int hw = p.Ho * p.Wo;
+  const int b0 = (int)(m0 / hw);               // first frame of the tile; rows belong to b0 .. b0 + BM/hw + 1
+  const int frame_px = p.H * p.W;
+  const long long in_left = ((long long)p.B - b0) * frame_px * sg.pix_stride * 4;
+  const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+                                               (unsigned)(in_left < 0x7fffffffll ? in_left : 0x7fffffffll));
+  const unsigned wbytes = (unsigned)p.ngroups * T * p.CoutP * p.Ktot * 2u;
+  const __amdgpu_buffer_rsrc_t rwh = make_rsrc(whi, wbytes), rwl = make_rsrc(wlo, wbytes);
 
   const int col4 = tid & 7, rbase = tid >> 3;
-  int pb[AR], py[AR], px[AR];
+  int roff[AR], pb[AR];        // byte offset of the row's centre pixel (+ channel column), frame index (or -1)
+  short py[AR], px[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const long long m = m0 + rbase + 32 * i;
-    if (m < M) {
-      const int hw = p.Ho * p.Wo;
-      const int b = (int)(m / hw);
-      const int r = (int)(m - (long long)b * hw);
-      const int oy = r / p.Wo;
-      pb[i] = b; py[i] = oy; px[i] = r - oy * p.Wo;
-    } else {
-      pb[i] = -1; py[i] = 0; px[i] = 0;
+    const int b = (int)(m / hw);
+    const int r = (int)(m - (long long)b * hw);
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    pb[i] = m < M ? b : -1; py[i] = (short)oy; px[i] = (short)ox;
+    roff[i] = ((((b - b0) * p.H + oy) * p.W + ox) * (int)sg.pix_stride + sg.ch_off + col4 * 4) * 4;
+  }
+  // taps of group g that read inside the image, one bit per tap and row
+  unsigned tapmask[AR];
+  auto make_masks = [&](int g) {
+    const int dil = p.dil[g];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      unsigned mk = 0;
+      for (int ky = 0; ky < p.kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx) {
+          const int iy = py[i] + (ky - p.pad_h) * dil, ix = px[i] + (kx - p.pad_w) * dil;
+          if (pb[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mk |= 1u << (ky * p.kw + kx);
+        }
+      tapmask[i] = mk;
     }
+  };
+  make_masks(0);
+
+  int boff[BI];                // weights: lane-constant byte offset inside one (group, tap) block
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int item = tid + 256 * j;
+    const int row = item >> 2, piece = item & 3;
+    boff[j] = row < BN ? ((n0 + row) * p.Ktot + piece * 8) * 2 : (int)OOB;
   }
 
-  f32x4 ra[AR];
-  f32x4 rbh[BI], rbl[BI];   // 8 halfs each (loaded as 16 B)
+  u32x4 ra[AR];
+  u32x4 rbh[BI], rbl[BI];   // 8 halfs each (loaded as 16 B)
   unsigned okmask = 0;
   int st_c = 0;
+  int ky_n = 0, kx_n = 0;   // tap coordinates of the step being loaded (no per-step division)
   auto load_step = [&](int g, int tap, int c0) {
     const int dil = p.dil[g];
-    const int ky = tap / p.kw, kx = tap - ky * p.kw;
-    const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
-    const bool cok = c0 + col4 * 4 < sg.Cp;     // channel tail of a slice whose width is not a multiple of 32
+    const int tapoff = (((ky_n - p.pad_h) * p.W + (kx_n - p.pad_w)) * dil * (int)sg.pix_stride + c0) * 4;
+    const unsigned cbad = c0 + col4 * 4 < sg.Cp ? 0u : OOB;   // channel tail of a slice whose width is not a multiple of 32
     okmask = 0;
     st_c = c0 + col4 * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const int iy = py[i] + dy, ix = px[i] + dx;
-      const bool ok = cok && pb[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + col4 * 4;
-      src = ok ? src : egne_zero_page;
-      ra[i] = *(const f32x4*)src;
+      const bool ok = ((tapmask[i] >> tap) & 1u) && !cbad;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? roff[i] + tapoff : (int)OOB, 0, 0);   // tapoff may be negative: not an soffset
       okmask |= (ok ? 1u : 0u) << i;
     }
+    const int wstep = (((g * T + tap) * p.CoutP) * p.Ktot + c0) * 2;
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-      const int item = tid + 256 * j;
-      const int row = item >> 2, piece = item & 3;
-      const bool ok = row < BN;
-      const long long off = ((long long)(g * T + tap) * p.CoutP + n0 + row) * p.Ktot + c0 + piece * 8;
-      rbh[j] = *(const f32x4*)(ok ? (const void*)(whi + off) : (const void*)egne_zero_page);
-      rbl[j] = *(const f32x4*)(ok ? (const void*)(wlo + off) : (const void*)egne_zero_page);
+      rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(rwh, boff[j], wstep, 0);
+      rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(rwl, boff[j], wstep, 0);
     }
   };
+  const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   auto store_step = [&]() {
     if (sg.scale) {   // fused InstanceNorm affine (+ activation) of the consumer, zero padding applied after it
       const bool same = pb[0] == pb[AR - 1] && pb[0] >= 0 && st_c < sg.Cp;
@@ -119,23 +159,20 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
         } else if (!ok) {
           sc = (f32x4)(0.f); sh = (f32x4)(0.f);
         }
-        f32x4 v = ra[i] * sc + sh;
+        f32x4 v = __builtin_bit_cast(f32x4, ra[i]) * sc + sh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = sg.act_in == EGNE_ACT_LEAKY ? (v[e] > 0.f ? v[e] : 0.01f * v[e]) : (sg.act_in == EGNE_ACT_RELU ? fmaxf(v[e], 0.f) : v[e]);
-        ra[i] = v;
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
+        ra[i] = __builtin_bit_cast(u32x4, v);
       }
     }
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      h4 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = ra[i][e] * a_scale;
-        const _Float16 h = (_Float16)x;
-        hi[e] = h;
-        lo[e] = (_Float16)(x - (float)h);
-      }
+      const f32x4 v = __builtin_bit_cast(f32x4, ra[i]);
+      const f32x2 x0 = {v[0] * a_scale, v[1] * a_scale}, x1 = {v[2] * a_scale, v[3] * a_scale};
+      const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
+      const h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x2), h2);
+      const h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x2), h2);
+      const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
       const int o = (rbase + 32 * i) * LDH + col4 * 4;
       *(h4*)&Ahi[o] = hi;
       *(h4*)&Alo[o] = lo;
@@ -143,10 +180,10 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       const int item = tid + 256 * j;
-      if ((item >> 2) < BN) {
+      if (BN * 4 % 256 == 0 || (item >> 2) < BN) {
         const int o = (item >> 2) * LDH + (item & 3) * 8;
-        *(f32x4*)&Bhi[o] = rbh[j];
-        *(f32x4*)&Blo[o] = rbl[j];
+        *(u32x4*)&Bhi[o] = rbh[j];
+        *(u32x4*)&Blo[o] = rbl[j];
       }
     }
   };
@@ -172,7 +209,11 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   const int brow = (wn * TN * 32 + li) * LDH + lh * 8;
   for (int step = 0; step < nsteps; ++step) {
     int ng = g, ntap = tap + 1, nc0 = c0;
-    if (ntap == T) { ntap = 0; nc0 += KC; if (nc0 >= sg.Cp) { nc0 = 0; ++ng; } }
+    if (++kx_n == p.kw) { kx_n = 0; ++ky_n; }
+    if (ntap == T) {
+      ntap = 0; ky_n = 0; kx_n = 0; nc0 += KC;
+      if (nc0 >= sg.Cp) { nc0 = 0; ++ng; if (GROUPED && ng < p.ngroups) make_masks(ng); }
+    }
     const bool more = step + 1 < nsteps;
     if (more) load_step(ng, ntap, nc0);
 #pragma unroll
@@ -205,7 +246,10 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) res[tm][tn][r] += act_apply(acc[tm][tn][r] * out_scale + bv, p.act);
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[tm][tn][r] * out_scale + bv;
+            res[tm][tn][r] += fmaxf(v, v * slope_out);
+          }
           acc[tm][tn] = (f32x16)(0.f);
         }
       }
@@ -216,22 +260,39 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
     g = ng; tap = ntap; c0 = nc0;
   }
 
+  // ---- epilogue: lane holds channel n of 16 rows (pixels) m = mrow + c_r, c_r = (r&3) + 8*(r>>2) + 4*lh ----
+  const long long left = M - m0;                                    // rows of this tile inside the tensor
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * 4));
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
+                                                p.residual ? (unsigned)((left < BM ? left : BM) * p.res_pix_stride * 4) : 0u);
+  const int ostep = (int)p.out_pix_stride * 4, rstep = (int)p.res_pix_stride * 4;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + (wn * TN + tn) * 32 + li;
     const bool nok = n < p.Cout_store;
     const float bv = (!GROUPED && p.bias && nok) ? p.bias[n] : 0.f;
+    float ps = 1.f, pt = 0.f;
+    if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      const int mrow = (wm * TM + tm) * 32 + 4 * lh;
+      const unsigned o0 = nok ? (unsigned)(mrow * ostep + (p.out_ch_off + n) * 4) : OOB;   // rows past M: range check
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      if (p.residual) {
+        const unsigned r0 = nok ? (unsigned)(mrow * rstep + (p.res_ch_off + n) * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(r0 + ((r & 3) + 8 * (r >> 2)) * rstep), 0, 0));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nok && m < M) {
-          float v = GROUPED ? res[tm][tn][r] : act_apply(acc[tm][tn][r] * out_scale + bv, p.act);
-          if (p.post_scale) v = v * p.post_scale[n] + p.post_shift[n];
-          if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
-          p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
-        }
+        float v;
+        if (GROUPED) v = res[tm][tn][r];
+        else { v = acc[tm][tn][r] * out_scale + bv; v = fmaxf(v, v * slope_out); }
+        v = v * ps + pt + rv[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
       }
     }
   }
