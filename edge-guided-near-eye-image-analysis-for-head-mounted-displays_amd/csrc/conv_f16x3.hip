@@ -79,15 +79,14 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   const __amdgpu_buffer_rsrc_t rwh = make_rsrc(whi, wbytes), rwl = make_rsrc(wlo, wbytes);
 
   const int col4 = tid & 7, rbase = tid >> 3;
-  int roff[AR], pb[AR];        // byte offset of the row's centre pixel (+ channel column), frame index (or -1)
-  short py[AR], px[AR];
+  int roff[AR], pb[AR], pyx[AR];   // byte offset of the row's centre pixel (+ channel column), frame index (or -1), oy<<16|ox
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const long long m = m0 + rbase + 32 * i;
     const int b = (int)(m / hw);
     const int r = (int)(m - (long long)b * hw);
     const int oy = r / p.Wo, ox = r - oy * p.Wo;
-    pb[i] = m < M ? b : -1; py[i] = (short)oy; px[i] = (short)ox;
+    pb[i] = m < M ? b : -1; pyx[i] = (oy << 16) | ox;
     roff[i] = ((((b - b0) * p.H + oy) * p.W + ox) * (int)sg.pix_stride + sg.ch_off + col4 * 4) * 4;
   }
   // taps of group g that read inside the image, one bit per tap and row
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
       unsigned mk = 0;
       for (int ky = 0; ky < p.kh; ++ky)
         for (int kx = 0; kx < p.kw; ++kx) {
-          const int iy = py[i] + (ky - p.pad_h) * dil, ix = px[i] + (kx - p.pad_w) * dil;
+          const int iy = (pyx[i] >> 16) + (ky - p.pad_h) * dil, ix = (pyx[i] & 0xffff) + (kx - p.pad_w) * dil;
           if (pb[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mk |= 1u << (ky * p.kw + kx);
         }
       tapmask[i] = mk;
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   auto store_step = [&]() {
-    if (sg.scale) {   // fused InstanceNorm affine (+ activation) of the consumer, zero padding applied after it
+    if (!GROUPED && sg.scale) {   // fused InstanceNorm affine (+ activation) of the consumer, zero padding applied after it
       const bool same = pb[0] == pb[AR - 1] && pb[0] >= 0 && st_c < sg.Cp;
       f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
       if (same) {
@@ -336,7 +335,8 @@ extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, 
   EGNE_REQUIRE(dp && whi && wlo, "conv_f16x3: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.nseg == 1 && d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP && d.stride == 1 && d.pad_mode == 0 &&
-               (d.seg[0].scale == nullptr) == (d.seg[0].shift == nullptr), "conv_f16x3: unsupported descriptor");
+               (d.seg[0].scale == nullptr) == (d.seg[0].shift == nullptr) && (d.ngroups == 1 || !d.seg[0].scale),
+               "conv_f16x3: unsupported descriptor");
   EGNE_REQUIRE(d.seg[0].Cp % 8 == 0 && (d.seg[0].Cp + 31) / 32 * 32 == d.Ktot && d.CoutP % 32 == 0,
                "conv_f16x3: Cp %d Ktot %d (must be Cp rounded up to 32) CoutP %d", d.seg[0].Cp, d.Ktot, d.CoutP);
   EGNE_REQUIRE(d.seg[0].ptr && ((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0,

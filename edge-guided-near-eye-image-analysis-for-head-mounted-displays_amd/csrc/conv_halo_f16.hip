@@ -45,7 +45,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 
 template <int WM, int WN, int D, bool LAT>
-__global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
   constexpr int TH = 4 * WM;
@@ -192,10 +192,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
       load_chunk(0);
     }
     const int wchunk = nt0 * 1024 + (c0 >> 4) * stride_k16;
-    // 4-slot ring: slot = (tap & 1) * 2 + ks holds the fragments of (tap, ks); refilled two taps ahead
-    u32x4 qh[4][WN], ql[4][WN];
+    // register ring: slot = (tap % RT) * 2 + ks holds the fragments of (tap, ks); refilled RT taps ahead
+    constexpr int RT = WN == 1 ? 2 : 1;
+    u32x4 qh[2 * RT][WN], ql[2 * RT][WN];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 2 * RT; ++s)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
         const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
       const int aoff = abase + (ky * d * HWd + kx * d) * LDH;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int slot = (tap & 1) * 2 + ks;
+        const int slot = (tap % RT) * 2 + ks;
         h8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
@@ -220,10 +221,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f16_kernel(const egne_conv_d
           bh[tn] = __builtin_bit_cast(h8, qh[slot][tn]);
           bl[tn] = __builtin_bit_cast(h8, ql[slot][tn]);
         }
-        if (tap + 2 < 9) {
+        if (tap + RT < 9) {
 #pragma unroll
           for (int tn = 0; tn < WN; ++tn) {
-            const int o = wchunk + (tap + 2) * stride_tap + ks * stride_k16 + tn * 1024;
+            const int o = wchunk + (tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
             qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
             ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
           }

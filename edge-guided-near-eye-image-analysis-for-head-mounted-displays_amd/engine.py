@@ -17,7 +17,7 @@ import os
 
 HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
-HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "64"))
+HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
