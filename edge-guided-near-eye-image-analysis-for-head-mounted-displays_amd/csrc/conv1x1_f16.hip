@@ -1,0 +1,206 @@
+// Streaming 1x1 convolution over a concatenation of NHWC slices on the split-f16 MFMA path (fp32 tensors, three
+// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; numerics: conv_f16x3.hip).
+//
+// The 1x1 convs of ESF-Net's dense blocks (models/RITnet_v2.py:59,61 conv21 / conv31, :84,86 conv11 / conv21,
+// :38 Transition_down) read 64..160 channels and write 32..64: 6 FLOP per byte, an HBM stream.  Nothing is
+// reused between pixels, so nothing is staged: every wave walks 32-pixel blocks on its own, each lane loads its
+// MFMA operand (8 channels of one pixel, two 16-byte pieces) straight from HBM through a BUFFER resource built
+// per block (rows past the tensor end and padded channel groups get the out-of-range offset 0x80000000 and load
+// zeros), splits it into hi / lo halves in registers and multiplies with weight fragments that sit in LDS for the
+// whole launch.  No barriers after the weight copy, no address arithmetic in the loop; the occupancy (4 waves per
+// SIMD) keeps ~150 KB of loads in flight per CU.
+//
+// K order: the slot (half h = lane>>5, j) of 16-channel group g holds channel 16*g + (j < 4 ? 4*h + j : 8 + 4*h + j - 4),
+// so that the two lanes of a pixel read ADJACENT 16-byte pieces (one full 32-byte sector per instruction); the
+// pack (egne_pack_conv1x1_weight_f16) uses the same order.  The product is computed transposed (weights as the
+// A operand): a lane ends up with 4 consecutive output channels of one pixel -> 16-byte stores.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, float s, h8& hi, h8& lo) {
+  const f32x4 va = __builtin_bit_cast(f32x4, a), vb = __builtin_bit_cast(f32x4, b);
+  const f32x2 x[4] = {{va[0] * s, va[1] * s}, {va[2] * s, va[3] * s}, {vb[0] * s, vb[1] * s}, {vb[2] * s, vb[3] * s}};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const h2 h = __builtin_convertvector(x[q], h2);
+    const h2 l = __builtin_convertvector(x[q] - __builtin_convertvector(h, f32x2), h2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1];
+    lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+
+// fhi / flo: [G][CoutP/32][64 lanes][8 halfs]; G = sum over slices of ceil(Cp/16)
+template <int TN>
+__global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
+                                                            const _Float16* __restrict__ flo, float a_scale, float out_scale,
+                                                            int G, long long M, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 wl[];   // [G][TN][hi|lo][64][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kq = lane >> 5;
+  const int NT = p.CoutP >> 5, nt0 = blockIdx.y * TN;
+  for (int it = tid; it < G * TN * 2 * 64; it += 256) {        // 16-byte items
+    const int l = it & 63, hl = (it >> 6) & 1;
+    const int tn = (it >> 7) % TN, g = (it >> 7) / TN;
+    const _Float16* src = (hl ? flo : fhi) + (((long long)g * NT + nt0 + tn) * 64 + l) * 8;
+    *(u32x4*)&wl[(long long)it * 8] = *(const u32x4*)src;
+  }
+  __syncthreads();
+
+  const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  // transposed product: lane holds output channels n = 32*nt + 8*j + 4*kq + e (r = 4*j + e) of pixel li
+  f32x4 bias[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = (nt0 + tn) * 32 + 8 * j + 4 * kq;
+      bias[tn][j] = (p.bias && n < p.Cout_store) ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
+    }
+
+  for (int blk = blockIdx.x * 4 + wave; blk < nblocks; blk += gridDim.x * 4) {
+    const long long m0 = (long long)blk * 32;
+    const long long rows = M - m0 < 32 ? M - m0 : 32;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) acc[tn] = (f32x16)(0.f);
+    int g = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+      const egne_seg sg = p.seg[s];
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(sg.ptr + m0 * sg.pix_stride, (unsigned)(rows * sg.pix_stride * 4));
+      const int voff = (li * (int)sg.pix_stride + sg.ch_off + 4 * kq) * 4;
+      const int n16 = (sg.Cp + 15) >> 4;
+      const bool tail8 = (sg.Cp & 15) != 0;                      // last group of the slice holds 8 channels only
+      for (int g0 = 0; g0 < n16; g0 += 4) {
+        u32x4 xa[4], xb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gg = g0 + u;
+          const int oa = gg < n16 ? voff : (int)OOB;
+          const int ob = (gg < n16 && !(tail8 && gg == n16 - 1)) ? voff : (int)OOB;
+          xa[u] = __builtin_amdgcn_raw_buffer_load_b128(r, oa, gg * 64, 0);        // channels 16g + 4kq .. +3
+          xb[u] = __builtin_amdgcn_raw_buffer_load_b128(r, ob + 32, gg * 64, 0);   // channels 16g + 8 + 4kq .. +3
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (g0 + u < n16) {
+            h8 ah, al;
+            split8(xa[u], xb[u], a_scale, ah, al);
+            const _Float16* wp = wl + ((long long)(g + g0 + u) * TN * 2 * 64 + lane) * 8;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              const h8 wh = *(const h8*)(wp + (tn * 2 + 0) * 512), wo = *(const h8*)(wp + (tn * 2 + 1) * 512);
+              acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc[tn], 0, 0, 0);
+              acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wo, ah, acc[tn], 0, 0, 0);
+              acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc[tn], 0, 0, 0);
+            }
+          }
+        }
+      }
+      g += n16;
+    }
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = (nt0 + tn) * 32 + 8 * j + 4 * kq;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[tn][4 * j + e] * out_scale + bias[tn][j][e];
+          v[e] = fmaxf(t, t * slope);
+        }
+        const int off = n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, off, 0, 0);
+      }
+  }
+}
+
+// OIHW (kh = kw = 1) fp32 -> hi / lo f16 fragments [G][CoutP/32][lane = h*32 + n%32][8]; kmap[g*16 + h*8 + j] names
+// the logical input channel of that K slot (or -1: padding)
+__global__ void pack_w1x1_f16_k(const float* __restrict__ w, int Cout, int Cin, const int* __restrict__ kmap, int G, int CoutP,
+                                float wscale, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  const long long total = (long long)G * CoutP * 16;
+  const int NT = CoutP >> 5;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), nn = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    long long q = i >> 9;
+    const int nt = (int)(q % NT);
+    const int g = (int)(q / NT);
+    const int n = nt * 32 + nn, ci = kmap[g * 16 + h * 8 + j];
+    const float v = (n < Cout && ci >= 0) ? w[(long long)n * Cin + ci] * wscale : 0.f;
+    const _Float16 hh = (_Float16)v;
+    hi[i] = hh;
+    lo[i] = (_Float16)(v - (float)hh);
+  }
+}
+
+}  // namespace
+
+extern "C" int egne_pack_conv1x1_weight_f16(const float* w_oihw, int Cout, int Cin, const int32_t* kmap, int G, int CoutP,
+                                            float wscale, void* fhi, void* flo, void* stream) {
+  EGNE_REQUIRE(w_oihw && kmap && fhi && flo && Cout > 0 && Cin > 0 && G > 0 && CoutP >= Cout && CoutP % 32 == 0 && wscale > 0.f,
+               "pack_conv1x1_f16: bad sizes Cout %d Cin %d G %d CoutP %d", Cout, Cin, G, CoutP);
+  long long total = (long long)G * CoutP * 16, g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pack_w1x1_f16_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kmap, G, CoutP, wscale,
+                     (_Float16*)fhi, (_Float16*)flo);
+  return egne::check_launch("egne_pack_conv1x1_weight_f16");
+}
+
+// 1x1 / stride 1 / no padding over up to EGNE_MAXSEG raw slices (no fused affine), CoutP 32 or a multiple of 64, no
+// residual, no post affine.  Weights in the order of egne_pack_conv1x1_weight_f16 (G = sum of ceil(Cp/16)).
+extern "C" int egne_conv1x1_f16x3_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                      void* stream) {
+  EGNE_REQUIRE(dp && fhi && flo, "conv1x1_f16: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.Ho == d.H && d.Wo == d.W &&
+               d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && !d.residual && !d.post_scale, "conv1x1_f16: unsupported descriptor");
+  EGNE_REQUIRE(d.CoutP % 32 == 0 && (d.CoutP == 32 || d.CoutP % 64 == 0) && d.Cout_store <= d.CoutP && d.Cout_store % 4 == 0 && d.out &&
+               ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
+               d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv1x1_f16: output");
+  EGNE_REQUIRE(!d.bias || ((uintptr_t)d.bias & 15) == 0, "conv1x1_f16: bias alignment");
+  int G = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && g.Cp % 8 == 0 && g.ch_off % 4 == 0 &&
+                 g.pix_stride % 4 == 0 && ((uintptr_t)g.ptr & 15) == 0 && g.ch_off + g.Cp <= g.pix_stride && g.pix_stride * 128 < (1ll << 31),
+                 "conv1x1_f16: slice %d", s);
+    G += (g.Cp + 15) / 16;
+  }
+  EGNE_REQUIRE(d.out_pix_stride * 128 < (1ll << 31) && ((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f,
+               "conv1x1_f16: strides / weights / scales");
+  const long long M = (long long)d.B * d.H * d.W;
+  const long long nb = (M + 31) / 32;
+  EGNE_REQUIRE(nb < (1ll << 31), "conv1x1_f16: too many pixels");
+  const int TN = d.CoutP == 32 ? 1 : 2;
+  const size_t lds = (size_t)G * TN * 2 * 64 * 8 * sizeof(_Float16);
+  EGNE_REQUIRE(lds <= 64 * 1024, "conv1x1_f16: K = %d groups of 16 does not fit the LDS weight image", G);
+  const int ny = d.CoutP / (32 * TN);
+  long long gx = (nb + 3) / 4;
+  const long long cap = 256 * 8;
+  if (gx > cap) gx = cap;
+  const float os = 1.0f / (a_scale * w_scale);
+  hipStream_t st = (hipStream_t)stream;
+  if (TN == 1)
+    hipLaunchKernelGGL((conv1x1_f16x3_kernel<1>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+                       a_scale, os, G, M, (int)nb);
+  else
+    hipLaunchKernelGGL((conv1x1_f16x3_kernel<2>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+                       a_scale, os, G, M, (int)nb);
+  return egne::check_launch("egne_conv1x1_f16x3_fwd");
+}

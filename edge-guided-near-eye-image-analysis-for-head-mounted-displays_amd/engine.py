@@ -20,6 +20,8 @@ F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA f
 HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
+S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
+S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
@@ -98,6 +100,9 @@ class ConvLayer:
         self.split = False      # allow the split-f16 (f16x3) kernel for this layer (frozen nets only)
         self.need_split = False
         self.need_sfrag = False  # fragment-order f16 pack for the split-f16 halo kernel
+        self.split1 = False      # allow the streaming split-f16 kernel for this 1x1 layer (frozen nets only)
+        self.need_s1 = False
+        self.s1hi = self.s1lo = None
         self.whi = self.wlo = None
         self.fhi = self.flo = None
         self.w_scale = 1.0
@@ -118,7 +123,8 @@ class ConvLayer:
         vers = tuple(w._version for w in self.weights) + tuple(
             (b._version if b is not None else -1) for b in (self.biases or []))
         have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
-                and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag))
+                and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
+                and (self.s1hi is not None or not self.need_s1))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
         L = _lib.lib()
@@ -152,6 +158,27 @@ class ConvLayer:
             wd = self.weights[0].detach()
             self.w40.zero_()
             self.w40[:self.Cout, :36].view(self.Cout, 9, 4)[:, :, :self.Cin].copy_(wd.permute(0, 2, 3, 1).reshape(self.Cout, 9, self.Cin))
+        if self.need_s1:
+            # streaming 1x1 kernel: K slots of 16-channel groups per slice, slot (h, j) <-> channel 16g + (j<4 ? 4h+j : 8+4h+j-4)
+            import math
+            wd = self.weights[0].detach().contiguous()
+            mx = float(wd.abs().max())
+            self.w_scale1 = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
+            if self.s1hi is None:
+                kmap, c0 = [], 0
+                for c, cp in self.in_layout:
+                    for g in range((cp + 15) // 16):
+                        for h in range(2):
+                            for j in range(8):
+                                ch = 16 * g + (4 * h + j if j < 4 else 8 + 4 * h + j - 4)
+                                kmap.append(c0 + ch if ch < c else -1)
+                    c0 += c
+                self.s1_G = len(kmap) // 16
+                self.s1_kmap = torch.tensor(kmap, dtype=torch.int32, device=dev)
+                self.s1hi = torch.empty(self.s1_G * self.CoutP * 16, dtype=torch.float16, device=dev)
+                self.s1lo = torch.empty_like(self.s1hi)
+            _lib.check(L.egne_pack_conv1x1_weight_f16(wd.data_ptr(), self.Cout, self.Cin, self.s1_kmap.data_ptr(), self.s1_G, self.CoutP,
+                                                      self.w_scale1, self.s1hi.data_ptr(), self.s1lo.data_ptr(), st), "pack_conv1x1_f16")
         if self.need_split or self.need_sfrag:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
@@ -212,6 +239,8 @@ class DgradLayer(ConvLayer):
         self.wp = self.wf = self.bp = None
         self.need_flat = self.need_frag = False
         self.split = self.need_split = self.need_sfrag = False
+        self.split1 = self.need_s1 = False
+        self.s1hi = self.s1lo = None
         self.whi = self.wlo = self.fhi = self.flo = None
         self.w_scale = 1.0
         self._versions, self.post = None, None
@@ -356,6 +385,12 @@ class Plan:
         lattice = (split and LATTICE_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)
                    and layer.CoutP in (32, 64) and residual is not None and pieces[0].scale is None
                    and min(W // d_ for d_ in layer.dils) >= LATTICE_MIN_W and H * W * pieces[0].stride < 2 ** 31)
+        # 1x1 over raw slices: streaming split-f16 kernel (weights in LDS, operands straight from HBM)
+        s1x1 = (F16X3_ENABLED and S1X1_ENABLED and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
+                and layer.G == 1 and layer.pad == (0, 0) and residual is None and layer.post is None
+                and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
+                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 65536
+                and B * H * W >= S1X1_MIN_PIX)
         if lattice:
             shalo = True
         if split and not shalo and halo and pieces[0].scale is not None:
@@ -364,7 +399,11 @@ class Plan:
             split = shalo = False
         if smallcin or split:
             halo = False
-        if smallcin:
+        if s1x1:
+            smallcin = split = shalo = halo = lattice = False
+            layer.need_s1 = True
+            layer.need_flat = True
+        elif smallcin:
             layer.need_c4 = True
             layer.need_flat = True   # the generic pack is still what the backward (wgrad) paths index with kinv
         elif shalo:
@@ -407,7 +446,10 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if lattice:
+        if s1x1:
+            self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
+                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3")
+        elif lattice:
             perf = 9 * layer.CoutP * pad32(layer.Ktot)
             for g in range(3):
                 dg = _lib.ConvDesc()

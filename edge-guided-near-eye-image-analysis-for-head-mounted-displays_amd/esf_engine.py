@@ -49,6 +49,7 @@ def _cl(conv, layout, pad=(0, 0), act=ACT_NONE, **kw):
     l = ConvLayer([conv.weight], [conv.bias] if conv.bias is not None else None, layout, pad=pad, act=act, **kw)
     from . import engine
     l.split = engine.ESF_SPLIT and _cl.eval_plan and (l.kh > 1 or l.kw > 1)
+    l.split1 = engine.ESF_SPLIT and _cl.eval_plan and l.kh == 1 and l.kw == 1
     return l
 
 

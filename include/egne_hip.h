@@ -121,6 +121,17 @@ int egne_pack_conv_weight_f16frag(const float* w_oihw, int Cout, int Cin, int kh
 int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
                               float w_scale, void* stream);
 
+/* Streaming 1x1 convolution over a concatenation of raw NHWC slices (models/RITnet_v2.py:59,61,84,86 conv21 / conv31 /
+ * conv11, :38 Transition_down in eval plans) on the split-f16 path: no staging, every lane loads its MFMA operand
+ * straight from HBM, weight fragments stay in LDS.  Same descriptor as egne_conv2d_fwd (`w` unused; no fused affine,
+ * residual or post affine; CoutP 32 or a multiple of 64).  Weights: hi / lo f16 fragments [G][CoutP/32][lane][8] where
+ * G = sum over slices of ceil(Cp/16) and kmap[g*16 + h*8 + j] (device int32) names the logical input channel in K
+ * slot (half h, j) of group g (-1 = padding); the kernel's slot order is channel 16g + (j<4 ? 4h+j : 8+4h+j-4). */
+int egne_pack_conv1x1_weight_f16(const float* w_oihw, int Cout, int Cin, const int32_t* kmap, int G, int CoutP,
+                                 float wscale, void* fhi, void* flo, void* stream);
+int egne_conv1x1_f16x3_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
+                           float w_scale, void* stream);
+
 /* First layers (vgg16_c.py:66 conv1_1 on 3 channels, utils.py:1047 convBlock conv1 on 1-2 channels):
  * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  The 9 taps are folded into K (one 40-wide K step,
  * exact fp32 MFMA), so the layer is a pure store stream.  w40: [32 or 64][40] fp32, column tap*4 + c. */

@@ -310,3 +310,39 @@ def test_conv_f16x3_grouped_msblock(G):
     err = (got - truth).abs().max().item() / truth.abs().max().item()
     print("grouped f16x3 err %.2e" % err)
     assert err < 2e-6
+
+
+@pytest.mark.parametrize("chans,Cout,B,H,W,act", [((32, 32), 32, 2, 37, 53, 0), ((38, 64, 24), 64, 1, 61, 35, 2),
+                                                  ((115, 8, 40), 100, 1, 19, 23, 1), ((32, 32, 32), 30, 3, 16, 16, 0)])
+def test_conv1x1_streaming_split(G, chans, Cout, B, H, W, act):
+    """Streaming split-f16 1x1 kernel (conv1x1_f16.hip) over several slices of one buffer and of a second buffer
+    (ragged slice widths: 8-channel tail groups, padded channels, pixel count not a multiple of 32)."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd import engine
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    xs = [_rand(G, B, c, H, W) * 2 for c in chans]
+    Cin = sum(chans)
+    w, b = _rand(G, Cout, Cin, 1, 1) / Cin ** 0.5, _rand(G, Cout)
+    t = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double())
+    truth = F.relu(t) if act == 1 else (F.leaky_relu(t, 0.01) if act == 2 else t)
+    pl = Plan(torch.device(DEV))
+    pieces = to_nhwc_buf(pl, xs[:-1], B, H, W) + to_nhwc_buf(pl, xs[-1:], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(p.C, p.Cp) for p in pieces], act=act)
+    layer.split1 = True
+    out = pl.buf(B, H, W, pad8(Cout) + 16)
+    out.fill_(777.0)
+    old = engine.S1X1_MIN_PIX
+    engine.S1X1_MIN_PIX = 0
+    try:
+        pl.conv(layer, pieces, Piece(out, 8, Cout), B, H, W)
+    finally:
+        engine.S1X1_MIN_PIX = old
+    assert pl.calls[-1][0] is pl.L.egne_conv1x1_f16x3_fwd
+    pl.run()
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert (o[..., :8] == 777.0).all() and (o[..., 8 + pad8(Cout):] == 777.0).all(), "wrote outside the output slice"
+    got = o[..., 8:8 + Cout].permute(0, 3, 1, 2).double()
+    err = (got - truth).abs().max().item() / truth.abs().max().item()
+    print("conv1x1 streaming err %.2e" % err)
+    assert err < 2e-6
