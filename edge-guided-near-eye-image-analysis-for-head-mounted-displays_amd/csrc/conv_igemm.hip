@@ -35,6 +35,18 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// Addressing: a staged row keeps ONE pixel index relative to the first frame of the tile (slice independent) and a
+// bit mask of the taps that fall inside the image; a K step turns it into a 32-bit byte offset of the slice's
+// buffer resource with one multiply-add, padded lanes get 0x80000000 (the buffer unit returns zeros).  Weights,
+// residual and output go through buffer instructions with lane-constant offsets.  Reflect padding (StyleEncoder
+// only) recomputes the mirrored coordinates per step.
 template <int WM, int WN, bool GROUPED>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p) {
   constexpr int BM = 128 * WM, BN = 32 * WN;
@@ -49,28 +61,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int T = p.kh * p.kw;
+  const int hw = p.Ho * p.Wo, frame_px = p.H * p.W;
+  const int b0 = (int)(m0 / hw);
 
   // ---- loader coordinates: thread (rbase, col4) stages rows rbase+32*i, floats col4*4..+3 ----
   const int col4 = tid & 7, rbase = tid >> 3;
-  int pb[AR], py[AR], px[AR];
+  int pb[AR], pyx[AR], pix[AR];     // frame (or -1), input centre (y<<16 | x), pixel index relative to frame b0
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    long long m = m0 + rbase + 32 * i;
-    if (m < M) {
-      int hw = p.Ho * p.Wo;
-      int b = (int)(m / hw);
-      int r = (int)(m - (long long)b * hw);
-      int oy = r / p.Wo;
-      pb[i] = b;
-      py[i] = oy * p.stride;
-      px[i] = (r - oy * p.Wo) * p.stride;
-    } else {
-      pb[i] = -1; py[i] = 0; px[i] = 0;
-    }
+    const long long m = m0 + rbase + 32 * i;
+    const int b = (int)(m / hw);
+    const int r = (int)(m - (long long)b * hw);
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    pb[i] = m < M ? b : -1;
+    pyx[i] = ((oy * p.stride) << 16) | (ox * p.stride);
+    pix[i] = (b - b0) * frame_px + oy * p.stride * p.W + ox * p.stride;
   }
+  unsigned tapmask[AR];
+  auto make_masks = [&](int g) {
+    const int dil = p.dil[g];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      unsigned mk = 0;
+      for (int ky = 0; ky < p.kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx) {
+          const int iy = (pyx[i] >> 16) + (ky - p.pad_h) * dil, ix = (pyx[i] & 0xffff) + (kx - p.pad_w) * dil;
+          if (pb[i] >= 0 && (p.pad_mode == 1 || (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W))) mk |= 1u << (ky * p.kw + kx);
+        }
+      tapmask[i] = mk;
+    }
+  };
+  make_masks(0);
 
-  f32x4 ra[AR];
-  f32x4 rb[WN];
+  const unsigned wbytes = (unsigned)p.ngroups * T * p.CoutP * p.Ktot * 4u;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, wbytes);
+  int boff[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) boff[j] = ((n0 + rbase + 32 * j) * p.Ktot + col4 * 4) * 4;
+
+  u32x4 ra[AR];
+  u32x4 rb[WN];
 
   auto advance = [&](KState& s) {
     if (++s.tap < T) return;
@@ -85,8 +115,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   };
 
   // Staging is split in two so that NOTHING consumes a loaded register before the MFMAs of the current
-  // step have been issued: load_step only issues unconditional loads (invalid lanes read the zero page),
-  // store_step applies the fused affine / activation, zeroes the padding and writes LDS.
+  // step have been issued: load_step only issues unconditional buffer loads, store_step applies the fused
+  // affine / activation, zeroes the padding and writes LDS.
   unsigned okmask = 0;       // bit i: row i of the staged step is inside the image
   int st_seg = 0, st_c = 0;  // slice / first channel of the staged step (for the deferred affine)
   auto load_step = [&](const KState& s) {
@@ -98,27 +128,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     const bool cok = c < sg.Cp;
     okmask = 0;
     st_seg = s.seg; st_c = c;
+    const long long left = ((long long)p.B - b0) * frame_px * sg.pix_stride * 4;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+                                                 (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+    const int ps4 = (int)sg.pix_stride * 4;
+    const int coff = (sg.ch_off + c) * 4;
+    if (p.pad_mode == 1) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int iy = py[i] + dy, ix = px[i] + dx;
-      bool ok = cok && pb[i] >= 0;
-      if (p.pad_mode == 1) {
+      for (int i = 0; i < AR; ++i) {
+        int iy = (pyx[i] >> 16) + dy, ix = (pyx[i] & 0xffff) + dx;
         iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
         ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
-      } else {
-        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const bool ok = cok && pb[i] >= 0;
+        const int q = (pb[i] - b0) * frame_px + iy * p.W + ix;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? q * ps4 + coff : (int)OOB, 0, 0);
+        okmask |= (ok ? 1u : 0u) << i;
       }
-      const float* src = sg.ptr + (((long long)pb[i] * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c;
-      src = ok ? src : egne_zero_page;
-      ra[i] = *(const f32x4*)src;
-      okmask |= (ok ? 1u : 0u) << i;
-    }
-    const float* wbase = p.w + ((long long)(s.g * T + s.tap) * p.CoutP + n0 + rbase) * p.Ktot + s.kofs + c;
+    } else {
+      const int tapd = dy * p.W + dx;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const float* src = cok ? wbase + (long long)(32 * j) * p.Ktot : egne_zero_page;
-      rb[j] = *(const f32x4*)src;
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = cok && ((tapmask[i] >> s.tap) & 1u);
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (pix[i] + tapd) * ps4 + coff : (int)OOB, 0, 0);
+        okmask |= (ok ? 1u : 0u) << i;
+      }
     }
+    const int wstep = (((s.g * T + s.tap) * p.CoutP) * p.Ktot + s.kofs + s.c0) * 4;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? boff[j] : (int)OOB, wstep, 0);
   };
 
   auto store_step = [&]() {
@@ -126,6 +163,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     if (sg.scale) {
       // per-(n,c) affine of the fused InstanceNorm / BatchNorm (+ activation); padding stays exactly zero.
       // A tile almost always lies inside one frame: then one scale/shift pair serves all staged rows.
+      const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
       const bool cok2 = st_c < sg.Cp;
       const bool same = pb[0] == pb[AR - 1] && pb[0] >= 0 && cok2;
       f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
@@ -144,21 +182,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
         } else if (!ok) {
           sc = (f32x4)(0.f); sh = (f32x4)(0.f);
         }
-        f32x4 v = ra[i] * sc + sh;
-        if (sg.act_in == EGNE_ACT_LEAKY) {
+        f32x4 v = __builtin_bit_cast(f32x4, ra[i]) * sc + sh;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-        } else if (sg.act_in == EGNE_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        ra[i] = v;
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
+        ra[i] = __builtin_bit_cast(u32x4, v);
       }
     }
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = ra[i];
+    for (int i = 0; i < AR; ++i) *(u32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = ra[i];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) *(f32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
+    for (int j = 0; j < WN; ++j) *(u32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
   };
 
   f32x16 acc[WM][WN];
@@ -170,6 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
       acc[a][b] = (f32x16)(0.f);
       if (GROUPED) res[a][b] = (f32x16)(0.f);
     }
+  const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
 
   // total number of K steps
   int steps_per_group = 0;
@@ -188,7 +222,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     KState nxt = cur;
     advance(nxt);
     const bool more = step + 1 < nsteps;
-    if (more) load_step(nxt);
+    if (more) {
+      if (GROUPED && nxt.g != cur.g) make_masks(nxt.g);
+      load_step(nxt);
+    }
 
     int rem = p.seg[cur.seg].Cp - cur.c0;
     const int nk8 = rem >= KC ? KC / 8 : (rem >> 3);
@@ -216,7 +253,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) res[tm][tn][r] += act_apply(acc[tm][tn][r] + bv, p.act);
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[tm][tn][r] + bv;
+            res[tm][tn][r] += fmaxf(v, v * slope_out);
+          }
           acc[tm][tn] = (f32x16)(0.f);
         }
       }
@@ -229,6 +269,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   }
 
   // ---- epilogue: lane holds column n of 16 rows: row = (r&3) + 8*(r>>2) + 4*lh ----
+  const long long left = M - m0;
+  const long long rows = left < BM ? left : BM;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
+                                                p.residual ? (unsigned)(rows * p.res_pix_stride * 4) : 0u);
+  const int ostep = (int)p.out_pix_stride * 4, rstep = (int)p.res_pix_stride * 4;
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn) {
     const int n = n0 + tn * 32 + li;
@@ -238,15 +284,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     if (p.post_scale) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
 #pragma unroll
     for (int tm = 0; tm < WM; ++tm) {
+      const int mrow = wave * 32 * WM + tm * 32 + 4 * lh;
+      const unsigned o0 = nok ? (unsigned)(mrow * ostep + (p.out_ch_off + n) * 4) : OOB;   // rows past M: range check
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      if (p.residual) {
+        const unsigned r0 = nok ? (unsigned)(mrow * rstep + (p.res_ch_off + n) * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(r0 + ((r & 3) + 8 * (r >> 2)) * rstep), 0, 0));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + wave * 32 * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nok && m < M) {
-          float v = GROUPED ? res[tm][tn][r] : act_apply(acc[tm][tn][r] + bv, p.act);
-          if (p.post_scale) v = v * ps + pt;
-          if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
-          p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
-        }
+        float v;
+        if (GROUPED) v = res[tm][tn][r];
+        else { v = acc[tm][tn][r] + bv; v = fmaxf(v, v * slope_out); }
+        v = v * ps + pt + rv[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
       }
     }
   }
