@@ -588,6 +588,7 @@ extern "C" int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, 
 extern "C" int egne_conv2d_wgrad_splits(const egne_conv_desc* dp) {
   if (!dp) return 0;
   const egne_conv_desc& d = *dp;
+  if (egne::wgrad_halo_supported(d, d.out_pix_stride)) return egne::wgrad_halo_splits(d);
   int per_tap = 0;
   for (int s = 0; s < d.nseg; ++s) per_tap += (d.seg[s].Cp + 31) / 32;
   const long long tiles = (long long)(d.CoutP / 32) * per_tap * d.kh * d.kw * d.ngroups;
@@ -624,9 +625,16 @@ extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int6
   const int T = d.kh * d.kw, nsplit = egne_conv2d_wgrad_splits(dp);
   hipStream_t st = (hipStream_t)stream;
   const size_t bytes = (size_t)nsplit * d.ngroups * T * d.CoutP * d.Ktot * sizeof(float);
-  if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
-  dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
-  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+  if (egne::wgrad_halo_supported(d, d.out_pix_stride)) {
+    // the gradient buffer mirrors the output buffer (same pixel stride): the split count above assumed it
+    EGNE_REQUIRE(gzs == d.out_pix_stride, "wgrad: gz stride %lld differs from the output stride %lld", (long long)gzs, (long long)d.out_pix_stride);
+    const int rc = egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
+    if (rc != EGNE_OK) return rc;
+  } else {
+    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
+    dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+  }
   for (int g = 0; g < d.ngroups; ++g) {
     EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
     const long long total = (long long)T * d.CoutP * d.Ktot;

@@ -34,6 +34,10 @@ inline int check_launch(const char* what) {
 bool halo3_supported(const egne_conv_desc& d);   // conv_halo3.hip
 int halo3_launch(const egne_conv_desc& d, hipStream_t st);
 
+bool wgrad_halo_supported(const egne_conv_desc& d, long long gzs);   // wgrad_halo.hip
+int wgrad_halo_splits(const egne_conv_desc& d);
+int wgrad_halo_launch(const egne_conv_desc& d, const float* gz, long long gzs, int gzo, float* ws, hipStream_t st);
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace egne

@@ -346,3 +346,46 @@ def test_conv1x1_streaming_split(G, chans, Cout, B, H, W, act):
     err = (got - truth).abs().max().item() / truth.abs().max().item()
     print("conv1x1 streaming err %.2e" % err)
     assert err < 2e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,norm", [(2, 32, 32, 16, 64, False), (2, 40, 24, 37, 53, True), (1, 64, 70, 9, 33, False)])
+def test_conv3x3_backward_halo_wgrad(G, B, Cin, Cout, H, W, norm):
+    """Backward of a 3x3 conv through the training plan (act_bwd + halo weight-gradient kernel wgrad_halo.hip +
+    dgrad) against torch autograd: ragged tiles, channel tails, fused InstanceNorm affine + LeakyReLU on the input."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = _rand(G, B, Cin, H, W)
+    w = (_rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5)).requires_grad_(True)
+    b = _rand(G, Cout).requires_grad_(True)
+    gy = _rand(G, B, Cout, H, W)
+    sc, sh = 0.5 + _rand(G, B, Cin).abs(), _rand(G, B, Cin)
+    xin = x.clone().requires_grad_(True)
+    xe = F.leaky_relu(xin * sc[:, :, None, None] + sh[:, :, None, None], 0.01) if norm else xin
+    y = F.conv2d(xe, w, b, padding=1)
+    y.backward(gy)
+    pl = Plan(torch.device(DEV), train=True)
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    if norm:
+        scp, shp = torch.zeros(B, px.Cp, device=DEV), torch.zeros(B, px.Cp, device=DEV)
+        scp[:, :Cin], shp[:, :Cin] = sc.to(DEV), sh.to(DEV)
+        pl.keep += [scp, shp]
+        px = px.with_norm(scp, shp, 2)
+        px.nograd = True     # the norm backward needs its statistics; only the weight path is under test here
+    wd, bd = torch.nn.Parameter(w.detach().to(DEV)), torch.nn.Parameter(b.detach().to(DEV))
+    wd.grad, bd.grad = torch.zeros_like(wd), torch.zeros_like(bd)
+    layer = ConvLayer([wd], [bd], [(Cin, pad8(Cin))], pad=(1, 1))
+    out = pl.buf(B, H, W, pad8(Cout))
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+    bw = pl.build_backward()
+    pl.run()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV)
+    bw.run()
+    torch.cuda.synchronize()
+    ew = (wd.grad.cpu() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    eb = (bd.grad.cpu() - b.grad).abs().max().item() / b.grad.abs().max().item()
+    print("wgrad err %.2e  bias grad err %.2e" % (ew, eb))
+    assert ew < 2e-5 and eb < 2e-5
+    if not norm:
+        gx = pl.gbuf(px.buf).cpu()[..., :Cin].permute(0, 3, 1, 2)
+        ex = (gx - xin.grad).abs().max().item() / xin.grad.abs().max().item()
+        assert ex < 2e-5
