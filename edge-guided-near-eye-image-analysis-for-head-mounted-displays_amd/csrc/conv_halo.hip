@@ -29,26 +29,54 @@ __device__ __forceinline__ float act1(float v, int act) {
   return v;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// All global traffic goes through BUFFER instructions on per-frame resources (see conv_halo_f16.hip): tile-independent
+// per-lane byte offsets plus one scalar per tile, out-of-image / padded lanes carry 0x80000000 and read zeros (or drop
+// their store) in the buffer unit's range check; activations are max(v, slope*v) -- no branches, no 64-bit address math.
 template <int WM, int WN, int D>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc p, const float* __restrict__ wf,
-                                                           int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, (WN <= 2 ? 2 : 1)) void conv3x3_halo_kernel(const egne_conv_desc p, const float* __restrict__ wf,
+                                                                              int tiles_x, int tiles_y, int ntiles) {
   constexpr int TH = 4 * WM;
-  constexpr int PF = WN >= 4 ? 1 : 4;   // B-fragment prefetch depth in k-steps (covers L2 latency at 1 wave/SIMD)
+  constexpr int PF = WN >= 4 ? 1 : 4;   // B-fragment prefetch depth in k-steps
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   constexpr int d = D;
   constexpr int HWd = TW + 2 * d, HHd = TH + 2 * d, npx = HHd * HWd;
+  constexpr int nitems = npx * 8;
+  constexpr int NI = (nitems + 255) / 256;
+  static_assert(HWd >= 32, "one wrap per 32-pixel step");
   const int nt0 = blockIdx.y * WN;          // first 32-wide N tile
   const int NT = p.CoutP >> 5, KT8 = p.Ktot >> 3;
   const egne_seg sg = p.seg[0];
   const int Cp = sg.Cp;
   const int c4 = tid & 7;
-  constexpr int nitems = npx * 8;
+  const unsigned frame_in = (unsigned)p.H * p.W * (unsigned)sg.pix_stride * 4u;
+  const unsigned frame_out = (unsigned)p.H * p.W * (unsigned)p.out_pix_stride * 4u;
+  const unsigned frame_res = (unsigned)p.H * p.W * (unsigned)p.res_pix_stride * 4u;
+
+  int hyx[NI];
+  {
+    int px = tid >> 3;
+    int hy = px / HWd, hx = px - hy * HWd;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      hyx[i] = tid + 256 * i < nitems ? (hy << 16) | hx : 0x7fff7fff;
+      hx += 32;
+      if (hx >= HWd) { hx -= HWd; ++hy; }
+    }
+  }
+  const int lofs0 = (tid >> 3) * LDK + c4 * 4;
+  const int ps4 = (int)sg.pix_stride * 4;
 
   // The workgroup walks over output tiles (grid-stride) and, inside a tile, over 32-channel chunks.
-  // The halo of the NEXT (tile, chunk) is prefetched into registers while the MFMAs of the current
-  // one run, so global-load latency is exposed once per workgroup, not once per tile.
+  // The halo of the NEXT (tile, chunk) is prefetched into registers while the MFMAs of the current one run.
   struct Tile { int b, y0, x0; };
   auto tile_of = [&](int t) {
     Tile r;
@@ -58,66 +86,51 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
     return r;
   };
 
-  int goff[NI_MAX];
-  const float* src = sg.ptr;
+  unsigned goff[NI];
+  __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr, 0);
   int stage_b = 0;
   auto map_tile = [&](const Tile& tl) {
+    const int ybase = tl.y0 - d, xbase = tl.x0 - d;
+    const int tbase = ((ybase * p.W + xbase) * (int)sg.pix_stride + sg.ch_off + c4 * 4) * 4;
 #pragma unroll
-    for (int i = 0; i < NI_MAX; ++i) {
-      const int item = tid + 256 * i;
-      goff[i] = -1;
-      if (item < nitems) {
-        const int px = item >> 3;
-        const int hy = px / HWd, hx = px - hy * HWd;
-        const int iy = tl.y0 - d + hy, ix = tl.x0 - d + hx;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-          goff[i] = (int)((((long long)iy * p.W + ix) * sg.pix_stride) + sg.ch_off + c4 * 4);
-      }
+    for (int i = 0; i < NI; ++i) {
+      const int hy = hyx[i] >> 16, hx = hyx[i] & 0xffff;
+      const unsigned iy = (unsigned)(ybase + hy), ix = (unsigned)(xbase + hx);
+      goff[i] = (iy < (unsigned)p.H && ix < (unsigned)p.W) ? (unsigned)(tbase + (hy * p.W + hx) * ps4) : OOB;
     }
-    src = sg.ptr + (long long)tl.b * p.H * p.W * sg.pix_stride;
+    rin = make_rsrc(sg.ptr + (long long)tl.b * p.H * p.W * sg.pix_stride, frame_in);
     stage_b = tl.b;
   };
 
-  f32x4 st[NI_MAX];
-  // load phase: unconditional loads only (invalid lanes read the zero page); the fused affine /
-  // activation and the zero padding are applied in the store phase, after the MFMAs of the current chunk.
+  u32x4 st[NI];
   f32x4 st_sc = {1.f, 1.f, 1.f, 1.f}, st_sh = {0.f, 0.f, 0.f, 0.f};
-  bool st_cok = true;
+  unsigned st_cmask = 0;
   auto load_chunk = [&](int c0) {
     const bool cok = c0 + c4 * 4 < Cp;
-    st_cok = cok;
+    st_cmask = cok ? 0u : OOB;
     if (sg.scale) {
-      const float* sp = cok ? sg.scale + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page;
-      const float* hp = cok ? sg.shift + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page;
-      st_sc = *(const f32x4*)sp;
-      st_sh = *(const f32x4*)hp;
+      st_sc = *(const f32x4*)(cok ? sg.scale + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page);
+      st_sh = *(const f32x4*)(cok ? sg.shift + (long long)stage_b * Cp + c0 + c4 * 4 : egne_zero_page);
     }
 #pragma unroll
-    for (int i = 0; i < NI_MAX; ++i) {
-      const float* q = (goff[i] >= 0 && cok) ? src + goff[i] + c0 : egne_zero_page;
-      st[i] = *(const f32x4*)q;
-    }
+    for (int i = 0; i < NI; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(goff[i] | st_cmask), c0 * 4, 0);
   };
+  const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   auto store_chunk = [&]() {
+    if (sg.scale) {   // zero padding AFTER the normalisation
 #pragma unroll
-    for (int i = 0; i < NI_MAX; ++i) {
-      const int item = tid + 256 * i;
-      if (item < nitems) {
-        f32x4 v = st[i];
-        if (sg.scale) {
-          v = v * st_sc + st_sh;
-          if (sg.act_in == EGNE_ACT_LEAKY) {
+      for (int i = 0; i < NI; ++i) {
+        f32x4 v = __builtin_bit_cast(f32x4, st[i]) * st_sc + st_sh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-          } else if (sg.act_in == EGNE_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (!(goff[i] >= 0 && st_cok)) v = (f32x4)(0.f);   // zero padding AFTER the normalisation
-        }
-        *(f32x4*)&lds[(item >> 3) * LDK + c4 * 4] = v;
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
+        if ((goff[i] | st_cmask) & OOB) v = (f32x4)(0.f);
+        st[i] = __builtin_bit_cast(u32x4, v);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i < NI - 1 || tid + 256 * i < nitems) *(u32x4*)&lds[lofs0 + i * 32 * LDK] = st[i];
   };
 
   f32x16 acc[WM][WN];
@@ -126,8 +139,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
 
-  const long long stride_k8 = (long long)NT * 256, stride_tap = (long long)KT8 * NT * 256;
-  const float* wlane = wf + (long long)nt0 * 256 + lane * 4;
+  // fragment-order weights [tap][k/8][n/32][lane][4]: byte offsets, lane part in the VGPR, the rest scalar
+  const unsigned wbytes = 9u * (unsigned)p.Ktot * (unsigned)p.CoutP * 4u;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(wf, wbytes);
+  const int stride_k8 = NT * 1024, stride_tap = KT8 * NT * 1024;
+  const int wlane = lane * 16;
+  const int out_step = (int)p.out_pix_stride * 4, res_step = (int)p.res_pix_stride * 4;
 
   int t = blockIdx.x;
   if (t >= ntiles) return;
@@ -151,21 +168,21 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
     }
     const int rem = Cp - c0;
     const int nk8 = rem >= KC ? 4 : (rem >> 3);
-    const float* wchunk = wlane + (long long)(c0 >> 3) * stride_k8;
+    const int wchunk = nt0 * 1024 + (c0 >> 3) * stride_k8;
     // software pipeline over the 9 x nk8 k-steps: B fragments ride a register ring PF steps ahead
     // (slot = k-step index inside the tap), the A fragment of the next step is read from LDS before
     // the MFMAs of the current one are issued.
-    f32x4 bq[PF == 4 ? 4 : 1][WN];
+    u32x4 bq[PF == 4 ? 4 : 1][WN];
     if (PF == 4) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         if (s < nk8) {
 #pragma unroll
-          for (int tn = 0; tn < WN; ++tn) bq[s][tn] = *(const f32x4*)(wchunk + s * stride_k8 + tn * 256);
+          for (int tn = 0; tn < WN; ++tn) bq[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wchunk + s * stride_k8 + tn * 1024, 0);
         }
     } else {
 #pragma unroll
-      for (int tn = 0; tn < WN; ++tn) bq[0][tn] = *(const f32x4*)(wchunk + tn * 256);
+      for (int tn = 0; tn < WN; ++tn) bq[0][tn] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wchunk + tn * 1024, 0);
     }
     const float* abase = &lds[(wave * WM * HWd + li) * LDK + lh * 4];
     f32x4 an[WM];
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
       const int tap1 = tap + 1;
       const int ky1 = tap1 / 3, kx1 = tap1 - ky1 * 3;
       const float* arow1 = abase + (ky1 * d * HWd + kx1 * d) * LDK;   // only dereferenced when tap < 8
-      const float* wtap1 = wchunk + (long long)tap1 * stride_tap;
+      const int wtap1 = wchunk + tap1 * stride_tap;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s < nk8) {
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
 #pragma unroll
           for (int tm = 0; tm < WM; ++tm) a[tm] = an[tm];
 #pragma unroll
-          for (int tn = 0; tn < WN; ++tn) bcur[tn] = bq[PF == 4 ? s : 0][tn];
+          for (int tn = 0; tn < WN; ++tn) bcur[tn] = __builtin_bit_cast(f32x4, bq[PF == 4 ? s : 0][tn]);
           // next A fragment
           if (s + 1 < nk8) {
 #pragma unroll
@@ -198,13 +215,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
           if (PF == 4) {
             if (tap < 8) {
 #pragma unroll
-              for (int tn = 0; tn < WN; ++tn) bq[s][tn] = *(const f32x4*)(wtap1 + s * stride_k8 + tn * 256);
+              for (int tn = 0; tn < WN; ++tn) bq[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wtap1 + s * stride_k8 + tn * 1024, 0);
             }
           } else {
-            const float* wn = (s + 1 < nk8) ? wtap1 - stride_tap + (s + 1) * stride_k8 : wtap1;
+            const int wn = (s + 1 < nk8) ? wtap1 - stride_tap + (s + 1) * stride_k8 : wtap1;
             if (s + 1 < nk8 || tap < 8) {
 #pragma unroll
-              for (int tn = 0; tn < WN; ++tn) bq[0][tn] = *(const f32x4*)(wn + tn * 256);
+              for (int tn = 0; tn < WN; ++tn) bq[0][tn] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wn + tn * 1024, 0);
             }
           }
 #pragma unroll
@@ -219,29 +236,46 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const egne_conv_desc 
     }
     if (!last_chunk) { c0 += KC; continue; }
 
-    // ---- epilogue of tile `cur`: MFMA row index = pixel x offset, tm = image row ------------------
+    // ---- epilogue of tile `cur`: lane holds channel n of 16 pixels x = x_lane + c_r, c_r = (r&3) + 8*(r>>2) ----
+    {
+      const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + (long long)cur.b * p.H * p.W * p.out_pix_stride, frame_out);
+      const __amdgpu_buffer_rsrc_t rres =
+          make_rsrc(p.residual ? p.residual + (long long)cur.b * p.H * p.W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
+      const int xl = cur.x0 + 4 * lh;
+      const int cmax = xl < p.W ? p.W - xl : 0;
 #pragma unroll
-    for (int tn = 0; tn < WN; ++tn) {
-      const int n = (nt0 + tn) * 32 + li;
-      const bool nok = n < p.Cout_store;
-      float bv = 0.f, ps = 1.f, pt = 0.f;
-      if (p.bias) bv = p.bias[n];
-      if (p.post_scale) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+      for (int tn = 0; tn < WN; ++tn) {
+        const int n = (nt0 + tn) * 32 + li;
+        const bool nok = n < p.Cout_store;
+        float bv = 0.f, ps = 1.f, pt = 0.f;
+        if (p.bias) bv = p.bias[n];
+        if (p.post_scale) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
 #pragma unroll
-      for (int tm = 0; tm < WM; ++tm) {
-        const int y = cur.y0 + wave * WM + tm;
+        for (int tm = 0; tm < WM; ++tm) {
+          const int y = cur.y0 + wave * WM + tm;
+          const int cm = (nok && y < p.H) ? cmax : 0;
+          const int pix = y * p.W + xl;
+          const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
+          float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int x = cur.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (nok && y < p.H && x < p.W) {
-            const long long m = ((long long)cur.b * p.H + y) * p.W + x;
-            float v = act1(acc[tm][tn][r] + bv, p.act);
-            if (p.post_scale) v = v * ps + pt;
-            if (p.residual) v += p.residual[m * p.res_pix_stride + p.res_ch_off + n];
-            p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+          if (p.residual) {
+            const unsigned r0 = (unsigned)((pix * (int)p.res_pix_stride + p.res_ch_off + n) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = (r & 3) + 8 * (r >> 2);
+              rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0));
+            }
           }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            float v = acc[tm][tn][r] + bv;
+            v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+          }
+          acc[tm][tn] = (f32x16)(0.f);
         }
-        acc[tm][tn] = (f32x16)(0.f);
       }
     }
     t = tn_;
@@ -320,7 +354,8 @@ extern "C" int egne_conv3x3_halo_fwd(const egne_conv_desc* dp, void* stream) {
   EGNE_REQUIRE(d.w && d.out && ((uintptr_t)d.w & 15) == 0, "conv_halo: null/unaligned weight or output");
   EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv_halo: output slice exceeds pixel stride");
   EGNE_REQUIRE((d.post_scale == nullptr) == (d.post_shift == nullptr), "conv_halo: post affine mismatch");
-  EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride < (1ll << 31), "conv_halo: frame too large for 32-bit offsets");
+  EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
+               (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv_halo: frame too large for 32-bit byte offsets");
   hipStream_t st = (hipStream_t)stream;
   const int c = d.CoutP;
   static const int gen = [] { const char* e = getenv("EGNE_HALO_V"); return e ? atoi(e) : 2; }();   // generation 3 (conv_halo3.hip) is opt-in: measured slower so far
