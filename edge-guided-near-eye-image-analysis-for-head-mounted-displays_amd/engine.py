@@ -27,8 +27,9 @@ ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
-HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "60"))
-HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "32"))  # wider layers: flat kernel is faster (measured)
+HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
+HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "60"))
+HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
 
 
 def pad8(c):
@@ -379,7 +380,7 @@ class Plan:
                  and pieces[0].Cp >= 32)
         # narrow 3x3 layers on wide images: split-f16 arithmetic AND the LDS halo (input fetched once for 9 taps)
         shalo = (split and HALO_F16_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.G == 1 and layer.pad == (1, 1)
-                 and layer.dils[0] <= 2 and W >= HALO_MIN_W and layer.CoutP <= HALO_F16_MAX_COUTP and residual is None
+                 and layer.dils[0] <= 2 and W >= HALO_F16_MIN_W and layer.CoutP <= HALO_F16_MAX_COUTP and residual is None
                  and H * W * pieces[0].stride < 2 ** 31)
         # fused dilated group of an MSBlock: three lattice-halo launches (out = o + sum_g relu(conv_g(o)))
         lattice = (split and LATTICE_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)
@@ -393,8 +394,8 @@ class Plan:
                 and B * H * W >= S1X1_MIN_PIX)
         if lattice:
             shalo = True
-        if split and not shalo and halo and pieces[0].scale is not None:
-            split = False            # fused-affine layers: the fp32 halo kernel beats the flat split kernel
+        if split and not shalo and halo and pieces[0].scale is not None and layer.CoutP <= 32 and W >= HALO_F16_MIN_W:
+            split = False            # narrow fused-affine layers: the fp32 halo kernel beats the flat split kernel
         if smallcin:
             split = shalo = False
         if smallcin or split:
