@@ -324,19 +324,22 @@ __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p,
   {
     const long long m = m0 + tid;
     const int hw = p.H * p.W;
-    const int b = m < M ? (int)(m / hw) : 0;
-    const int r = m < M ? (int)(m - (long long)b * hw) : 0;
+    const int b0 = (int)(m0 / hw);
+    const int b = (int)(m / hw);
+    const int r = (int)(m - (long long)b * hw);
     const int y = r / p.W, x = r - y * p.W;
-    f32x4 v[9];
+    const long long left = ((long long)p.B - b0) * hw * sg.pix_stride * 4;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * hw * sg.pix_stride, (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+    const int base = (((b - b0) * hw + r) * (int)sg.pix_stride + sg.ch_off) * 4;
+    u32x4 v[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-      const bool ok = m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const float* src = ok ? sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off : egne_zero_page;
-      v[t] = *(const f32x4*)src;
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = m < M && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+      v[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? base + (dy * p.W + dx) * (int)sg.pix_stride * 4 : (int)OOB, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) *(f32x4*)&As[tid * C4LD + t * 4] = v[t];
+    for (int t = 0; t < 9; ++t) *(u32x4*)&As[tid * C4LD + t * 4] = v[t];
     *(f32x4*)&As[tid * C4LD + 36] = (f32x4)(0.f);
     for (int i = tid; i < 32 * WN * 10; i += 256) {
       const int n = i / 10, q = i - n * 10;
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p,
     }
   }
   __syncthreads();
+  // transposed product (weights as the A operand): lane = pixel li, channels n = 8*j + 4*lh + e -> 16-byte stores
   f32x16 acc[2][WN];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -362,28 +366,33 @@ __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p,
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < WN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], bq[tn][j], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[tn][j], a[tm][j], acc[tm][tn], 0, 0, 0);
   }
+  const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const long long left = M - m0;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < 256 ? left : 256) * p.out_pix_stride * 4));
 #pragma unroll
-  for (int tn = 0; tn < WN; ++tn) {
-    const int n = tn * 32 + li;
-    const bool nok = n < p.Cout_store;
-    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-    float ps = 1.f, pt = 0.f;
-    if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+  for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int j = 0; j < 4; ++j) {
+      const int n = tn * 32 + 8 * j + 4 * lh;
+      const bool nok = n < p.Cout_store;
+      const f32x4 bv = (p.bias && nok) ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
+      f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+      if (p.post_scale && nok) { ps = *(const f32x4*)(p.post_scale + n); pt = *(const f32x4*)(p.post_shift + n); }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nok && m < M) {
-          float v = act_apply(acc[tm][tn][r] + bv, p.act);
-          if (p.post_scale) v = v * ps + pt;
-          p.out[m * p.out_pix_stride + p.out_ch_off + n] = v;
+      for (int tm = 0; tm < 2; ++tm) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[tm][tn][4 * j + e] + bv[e];
+          v[e] = fmaxf(t, t * slope) * ps[e] + pt[e];
         }
+        const int row = wave * 64 + tm * 32 + li;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
+                                               nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
       }
     }
-  }
 }
 
 template <int WM, int WN>
@@ -411,7 +420,10 @@ extern "C" int egne_conv3x3_smallcin_fwd(const egne_conv_desc* dp, const float* 
   EGNE_REQUIRE(d.Cout_store <= 64 && d.out && d.residual == nullptr, "conv_smallcin: Cout");
   EGNE_REQUIRE(((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0 && ((uintptr_t)w40 & 15) == 0,
                "conv_smallcin: alignment");
-  EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv_smallcin: output slice exceeds pixel stride");
+  EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride && d.Cout_store % 4 == 0 && d.out_ch_off % 4 == 0 && d.out_pix_stride % 4 == 0 &&
+               ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride * 1024 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0),
+               "conv_smallcin: output slice / alignment");
+  EGNE_REQUIRE(2ll * d.H * d.W * d.seg[0].pix_stride * 4 < (1ll << 31), "conv_smallcin: frame too large for 32-bit byte offsets");
   const long long M = (long long)d.B * d.H * d.W;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 255) / 256));
