@@ -207,14 +207,14 @@ def main():
         }
         tot_t = max(sum(x[0] for x in fam.values()), 1e-9)
         r_fp32 = {"bound": "mfma", "kernel": "exact-fp32 implicit-GEMM conv family on v_mfma_f32_32x32x2_f32: conv_igemm_kernel, "
-                  "conv3x3_halo_kernel, conv3x3_c4_kernel (+ conv_wgrad_kernel in train mode); all training convs, 1x1 / multi-slice convs",
+                  "conv3x3_halo_kernel, conv3x3_c4_kernel (+ conv_wgrad_kernel, conv3x3_wgrad_halo_kernel in train mode); all training convs, fused-affine / wide 1x1 convs in inference",
                   "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                   "launches_per_step": conv_n // max(a.steps, 1), "avg_launch_ms": round(1e3 * conv_t / max(conv_n, 1), 4),
                   "algorithmic_gflop_per_frame": round(conv_f / a.steps / B / 1e9, 2), "time_share": round(conv_t / tot_t, 4)}
         sp_ach = sp_f / sp_t / 1e12 if sp_t > 0 else 0.0
         r_split = {"bound": "mfma", "kernel": "split-f16 conv family (fp32 tensors, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate): "
-                   "conv_f16x3_kernel, conv3x3_halo_f16_kernel; inference plans of BDCN and of ESF-Net's single-slice convs",
+                   "conv_f16x3_kernel, conv3x3_halo_f16_kernel, conv1x1_f16x3_kernel; inference plans of BDCN and ESF-Net",
                    "achieved": round(sp_ach, 2), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1),
                    "unit": "TFLOP/s (algorithmic, fp32-equivalent; peak = 2500 dense f16 MFMA / 3 MFMAs per product)",
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": None,
