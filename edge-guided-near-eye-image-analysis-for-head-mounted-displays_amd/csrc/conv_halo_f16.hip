@@ -44,11 +44,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int WM, int WN, int D, bool LAT>
+// NW = waves along N: <WM=2, WN, NW=1> gives every wave 2 tile rows x all 32*WN channels; <WM=4, WN=1, NW=2> gives a
+// wave 4 tile rows x 32 of the 64 channels -- same accumulators, but each weight fragment fetched from L1/L2 feeds
+// twice as many MFMAs (PMC: the weight ring of the <2,2,1> shape ran the vector L1 at 80 % of its 64 B/clk).
+template <int WM, int WN, int D, bool LAT, int NW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int TH = 4 * WM;
+  constexpr int TH = (4 / NW) * WM;
   constexpr int d = D;
   constexpr int HWd = TW + 2 * d, HHd = TH + 2 * d, npx = HHd * HWd;
   constexpr int nitems = npx * 8;
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int nt0 = blockIdx.y * WN;
+  const int wrow = wave / NW;                // wave's row group inside the tile
+  const int nt0 = (blockIdx.y * NW + wave % NW) * WN;
   const int NT = p.CoutP >> 5, KT16 = p.Ktot >> 4;
   const egne_seg sg = p.seg[0];
   const int Cp = sg.Cp;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
   map_tile(cur);
   load_chunk(0);
   int c0 = 0;
-  const int abase = (wave * WM * HWd + li) * LDH + lh * 8;
+  const int abase = (wrow * WM * HWd + li) * LDH + lh * 8;
   while (true) {
     __syncthreads();
     store_chunk();
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
     }
     const int wchunk = nt0 * 1024 + (c0 >> 4) * stride_k16;
     // register ring: slot = (tap % RT) * 2 + ks holds the fragments of (tap, ks); refilled RT taps ahead
-    constexpr int RT = WN == 1 ? 2 : 1;
+    constexpr int RT = (WN == 1 && NW == 1) ? 2 : 1;
     u32x4 qh[2 * RT][WN], ql[2 * RT][WN];
 #pragma unroll
     for (int s = 0; s < 2 * RT; ++s)
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
         ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
       }
-#pragma unroll
+    constexpr int TAP_UNROLL = NW == 2 ? 1 : 9;   // the NW = 2 shape only fits 2 waves per SIMD with the tap loop rolled
+#pragma unroll TAP_UNROLL
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int aoff = abase + (ky * d * HWd + kx * d) * LDH;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
-          const int y = cur.py + S * (cur.y0 + wave * WM + tm);
+          const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
           const int cm = (nok && y < p.H) ? cmax : 0;
           const int pix = y * p.W + xl;
           const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
@@ -309,17 +314,17 @@ __global__ void pack_weight_f16frag_k(const float* __restrict__ w, int Cout, int
   }
 }
 
-template <int WM, int WN, int D, bool LAT>
+template <int WM, int WN, int D, bool LAT, int NW = 1>
 int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
-  constexpr int TH = 4 * WM;
+  constexpr int TH = (4 / NW) * WM;
   const int S = LAT ? d.dil[0] : 1;
   const int lw = (d.W + S - 1) / S, lh_ = (d.H + S - 1) / S;     // lattice extent (largest phase)
   const int tiles_x = (lw + TW - 1) / TW, tiles_y = (lh_ + TH - 1) / TH;
   const size_t lds = (size_t)2 * (TH + 2 * D) * (TW + 2 * D) * LDH * sizeof(_Float16);
-  const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN);
+  const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN * NW);
   int gx = (256 * 2 + ny - 1) / ny;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
+  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
                      tiles_y, ntiles);
   return egne::check_launch("egne_conv3x3_halo_f16_fwd");
 }
@@ -358,6 +363,13 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   const _Float16* h = (const _Float16*)fhi;
   const _Float16* l = (const _Float16*)flo;
   const bool w2 = d.CoutP % 64 == 0;   // wider layers: several 64-wide N tiles along grid.y, each re-stages the halo
+  // opt-in: measured equal to the <2,2,1> shape (the rolled tap loop gives back what the halved weight traffic gains)
+  static const int nw2 = [] { const char* e = getenv("EGNE_SHALO_NW2"); return e ? atoi(e) : 0; }();
+  if (nw2 && w2) {
+    if (d.dil[0] == 1) return launch_hf<4, 1, 1, false, 2>(d, h, l, a_scale, os, st);
+    if (d.dil[0] == 2) return launch_hf<4, 1, 2, false, 2>(d, h, l, a_scale, os, st);
+    return launch_hf<4, 1, 1, true, 2>(d, h, l, a_scale, os, st);
+  }
   if (d.dil[0] == 1) return w2 ? launch_hf<2, 2, 1, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false>(d, h, l, a_scale, os, st);
   if (d.dil[0] == 2) return w2 ? launch_hf<2, 2, 2, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2, false>(d, h, l, a_scale, os, st);
   // larger dilations: lattice mode (the dilation-S conv as S*S ordinary convs on sub-lattices)
