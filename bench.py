@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--config", default="baseline_edge", help="configs/<name>.yaml (baseline_adain_edge = BASELINE.json configs[3])")
+    ap.add_argument("--chz", type=int, default=32, help="ESF-Net base width (64 = BASELINE.json configs[4]'s wider model)")
     ap.add_argument("--fit", action="store_true", help="inference: also run the ellipse-fit stage of evaluate.py (2 fits per frame)")
     ap.add_argument("--layers", action="store_true", help="print a per-launch time / TFLOP/s table to stderr")
     return ap.parse_args()
@@ -98,7 +99,7 @@ def main():
         setting = yaml.safe_load(f)
     bd = BDCN()
     bd.load_state_dict(synth.seeded_state_dict(bd.state_dict(), kind="bdcn"))
-    net = DenseNet2D(dict(setting))
+    net = DenseNet2D(dict(setting), chz=a.chz)
     net.load_state_dict(synth.seeded_state_dict(net.state_dict(), kind="esf"))
     bd_sd = {k: v.clone() for k, v in bd.state_dict().items()}
     net_sd = {k: v.clone() for k, v in net.state_dict().items()}
@@ -190,10 +191,10 @@ def main():
             "value": round(frames / dt, 2), "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (a.config + ".yaml (chz=32) TRAIN step (BASELINE.json configs[2] shape, but fp32 and "
-                                    "batch=%d/GPU), 240x320 synthetic TEyeD-shaped batch, seeded random-init weights" % B) if train
-                       else ("BASELINE.json configs[1]: %s.yaml (chz=32) inference, batch=%d/GPU, fp32, "
-                             "240x320 synthetic IR frames, seeded random-init weights" % (a.config, B)),
+            "config": {"workload": ("%s.yaml (chz=%d) TRAIN step (BASELINE.json configs[2] shape in fp32, batch=%d/GPU), 240x320 "
+                                    "synthetic TEyeD-shaped batch, seeded random-init weights" % (a.config, a.chz, B)) if train
+                       else ("BASELINE.json configs[1]: %s.yaml (chz=%d) inference, batch=%d/GPU, fp32, "
+                             "240x320 synthetic IR frames, seeded random-init weights" % (a.config, a.chz, B)),
                        "frames_per_gpu_per_step": B, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "ellipse_fit_stage": bool(a.fit),
                        "arithmetic": "fp32 tensors everywhere; training: exact fp32 MFMA; inference: split-f16 MFMA products "

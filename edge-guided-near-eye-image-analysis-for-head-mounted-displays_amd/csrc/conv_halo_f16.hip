@@ -47,7 +47,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // NW = waves along N: <WM=2, WN, NW=1> gives every wave 2 tile rows x all 32*WN channels; <WM=4, WN=1, NW=2> gives a
 // wave 4 tile rows x 32 of the 64 channels -- same accumulators, but each weight fragment fetched from L1/L2 feeds
 // twice as many MFMAs (PMC: the weight ring of the <2,2,1> shape ran the vector L1 at 80 % of its 64 B/clk).
-template <int WM, int WN, int D, bool LAT, int NW>
+template <int WM, int WN, int D, bool LAT, int NW, int PF = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
@@ -188,13 +188,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
     __syncthreads();
     const bool last_chunk = c0 + KC >= Cp;
     const int tnext = t + gridDim.x;
-    if (!last_chunk) {
-      load_chunk(c0 + KC);
-    } else if (tnext < ntiles) {
-      const Tile nx = tile_of(tnext);
-      map_tile(nx);
-      load_chunk(0);
-    }
+    // PF: where the halo prefetch of the next (tile, chunk) is issued.  vmcnt retires in order, so a prefetch in
+    // front of the weight ring (PF 0) makes the ring's first wait cover the HBM latency of the halo as well.
+    auto prefetch = [&]() {
+      if (!last_chunk) {
+        load_chunk(c0 + KC);
+      } else if (tnext < ntiles) {
+        const Tile nx = tile_of(tnext);
+        map_tile(nx);
+        load_chunk(0);
+      }
+    };
+    if (PF == 0) prefetch();
     const int wchunk = nt0 * 1024 + (c0 >> 4) * stride_k16;
     // register ring: slot = (tap % RT) * 2 + ks holds the fragments of (tap, ks); refilled RT taps ahead
     constexpr int RT = (WN == 1 && NW == 1) ? 2 : 1;
@@ -212,6 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int aoff = abase + (ky * d * HWd + kx * d) * LDH;
+      if (PF == 1 && tap == 1) prefetch();      // behind the ring's first refills
+      if (PF == 2 && tap == 4) prefetch();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int slot = (tap % RT) * 2 + ks;
@@ -314,7 +321,7 @@ __global__ void pack_weight_f16frag_k(const float* __restrict__ w, int Cout, int
   }
 }
 
-template <int WM, int WN, int D, bool LAT, int NW = 1>
+template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0>
 int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   constexpr int TH = (4 / NW) * WM;
   const int S = LAT ? d.dil[0] : 1;
@@ -324,7 +331,7 @@ int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo,
   const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN * NW);
   int gx = (256 * 2 + ny - 1) / ny;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
+  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW, PF>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
                      tiles_y, ntiles);
   return egne::check_launch("egne_conv3x3_halo_f16_fwd");
 }
@@ -370,6 +377,9 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
     if (d.dil[0] == 2) return launch_hf<4, 1, 2, false, 2>(d, h, l, a_scale, os, st);
     return launch_hf<4, 1, 1, true, 2>(d, h, l, a_scale, os, st);
   }
+  static const int pf = [] { const char* e = getenv("EGNE_SHALO_PF"); return e ? atoi(e) : 0; }();
+  if (d.dil[0] == 1 && pf == 1) return w2 ? launch_hf<2, 2, 1, false, 1, 1>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false, 1, 1>(d, h, l, a_scale, os, st);
+  if (d.dil[0] == 1 && pf == 2) return w2 ? launch_hf<2, 2, 1, false, 1, 2>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false, 1, 2>(d, h, l, a_scale, os, st);
   if (d.dil[0] == 1) return w2 ? launch_hf<2, 2, 1, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false>(d, h, l, a_scale, os, st);
   if (d.dil[0] == 2) return w2 ? launch_hf<2, 2, 2, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2, false>(d, h, l, a_scale, os, st);
   // larger dilations: lattice mode (the dilation-S conv as S*S ordinary convs on sub-lattices)

@@ -189,6 +189,47 @@ def test_esf_vs_oracle_fresh_seed(edge_of):
     np.testing.assert_allclose(loss.cpu().numpy(), ref[3].numpy(), rtol=1e-3)
 
 
+@pytest.mark.parametrize("chz,cfg", [(16, "baseline_edge"), (64, "baseline_edge"), (64, "baseline_adain_edge")])
+def test_esf_width_generalisation_vs_oracle(edge_of, chz, cfg):
+    """BASELINE.json configs[4] names a 64-channel model; the reference only runs chz=32, so the widths
+    follow section 8a-note and the check is HIP against the CPU oracle: eval forward, then one training step
+    (loss, gradient norms of every parameter)."""
+    from common import batch_args, setting
+    from egne_amd import synth
+    from egne_amd.models.RITnet_v2 import DenseNet2D
+    from oracle import esfnet as oesf
+    b, edge = edge_of(B=2, seed=77)
+    m = DenseNet2D(dict(setting(cfg)), chz=chz)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=3, kind="esf"))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = oesf.esf_forward(sd, setting(cfg), *batch_args(b, edge.cpu()))
+    m = m.to(DEV).eval()
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut = m(*args)
+    assert (op.cpu() - ref[0]).abs().max().item() < TOL
+    np.testing.assert_allclose(elOut.cpu().numpy(), ref[4].numpy(), atol=TOL)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref[3].numpy(), rtol=1e-3)
+    # training step against the oracle's autograd
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    lref = oesf.esf_forward(sdg, setting(cfg), *batch_args(b, edge.cpu()), training=True)[3]
+    lref.sum().backward()
+    m.train()
+    lhip = m(*args)[3]
+    np.testing.assert_allclose(lhip.detach().cpu().numpy(), lref.detach().numpy(), rtol=1e-3)
+    lhip.sum().backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    scale = max(v.grad.norm().item() for v in sdg.values() if v.grad is not None)
+    for n, p in m.named_parameters():
+        if sdg[n].grad is None:
+            continue
+        r, g = sdg[n].grad.double().norm().item(), p.grad.double().norm().item()
+        worst = max(worst, abs(r - g) / max(r, 1e-6 * scale))
+    assert worst < 1e-2, "gradient norms differ by %.2e" % worst
+
+
 def test_weights_repack_after_update(edge_of):
     """load_state_dict / in-place updates must reach the packed copies (checkpoint round trip)."""
     from common import batch_args, esf_module
