@@ -21,6 +21,9 @@ HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
+BIG_ENABLED = os.environ.get("EGNE_BIG", "1") != "0"
+BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
+BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
 S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
@@ -101,6 +104,8 @@ class ConvLayer:
         self.split = False      # allow the split-f16 (f16x3) kernel for this layer (frozen nets only)
         self.need_split = False
         self.need_sfrag = False  # fragment-order f16 pack for the split-f16 halo kernel
+        self.need_big = False    # LDS-image pack for the deep 256-wide split-f16 kernel
+        self.wimg = None
         self.split1 = False      # allow the streaming split-f16 kernel for this 1x1 layer (frozen nets only)
         self.need_s1 = False
         self.s1hi = self.s1lo = None
@@ -125,7 +130,7 @@ class ConvLayer:
             (b._version if b is not None else -1) for b in (self.biases or []))
         have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
-                and (self.s1hi is not None or not self.need_s1))
+                and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
         L = _lib.lib()
@@ -180,6 +185,18 @@ class ConvLayer:
                 self.s1lo = torch.empty_like(self.s1hi)
             _lib.check(L.egne_pack_conv1x1_weight_f16(wd.data_ptr(), self.Cout, self.Cin, self.s1_kmap.data_ptr(), self.s1_G, self.CoutP,
                                                       self.w_scale1, self.s1hi.data_ptr(), self.s1lo.data_ptr(), st), "pack_conv1x1_f16")
+        if self.need_big:
+            import math
+            wd = self.weights[0].detach().contiguous()
+            mx = float(wd.abs().max())
+            self.w_scale_big = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
+            bn = 256 if self.Cout % 256 == 0 else 128
+            self.big_bn, self.big_coutp = bn, (self.Cout + bn - 1) // bn * bn
+            kts = pad32(self.Ktot)
+            if self.wimg is None:
+                self.wimg = torch.empty(self.big_coutp * kts * T * 2, dtype=torch.float16, device=dev)
+            _lib.check(L.egne_pack_conv_weight_f16img(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, bn, kts, self.w_scale_big,
+                                                      self.wimg.data_ptr(), st), "pack_f16img")
         if self.need_split or self.need_sfrag:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
@@ -242,6 +259,7 @@ class DgradLayer(ConvLayer):
         self.split = self.need_split = self.need_sfrag = False
         self.split1 = self.need_s1 = False
         self.s1hi = self.s1lo = None
+        self.need_big, self.wimg = False, None
         self.whi = self.wlo = self.fhi = self.flo = None
         self.w_scale = 1.0
         self._versions, self.post = None, None
@@ -392,6 +410,10 @@ class Plan:
                 and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
                 and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 65536
                 and B * H * W >= S1X1_MIN_PIX)
+        # wide trunk layers: deep 256-wide split-f16 kernel (weights by LDS-DMA, one barrier per K step)
+        big = (split and BIG_ENABLED and layer.G == 1 and pieces[0].scale is None and pieces[0].Cp % 32 == 0 and residual is None
+               and layer.post is None and layer.Cout % 128 == 0 and layer.Cout >= BIG_MIN_COUT and layer.Cin >= BIG_MIN_CIN
+               and B * Ho * Wo >= 256 * 128)
         if lattice:
             shalo = True
         if split and not shalo and halo and pieces[0].scale is not None and layer.CoutP <= 32 and W >= HALO_F16_MIN_W:
@@ -400,7 +422,11 @@ class Plan:
             split = shalo = False
         if smallcin or split:
             halo = False
-        if s1x1:
+        if big:
+            smallcin = shalo = halo = lattice = s1x1 = False
+            layer.need_big = True
+            layer.need_flat = True
+        elif s1x1:
             smallcin = split = shalo = halo = lattice = False
             layer.need_s1 = True
             layer.need_flat = True
@@ -409,7 +435,7 @@ class Plan:
             layer.need_flat = True   # the generic pack is still what the backward (wgrad) paths index with kinv
         elif shalo:
             layer.need_sfrag = True
-        elif split:
+        elif split and not big:
             layer.need_split = True
         elif halo:
             layer.need_frag = True
@@ -433,9 +459,11 @@ class Plan:
             s.shift = p.shift.data_ptr() if p.shift is not None else None
             s.act_in = p.act_in
         d.Ktot, d.CoutP = (pad32(layer.Ktot), layer.split_coutp()) if split else (layer.Ktot, layer.CoutP)
+        if big:
+            d.CoutP = layer.big_coutp
         if shalo:
             d.CoutP = layer.CoutP
-        d.w = (layer.fhi.data_ptr() if shalo else layer.whi.data_ptr()) if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
+        d.w = (layer.wimg.data_ptr() if big else (layer.fhi.data_ptr() if shalo else layer.whi.data_ptr())) if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
         d.bias = layer.bp.data_ptr() if layer.biases is not None else None
         d.act = layer.act
         if layer.post is not None:
@@ -447,7 +475,10 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if s1x1:
+        if big:
+            self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
+                      flops=flops, kind="conv_f16x3")
+        elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
                                                       layer.w_scale1), name, flops=flops, kind="conv_f16x3")
         elif lattice:

@@ -113,6 +113,14 @@ int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Cin, int kh, 
 int egne_conv2d_f16x3_fwd(const egne_conv_desc* d, const void* whi, const void* wlo, float a_scale,
                           float w_scale, void* stream);
 
+/* Deep variant of egne_conv2d_f16x3_fwd for the wide trunk layers (vgg16_c.py:70-78): 256 x 256 (or 256 x 128) tile, 8 waves,
+ * two LDS stages, one barrier per K step; weights as ready-made LDS images staged by LDS-DMA
+ * ([Cout tile][step = chunk*taps + tap][BN rows][128 B], hi | lo granules, swizzled; BN = 256 if Cout % 256 == 0 else 128),
+ * fp32 activations converted while staging.  One input slice without fused affine, Cp % 32 == 0, stride 1, zero padding. */
+int egne_pack_conv_weight_f16img(const float* w_oihw, int Cout, int Cin, int kh, int kw, int BN, int Ktot, float wscale,
+                                 void* wimg, void* stream);
+int egne_conv2d_f16x3_big_fwd(const egne_conv_desc* d, const void* wimg, float a_scale, float w_scale, void* stream);
+
 /* Split-f16 variant of the LDS-halo 3x3 kernel (narrow full-resolution layers: Cout 32 / 64, dilation <= 2, one
  * input slice, fused affine allowed).  Weights: hi / lo f16 in MFMA-fragment order
  * [tap][Ktot/16][CoutP/32][lane][8], Ktot = slice width rounded up to 32. */

@@ -258,7 +258,8 @@ def test_errors_are_reported(G):
         _lib.check(rc, "conv")
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,d", [(2, 64, 64, 33, 47, 1), (1, 128, 256, 20, 24, 1), (1, 512, 512, 9, 13, 2)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,d", [(2, 64, 64, 33, 47, 1), (1, 128, 256, 20, 24, 1), (1, 512, 512, 9, 13, 2),
+                                              (2, 64, 128, 128, 131, 1), (1, 96, 256, 150, 223, 2), (3, 128, 384, 101, 110, 1)])
 def test_conv_f16x3_split_precision(G, B, Cin, Cout, H, W, d):
     """Split-f16 MFMA convolution (conv_f16x3.hip): error against a float64 convolution must be at the fp32
     level (the fp32 CPU conv is measured against the same truth for comparison)."""
@@ -276,6 +277,8 @@ def test_conv_f16x3_split_precision(G, B, Cin, Cout, H, W, d):
     out = pl.buf(B, H, W, Cout)
     pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
     assert pl.meta[-1][0] == "conv_f16x3"
+    if B * H * W >= 256 * 128 and Cout >= 256:      # the last two cases run the deep 256-wide kernel (ragged M, 128- and 256-wide N tiles)
+        assert pl.calls[-1][0] is pl.L.egne_conv2d_f16x3_big_fwd
     pl.run()
     torch.cuda.synchronize()
     got = out.cpu().permute(0, 3, 1, 2).double()
