@@ -24,6 +24,8 @@ S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
 BIG_ENABLED = os.environ.get("EGNE_BIG", "1") != "0"
 BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
 BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
+BIG_SPLIT_TAIL = os.environ.get("EGNE_BIG_SPLIT_TAIL", "1") != "0"
+BIG_CUS = 256
 S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
@@ -422,10 +424,22 @@ class Plan:
             split = shalo = False
         if smallcin or split:
             halo = False
+        big_tail = 0     # frames handed to the 128x128 kernel so that the 256x256 launch fills whole rounds of 256 CUs
         if big:
             smallcin = shalo = halo = lattice = s1x1 = False
             layer.need_big = True
             layer.need_flat = True
+            bn = 256 if layer.Cout % 256 == 0 else 128
+            ny = (layer.Cout + bn - 1) // bn
+            wgs = lambda nb: (nb * Ho * Wo + 255) // 256 * ny      # noqa: E731
+            full = wgs(B) // BIG_CUS
+            if BIG_SPLIT_TAIL and full >= 1 and 0.04 < wgs(B) / BIG_CUS - full < 0.65:
+                b1 = B
+                while b1 > 1 and wgs(b1) > full * BIG_CUS:
+                    b1 -= 1
+                if wgs(b1) >= 0.9 * full * BIG_CUS:
+                    big_tail = B - b1
+                    layer.need_split = True
         elif s1x1:
             smallcin = split = shalo = halo = lattice = False
             layer.need_s1 = True
@@ -475,7 +489,23 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
-        if big:
+        if big and big_tail:
+            # two launches over disjoint frame ranges: [0, B - tail) on the 256-wide kernel, the rest on the 128x128 kernel
+            layer.ensure_packed(self.device)
+            d2 = _lib.ConvDesc()
+            C.memmove(C.byref(d2), C.byref(d), C.sizeof(_lib.ConvDesc))
+            b1 = B - big_tail
+            d.B, d2.B = b1, big_tail
+            p0 = pieces[0]
+            d2.seg[0].ptr = p0.ptr + 4 * b1 * H * W * p0.stride
+            d2.out = dst.ptr + 4 * b1 * Ho * Wo * dst.stride
+            d2.Ktot, d2.CoutP = pad32(layer.Ktot), layer.split_coutp()
+            self.keep.append(d2)
+            self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
+                      flops=flops * b1 / B, kind="conv_f16x3")
+            self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d2), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE, layer.w_scale),
+                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3")
+        elif big:
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
                       flops=flops, kind="conv_f16x3")
         elif s1x1:
