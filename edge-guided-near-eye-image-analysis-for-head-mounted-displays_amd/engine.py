@@ -34,6 +34,7 @@ F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "60"))
+HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
 
 
@@ -400,7 +401,8 @@ class Plan:
                  and pieces[0].Cp >= 32)
         # narrow 3x3 layers on wide images: split-f16 arithmetic AND the LDS halo (input fetched once for 9 taps)
         shalo = (split and HALO_F16_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.G == 1 and layer.pad == (1, 1)
-                 and layer.dils[0] <= 2 and W >= HALO_F16_MIN_W and layer.CoutP <= HALO_F16_MAX_COUTP and residual is None
+                 and layer.dils[0] <= 2 and W >= (HALO_F16_MIN_W if layer.CoutP > 64 else HALO_F16_MIN_W_NARROW)
+                 and layer.CoutP <= HALO_F16_MAX_COUTP and residual is None
                  and H * W * pieces[0].stride < 2 ** 31)
         # fused dilated group of an MSBlock: three lattice-halo launches (out = o + sum_g relu(conv_g(o)))
         lattice = (split and LATTICE_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)

@@ -13,6 +13,10 @@ CASES = [  # name, B, Cin, Cout, H, W, dil
     ("ms2 128->32 120x160", 64, 128, 32, 120, 160, 1),
     ("ms3 256->32 60x80", 64, 256, 32, 60, 80, 1),
     ("enc.b1 64->64", 128, 64, 64, 120, 160, 1),
+    ("ms4 512->32 30x40", 64, 512, 32, 30, 40, 1),
+    ("ms5 512->32 30x40 d2?", 64, 512, 32, 30, 40, 1),
+    ("enc.b3 128->128 30x40", 128, 128, 128, 30, 40, 1),
+    ("dec.up3 62->62 60x80", 64, 64, 64, 60, 80, 1),
     ("vgg2_2 64x120x160", 64, 128, 128, 120, 160, 1),
     ("vgg3_2 64x60x80", 64, 256, 256, 60, 80, 1),
     ("vgg4_2 64x30x40", 64, 512, 512, 30, 40, 1),
