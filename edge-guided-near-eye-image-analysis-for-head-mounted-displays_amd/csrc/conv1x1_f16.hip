@@ -189,7 +189,12 @@ extern "C" int egne_conv1x1_f16x3_fwd(const egne_conv_desc* dp, const void* fhi,
   EGNE_REQUIRE(nb < (1ll << 31), "conv1x1_f16: too many pixels");
   const int TN = d.CoutP == 32 ? 1 : 2;
   const size_t lds = (size_t)G * TN * 2 * 64 * 8 * sizeof(_Float16);
-  EGNE_REQUIRE(lds <= 64 * 1024, "conv1x1_f16: K = %d groups of 16 does not fit the LDS weight image", G);
+  EGNE_REQUIRE(lds <= 80 * 1024, "conv1x1_f16: K = %d groups of 16 does not fit the LDS weight image", G);
+  static bool once = [] {
+    return hipFuncSetAttribute((const void*)conv1x1_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)conv1x1_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+  }();
+  if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_f16: cannot raise the dynamic LDS limit");
   const int ny = d.CoutP / (32 * TN);
   long long gx = (nb + 3) / 4;
   const long long cap = 256 * 8;

@@ -412,7 +412,7 @@ class Plan:
         s1x1 = (F16X3_ENABLED and S1X1_ENABLED and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
                 and layer.G == 1 and layer.pad == (0, 0) and residual is None and layer.post is None
                 and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
-                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 65536
+                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 80 * 1024
                 and B * H * W >= S1X1_MIN_PIX)
         # wide trunk layers: deep 256-wide split-f16 kernel (weights by LDS-DMA, one barrier per K step)
         big = (split and BIG_ENABLED and layer.G == 1 and pieces[0].scale is None and pieces[0].Cp % 32 == 0 and residual is None
