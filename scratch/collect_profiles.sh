@@ -2,10 +2,12 @@
 # Runs on the GPU box (via gpurun): final benches, rocprofv3 kernel stats and the PMC HBM-traffic passes.
 # usage: bash scratch/collect_profiles.sh <tag>   -> gpurun_out/<tag>/...
 tag=${1:-final}
+only=${2:-all}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+if [ "$only" = all ]; then
 python3 $R/bench.py --steps 10 --warmup 3 > $out/bench_infer.json 2> $out/bench_infer.err
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --fit > $out/bench_infer_fit.json 2>/dev/null
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --batch 128 > $out/bench_infer_b128.json 2>/dev/null
@@ -18,14 +20,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- pytho
 cp $out/stats/r_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o r -- python3 $R/bench.py --mode train --steps 3 --warmup 2 --no-cpu-baseline > $out/stats_train.log 2>&1
 cp $out/stats_train/r_kernel_stats.csv $out/kernel_stats_train.csv 2>/dev/null
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmc_$c -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
-fam = lambda k: ("split_f16" if any(s in k for s in ("conv_f16x3_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel")) else
-                 "fp32_conv" if any(s in k for s in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad")) else "other")
+fam = lambda k: ("split_f16" if any(s in k for s in ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel")) else
+                 "fp32_conv" if any(s in k for s in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel")) else "other")
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 cnt = collections.Counter()
 for c in tot:
