@@ -127,13 +127,23 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ 
   }
 }
 
-__global__ void reduce_chunks_k(const double* __restrict__ ws, int stride, int n, int nchunk, float* __restrict__ out,
-                                int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// 256 threads = 32 channels x 8 interleaved chunk ranges, summed through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void reduce_chunks_k(const double* __restrict__ ws, int stride, int n, int nchunk, float* __restrict__ out,
+                                                       int accumulate) {
+  __shared__ double part[8][32];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + c;
   double s = 0;
-  for (int k = 0; k < nchunk; ++k) s += ws[(long long)k * stride + i];
-  out[i] = accumulate ? out[i] + (float)s : (float)s;
+  if (i < n)
+    for (int k = q; k < nchunk; k += 8) s += ws[(long long)k * stride + i];
+  part[q][c] = s;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    double t = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += part[r][c];
+    out[i] = accumulate ? out[i] + (float)t : (float)t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,21 +439,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
 }
 
 // sum the split partials and add into the OIHW gradient of group g
-__global__ void wgrad_reduce_k(const float* __restrict__ ws, int nsplit, int G, int g, int T, int Cout, int Cin,
-                               const int* __restrict__ kinv, int CoutP, int Ktot, float* __restrict__ gw) {
+// sum the split partials and add into the OIHW gradient of group g: a block = 32 elements x 8 interleaved split ranges,
+// combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nsplit, int G, int g, int T, int Cout, int Cin,
+                                                      const int* __restrict__ kinv, int CoutP, int Ktot, float* __restrict__ gw) {
+  __shared__ float part[8][32];
   const long long total = (long long)T * CoutP * Ktot;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % Ktot);
-    long long q = i / Ktot;
-    const int n = (int)(q % CoutP);
-    const int t = (int)(q / CoutP);
-    const int ci = kinv[k];
-    if (n >= Cout || ci < 0) continue;
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+    const long long i = base + c;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += ws[((long long)sp * G + g) * total + i];
-    gw[((long long)n * Cin + ci) * T + t] += s;
+    if (i < total)
+      for (int sp = q; sp < nsplit; sp += 8) s += ws[((long long)sp * G + g) * total + i];
+    __syncthreads();
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && i < total) {
+      const int k = (int)(i % Ktot);
+      const long long r = i / Ktot;
+      const int n = (int)(r % CoutP);
+      const int t = (int)(r / CoutP);
+      const int ci = kinv[k];
+      if (n < Cout && ci >= 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += part[j][c];
+        gw[((long long)n * Cin + ci) * T + t] += v;
+      }
+    }
   }
 }
+
 
 // dgrad pack: forward OIHW w -> weights of the transposed conv for input channels [ci0, ci0+Cpiece):
 // out[tap'][n = ci - ci0][k = co] = w[co][ci][T-1-tap'], flat ([tap][CoutP'][Ktot']) or fragment order.
@@ -510,7 +536,7 @@ extern "C" int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, i
   hipLaunchKernelGGL(act_bwd_bias_partial, dim3(nchunk, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, y,
                      (long long)ys, yo, act, Cp, (long long)npix, nchunk, (double*)ws);
   if (dbias)
-    hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
+    hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 31) / 32), dim3(256), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
                        nchunk, dbias, accumulate);
   return egne::check_launch("egne_act_bwd_bias");
 }
@@ -638,7 +664,7 @@ extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int6
   for (int g = 0; g < d.ngroups; ++g) {
     EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
     const long long total = (long long)T * d.CoutP * d.Ktot;
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(total)), dim3(256), 0, st, (const float*)ws, nsplit, d.ngroups, g, T, Cout,
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(total * 8)), dim3(256), 0, st, (const float*)ws, nsplit, d.ngroups, g, T, Cout,
                        Cin, kinv, d.CoutP, d.Ktot, gw[g]);
   }
   return egne::check_launch("egne_conv2d_wgrad");
