@@ -340,8 +340,9 @@ __global__ void conf_loss_bwd_k(const float* __restrict__ x, int ld, const long 
 // One workgroup = one 32(co) x 32(k) tile over a pixel range; the 4 waves split each 32-pixel chunk
 // (K-split) and are reduced through LDS at the end.  Partials go to ws[split][tap][CoutP][Ktot].
 // ------------------------------------------------------------------------------------------------
-constexpr int WPX = 32;   // pixels per chunk
+constexpr int WPX = 128;  // pixels per chunk (two barriers per 16 MFMAs of every wave)
 constexpr int WLD = 33;   // LDS row pitch (floats): lanes read consecutive floats of one pixel row
+constexpr int WNR = WPX / 32;
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p, const float* __restrict__ gz, long long gzs,
                                                          int gzo, int nsplit, float* __restrict__ ws) {
@@ -374,51 +375,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
   const int dil = p.dil[g];
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
   const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+  // 1x1 / stride 1 / no padding: the input pixel of output pixel m is pixel m (no div / mod per row)
+  const bool simple = T == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && p.H == p.Ho && p.W == p.Wo;
+  const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const int hw = p.Ho * p.Wo;
 
-  // loader: thread -> (pixel row = tid>>3, float4 column = tid&7) of both 32x32 tiles
+  // loader: thread -> (pixel rows tid>>3 + 32*i, float4 column = tid&7) of both tiles
   const int lr = tid >> 3, lc = (tid & 7) * 4;
+  const bool aok = co0 + lc < p.Cout_store, bok = c0 + lc < sg.Cp;
   f32x16 acc = (f32x16)(0.f);
   for (long long mc = m_begin; mc < m_end; mc += WPX) {
-    const long long m = mc + lr;
-    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
-    if (m < m_end) {
-      if (co0 + lc < p.Cout_store) av = *(const f32x4*)(gz + m * gzs + gzo + co0 + lc);
-      const int hw = p.Ho * p.Wo;
-      const int b = (int)(m / hw);
-      const int r = (int)(m - (long long)b * hw);
-      const int oy = r / p.Wo, ox = r - oy * p.Wo;
-      int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
-      bool ok = c0 + lc < sg.Cp;
-      if (p.pad_mode == 1) {
-        iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
-        ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
-      } else {
-        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      }
-      if (ok) {
-        bv = *(const f32x4*)(sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + lc);
-        if (sg.scale) {
-          const f32x4 sc = *(const f32x4*)(sg.scale + (long long)b * sg.Cp + c0 + lc);
-          const f32x4 sh = *(const f32x4*)(sg.shift + (long long)b * sg.Cp + c0 + lc);
-          bv = bv * sc + sh;
+    f32x4 av[WNR], bv[WNR];
+    int bb[WNR];
+#pragma unroll
+    for (int i = 0; i < WNR; ++i) {
+      const long long m = mc + lr + 32 * i;
+      const bool in = m < m_end;
+      const float* ap = (in && aok) ? gz + m * gzs + gzo + co0 + lc : egne_zero_page;
+      const float* bp = egne_zero_page;
+      bb[i] = -1;
+      if (simple) {
+        if (in && bok) bp = sg.ptr + m * sg.pix_stride + sg.ch_off + c0 + lc;
+        if (sg.scale && in && bok) bb[i] = (int)(m / hw);
+      } else if (in && bok) {
+        const int b = (int)(m / hw);
+        const int r = (int)(m - (long long)b * hw);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
+        bool ok = true;
+        if (p.pad_mode == 1) {
+          iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+        } else {
+          ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         }
-        if (sg.act_in == EGNE_ACT_LEAKY) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[e] = bv[e] > 0.f ? bv[e] : 0.01f * bv[e];
-        } else if (sg.act_in == EGNE_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[e] = fmaxf(bv[e], 0.f);
+        if (ok) {
+          bp = sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + lc;
+          bb[i] = b;
         }
       }
+      av[i] = *(const f32x4*)ap;
+      bv[i] = *(const f32x4*)bp;
+    }
+    if (sg.scale) {
+#pragma unroll
+      for (int i = 0; i < WNR; ++i) {
+        const bool ok = bb[i] >= 0;
+        const f32x4 sc = *(const f32x4*)(ok ? sg.scale + (long long)bb[i] * sg.Cp + c0 + lc : egne_zero_page);
+        const f32x4 sh = *(const f32x4*)(ok ? sg.shift + (long long)bb[i] * sg.Cp + c0 + lc : egne_zero_page);
+        f32x4 v = bv[i] * sc + sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
+        bv[i] = ok ? v : (f32x4)(0.f);
+      }
+    } else if (slope_in != 1.f) {
+#pragma unroll
+      for (int i = 0; i < WNR; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[i][e] = fmaxf(bv[i][e], bv[i][e] * slope_in);
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { As[lr * WLD + lc + e] = av[e]; Bs[lr * WLD + lc + e] = bv[e]; }
-    __syncthreads();
-    // wave w consumes pixel pairs 4w..4w+3 of the chunk: D[co][k] += A[co][px] * B[px][k]
+    for (int i = 0; i < WNR; ++i)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int px = (wave * 4 + s) * 2 + lh;
+      for (int e = 0; e < 4; ++e) { As[(lr + 32 * i) * WLD + lc + e] = av[i][e]; Bs[(lr + 32 * i) * WLD + lc + e] = bv[i][e]; }
+    __syncthreads();
+    // wave w consumes pixel pairs 16w..16w+15 of the chunk: D[co][k] += A[co][px] * B[px][k]
+#pragma unroll
+    for (int s = 0; s < WPX / 8; ++s) {
+      const int px = (wave * (WPX / 8) + s) * 2 + lh;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[px * WLD + li], Bs[px * WLD + li], acc, 0, 0, 0);
     }
   }
