@@ -124,6 +124,10 @@ def lib():
             raise RuntimeError(
                 "HIP extension not built: %s is missing (run __graft_entry__.build()). "
                 "This package has no CPU fallback." % LIB_PATH)
+        # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64, and the extension (linked against
+        # libamdhip64.so.7) must bind to THAT copy.  Loaded before torch it would pull /opt/rocm's runtime in, and two HIP
+        # runtimes in one process do not see each other's device context ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
