@@ -126,54 +126,60 @@ __global__ void norm_act_pool2_k(const float* __restrict__ x, long long xs, int 
   }
 }
 
+// grid = (tiles over Wo * Cp/4, Ho, B): no 64-bit div / mod per element (they cost more issue time than the 4 loads)
 __global__ void maxpool2_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
                            int yo, int B, int H, int W, int Ho, int Wo, int stride, int Cp) {
-  const int nv = Cp >> 2;
-  const long long total = (long long)B * Ho * Wo * nv;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % nv) * 4;
-    long long p = i / nv;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
-    const int y0 = oy * stride, x0 = ox * stride;
-    const int y1 = y0 + 1 < H ? y0 + 1 : y0, x1 = x0 + 1 < W ? x0 + 1 : x0;  // ceil_mode: clipped window
-    const float* s = x + ((long long)b * H * W) * xs + xo + c;
-    const f32x4 a = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
-    const f32x4 bb = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
-    const f32x4 cc = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
-    const f32x4 d = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
-    f32x4 r;
+  const unsigned nv = Cp >> 2;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)Wo * nv) return;
+  const int ox = (int)(t / nv), c = (int)(t - ox * nv) * 4;
+  const int b = blockIdx.z;
+  const int x0 = ox * stride, x1 = x0 + 1 < W ? x0 + 1 : x0;  // ceil_mode: clipped window
+  const float* s = x + ((long long)b * H * W) * xs + xo + c;
+  // 4 output rows per thread: 16 independent loads in flight
+  f32x4 v[4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(a[e], bb[e]), fmaxf(cc[e], d[e]));
-    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+  for (int j = 0; j < 4; ++j) {
+    const int oy = blockIdx.y * 4 + j;
+    const int y0 = oy < Ho ? oy * stride : 0, y1 = y0 + 1 < H ? y0 + 1 : y0;
+    v[j][0] = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
+    v[j][1] = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
+    v[j][2] = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
+    v[j][3] = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = blockIdx.y * 4 + j;
+    if (oy < Ho) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(v[j][0][e], v[j][1][e]), fmaxf(v[j][2][e], v[j][3][e]));
+      *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+    }
   }
 }
 
 __global__ void upsample2x_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
                              int yo, int B, int H, int W, int Cp) {
-  const int Ho = 2 * H, Wo = 2 * W, nv = Cp >> 2;
-  const long long total = (long long)B * Ho * Wo * nv;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % nv) * 4;
-    long long p = i / nv;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
-    // ATen area_pixel_compute_source_index(scale=0.5, align_corners=false): max(0.5*(d+0.5)-0.5, 0)
-    float sy = 0.5f * (oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
-    float sx = 0.5f * (ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float* s = x + ((long long)b * H * W) * xs + xo + c;
-    const f32x4 a = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
-    const f32x4 bb = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
-    const f32x4 cc = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
-    const f32x4 d = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
-    const f32x4 r = hy * (hx * a + lx * bb) + ly * (hx * cc + lx * d);
-    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
-  }
+  const int Ho = 2 * H, Wo = 2 * W;
+  const unsigned nv = Cp >> 2;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)Wo * nv) return;
+  const int ox = (int)(t / nv), c = (int)(t - ox * nv) * 4;
+  const int oy = blockIdx.y, b = blockIdx.z;
+  // ATen area_pixel_compute_source_index(scale=0.5, align_corners=false): max(0.5*(d+0.5)-0.5, 0)
+  float sy = 0.5f * (oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+  float sx = 0.5f * (ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+  const float* s = x + ((long long)b * H * W) * xs + xo + c;
+  const f32x4 a = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
+  const f32x4 bb = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
+  const f32x4 cc = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
+  const f32x4 d = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
+  const f32x4 r = hy * (hx * a + lx * bb) + ly * (hx * cc + lx * d);
+  *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
 }
 
 __global__ void nchw_to_nhwc_k(const float* __restrict__ x, int B, int C, int H, int W, float* __restrict__ y,
@@ -313,7 +319,8 @@ extern "C" int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64
   // ceil_mode output size; the last window must start inside the input
   auto osz = [&](int n) { int o = (n - 2 + stride - 1) / stride + 1; if ((o - 1) * stride >= n) --o; return o; };
   EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2 && Ho == osz(H) && Wo == osz(W), "maxpool2: output %dx%d != %dx%d", Ho, Wo, osz(H), osz(W));
-  hipLaunchKernelGGL(maxpool2_k, dim3(grid_for((long long)B * Ho * Wo * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x,
+  EGNE_REQUIRE(Ho <= 65535 && B <= 65535, "maxpool2: grid limits");
+  hipLaunchKernelGGL(maxpool2_k, dim3((Wo * (Cp / 4) + 255) / 256, (Ho + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x,
                      (long long)xs, xo, y, (long long)ys, yo, B, H, W, Ho, Wo, stride, Cp);
   return egne::check_launch("egne_maxpool2");
 }
@@ -322,7 +329,8 @@ extern "C" int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int
                                int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "upsample2x: bad slices");
   EGNE_REQUIRE(B > 0 && H > 0 && W > 0, "upsample2x: bad shape");
-  hipLaunchKernelGGL(upsample2x_k, dim3(grid_for((long long)B * 4 * H * W * (Cp / 4))), dim3(256), 0,
+  EGNE_REQUIRE(2 * H <= 65535 && B <= 65535, "upsample2x: grid limits");
+  hipLaunchKernelGGL(upsample2x_k, dim3((2 * W * (Cp / 4) + 255) / 256, 2 * H, B), dim3(256), 0,
                      (hipStream_t)stream, x, (long long)xs, xo, y, (long long)ys, yo, B, H, W, Cp);
   return egne::check_launch("egne_upsample2x");
 }
