@@ -50,7 +50,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 template <int WM, int WN, int D, bool LAT, int NW, int PF = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
-                                                               float out_scale, int tiles_x, int tiles_y, int ntiles) {
+                                                               float out_scale, int tiles_x, int tiles_y, int ntiles, int vH, int vW,
+                                                               int rstep, int cstep) {
+  // (vH, vW, rstep, cstep): the image as the kernel walks it.  Normal: (H, W, W, 1).  Transposed ("tall tiles", lattice mode
+  // on lattices much wider than 8 x 32 tiles fit): (W, H, 1, W) -- the 32-long MFMA rows then run along image y.
   constexpr int TH = (4 / NW) * WM;
   constexpr int d = D;
   constexpr int HWd = TW + 2 * d, HHd = TH + 2 * d, npx = HHd * HWd;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
     for (int i = 0; i < NI; ++i) {
       const bool in = tid + 256 * i < nitems;
       hyx[i] = in ? ((S * hy) << 16) | (S * hx) : 0x7fff7fff;
-      roff[i] = ((S * hy * p.W + S * hx) * (int)sg.pix_stride + c4 * 4) * 4;
+      roff[i] = ((S * hy * rstep + S * hx * cstep) * (int)sg.pix_stride + c4 * 4) * 4;
       hx += 32;
       if (hx >= HWd) { hx -= HWd; ++hy; }
     }
@@ -106,11 +109,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
   int stage_b = 0;
   auto map_tile = [&](const Tile& tl) {
     const int ybase = tl.py + S * (tl.y0 - d), xbase = tl.px + S * (tl.x0 - d);
-    const int tbase = ((ybase * p.W + xbase) * (int)sg.pix_stride + sg.ch_off) * 4;
+    const int tbase = ((ybase * rstep + xbase * cstep) * (int)sg.pix_stride + sg.ch_off) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const unsigned iy = (unsigned)(ybase + (hyx[i] >> 16)), ix = (unsigned)(xbase + (hyx[i] & 0xffff));
-      goff[i] = (iy < (unsigned)p.H && ix < (unsigned)p.W) ? (unsigned)(tbase + roff[i]) : OOB;
+      goff[i] = (iy < (unsigned)vH && ix < (unsigned)vW) ? (unsigned)(tbase + roff[i]) : OOB;
     }
     rin = make_rsrc(sg.ptr + (long long)tl.b * p.H * p.W * sg.pix_stride, frame_in);
     stage_b = tl.b;
@@ -170,10 +173,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
   const unsigned wbytes = 9u * (unsigned)p.Ktot * (unsigned)p.CoutP * 2u;
   const __amdgpu_buffer_rsrc_t rwh = make_rsrc(fhi, wbytes), rwl = make_rsrc(flo, wbytes);
   const int stride_k16 = NT * 1024, stride_tap = KT16 * NT * 1024;
+  // transposed walk: the LDS tap (ky, kx) is the image tap (kx, ky) -> fetch the transposed 3x3 weight
+  const bool tposed = cstep != 1;
+  auto wtap = [&](int t) { return tposed ? (t % 3) * 3 + t / 3 : t; };
   const int wlane = lane * 16;
 
   // epilogue constants: lane -> channel n, first x of the lane inside a tile row
-  const int out_step = S * (int)p.out_pix_stride * 4, res_step = S * (int)p.res_pix_stride * 4;
+  const int out_step = S * cstep * (int)p.out_pix_stride * 4, res_step = S * cstep * (int)p.res_pix_stride * 4;
 
   int t = blockIdx.x;
   if (t >= ntiles) return;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
     for (int s = 0; s < 2 * RT; ++s)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
-        const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
+        const int o = wchunk + wtap(s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
         qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
         ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
       }
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         if (tap + RT < 9) {
 #pragma unroll
           for (int tn = 0; tn < WN; ++tn) {
-            const int o = wchunk + (tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
+            const int o = wchunk + wtap(tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
             qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
             ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
           }
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
       const __amdgpu_buffer_rsrc_t rres =
           make_rsrc(p.residual ? p.residual + (long long)cur.b * p.H * p.W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
       const int xl = cur.px + S * (cur.x0 + 4 * lh);
-      const int cmax = xl < p.W ? (p.W - xl + S - 1) / S : 0;      // c_r < cmax  <=>  x < W
+      const int cmax = xl < vW ? (vW - xl + S - 1) / S : 0;      // c_r < cmax  <=>  x < W
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
         const int n = (nt0 + tn) * 32 + li;
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
-          const int cm = (nok && y < p.H) ? cmax : 0;
-          const int pix = y * p.W + xl;
+          const int cm = (nok && y < vH) ? cmax : 0;
+          const int pix = y * rstep + xl * cstep;
           const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
           float rv[16];
 #pragma unroll
@@ -325,14 +331,20 @@ template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0>
 int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   constexpr int TH = (4 / NW) * WM;
   const int S = LAT ? d.dil[0] : 1;
-  const int lw = (d.W + S - 1) / S, lh_ = (d.H + S - 1) / S;     // lattice extent (largest phase)
+  auto ntile = [&](int vh, int vw) { return ((((vw + S - 1) / S) + TW - 1) / TW) * ((((vh + S - 1) / S) + TH - 1) / TH); };
+  // lattice mode: walk the image transposed when 8 x 32 tiles fit the lattice better that way (dilation 8 on 240x320: 30 x 40
+  // lattice points per phase = 8 wide tiles at 59 % fill or 5 tall tiles at 94 %)
+  static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
+  const bool tall = LAT && tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W);
+  const int vH = tall ? d.W : d.H, vW = tall ? d.H : d.W, rstep = tall ? 1 : d.W, cstep = tall ? d.W : 1;
+  const int lw = (vW + S - 1) / S, lh_ = (vH + S - 1) / S;     // lattice extent (largest phase)
   const int tiles_x = (lw + TW - 1) / TW, tiles_y = (lh_ + TH - 1) / TH;
   const size_t lds = (size_t)2 * (TH + 2 * D) * (TW + 2 * D) * LDH * sizeof(_Float16);
   const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN * NW);
   int gx = (256 * 2 + ny - 1) / ny;
   if (gx > ntiles) gx = ntiles;
   hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW, PF>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
-                     tiles_y, ntiles);
+                     tiles_y, ntiles, vH, vW, rstep, cstep);
   return egne::check_launch("egne_conv3x3_halo_f16_fwd");
 }
 
