@@ -335,7 +335,7 @@ int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo,
   // lattice mode: walk the image transposed when 8 x 32 tiles fit the lattice better that way (dilation 8 on 240x320: 30 x 40
   // lattice points per phase = 8 wide tiles at 59 % fill or 5 tall tiles at 94 %)
   static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
-  const bool tall = LAT && tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W);
+  const bool tall = tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W);
   const int vH = tall ? d.W : d.H, vW = tall ? d.H : d.W, rstep = tall ? 1 : d.W, cstep = tall ? d.W : 1;
   const int lw = (vW + S - 1) / S, lh_ = (vH + S - 1) / S;     // lattice extent (largest phase)
   const int tiles_x = (lw + TW - 1) / TW, tiles_y = (lh_ + TH - 1) / TH;
