@@ -47,13 +47,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // NW = waves along N: <WM=2, WN, NW=1> gives every wave 2 tile rows x all 32*WN channels; <WM=4, WN=1, NW=2> gives a
 // wave 4 tile rows x 32 of the 64 channels -- same accumulators, but each weight fragment fetched from L1/L2 feeds
 // twice as many MFMAs (PMC: the weight ring of the <2,2,1> shape ran the vector L1 at 80 % of its 64 B/clk).
-template <int WM, int WN, int D, bool LAT, int NW, int PF = 0>
+template <int WM, int WN, int D, bool LAT, int NW, int PF = 0, bool TP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
-                                                               float out_scale, int tiles_x, int tiles_y, int ntiles, int vH, int vW,
-                                                               int rstep, int cstep) {
-  // (vH, vW, rstep, cstep): the image as the kernel walks it.  Normal: (H, W, W, 1).  Transposed ("tall tiles", lattice mode
-  // on lattices much wider than 8 x 32 tiles fit): (W, H, 1, W) -- the 32-long MFMA rows then run along image y.
+                                                               float out_scale, int tiles_x, int tiles_y, int ntiles) {
+  // (vH, vW, rstep, cstep): the image as the kernel walks it.  Normal: (H, W, W, 1).  TP = transposed ("tall tiles", for maps
+  // that 8 x 32 tiles fit badly): (W, H, 1, W) -- the 32-long MFMA rows then run along image y.  A template parameter: as
+  // run-time values the extra address arithmetic cost the normal path 5 %.
+  const int vH = TP ? p.W : p.H, vW = TP ? p.H : p.W, rstep = TP ? 1 : p.W, cstep = TP ? p.W : 1;
   constexpr int TH = (4 / NW) * WM;
   constexpr int d = D;
   constexpr int HWd = TW + 2 * d, HHd = TH + 2 * d, npx = HHd * HWd;
@@ -174,8 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
   const __amdgpu_buffer_rsrc_t rwh = make_rsrc(fhi, wbytes), rwl = make_rsrc(flo, wbytes);
   const int stride_k16 = NT * 1024, stride_tap = KT16 * NT * 1024;
   // transposed walk: the LDS tap (ky, kx) is the image tap (kx, ky) -> fetch the transposed 3x3 weight
-  const bool tposed = cstep != 1;
-  auto wtap = [&](int t) { return tposed ? (t % 3) * 3 + t / 3 : t; };
+  auto wtap = [&](int t) { return TP ? (t % 3) * 3 + t / 3 : t; };
   const int wlane = lane * 16;
 
   // epilogue constants: lane -> channel n, first x of the lane inside a tile row
@@ -327,25 +327,33 @@ __global__ void pack_weight_f16frag_k(const float* __restrict__ w, int Cout, int
   }
 }
 
-template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0>
-int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
+template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0, bool TP = false>
+int launch_hf_tp(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   constexpr int TH = (4 / NW) * WM;
   const int S = LAT ? d.dil[0] : 1;
-  auto ntile = [&](int vh, int vw) { return ((((vw + S - 1) / S) + TW - 1) / TW) * ((((vh + S - 1) / S) + TH - 1) / TH); };
-  // lattice mode: walk the image transposed when 8 x 32 tiles fit the lattice better that way (dilation 8 on 240x320: 30 x 40
-  // lattice points per phase = 8 wide tiles at 59 % fill or 5 tall tiles at 94 %)
-  static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
-  const bool tall = tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W);
-  const int vH = tall ? d.W : d.H, vW = tall ? d.H : d.W, rstep = tall ? 1 : d.W, cstep = tall ? d.W : 1;
+  const int vH = TP ? d.W : d.H, vW = TP ? d.H : d.W;
   const int lw = (vW + S - 1) / S, lh_ = (vH + S - 1) / S;     // lattice extent (largest phase)
   const int tiles_x = (lw + TW - 1) / TW, tiles_y = (lh_ + TH - 1) / TH;
   const size_t lds = (size_t)2 * (TH + 2 * D) * (TW + 2 * D) * LDH * sizeof(_Float16);
   const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN * NW);
   int gx = (256 * 2 + ny - 1) / ny;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW, PF>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
-                     tiles_y, ntiles, vH, vW, rstep, cstep);
+  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW, PF, TP>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
+                     tiles_y, ntiles);
   return egne::check_launch("egne_conv3x3_halo_f16_fwd");
+}
+
+// Walk the image transposed when 8 x 32 tiles fit it better that way (dilation 8 on 240x320: 30 x 40 lattice points per
+// phase = 8 wide tiles at 59 % fill or 5 tall tiles at 94 %; plain 60x80 and 30x40 maps likewise).  D = 1 shapes only.
+template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0>
+int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
+  constexpr int TH = (4 / NW) * WM;
+  const int S = LAT ? d.dil[0] : 1;
+  auto ntile = [&](int vh, int vw) { return ((((vw + S - 1) / S) + TW - 1) / TW) * ((((vh + S - 1) / S) + TH - 1) / TH); };
+  static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
+  if (D == 1 && NW == 1 && PF == 0 && tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W))
+    return launch_hf_tp<WM, WN, (D == 1 && NW == 1 && PF == 0 ? D : 1), LAT, (D == 1 && NW == 1 && PF == 0 ? NW : 1), 0, true>(d, fhi, flo, a_scale, os, st);
+  return launch_hf_tp<WM, WN, D, LAT, NW, PF, false>(d, fhi, flo, a_scale, os, st);
 }
 
 }  // namespace
