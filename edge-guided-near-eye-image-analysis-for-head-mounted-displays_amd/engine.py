@@ -26,6 +26,7 @@ BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
 BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
 BIG_SPLIT_TAIL = os.environ.get("EGNE_BIG_SPLIT_TAIL", "1") != "0"
 BIG_CUS = 256
+EVENT_KINDS = None   # bench.py: restrict the per-launch HIP events of Plan.run(events) to these kernel families
 S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
@@ -664,6 +665,11 @@ class Plan:
                     _lib.check(rc, name)
             return
         for (fn, args, name), (kind, flops) in zip(self.calls, self.meta):
+            if EVENT_KINDS is not None and kind not in EVENT_KINDS:      # untimed launch (each event pair costs ~2 us of GPU time)
+                rc = fn(*args, st)
+                if rc != 0:
+                    _lib.check(rc, name)
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*args, st)
