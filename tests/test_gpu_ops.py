@@ -392,3 +392,32 @@ def test_conv3x3_backward_halo_wgrad(G, B, Cin, Cout, H, W, norm):
         gx = pl.gbuf(px.buf).cpu()[..., :Cin].permute(0, 3, 1, 2)
         ex = (gx - xin.grad).abs().max().item() / xin.grad.abs().max().item()
         assert ex < 2e-5
+
+
+def test_msblock_lattice_groups_wide_and_tall_tiles(G):
+    """Dilated group of an MSBlock (bdcn_new.py:49-55) on a 240x320 frame: three lattice-halo launches (dilation 4 / 8 / 12
+    as 16 / 64 / 144 ordinary 3x3 convs on sub-lattices) accumulating through the residual; the dilation-4 and -8 lattices
+    (60x80, 30x40 points) are walked transposed ("tall" tiles, transposed 3x3 taps), dilation 12 (20x27) is not."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    B, H, W = 1, 240, 320
+    o = F.relu(_rand(G, B, 32, H, W)) * 2
+    ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+    bs = [_rand(G, 32) for _ in range(3)]
+    truth = o.double()
+    for w, b, d in zip(ws, bs, (4, 8, 12)):
+        truth = truth + F.relu(F.conv2d(o.double(), w.double(), b.double(), padding=d, dilation=d))
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [o], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV)) for w in ws], [torch.nn.Parameter(b.to(DEV)) for b in bs], [(32, 32)],
+                      pad=(1, 1), dils=(4, 8, 12), act=1)
+    layer.split = True
+    out = pl.buf(B, H, W, 32)
+    pl.conv(layer, [px], Piece(out, 0, 32), B, H, W, residual=px)
+    assert len(pl.calls) == 3 and all(c[0] is pl.L.egne_conv3x3_halo_f16_fwd for c in pl.calls)
+    pl.run()
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    err = (got - truth).abs().max().item() / truth.abs().max().item()
+    print("lattice group err %.2e" % err)
+    assert err < 2e-6
