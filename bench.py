@@ -221,7 +221,7 @@ def main():
                   "algorithmic_gflop_per_frame": round(conv_f / a.steps / B / 1e9, 2), "time_share": round(conv_t / tot_t, 4)}
         sp_ach = sp_f / sp_t / 1e12 if sp_t > 0 else 0.0
         r_split = {"bound": "mfma", "kernel": "split-f16 conv family (fp32 tensors, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate): "
-                   "conv_f16x3_kernel, conv3x3_halo_f16_kernel, conv1x1_f16x3_kernel; inference plans of BDCN and ESF-Net",
+                   "conv_f16x3_big_kernel (deep 256-wide trunk tiles), conv3x3_halo_f16_kernel, conv_f16x3_kernel, conv1x1_f16x3_kernel; inference plans of BDCN and ESF-Net",
                    "achieved": round(sp_ach, 2), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1),
                    "unit": "TFLOP/s (algorithmic, fp32-equivalent; peak = 2500 dense f16 MFMA / 3 MFMAs per product)",
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": None,
