@@ -21,6 +21,8 @@ HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
+MS1X1_ENABLED = os.environ.get("EGNE_MS1X1", "1") != "0"
+MS1X1_MIN_PIX = int(os.environ.get("EGNE_MS1X1_MIN_PIX", "30000"))
 BIG_ENABLED = os.environ.get("EGNE_BIG", "1") != "0"
 BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
 BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
@@ -108,6 +110,8 @@ class ConvLayer:
         self.split = False      # allow the split-f16 (f16x3) kernel for this layer (frozen nets only)
         self.need_split = False
         self.need_sfrag = False  # fragment-order f16 pack for the split-f16 halo kernel
+        self.need_m1 = False     # [CoutP][Ktot] hi/lo pack (slices padded to 32) for the LDS-staged multi-slice 1x1 kernel
+        self.m1hi = self.m1lo = None
         self.need_big = False    # LDS-image pack for the deep 256-wide split-f16 kernel
         self.wimg = None
         self.split1 = False      # allow the streaming split-f16 kernel for this 1x1 layer (frozen nets only)
@@ -134,7 +138,8 @@ class ConvLayer:
             (b._version if b is not None else -1) for b in (self.biases or []))
         have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
-                and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big))
+                and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big)
+                and (self.m1hi is not None or not self.need_m1))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return
         L = _lib.lib()
@@ -189,6 +194,24 @@ class ConvLayer:
                 self.s1lo = torch.empty_like(self.s1hi)
             _lib.check(L.egne_pack_conv1x1_weight_f16(wd.data_ptr(), self.Cout, self.Cin, self.s1_kmap.data_ptr(), self.s1_G, self.CoutP,
                                                       self.w_scale1, self.s1hi.data_ptr(), self.s1lo.data_ptr(), st), "pack_conv1x1_f16")
+        if self.need_m1:
+            import math
+            wd = self.weights[0].detach().contiguous()
+            mx = float(wd.abs().max())
+            self.w_scale_m1 = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
+            if self.m1hi is None:
+                kmap, c0 = [], 0
+                for c, cp in self.in_layout:
+                    kmap += list(range(c0, c0 + c)) + [-1] * (pad32(cp) - c)
+                    c0 += c
+                self.m1_ktot = len(kmap)
+                self.m1_coutp = (self.Cout + 63) // 64 * 64
+                self.m1_kmap = torch.tensor(kmap, dtype=torch.int32, device=dev)
+                self.m1hi = torch.empty(self.m1_coutp * self.m1_ktot, dtype=torch.float16, device=dev)
+                self.m1lo = torch.empty_like(self.m1hi)
+            _lib.check(L.egne_pack_conv1x1_weight_f16x2_map(wd.data_ptr(), self.Cout, self.Cin, self.m1_kmap.data_ptr(), self.m1_coutp,
+                                                            self.m1_ktot, self.w_scale_m1, self.m1hi.data_ptr(), self.m1lo.data_ptr(), st),
+                       "pack_conv1x1_f16x2_map")
         if self.need_big:
             import math
             wd = self.weights[0].detach().contiguous()
@@ -264,6 +287,7 @@ class DgradLayer(ConvLayer):
         self.split1 = self.need_s1 = False
         self.s1hi = self.s1lo = None
         self.need_big, self.wimg = False, None
+        self.need_m1, self.m1hi, self.m1lo = False, None, None
         self.whi = self.wlo = self.fhi = self.flo = None
         self.w_scale = 1.0
         self._versions, self.post = None, None
@@ -415,6 +439,10 @@ class Plan:
                 and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
                 and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 80 * 1024
                 and B * H * W >= S1X1_MIN_PIX)
+        # 1x1 over raw slices that the streaming kernel cannot take (K or Cout too large): LDS-staged split-f16 GEMM
+        ms1x1 = (F16X3_ENABLED and MS1X1_ENABLED and not s1x1 and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
+                 and layer.G == 1 and layer.pad == (0, 0) and residual is None and layer.post is None
+                 and all(pc.scale is None for pc in pieces) and layer.Cout > 32 and B * H * W >= MS1X1_MIN_PIX)
         # wide trunk layers: deep 256-wide split-f16 kernel (weights by LDS-DMA, one barrier per K step)
         big = (split and BIG_ENABLED and layer.G == 1 and pieces[0].scale is None and pieces[0].Cp % 32 == 0 and residual is None
                and layer.post is None and layer.Cout % 128 == 0 and layer.Cout >= BIG_MIN_COUT and layer.Cin >= BIG_MIN_CIN
@@ -446,6 +474,10 @@ class Plan:
         elif s1x1:
             smallcin = split = shalo = halo = lattice = False
             layer.need_s1 = True
+            layer.need_flat = True
+        elif ms1x1:
+            smallcin = split = shalo = halo = lattice = False
+            layer.need_m1 = True
             layer.need_flat = True
         elif smallcin:
             layer.need_c4 = True
@@ -511,6 +543,10 @@ class Plan:
         elif big:
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
                       flops=flops, kind="conv_f16x3")
+        elif ms1x1:
+            d.Ktot, d.CoutP = layer.m1_ktot, layer.m1_coutp
+            self._add(self.L.egne_conv1x1_ms_f16x3_fwd, (C.byref(d), layer.m1hi.data_ptr(), layer.m1lo.data_ptr(), F16X3_ASCALE,
+                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3")
         elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
                                                       layer.w_scale1), name, flops=flops, kind="conv_f16x3")

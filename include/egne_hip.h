@@ -140,6 +140,15 @@ int egne_pack_conv1x1_weight_f16(const float* w_oihw, int Cout, int Cin, const i
 int egne_conv1x1_f16x3_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
                            float w_scale, void* stream);
 
+/* LDS-staged variant of the split-f16 1x1 convolution over raw slices, for the layers whose K or Cout exceed what the
+ * streaming kernel keeps in LDS (decoder conv11 / conv21 at 30x40 and 60x80, models/RITnet_v2.py:84,86; dense block 3):
+ * 128x128 (CoutP % 128 == 0) or 256x64 tiles.  d->Ktot = sum of the slice widths rounded up to 32 each; weights: hi / lo
+ * f16 [CoutP][Ktot] with kmap[k] (device int32) naming the logical input channel of K column k (-1 = padding). */
+int egne_pack_conv1x1_weight_f16x2_map(const float* w_oihw, int Cout, int Cin, const int32_t* kmap, int CoutP, int Ktot,
+                                       float wscale, void* whi, void* wlo, void* stream);
+int egne_conv1x1_ms_f16x3_fwd(const egne_conv_desc* d, const void* whi, const void* wlo, float a_scale,
+                              float w_scale, void* stream);
+
 /* First layers (vgg16_c.py:66 conv1_1 on 3 channels, utils.py:1047 convBlock conv1 on 1-2 channels):
  * 3x3 / stride 1 / pad 1, logical Cin <= 4, Cout <= 64.  The 9 taps are folded into K (one 40-wide K step,
  * exact fp32 MFMA), so the layer is a pure store stream.  w40: [32 or 64][40] fp32, column tap*4 + c. */

@@ -316,7 +316,9 @@ def test_conv_f16x3_grouped_msblock(G):
 
 
 @pytest.mark.parametrize("chans,Cout,B,H,W,act", [((32, 32), 32, 2, 37, 53, 0), ((38, 64, 24), 64, 1, 61, 35, 2),
-                                                  ((115, 8, 40), 100, 1, 19, 23, 1), ((32, 32, 32), 30, 3, 16, 16, 0)])
+                                                  ((115, 8, 40), 100, 1, 19, 23, 1), ((32, 32, 32), 30, 3, 16, 16, 0),
+                                                  ((76, 96), 96, 2, 30, 41, 0), ((306, 128, 115), 180, 1, 30, 40, 2),
+                                                  ((100, 64, 38, 62), 62, 2, 33, 17, 1)])
 def test_conv1x1_streaming_split(G, chans, Cout, B, H, W, act):
     """Streaming split-f16 1x1 kernel (conv1x1_f16.hip) over several slices of one buffer and of a second buffer
     (ragged slice widths: 8-channel tail groups, padded channels, pixel count not a multiple of 32)."""
@@ -334,13 +336,15 @@ def test_conv1x1_streaming_split(G, chans, Cout, B, H, W, act):
     layer.split1 = True
     out = pl.buf(B, H, W, pad8(Cout) + 16)
     out.fill_(777.0)
-    old = engine.S1X1_MIN_PIX
-    engine.S1X1_MIN_PIX = 0
+    old = engine.S1X1_MIN_PIX, engine.MS1X1_MIN_PIX
+    engine.S1X1_MIN_PIX = engine.MS1X1_MIN_PIX = 0
     try:
         pl.conv(layer, pieces, Piece(out, 8, Cout), B, H, W)
     finally:
-        engine.S1X1_MIN_PIX = old
-    assert pl.calls[-1][0] is pl.L.egne_conv1x1_f16x3_fwd
+        engine.S1X1_MIN_PIX, engine.MS1X1_MIN_PIX = old
+    # Cout 96 / K 549 do not fit the streaming kernel's LDS weight image: LDS-staged multi-slice GEMM (conv1x1_ms_f16.hip)
+    staged = Cout in (96, 180)
+    assert pl.calls[-1][0] is (pl.L.egne_conv1x1_ms_f16x3_fwd if staged else pl.L.egne_conv1x1_f16x3_fwd)
     pl.run()
     torch.cuda.synchronize()
     o = out.cpu()
