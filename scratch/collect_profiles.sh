@@ -27,7 +27,7 @@ done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
-fam = lambda k: ("split_f16" if any(s in k for s in ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel")) else
+fam = lambda k: ("split_f16" if any(s in k for s in ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel")) else
                  "fp32_conv" if any(s in k for s in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel")) else "other")
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 cnt = collections.Counter()
