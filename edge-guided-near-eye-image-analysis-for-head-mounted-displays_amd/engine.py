@@ -242,15 +242,20 @@ class ConvLayer:
                                                              self.w_scale, self.whi.data_ptr() + 2 * g * per,
                                                              self.wlo.data_ptr() + 2 * g * per, st), "pack_f16x2")
             if self.need_sfrag:
-                perf = T * self.CoutP * kts
+                perf = T * self.sfrag_coutp() * kts
                 if self.fhi is None:
                     self.fhi = torch.empty(self.G * perf, dtype=torch.float16, device=dev)
                     self.flo = torch.empty(self.G * perf, dtype=torch.float16, device=dev)
                 for g, wd in enumerate(ws):
-                    _lib.check(L.egne_pack_conv_weight_f16frag(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.CoutP, kts,
+                    _lib.check(L.egne_pack_conv_weight_f16frag(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.sfrag_coutp(), kts,
                                                                self.w_scale, self.fhi.data_ptr() + 2 * g * perf,
                                                                self.flo.data_ptr() + 2 * g * perf, st), "pack_f16frag")
         self._versions = vers
+
+    def sfrag_coutp(self):
+        """Row count of the fragment-order f16 pack: above 64 channels a multiple of 64, so that the halo kernel runs its
+        64-wide shape (96 channels: two 64-wide tiles instead of three 32-wide ones that each re-stage the halo)."""
+        return self.CoutP if self.CoutP <= 64 else (self.CoutP + 63) // 64 * 64
 
     def split_coutp(self):
         """Row count of the f16 pack: 128-padded for wide layers (128x128 tile), 32-padded otherwise (256x32 tile)."""
@@ -511,7 +516,7 @@ class Plan:
         if big:
             d.CoutP = layer.big_coutp
         if shalo:
-            d.CoutP = layer.CoutP
+            d.CoutP = layer.sfrag_coutp()
         d.w = (layer.wimg.data_ptr() if big else (layer.fhi.data_ptr() if shalo else layer.whi.data_ptr())) if split else (layer.wf.data_ptr() if halo else layer.wp.data_ptr())
         d.bias = layer.bp.data_ptr() if layer.biases is not None else None
         d.act = layer.act
@@ -551,7 +556,7 @@ class Plan:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
                                                       layer.w_scale1), name, flops=flops, kind="conv_f16x3")
         elif lattice:
-            perf = 9 * layer.CoutP * pad32(layer.Ktot)
+            perf = 9 * layer.sfrag_coutp() * pad32(layer.Ktot)
             for g in range(3):
                 dg = _lib.ConvDesc()
                 C.memmove(C.byref(dg), C.byref(d), C.sizeof(_lib.ConvDesc))
