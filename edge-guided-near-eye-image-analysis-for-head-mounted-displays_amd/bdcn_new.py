@@ -139,6 +139,7 @@ class BDCN(nn.Module):
             conv = getattr(f, name)
             layer = ConvLayer([conv.weight], [conv.bias], [(cin, pad8(cin))], pad=(1, 1), dils=(d,), act=ACT_RELU)
             layer.split = cin % 32 == 0      # frozen trunk: split-f16 MFMA (conv_f16x3.hip), edge map tolerance 1e-3
+            layer.split_c4 = cin <= 4        # conv1_1: streaming split-f16 first-layer kernel (conv3x3_c4_f16.hip)
             ob = pl.buf(B, hh, ww, cout)
             dst = Piece(ob, 0, cout)
             pl.conv(layer, [cur], dst, B, hh, ww, name="vgg." + name)

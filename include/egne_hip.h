@@ -154,6 +154,15 @@ int egne_conv1x1_ms_f16x3_fwd(const egne_conv_desc* d, const void* whi, const vo
  * exact fp32 MFMA), so the layer is a pure store stream.  w40: [32 or 64][40] fp32, column tap*4 + c. */
 int egne_conv3x3_smallcin_fwd(const egne_conv_desc* d, const float* w40, void* stream);
 
+/* Split-f16, streaming form of egne_conv3x3_smallcin_fwd for frozen / inference plans: the 9 taps folded into K = 48 (three
+ * K=16 steps), nothing staged -- a lane's operand for one step is the 4-channel vectors of two taps of its pixel (two 16-byte
+ * buffer loads), weight fragments in registers, 16-byte stores.  Weights: hi / lo f16 [3][CoutP/32][lane][8], K slot
+ * (step s, half h, j) = tap 4s + 2h + (j>>2), channel j&3; d->CoutP = 32 or 64. */
+int egne_pack_conv3x3_c4_weight_f16(const float* w_oihw, int Cout, int Cin, int CoutP, float wscale, void* fhi, void* flo,
+                                    void* stream);
+int egne_conv3x3_smallcin_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
+                                  float w_scale, void* stream);
+
 /* OIHW (torch layout) -> packed [tap][CoutP][Ktot].  kinv[k] (device int32, k < Ktot) names the
  * input channel stored at padded K position k, or -1 for a padding column; rows Cout..CoutP-1 are
  * zero.  Used at load_state_dict / after optimizer steps. */

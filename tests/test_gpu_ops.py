@@ -425,3 +425,41 @@ def test_msblock_lattice_groups_wide_and_tall_tiles(G):
     err = (got - truth).abs().max().item() / truth.abs().max().item()
     print("lattice group err %.2e" % err)
     assert err < 2e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,B,H,W,post", [(3, 64, 2, 37, 53, False), (1, 32, 3, 16, 48, True), (2, 30, 1, 41, 33, True)])
+def test_first_layer_streaming_split(G, Cin, Cout, B, H, W, post):
+    """Streaming split-f16 first-layer kernel (conv3x3_c4_f16.hip: 9 taps folded into K = 48, operands straight from HBM)
+    against a float64 convolution; with the folded eval-mode BatchNorm (post affine) of ESF-Net's head."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = _rand(G, B, Cin, H, W) * 2
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    truth = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01)
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=2)
+    layer.split = True
+    if post:
+        ps, pt = 0.5 + _rand(G, Cout).abs(), _rand(G, Cout)
+        truth = truth * ps.double()[None, :, None, None] + pt.double()[None, :, None, None]
+        psd, ptd = torch.zeros(layer.CoutP, device=DEV), torch.zeros(layer.CoutP, device=DEV)
+        psd[:Cout], ptd[:Cout] = ps.to(DEV), pt.to(DEV)
+        layer.post = (psd, ptd)
+    out = pl.buf(B, H, W, pad8(Cout) + 16)
+    out.fill_(777.0)
+    from egne_amd import engine
+    old_mode, engine.C4H_MODE = engine.C4H_MODE, "all"
+    try:
+        pl.conv(layer, [px], Piece(out, 8, Cout), B, H, W)
+    finally:
+        engine.C4H_MODE = old_mode
+    assert pl.calls[-1][0] is pl.L.egne_conv3x3_smallcin_f16_fwd
+    pl.run()
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert (o[..., :8] == 777.0).all() and (o[..., 8 + pad8(Cout):] == 777.0).all(), "wrote outside the output slice"
+    got = o[..., 8:8 + Cout].permute(0, 3, 1, 2).double()
+    err = (got - truth).abs().max().item() / truth.abs().max().item()
+    print("first-layer streaming err %.2e" % err)
+    assert err < 2e-6
