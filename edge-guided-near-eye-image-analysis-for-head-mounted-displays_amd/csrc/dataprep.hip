@@ -1,0 +1,134 @@
+// Device-side batch preparation: the signed, normalised distance maps of the three classes
+// (CurriculumLib.py:131-136 -> helperfunctions.one_hot2dist :356-371, exact Euclidean distance transform) and the
+// per-image z-score (CurriculumLib.py:139).  The reference computes both on the host per sample in the DataLoader; at
+// >1000 frames/s that is the bottleneck of a real training loop (the EDT alone is ~2 ms per frame and class on a core).
+//
+// one_hot2dist(posmask):  res = edt(~pos) * ~pos - (edt(pos) - 1) * pos,  / sqrt((H-1)^2 + (W-1)^2),  0 if the class is absent,
+// where edt(m)[p] = distance from p to the nearest pixel with m == 0 (scipy.ndimage.distance_transform_edt; exact: integer
+// squared distances, sqrt in double).  Separable and exact here too: (1) per column the vertical distance to the nearest
+// pixel inside / outside the class, (2) per row  d2(y,x) = min over x' of (x-x')^2 + g(y,x')^2  from an LDS copy of the row.
+// Integer arithmetic up to the final double sqrt / divide, so the float32 result is bit-identical to the reference's.
+// Quirk kept: for a class that fills the whole frame scipy measures to a virtual background pixel at (-1, 0).
+#include "common.h"
+
+namespace {
+
+constexpr unsigned short NONE = 0xffff;   // no such pixel in the column
+
+// grid (ceil(W/256), ncls, B): one thread per column; g[b][c][0][y][x] = rows to the nearest pixel OUTSIDE class c,
+// g[b][c][1][y][x] = rows to the nearest pixel INSIDE class c; flags[b][c] bit0 = class present, bit1 = some pixel outside it
+__global__ void edt_columns_k(const long long* __restrict__ label, int H, int W, int ncls, unsigned short* __restrict__ g,
+                              int* __restrict__ flags) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const long long* lab = label + (long long)b * H * W + x;
+  unsigned short* gout = g + (((long long)b * ncls + c) * 2) * H * W + x;      // nearest outside
+  unsigned short* gin = gout + (long long)H * W;                              // nearest inside
+  int last_in = -1, last_out = -1, seen = 0;
+  for (int y = 0; y < H; ++y) {
+    const bool in = lab[(long long)y * W] == c;
+    if (in) last_in = y; else last_out = y;
+    seen |= in ? 1 : 2;
+    gout[(long long)y * W] = last_out < 0 ? NONE : (unsigned short)(y - last_out);
+    gin[(long long)y * W] = last_in < 0 ? NONE : (unsigned short)(y - last_in);
+  }
+  last_in = -1; last_out = -1;
+  for (int y = H - 1; y >= 0; --y) {
+    const bool in = lab[(long long)y * W] == c;
+    if (in) last_in = y; else last_out = y;
+    const unsigned short a = last_out < 0 ? NONE : (unsigned short)(last_out - y);
+    const unsigned short e = last_in < 0 ? NONE : (unsigned short)(last_in - y);
+    if (a < gout[(long long)y * W]) gout[(long long)y * W] = a;
+    if (e < gin[(long long)y * W]) gin[(long long)y * W] = e;
+  }
+  if (seen) atomicOr(&flags[b * ncls + c], seen);
+}
+
+// grid (H, ncls, B), one workgroup per image row; dynamic LDS: 2*W u16 + W bytes
+__global__ void edt_rows_k(const long long* __restrict__ label, int H, int W, int ncls, const unsigned short* __restrict__ g,
+                           const int* __restrict__ flags, double mx, float* __restrict__ out) {
+  extern __shared__ unsigned short row[];           // [0,W): nearest outside, [W,2W): nearest inside
+  unsigned char* in_row = (unsigned char*)(row + 2 * W);
+  const int y = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const unsigned short* gout = g + ((((long long)b * ncls + c) * 2) * H + y) * W;
+  const unsigned short* gin = gout + (long long)H * W;
+  const long long* lab = label + ((long long)b * H + y) * W;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    row[x] = gout[x];
+    row[W + x] = gin[x];
+    in_row[x] = lab[x] == c;
+  }
+  __syncthreads();
+  const int fl = flags[b * ncls + c];
+  float* o = out + (((long long)b * ncls + c) * H + y) * W;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    double res = 0.0;
+    if (fl & 1) {                                   // class present in this frame
+      const bool in = in_row[x];
+      if (in && !(fl & 2)) {
+        res = -(sqrt((double)((y + 1) * (y + 1) + x * x)) - 1.0);           // scipy: no background anywhere
+      } else {
+        const unsigned short* gv = in ? row : row + W;                      // inside: distance to the outside, and vice versa
+        int best = 0x7fffffff;
+        for (int xp = 0; xp < W; ++xp) {
+          const int v = gv[xp];
+          if (v != NONE) {
+            const int dx = x - xp, d2 = dx * dx + v * v;
+            best = d2 < best ? d2 : best;
+          }
+        }
+        const double dist = sqrt((double)best);
+        res = in ? -(dist - 1.0) : dist;
+      }
+    }
+    o[x] = (float)(res / mx);
+  }
+}
+
+// one workgroup per image: mean, then population std around it, both in double (numpy: (img - img.mean()) / img.std())
+__global__ __launch_bounds__(256) void zscore_k(const float* __restrict__ x, float* __restrict__ y, int n) {
+  __shared__ double sh[256];
+  const float* xi = x + (long long)blockIdx.x * n;
+  float* yi = y + (long long)blockIdx.x * n;
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += xi[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  const double mean = sh[0] / n;
+  __syncthreads();
+  double q = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double d = xi[i] - mean; q += d * d; }
+  sh[threadIdx.x] = q;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  const double sd = sqrt(sh[0] / n);
+  for (int i = threadIdx.x; i < n; i += 256) yi[i] = (float)((xi[i] - mean) / sd);
+}
+
+}  // namespace
+
+extern "C" int64_t egne_dist_maps_workspace_bytes(int B, int H, int W, int ncls) {
+  return (int64_t)B * ncls * 2 * H * W * sizeof(unsigned short) + (int64_t)B * ncls * sizeof(int) + 16;
+}
+
+extern "C" int egne_dist_maps(const int64_t* label, int B, int H, int W, int ncls, float* out, void* ws, void* stream) {
+  EGNE_REQUIRE(label && out && ws && B > 0 && B <= 65535 && H > 1 && W > 1 && H < 32768 && W < 32768 && H <= 65535 && ncls > 0 && ncls <= 16,
+               "dist_maps: bad arguments (B %d H %d W %d classes %d)", B, H, W, ncls);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* g = (unsigned short*)ws;
+  int* flags = (int*)((char*)ws + ((size_t)B * ncls * 2 * H * W * sizeof(unsigned short) + 15) / 16 * 16);
+  if (hipMemsetAsync(flags, 0, (size_t)B * ncls * sizeof(int), st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "dist_maps: memset failed");
+  hipLaunchKernelGGL(edt_columns_k, dim3((W + 255) / 256, ncls, B), dim3(256), 0, st, (const long long*)label, H, W, ncls, g, flags);
+  const double mx = sqrt((double)(H - 1) * (H - 1) + (double)(W - 1) * (W - 1));
+  const size_t lds = (size_t)2 * W * sizeof(unsigned short) + W;
+  EGNE_REQUIRE(lds <= 64 * 1024, "dist_maps: row too wide for LDS");
+  hipLaunchKernelGGL(edt_rows_k, dim3(H, ncls, B), dim3(256), lds, st, (const long long*)label, H, W, ncls, g, flags, mx, out);
+  return egne::check_launch("egne_dist_maps");
+}
+
+extern "C" int egne_zscore(const float* x, float* y, int B, int n, void* stream) {
+  EGNE_REQUIRE(x && y && B > 0 && n > 1, "zscore: bad arguments");
+  hipLaunchKernelGGL(zscore_k, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return egne::check_launch("egne_zscore");
+}

@@ -376,6 +376,15 @@ int egne_ellipse_fit(const int64_t* mask, const int32_t* frame_of, const int32_t
                      int H, int W, const float* xs, const float* ys, const double* init, double* out,
                      int32_t* evals, void* stream);
 
+/* Device-side batch preparation (the reference does this per sample on the host in its Dataset).
+ * egne_dist_maps: out[b][c] = helperfunctions.one_hot2dist(label[b] == c) (helperfunctions.py:356-371, called from
+ *   CurriculumLib.py:131-136): signed exact Euclidean distance transform normalised by the image diagonal, 0 for an absent
+ *   class; label int64 [B,H,W], out float32 [B,ncls,H,W] (the float32 cast of the reference's float64 result, bit-identical).
+ * egne_zscore: (img - img.mean()) / img.std() per image (CurriculumLib.py:139), statistics in double. */
+int64_t egne_dist_maps_workspace_bytes(int B, int H, int W, int ncls);
+int egne_dist_maps(const int64_t* label, int B, int H, int W, int ncls, float* out, void* ws, void* stream);
+int egne_zscore(const float* x, float* y, int B, int n, void* stream);
+
 const char* egne_last_error(void);
 int egne_version(void);
 int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc */

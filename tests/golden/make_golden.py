@@ -198,6 +198,38 @@ def gold_esf_adain_train(bd):
     esf_case("esf_adain_edge_detach_b2", "baseline_adain_edge", "v2", b, edge, False, overrides={"seg_detach": 1})
 
 
+def prep_labels():
+    """Label maps for the data-prep fixture: synthetic eyes (one with the mask absent = all background), a frame filled by
+    one class, random blobs with thin structures, a single-pixel class."""
+    b = synth.make_batch(3, seed=2024, mask_absent_every=3)
+    lab = [b["label"].numpy()[i].astype(np.int64) for i in range(3)]
+    lab[2] = np.zeros_like(lab[2])                      # mask absent: classes 1 and 2 missing, class 0 everywhere
+    rng = np.random.RandomState(7)
+    blobs = (rng.rand(240, 320) > 0.97).astype(np.int64)
+    blobs[100:103, :] = 2
+    blobs[:, 17] = 1
+    lab.append(blobs)
+    one = np.ones((240, 320), np.int64)
+    one[5, 300] = 2
+    lab.append(one)
+    return np.stack(lab)
+
+
+def gold_prep():
+    """helperfunctions.one_hot2dist (called per class from CurriculumLib.py:131-136) and the z-score of :139."""
+    hf = REF["hf"]
+    lab = prep_labels()
+    dist = np.zeros((lab.shape[0], 3) + lab.shape[1:], np.float64)
+    for i in range(lab.shape[0]):
+        for c in range(3):
+            dist[i, c] = hf.one_hot2dist(lab[i].astype(np.uint8) == c)
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, size=(3, 240, 320)).astype(np.uint8)
+    img[1] = (img[1] // 4 + 20).astype(np.uint8)
+    z = np.stack([(im - im.mean()) / im.std() for im in img])        # CurriculumLib.py:139 verbatim expression on uint8 frames
+    save("dataprep", label=lab.astype(np.uint8), dist=dist.astype(np.float32), img=img, z=z.astype(np.float32))
+
+
 def gold_losses():
     L = REF["loss"]
     g = torch.Generator().manual_seed(5)
@@ -354,7 +386,7 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "adain", "loss", "fit", "metrics", "keys", "evaluate"]
+    what = sys.argv[1:] or ["bdcn", "esf", "adain", "prep", "loss", "fit", "metrics", "keys", "evaluate"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
@@ -362,6 +394,8 @@ if __name__ == "__main__":
         gold_esf(bd or ref_bdcn())
     if "adain" in what:
         gold_esf_adain_train(bd or ref_bdcn())
+    if "prep" in what:
+        gold_prep()
     if "loss" in what:
         gold_losses()
     if "fit" in what:

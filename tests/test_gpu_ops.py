@@ -463,3 +463,28 @@ def test_first_layer_streaming_split(G, Cin, Cout, B, H, W, post):
     err = (got - truth).abs().max().item() / truth.abs().max().item()
     print("first-layer streaming err %.2e" % err)
     assert err < 2e-6
+
+
+def test_dataprep_dist_maps_bit_exact_and_zscore(G):
+    """Device-side batch preparation (dataprep.hip) against the fixture produced by the reference's own
+    helperfunctions.one_hot2dist: the exact EDT must agree bit for bit (classes absent, a class filling the frame, thin
+    structures, a single-pixel class); z-score within one float32 ulp."""
+    from common import gold
+    from egne_amd import dataprep
+    g = gold("dataprep")
+    lab = torch.from_numpy(g["label"].astype(np.int64)).cuda()
+    got = dataprep.dist_maps(lab).cpu().numpy()
+    assert np.array_equal(got, g["dist"]), "dist maps differ in %d values" % (got != g["dist"]).sum()
+    z = dataprep.zscore(torch.from_numpy(g["img"].astype(np.float32)).cuda()).cpu().numpy()
+    np.testing.assert_allclose(z, g["z"], rtol=2e-7, atol=1e-7)
+    # throughput at the bench batch (printed, not asserted)
+    big = lab[:1].repeat(64, 1, 1)
+    dataprep.dist_maps(big)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dataprep.dist_maps(big)
+    e1.record()
+    torch.cuda.synchronize()
+    print("dist_maps: %.0f frames/s" % (64 * 5 / (e0.elapsed_time(e1) * 1e-3)))

@@ -172,3 +172,13 @@ def test_ellipse_transform():
     Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
     for p, ref in zip(g["params"], g["out"]):
         np.testing.assert_allclose(ofit.transform(p, Hm), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_dataprep_dist_maps_and_zscore():
+    """Batch preparation: oracle vs the reference's one_hot2dist / z-score fixture, bit for bit."""
+    from oracle import dataprep as oprep
+    g = gold("dataprep")
+    got = oprep.dist_maps(g["label"].astype(np.int64))
+    assert np.array_equal(got, g["dist"])
+    assert (g["dist"][2, 1:] == 0).all() and (g["dist"][2, 0] < 0).any()        # absent classes: zeros; full-frame class: scipy's quirk
+    np.testing.assert_array_equal(oprep.zscore(g["img"]), g["z"])
