@@ -46,6 +46,8 @@ def build_parser():
     a('--visual_dir', type=str, default='iris')
     a('--method', type=str, default='baseline')
     a('--synthetic', type=int, default=0, help='N>0: run on N synthetic TEyeD-shaped frames (no dataset / checkpoint needed)')
+    a('--device_prep', type=int, default=0, help='1: compute the distance maps from the labels on the GPU (egne_amd.dataprep) '
+                                                 'instead of taking them from the Dataset (CurriculumLib.py:131-136)')
     return p
 
 

@@ -32,6 +32,15 @@ def test_train_py_synthetic_loss_decreases(tmp_path, monkeypatch):
     assert not any("dsIdentify" in k for k in ck["state_dict"])
 
 
+def test_train_py_device_prep(tmp_path, monkeypatch):
+    """--device_prep 1: distance maps from egne_amd.dataprep inside the training loop."""
+    monkeypatch.chdir(tmp_path)
+    from egne_amd import train as TR
+    TR.main(["--synthetic", "4", "--batchsize", "2", "--epochs", "1", "--setting", "configs/baseline_edge.yaml",
+             "--device_prep", "1", "--expname", "p"])
+    assert os.path.exists(os.path.join("logs", "ritnet_v2", "p", "weights", "ritnet_v2_0.pkl"))
+
+
 def test_evaluate_py_synthetic():
     from egne_amd import evaluate as E
     pup, iri = E.main(["--synthetic", "2"])
