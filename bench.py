@@ -234,6 +234,12 @@ def main():
         pl_[0] += e0.elapsed_time(e1) * 1e-3 / a.steps
     FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad")
     conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in FP32_FAM) for i in range(3)]
+    # the split-f16 family is reported as a whole and per kernel (kind "conv_f16x3:<kernel>")
+    sub = {k.split(":")[1]: v for k, v in fam.items() if k.startswith("conv_f16x3:")}
+    for k in [k for k in fam if k.startswith("conv_f16x3:")]:
+        v = fam.pop(k)
+        d = fam.setdefault("conv_f16x3", [0.0, 0.0, 0])
+        d[0] += v[0]; d[1] += v[1]; d[2] += v[2]
     sp_t, sp_f, sp_n = fam.get("conv_f16x3", [0.0, 0.0, 0])
     if a.layers and rank == 0:
         for lname, (sec, fl, kind) in per_layer.items():
@@ -280,7 +286,12 @@ def main():
                    "unit": "TFLOP/s (algorithmic, fp32-equivalent; peak = 2500 dense f16 MFMA / 3 MFMAs per product)",
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": None,
                    "launches_per_step": sp_n // max(a.steps, 1), "avg_launch_ms": round(1e3 * sp_t / max(sp_n, 1), 4),
-                   "algorithmic_gflop_per_frame": round(sp_f / a.steps / B / 1e9, 2), "time_share": round(sp_t / tot_t, 4)}
+                   "algorithmic_gflop_per_frame": round(sp_f / a.steps / B / 1e9, 2), "time_share": round(sp_t / tot_t, 4),
+                   # per kernel: big = conv_f16x3_big_kernel (MFMA-issue bound), halo / lattice = conv3x3_halo_f16_kernel (narrow
+                   # full-resolution layers and the lattice launches are HBM-bound), flat = conv_f16x3_kernel, stream1x1 /
+                   # gemm1x1 = the 1x1 kernels (HBM-bound), first = conv3x3_c4_f16_kernel (HBM write stream)
+                   "by_kernel": {k: {"tflops": round(v[1] / v[0] / 1e12, 1) if v[0] > 0 else 0.0, "time_share": round(v[0] / tot_t, 4),
+                                     "launches_per_step": v[2] // max(a.steps, 1)} for k, v in sorted(sub.items())}}
         # HBM traffic per launch from the committed PMC run (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE);
         # inference plans only -- bench.py cannot run the PMC passes itself
         try:

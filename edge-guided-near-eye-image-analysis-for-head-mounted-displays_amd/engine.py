@@ -564,19 +564,19 @@ class Plan:
             d2.Ktot, d2.CoutP = pad32(layer.Ktot), layer.split_coutp()
             self.keep.append(d2)
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
-                      flops=flops * b1 / B, kind="conv_f16x3")
+                      flops=flops * b1 / B, kind="conv_f16x3:big")
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d2), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE, layer.w_scale),
-                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3")
+                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat")
         elif big:
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
-                      flops=flops, kind="conv_f16x3")
+                      flops=flops, kind="conv_f16x3:big")
         elif ms1x1:
             d.Ktot, d.CoutP = layer.m1_ktot, layer.m1_coutp
             self._add(self.L.egne_conv1x1_ms_f16x3_fwd, (C.byref(d), layer.m1hi.data_ptr(), layer.m1lo.data_ptr(), F16X3_ASCALE,
-                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3")
+                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3:gemm1x1")
         elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
-                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3")
+                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1")
         elif lattice:
             perf = 9 * layer.sfrag_coutp() * pad32(layer.Ktot)
             for g in range(3):
@@ -590,17 +590,17 @@ class Plan:
                 self.keep.append(dg)
                 self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(dg), layer.fhi.data_ptr() + 2 * g * perf,
                                                              layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
-                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3")
+                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice")
         elif shalo:
             self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
-                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3")
+                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:halo")
         elif split:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
-                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3")
+                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3:flat")
         elif smallcin and c4h:
             d.CoutP = layer.c4_coutp
             self._add(self.L.egne_conv3x3_smallcin_f16_fwd, (C.byref(d), layer.c4hi.data_ptr(), layer.c4lo.data_ptr(), F16X3_ASCALE,
-                                                             layer.w_scale_c4), name, flops=flops, kind="conv_f16x3")
+                                                             layer.w_scale_c4), name, flops=flops, kind="conv_f16x3:first")
         elif smallcin:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif halo:
@@ -732,7 +732,7 @@ class Plan:
                     _lib.check(rc, name)
             return
         for (fn, args, name), (kind, flops) in zip(self.calls, self.meta):
-            if EVENT_KINDS is not None and kind not in EVENT_KINDS:      # untimed launch (each event pair costs ~2 us of GPU time)
+            if EVENT_KINDS is not None and kind.split(":")[0] not in EVENT_KINDS:      # untimed launch (each event pair costs ~2 us of GPU time)
                 rc = fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, name)

@@ -276,7 +276,7 @@ def test_conv_f16x3_split_precision(G, B, Cin, Cout, H, W, d):
     layer.split = True
     out = pl.buf(B, H, W, Cout)
     pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
-    assert pl.meta[-1][0] == "conv_f16x3"
+    assert pl.meta[-1][0].startswith("conv_f16x3")
     if B * H * W >= 256 * 128 and Cout >= 256:      # the last two cases run the deep 256-wide kernel (ragged M, 128- and 256-wide N tiles)
         assert pl.calls[-1][0] is pl.L.egne_conv2d_f16x3_big_fwd
     pl.run()
@@ -306,7 +306,7 @@ def test_conv_f16x3_grouped_msblock(G):
     layer.split = True
     out = pl.buf(B, H, W, 32)
     pl.conv(layer, [px], Piece(out, 0, 32), B, H, W, residual=px)
-    assert pl.meta[-1][0] == "conv_f16x3"
+    assert pl.meta[-1][0].startswith("conv_f16x3")
     pl.run()
     torch.cuda.synchronize()
     got = out.cpu().permute(0, 3, 1, 2).double()
