@@ -16,38 +16,53 @@ def parse_precision(prec):
     return torch.float32
 
 
+# (flag, type, default, help).  Names and defaults are the drop-in surface (reference args.py:30-65); the table form, the
+# grouping and the help texts are this repo's.
+_TRAINING = (
+    ("lr", float, 5e-4, "Adam step size (train.py)"),
+    ("epochs", int, 40, "upper bound on training epochs"),
+    ("batchsize", int, 12, "frames per optimiser step and per rank"),
+    ("workers", int, 0, "DataLoader worker processes"),
+    ("overfit", int, 0, "N > 0: stop every epoch after N batches"),
+    ("resume", int, 0, "1: continue from --loadfile"),
+    ("selfCorr", int, 0, "self-consistency loss term (off in the reference pipeline; not built here)"),
+    ("disentangle", int, 1, "dataset-identity confusion loss on the latent"),
+)
+_MODEL = (
+    ("model", str, "ritnet_v2", "key into modelSummary.model_dict"),
+    ("setting", str, "error", "path of the yaml with the 10 model switches (configs/*.yaml)"),
+    ("prec", int, 32, "16 | 32 | 64 (64 maps to float32, as in the reference)"),
+    ("edge_thres", int, 0, "1: binarise the edge map at 0.1 before it enters the network"),
+    ("loadfile", str, "./weights/all.git_ok", "checkpoint to load"),
+)
+_DATA = (
+    ("curObj", str, None, "name of the pickled curriculum object (cond_<name>.pkl)"),
+    ("path2data", str, "/media/rakshit/Monster", "dataset root"),
+    ("test_mode", str, "leaveoneout", "evaluation split strategy"),
+    ("synthetic", int, 0, "N > 0: run on N synthetic TEyeD-shaped frames (no dataset / checkpoint needed)"),
+    ("device_prep", int, 0, "1: distance maps computed from the labels on the GPU (egne_amd.dataprep) instead of taken "
+                            "from the Dataset (CurriculumLib.py:131-136)"),
+)
+_OUTPUT = (
+    ("expname", str, "dev", "sub-directory of logs/<model>/"),
+    ("disp", int, 0, "1: show intermediate outputs"),
+    ("test_save_op_masks", int, 0, "1: write predicted masks"),
+    ("record_iou", int, 0, None),
+    ("record_img", int, 0, None),
+    ("iou_filename", str, "test.pkl", None),
+    ("visual_dir", str, "iris", None),
+    ("method", str, "baseline", None),
+    ("test_normal", int, 0, None),
+    ("id", int, 0, None),
+)
+
+
 def build_parser():
-    p = argparse.ArgumentParser()
-    a = p.add_argument
-    a('--lr', type=float, default=5e-4, help='learning rate')
-    a('--prec', type=int, default=32, help='precision. 16, 32, 64')
-    a('--disp', type=int, default=0, help='display intermediate ouput')
-    a('--model', type=str, default='ritnet_v2', help='select model')
-    a('--curObj', type=str, default=None, help='select curriculum to train on')
-    a('--epochs', type=int, default=40, help='total number of epochs')
-    a('--resume', type=int, default=0, help='resume?')
-    a('--workers', type=int, default=0, help='number of workers')
-    a('--overfit', type=int, default=0, help='overfit to N batches?')
-    a('--expname', type=str, default='dev', help='experiment number')
-    a('--selfCorr', type=int, default=0, help='self regulation?')
-    a('--loadfile', type=str, default='./weights/all.git_ok', help='load experiment')
-    a('--path2data', type=str, default='/media/rakshit/Monster', help='path to dataset')
-    a('--batchsize', type=int, default=12, help='select a batchsize')
-    a('--test_mode', type=str, default='leaveoneout', help='testing strategy?')
-    a('--disentangle', type=int, default=1, help='Explicit dataset bias removal?')
-    a('--test_save_op_masks', type=int, default=0, help='save predicted output masks')
-    a('--setting', type=str, default='error', help='where is setting ?')
-    a('--id', type=int, default=0)
-    a('--edge_thres', type=int, default=0, help='edge thres?')
-    a('--test_normal', type=int, default=0)
-    a('--record_iou', type=int, default=0)
-    a('--record_img', type=int, default=0)
-    a('--iou_filename', type=str, default='test.pkl')
-    a('--visual_dir', type=str, default='iris')
-    a('--method', type=str, default='baseline')
-    a('--synthetic', type=int, default=0, help='N>0: run on N synthetic TEyeD-shaped frames (no dataset / checkpoint needed)')
-    a('--device_prep', type=int, default=0, help='1: compute the distance maps from the labels on the GPU (egne_amd.dataprep) '
-                                                 'instead of taking them from the Dataset (CurriculumLib.py:131-136)')
+    p = argparse.ArgumentParser(description="entry scripts of the MI355X hot path (test.py / train.py / evaluate.py)")
+    for title, table in (("training", _TRAINING), ("model", _MODEL), ("data", _DATA), ("output", _OUTPUT)):
+        grp = p.add_argument_group(title)
+        for name, typ, default, text in table:
+            grp.add_argument("--" + name, type=typ, default=default, help=text)
     return p
 
 
