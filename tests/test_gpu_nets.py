@@ -230,6 +230,25 @@ def test_esf_width_generalisation_vs_oracle(edge_of, chz, cfg):
     assert worst < 1e-2, "gradient norms differ by %.2e" % worst
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 96, 128), (2, 160, 224), (1, 330, 250)])
+def test_bdcn_other_resolutions_vs_oracle(B, H, W):
+    """The kernel selection (halo / lattice / transposed tiles / deep trunk tiles) keys on the map size and 240x320 is what
+    the fixtures pin; ESF-Net itself is tied to 240x320 by its regression head (Linear 480), the edge extractor is not:
+    other sizes are checked against the CPU oracle."""
+    from common import bdcn_module
+    from oracle import bdcn as obdcn
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 1, H, W, generator=g)
+    bd = bdcn_module()
+    ref = obdcn.calc_edge({k: v for k, v in bd.state_dict().items()}, x)
+    bd = bd.to(DEV)
+    with torch.no_grad():
+        got = bd.forward_fuse(torch.cat((x,) * 3, 1).to(DEV))
+    err = (got.cpu() - ref).abs().max().item()
+    print("bdcn %dx%dx%d err %.2e" % (B, H, W, err))
+    assert err < TOL
+
+
 def test_weights_repack_after_update(edge_of):
     """load_state_dict / in-place updates must reach the packed copies (checkpoint round trip)."""
     from common import batch_args, esf_module
