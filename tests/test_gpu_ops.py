@@ -488,3 +488,27 @@ def test_dataprep_dist_maps_bit_exact_and_zscore(G):
     e1.record()
     torch.cuda.synchronize()
     print("dist_maps: %.0f frames/s" % (64 * 5 / (e0.elapsed_time(e1) * 1e-3)))
+
+
+def test_deep_trunk_kernel_with_frame_tail(G):
+    """conv4-like layer at a batch where the 256x256 launch is cut to whole rounds of workgroups and the remaining frames go to
+    the 128x128 kernel (engine.BIG_SPLIT_TAIL): both launches together must equal the convolution of the whole batch
+    (reference here: torch's own fp32 convolution on the GPU, the split kernels' error bound is 2e-6 of the output scale)."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    B, Cin, Cout, H, W = 40, 256, 512, 30, 40
+    x = F.relu(_rand(G, B, Cin, H, W))
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, Cin)], pad=(1, 1), act=1)
+    layer.split = True
+    out = pl.buf(B, H, W, Cout)
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+    assert [c[0] for c in pl.calls] == [pl.L.egne_conv2d_f16x3_big_fwd, pl.L.egne_conv2d_f16x3_fwd], "expected the big + tail launches"
+    pl.run()
+    ref = F.relu(F.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), padding=1))
+    torch.cuda.synchronize()
+    err = (out.permute(0, 3, 1, 2) - ref).abs().max().item() / ref.abs().max().item()
+    print("big + tail err vs torch fp32 %.2e" % err)
+    assert err < 1e-5
