@@ -75,6 +75,7 @@ SIGNATURES = {
     "egne_conv2d_f16x3_big_fwd": (i32, [C.POINTER(ConvDesc), vp, f32, f32, vp]),
     "egne_pack_conv_weight_f16img": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "egne_pack_conv1x1_weight_f16": (i32, [vp, i32, i32, vp, i32, i32, f32, vp, vp, vp]),
+    "egne_absmax": (i32, [vp, i64, i32, i32, i64, vp, vp]),
     "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "egne_norm_stats": (i32, [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "egne_affine_inplace": (i32, [vp, i64, i32, i32, i64, vp, vp, vp]),
@@ -114,7 +115,8 @@ SIGNATURES = {
     "egne_conv2d_wgrad_workspace_bytes": (i64, [C.POINTER(ConvDesc)]),
     "egne_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, i64, i32, i32, i32, vp, C.POINTER(vp), vp, vp]),
     "egne_pack_conv_weight_dgrad": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
-    "egne_ellipse_fit": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "egne_ellipse_fit": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "egne_ellipse_init_from_pred": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "egne_last_error": (C.c_char_p, []),
     "egne_version": (i32, []),
     "egne_sizeof": (i32, [i32]),

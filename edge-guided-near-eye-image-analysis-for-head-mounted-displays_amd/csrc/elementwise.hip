@@ -7,6 +7,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// max |x| over a channel slice, as the bit pattern of the float (non-negative floats order like unsigned integers; a NaN
+// anywhere yields a pattern above +inf).  Calibration of the split-f16 pre-scale: the caller zeroes out_bits first.
+__global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, long long pix_stride, int ch_off, int Cp,
+                                                long long npix, unsigned* __restrict__ out_bits) {
+  const int nv = Cp >> 2;
+  const long long total = npix * nv;
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / nv;
+    const int c = (int)(i - p * nv) * 4;
+    const f32x4 v = *(const f32x4*)(x + p * pix_stride + ch_off + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu;
+      m = b > m ? b : m;
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm / BatchNorm statistics: two deterministic stages, fp64 accumulation.
 //   stage 1: grid (nchunk, ceil(Cp/32), Bn); block = 8 channel-vectors x 32 pixel rows
@@ -252,6 +276,15 @@ static int norm_nchunk(int Bn, long long npix, int Cp) {
   long long maxchunk = npix / 64 > 0 ? npix / 64 : 1;
   long long n = want < maxchunk ? want : maxchunk;
   return (int)(n > 256 ? 256 : n);
+}
+
+extern "C" int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, void* out_bits, void* stream) {
+  EGNE_REQUIRE(x && out_bits && Cp > 0 && Cp % 4 == 0 && ch_off % 4 == 0 && pix_stride % 4 == 0 && npix > 0, "absmax: bad arguments");
+  long long total = npix * (Cp >> 2), g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(absmax_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)pix_stride, ch_off, Cp,
+                     (long long)npix, (unsigned*)out_bits);
+  return egne::check_launch("egne_absmax");
 }
 
 extern "C" int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int per_sample) {

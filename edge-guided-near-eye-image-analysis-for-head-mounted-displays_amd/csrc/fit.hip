@@ -77,7 +77,7 @@ struct Shared {
   int flag, nseg;
 };
 
-__global__ __launch_bounds__(NT) void ellipse_fit_k(const long long* __restrict__ mask, const int* __restrict__ frame_of,
+__global__ __launch_bounds__(NT) void ellipse_fit_k(const long long* __restrict__ mask, int nframes, const int* __restrict__ frame_of,
                                                     const int* __restrict__ cls, int H, int W,
                                                     const float* __restrict__ xs, const float* __restrict__ ys,
                                                     const double* __restrict__ init, double* __restrict__ out,
@@ -88,7 +88,13 @@ __global__ __launch_bounds__(NT) void ellipse_fit_k(const long long* __restrict_
   const int wpr = (W + 31) >> 5, nwords = H * wpr;
   float* lxs = (float*)(bits + nwords);
   float* lys = lxs + W;
-  const long long* m = mask + (long long)frame_of[e] * H * W;
+  const int fr = frame_of[e];
+  if (fr < 0 || fr >= nframes) {   // a fit that names a frame the mask tensor does not hold: report NaN, read nothing
+    if (tid < 5) out[e * 5 + tid] = __longlong_as_double(0x7ff8000000000000ll);
+    if (tid == 0 && evals) evals[e] = 0;
+    return;
+  }
+  const long long* m = mask + (long long)fr * H * W;
   const int k = cls[e];
   unsigned cnt = 0;
   for (int w = tid; w < nwords; w += NT) {
@@ -127,9 +133,22 @@ __global__ __launch_bounds__(NT) void ellipse_fit_k(const long long* __restrict_
     }
     __syncthreads();
     const float ecx = sh.prm[0], ecy = sh.prm[1], ea = sh.prm[2], eb = sh.prm[3], ct = sh.prm[4], st = sh.prm[5];
+    // Only pixels inside the ellipse count (ne, ni), and the ellipse lies within max(a, b) of its centre: scan the
+    // bounding box (0.1 % + 2 pixels of slack, orders of magnitude above float32 round-off) instead of the frame.
+    // Degenerate parameters (NaN / huge axes) fall back to the full frame, where the map is evaluated as before.
+    int y_lo = 0, y_hi = H - 1, w_lo = 0, w_hi = wpr - 1;
+    const float rr = fmaxf(ea, eb) * 1.001f;
+    if (rr < 4.f && fabsf(ecx) < 4.f && fabsf(ecy) < 4.f) {
+      const float sx = 0.5f * (float)(W - 1), sy = 0.5f * (float)(H - 1);
+      const int xl = (int)floorf((ecx - rr + 1.f) * sx) - 2, xh = (int)ceilf((ecx + rr + 1.f) * sx) + 2;
+      const int yl = (int)floorf((ecy - rr + 1.f) * sy) - 2, yh = (int)ceilf((ecy + rr + 1.f) * sy) + 2;
+      y_lo = max(yl, 0); y_hi = min(yh, H - 1);
+      w_lo = max(xl, 0) >> 5; w_hi = min(xh, W - 1) >> 5;
+    }
+    const int bw = w_hi - w_lo + 1, nbox = (y_hi >= y_lo && bw > 0) ? (y_hi - y_lo + 1) * bw : 0;
     unsigned ne = 0, ni = 0;
-    for (int w = tid; w < nwords; w += NT) {
-      const int y = w / wpr, x0 = (w - y * wpr) << 5;
+    for (int q = tid; q < nbox; q += NT) {
+      const int yq = q / bw, y = y_lo + yq, wx = w_lo + (q - yq * bw), w = y * wpr + wx, x0 = wx << 5;
       const float dy = __fsub_rn(lys[y], ecy);
       const float dyst = __fmul_rn(dy, st), dyct = __fmul_rn(dy, ct);
       unsigned word = 0;
@@ -201,16 +220,55 @@ __global__ __launch_bounds__(NT) void ellipse_fit_k(const long long* __restrict_
   }
 }
 
+// evaluate.py:135-151: the regressed ellipses (normalised [-1,1] coordinates, float32) -> pixel ellipses that seed the
+// search: my_ellipse(p).transform(H)[0][:-1] with H = [[W/2,0,W/2],[0,H/2,H/2],[0,0,1]] (helperfunctions.py:25-33,
+// :50-63,:124-129) in float64.  Fit 2f = iris (elPred[f,0:5], class 1), fit 2f+1 = pupil (elPred[f,5:10], class 2).
+__global__ void ellipse_init_k(const float* __restrict__ elPred, int nframes, int H, int W, double* __restrict__ init,
+                               int* __restrict__ frame_of, int* __restrict__ cls) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * nframes) return;
+  const int f = e >> 1, k = e & 1;
+  double el[5];
+  for (int i = 0; i < 5; ++i) el[i] = (double)elPred[f * 10 + 5 * k + i];
+  const M3 Hr = rot(-el[4]), Ht = trans(-el[0], -el[1]);
+  M3 Q = {{{1.0 / (el[2] * el[2]), 0, 0}, {0, 1.0 / (el[3] * el[3]), 0}, {0, 0, -1.0}}};
+  const M3 mat = mul(mul(mul(mul(tr(Ht), tr(Hr)), Q), Hr), Ht);
+  const M3 Hi = {{{2.0 / W, 0, -1.0}, {0, 2.0 / H, -1.0}, {0, 0, 1.0}}};       // inverse of the un-normalising homography
+  const M3 mt = mul(mul(tr(Hi), mat), Hi);
+  const double a = mt.v[0][0], b = 2 * mt.v[0][1], c = mt.v[1][1], dd = 2 * mt.v[0][2], ee = 2 * mt.v[1][2];
+  double theta;
+  if (fabs(b) <= EPS_B && a <= c) theta = 0.0;
+  else if (fabs(b) <= EPS_B && a > c) theta = 3.141592653589793 / 2;
+  else theta = 0.5 * atan2(b, a - c);
+  const double den = b * b - 4 * a * c;
+  const double tx = (2 * c * dd - b * ee) / den, ty = (2 * a * ee - b * dd) / den;
+  const M3 R = rot(theta), T = trans(tx, ty);
+  const M3 mn = mul(mul(mul(mul(tr(R), tr(T)), mt), T), R);
+  init[e * 5 + 0] = tx; init[e * 5 + 1] = ty;
+  init[e * 5 + 2] = sqrt(1.0 / mn.v[0][0]); init[e * 5 + 3] = sqrt(1.0 / mn.v[1][1]);
+  init[e * 5 + 4] = theta;
+  frame_of[e] = f;
+  cls[e] = 1 + k;
+}
+
 }  // namespace
 
-extern "C" int egne_ellipse_fit(const int64_t* mask, const int32_t* frame_of, const int32_t* cls, int n, int H, int W,
+extern "C" int egne_ellipse_init_from_pred(const float* elPred, int nframes, int H, int W, double* init, int32_t* frame_of,
+                                           int32_t* cls, void* stream) {
+  EGNE_REQUIRE(elPred && init && frame_of && cls && nframes > 0 && H > 1 && W > 1, "ellipse_init_from_pred: bad arguments");
+  hipLaunchKernelGGL(ellipse_init_k, dim3((2 * nframes + 63) / 64), dim3(64), 0, (hipStream_t)stream, elPred, nframes, H, W, init,
+                     frame_of, cls);
+  return egne::check_launch("egne_ellipse_init_from_pred");
+}
+
+extern "C" int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t* frame_of, const int32_t* cls, int n, int H, int W,
                                 const float* xs, const float* ys, const double* init, double* out, int32_t* evals,
                                 void* stream) {
   EGNE_REQUIRE(mask && frame_of && cls && xs && ys && init && out, "ellipse_fit: null pointer");
-  EGNE_REQUIRE(n > 0 && H > 1 && W > 1, "ellipse_fit: bad shape");
+  EGNE_REQUIRE(n > 0 && nframes > 0 && H > 1 && W > 1, "ellipse_fit: bad shape");
   const size_t lds = ((size_t)H * ((W + 31) / 32) + W + H) * 4;
   EGNE_REQUIRE(lds <= 120 * 1024, "ellipse_fit: %dx%d mask does not fit LDS", H, W);
-  hipLaunchKernelGGL(ellipse_fit_k, dim3(n), dim3(NT), lds, (hipStream_t)stream, (const long long*)mask, frame_of, cls, H,
+  hipLaunchKernelGGL(ellipse_fit_k, dim3(n), dim3(NT), lds, (hipStream_t)stream, (const long long*)mask, nframes, frame_of, cls, H,
                      W, xs, ys, init, out, evals);
   return egne::check_launch("egne_ellipse_fit");
 }

@@ -34,7 +34,8 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
-F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))
+F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
+CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "60"))
@@ -144,7 +145,7 @@ class ConvLayer:
                 and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big)
                 and (self.m1hi is not None or not self.need_m1) and (self.c4hi is not None or not self.need_c4h))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
-            return
+            return False
         L = _lib.lib()
         T = self.kh * self.kw
         n = self.G * T * self.CoutP * self.Ktot
@@ -265,6 +266,7 @@ class ConvLayer:
                                                                self.w_scale, self.fhi.data_ptr() + 2 * g * perf,
                                                                self.flo.data_ptr() + 2 * g * perf, st), "pack_f16frag")
         self._versions = vers
+        return True
 
     def sfrag_coutp(self):
         """Row count of the fragment-order f16 pack: above 64 channels a multiple of 64, so that the halo kernel runs its
@@ -317,7 +319,7 @@ class DgradLayer(ConvLayer):
         vers = (w._version, w.data_ptr())
         have = (self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
         if have and vers == self._versions:
-            return
+            return False
         L = _lib.lib()
         n = self.kh * self.kw * self.CoutP * self.Ktot
         st = _lib.stream_ptr()
@@ -333,6 +335,7 @@ class DgradLayer(ConvLayer):
             _lib.check(L.egne_pack_conv_weight_dgrad(wd.data_ptr(), self.fwd.Cout, self.fwd.Cin, self.kh, self.kw, self.ci0,
                                                      self.Cout, self.CoutP, self.Ktot, 1, self.wf.data_ptr(), st), "pack_dgrad")
         self._versions = vers
+        return True
 
 
 class TransposedLayer(ConvLayer):
@@ -386,6 +389,8 @@ class Plan:
         self.layers = []    # ConvLayers to (re)pack before running
         self.pre = []       # python callables run before the launches (BN folding etc.)
         self.meta = []      # per call: (kernel family, algorithmic FLOPs) for bench.py's roofline
+        self.cal = {}       # call index -> (index of the a_scale argument, raw input Pieces, pixels): split-f16 pre-scale calibration
+        self.calibrated = False
         self.L = _lib.lib()
 
     # ---- memory ------------------------------------------------------------------------------
@@ -426,7 +431,9 @@ class Plan:
             torch._foreach_zero_(ts)
 
     # ---- launches ----------------------------------------------------------------------------
-    def _add(self, fn, args, name, flops=0.0, kind=None):
+    def _add(self, fn, args, name, flops=0.0, kind=None, cal=None):
+        if cal is not None and CALIBRATE:
+            self.cal[len(self.calls)] = cal
         self.calls.append((fn, args, name))
         self.meta.append((kind or name.split(".")[0], flops))
 
@@ -551,6 +558,11 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw * layer.G
+        # split-f16 kernels multiply their input by a power of two before the f16 split; for RAW inputs (no normalisation
+        # fused on load) that factor comes from the measured max |x| of the slices (calibration pass of Plan.run)
+        raw = all(pc.scale is None for pc in pieces)
+        cal3 = (3, list(pieces), B * H * W) if raw else None
+        cal2 = (2, list(pieces), B * H * W) if raw else None
         if big and big_tail:
             # two launches over disjoint frame ranges: [0, B - tail) on the 256-wide kernel, the rest on the 128x128 kernel
             layer.ensure_packed(self.device)
@@ -564,19 +576,19 @@ class Plan:
             d2.Ktot, d2.CoutP = pad32(layer.Ktot), layer.split_coutp()
             self.keep.append(d2)
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
-                      flops=flops * b1 / B, kind="conv_f16x3:big")
+                      flops=flops * b1 / B, kind="conv_f16x3:big", cal=cal2)
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d2), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE, layer.w_scale),
-                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat")
+                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat", cal=cal3)
         elif big:
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
-                      flops=flops, kind="conv_f16x3:big")
+                      flops=flops, kind="conv_f16x3:big", cal=cal2)
         elif ms1x1:
             d.Ktot, d.CoutP = layer.m1_ktot, layer.m1_coutp
             self._add(self.L.egne_conv1x1_ms_f16x3_fwd, (C.byref(d), layer.m1hi.data_ptr(), layer.m1lo.data_ptr(), F16X3_ASCALE,
-                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3:gemm1x1")
+                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3:gemm1x1", cal=cal3)
         elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
-                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1")
+                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1", cal=cal3)
         elif lattice:
             perf = 9 * layer.sfrag_coutp() * pad32(layer.Ktot)
             for g in range(3):
@@ -590,17 +602,17 @@ class Plan:
                 self.keep.append(dg)
                 self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(dg), layer.fhi.data_ptr() + 2 * g * perf,
                                                              layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
-                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice")
+                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice", cal=cal3)
         elif shalo:
             self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
-                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:halo")
+                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:halo", cal=cal3)
         elif split:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
-                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3:flat")
+                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3:flat", cal=cal3)
         elif smallcin and c4h:
             d.CoutP = layer.c4_coutp
             self._add(self.L.egne_conv3x3_smallcin_f16_fwd, (C.byref(d), layer.c4hi.data_ptr(), layer.c4lo.data_ptr(), F16X3_ASCALE,
-                                                             layer.w_scale_c4), name, flops=flops, kind="conv_f16x3:first")
+                                                             layer.w_scale_c4), name, flops=flops, kind="conv_f16x3:first", cal=cal3)
         elif smallcin:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif halo:
@@ -720,11 +732,14 @@ class Plan:
         """Replay the launches on torch's current stream.  ``events`` (a list) receives one
         (kernel family, flops, start_event, end_event) per launch -- HIP events recorded on the
         launch stream, used by bench.py to time individual kernels inside the timed region."""
+        repacked = False
         for layer in self.layers:
-            layer.ensure_packed(self.device)
+            repacked = bool(layer.ensure_packed(self.device)) or repacked
         for f in self.pre:
             f()
         st = _lib.stream_ptr()
+        if self.cal and (repacked or not self.calibrated):
+            return self._run_calibrating(st)
         if events is None:
             for fn, args, name in self.calls:
                 rc = fn(*args, st)
@@ -744,6 +759,43 @@ class Plan:
             if rc != 0:
                 _lib.check(rc, name)
             events.append((kind, flops, e0, e1, name))
+
+
+def _a_scale_for(vmax):
+    """Power-of-two pre-scale that puts the measured max |x| in [1024, 2048): 32x of headroom below the f16 range for
+    later batches, and elements down to 2^-14 of the max still split into two NORMAL f16 halves."""
+    import math
+    if vmax == 0.0:
+        return F16X3_ASCALE
+    e = math.floor(math.log2(2048.0 / vmax))
+    return 2.0 ** max(-100, min(100, e))
+
+
+def _run_calibrating(self, st):
+    """First run of an inference plan (and the run after a weight update): every split-f16 launch that reads RAW
+    activations first has the max |x| of its input measured on the device (egne_absmax) and its a_scale argument set
+    from it.  One small sync per such launch, paid once; later runs replay the stored scales with no sync."""
+    import math
+    mx = torch.zeros(1, dtype=torch.int32, device=self.device)
+    for i, (fn, args, name) in enumerate(self.calls):
+        ent = self.cal.get(i)
+        if ent is not None:
+            ai, pieces, npix = ent
+            mx.zero_()
+            for pc in pieces:
+                _lib.check(self.L.egne_absmax(pc.ptr, pc.stride, pc.off, pc.Cp, npix, mx.data_ptr(), st), "absmax")
+            v = float(mx.view(torch.float32).item())
+            if not math.isfinite(v):
+                raise RuntimeError("non-finite activations enter %s (max |x| = %r)" % (name, v))
+            args = args[:ai] + (_a_scale_for(v),) + args[ai + 1:]
+            self.calls[i] = (fn, args, name)
+        rc = fn(*args, st)
+        if rc != 0:
+            _lib.check(rc, name)
+    self.calibrated = True
+
+
+Plan._run_calibrating = _run_calibrating
 
 
 class VersionGuard:

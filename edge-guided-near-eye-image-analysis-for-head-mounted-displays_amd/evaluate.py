@@ -21,7 +21,7 @@ from egne_amd import _entry  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from egne_amd.utils import fit_ellipses  # noqa: E402
+from egne_amd.utils import fit_ellipses_from_pred  # noqa: E402
 
 
 def parse_args(argv=None):
@@ -64,7 +64,6 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
     """evaluate.py:112-166 for a batch of frames [N,1,H,W] (the reference loops one frame at a time).
     Returns edge maps [N,H,W], class maps [N,H,W], pupil ellipses [N,5], iris ellipses [N,5] (pixels)."""
     from egne_amd.utils import calc_edge
-    from egne_amd import ellipse
     assert frames.dim() == 4, 'Frame must be [N,1,H,W]'
     dev = frames.device
     N, _, H, W = frames.shape
@@ -77,15 +76,10 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
         z = lambda *s: torch.zeros(s, device=dev)              # noqa: E731
         out = model(frames, edge, labels.long(), z(N, 2), z(N, 2, 5), z(N, H, W), z(N, 3, H, W), z(N, 4),
                     torch.zeros(N, dtype=torch.long, device=dev), 0)
-        elPred = out[1].cpu().numpy()
+        fit = fit_ellipses_from_pred(model.predictions(), out[1])     # [N,2,5] on the device: (iris, pupil)
         mask = model.predictions()
-    Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
-    init, frame_of, cls = [], [], []
-    for i in range(N):
-        init.append(ellipse.transform(elPred[i, 0:5].astype(np.float64), Hm)); frame_of.append(i); cls.append(1)   # iris
-        init.append(ellipse.transform(elPred[i, 5:10].astype(np.float64), Hm)); frame_of.append(i); cls.append(2)  # pupil
-    fit = fit_ellipses(mask, frame_of, cls, np.stack(init))
-    return edge[:, 0].cpu().numpy(), mask.cpu().numpy(), fit[1::2], fit[0::2]
+    fit = fit.cpu().numpy()
+    return edge[:, 0].cpu().numpy(), mask.cpu().numpy(), fit[:, 1], fit[:, 0]
 
 
 def rescale_to_original(seg_map, pupil_ellipse, iris_ellipse, scale_shift, orig_shape):
@@ -151,11 +145,12 @@ def main(argv=None):
     args = parse_args(argv)
     device = torch.device('cuda')
     setting = _entry.load_setting(args.setting)
-    if args.synthetic or not os.path.exists(args.loadfile):
+    if args.synthetic:
         edge_net, model = _entry.seeded_networks(setting)
-        if not args.synthetic:
-            print('checkpoint %s not found: running with seeded random weights' % args.loadfile)
     else:
+        for need in (args.loadfile, 'gen_00000016.pt'):        # the reference dies in torch.load (evaluate.py:360-371)
+            if not os.path.exists(need):
+                sys.exit('evaluate.py: weights file %r not found (use --synthetic N for seeded random weights)' % need)
         from egne_amd.bdcn_new import BDCN
         from egne_amd.modelSummary import get_model
         edge_net = BDCN()

@@ -222,6 +222,7 @@ class DenseNet2D(nn.Module):
             raise NotImplementedError("selfCorr is disabled in the reference pipeline (--selfCorr 0, args.py:41)")
         B, _, H, W = x.shape
         pl = self._plan(B, H, W, x.device)
+        self._last_plan = pl
         pl.in_img.copy_(x)
         pl.in_edge.copy_(x_edge)
         pl.t_target.copy_(target)
@@ -242,6 +243,9 @@ class DenseNet2D(nn.Module):
         return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), loss, pl.elOut.clone()
 
     def predictions(self):
-        """Argmax mask [B,H,W] int64 of the last forward (device-side get_predictions, utils.py:65-81)."""
-        last = next(reversed(self._plans.values()))
-        return last.mask
+        """Argmax mask [B,H,W] int64 of the last forward (device-side get_predictions, utils.py:65-81).
+        A copy: the plan buffer it comes from is overwritten by the next forward of the same shape."""
+        last = getattr(self, "_last_plan", None)
+        if last is None:
+            raise RuntimeError("predictions(): no forward pass has run yet")
+        return last.mask.clone()

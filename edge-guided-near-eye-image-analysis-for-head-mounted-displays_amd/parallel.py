@@ -44,6 +44,46 @@ def broadcast_state(model, src=0):
             dist.broadcast(t.data, src=src)
 
 
+def broadcast_buffers(model, src=0):
+    """BatchNorm running statistics of rank ``src`` on every rank.  nn.DataParallel keeps replica 0's buffers
+    and drops the others'; ranks here update their own, so they are re-aligned before each validation pass
+    (and therefore before every checkpoint)."""
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in model.buffers():
+            dist.broadcast(t.data, src=src)
+
+
+def sum_over_ranks(values, device=None):
+    """Element-wise sum of a short list of python floats over all ranks (validation means)."""
+    if world_size() == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def gather_lists(values):
+    """Concatenation over ranks (rank order) of a python list of per-batch numbers; every rank gets the result."""
+    if world_size() == 1:
+        return list(values)
+    out = [None] * world_size()
+    dist.all_gather_object(out, list(values))
+    return [v for part in out for v in part]
+
+
+def samplers(train_set, valid_set, rank, world, seed=0):
+    """(train sampler, validation sampler) that give every rank a disjoint shard: one permutation per epoch shared
+    by all ranks (``set_epoch``), drop_last so that every rank sees the same number of batches.  (None, None) for
+    a single process."""
+    if world == 1:
+        return None, None
+    from torch.utils.data.distributed import DistributedSampler
+    return (DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=seed, drop_last=True),
+            DistributedSampler(valid_set, num_replicas=world, rank=rank, shuffle=False, drop_last=True))
+
+
 def grad_arena(model):
     """The flat fp32 buffer all ``p.grad`` are views of (models with ``_ensure_grad_arena``), or a freshly
     flattened copy for foreign modules."""

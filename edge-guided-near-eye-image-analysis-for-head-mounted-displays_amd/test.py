@@ -10,7 +10,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import egne_amd  # noqa: E402,F401
-from egne_amd import _entry  # noqa: E402
+from egne_amd import _entry, parallel  # noqa: E402
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -46,7 +46,12 @@ def calc_acc(args, testloader, model, edge_model, device):
         dists_pupil_latent.append(lat_p); dists_pupil_seg.append(seg_p)
         dists_iris_latent.append(lat_i); dists_iris_seg.append(seg_i)
         losses.append(loss.mean().item())
+    if parallel.world_size() > 1:     # frames shard over ranks (no data-path collective); only the per-batch metrics are gathered
+        ious, dists_pupil_latent, dists_pupil_seg, dists_iris_latent, dists_iris_seg, losses = (
+            parallel.gather_lists(v) for v in (ious, dists_pupil_latent, dists_pupil_seg, dists_iris_latent, dists_iris_seg, losses))
     ious = np.nanmean(np.stack(ious)) if ious else np.nan
+    if parallel.world_size() > 1 and torch.distributed.get_rank() != 0:
+        return ious, np.nanmedian(dists_pupil_seg), np.nanmedian(dists_iris_seg), float(np.mean(losses))
     print('mIoU: {}'.format(ious))
     print('Latent space PUPIL dist. Med: {}, STD: {}'.format(np.nanmedian(dists_pupil_latent), np.nanstd(dists_pupil_latent)))
     print('Segmentation PUPIL dist. Med: {}, STD: {}'.format(np.nanmedian(dists_pupil_seg), np.nanstd(dists_pupil_seg)))
@@ -58,7 +63,10 @@ def calc_acc(args, testloader, model, edge_model, device):
 def main(argv=None):
     args = parse_args(argv)
     setting = _entry.load_setting(args.setting)
-    device = torch.device("cuda")
+    rank, world = parallel.init()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
     if args.synthetic:
         testObj = _entry.SyntheticEyes(args.synthetic)
         edge_net, model = _entry.seeded_networks(setting, args.model)
@@ -71,7 +79,8 @@ def main(argv=None):
         edge_net.load_state_dict(torch.load('gen_00000016.pt', map_location='cpu')['a'])   # test.py:280-283
         model = get_model(args.model, setting)
         model.load_state_dict(torch.load(args.loadfile, map_location='cpu')['state_dict'], strict=False)
-    loader = DataLoader(testObj, batch_size=args.batchsize, shuffle=False, num_workers=args.workers, drop_last=True)
+    _, samp = parallel.samplers(testObj, testObj, rank, world)
+    loader = DataLoader(testObj, batch_size=args.batchsize, shuffle=False, sampler=samp, num_workers=args.workers, drop_last=True)
     edge_net, model = edge_net.to(device).eval(), model.to(device).to(args.prec)
     return calc_acc(args, loader, model, edge_net, device)
 

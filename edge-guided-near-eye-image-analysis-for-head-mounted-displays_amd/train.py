@@ -41,7 +41,9 @@ class EarlyStopping:
 
 
 def lossandaccuracy(args, loader, model, edge_model, alpha, device):
-    """utils.py:658-760 (the shipped version dies in np.stack([])): validation loss + mIoU."""
+    """utils.py:658-760 (the shipped version dies in np.stack([])): validation loss + mIoU.
+    Under torchrun every rank validates ITS shard of the loader; the means are combined over ranks so that all
+    ranks feed the same numbers to the LR scheduler / early stopping."""
     model.eval()
     losses, ious = [], []
     for bt, batch in enumerate(loader):
@@ -55,7 +57,9 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
         losses.append(out[3].mean().item())
         ious.append(getSeg_metrics(labels.numpy(), model.predictions().cpu().numpy(), cond.numpy().astype(np.float32)[:, 1])[0])
     model.train()
-    return float(np.mean(losses)) if losses else float('nan'), float(np.nanmean(ious)) if ious else float('nan')
+    ious = [v for v in ious if v == v]
+    sums = parallel.sum_over_ranks([float(np.sum(losses)), float(len(losses)), float(np.sum(ious)), float(len(ious))], device)
+    return (sums[0] / sums[1] if sums[1] else float('nan')), (sums[2] / sums[3] if sums[3] else float('nan'))
 
 
 def main(argv=None):
@@ -66,8 +70,9 @@ def main(argv=None):
     device = torch.device("cuda", local)
     torch.manual_seed(0)                                      # train.py:34-36
     setting = _entry.load_setting(args.setting)
+    startEp = 0
     if args.synthetic:
-        trainObj = _entry.SyntheticEyes(args.synthetic, seed=1234 + rank)
+        trainObj = _entry.SyntheticEyes(args.synthetic, seed=1234)   # same set on every rank; the sampler below shards it
         validObj = _entry.SyntheticEyes(max(args.batchsize, 4), seed=99)
         edge_net, model = _entry.seeded_networks(setting, args.model, bool(args.disentangle))
     else:
@@ -81,22 +86,33 @@ def main(argv=None):
         if args.disentangle:                                   # train.py:182-186
             model.disentangle = True
             model.setDatasetInfo(int(torch.unique(trainObj.imList[:, 2]).numel()))
-        if args.resume and os.path.exists(args.loadfile):
-            model.load_state_dict(torch.load(args.loadfile, map_location='cpu')['state_dict'], strict=False)
+    logdir = os.path.join('logs', args.model, args.expname)
+    if args.resume:                                            # train.py:149-160: priority 1) checkpoint.pt 2) --loadfile
+        found = [f for f in (os.path.join(logdir, 'checkpoint.pt'), args.loadfile) if f and os.path.exists(f)]
+        if not found:
+            sys.exit('--resume: neither %s nor --loadfile %r exists' % (os.path.join(logdir, 'checkpoint.pt'), args.loadfile))
+        netDict = torch.load(found[0], map_location='cpu')
+        model.load_state_dict(netDict['state_dict'], strict=False)      # the dataset-identity head is never checkpointed
+        startEp = netDict['epoch'] + 1 if 'epoch' in netDict else 0
     model.selfCorr = bool(args.selfCorr)
     edge_net, model = edge_net.to(device).eval(), model.to(device).to(args.prec).train()
     parallel.broadcast_state(model)
     params = [p for n, p in model.named_parameters() if 'dsIdentify' not in n]     # train.py:146-148
     optimizer = torch.optim.Adam(params, lr=args.lr)
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'max', patience=5, factor=0.1)   # train.py:192
-    logdir = os.path.join('logs', args.model, args.expname)
     os.makedirs(os.path.join(logdir, 'weights'), exist_ok=True)
     stopper = EarlyStopping(patience=10, delta=0.001, path=os.path.join(logdir, 'checkpoint.pt') if rank == 0 else None)
-    # each rank loads its own shard (DataParallel scatter equivalent); synthetic sets are per-rank already
-    trainloader = DataLoader(trainObj, batch_size=args.batchsize, shuffle=True, num_workers=args.workers, drop_last=True)
-    validloader = DataLoader(validObj, batch_size=args.batchsize, shuffle=False, num_workers=args.workers, drop_last=True)
-    for epoch in range(args.epochs):
+    # DataParallel scatters every batch over the GPUs (train.py:205); here every rank draws batches of --batchsize from
+    # ITS disjoint shard of one shared per-epoch permutation, so the global batch is world * batchsize
+    tsamp, vsamp = parallel.samplers(trainObj, validObj, rank, world)
+    trainloader = DataLoader(trainObj, batch_size=args.batchsize, shuffle=tsamp is None, sampler=tsamp, num_workers=args.workers,
+                             drop_last=True)
+    validloader = DataLoader(validObj, batch_size=args.batchsize, shuffle=False, sampler=vsamp, num_workers=args.workers,
+                             drop_last=True)
+    for epoch in range(startEp, args.epochs):
         alpha = epoch / args.epochs                                                 # helperfunctions.linVal, train.py:248
+        if tsamp is not None:
+            tsamp.set_epoch(epoch)
         t_edge = t_net = 0.0
         t0 = time.time()
         for bt, batch in enumerate(trainloader):
@@ -123,6 +139,7 @@ def main(argv=None):
                                                                                   parallel.mean_loss(loss.detach()).item(), t_edge, t_net))
             elif world > 1 and bt % 30 == 0:
                 parallel.mean_loss(loss.detach())
+        parallel.broadcast_buffers(model)      # validate with rank 0's BatchNorm statistics (DataParallel keeps replica 0's)
         vloss, viou = lossandaccuracy(args, validloader, model, edge_net, alpha, device)
         if rank == 0:
             print('Epoch {} done in {:.1f}s: valid loss {:.4f} mIoU {:.4f}'.format(epoch, time.time() - t0, vloss, viou))

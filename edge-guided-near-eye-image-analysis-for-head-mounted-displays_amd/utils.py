@@ -206,16 +206,54 @@ def fit_ellipses(mask, frame_of, cls, init, return_evals=False):
     dev = mask.device
     F, H, W = mask.shape
     n = len(frame_of)
-    fo = torch.as_tensor(np.asarray(frame_of, dtype=np.int32)).to(dev)
+    fo_h = np.asarray(frame_of, dtype=np.int32)
+    if n and (fo_h.min() < 0 or fo_h.max() >= F):
+        raise ValueError("fit_ellipses: frame index %d outside the %d class maps given" % (int(fo_h.max()), F))
+    fo = torch.as_tensor(fo_h).to(dev)
     cl = torch.as_tensor(np.asarray(cls, dtype=np.int32)).to(dev)
     ini = torch.as_tensor(np.asarray(init, dtype=np.float64).reshape(n, 5)).to(dev)
     out = torch.empty((n, 5), dtype=torch.float64, device=dev)
     ev = torch.zeros((n,), dtype=torch.int32, device=dev)
     xs, ys = _mesh_axes(H, W, dev)
     m = mask.contiguous()
-    _lib.check(L.egne_ellipse_fit(m.data_ptr(), fo.data_ptr(), cl.data_ptr(), n, H, W, xs.data_ptr(), ys.data_ptr(),
+    _lib.check(L.egne_ellipse_fit(m.data_ptr(), F, fo.data_ptr(), cl.data_ptr(), n, H, W, xs.data_ptr(), ys.data_ptr(),
                                   ini.data_ptr(), out.data_ptr(), ev.data_ptr(), _lib.stream_ptr()), "ellipse_fit")
     return (out.cpu().numpy(), ev.cpu().numpy()) if return_evals else out.cpu().numpy()
+
+
+def ellipse_seeds_from_pred(elPred, H, W):
+    """evaluate.py:135-151 on the device: elPred [F,10] float32 (normalised ellipses of the regression head)
+    -> (init [2F,5] float64 pixel ellipses, frame_of [2F] int32, cls [2F] int32), all on the GPU.
+    Fit 2f is the iris (class 1) of frame f, fit 2f+1 its pupil (class 2)."""
+    require_cuda(elPred, "elPred")
+    L = _lib.lib()
+    F = elPred.shape[0]
+    ep = elPred.detach().to(torch.float32).contiguous()
+    init = torch.empty((2 * F, 5), dtype=torch.float64, device=ep.device)
+    fo = torch.empty((2 * F,), dtype=torch.int32, device=ep.device)
+    cl = torch.empty((2 * F,), dtype=torch.int32, device=ep.device)
+    _lib.check(L.egne_ellipse_init_from_pred(ep.data_ptr(), F, H, W, init.data_ptr(), fo.data_ptr(), cl.data_ptr(),
+                                             _lib.stream_ptr()), "ellipse_init_from_pred")
+    return init, fo, cl
+
+
+def fit_ellipses_from_pred(mask, elPred, out=None):
+    """The fit stage of evaluate.py:135-166 with no host hop: seeds from ``elPred`` on the device, both searches of
+    every frame in one launch.  Returns a DEVICE tensor [F,2,5] float64 (iris, pupil) x (cx,cy,a,b,theta); nothing
+    here synchronises -- the caller decides when to read it."""
+    require_cuda(mask, "mask")
+    L = _lib.lib()
+    F, H, W = mask.shape
+    if elPred.shape[0] != F:
+        raise ValueError("fit_ellipses_from_pred: %d ellipse rows for %d class maps" % (elPred.shape[0], F))
+    init, fo, cl = ellipse_seeds_from_pred(elPred, H, W)
+    if out is None:
+        out = torch.empty((F, 2, 5), dtype=torch.float64, device=mask.device)
+    xs, ys = _mesh_axes(H, W, mask.device)
+    m = mask.contiguous()
+    _lib.check(L.egne_ellipse_fit(m.data_ptr(), F, fo.data_ptr(), cl.data_ptr(), 2 * F, H, W, xs.data_ptr(), ys.data_ptr(),
+                                  init.data_ptr(), out.data_ptr(), None, _lib.stream_ptr()), "ellipse_fit")
+    return out
 
 
 def search_proper_parameter_iou_for_our_data(seg, ell_para):

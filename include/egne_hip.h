@@ -169,6 +169,12 @@ int egne_conv3x3_smallcin_f16_fwd(const egne_conv_desc* d, const void* fhi, cons
 int egne_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw,
                           const int32_t* kinv, int CoutP, int Ktot, float* w_packed, void* stream);
 
+/* max |x| over the channel slice [ch_off, ch_off+Cp) of npix NHWC pixels, written as the float's bit pattern with an
+ * integer atomic max into *out_bits (zero it first; a NaN input gives a pattern above +inf).  Used once per plan to
+ * choose the power-of-two pre-scale of the split-f16 kernels (a_scale): |x| * a_scale must stay below the f16 range,
+ * which the fixed scale of round 1 did not guarantee for arbitrary checkpoints. */
+int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, void* out_bits, void* stream);
+
 /* Per-(n,c) mean / inverse std over H*W of an NHWC slice -> scale = rstd, shift = -mean*rstd
  * ([B][Cp]).  F.instance_norm at models/RITnet_v2.py:40,57 (eps 1e-5, biased variance).  With
  * per_sample=0 the statistics run over (B,H,W): training-mode BatchNorm2d of utils.py:1049 and
@@ -371,10 +377,21 @@ int egne_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int kh, 
  * xs[W] / ys[H] the float32 mesh axes exactly as torch.linspace(-1,1,.) produces them (utils.py:27-60
  * create_meshgrid; passed in because ATen's vectorised linspace is not a closed formula),
  * init [n][5] (cx,cy,a,b,theta) pixels, out [n][5] doubles, evals[n] IoU evaluation count (optional).
+ * nframes = number of class maps in `mask`; a fit whose frame_of is outside [0, nframes) reads nothing and
+ * reports NaN.  Each IoU evaluation scans the ellipse's bounding box only (pixels outside it cannot be inside
+ * the ellipse, so the counts -- and therefore the search -- are unchanged).
+ *
+ * egne_ellipse_init_from_pred: the seeds of that search straight from the network's regression output on the
+ * device (evaluate.py:135-151 does this per frame on the host): elPred [nframes][10] float32 normalised
+ * ellipses -> init [2*nframes][5] float64 pixel ellipses via my_ellipse(p).transform(H)
+ * (helperfunctions.py:124-129), fit 2f = iris / class 1 from elPred[f][0:5], fit 2f+1 = pupil / class 2 from
+ * elPred[f][5:10]; also fills frame_of / cls [2*nframes].
  */
-int egne_ellipse_fit(const int64_t* mask, const int32_t* frame_of, const int32_t* cls, int n,
+int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t* frame_of, const int32_t* cls, int n,
                      int H, int W, const float* xs, const float* ys, const double* init, double* out,
                      int32_t* evals, void* stream);
+int egne_ellipse_init_from_pred(const float* elPred, int nframes, int H, int W, double* init,
+                                int32_t* frame_of, int32_t* cls, void* stream);
 
 /* Device-side batch preparation (the reference does this per sample on the host in its Dataset).
  * egne_dist_maps: out[b][c] = helperfunctions.one_hot2dist(label[b] == c) (helperfunctions.py:356-371, called from

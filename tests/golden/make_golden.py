@@ -198,6 +198,37 @@ def gold_esf_adain_train(bd):
     esf_case("esf_adain_edge_detach_b2", "baseline_adain_edge", "v2", b, edge, False, overrides={"seg_detach": 1})
 
 
+def gold_dp(bd):
+    """DataParallel semantics of train.py:205,285 with two replicas, from the reference modules: the batch is scattered
+    (here: shard 0 = seed 1234, shard 1 = seed 4321 with one mask-absent sample), every replica runs the forward with ITS
+    OWN BatchNorm batch statistics and ITS OWN loss normalisation, the caller takes loss.mean() over replicas, so the
+    parameter gradient is the AVERAGE of the per-shard gradients.  Replica 0's BatchNorm buffers are the ones kept."""
+    setting = load_setting("baseline_edge")
+    shards = [synth.make_batch(2, seed=1234), synth.make_batch(2, seed=4321, mask_absent_every=2)]
+    grads, losses, rm = [], [], None
+    for i, b in enumerate(shards):
+        m = ref_esf(setting)            # replicas start from the same (seeded) parameters
+        with torch.no_grad():
+            edge = bd(torch.cat((b["img"],) * 3, 1))[-1]
+        m.train()
+        m.zero_grad()
+        out = quiet(m, *batch_args(b, edge))
+        (out[3].sum() / len(shards)).backward()          # loss.mean() over the replicas
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        losses.append(npy(out[3]))
+        if i == 0:
+            rm = (npy(m.enc.head.bn.running_mean), npy(m.enc.head.bn.running_var))
+    names = sorted(grads[0])
+    tot = {k: grads[0][k] + grads[1][k] for k in names}
+    arrs = dict(loss=np.stack(losses), grad_names=np.array(names),
+                grad_l2=np.array([tot[k].double().norm().item() for k in names]),
+                grad_sum=np.array([tot[k].double().sum().item() for k in names]),
+                head_rm=rm[0], head_rv=rm[1])
+    for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight", "enc.down_block1.conv21.weight"):
+        arrs["grad::" + k] = npy(tot[k])
+    save("dp_two_shards", **arrs)
+
+
 def prep_labels():
     """Label maps for the data-prep fixture: synthetic eyes (one with the mask absent = all background), a frame filled by
     one class, random blobs with thin structures, a single-pixel class."""
@@ -386,7 +417,7 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "adain", "prep", "loss", "fit", "metrics", "keys", "evaluate"]
+    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
@@ -394,6 +425,8 @@ if __name__ == "__main__":
         gold_esf(bd or ref_bdcn())
     if "adain" in what:
         gold_esf_adain_train(bd or ref_bdcn())
+    if "dp" in what:
+        gold_dp(bd or ref_bdcn())
     if "prep" in what:
         gold_prep()
     if "loss" in what:

@@ -1,0 +1,318 @@
+"""-m gpu: the plans bench.py measures (B=64 inference, B=40 for the frame-tail split, a B=32 training plan) against the
+reference fixtures.  Kernel selection keys on the batch size (deep trunk kernel, streaming / LDS 1x1 kernels, tail
+launches), so the golden B=2 batch is tiled: InstanceNorm is per sample, eval BatchNorm is folded and every loss term is
+a mean over valid samples, hence EVERY pair of frames of the big batch must reproduce the B=2 fixture.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _kinds(pl):
+    return {k for k, _ in pl.meta}
+
+
+def _names(pl):
+    return [n for _, _, n in pl.calls]
+
+
+@pytest.mark.parametrize("rep", [32, 20])
+def test_bdcn_big_batch_vs_reference(rep):
+    from common import bdcn_module, gold
+    from egne_amd import synth
+    g = gold("bdcn_b2_240x320")
+    bd = bdcn_module().to(DEV)
+    b = synth.make_batch(2, seed=1234)
+    x = torch.cat((b["img"],) * 3, 1).to(DEV).repeat(rep, 1, 1, 1)
+    got = bd.forward_fuse(x).cpu().numpy().reshape(rep, 2, 1, 240, 320)
+    err = np.abs(got - g["fuse"][None]).max()
+    assert err < TOL, "B=%d fused edge map off by %.2e" % (2 * rep, err)
+    pl = next(iter(bd._plans.values()))
+    kinds = _kinds(pl)
+    assert "conv_f16x3:big" in kinds, kinds            # the deep trunk kernel is part of this plan
+    if rep == 20:                                      # B=40: ragged last round -> frame tail on the flat kernel
+        assert any(n.endswith(".tail") for n in _names(pl)), "no .tail launch in the B=40 plan"
+    print("B=%d: edge err %.2e, kernels %s" % (2 * rep, err, sorted(kinds)))
+
+
+def test_bdcn_side_outputs_big_batch():
+    """All 11 maps at B=64 (the 10 side outputs only at the fixture's 8x8 sub-grid)."""
+    from common import bdcn_module, gold
+    from egne_amd import synth
+    g = gold("bdcn_b2_240x320")
+    bd = bdcn_module().to(DEV)
+    b = synth.make_batch(2, seed=1234)
+    outs = bd(torch.cat((b["img"],) * 3, 1).to(DEV).repeat(32, 1, 1, 1))
+    for i in range(10):
+        o = outs[i][:, :, ::8, ::8].cpu().numpy().reshape(32, 2, 1, 30, 40)
+        assert np.abs(o - g["map%d_sub" % i][None]).max() < TOL, "side output %d" % i
+
+
+def _tiled_args(b, edge, rep):
+    from common import batch_args
+    out = []
+    for a in batch_args(b, edge):
+        if torch.is_tensor(a):
+            a = a.to(DEV)
+            out.append(a.repeat(*([rep] + [1] * (a.dim() - 1))))
+        else:
+            out.append(a)
+    return out
+
+
+@pytest.mark.parametrize("name", ["esf_edge_b2", "esf_edge_b2_absent1", "esf_adain_edge_b2"])
+def test_esf_eval_b64_vs_reference(name):
+    from common import ESF_CASES, bdcn_module, esf_module, gold
+    from egne_amd import synth
+    from egne_amd.utils import calc_edge
+    cfg, variant, kw = ESF_CASES[name]
+    kw = dict(kw)
+    g = gold(name)
+    rep = 32
+    bd = bdcn_module().to(DEV)
+    b = synth.make_batch(kw.pop("B"), **kw)
+    x = b["img"].to(DEV).repeat(rep, 1, 1, 1)
+    edge = calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), x, bd, DEV)     # B=64 edge maps from the B=64 plan
+    m = esf_module(cfg, variant).to(DEV).eval()
+    args = _tiled_args(b, edge[:2], rep)
+    args[1] = edge
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut = m(*args)
+    assert tuple(op.shape) == (64, 3, 240, 320)
+    opc = op.cpu().numpy().reshape(rep, 2, 3, 240, 320)
+    ref = g["op"]
+    got = opc if ref.shape[-1] == 320 else opc[..., ::4, ::4]
+    err = np.abs(got - ref[None]).max()
+    assert err < TOL, "logits off by %.2e" % err
+    for t, k in ((elOut, "elOut"), (elPred, "elPred"), (latent, "latent")):
+        v = t.cpu().numpy()
+        np.testing.assert_allclose(v.reshape((rep, 2) + v.shape[1:]), np.broadcast_to(g[k][None], (rep,) + g[k].shape), atol=TOL)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-3)
+    mask = m.predictions().cpu().numpy().astype(np.uint8).reshape(rep, 2, 240, 320)
+    bad = 0
+    for r in range(rep):
+        bad = max(bad, np.count_nonzero(np.packbits(mask[r] == 1) != g["mask"]) + np.count_nonzero(np.packbits(mask[r] == 2) != g["mask2"]))
+    assert bad <= 2 * int(g["gap_lt_2e3"]), "mask differs in %d packed bytes (near-tie budget %d)" % (bad, int(g["gap_lt_2e3"]))
+    kinds = _kinds(m._last_plan)
+    assert any(k.startswith("conv_f16x3:") for k in kinds), kinds
+    print("%s at B=64: logits err %.2e, worst mask byte diff %d, kernels %s" % (name, err, bad, sorted(kinds)))
+
+
+@pytest.mark.parametrize("name", ["esf_edge_b2", "esf_edge_b2_absent1"])
+def test_esf_train_b32_vs_reference(name):
+    """Training plan at B=32 (bench.py's shape family) on the golden batch tiled x16: batch-statistic BatchNorm sees the
+    same mean / biased variance, every loss term is a mean over valid samples, so loss and parameter gradients equal the
+    B=2 reference values."""
+    from common import ESF_CASES, bdcn_module, esf_module, gold
+    from egne_amd import engine, synth
+    from egne_amd.utils import calc_edge
+    cfg, variant, kw = ESF_CASES[name]
+    kw = dict(kw)
+    g = gold(name)
+    rep = 16
+    b = synth.make_batch(kw.pop("B"), **kw)
+    old = engine.F16X3_ENABLED
+    engine.F16X3_ENABLED = False          # exact-fp32 edge maps: the gradient fixtures are sensitive to 1e-6 input changes
+    try:
+        bd = bdcn_module().to(DEV)
+        edge = calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), b["img"].to(DEV), bd, DEV)
+    finally:
+        engine.F16X3_ENABLED = old
+    m = esf_module(cfg, variant).to(DEV).train()
+    args = _tiled_args(b, edge, rep)
+    op, elPred, latent, loss, elOut = m(*args)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g["t_loss"], rtol=1e-3)
+    o = op.detach().cpu()[:, :, ::4, ::4].numpy().reshape(rep, 2, 3, 60, 80)
+    assert np.abs(o - g["t_op_sub"][None]).max() < TOL
+    np.testing.assert_allclose(m.enc.head.bn.running_mean.cpu().numpy(), g["t_head_rm"], rtol=1e-4, atol=1e-5)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([params[n].grad.double().norm().item() for n in names])
+    ref = g["grad_l2"]
+    rel = np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max())
+    worst = int(np.argmax(rel))
+    assert rel.max() < 1e-2, "grad L2 of %s: %.6e vs %.6e" % (names[worst], got[worst], ref[worst])
+    for k in ("dec.final.conv2.weight", "enc.head.conv1.weight", "enc.down_block1.conv21.weight"):
+        r = g["grad::" + k]
+        e = np.abs(params[k].grad.cpu().numpy() - r).max()
+        assert e <= 1.5e-2 * np.abs(r).max() + 1e-7, "%s: max err %.3e (scale %.3e)" % (k, e, np.abs(r).max())
+
+
+def test_predictions_follow_the_last_forward(capsys):
+    """Cached plans of several batch sizes: predictions() must be the mask of the forward that ran last."""
+    from common import batch_args, bdcn_module, esf_module
+    from egne_amd import synth
+    from egne_amd.utils import calc_edge
+    bd = bdcn_module().to(DEV)
+    m = esf_module("baseline_edge").to(DEV).eval()
+    ns = types.SimpleNamespace(prec=torch.float32, edge_thres=0)
+    masks = {}
+    for B in (2, 3, 2, 1, 3):
+        b = synth.make_batch(B, seed=10 + B)
+        edge = calc_edge(ns, b["img"].to(DEV), bd, DEV)
+        args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+        with torch.no_grad():
+            op = m(*args)[0]
+        pred = m.predictions()
+        assert tuple(pred.shape) == (B, 240, 320)
+        assert torch.equal(pred, op.max(1)[1])
+        held = masks.setdefault(B, pred)
+        assert torch.equal(held, pred)          # same input -> same mask, and the copy handed out earlier was not overwritten
+
+
+def test_fit_rejects_frames_it_was_not_given():
+    import ctypes as C
+    from egne_amd import _lib
+    from egne_amd.utils import _mesh_axes, fit_ellipses
+    mask = torch.zeros((2, 240, 320), dtype=torch.int64, device=DEV)
+    mask[:, 100:140, 130:190] = 1
+    init = np.array([[160.0, 120.0, 30.0, 20.0, 0.0]] * 2)
+    with pytest.raises(ValueError):
+        fit_ellipses(mask, [0, 2], [1, 1], init)
+    # straight through the C-ABI: the out-of-range fit reports NaN and reads nothing, the valid one is unaffected
+    L = _lib.lib()
+    fo = torch.tensor([0, 7], dtype=torch.int32, device=DEV)
+    cl = torch.tensor([1, 1], dtype=torch.int32, device=DEV)
+    ini = torch.from_numpy(init).to(DEV)
+    out = torch.zeros((2, 5), dtype=torch.float64, device=DEV)
+    xs, ys = _mesh_axes(240, 320, mask.device)
+    _lib.check(L.egne_ellipse_fit(mask.data_ptr(), 2, fo.data_ptr(), cl.data_ptr(), 2, 240, 320, xs.data_ptr(), ys.data_ptr(),
+                                  ini.data_ptr(), out.data_ptr(), None, _lib.stream_ptr()))
+    o = out.cpu().numpy()
+    assert np.isnan(o[1]).all() and np.array_equal(o[0], fit_ellipses(mask, [0], [1], init[:1])[0])
+
+
+def test_ellipse_seeds_on_device_vs_reference():
+    """egne_ellipse_init_from_pred against my_ellipse.transform of the reference (fixture) -- float64 conic algebra."""
+    from common import gold
+    from egne_amd.utils import ellipse_seeds_from_pred
+    g = gold("ellipse_transform")
+    prm = g["params"].astype(np.float32)                     # the regression head emits float32
+    from oracle import fit as ofit
+    Hm = np.array([[160.0, 0, 160.0], [0, 120.0, 120.0], [0, 0, 1]])
+    want = np.stack([ofit.transform(p.astype(np.float64), Hm) for p in prm])     # oracle == reference on the fixture (CPU test)
+    el = torch.from_numpy(prm.reshape(8, 10)).to(DEV)
+    init, fo, cl = ellipse_seeds_from_pred(el, 240, 320)
+    np.testing.assert_allclose(init.cpu().numpy(), want, rtol=1e-11, atol=1e-11)
+    assert fo.cpu().tolist() == [i // 2 for i in range(16)] and cl.cpu().tolist() == [1, 2] * 8
+    # and the float64 fixture itself within float32 input rounding
+    np.testing.assert_allclose(init.cpu().numpy(), g["out"], rtol=2e-5, atol=2e-5)
+
+
+def test_data_parallel_two_shards_vs_reference():
+    """DP arithmetic with real gradients on one GPU: two shards run one after the other (own BatchNorm statistics, own
+    loss normalisation), their gradient arenas combined exactly as parallel.allreduce_grads does (SUM over ranks, then
+    / world) -- against the reference run as two DataParallel replicas (fixture dp_two_shards; train.py:205,285)."""
+    from common import batch_args, bdcn_module, esf_module, gold
+    from egne_amd import engine, synth
+    from egne_amd.utils import calc_edge
+    g = gold("dp_two_shards")
+    old = engine.F16X3_ENABLED
+    engine.F16X3_ENABLED = False
+    try:
+        bd = bdcn_module().to(DEV)
+        shards = []
+        for kw in (dict(seed=1234), dict(seed=4321, mask_absent_every=2)):
+            b = synth.make_batch(2, **kw)
+            shards.append((b, calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), b["img"].to(DEV), bd, DEV)))
+    finally:
+        engine.F16X3_ENABLED = old
+    arenas, rm = [], None
+    for i, (b, edge) in enumerate(shards):
+        m = esf_module("baseline_edge").to(DEV).train()          # every rank starts from the broadcast parameters
+        args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+        loss = m(*args)[3]
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g["loss"][i], rtol=1e-3)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        arenas.append(m._ensure_grad_arena().clone())
+        if i == 0:
+            rm = m.enc.head.bn.running_mean.cpu().numpy()
+    flat = m._ensure_grad_arena()
+    flat.copy_(arenas[0] + arenas[1])        # dist.all_reduce(SUM)
+    flat.div_(2)                             # / world  (parallel.allreduce_grads.finish)
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([params[n].grad.double().norm().item() for n in names])
+    ref = g["grad_l2"]
+    rel = np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max())
+    worst = int(np.argmax(rel))
+    assert rel.max() < 1e-2, "averaged grad L2 of %s: %.6e vs %.6e" % (names[worst], got[worst], ref[worst])
+    for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight", "enc.down_block1.conv21.weight"):
+        r = g["grad::" + k]
+        e = np.abs(params[k].grad.cpu().numpy() - r).max()
+        assert e <= 1.5e-2 * np.abs(r).max() + 1e-7, "%s: max err %.3e (scale %.3e)" % (k, e, np.abs(r).max())
+    np.testing.assert_allclose(rm, g["head_rm"], rtol=1e-4, atol=1e-5)       # rank 0's running statistics are the ones kept
+
+
+@pytest.mark.parametrize("mag", [1e-4, 1.0, 3e3, 1e6])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 80), (1, 128, 256, 150, 223), (2, 32, 32, 120, 160)])
+def test_split_kernels_any_activation_magnitude(mag, shape):
+    """The split-f16 kernels pre-scale their input by a power of two chosen from its measured max (calibration pass): the
+    error against float64 stays at the fp32 level whether activations are 1e-4 or 1e6 (round 1's fixed scale of 16
+    overflowed the f16 range above 4094)."""
+    import torch.nn.functional as F
+    from gpu_util import to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(int(mag * 7) % 1000 + Cin)
+    x = F.relu(torch.randn(B, Cin, H, W, generator=g)) * 3 * mag
+    w, b = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5), torch.randn(Cout, generator=g) * mag
+    truth = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=1)
+    layer.split = True
+    out = pl.buf(B, H, W, Cout)
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+    assert pl.meta[-1][0].startswith("conv_f16x3") and pl.cal
+    for _ in range(2):          # calibrating run, then the replay with the stored scale
+        pl.run()
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 2e-6, "mag %g: relative error %.2e" % (mag, err)
+    a_scale = pl.calls[-1][1][pl.cal[len(pl.calls) - 1][0]]
+    assert 1024 <= a_scale * x.abs().max().item() < 2048, a_scale
+
+
+def test_esf_large_raw_activations_vs_oracle():
+    """A checkpoint whose activations are ~3000x those of the seeded weights (head BatchNorm gamma / beta x 3000: the raw
+    skip / dense-block tensors grow by that factor, the normalised ones do not): eval forward against the CPU oracle."""
+    from common import batch_args, bdcn_module, esf_module, setting
+    from egne_amd import synth
+    from egne_amd.utils import calc_edge
+    from oracle import esfnet as oesf
+    bd = bdcn_module().to(DEV)
+    b = synth.make_batch(2, seed=77)
+    edge = calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), b["img"].to(DEV), bd, DEV)
+    m = esf_module("baseline_edge", seed=2)
+    with torch.no_grad():
+        m.enc.head.bn.weight.mul_(3000.0)
+        m.enc.head.bn.bias.add_(0.3).mul_(3000.0)
+        ref = oesf.esf_forward(m.state_dict(), setting("baseline_edge"), *batch_args(b, edge.cpu()))
+    m = m.to(DEV).eval()
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut = m(*args)
+    assert torch.isfinite(op).all() and torch.isfinite(loss).all()
+    scale = ref[0].abs().max().item()
+    err = (op.cpu() - ref[0]).abs().max().item()
+    print("logit scale %.3g, err %.3g (relative %.2e)" % (scale, err, err / scale))
+    assert err < 1e-3 * max(1.0, scale)
+    assert (m.predictions().cpu() != ref[0].max(1)[1]).float().mean().item() < 1e-4

@@ -173,6 +173,24 @@ chk = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().res
 both = [torch.zeros_like(chk) for _ in range(2)]
 dist.all_gather(both, chk)
 assert torch.equal(both[0], both[1])
+# data sharding of train.py: disjoint shards of ONE per-epoch permutation, reshuffled by set_epoch, same length on every rank
+from egne_amd import _entry
+ds = _entry.SyntheticEyes(10, seed=1)
+ts, vs = parallel.samplers(ds, ds, rank, world)
+for ep in range(2):
+    ts.set_epoch(ep)
+    idx = torch.tensor(list(ts))
+    allidx = [torch.zeros_like(idx) for _ in range(2)]
+    dist.all_gather(allidx, idx)
+    assert len(idx) == 5 and len(set(allidx[0].tolist()) | set(allidx[1].tolist())) == 10, allidx
+    if ep == 0: first = idx.clone()
+assert not torch.equal(first, idx)
+assert sorted(list(vs)) == list(range(rank, 10, 2))
+s = parallel.sum_over_ranks([1.0 + rank, 10.0])
+assert s == [3.0, 20.0]
+m.enc.head.bn.running_mean.fill_(float(rank + 7))
+parallel.broadcast_buffers(m)
+assert m.enc.head.bn.running_mean.eq(7.0).all()
 dist.barrier(); dist.destroy_process_group()
 print('rank', rank, 'ok')
 """
@@ -214,3 +232,11 @@ def test_entry_args_and_checkpoint_format():
     ds = _entry.SyntheticEyes(2)
     s = ds[1]
     assert len(s) == 9 and tuple(s[0].shape) == (1, 240, 320) and s[7].dtype == torch.bool and tuple(s[8].shape) == (3,)
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus():
+    """bench.py --gpus N must either run N ranks or fail loudly (round 1 silently ran one rank)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in p.stdout

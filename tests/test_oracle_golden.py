@@ -122,6 +122,28 @@ def test_esf_train_mode_and_grads(name, edges):
         np.testing.assert_allclose(sd[k].grad.numpy(), ref, atol=2e-3 * np.abs(ref).max())
 
 
+def test_data_parallel_two_shards(edges):
+    """The oracle run as two data-parallel replicas (own BatchNorm statistics and loss normalisation per shard, gradients
+    averaged) against the reference run the same way (fixture dp_two_shards: train.py:205,285 semantics)."""
+    g = gold("dp_two_shards")
+    m = esf_module("baseline_edge")
+    tot = None
+    for i, kw in enumerate((dict(B=2, seed=1234), dict(B=2, seed=4321, mask_absent_every=2))):
+        b, edge = edges(**kw)
+        sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+        out = oesf.esf_forward(sd, setting("baseline_edge"), *batch_args(b, edge), training=True)
+        np.testing.assert_allclose(out[3].detach().numpy(), g["loss"][i], rtol=3e-5)
+        (out[3].sum() / 2).backward()
+        gr = {k: v.grad for k, v in sd.items() if v.grad is not None}
+        tot = gr if tot is None else {k: tot[k] + gr[k] for k in tot}
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([tot[n].double().norm().item() for n in names])
+    np.testing.assert_allclose(got, g["grad_l2"], rtol=2e-3, atol=1e-7)
+    for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight"):
+        ref = g["grad::" + k]
+        np.testing.assert_allclose(tot[k].numpy(), ref, atol=2e-3 * np.abs(ref).max())
+
+
 def test_loss_terms():
     g = gold("loss_cases")
     op, tgt = torch.from_numpy(g["op"]), torch.from_numpy(g["tgt"].astype(np.int64))
