@@ -1,0 +1,406 @@
+// A 1x1 convolution over a concatenation of raw NHWC slices FUSED with the 3x3 "same" convolution that consumes it, on
+// the split-f16 MFMA path (fp32 tensors, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; numerics:
+// conv_f16x3.hip).  models/RITnet_v2.py:59-62 (conv22(conv21(cat(x, x1))), conv32(conv31(cat(x, x1, x22)))) and :84-87
+// (conv12(conv11(cat(up, skip))), conv22(conv21(cat(up, skip, x1)))): the 1x1 result is read exactly once, by that 3x3,
+// and the pair is HBM-bound (ESF-Net block 0: 3 + 2 tensor passes for conv21/conv22).  Here the 1x1 output never leaves
+// the CU.  A workgroup is 8 waves with FIXED ROLES and two LDS halo images:
+//
+//   producers (waves 0-3)  evaluate the 1x1 on the (TH+2) x 34 halo of tile i+1 the way the streaming 1x1 kernel
+//             (conv1x1_f16.hip) walks an image: a lane's MFMA operand (8 channels of one pixel) comes straight from
+//             HBM / L2 through a per-frame BUFFER resource (out-of-image halo pixels carry the offset 0x80000000 and
+//             load zeros), 4 channel groups (8 KB per wave) per batch, the next batch in flight while the current one is
+//             converted and multiplied; the product is computed transposed, so that a lane ends up with 4 consecutive
+//             channels of its pixel: bias added, ZERO outside the image (the 3x3's zero padding pads the 1x1 OUTPUT),
+//             scaled, split into hi / lo halves and written to image (i+1)&1 (80-B pixel pitch per 32 channels);
+//   consumers (waves 4-7)  run the 9 taps of the 3x3 on tile i from image i&1 exactly as conv_halo_f16.hip does (weights
+//             through a register ring from L2), all 32-channel chunks resident, then the epilogue.
+//
+// One s_barrier per tile.  The producers' vector-memory queue holds nothing but their own loads, so a wait for one batch
+// never covers the latency of a later one, and the HBM latency of tile i+1 hides behind the matrix work of tile i.
+// Tiles are dealt so that the workgroups of one XCD work on neighbouring tiles (halo overlap served by that XCD's L2).
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int LDH = 40, TW = 32, HWd = TW + 2, MAXG = 48;
+constexpr unsigned OOB = 0x80000000u;
+
+struct GroupTab { int v[MAXG]; };      // per 16-channel group: (slice << 16) | (8-channel tail << 15) | group index inside the slice
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, float s, h8& hi, h8& lo) {
+  const f32x4 va = __builtin_bit_cast(f32x4, a), vb = __builtin_bit_cast(f32x4, b);
+  const f32x2 x[4] = {{va[0] * s, va[1] * s}, {va[2] * s, va[3] * s}, {vb[0] * s, vb[1] * s}, {vb[2] * s, vb[3] * s}};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const h2 h = __builtin_convertvector(x[q], h2);
+    const h2 l = __builtin_convertvector(x[q] - __builtin_convertvector(h, f32x2), h2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1];
+    lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// NCH: 32-channel chunks of the intermediate (1x1 output = 3x3 input); WN: 32-wide output tiles of the 3x3 (CoutP2 = 32*WN);
+// TH: tile rows (8: two per consumer wave, 4: one per wave -- what two images of a 64-channel intermediate leave room for);
+// NB: batches of 4 channel groups of the 1x1's K (ceil(groups / 4)).
+// p1: the 1x1 (slices, bias, CoutP = 32*NCH); p2: the 3x3 (bias, act, post affine, residual, output).
+// w1hi / w1lo: fragments of egne_pack_conv1x1_weight_f16; f2hi / f2lo: fragments of egne_pack_conv_weight_f16frag.
+template <int NCH, int WN, int TH, int NB>
+__global__ __launch_bounds__(512)
+void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, const GroupTab gt, const _Float16* __restrict__ w1hi,
+                          const _Float16* __restrict__ w1lo, int G1, const _Float16* __restrict__ f2hi,
+                          const _Float16* __restrict__ f2lo, float a1, float os1, float a2, float os2, int tiles_x, int tiles_y,
+                          int ntiles) {
+  constexpr int WM = TH / 4;
+  constexpr int GB = 4;                          // 16-channel groups per producer batch (8 KB of loads per wave)
+  constexpr int HHd = TH + 2, NPX = HHd * HWd, NMT = (NPX + 31) / 32;
+  constexpr int IMG = 2 * NCH * NPX * LDH;          // halfs per image: [hi | lo][NCH][NPX][LDH]
+  extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+  float* lbias = (float*)(ldsh + 2 * IMG);          // the 1x1's bias: read at every job end through LDS, so that the read is
+                                                    // not queued (vmcnt retires in order) behind the next item's prefetch
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too: descriptors and loop counters derived from it stay scalar
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = p2.H, W = p2.W;
+
+  // tile sequence of this workgroup: blocks b and b + 8 share an XCD (round-robin dispatch, a speed assumption only), so
+  // chunk c of `per` consecutive tiles goes to the blocks with b % 8 == c % 8
+  const int per = gridDim.x >> 3;
+  auto tile_at = [&](int i) { return (gridDim.x & 7) ? (int)blockIdx.x + i * (int)gridDim.x : ((i * 8 + ((int)blockIdx.x & 7)) * per + ((int)blockIdx.x >> 3)); };
+  struct Tile { int b, y0, x0; };
+  auto decode = [&](int t) {
+    Tile r;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    r.b = t; r.y0 = ty * TH; r.x0 = tx * TW;
+    return r;
+  };
+  int nmine = 0;
+  while (tile_at(nmine) < ntiles) ++nmine;          // contiguous prefix: tile_at is increasing in i
+  if (tid < 32 * NCH) lbias[tid] = p1.bias ? p1.bias[tid] : 0.f;
+  // the 1x1's weight fragments live in LDS for the whole launch ([group][tile][hi | lo][lane][8]): read through the LDS
+  // queue they never wait behind the producers' prefetched activations (vmcnt retires in order)
+  _Float16* lw = (_Float16*)(lbias + 32 * NCH);
+  for (int it = tid; it < G1 * NCH * 2 * 64; it += 512) {        // 16-byte items
+    const int l = it & 63, hl = (it >> 6) & 1, q = it >> 7;      // q = group * NCH + tile
+    *(u32x4*)&lw[(long long)it * 8] = *(const u32x4*)((hl ? w1lo : w1hi) + ((long long)q * 64 + l) * 8);
+  }
+  __syncthreads();
+
+  if (wave < 4) {
+    // =================================================================== producers: 1x1 on the halo -> LDS image
+    // Every producer wave runs a STATIC schedule of N = JOBS * NB items per tile (item = 4 channel groups of one 32-pixel
+    // block; wave w owns blocks w, w + 4, ...; a block past the halo is all out-of-range lanes: no traffic, nothing
+    // written).  Loads run DIST = 2 items ahead through a ring of 3 register buffers and wrap into the NEXT tile, so the
+    // pipeline never drains at a tile boundary; with no data-dependent control flow inside, every wait is a counted vmcnt.
+    constexpr int JOBS = (NMT + 3) / 4, N = JOBS * NB, NBUF = 3, DIST = 2;
+    static_assert(N % NBUF == 0 && N >= DIST, "buffer index of an item must not depend on the tile");
+    u32x4 xa[NBUF][GB], xb[NBUF][GB];
+    f32x16 acc[NCH];
+
+    auto pixel = [&](const Tile& tl, int job, int& hp, bool& valid, int& pix) {
+      hp = (wave + 4 * job) * 32 + li;
+      const int hy = hp / HWd, hx = hp - hy * HWd;
+      const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
+      valid = hp < NPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      pix = y * W + x;
+    };
+    // Loads are issued UNCONDITIONALLY (groups past the end and tiles past the last one carry the out-of-range offset
+    // and return zeros without touching memory): a conditionally issued load makes the compiler's vmcnt bookkeeping
+    // assume the shortest queue at every join and wait for everything.
+    auto issue = [&](const Tile& tl, bool on, auto kc) {
+      constexpr int K = decltype(kc)::value, BUF = K % NBUF, job = K / NB, bi = K % NB;
+      int hp, pix; bool valid;
+      pixel(tl, job, hp, valid, pix);
+      valid = valid && on;
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const int gg = bi * GB + u;
+        const int e = gt.v[gg < G1 ? gg : 0];
+        const egne_seg sg = p1.seg[e >> 16];
+        const __amdgpu_buffer_rsrc_t r =
+            make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
+        const int voff = (valid && gg < G1) ? (pix * (int)sg.pix_stride + sg.ch_off + 4 * lh) * 4 : (int)OOB;
+        const int lg = e & 0x7fff;
+        xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff, lg * 64, 0);                              // channels 16g + 4lh .. +3
+        xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, (e & 0x8000) ? (int)OOB : voff + 32, lg * 64, 0);   // 16g + 8 + 4lh .. +3
+      }
+    };
+    auto compute = [&](const Tile& tl, const Tile& nx, bool nx_on, _Float16* img, auto kc) {
+      constexpr int K = decltype(kc)::value, BUF = K % NBUF, job = K / NB, bi = K % NB;
+      if (bi == 0) {
+#pragma unroll
+        for (int tn = 0; tn < NCH; ++tn) acc[tn] = (f32x16)(0.f);
+      }
+      if constexpr (K + DIST < N) issue(tl, true, std::integral_constant<int, K + DIST>{});
+      else issue(nx, nx_on, std::integral_constant<int, K + DIST - N>{});
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        if (bi * GB + u < G1) {
+          h8 ah, al;
+          split8(xa[BUF][u], xb[BUF][u], a1, ah, al);
+#pragma unroll
+          for (int tn = 0; tn < NCH; ++tn) {
+            const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
+            const h8 bh = *(const h8*)wp, bl = *(const h8*)(wp + 512);
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[tn], 0, 0, 0);
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[tn], 0, 0, 0);
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[tn], 0, 0, 0);
+          }
+        }
+      }
+      if (bi == NB - 1) {
+        // transposed product: the lane holds channels n = 32*tn + 8*j + 4*lh + e (register 4*j + e) of halo pixel hp
+        _Float16* Thi = img;
+        _Float16* Tlo = img + NCH * NPX * LDH;
+        int hp, pix; bool valid;
+        pixel(tl, job, hp, valid, pix);
+        if (hp < NPX) {
+          const float vs = valid ? a2 : 0.f, vo = valid ? os1 * a2 : 0.f;
+#pragma unroll
+          for (int tn = 0; tn < NCH; ++tn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 b4 = *(const f32x4*)(lbias + tn * 32 + 8 * j + 4 * lh);
+              const f32x2 v0 = {acc[tn][4 * j] * vo + b4[0] * vs, acc[tn][4 * j + 1] * vo + b4[1] * vs};
+              const f32x2 v1 = {acc[tn][4 * j + 2] * vo + b4[2] * vs, acc[tn][4 * j + 3] * vo + b4[3] * vs};
+              const h2 h0 = __builtin_convertvector(v0, h2), h1 = __builtin_convertvector(v1, h2);
+              const h2 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2), h2);
+              const h2 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2), h2);
+              const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+              const int o = (tn * NPX + hp) * LDH + 8 * j + 4 * lh;
+              *(h4*)&Thi[o] = hi;
+              *(h4*)&Tlo[o] = lo;
+            }
+        }
+      }
+    };
+    auto produce = [&](int i) {           // tile i of this workgroup into image i & 1; prefetches the head of tile i + 1
+      const Tile tl = decode(tile_at(i));
+      const bool nx_on = i + 1 < nmine;
+      const Tile nx = decode(tile_at(nx_on ? i + 1 : i));
+      _Float16* img = ldsh + (i & 1) * IMG;
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        (compute(tl, nx, nx_on, img, std::integral_constant<int, Ks>{}), ...);
+      }(std::make_integer_sequence<int, N>{});
+    };
+
+    if (nmine > 0) {
+      const Tile t0 = decode(tile_at(0));
+      issue(t0, true, std::integral_constant<int, 0>{});
+      issue(t0, true, std::integral_constant<int, 1>{});
+      produce(0);
+    }
+    lds_barrier();
+    for (int i = 0; i < nmine; ++i) {
+      if (i + 1 < nmine) produce(i + 1);
+      lds_barrier();
+    }
+  } else {
+    // =================================================================== consumers: 9 taps from the LDS image
+    const int cw = wave - 4;
+    const unsigned frame_out = (unsigned)H * W * (unsigned)p2.out_pix_stride * 4u;
+    const unsigned frame_res = (unsigned)H * W * (unsigned)p2.res_pix_stride * 4u;
+    const float slope_out = p2.act == EGNE_ACT_RELU ? 0.f : (p2.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+    constexpr int KT16 = NCH * 2, NT2 = WN;
+    const unsigned w2bytes = 9u * (unsigned)(KT16 * 16) * (unsigned)(NT2 * 32) * 2u;
+    const __amdgpu_buffer_rsrc_t rwh = make_rsrc(f2hi, w2bytes), rwl = make_rsrc(f2lo, w2bytes);
+    constexpr int stride_k16 = NT2 * 1024, stride_tap = KT16 * NT2 * 1024;
+    const int wlane = lane * 16;
+    const int abase = (cw * WM * HWd + li) * LDH + lh * 8;
+    const int out_step = (int)p2.out_pix_stride * 4, res_step = (int)p2.res_pix_stride * 4;
+
+    lds_barrier();
+    for (int i = 0; i < nmine; ++i) {
+      const Tile tl = decode(tile_at(i));
+      const _Float16* Thi = ldsh + (i & 1) * IMG;
+      const _Float16* Tlo = Thi + NCH * NPX * LDH;
+      f32x16 acc[WM][WN];
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
+#pragma unroll 1
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int wchunk = ch * 2 * stride_k16;
+        constexpr int RT = WN == 1 ? 2 : 1;
+        u32x4 qh[2 * RT][WN], ql[2 * RT][WN];
+#pragma unroll
+        for (int s = 0; s < 2 * RT; ++s)
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn) {
+            const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
+            qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
+            ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
+          }
+        constexpr int TAP_UNROLL = (WM == 2 && WN == 2) ? 1 : 9;     // the widest shape only fits 256 registers with the tap loop rolled
+#pragma unroll TAP_UNROLL
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int aoff = abase + ch * NPX * LDH + (ky * HWd + kx) * LDH;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int slot = (tap % RT) * 2 + ks;
+            h8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+            for (int tm = 0; tm < WM; ++tm) {
+              ah[tm] = *(const h8*)&Thi[aoff + tm * HWd * LDH + ks * 16];
+              al[tm] = *(const h8*)&Tlo[aoff + tm * HWd * LDH + ks * 16];
+            }
+#pragma unroll
+            for (int tn = 0; tn < WN; ++tn) {
+              bh[tn] = __builtin_bit_cast(h8, qh[slot][tn]);
+              bl[tn] = __builtin_bit_cast(h8, ql[slot][tn]);
+            }
+            if (tap + RT < 9) {
+#pragma unroll
+              for (int tn = 0; tn < WN; ++tn) {
+                const int o = wchunk + (tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
+                qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
+                ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
+              }
+            }
+#pragma unroll
+            for (int tm = 0; tm < WM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < WN; ++tn) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+              }
+          }
+        }
+      }
+
+      // ---- epilogue: lane holds channel n of 16 pixels x = x_lane + c_r, c_r = (r&3) + 8*(r>>2), of tile row tm ----
+      {
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(p2.out + (long long)tl.b * H * W * p2.out_pix_stride, frame_out);
+        const __amdgpu_buffer_rsrc_t rres =
+            make_rsrc(p2.residual ? p2.residual + (long long)tl.b * H * W * p2.res_pix_stride : nullptr, p2.residual ? frame_res : 0u);
+        const int xl = tl.x0 + 4 * lh;
+        const int cmax = xl < W ? W - xl : 0;      // c_r < cmax  <=>  x < W
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn) {
+          const int n = tn * 32 + li;
+          const bool nok = n < p2.Cout_store;
+          const float bv = (p2.bias && nok) ? p2.bias[n] : 0.f;
+          float ps = 1.f, pt = 0.f;
+          if (p2.post_scale && nok) { ps = p2.post_scale[n]; pt = p2.post_shift[n]; }
+#pragma unroll
+          for (int tm = 0; tm < WM; ++tm) {
+            const int y = tl.y0 + cw * WM + tm;
+            const int cm = (nok && y < H) ? cmax : 0;
+            const int pix = y * W + xl;
+            const unsigned o0 = (unsigned)((pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4);
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (p2.residual) {
+              const unsigned r0 = (unsigned)((pix * (int)p2.res_pix_stride + p2.res_ch_off + n) * 4);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2);
+                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0));
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = (r & 3) + 8 * (r >> 2);
+              float v = acc[tm][tn][r] * os2 + bv;
+              v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+            }
+          }
+        }
+      }
+      lds_barrier();      // image i&1 may be overwritten, image (i+1)&1 is complete
+    }
+  }
+}
+
+template <int NCH, int WN, int TH, int NB>
+int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const GroupTab& gt, const _Float16* w1hi, const _Float16* w1lo,
+                 int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
+  const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y * d2.B;
+  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (size_t)G1 * NCH * 2048;
+  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024) == hipSuccess;
+  if (!once || lds > 160 * 1024) return egne::fail(EGNE_ERR_LAUNCH, "conv_fused_1x1_3x3: %zu bytes of LDS", lds);
+  int gx = 256;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
+                     a2, os2, tiles_x, tiles_y, ntiles);
+  return egne::check_launch("egne_conv1x1_3x3_fused_f16_fwd");
+}
+
+}  // namespace
+
+// d1: the 1x1 convolution (kh = kw = 1, stride 1, raw slices without fused affine, no activation / residual / post affine,
+//     CoutP = 32 or 64 = d2's input width rounded up to 32; its output pointer is ignored -- the result is not stored);
+// d2: the 3x3 / stride 1 / pad 1 / dilation 1 convolution on that result (CoutP 32 or 64; seg[] ignored).
+// w1*: egne_pack_conv1x1_weight_f16 fragments, f2*: egne_pack_conv_weight_f16frag fragments (Ktot = d1.CoutP).
+// a1 pre-scales the slices, a2 the 1x1 result (both powers of two; |x|*a must stay inside the f16 range).
+extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const egne_conv_desc* dp2, const void* w1hi, const void* w1lo,
+                                              float a1, float w1_scale, const void* f2hi, const void* f2lo, float a2, float w2_scale,
+                                              void* stream) {
+  EGNE_REQUIRE(dp1 && dp2 && w1hi && w1lo && f2hi && f2lo, "conv_fused_1x1_3x3: null pointer");
+  const egne_conv_desc& d1 = *dp1;
+  const egne_conv_desc& d2 = *dp2;
+  EGNE_REQUIRE(d1.kh == 1 && d1.kw == 1 && d1.stride == 1 && d1.pad_h == 0 && d1.pad_w == 0 && d1.ngroups == 1 && d1.nseg >= 1 &&
+               d1.nseg <= EGNE_MAXSEG && !d1.residual && !d1.post_scale && d1.act == EGNE_ACT_NONE && d1.CoutP == 32,
+               "conv_fused_1x1_3x3: 1x1 descriptor");
+  EGNE_REQUIRE(d2.kh == 3 && d2.kw == 3 && d2.stride == 1 && d2.pad_mode == 0 && d2.ngroups == 1 && d2.pad_h == 1 && d2.pad_w == 1 &&
+               d2.dil[0] == 1 && d2.Ho == d2.H && d2.Wo == d2.W && d2.B == d1.B && d2.H == d1.H && d2.W == d1.W && d2.Ktot == d1.CoutP &&
+               (d2.CoutP == 32 || d2.CoutP == 64), "conv_fused_1x1_3x3: 3x3 descriptor");
+  EGNE_REQUIRE(!d1.bias || ((uintptr_t)d1.bias & 15) == 0, "conv_fused_1x1_3x3: bias alignment");
+  GroupTab gt;
+  int G = 0;
+  for (int s = 0; s < d1.nseg; ++s) {
+    const egne_seg& g = d1.seg[s];
+    EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && g.Cp % 8 == 0 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
+                 ((uintptr_t)g.ptr & 15) == 0 && g.ch_off + g.Cp <= g.pix_stride && (long long)d1.H * d1.W * g.pix_stride * 4 < (1ll << 31),
+                 "conv_fused_1x1_3x3: slice %d", s);
+    const int n16 = (g.Cp + 15) / 16;
+    EGNE_REQUIRE(G + n16 <= MAXG, "conv_fused_1x1_3x3: more than %d channel groups", MAXG);
+    for (int k = 0; k < n16; ++k) gt.v[G + k] = (s << 16) | ((k == n16 - 1 && (g.Cp & 15)) ? 0x8000 : 0) | k;
+    G += n16;
+  }
+  for (int k = G; k < MAXG; ++k) gt.v[k] = 0;
+  EGNE_REQUIRE(d2.out && d2.Cout_store <= d2.CoutP && d2.out_ch_off + d2.Cout_store <= d2.out_pix_stride &&
+               (long long)d2.H * d2.W * d2.out_pix_stride * 4 < (1ll << 31) &&
+               (!d2.residual || (long long)d2.H * d2.W * d2.res_pix_stride * 4 < (1ll << 31)), "conv_fused_1x1_3x3: output");
+  EGNE_REQUIRE(((uintptr_t)w1hi & 15) == 0 && ((uintptr_t)w1lo & 15) == 0 && ((uintptr_t)f2hi & 15) == 0 && ((uintptr_t)f2lo & 15) == 0 &&
+               a1 > 0.f && a2 > 0.f && w1_scale > 0.f && w2_scale > 0.f, "conv_fused_1x1_3x3: weights / scales");
+  const float os1 = 1.0f / (a1 * w1_scale), os2 = 1.0f / (a2 * w2_scale);
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16 *a = (const _Float16*)w1hi, *b = (const _Float16*)w1lo, *c = (const _Float16*)f2hi, *e = (const _Float16*)f2lo;
+  EGNE_REQUIRE(d1.CoutP == 32 && G <= 12, "conv_fused_1x1_3x3: a 32-channel intermediate and at most 192 input channels are built (got %d, %d groups)",
+               d1.CoutP, G);
+  const int nb = (G + 3) / 4;
+#define EGNE_FUSED(WN_) \
+  (nb == 1 ? launch_fused<1, WN_, 8, 1>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+           : nb == 2 ? launch_fused<1, WN_, 8, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+                     : launch_fused<1, WN_, 8, 3>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
+  return d2.CoutP == 32 ? EGNE_FUSED(1) : EGNE_FUSED(2);
+#undef EGNE_FUSED
+}

@@ -35,6 +35,8 @@ HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
+FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
+FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
 CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
@@ -623,6 +625,71 @@ class Plan:
             self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, d, B, H, W, Ho, Wo, name))
         return Ho, Wo
 
+    def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair"):
+        """``l2(l1(cat(pieces)))``: a 1x1 convolution over raw slices followed by the 3x3 that is its only consumer
+        (RITnet_v2.py:59-62,84-87).  Inference plans run the pair as ONE launch whose intermediate stays in LDS
+        (conv_fused_1x1_3x3_f16.hip); otherwise two launches through ``tmp`` (a Piece, allocated here if None)."""
+        fused = (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split1 and l2.split and l1.kh == 1 and l1.kw == 1
+                 and l1.stride == 1 and l1.G == 1 and l1.pad == (0, 0) and l1.act == ACT_NONE and l1.post is None
+                 and all(pc.scale is None for pc in pieces) and l1.CoutP == 32 and len(pieces) <= _lib.MAXSEG
+                 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 12
+                 and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
+                 and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP in (32, 64)
+                 and W >= FUSE_1X1_MIN_W and all(H * W * pc.stride < 2 ** 29 for pc in pieces) and H * W * dst.stride < 2 ** 29)
+        if not fused:
+            if tmp is None:
+                tmp = Piece(self.buf(B, H, W, pad8(l1.Cout)), 0, l1.Cout)
+            self.conv(l1, pieces, tmp, B, H, W, name=name + ".a")
+            return self.conv(l2, [tmp], dst, B, H, W, residual=residual, name=name + ".b")
+        for p, (c, cp) in zip(pieces, l1.in_layout):
+            assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
+        l1.need_s1 = True
+        l1.need_flat = True
+        l2.need_sfrag = True
+        for l in (l1, l2):
+            if l not in self.layers:
+                self.layers.append(l)
+            l.ensure_packed(self.device)
+        d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        for d, l in ((d1, l1), (d2, l2)):
+            d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
+            d.kh, d.kw, d.stride = l.kh, l.kw, 1
+            d.pad_h, d.pad_w, d.pad_mode, d.ngroups = l.pad[0], l.pad[1], 0, 1
+            for g in range(_lib.MAXGROUP):
+                d.dil[g] = 1
+            d.bias = l.bp.data_ptr() if l.biases is not None else None
+            d.act = l.act
+        d1.nseg = len(pieces)
+        for i, p in enumerate(pieces):
+            sg = d1.seg[i]
+            sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp, sg.act_in = p.ptr, p.stride, p.off, p.Cp, ACT_NONE
+        d1.Ktot, d1.CoutP = l1.Ktot, l1.CoutP
+        d2.nseg = 0
+        d2.Ktot, d2.CoutP = l1.CoutP, l2.sfrag_coutp()
+        if l2.post is not None:
+            d2.post_scale, d2.post_shift = l2.post[0].data_ptr(), l2.post[1].data_ptr()
+        if residual is not None:
+            d2.residual, d2.res_pix_stride, d2.res_ch_off = residual.ptr, residual.stride, residual.off
+        d2.out, d2.out_pix_stride, d2.out_ch_off = dst.ptr, dst.stride, dst.off
+        d2.Cout_store = min(l2.Cout_store, dst.Cp)
+        assert tuple(dst.buf.shape[1:3]) == (H, W), (name, tuple(dst.buf.shape), H, W)
+        self.keep += [d1, d2]
+
+        def rescale(args, vmax, l1=l1):
+            # a1 from the measured max of the slices; a2 from a bound on the 1x1 result: max|in| * max_co sum_c |w| + max|b|
+            with torch.no_grad():
+                w = l1.weights[0].detach()
+                bound = vmax * float(w.abs().sum(dim=(1, 2, 3)).max())
+                if l1.biases is not None and l1.biases[0] is not None:
+                    bound += float(l1.biases[0].detach().abs().max())
+            return args[:4] + (_a_scale_for(vmax),) + args[5:8] + (_a_scale_for(bound),) + args[9:]
+        flops = 2.0 * B * H * W * (l1.Cout * l1.Cin + l2.Cout * l2.Cin * 9)
+        self._add(self.L.egne_conv1x1_3x3_fused_f16_fwd,
+                  (C.byref(d1), C.byref(d2), l1.s1hi.data_ptr(), l1.s1lo.data_ptr(), F16X3_ASCALE, l1.w_scale1,
+                   l2.fhi.data_ptr(), l2.flo.data_ptr(), F16X3_ASCALE, l2.w_scale), name, flops=flops, kind="conv_f16x3:fused1x1",
+                  cal=(rescale, list(pieces), B * H * W))
+        return H, W
+
     def _bw_conv(self, bw, layer, pieces, dst, d, B, H, W, Ho, Wo, name):
         """Backward of y = act(conv(pieces) + b): mask + bias grad, weight grad, data grads."""
         L = self.L
@@ -787,7 +854,7 @@ def _run_calibrating(self, st):
             v = float(mx.view(torch.float32).item())
             if not math.isfinite(v):
                 raise RuntimeError("non-finite activations enter %s (max |x| = %r)" % (name, v))
-            args = args[:ai] + (_a_scale_for(v),) + args[ai + 1:]
+            args = ai(args, v) if callable(ai) else args[:ai] + (_a_scale_for(v),) + args[ai + 1:]
             self.calls[i] = (fn, args, name)
         rc = fn(*args, st)
         if rc != 0:

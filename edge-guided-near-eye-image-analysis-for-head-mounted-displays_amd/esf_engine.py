@@ -197,18 +197,13 @@ def build_forward_plan(model, B, H, W, dev, training):
         sc, sh, _, _ = pl.norm_stats(d["x"], NB, h * w, name=nm + ".in_x")
         l = _cl(blk.conv1, _lay([d["x"]]), pad=(1, 1), act=ACT_LEAKY)
         pl.conv(l, [d["x"].with_norm(sc, sh)], d["x1"], NB, h, w, name=nm + ".conv1")
-        tmp = pl.buf(NB, h, w, pad8(inters[i]))
-        tp = Piece(tmp, 0, inters[i])
-        l = _cl(blk.conv21, _lay([d["x"], d["x1"]]))
-        pl.conv(l, [d["x"], d["x1"]], tp, NB, h, w, name=nm + ".conv21")
-        l = _cl(blk.conv22, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
-        pl.conv(l, [tp], d["x22"], NB, h, w, name=nm + ".conv22")
-        if training:   # backward needs both 1x1 outputs: no buffer reuse
-            tp = Piece(pl.buf(NB, h, w, pad8(inters[i])), 0, inters[i])
-        l = _cl(blk.conv31, _lay([d["x"], d["x1"], d["x22"]]))
-        pl.conv(l, [d["x"], d["x1"], d["x22"]], tp, NB, h, w, name=nm + ".conv31")
-        l = _cl(blk.conv32, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
-        pl.conv(l, [tp], d["out"], NB, h, w, name=nm + ".conv32")
+        # conv22(conv21(cat(x, x1))) and conv32(conv31(cat(x, x1, x22))): each 1x1 feeds exactly one 3x3 (RITnet_v2.py:59-62)
+        l1 = _cl(blk.conv21, _lay([d["x"], d["x1"]]))
+        l2 = _cl(blk.conv22, [(inters[i], pad8(inters[i]))], pad=(1, 1), act=ACT_LEAKY)
+        pl.conv_pair(l1, [d["x"], d["x1"]], l2, d["x22"], NB, h, w, name=nm + ".conv2")
+        l1 = _cl(blk.conv31, _lay([d["x"], d["x1"], d["x22"]]))
+        l2 = _cl(blk.conv32, [(inters[i], pad8(inters[i]))], pad=(1, 1), act=ACT_LEAKY)
+        pl.conv_pair(l1, [d["x"], d["x1"], d["x22"]], l2, d["out"], NB, h, w, name=nm + ".conv3")
         sc2, sh2, _, _ = pl.norm_stats(d["out"], NB, h * w, name=nm + ".in_out")
         tdl = _cl(blk.TD.conv, _lay([d["out"], d["x"]]))
         tin = [d["out"].with_norm(sc2, sh2, ACT_LEAKY), d["x"].with_norm(sc, sh, ACT_LEAKY)]
@@ -262,19 +257,13 @@ def build_forward_plan(model, B, H, W, dev, training):
         if variant == "concat":
             skip = skip + [D[lvl]["out"].samples(B), D[lvl]["x"].samples(B)]
         cat = up_pieces + skip
-        t = pl.buf(B, h, w, pad8(oc))
-        tp = Piece(t, 0, oc)
-        l = _cl(ub.conv11, _lay(cat))
-        pl.conv(l, cat, tp, B, h, w, name=nm + ".conv11")
-        l = _cl(ub.conv12, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
-        pl.conv(l, [tp], x1, B, h, w, name=nm + ".conv12")
-        if training:
-            tp = Piece(pl.buf(B, h, w, pad8(oc)), 0, oc)
-        l = _cl(ub.conv21, _lay(cat + [x1]))
-        pl.conv(l, cat + [x1], tp, B, h, w, name=nm + ".conv21")
+        l1 = _cl(ub.conv11, _lay(cat))
+        l2 = _cl(ub.conv12, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
+        pl.conv_pair(l1, cat, l2, x1, B, h, w, name=nm + ".conv1")
+        l1 = _cl(ub.conv21, _lay(cat + [x1]))
         y = pl.buf(B, h, w, pad8(oc))
-        l = _cl(ub.conv22, _lay([tp]), pad=(1, 1), act=ACT_LEAKY)
-        pl.conv(l, [tp], Piece(y, 0, oc), B, h, w, name=nm + ".conv22")
+        l2 = _cl(ub.conv22, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
+        pl.conv_pair(l1, cat + [x1], l2, Piece(y, 0, oc), B, h, w, name=nm + ".conv2")
         prev, ph, pw = [Piece(y, 0, oc)], h, w
         pl.dbg[nm] = prev[0]
 

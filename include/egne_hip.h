@@ -140,6 +140,17 @@ int egne_pack_conv1x1_weight_f16(const float* w_oihw, int Cout, int Cin, const i
 int egne_conv1x1_f16x3_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
                            float w_scale, void* stream);
 
+/* A 1x1 convolution over raw slices FUSED with the 3x3 / pad 1 convolution that is its only consumer
+ * (models/RITnet_v2.py:59-62 conv22(conv21(.)), conv32(conv31(.)); :84-87 conv12(conv11(.)), conv22(conv21(.))): the 1x1 is
+ * evaluated on each tile's halo and kept in LDS as hi / lo halves, the 3x3 runs from there -- its input is never stored.
+ * d1 = the 1x1 (slices as for egne_conv1x1_f16x3_fwd; CoutP 32 or 64; no activation; output fields ignored),
+ * d2 = the 3x3 (Ktot = d1->CoutP, CoutP 32 or 64, bias / act / post affine / residual / output as for
+ * egne_conv3x3_halo_f16_fwd; seg[] ignored).  w1hi / w1lo: egne_pack_conv1x1_weight_f16, f2hi / f2lo:
+ * egne_pack_conv_weight_f16frag.  a1 pre-scales the slices, a2 the 1x1 result (powers of two). */
+int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* d1, const egne_conv_desc* d2, const void* w1hi, const void* w1lo,
+                                   float a1, float w1_scale, const void* f2hi, const void* f2lo, float a2, float w2_scale,
+                                   void* stream);
+
 /* LDS-staged variant of the split-f16 1x1 convolution over raw slices, for the layers whose K or Cout exceed what the
  * streaming kernel keeps in LDS (decoder conv11 / conv21 at 30x40 and 60x80, models/RITnet_v2.py:84,86; dense block 3):
  * 128x128 (CoutP % 128 == 0) or 256x64 tiles.  d->Ktot = sum of the slice widths rounded up to 32 each; weights: hi / lo

@@ -512,3 +512,77 @@ def test_deep_trunk_kernel_with_frame_tail(G):
     err = (out.permute(0, 3, 1, 2) - ref).abs().max().item() / ref.abs().max().item()
     print("big + tail err vs torch fp32 %.2e" % err)
     assert err < 1e-5
+
+
+@pytest.mark.parametrize("chans,C1,C2,B,H,W,res,post", [
+    ((32, 32), 32, 32, 2, 61, 83, False, False),            # ESF block 0 conv21 + conv22 class: ragged tiles in x and y
+    ((32, 32, 32), 32, 32, 3, 24, 64, True, False),         # conv31 + conv32 class, residual add in the epilogue
+    ((38, 64), 64, 64, 2, 37, 70, False, True),             # block 1: 8-channel tail group, two LDS chunks, 64-wide 3x3, 4-row tiles
+    ((38, 64, 64), 64, 64, 1, 120, 160, False, False),
+    ((62, 32, 32), 32, 32, 2, 50, 96, False, False),        # up block 1 conv11 + conv12 class (62 logical of 64 channels)
+    ((100, 64, 38, 62), 62, 62, 1, 33, 65, False, False),   # up block 2 class: 62-channel intermediate and output (padded to 64)
+    ((64, 32), 64, 32, 1, 20, 100, False, False),           # two chunks in, 32 out
+    ((32, 40), 30, 64, 2, 17, 61, False, False),            # one (padded) chunk in, 64 out
+])
+def test_conv1x1_3x3_fused(G, chans, C1, C2, B, H, W, res, post):
+    """conv_fused_1x1_3x3_f16.hip: 3x3(1x1(cat(slices)) + b1) with the intermediate in LDS only, against float64.  The 3x3's
+    zero padding applies to the 1x1 OUTPUT (b1 must not leak into the border), LeakyReLU + optional eval-BatchNorm affine
+    and residual in the epilogue."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd import engine
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    xs = [_rand(G, B, c, H, W) * 2 for c in chans]
+    Cin = sum(chans)
+    w1, b1 = _rand(G, C1, Cin, 1, 1) / Cin ** 0.5, _rand(G, C1)
+    w2, b2 = _rand(G, C2, C1, 3, 3) / (3 * C1 ** 0.5), _rand(G, C2)
+    t = F.conv2d(torch.cat(xs, 1).double(), w1.double(), b1.double())
+    truth = F.leaky_relu(F.conv2d(t, w2.double(), b2.double(), padding=1), 0.01)
+    ps = pt = rz = None
+    if post:
+        ps, pt = _rand(G, C2).abs() + 0.5, _rand(G, C2)
+        truth = truth * ps.double()[None, :, None, None] + pt.double()[None, :, None, None]
+    if res:
+        rz = _rand(G, B, C2, H, W)
+        truth = truth + rz.double()
+    pl = Plan(torch.device(DEV))
+    pieces = to_nhwc_buf(pl, xs[:-1], B, H, W) + to_nhwc_buf(pl, xs[-1:], B, H, W)
+    l1 = ConvLayer([torch.nn.Parameter(w1.to(DEV))], [torch.nn.Parameter(b1.to(DEV))], [(p.C, p.Cp) for p in pieces])
+    l2 = ConvLayer([torch.nn.Parameter(w2.to(DEV))], [torch.nn.Parameter(b2.to(DEV))], [(C1, pad8(C1))], pad=(1, 1), act=2)
+    l1.split1 = l2.split = True
+    if post:
+        a, b_ = torch.zeros(l2.CoutP, device=DEV), torch.zeros(l2.CoutP, device=DEV)
+        a[:C2], b_[:C2] = ps.to(DEV), pt.to(DEV)
+        l2.post = (a, b_)
+    out = pl.buf(B, H, W, pad8(C2) + 16)
+    out.fill_(777.0)
+    rp = to_nhwc_buf(pl, [rz], B, H, W)[0] if res else None
+    old = engine.FUSE_1X1_MIN_W
+    engine.FUSE_1X1_MIN_W = 0
+    try:
+        pl.conv_pair(l1, pieces, l2, Piece(out, 8, C2), B, H, W, residual=rp)
+    finally:
+        engine.FUSE_1X1_MIN_W = old
+    fusable = C1 <= 32 and sum((c + 15) // 16 for c in [(x + 7) // 8 * 8 for x in chans]) <= 12
+    assert len(pl.calls) == (1 if fusable else 2) and (not fusable or pl.calls[0][0] is pl.L.egne_conv1x1_3x3_fused_f16_fwd)
+    for _ in range(2):      # calibrating run, replay
+        pl.run()
+        torch.cuda.synchronize()
+        o = out.cpu()
+        assert (o[..., :8] == 777.0).all() and (o[..., 8 + pad8(C2):] == 777.0).all(), "stores outside the output slice"
+        got = o[..., 8:8 + C2].permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 3e-6, "relative error %.2e" % err
+    # the unfused pair (two launches through a temporary) is the same function
+    pl2 = Plan(torch.device(DEV))
+    out2 = pl2.buf(B, H, W, pad8(C2))
+    old = engine.FUSE_1X1
+    engine.FUSE_1X1 = False
+    try:
+        pl2.conv_pair(l1, pieces, l2, Piece(out2, 0, C2), B, H, W, residual=rp)
+    finally:
+        engine.FUSE_1X1 = old
+    assert len(pl2.calls) == 2
+    pl2.run()
+    torch.cuda.synchronize()
+    got2 = out2.cpu()[..., :C2].permute(0, 3, 1, 2).double()
+    assert (got2 - truth).abs().max().item() / truth.abs().max().item() < 3e-6
