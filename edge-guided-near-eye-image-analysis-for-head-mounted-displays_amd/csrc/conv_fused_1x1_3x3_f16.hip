@@ -69,8 +69,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
                           const _Float16* __restrict__ w1lo, int G1, const _Float16* __restrict__ f2hi,
                           const _Float16* __restrict__ f2lo, float a1, float os1, float a2, float os2, int tiles_x, int tiles_y,
                           int ntiles) {
-  constexpr int WM = TH / 4;
-  constexpr int GB = 4;                          // 16-channel groups per producer batch (8 KB of loads per wave)
+  constexpr int GB = NCH == 1 ? 4 : 2;              // 16-channel groups per producer item (8 / 4 KB of loads per wave)
+  constexpr bool WLDS = NCH == 1;                   // the 1x1's weights in LDS (they fit beside two 32-channel images only)
   constexpr int HHd = TH + 2, NPX = HHd * HWd, NMT = (NPX + 31) / 32;
   constexpr int IMG = 2 * NCH * NPX * LDH;          // halfs per image: [hi | lo][NCH][NPX][LDH]
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
@@ -100,7 +100,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   // the 1x1's weight fragments live in LDS for the whole launch ([group][tile][hi | lo][lane][8]): read through the LDS
   // queue they never wait behind the producers' prefetched activations (vmcnt retires in order)
   _Float16* lw = (_Float16*)(lbias + 32 * NCH);
-  for (int it = tid; it < G1 * NCH * 2 * 64; it += 512) {        // 16-byte items
+  for (int it = tid; it < (WLDS ? G1 * NCH * 2 * 64 : 0); it += 512) {        // 16-byte items
     const int l = it & 63, hl = (it >> 6) & 1, q = it >> 7;      // q = group * NCH + tile
     *(u32x4*)&lw[(long long)it * 8] = *(const u32x4*)((hl ? w1lo : w1hi) + ((long long)q * 64 + l) * 8);
   }
@@ -112,10 +112,28 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     // block; wave w owns blocks w, w + 4, ...; a block past the halo is all out-of-range lanes: no traffic, nothing
     // written).  Loads run DIST = 2 items ahead through a ring of 3 register buffers and wrap into the NEXT tile, so the
     // pipeline never drains at a tile boundary; with no data-dependent control flow inside, every wait is a counted vmcnt.
-    constexpr int JOBS = (NMT + 3) / 4, N = JOBS * NB, NBUF = 3, DIST = 2;
-    static_assert(N % NBUF == 0 && N >= DIST, "buffer index of an item must not depend on the tile");
+    // Without room for the weights in LDS (64-channel intermediate) they come from L2 into a register double buffer, one
+    // item EARLY and in front of that step's activation prefetch, which costs one level of prefetch distance: DIST = 3.
+    constexpr int JOBS = (NMT + 3) / 4, N = JOBS * NB, NBUF = WLDS ? 3 : 4, DIST = NBUF - 1;
+    static_assert(N % NBUF == 0 && (WLDS || N % 2 == 0) && N >= DIST, "buffer index of an item must not depend on the tile");
     u32x4 xa[NBUF][GB], xb[NBUF][GB];
+    u32x4 wq[WLDS ? 1 : 2][GB][NCH][2];
     f32x16 acc[NCH];
+    const unsigned w1bytes = (unsigned)G1 * NCH * 64u * 16u;
+    const __amdgpu_buffer_rsrc_t rw1h = make_rsrc(w1hi, w1bytes), rw1l = make_rsrc(w1lo, w1bytes);
+    auto load_w = [&](auto kc) {          // weight fragments of item K (they depend on its batch index only)
+      constexpr int K = decltype(kc)::value, bi = K % NB;
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const int gg = bi * GB + u;
+        const int wo = gg < G1 ? (gg * NCH * 64 + lane) * 16 : (int)OOB;
+#pragma unroll
+        for (int tn = 0; tn < NCH; ++tn) {
+          wq[K & 1][u][tn][0] = __builtin_amdgcn_raw_buffer_load_b128(rw1h, wo, tn * 1024, 0);
+          wq[K & 1][u][tn][1] = __builtin_amdgcn_raw_buffer_load_b128(rw1l, wo, tn * 1024, 0);
+        }
+      }
+    };
 
     auto pixel = [&](const Tile& tl, int job, int& hp, bool& valid, int& pix) {
       hp = (wave + 4 * job) * 32 + li;
@@ -151,6 +169,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
 #pragma unroll
         for (int tn = 0; tn < NCH; ++tn) acc[tn] = (f32x16)(0.f);
       }
+      if constexpr (!WLDS) load_w(std::integral_constant<int, (K + 1) % N>{});
       if constexpr (K + DIST < N) issue(tl, true, std::integral_constant<int, K + DIST>{});
       else issue(nx, nx_on, std::integral_constant<int, K + DIST - N>{});
 #pragma unroll
@@ -160,8 +179,13 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
           split8(xa[BUF][u], xb[BUF][u], a1, ah, al);
 #pragma unroll
           for (int tn = 0; tn < NCH; ++tn) {
-            const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
-            const h8 bh = *(const h8*)wp, bl = *(const h8*)(wp + 512);
+            h8 bh, bl;
+            if constexpr (WLDS) {
+              const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
+              bh = *(const h8*)wp; bl = *(const h8*)(wp + 512);
+            } else {
+              bh = __builtin_bit_cast(h8, wq[K & 1][u][tn][0]); bl = __builtin_bit_cast(h8, wq[K & 1][u][tn][1]);
+            }
             acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[tn], 0, 0, 0);
             acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[tn], 0, 0, 0);
             acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[tn], 0, 0, 0);
@@ -206,8 +230,10 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
 
     if (nmine > 0) {
       const Tile t0 = decode(tile_at(0));
-      issue(t0, true, std::integral_constant<int, 0>{});
-      issue(t0, true, std::integral_constant<int, 1>{});
+      if constexpr (!WLDS) load_w(std::integral_constant<int, 0>{});
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        (issue(t0, true, std::integral_constant<int, Ks>{}), ...);
+      }(std::make_integer_sequence<int, DIST>{});
       produce(0);
     }
     lds_barrier();
@@ -217,7 +243,14 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     }
   } else {
     // =================================================================== consumers: 9 taps from the LDS image
+    // Wave -> (rows, output tiles): 8-row tiles give every wave two rows and all WN output tiles; with 4-row tiles and
+    // 64 output channels a wave takes two rows and ONE of the two output tiles, so that every weight fragment it pulls
+    // from L2 feeds two row blocks and the register ring runs two taps ahead (a 64-wide wave tile on one row would
+    // pull twice the weights per pixel with one tap of look-ahead: measured L2-latency bound).
+    constexpr int NSPLIT = (TH == 4 && WN == 2) ? 2 : 1;
+    constexpr int WNW = WN / NSPLIT, WMW = TH * NSPLIT / 4;
     const int cw = wave - 4;
+    const int row0 = (cw / NSPLIT) * WMW, nt0 = (cw % NSPLIT) * WNW;
     const unsigned frame_out = (unsigned)H * W * (unsigned)p2.out_pix_stride * 4u;
     const unsigned frame_res = (unsigned)H * W * (unsigned)p2.res_pix_stride * 4u;
     const float slope_out = p2.act == EGNE_ACT_RELU ? 0.f : (p2.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
@@ -225,34 +258,47 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     const unsigned w2bytes = 9u * (unsigned)(KT16 * 16) * (unsigned)(NT2 * 32) * 2u;
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(f2hi, w2bytes), rwl = make_rsrc(f2lo, w2bytes);
     constexpr int stride_k16 = NT2 * 1024, stride_tap = KT16 * NT2 * 1024;
-    const int wlane = lane * 16;
-    const int abase = (cw * WM * HWd + li) * LDH + lh * 8;
+    const int wlane = lane * 16 + nt0 * 1024;
+    const int abase = (row0 * HWd + li) * LDH + lh * 8;
     const int out_step = (int)p2.out_pix_stride * 4, res_step = (int)p2.res_pix_stride * 4;
 
+    // 32 -> 32 channels: the 36 weight fragments of the 3x3 (144 registers) stay in registers for the whole launch
+    constexpr bool WREG = NCH == 1 && WNW == 1;
+    u32x4 wrh[WREG ? 18 : 1], wrl[WREG ? 18 : 1];
+    if constexpr (WREG) {
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        const int o = (s >> 1) * stride_tap + (s & 1) * stride_k16;
+        wrh[s] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
+        wrl[s] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
+      }
+    }
     lds_barrier();
     for (int i = 0; i < nmine; ++i) {
       const Tile tl = decode(tile_at(i));
       const _Float16* Thi = ldsh + (i & 1) * IMG;
       const _Float16* Tlo = Thi + NCH * NPX * LDH;
-      f32x16 acc[WM][WN];
+      f32x16 acc[WMW][WNW];
 #pragma unroll
-      for (int a = 0; a < WM; ++a)
+      for (int a = 0; a < WMW; ++a)
 #pragma unroll
-        for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
+        for (int n = 0; n < WNW; ++n) acc[a][n] = (f32x16)(0.f);
 #pragma unroll 1
       for (int ch = 0; ch < NCH; ++ch) {
         const int wchunk = ch * 2 * stride_k16;
-        constexpr int RT = WN == 1 ? 2 : 1;
-        u32x4 qh[2 * RT][WN], ql[2 * RT][WN];
+        constexpr int RT = WNW == 1 ? 3 : 2;      // taps of look-ahead of the weight ring (2 loads per tap, k step and output tile)
+        u32x4 qh[2 * RT][WNW], ql[2 * RT][WNW];
+        if constexpr (!WREG) {
 #pragma unroll
-        for (int s = 0; s < 2 * RT; ++s)
+          for (int s = 0; s < 2 * RT; ++s)
 #pragma unroll
-          for (int tn = 0; tn < WN; ++tn) {
-            const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
-            qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
-            ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
-          }
-        constexpr int TAP_UNROLL = (WM == 2 && WN == 2) ? 1 : 9;     // the widest shape only fits 256 registers with the tap loop rolled
+            for (int tn = 0; tn < WNW; ++tn) {
+              const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
+              qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
+              ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
+            }
+        }
+        constexpr int TAP_UNROLL = (WMW == 2 && WNW == 2) ? 1 : 9;     // the widest shape only fits 256 registers with the tap loop rolled
 #pragma unroll TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
           const int ky = tap / 3, kx = tap - ky * 3;
@@ -260,29 +306,32 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const int slot = (tap % RT) * 2 + ks;
-            h8 ah[WM], al[WM], bh[WN], bl[WN];
+            h8 ah[WMW], al[WMW], bh[WNW], bl[WNW];
 #pragma unroll
-            for (int tm = 0; tm < WM; ++tm) {
+            for (int tm = 0; tm < WMW; ++tm) {
               ah[tm] = *(const h8*)&Thi[aoff + tm * HWd * LDH + ks * 16];
               al[tm] = *(const h8*)&Tlo[aoff + tm * HWd * LDH + ks * 16];
             }
 #pragma unroll
-            for (int tn = 0; tn < WN; ++tn) {
-              bh[tn] = __builtin_bit_cast(h8, qh[slot][tn]);
-              bl[tn] = __builtin_bit_cast(h8, ql[slot][tn]);
+            for (int tn = 0; tn < WNW; ++tn) {
+              bh[tn] = __builtin_bit_cast(h8, WREG ? wrh[(tap * 2 + ks) % (WREG ? 18 : 1)] : qh[slot][tn]);
+              bl[tn] = __builtin_bit_cast(h8, WREG ? wrl[(tap * 2 + ks) % (WREG ? 18 : 1)] : ql[slot][tn]);
             }
-            if (tap + RT < 9) {
+            if (!WREG && tap + RT < 9) {
 #pragma unroll
-              for (int tn = 0; tn < WN; ++tn) {
+              for (int tn = 0; tn < WNW; ++tn) {
                 const int o = wchunk + (tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
                 qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
                 ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
               }
             }
+            // keep the refill HERE, RT taps ahead of its use: left alone the scheduler either sinks it next to the use (one
+            // L2 latency per step) or hoists all 36 loads of a chunk to the top (144 registers)
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int tm = 0; tm < WM; ++tm)
+            for (int tm = 0; tm < WMW; ++tm)
 #pragma unroll
-              for (int tn = 0; tn < WN; ++tn) {
+              for (int tn = 0; tn < WNW; ++tn) {
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
@@ -299,15 +348,15 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         const int xl = tl.x0 + 4 * lh;
         const int cmax = xl < W ? W - xl : 0;      // c_r < cmax  <=>  x < W
 #pragma unroll
-        for (int tn = 0; tn < WN; ++tn) {
-          const int n = tn * 32 + li;
+        for (int tn = 0; tn < WNW; ++tn) {
+          const int n = (nt0 + tn) * 32 + li;
           const bool nok = n < p2.Cout_store;
           const float bv = (p2.bias && nok) ? p2.bias[n] : 0.f;
           float ps = 1.f, pt = 0.f;
           if (p2.post_scale && nok) { ps = p2.post_scale[n]; pt = p2.post_shift[n]; }
 #pragma unroll
-          for (int tm = 0; tm < WM; ++tm) {
-            const int y = tl.y0 + cw * WM + tm;
+          for (int tm = 0; tm < WMW; ++tm) {
+            const int y = tl.y0 + row0 + tm;
             const int cm = (nok && y < H) ? cmax : 0;
             const int pix = y * W + xl;
             const unsigned o0 = (unsigned)((pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4);
@@ -342,7 +391,7 @@ int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const Group
                  int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
-  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (size_t)G1 * NCH * 2048;
+  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0);
   static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024) == hipSuccess;
   if (!once || lds > 160 * 1024) return egne::fail(EGNE_ERR_LAUNCH, "conv_fused_1x1_3x3: %zu bytes of LDS", lds);
@@ -367,7 +416,7 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   const egne_conv_desc& d1 = *dp1;
   const egne_conv_desc& d2 = *dp2;
   EGNE_REQUIRE(d1.kh == 1 && d1.kw == 1 && d1.stride == 1 && d1.pad_h == 0 && d1.pad_w == 0 && d1.ngroups == 1 && d1.nseg >= 1 &&
-               d1.nseg <= EGNE_MAXSEG && !d1.residual && !d1.post_scale && d1.act == EGNE_ACT_NONE && d1.CoutP == 32,
+               d1.nseg <= EGNE_MAXSEG && !d1.residual && !d1.post_scale && d1.act == EGNE_ACT_NONE && (d1.CoutP == 32 || d1.CoutP == 64),
                "conv_fused_1x1_3x3: 1x1 descriptor");
   EGNE_REQUIRE(d2.kh == 3 && d2.kw == 3 && d2.stride == 1 && d2.pad_mode == 0 && d2.ngroups == 1 && d2.pad_h == 1 && d2.pad_w == 1 &&
                d2.dil[0] == 1 && d2.Ho == d2.H && d2.Wo == d2.W && d2.B == d1.B && d2.H == d1.H && d2.W == d1.W && d2.Ktot == d1.CoutP &&
@@ -394,13 +443,22 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   const float os1 = 1.0f / (a1 * w1_scale), os2 = 1.0f / (a2 * w2_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *a = (const _Float16*)w1hi, *b = (const _Float16*)w1lo, *c = (const _Float16*)f2hi, *e = (const _Float16*)f2lo;
-  EGNE_REQUIRE(d1.CoutP == 32 && G <= 12, "conv_fused_1x1_3x3: a 32-channel intermediate and at most 192 input channels are built (got %d, %d groups)",
-               d1.CoutP, G);
-  const int nb = (G + 3) / 4;
+  EGNE_REQUIRE(G <= 12, "conv_fused_1x1_3x3: at most 192 input channels (12 groups of 16) are built, got %d groups", G);
+  if (d1.CoutP == 32) {
+    const int nb = (G + 3) / 4;
 #define EGNE_FUSED(WN_) \
   (nb == 1 ? launch_fused<1, WN_, 8, 1>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
            : nb == 2 ? launch_fused<1, WN_, 8, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
                      : launch_fused<1, WN_, 8, 3>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
-  return d2.CoutP == 32 ? EGNE_FUSED(1) : EGNE_FUSED(2);
+    return d2.CoutP == 32 ? EGNE_FUSED(1) : EGNE_FUSED(2);
 #undef EGNE_FUSED
+  }
+  // 64-channel intermediate: 4-row tiles, items of 2 groups, an even number of batches per 32-pixel block
+  const int nb2 = ((G + 1) / 2 + 1) / 2 * 2;
+#define EGNE_FUSED2(WN_) \
+  (nb2 == 2 ? launch_fused<2, WN_, 4, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+            : nb2 == 4 ? launch_fused<2, WN_, 4, 4>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+                       : launch_fused<2, WN_, 4, 6>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
+  return d2.CoutP == 32 ? EGNE_FUSED2(1) : EGNE_FUSED2(2);
+#undef EGNE_FUSED2
 }

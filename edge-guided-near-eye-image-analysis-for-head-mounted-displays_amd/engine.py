@@ -631,7 +631,7 @@ class Plan:
         (conv_fused_1x1_3x3_f16.hip); otherwise two launches through ``tmp`` (a Piece, allocated here if None)."""
         fused = (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split1 and l2.split and l1.kh == 1 and l1.kw == 1
                  and l1.stride == 1 and l1.G == 1 and l1.pad == (0, 0) and l1.act == ACT_NONE and l1.post is None
-                 and all(pc.scale is None for pc in pieces) and l1.CoutP == 32 and len(pieces) <= _lib.MAXSEG
+                 and all(pc.scale is None for pc in pieces) and l1.CoutP in (32, 64) and len(pieces) <= _lib.MAXSEG
                  and sum((pc.Cp + 15) // 16 for pc in pieces) <= 12
                  and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
                  and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP in (32, 64)

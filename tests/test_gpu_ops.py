@@ -562,7 +562,7 @@ def test_conv1x1_3x3_fused(G, chans, C1, C2, B, H, W, res, post):
         pl.conv_pair(l1, pieces, l2, Piece(out, 8, C2), B, H, W, residual=rp)
     finally:
         engine.FUSE_1X1_MIN_W = old
-    fusable = C1 <= 32 and sum((c + 15) // 16 for c in [(x + 7) // 8 * 8 for x in chans]) <= 12
+    fusable = sum((c + 15) // 16 for c in [(x + 7) // 8 * 8 for x in chans]) <= 12
     assert len(pl.calls) == (1 if fusable else 2) and (not fusable or pl.calls[0][0] is pl.L.egne_conv1x1_3x3_fused_f16_fwd)
     for _ in range(2):      # calibrating run, replay
         pl.run()
