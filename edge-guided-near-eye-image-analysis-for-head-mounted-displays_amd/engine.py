@@ -19,6 +19,7 @@ HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
 HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
+MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
 MS1X1_ENABLED = os.environ.get("EGNE_MS1X1", "1") != "0"
@@ -480,7 +481,14 @@ class Plan:
         big = (split and BIG_ENABLED and layer.G == 1 and pieces[0].scale is None and pieces[0].Cp % 32 == 0 and residual is None
                and layer.post is None and layer.Cout % 128 == 0 and layer.Cout >= BIG_MIN_COUT and layer.Cin >= BIG_MIN_CIN
                and B * Ho * Wo >= 256 * 128)
-        if lattice:
+        # ... or, for the standard dilations, ONE launch with the 4-way sum in registers (msblock_dil_f16.hip)
+        msdil = (split and MSDIL_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)
+                 and layer.dils == (4, 8, 12) and layer.CoutP == 32 and pieces[0].Cp == 32 and residual is not None
+                 and pieces[0].scale is None and layer.act == ACT_RELU and layer.post is None
+                 and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29)
+        if msdil:
+            lattice = False
+        if lattice or msdil:
             shalo = True
         if split and not shalo and halo and pieces[0].scale is not None and layer.CoutP <= 32 and W >= HALO_F16_MIN_W:
             split = False            # narrow fused-affine layers: the fp32 halo kernel beats the flat split kernel
@@ -591,6 +599,9 @@ class Plan:
         elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
                                                       layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1", cal=cal3)
+        elif msdil:
+            self._add(self.L.egne_msblock_dil_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
+                                                        layer.w_scale), name, flops=flops, kind="conv_f16x3:msdil", cal=cal3)
         elif lattice:
             perf = 9 * layer.sfrag_coutp() * pad32(layer.Ktot)
             for g in range(3):

@@ -129,6 +129,14 @@ int egne_pack_conv_weight_f16frag(const float* w_oihw, int Cout, int Cin, int kh
 int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,
                               float w_scale, void* stream);
 
+/* The dilated branch of a BDCN MSBlock in ONE launch (bdcn_new.py:51-54): out = o + sum_g relu(conv3x3_{dil g}(o) + b_g),
+ * 32 -> 32 channels, dilations {4, 8, 12}.  Same descriptor as the grouped form of egne_conv2d_f16x3_fwd (ngroups = 3,
+ * one raw 32-channel slice, CoutP = Ktot = 32, bias [3][32], act = ReLU, residual = the input slice); weights: three
+ * consecutive egne_pack_conv_weight_f16frag packs.  A workgroup keeps the 4-way sum of its 8 x 32 tile in registers, so o
+ * is read once and out written once (round 1: three launches accumulating through HBM). */
+int egne_msblock_dil_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
+                             void* stream);
+
 /* Streaming 1x1 convolution over a concatenation of raw NHWC slices (models/RITnet_v2.py:59,61,84,86 conv21 / conv31 /
  * conv11, :38 Transition_down in eval plans) on the split-f16 path: no staging, every lane loads its MFMA operand
  * straight from HBM, weight fragments stay in LDS.  Same descriptor as egne_conv2d_fwd (`w` unused; no fused affine,

@@ -417,7 +417,13 @@ def test_msblock_lattice_groups_wide_and_tall_tiles(G):
                       pad=(1, 1), dils=(4, 8, 12), act=1)
     layer.split = True
     out = pl.buf(B, H, W, 32)
-    pl.conv(layer, [px], Piece(out, 0, 32), B, H, W, residual=px)
+    from egne_amd import engine
+    old = engine.MSDIL_ENABLED
+    engine.MSDIL_ENABLED = False          # round 1's path, still what other dilation sets take
+    try:
+        pl.conv(layer, [px], Piece(out, 0, 32), B, H, W, residual=px)
+    finally:
+        engine.MSDIL_ENABLED = old
     assert len(pl.calls) == 3 and all(c[0] is pl.L.egne_conv3x3_halo_f16_fwd for c in pl.calls)
     pl.run()
     torch.cuda.synchronize()
@@ -586,3 +592,38 @@ def test_conv1x1_3x3_fused(G, chans, C1, C2, B, H, W, res, post):
     torch.cuda.synchronize()
     got2 = out2.cpu()[..., :C2].permute(0, 3, 1, 2).double()
     assert (got2 - truth).abs().max().item() / truth.abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize("B,H,W,stride_pad", [(2, 240, 320, 0), (3, 37, 53, 0), (2, 120, 160, 8), (5, 30, 40, 0), (4, 29, 39, 0), (1, 9, 33, 0)])
+def test_msblock_dilated_group_one_launch(G, B, H, W, stride_pad):
+    """msblock_dil_f16.hip: out = o + sum_g relu(conv_{dil 4,8,12}(o) + b_g) in ONE launch (bdcn_new.py:51-54), against float64:
+    every BDCN stage size (240x320 ... 29x39: maps smaller than the 12-pixel reach of the widest dilation), ragged tiles,
+    an input slice inside a wider buffer."""
+    from gpu_util import DEV
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    o = F.relu(_rand(G, B, 32, H, W)) * 2
+    ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+    bs = [_rand(G, 32) for _ in range(3)]
+    truth = o.double()
+    for w, b, d in zip(ws, bs, (4, 8, 12)):
+        truth = truth + F.relu(F.conv2d(o.double(), w.double(), b.double(), padding=d, dilation=d))
+    pl = Plan(torch.device(DEV))
+    buf = pl.buf(B, H, W, 32 + stride_pad)
+    buf.fill_(55.0)
+    buf[..., stride_pad:] = o.permute(0, 2, 3, 1).to(DEV)
+    px = Piece(buf, stride_pad, 32)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV)) for w in ws], [torch.nn.Parameter(b.to(DEV)) for b in bs], [(32, 32)],
+                      pad=(1, 1), dils=(4, 8, 12), act=1)
+    layer.split = True
+    out = pl.buf(B, H, W, 48)
+    out.fill_(777.0)
+    pl.conv(layer, [px], Piece(out, 8, 32), B, H, W, residual=px)
+    assert len(pl.calls) == 1 and pl.calls[0][0] is pl.L.egne_msblock_dil_f16_fwd
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        oc = out.cpu()
+        assert (oc[..., :8] == 777.0).all() and (oc[..., 40:] == 777.0).all()
+        got = oc[..., 8:40].permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 2e-6, "relative error %.2e" % err
