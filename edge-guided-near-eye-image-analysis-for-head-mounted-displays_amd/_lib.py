@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("post_scale", c_fp), ("post_shift", c_fp),
                 ("residual", c_fp), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
                 ("out", c_fp), ("out_pix_stride", C.c_int64), ("out_ch_off", C.c_int32),
-                ("Cout_store", C.c_int32)]
+                ("Cout_store", C.c_int32),
+                ("stats_ws", c_fp), ("stats_nchunk", C.c_int32)]
 
 
 class BdcnTailDesc(C.Structure):
@@ -80,6 +81,7 @@ SIGNATURES = {
     "egne_absmax": (i32, [vp, i64, i32, i32, i64, vp, vp]),
     "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "egne_norm_stats": (i32, [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
+    "egne_norm_stats_finish": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "egne_affine_inplace": (i32, [vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_affine": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_avgpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),

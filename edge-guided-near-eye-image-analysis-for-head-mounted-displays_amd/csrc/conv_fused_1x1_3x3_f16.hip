@@ -354,6 +354,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
           const float bv = (p2.bias && nok) ? p2.bias[n] : 0.f;
           float ps = 1.f, pt = 0.f;
           if (p2.post_scale && nok) { ps = p2.post_scale[n]; pt = p2.post_shift[n]; }
+          float st_s = 0.f, st_q = 0.f;     // sum / sum of squares of this wave's stored values of channel n (stats_ws)
 #pragma unroll
           for (int tm = 0; tm < WMW; ++tm) {
             const int y = tl.y0 + row0 + tm;
@@ -377,6 +378,16 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
               float v = acc[tm][tn][r] * os2 + bv;
               v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+              const float vm = c < cm ? v : 0.f;
+              st_s += vm; st_q += vm * vm;
+            }
+          }
+          if (p2.stats_ws) {                 // one chunk = this wave's rows of this tile (fixed order: deterministic)
+            st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
+            if (lh == 0 && n < p2.Cout_store) {
+              const int tile_in_frame = (tl.y0 / TH) * tiles_x + tl.x0 / TW;
+              double2* w = (double2*)p2.stats_ws + ((long long)tl.b * p2.stats_nchunk + tile_in_frame * (4 / NSPLIT) + cw / NSPLIT) * p2.Cout_store + n;
+              *w = make_double2((double)st_s, (double)st_q);
             }
           }
         }
@@ -440,6 +451,11 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                (!d2.residual || (long long)d2.H * d2.W * d2.res_pix_stride * 4 < (1ll << 31)), "conv_fused_1x1_3x3: output");
   EGNE_REQUIRE(((uintptr_t)w1hi & 15) == 0 && ((uintptr_t)w1lo & 15) == 0 && ((uintptr_t)f2hi & 15) == 0 && ((uintptr_t)f2lo & 15) == 0 &&
                a1 > 0.f && a2 > 0.f && w1_scale > 0.f && w2_scale > 0.f, "conv_fused_1x1_3x3: weights / scales");
+  {
+    const int th = d1.CoutP == 32 ? 8 : 4, rg = (d1.CoutP == 64 && d2.CoutP == 64) ? 2 : 4;
+    EGNE_REQUIRE(!d2.stats_ws || (((uintptr_t)d2.stats_ws & 15) == 0 && d2.stats_nchunk == ((d2.W + 31) / 32) * ((d2.H + th - 1) / th) * rg),
+                 "conv_fused_1x1_3x3: stats_nchunk must be tiles * %d for this shape", rg);
+  }
   const float os1 = 1.0f / (a1 * w1_scale), os2 = 1.0f / (a2 * w2_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *a = (const _Float16*)w1hi, *b = (const _Float16*)w1lo, *c = (const _Float16*)f2hi, *e = (const _Float16*)f2lo;

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         float ps = 1.f, pt = 0.f;
         if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+        float st_s = 0.f, st_q = 0.f;       // sum / sum of squares of this wave's stored values of channel n (stats_ws)
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
@@ -296,8 +297,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             float v = acc[tm][tn][r] * out_scale + bv;
             v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+            const float vm = c < cm ? v : 0.f;
+            st_s += vm; st_q += vm * vm;
           }
           acc[tm][tn] = (f32x16)(0.f);
+        }
+        if (!LAT && !TP && NW == 1 && p.stats_ws) {     // one chunk = this wave's rows of this tile (fixed order: deterministic)
+          st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
+          if (lh == 0 && n < p.Cout_store) {
+            const int tile_in_frame = (cur.y0 / TH) * tiles_x + cur.x0 / TW;
+            double2* w = (double2*)p.stats_ws + ((long long)cur.b * p.stats_nchunk + tile_in_frame * 4 + wave) * p.Cout_store + n;
+            *w = make_double2((double)st_s, (double)st_q);
+          }
         }
       }
     }
@@ -351,7 +362,7 @@ int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo,
   const int S = LAT ? d.dil[0] : 1;
   auto ntile = [&](int vh, int vw) { return ((((vw + S - 1) / S) + TW - 1) / TW) * ((((vh + S - 1) / S) + TH - 1) / TH); };
   static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
-  if (D == 1 && NW == 1 && PF == 0 && tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W))
+  if (D == 1 && NW == 1 && PF == 0 && tall_ok && !d.stats_ws && ntile(d.W, d.H) < ntile(d.H, d.W))
     return launch_hf_tp<WM, WN, (D == 1 && NW == 1 && PF == 0 ? D : 1), LAT, (D == 1 && NW == 1 && PF == 0 ? NW : 1), 0, true>(d, fhi, flo, a_scale, os, st);
   return launch_hf_tp<WM, WN, D, LAT, NW, PF, false>(d, fhi, flo, a_scale, os, st);
 }
@@ -383,6 +394,8 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   EGNE_REQUIRE(d.CoutP % 32 == 0 && d.Cout_store <= d.CoutP && d.out && d.out_ch_off + d.Cout_store <= d.out_pix_stride,
                "conv_halo_f16: CoutP %d", d.CoutP);
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv_halo_f16: weights / scales");
+  EGNE_REQUIRE(!d.stats_ws || (d.dil[0] == 1 && ((uintptr_t)d.stats_ws & 15) == 0 && d.stats_nchunk == ((d.W + 31) / 32) * ((d.H + 7) / 8) * 4),
+               "conv_halo_f16: stats_ws needs dilation 1 and stats_nchunk = tiles * 4");
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
                (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv_halo_f16: frame too large for 32-bit byte offsets");
   const float os = 1.0f / (a_scale * w_scale);

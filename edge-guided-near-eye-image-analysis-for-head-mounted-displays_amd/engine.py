@@ -36,6 +36,7 @@ HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
+STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm statistics from the producing conv's epilogue
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
 FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
 CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
@@ -440,8 +441,23 @@ class Plan:
         self.calls.append((fn, args, name))
         self.meta.append((kind or name.split(".")[0], flops))
 
-    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv"):
-        """pieces: input Pieces in concat order; dst: output Piece.  Returns (Ho, Wo)."""
+    def _stats_ws(self, d, B, nchunk):
+        """Partial-sum workspace for InstanceNorm statistics written from a convolution's epilogue."""
+        ws = self.vec(B * nchunk * int(d.Cout_store) * 2, dtype=torch.float64)
+        d.stats_ws, d.stats_nchunk = ws.data_ptr(), nchunk
+        return ws
+
+    def _stats_finish(self, ws, d, B, HW, nchunk, name, eps=1e-5):
+        Cs = int(d.Cout_store)
+        scale, shift = self.vec(B, Cs), self.vec(B, Cs)
+        self._add(self.L.egne_norm_stats_finish, (ws.data_ptr(), Cs, B, nchunk, HW, eps, scale.data_ptr(), shift.data_ptr()),
+                  name + ".stats", kind="norm_stats")
+        return scale, shift
+
+    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False):
+        """pieces: input Pieces in concat order; dst: output Piece.  Returns (Ho, Wo); with ``stats`` also leaves the
+        per-sample InstanceNorm (scale, shift) of the OUTPUT in ``self.last_stats`` -- from partial sums written by the
+        kernel's epilogue where the kernel can do that, from a separate statistics pass otherwise."""
         assert len(pieces) == len(layer.in_layout) and len(pieces) <= _lib.MAXSEG, name
         for p, (c, cp) in zip(pieces, layer.in_layout):
             assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
@@ -617,8 +633,16 @@ class Plan:
                                                              layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
                           name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice", cal=cal3)
         elif shalo:
+            tx, ty = (W + 31) // 32, (H + 7) // 8
+            tall = ((H + 31) // 32) * ((W + 7) // 8) < tx * ty          # the kernel would walk the map transposed
+            fuse_stats = stats and STATS_FUSED and layer.dils[0] == 1 and not tall and dst.Cp == int(d.Cout_store)
+            if fuse_stats:
+                ws = self._stats_ws(d, B, tx * ty * 4)
             self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
                                                          layer.w_scale), name, flops=flops, kind="conv_f16x3:halo", cal=cal3)
+            if fuse_stats:
+                self.last_stats = self._stats_finish(ws, d, B, H * W, tx * ty * 4, name)
+                stats = False
         elif split:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
                                                      layer.w_scale), name, flops=flops, kind="conv_f16x3:flat", cal=cal3)
@@ -632,11 +656,13 @@ class Plan:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
+        if stats:
+            self.last_stats = self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2]
         if self.train:
             self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, d, B, H, W, Ho, Wo, name))
         return Ho, Wo
 
-    def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair"):
+    def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False):
         """``l2(l1(cat(pieces)))``: a 1x1 convolution over raw slices followed by the 3x3 that is its only consumer
         (RITnet_v2.py:59-62,84-87).  Inference plans run the pair as ONE launch whose intermediate stays in LDS
         (conv_fused_1x1_3x3_f16.hip); otherwise two launches through ``tmp`` (a Piece, allocated here if None)."""
@@ -651,7 +677,7 @@ class Plan:
             if tmp is None:
                 tmp = Piece(self.buf(B, H, W, pad8(l1.Cout)), 0, l1.Cout)
             self.conv(l1, pieces, tmp, B, H, W, name=name + ".a")
-            return self.conv(l2, [tmp], dst, B, H, W, residual=residual, name=name + ".b")
+            return self.conv(l2, [tmp], dst, B, H, W, residual=residual, name=name + ".b", stats=stats)
         for p, (c, cp) in zip(pieces, l1.in_layout):
             assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
         l1.need_s1 = True
@@ -695,10 +721,19 @@ class Plan:
                     bound += float(l1.biases[0].detach().abs().max())
             return args[:4] + (_a_scale_for(vmax),) + args[5:8] + (_a_scale_for(bound),) + args[9:]
         flops = 2.0 * B * H * W * (l1.Cout * l1.Cin + l2.Cout * l2.Cin * 9)
+        fuse_stats = stats and STATS_FUSED and dst.Cp == int(d2.Cout_store)
+        if fuse_stats:
+            th = 8 if l1.CoutP == 32 else 4
+            nchunk = ((W + 31) // 32) * ((H + th - 1) // th) * (2 if (l1.CoutP == 64 and d2.CoutP == 64) else 4)
+            ws = self._stats_ws(d2, B, nchunk)
         self._add(self.L.egne_conv1x1_3x3_fused_f16_fwd,
                   (C.byref(d1), C.byref(d2), l1.s1hi.data_ptr(), l1.s1lo.data_ptr(), F16X3_ASCALE, l1.w_scale1,
                    l2.fhi.data_ptr(), l2.flo.data_ptr(), F16X3_ASCALE, l2.w_scale), name, flops=flops, kind="conv_f16x3:fused1x1",
                   cal=(rescale, list(pieces), B * H * W))
+        if fuse_stats:
+            self.last_stats = self._stats_finish(ws, d2, B, H * W, nchunk, name)
+        elif stats:
+            self.last_stats = self.norm_stats(dst, B, H * W, name=name + ".stats")[:2]
         return H, W
 
     def _bw_conv(self, bw, layer, pieces, dst, d, B, H, W, Ho, Wo, name):

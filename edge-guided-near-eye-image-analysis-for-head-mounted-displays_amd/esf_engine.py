@@ -179,8 +179,10 @@ def build_forward_plan(model, B, H, W, dev, training):
         fold = _BNFold(enc.head.bn, l.CoutP, dev)
         pl.pre.append(fold.guard)
         l.post = (fold.scale, fold.shift)
+    x_stats = None
     if not training:
-        pl.conv(l, [Piece(t0, 0, chz)], D[0]["x"], NB, H, W, name="enc.head.conv2")
+        pl.conv(l, [Piece(t0, 0, chz)], D[0]["x"], NB, H, W, name="enc.head.conv2", stats=True)
+        x_stats = pl.last_stats          # InstanceNorm statistics of block 0's input, from the conv's epilogue
     else:
         pre = pl.buf(NB, H, W, pad8(chz))
         pl.conv(l, [Piece(t0, 0, chz)], Piece(pre, 0, chz), NB, H, W, name="enc.head.conv2")
@@ -194,7 +196,11 @@ def build_forward_plan(model, B, H, W, dev, training):
         h, w = res[i]
         d = D[i]
         nm = "enc.b%d" % i
-        sc, sh, _, _ = pl.norm_stats(d["x"], NB, h * w, name=nm + ".in_x")
+        if x_stats is not None:
+            sc, sh = x_stats
+            x_stats = None
+        else:
+            sc, sh, _, _ = pl.norm_stats(d["x"], NB, h * w, name=nm + ".in_x")
         l = _cl(blk.conv1, _lay([d["x"]]), pad=(1, 1), act=ACT_LEAKY)
         pl.conv(l, [d["x"].with_norm(sc, sh)], d["x1"], NB, h, w, name=nm + ".conv1")
         # conv22(conv21(cat(x, x1))) and conv32(conv31(cat(x, x1, x22))): each 1x1 feeds exactly one 3x3 (RITnet_v2.py:59-62)
@@ -203,8 +209,8 @@ def build_forward_plan(model, B, H, W, dev, training):
         pl.conv_pair(l1, [d["x"], d["x1"]], l2, d["x22"], NB, h, w, name=nm + ".conv2")
         l1 = _cl(blk.conv31, _lay([d["x"], d["x1"], d["x22"]]))
         l2 = _cl(blk.conv32, [(inters[i], pad8(inters[i]))], pad=(1, 1), act=ACT_LEAKY)
-        pl.conv_pair(l1, [d["x"], d["x1"], d["x22"]], l2, d["out"], NB, h, w, name=nm + ".conv3")
-        sc2, sh2, _, _ = pl.norm_stats(d["out"], NB, h * w, name=nm + ".in_out")
+        pl.conv_pair(l1, [d["x"], d["x1"], d["x22"]], l2, d["out"], NB, h, w, name=nm + ".conv3", stats=True)
+        sc2, sh2 = pl.last_stats
         tdl = _cl(blk.TD.conv, _lay([d["out"], d["x"]]))
         tin = [d["out"].with_norm(sc2, sh2, ACT_LEAKY), d["x"].with_norm(sc, sh, ACT_LEAKY)]
         if pools[i] and not training:

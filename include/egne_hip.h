@@ -84,6 +84,12 @@ typedef struct {
   int64_t out_pix_stride;
   int32_t out_ch_off;
   int32_t Cout_store;         /* channels written (logical Cout rounded up to the slice's padding) */
+  /* Optional (egne_conv3x3_halo_f16_fwd, egne_conv1x1_3x3_fused_f16_fwd): per-(frame, chunk, channel) partial sums of the
+   * STORED output values, [B][stats_nchunk][Cout_store][2] doubles (sum, sum of squares), for a following
+   * egne_norm_stats_finish -- the InstanceNorm statistics of the consumer (models/RITnet_v2.py:40,57) without another
+   * pass over the tensor.  A chunk is one wave's rows of one tile: stats_nchunk = ceil(W/32) * ceil(H/8) * 4. */
+  double* stats_ws;
+  int32_t stats_nchunk;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
@@ -203,6 +209,11 @@ int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int per_sample);
 int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW,
                     int per_sample, float eps, float* scale, float* shift,
                     float* mean_out, float* var_out, void* ws, void* stream);
+
+/* Second stage of egne_norm_stats on partial sums that a convolution wrote from its epilogue (egne_conv_desc.stats_ws):
+ * ws [B][nchunk][Cp][2] doubles -> scale = rstd, shift = -mean*rstd ([B][Cp]); fixed summation order (deterministic). */
+int egne_norm_stats_finish(const void* ws, int Cp, int B, int nchunk, int HW, float eps, float* scale, float* shift,
+                           void* stream);
 
 /* y = x*scale[c] + shift[c] in place over an NHWC slice (training-mode BatchNorm apply). */
 int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix,

@@ -627,3 +627,49 @@ def test_msblock_dilated_group_one_launch(G, B, H, W, stride_pad):
         got = oc[..., 8:40].permute(0, 3, 1, 2).double()
         err = (got - truth).abs().max().item() / truth.abs().max().item()
         assert err < 2e-6, "relative error %.2e" % err
+
+
+@pytest.mark.parametrize("kind,B,H,W,C1,C2", [("halo", 3, 61, 83, 32, 32), ("halo", 2, 120, 160, 64, 96), ("pair", 3, 61, 83, 32, 32),
+                                              ("pair", 2, 37, 70, 64, 64), ("halo", 2, 60, 80, 32, 32), ("halo", 2, 64, 96, 32, 64)])
+def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C2):
+    """stats=True: the producing kernel writes per-tile partial sums of the values it stores and egne_norm_stats_finish turns
+    them into the consumer's InstanceNorm (scale, shift) (models/RITnet_v2.py:40,57: eps 1e-5, biased variance) -- compared
+    with the statistics of the stored tensor itself.  60x80 is walked transposed by the halo kernel: separate pass."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd import engine
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    pl = Plan(torch.device(DEV))
+    out = pl.buf(B, H, W, pad8(C2))
+    if kind == "halo":
+        x = _rand(G, B, C1, H, W)
+        (px,) = to_nhwc_buf(pl, [x], B, H, W)
+        w, b = _rand(G, C2, C1, 3, 3) / (3 * C1 ** 0.5), _rand(G, C2)
+        layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(C1, pad8(C1))], pad=(1, 1), act=2)
+        layer.split = True
+        pl.conv(layer, [px], Piece(out, 0, C2), B, H, W, stats=True)
+    else:
+        xs = [_rand(G, B, 32, H, W), _rand(G, B, 40, H, W)]
+        pieces = to_nhwc_buf(pl, xs, B, H, W)
+        w1, b1 = _rand(G, C1, 72, 1, 1) / 8, _rand(G, C1)
+        w2, b2 = _rand(G, C2, C1, 3, 3) / (3 * C1 ** 0.5), _rand(G, C2)
+        l1 = ConvLayer([torch.nn.Parameter(w1.to(DEV))], [torch.nn.Parameter(b1.to(DEV))], [(p.C, p.Cp) for p in pieces])
+        l2 = ConvLayer([torch.nn.Parameter(w2.to(DEV))], [torch.nn.Parameter(b2.to(DEV))], [(C1, pad8(C1))], pad=(1, 1), act=2)
+        l1.split1 = l2.split = True
+        old = engine.FUSE_1X1_MIN_W
+        engine.FUSE_1X1_MIN_W = 0
+        try:
+            pl.conv_pair(l1, pieces, l2, Piece(out, 0, C2), B, H, W, stats=True)
+        finally:
+            engine.FUSE_1X1_MIN_W = old
+    scale, shift = pl.last_stats
+    fused = pl.calls[-1][0] is pl.L.egne_norm_stats_finish
+    tall = ((H + 31) // 32) * ((W + 7) // 8) < ((W + 31) // 32) * ((H + 7) // 8)      # the halo kernel walks such maps transposed
+    assert fused == (kind == "pair" or not tall)
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        y = out.cpu().double()[..., :C2]
+        mean, var = y.mean((1, 2)), y.var((1, 2), unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        np.testing.assert_allclose(scale.cpu().numpy()[:, :C2], rstd.numpy(), rtol=2e-6)
+        np.testing.assert_allclose(shift.cpu().numpy()[:, :C2], (-mean * rstd).numpy(), rtol=2e-5, atol=2e-6)
