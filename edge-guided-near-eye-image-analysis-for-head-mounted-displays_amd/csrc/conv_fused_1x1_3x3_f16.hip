@@ -61,9 +61,13 @@ __device__ __forceinline__ void lds_barrier() {
 // NCH: 32-channel chunks of the intermediate (1x1 output = 3x3 input); WN: 32-wide output tiles of the 3x3 (CoutP2 = 32*WN);
 // TH: tile rows (8: two per consumer wave, 4: one per wave -- what two images of a 64-channel intermediate leave room for);
 // NB: batches of 4 channel groups of the 1x1's K (ceil(groups / 4)).
+// C4: the first convolution is not a 1x1 but a 3x3 / pad 1 on <= 4 input channels (utils.py:1047 convBlock: conv2(leaky(conv1(x))))
+//     with its 9 taps folded into K as in conv3x3_c4_f16.hip: group s of a pixel = the 4-channel vectors of taps 4s + 2h and
+//     4s + 2h + 1 (h = lane half), three groups, weights from egne_pack_conv3x3_c4_weight_f16; its activation is applied
+//     before the result is split into the LDS image.
 // p1: the 1x1 (slices, bias, CoutP = 32*NCH); p2: the 3x3 (bias, act, post affine, residual, output).
 // w1hi / w1lo: fragments of egne_pack_conv1x1_weight_f16; f2hi / f2lo: fragments of egne_pack_conv_weight_f16frag.
-template <int NCH, int WN, int TH, int NB>
+template <int NCH, int WN, int TH, int NB, bool C4 = false>
 __global__ __launch_bounds__(512)
 void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, const GroupTab gt, const _Float16* __restrict__ w1hi,
                           const _Float16* __restrict__ w1lo, int G1, const _Float16* __restrict__ f2hi,
@@ -135,12 +139,14 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       }
     };
 
+    int pyy, pxx;                                   // image coordinates of the lane's halo pixel (set by pixel())
     auto pixel = [&](const Tile& tl, int job, int& hp, bool& valid, int& pix) {
       hp = (wave + 4 * job) * 32 + li;
       const int hy = hp / HWd, hx = hp - hy * HWd;
       const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
       valid = hp < NPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
       pix = y * W + x;
+      pyy = y; pxx = x;
     };
     // Loads are issued UNCONDITIONALLY (groups past the end and tiles past the last one carry the out-of-range offset
     // and return zeros without touching memory): a conditionally issued load makes the compiler's vmcnt bookkeeping
@@ -150,6 +156,26 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       int hp, pix; bool valid;
       pixel(tl, job, hp, valid, pix);
       valid = valid && on;
+      if constexpr (C4) {
+        const egne_seg sg = p1.seg[0];
+        const __amdgpu_buffer_rsrc_t r =
+            make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int gg = bi * GB + u;
+          int offs[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int tap = 4 * gg + 2 * lh + t, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int yy = pyy + ky - 1, xx = pxx + kx - 1;
+            const bool ok = valid && tap < 9 && gg < G1 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            offs[t] = ok ? ((yy * W + xx) * (int)sg.pix_stride + sg.ch_off) * 4 : (int)OOB;
+          }
+          xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[0], 0, 0);
+          xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[1], 0, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int gg = bi * GB + u;
@@ -205,8 +231,13 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const f32x4 b4 = *(const f32x4*)(lbias + tn * 32 + 8 * j + 4 * lh);
-              const f32x2 v0 = {acc[tn][4 * j] * vo + b4[0] * vs, acc[tn][4 * j + 1] * vo + b4[1] * vs};
-              const f32x2 v1 = {acc[tn][4 * j + 2] * vo + b4[2] * vs, acc[tn][4 * j + 3] * vo + b4[3] * vs};
+              f32x2 v0 = {acc[tn][4 * j] * vo + b4[0] * vs, acc[tn][4 * j + 1] * vo + b4[1] * vs};
+              f32x2 v1 = {acc[tn][4 * j + 2] * vo + b4[2] * vs, acc[tn][4 * j + 3] * vo + b4[3] * vs};
+              if constexpr (C4) {                    // activation of the first convolution (scaling by a2 > 0 commutes with it)
+                const float sl = p1.act == EGNE_ACT_RELU ? 0.f : (p1.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+                v0[0] = fmaxf(v0[0], v0[0] * sl); v0[1] = fmaxf(v0[1], v0[1] * sl);
+                v1[0] = fmaxf(v1[0], v1[0] * sl); v1[1] = fmaxf(v1[1], v1[1] * sl);
+              }
               const h2 h0 = __builtin_convertvector(v0, h2), h1 = __builtin_convertvector(v1, h2);
               const h2 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2), h2);
               const h2 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2), h2);
@@ -354,7 +385,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
           const float bv = (p2.bias && nok) ? p2.bias[n] : 0.f;
           float ps = 1.f, pt = 0.f;
           if (p2.post_scale && nok) { ps = p2.post_scale[n]; pt = p2.post_shift[n]; }
-          float st_s = 0.f, st_q = 0.f;     // sum / sum of squares of this wave's stored values of channel n (stats_ws)
+          double st_s = 0., st_q = 0.;       // sum / sum of squares of this wave's stored values of channel n (stats_ws)
 #pragma unroll
           for (int tm = 0; tm < WMW; ++tm) {
             const int y = tl.y0 + row0 + tm;
@@ -378,7 +409,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
               float v = acc[tm][tn][r] * os2 + bv;
               v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
-              const float vm = c < cm ? v : 0.f;
+              const double vm = c < cm ? (double)v : 0.;
               st_s += vm; st_q += vm * vm;
             }
           }
@@ -387,7 +418,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             if (lh == 0 && n < p2.Cout_store) {
               const int tile_in_frame = (tl.y0 / TH) * tiles_x + tl.x0 / TW;
               double2* w = (double2*)p2.stats_ws + ((long long)tl.b * p2.stats_nchunk + tile_in_frame * (4 / NSPLIT) + cw / NSPLIT) * p2.Cout_store + n;
-              *w = make_double2((double)st_s, (double)st_q);
+              *w = make_double2(st_s, st_q);
             }
           }
         }
@@ -397,18 +428,18 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   }
 }
 
-template <int NCH, int WN, int TH, int NB>
+template <int NCH, int WN, int TH, int NB, bool C4 = false>
 int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const GroupTab& gt, const _Float16* w1hi, const _Float16* w1lo,
                  int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
   const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0);
-  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024) == hipSuccess;
   if (!once || lds > 160 * 1024) return egne::fail(EGNE_ERR_LAUNCH, "conv_fused_1x1_3x3: %zu bytes of LDS", lds);
   int gx = 256;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
+  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
                      a2, os2, tiles_x, tiles_y, ntiles);
   return egne::check_launch("egne_conv1x1_3x3_fused_f16_fwd");
 }
@@ -477,4 +508,35 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                        : launch_fused<2, WN_, 4, 6>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
   return d2.CoutP == 32 ? EGNE_FUSED2(1) : EGNE_FUSED2(2);
 #undef EGNE_FUSED2
+}
+
+// The same with a 3x3 / pad 1 convolution on <= 4 input channels in front (utils.py:1047-1048 convBlock: conv1 -> LeakyReLU ->
+// conv2 -> LeakyReLU [-> eval BatchNorm as d2's post affine]): d1 = that convolution (one slice of >= 4 padded channels,
+// CoutP = 32, its activation applied before the 3x3), c4hi / c4lo = egne_pack_conv3x3_c4_weight_f16 with CoutP 32.
+extern "C" int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const egne_conv_desc* dp2, const void* c4hi, const void* c4lo,
+                                                float a1, float w1_scale, const void* f2hi, const void* f2lo, float a2, float w2_scale,
+                                                void* stream) {
+  EGNE_REQUIRE(dp1 && dp2 && c4hi && c4lo && f2hi && f2lo, "conv_fused_c4_3x3: null pointer");
+  const egne_conv_desc& d1 = *dp1;
+  const egne_conv_desc& d2 = *dp2;
+  EGNE_REQUIRE(d1.kh == 3 && d1.kw == 3 && d1.stride == 1 && d1.pad_h == 1 && d1.pad_w == 1 && d1.pad_mode == 0 && d1.ngroups == 1 &&
+               d1.dil[0] == 1 && d1.nseg == 1 && !d1.residual && !d1.post_scale && d1.CoutP == 32, "conv_fused_c4_3x3: first descriptor");
+  const egne_seg& g = d1.seg[0];
+  EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && g.Cp >= 4 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
+               ((uintptr_t)g.ptr & 15) == 0 && g.ch_off + 4 <= g.pix_stride && (long long)d1.H * d1.W * g.pix_stride * 4 < (1ll << 31),
+               "conv_fused_c4_3x3: input slice");
+  EGNE_REQUIRE(d2.kh == 3 && d2.kw == 3 && d2.stride == 1 && d2.pad_mode == 0 && d2.ngroups == 1 && d2.pad_h == 1 && d2.pad_w == 1 &&
+               d2.dil[0] == 1 && d2.Ho == d2.H && d2.Wo == d2.W && d2.B == d1.B && d2.H == d1.H && d2.W == d1.W && d2.Ktot == 32 &&
+               d2.CoutP == 32, "conv_fused_c4_3x3: 3x3 descriptor");
+  EGNE_REQUIRE(d2.out && d2.Cout_store <= d2.CoutP && d2.out_ch_off + d2.Cout_store <= d2.out_pix_stride &&
+               (long long)d2.H * d2.W * d2.out_pix_stride * 4 < (1ll << 31) &&
+               (!d2.residual || (long long)d2.H * d2.W * d2.res_pix_stride * 4 < (1ll << 31)), "conv_fused_c4_3x3: output");
+  EGNE_REQUIRE(!d2.stats_ws || (((uintptr_t)d2.stats_ws & 15) == 0 && d2.stats_nchunk == ((d2.W + 31) / 32) * ((d2.H + 7) / 8) * 4),
+               "conv_fused_c4_3x3: stats_nchunk must be tiles * 4");
+  EGNE_REQUIRE(((uintptr_t)c4hi & 15) == 0 && ((uintptr_t)c4lo & 15) == 0 && ((uintptr_t)f2hi & 15) == 0 && ((uintptr_t)f2lo & 15) == 0 &&
+               a1 > 0.f && a2 > 0.f && w1_scale > 0.f && w2_scale > 0.f && (!d1.bias || ((uintptr_t)d1.bias & 15) == 0), "conv_fused_c4_3x3: weights / scales");
+  GroupTab gt;
+  for (int k = 0; k < MAXG; ++k) gt.v[k] = 0;
+  return launch_fused<1, 1, 8, 1, true>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 3, (const _Float16*)f2hi, (const _Float16*)f2lo,
+                                        a1, 1.0f / (a1 * w1_scale), a2, 1.0f / (a2 * w2_scale), (hipStream_t)stream);
 }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
         float ps = 1.f, pt = 0.f;
         if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
-        float st_s = 0.f, st_q = 0.f;       // sum / sum of squares of this wave's stored values of channel n (stats_ws)
+        double st_s = 0., st_q = 0.;         // sum / sum of squares of this wave's stored values of channel n (stats_ws)
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             float v = acc[tm][tn][r] * out_scale + bv;
             v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
-            const float vm = c < cm ? v : 0.f;
+            const double vm = c < cm ? (double)v : 0.;
             st_s += vm; st_q += vm * vm;
           }
           acc[tm][tn] = (f32x16)(0.f);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           if (lh == 0 && n < p.Cout_store) {
             const int tile_in_frame = (cur.y0 / TH) * tiles_x + cur.x0 / TW;
             double2* w = (double2*)p.stats_ws + ((long long)cur.b * p.stats_nchunk + tile_in_frame * 4 + wave) * p.Cout_store + n;
-            *w = make_double2((double)st_s, (double)st_q);
+            *w = make_double2(st_s, st_q);
           }
         }
       }

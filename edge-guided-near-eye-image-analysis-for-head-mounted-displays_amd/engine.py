@@ -673,6 +673,15 @@ class Plan:
                  and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
                  and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP in (32, 64)
                  and W >= FUSE_1X1_MIN_W and all(H * W * pc.stride < 2 ** 29 for pc in pieces) and H * W * dst.stride < 2 ** 29)
+        # convBlock (utils.py:1047-1048): a 3x3 on <= 4 input channels in front of the 3x3 -- same kernel, taps folded into K
+        fused_c4 = (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
+                    and l1.stride == 1 and l1.G == 1 and l1.pad == (1, 1) and l1.pad_mode == 0 and l1.dils[0] == 1 and l1.Cin <= 4
+                    and l1.post is None and len(pieces) == 1 and pieces[0].scale is None and pieces[0].Cp >= 4 and l1.CoutP == 32
+                    and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
+                    and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP == 32
+                    and W >= FUSE_1X1_MIN_W and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29)
+        if fused_c4:
+            return self._conv_pair_c4(l1, pieces[0], l2, dst, B, H, W, residual, name, stats)
         if not fused:
             if tmp is None:
                 tmp = Piece(self.buf(B, H, W, pad8(l1.Cout)), 0, l1.Cout)
@@ -730,6 +739,59 @@ class Plan:
                   (C.byref(d1), C.byref(d2), l1.s1hi.data_ptr(), l1.s1lo.data_ptr(), F16X3_ASCALE, l1.w_scale1,
                    l2.fhi.data_ptr(), l2.flo.data_ptr(), F16X3_ASCALE, l2.w_scale), name, flops=flops, kind="conv_f16x3:fused1x1",
                   cal=(rescale, list(pieces), B * H * W))
+        if fuse_stats:
+            self.last_stats = self._stats_finish(ws, d2, B, H * W, nchunk, name)
+        elif stats:
+            self.last_stats = self.norm_stats(dst, B, H * W, name=name + ".stats")[:2]
+        return H, W
+
+    def _conv_pair_c4(self, l1, src, l2, dst, B, H, W, residual, name, stats):
+        l1.need_c4h = True
+        l1.need_flat = True
+        l2.need_sfrag = True
+        for l in (l1, l2):
+            if l not in self.layers:
+                self.layers.append(l)
+            l.ensure_packed(self.device)
+        assert l1.c4_coutp == 32
+        d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        for d, l in ((d1, l1), (d2, l2)):
+            d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
+            d.kh, d.kw, d.stride = 3, 3, 1
+            d.pad_h, d.pad_w, d.pad_mode, d.ngroups = 1, 1, 0, 1
+            for g in range(_lib.MAXGROUP):
+                d.dil[g] = 1
+            d.bias = l.bp.data_ptr() if l.biases is not None else None
+            d.act = l.act
+        d1.nseg = 1
+        sg = d1.seg[0]
+        sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp, sg.act_in = src.ptr, src.stride, src.off, src.Cp, ACT_NONE
+        d1.Ktot, d1.CoutP = src.Cp, 32
+        d2.nseg = 0
+        d2.Ktot, d2.CoutP = 32, 32
+        if l2.post is not None:
+            d2.post_scale, d2.post_shift = l2.post[0].data_ptr(), l2.post[1].data_ptr()
+        if residual is not None:
+            d2.residual, d2.res_pix_stride, d2.res_ch_off = residual.ptr, residual.stride, residual.off
+        d2.out, d2.out_pix_stride, d2.out_ch_off = dst.ptr, dst.stride, dst.off
+        d2.Cout_store = min(l2.Cout_store, dst.Cp)
+        self.keep += [d1, d2]
+
+        def rescale(args, vmax, l1=l1):
+            with torch.no_grad():
+                bound = vmax * float(l1.weights[0].detach().abs().sum(dim=(1, 2, 3)).max())
+                if l1.biases is not None and l1.biases[0] is not None:
+                    bound += float(l1.biases[0].detach().abs().max())
+            return args[:4] + (_a_scale_for(vmax),) + args[5:8] + (_a_scale_for(bound),) + args[9:]
+        flops = 2.0 * B * H * W * 9 * (l1.Cout * l1.Cin + l2.Cout * l2.Cin)
+        fuse_stats = stats and STATS_FUSED and dst.Cp == int(d2.Cout_store)
+        nchunk = ((W + 31) // 32) * ((H + 7) // 8) * 4
+        if fuse_stats:
+            ws = self._stats_ws(d2, B, nchunk)
+        self._add(self.L.egne_conv3x3c4_3x3_fused_f16_fwd,
+                  (C.byref(d1), C.byref(d2), l1.c4hi.data_ptr(), l1.c4lo.data_ptr(), F16X3_ASCALE, l1.w_scale_c4,
+                   l2.fhi.data_ptr(), l2.flo.data_ptr(), F16X3_ASCALE, l2.w_scale), name, flops=flops, kind="conv_f16x3:fused3x3c4",
+                  cal=(rescale, [src], B * H * W))
         if fuse_stats:
             self.last_stats = self._stats_finish(ws, d2, B, H * W, nchunk, name)
         elif stats:

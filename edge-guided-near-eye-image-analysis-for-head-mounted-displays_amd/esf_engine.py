@@ -170,20 +170,20 @@ def build_forward_plan(model, B, H, W, dev, training):
     D = [dbuf(i) for i in range(5)]
 
     t0 = pl.buf(NB, H, W, pad8(chz))
-    l = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
+    l1 = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
     xin_p = Piece(xin, 0, in_c, 8)
     xin_p.nograd = True
-    pl.conv(l, [xin_p], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
     l = _cl(enc.head.conv2, [(chz, pad8(chz))], pad=(1, 1), act=ACT_LEAKY)
+    x_stats = None
     if not training:
         fold = _BNFold(enc.head.bn, l.CoutP, dev)
         pl.pre.append(fold.guard)
         l.post = (fold.scale, fold.shift)
-    x_stats = None
-    if not training:
-        pl.conv(l, [Piece(t0, 0, chz)], D[0]["x"], NB, H, W, name="enc.head.conv2", stats=True)
-        x_stats = pl.last_stats          # InstanceNorm statistics of block 0's input, from the conv's epilogue
+        # conv2(leaky(conv1(x))) as one launch where the kernel allows it; InstanceNorm statistics of block 0's input from its epilogue
+        pl.conv_pair(l1, [xin_p], l, D[0]["x"], NB, H, W, tmp=Piece(t0, 0, chz), name="enc.head", stats=True)
+        x_stats = pl.last_stats
     else:
+        pl.conv(l1, [xin_p], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
         pre = pl.buf(NB, H, W, pad8(chz))
         pl.conv(l, [Piece(t0, 0, chz)], Piece(pre, 0, chz), NB, H, W, name="enc.head.conv2")
         _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn")

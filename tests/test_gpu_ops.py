@@ -673,3 +673,48 @@ def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C
         rstd = 1.0 / torch.sqrt(var + 1e-5)
         np.testing.assert_allclose(scale.cpu().numpy()[:, :C2], rstd.numpy(), rtol=2e-6)
         np.testing.assert_allclose(shift.cpu().numpy()[:, :C2], (-mean * rstd).numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("Cin,B,H,W,post", [(1, 3, 61, 83, True), (2, 2, 240, 320, True), (3, 2, 33, 64, False)])
+def test_convblock_pair_fused(G, Cin, B, H, W, post):
+    """utils.py:1047-1048 convBlock: conv2(leaky(conv1(x))) with conv1 on 1-3 channels, as ONE launch (the first conv's 9 taps
+    folded into K on each tile's halo, its result kept in LDS), LeakyReLU + eval-BatchNorm affine in the epilogue, against float64."""
+    from gpu_util import DEV
+    from egne_amd import engine
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    x = _rand(G, B, Cin, H, W) * 2
+    w1, b1 = _rand(G, 32, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, 32)
+    w2, b2 = _rand(G, 32, 32, 3, 3) / (3 * 32 ** 0.5), _rand(G, 32)
+    t = F.leaky_relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1), 0.01)
+    truth = F.leaky_relu(F.conv2d(t, w2.double(), b2.double(), padding=1), 0.01)
+    pl = Plan(torch.device(DEV))
+    xin = pl.buf(B, H, W, 8)
+    xin[..., :Cin] = x.permute(0, 2, 3, 1).to(DEV)
+    l1 = ConvLayer([torch.nn.Parameter(w1.to(DEV))], [torch.nn.Parameter(b1.to(DEV))], [(Cin, 8)], pad=(1, 1), act=2)
+    l2 = ConvLayer([torch.nn.Parameter(w2.to(DEV))], [torch.nn.Parameter(b2.to(DEV))], [(32, 32)], pad=(1, 1), act=2)
+    l1.split = l2.split = True
+    if post:
+        ps, pt = _rand(G, 32).abs() + 0.5, _rand(G, 32)
+        truth = truth * ps.double()[None, :, None, None] + pt.double()[None, :, None, None]
+        l2.post = (ps.to(DEV), pt.to(DEV))
+    out = pl.buf(B, H, W, 48)
+    out.fill_(777.0)
+    old = engine.FUSE_1X1_MIN_W
+    engine.FUSE_1X1_MIN_W = 0
+    try:
+        pl.conv_pair(l1, [Piece(xin, 0, Cin, 8)], l2, Piece(out, 8, 32), B, H, W, stats=True)
+    finally:
+        engine.FUSE_1X1_MIN_W = old
+    assert pl.calls[0][0] is pl.L.egne_conv3x3c4_3x3_fused_f16_fwd and len(pl.calls) == 2
+    scale, shift = pl.last_stats
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        o = out.cpu()
+        assert (o[..., :8] == 777.0).all() and (o[..., 40:] == 777.0).all()
+        got = o[..., 8:40].permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 3e-6, "relative error %.2e" % err
+        y = o[..., 8:40].double()
+        rstd = 1.0 / torch.sqrt(y.var((1, 2), unbiased=False) + 1e-5)
+        np.testing.assert_allclose(scale.cpu().numpy(), rstd.numpy(), rtol=2e-6)
