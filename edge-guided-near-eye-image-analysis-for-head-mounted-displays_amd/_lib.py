@@ -67,6 +67,7 @@ SIGNATURES = {
     "egne_conv3x3_halo_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_conv1x1_3x3_fused_f16_fwd": (i32, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), vp, vp, f32, f32, vp, vp, f32, f32, vp]),
     "egne_conv3x3c4_3x3_fused_f16_fwd": (i32, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), vp, vp, f32, f32, vp, vp, f32, f32, vp]),
+    "egne_msblock_dil_scores_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp, vp, vp, vp, i32, vp]),
     "egne_msblock_dil_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_conv1x1_f16x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_dist_maps_workspace_bytes": (i64, [i32, i32, i32, i32]),

@@ -18,6 +18,10 @@ import torch.nn as nn
 from . import _lib
 from .engine import ACT_RELU, ConvLayer, Piece, Plan, VersionGuard, maxpool_out, pad8, require_cuda
 
+import os
+
+SCORES_FUSED = os.environ.get("EGNE_SCORES_FUSED", "1") != "0"     # stage score heads in the epilogue of the MSBlock kernel
+
 # (name, cin, cout, dilation) / pool markers; vgg16_c.py:11-39
 _VGG = [("conv1_1", 3, 64, 1), ("conv1_2", 64, 64, 1), ("P", 2),
         ("conv2_1", 64, 128, 1), ("conv2_2", 128, 128, 1), ("P", 2),
@@ -153,7 +157,25 @@ class BDCN(nn.Module):
             ms_bufs = []
             h_s, w_s = feats[fi][2], feats[fi][3]
             o_buf = pl.buf(B, h_s, w_s, 32)
-            for b in blocks:
+            nb = len(blocks)
+            dn = [getattr(self, "conv%s_down" % b) for b in blocks]
+            sa, sb = getattr(self, "score_dsn" + st), getattr(self, "score_dsn%s_1" % st)
+            s = pl.vec(B, h_s, w_s)
+            s1 = pl.vec(B, h_s, w_s)
+            # Score heads fused into the dilated-branch kernel (bdcn_new.py:118-166 is linear after the MSBlock): per block
+            # and head ONE 32-vector  head_w[21] @ down_w[21, 32]; the constant  head_w @ sum_k down_b[k] + head_b  rides with
+            # the stage's first block.  The 32-channel block outputs are then never written.
+            cw, cc = pl.vec(nb, 2, 32), pl.vec(2)
+
+            def refresh_scores(cw=cw, cc=cc, dn=dn, sa=sa, sb=sb):
+                with torch.no_grad():
+                    heads = torch.stack([sa.weight.detach().reshape(21), sb.weight.detach().reshape(21)])      # [2, 21]
+                    for k, m in enumerate(dn):
+                        cw[k].copy_(heads @ m.weight.detach().reshape(21, 32))
+                    bsum = torch.stack([m.bias.detach() for m in dn]).sum(0)
+                    cc.copy_(heads @ bsum + torch.cat([sa.bias.detach(), sb.bias.detach()]))
+            fused_scores = None
+            for bi, b in enumerate(blocks):
                 src, c_in, hh, ww = feats[fi]
                 fi += 1
                 mb = getattr(self, "msblock" + b)
@@ -167,33 +189,36 @@ class BDCN(nn.Module):
                                [mb.conv1.bias, mb.conv2.bias, mb.conv3.bias], [(32, 32)], pad=(1, 1), dils=dil,
                                act=ACT_RELU)
                 lg.split = True
-                msb = pl.buf(B, hh, ww, 32)
-                pl.conv(lg, [o], Piece(msb, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b)
-                ms_bufs.append(msb)
-            nb = len(blocks)
-            wd, bd = pl.vec(nb, 21, 32), pl.vec(nb, 21)
-            heads = pl.vec(2, 21)
-            hb = pl.vec(2)
-            dn = [getattr(self, "conv%s_down" % b) for b in blocks]
-            sa, sb = getattr(self, "score_dsn" + st), getattr(self, "score_dsn%s_1" % st)
+                if fused_scores is None:
+                    fused_scores = SCORES_FUSED and pl.msdil_ok(lg, o, hh, ww)
+                    if fused_scores:
+                        pl.pre.append(VersionGuard([p for m in dn + [sa, sb] for p in (m.weight, m.bias)], refresh_scores))
+                if fused_scores:
+                    pl.conv(lg, [o], Piece(o_buf, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b, scores=(cw[bi], cc, s, s1, bi > 0))
+                else:
+                    msb = pl.buf(B, hh, ww, 32)
+                    pl.conv(lg, [o], Piece(msb, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b)
+                    ms_bufs.append(msb)
+            if not fused_scores:
+                wd, bd = pl.vec(nb, 21, 32), pl.vec(nb, 21)
+                heads = pl.vec(2, 21)
+                hb = pl.vec(2)
 
-            def refresh(wd=wd, bd=bd, heads=heads, hb=hb, dn=dn, sa=sa, sb=sb):
-                with torch.no_grad():
-                    for k, m in enumerate(dn):
-                        wd[k].copy_(m.weight.detach().reshape(21, 32))
-                        bd[k].copy_(m.bias.detach())
-                    heads[0].copy_(sa.weight.detach().reshape(21))
-                    heads[1].copy_(sb.weight.detach().reshape(21))
-                    hb[0:1].copy_(sa.bias.detach())
-                    hb[1:2].copy_(sb.bias.detach())
-            pl.pre.append(VersionGuard([p for m in dn + [sa, sb] for p in (m.weight, m.bias)], refresh))
-            s = pl.vec(B, h_s, w_s)
-            s1 = pl.vec(B, h_s, w_s)
-            arr = (C.c_void_p * nb)(*[t.data_ptr() for t in ms_bufs])
-            pl.keep.append(arr)
-            pl.raw(L.egne_bdcn_stage_scores,
-                   (arr, nb, 32, B * h_s * w_s, wd.data_ptr(), bd.data_ptr(), heads.data_ptr(), hb.data_ptr(),
-                    heads.data_ptr() + 4 * 21, hb.data_ptr() + 4, s.data_ptr(), s1.data_ptr()), "bdcn.scores" + st)
+                def refresh(wd=wd, bd=bd, heads=heads, hb=hb, dn=dn, sa=sa, sb=sb):
+                    with torch.no_grad():
+                        for k, m in enumerate(dn):
+                            wd[k].copy_(m.weight.detach().reshape(21, 32))
+                            bd[k].copy_(m.bias.detach())
+                        heads[0].copy_(sa.weight.detach().reshape(21))
+                        heads[1].copy_(sb.weight.detach().reshape(21))
+                        hb[0:1].copy_(sa.bias.detach())
+                        hb[1:2].copy_(sb.bias.detach())
+                pl.pre.append(VersionGuard([p for m in dn + [sa, sb] for p in (m.weight, m.bias)], refresh))
+                arr = (C.c_void_p * nb)(*[t.data_ptr() for t in ms_bufs])
+                pl.keep.append(arr)
+                pl.raw(L.egne_bdcn_stage_scores,
+                       (arr, nb, 32, B * h_s * w_s, wd.data_ptr(), bd.data_ptr(), heads.data_ptr(), hb.data_ptr(),
+                        heads.data_ptr() + 4 * 21, hb.data_ptr() + 4, s.data_ptr(), s1.data_ptr()), "bdcn.scores" + st)
             tail.s[si], tail.s1[si] = s.data_ptr(), s1.data_ptr()
             tail.h[si], tail.w[si] = h_s, w_s
             if st in _UPS:

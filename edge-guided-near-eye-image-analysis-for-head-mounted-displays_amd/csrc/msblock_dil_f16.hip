@@ -46,7 +46,8 @@ __device__ __forceinline__ void lds_barrier() {
 template <int D0, int D1, int D2, int NPW>       // NPW: producer waves (4 or 8); 4 consumer waves follow them
 __global__ __launch_bounds__(64 * (NPW + 4))
 void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
-                        float out_scale, int tiles_x, int tiles_y, int ntiles) {
+                        float out_scale, int tiles_x, int tiles_y, int ntiles, const float* __restrict__ score_w,
+                        const float* __restrict__ score_c, float* __restrict__ s0, float* __restrict__ s1, int accumulate) {
   constexpr int DMAX = D2 > D1 ? (D2 > D0 ? D2 : D0) : (D1 > D0 ? D1 : D0);
   constexpr int SWMAX = TW + 2 * DMAX, NPXMAX = TH * SWMAX;
   // LDS: two strip buffers [hi | lo][NPXMAX][32 halfs] -- 64 bytes per pixel and half, NO padding: the 16-byte chunk c of
@@ -227,6 +228,9 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       const int cmax = xl < W ? W - xl : 0;
       const bool nok = li < p.Cout_store;
       const float b0 = p.bias ? p.bias[li] : 0.f, b1 = p.bias ? p.bias[p.CoutP + li] : 0.f, b2 = p.bias ? p.bias[2 * p.CoutP + li] : 0.f;
+      // optional: this block's share of the stage's two score maps (bdcn_new.py:118-166: 1x1 "down" conv 32 -> 21, summed over
+      // the stage's blocks, then the two 21 -> 1 heads -- all linear, so per block and head ONE 32-vector, score_w[2][32])
+      const float cw0 = score_w ? score_w[li] : 0.f, cw1 = score_w ? score_w[32 + li] : 0.f;
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
         const int y = tl.y0 + cw * 2 + tm;
@@ -234,7 +238,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
         const int pix = y * W + xl;
         const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + li) * 4);
         const unsigned r0 = (unsigned)((pix * (int)p.res_pix_stride + p.res_ch_off + li) * 4);
-        float rv[16];
+        float rv[16], sc[32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = (r & 3) + 8 * (r >> 2);
@@ -245,7 +249,29 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
           const int c = (r & 3) + 8 * (r >> 2);
           const float v = fmaxf(acc[0][tm][r] * out_scale + b0, 0.f) + fmaxf(acc[1][tm][r] * out_scale + b1, 0.f) +
                           fmaxf(acc[2][tm][r] * out_scale + b2, 0.f) + rv[r];      // o + o1 + o2 + o3 (bdcn_new.py:54)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+          if (p.out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
+          sc[r] = v * cw0; sc[16 + r] = v * cw1;
+        }
+        if (score_w) {
+          // sum over the 32 channels (= lanes of one half): transpose-reduce, 31 exchanges for the 32 (head, pixel) values;
+          // lane li ends up with the total of value li = (head li >> 4, pixel register li & 15)
+          auto stage = [&](auto stc) {
+            constexpr int ST = decltype(stc)::value;
+            const bool up = (li & ST) != 0;
+#pragma unroll
+            for (int j = 0; j < ST; ++j) {
+              const float send = up ? sc[j] : sc[j + ST], keep = up ? sc[j + ST] : sc[j];
+              sc[j] = keep + __shfl_xor(send, ST);
+            }
+          };
+          stage(std::integral_constant<int, 16>{}); stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 4>{});
+          stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 1>{});
+          const int r = li & 15, c = (r & 3) + 8 * (r >> 2), x = xl + c;
+          if (y < H && x < W) {
+            float* dstp = ((li >> 4) ? s1 : s0) + ((long long)tl.b * H + y) * W + x;
+            const float t = sc[0] + (accumulate ? *dstp : score_c[li >> 4]);
+            *dstp = t;
+          }
         }
       }
     }
@@ -258,34 +284,34 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
 // d: the grouped dilated convolution of an MSBlock exactly as egne_conv2d_f16x3_fwd takes it (ngroups = 3, 3x3, pad 1,
 // dil = {4, 8, 12}, one raw 32-channel input slice, CoutP = 32, bias [3][32], act = ReLU, residual = the input, out).
 // fhi / flo: egne_pack_conv_weight_f16frag per group, 9 * 32 * 32 halfs each, consecutive.
-extern "C" int egne_msblock_dil_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
-                                        void* stream) {
+extern "C" int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                               const float* score_w, const float* score_c, float* s0, float* s1, int accumulate,
+                                               void* stream) {
   EGNE_REQUIRE(dp && fhi && flo, "msblock_dil: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_mode == 0 && d.ngroups == 3 && d.pad_h == 1 && d.pad_w == 1 &&
                d.dil[0] == 4 && d.dil[1] == 8 && d.dil[2] == 12 && d.Ho == d.H && d.Wo == d.W && d.nseg == 1 && d.CoutP == 32 &&
-               d.Ktot == 32 && d.act == EGNE_ACT_RELU && !d.post_scale && d.residual && d.out, "msblock_dil: descriptor");
+               d.Ktot == 32 && d.act == EGNE_ACT_RELU && !d.post_scale && d.residual && (d.out || score_w), "msblock_dil: descriptor");
   const egne_seg& g = d.seg[0];
   EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && g.Cp == 32 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
                ((uintptr_t)g.ptr & 15) == 0 && (long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31), "msblock_dil: input slice");
-  EGNE_REQUIRE(d.Cout_store <= 32 && d.out_ch_off + d.Cout_store <= d.out_pix_stride && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
+  EGNE_REQUIRE(d.Cout_store <= 32 && (!d.out || (d.out_ch_off + d.Cout_store <= d.out_pix_stride && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31))) &&
                (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31), "msblock_dil: output / residual");
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "msblock_dil: weights / scales");
+  EGNE_REQUIRE(!score_w || (score_c && s0 && s1 && d.Cout_store == 32), "msblock_dil: score maps need score_c, s0, s1 and all 32 channels");
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B;
   constexpr size_t lds = ((size_t)2 * 2 * TH * (TW + 24) * 32 + 2 * 12 * 512) * sizeof(_Float16);
-  static bool once = hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  static bool once = hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "msblock_dil: cannot raise the dynamic LDS limit to %zu", lds);
-  // 4 producer waves measured faster than 8 (1.43 vs 1.52 ms at 64 x 240 x 320: three waves per SIMD leave 168 registers)
-  static const int npw = [] { const char* e = getenv("EGNE_MSDIL_NPW"); return e ? atoi(e) : 4; }();
   int gx = 256;
   if (gx > ntiles) gx = ntiles;
-  if (npw == 4)
-    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4>), dim3(gx), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
-                       (const _Float16*)flo, a_scale, 1.0f / (a_scale * w_scale), tiles_x, tiles_y, ntiles);
-  else
-    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 8>), dim3(gx), dim3(768), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
-                       (const _Float16*)flo, a_scale, 1.0f / (a_scale * w_scale), tiles_x, tiles_y, ntiles);
+  hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4>), dim3(gx), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+                     (const _Float16*)flo, a_scale, 1.0f / (a_scale * w_scale), tiles_x, tiles_y, ntiles, score_w, score_c, s0, s1, accumulate);
   return egne::check_launch("egne_msblock_dil_f16_fwd");
+}
+
+extern "C" int egne_msblock_dil_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                        void* stream) {
+  return egne_msblock_dil_scores_f16_fwd(dp, fhi, flo, a_scale, w_scale, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }

@@ -454,7 +454,13 @@ class Plan:
                   name + ".stats", kind="norm_stats")
         return scale, shift
 
-    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False):
+    def msdil_ok(self, layer, piece, H, W):
+        """True if pl.conv will run this grouped dilated MSBlock convolution on the one-launch kernel (msblock_dil_f16.hip)."""
+        return (F16X3_ENABLED and layer.split and MSDIL_ENABLED and layer.G == 3 and layer.kh == 3 and layer.kw == 3
+                and layer.pad == (1, 1) and layer.dils == (4, 8, 12) and layer.CoutP == 32 and piece.Cp == 32 and piece.scale is None
+                and layer.act == ACT_RELU and layer.post is None and H * W * piece.stride < 2 ** 29)
+
+    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None):
         """pieces: input Pieces in concat order; dst: output Piece.  Returns (Ho, Wo); with ``stats`` also leaves the
         per-sample InstanceNorm (scale, shift) of the OUTPUT in ``self.last_stats`` -- from partial sums written by the
         kernel's epilogue where the kernel can do that, from a separate statistics pass otherwise."""
@@ -615,6 +621,15 @@ class Plan:
         elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
                                                       layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1", cal=cal3)
+        elif msdil and scores is not None:
+            # the block's output is consumed by the stage's score heads only: they are evaluated in the epilogue and the
+            # 32-channel map is never stored (scores = (weights [2][32], constants [2], s, s1, accumulate))
+            cw_, cc_, s0_, s1_, accum = scores
+            d.out = None
+            self._add(self.L.egne_msblock_dil_scores_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
+                                                               layer.w_scale, cw_.data_ptr(), cc_.data_ptr(), s0_.data_ptr(),
+                                                               s1_.data_ptr(), int(accum)), name, flops=flops,
+                      kind="conv_f16x3:msdil", cal=cal3)
         elif msdil:
             self._add(self.L.egne_msblock_dil_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:msdil", cal=cal3)
@@ -656,6 +671,7 @@ class Plan:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
+        assert scores is None or msdil, "score fusion needs the one-launch MSBlock kernel (check Plan.msdil_ok first)"
         if stats:
             self.last_stats = self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2]
         if self.train:

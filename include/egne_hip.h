@@ -142,6 +142,13 @@ int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* d, const void* fhi, const vo
  * is read once and out written once (round 1: three launches accumulating through HBM). */
 int egne_msblock_dil_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
                              void* stream);
+/* ... with the stage's score heads in the epilogue (bdcn_new.py:118-166: conv*_down 32 -> 21 summed over the stage's blocks,
+ * then score_dsn* / score_dsn*_1 21 -> 1; linear, so per block and head one 32-vector): s0[p] (+)= score_w[0] . out[p],
+ * s1[p] (+)= score_w[1] . out[p]; the first block of a stage (accumulate = 0) also adds the constants score_c[2].  With
+ * d->out == NULL the 32-channel block output is not stored at all (nothing else reads it). */
+int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                    const float* score_w, const float* score_c, float* s0, float* s1, int accumulate,
+                                    void* stream);
 
 /* Streaming 1x1 convolution over a concatenation of raw NHWC slices (models/RITnet_v2.py:59,61,84,86 conv21 / conv31 /
  * conv11, :38 Transition_down in eval plans) on the split-f16 path: no staging, every lane loads its MFMA operand

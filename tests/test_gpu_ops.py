@@ -718,3 +718,44 @@ def test_convblock_pair_fused(G, Cin, B, H, W, post):
         y = o[..., 8:40].double()
         rstd = 1.0 / torch.sqrt(y.var((1, 2), unbiased=False) + 1e-5)
         np.testing.assert_allclose(scale.cpu().numpy(), rstd.numpy(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 240, 320), (3, 29, 39), (2, 61, 83)])
+def test_msblock_dilated_group_with_fused_scores(G, B, H, W):
+    """egne_msblock_dil_scores_f16_fwd: the two score maps of a BDCN stage accumulated from the epilogues of its blocks
+    (s = sum_k w_k . out_k + c), block outputs never stored, against float64."""
+    from gpu_util import DEV
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    pl = Plan(torch.device(DEV))
+    s0, s1 = pl.vec(B, H, W), pl.vec(B, H, W)
+    s0.fill_(123.0); s1.fill_(-5.0)            # stale contents must be overwritten by the first block
+    cc = torch.tensor([0.7, -1.3])
+    ccd = cc.to(DEV)
+    pl.keep.append(ccd)
+    want0, want1 = torch.full((B, H, W), 0.7, dtype=torch.float64), torch.full((B, H, W), -1.3, dtype=torch.float64)
+    for k in range(2):
+        o = F.relu(_rand(G, B, 32, H, W)) * 2
+        ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+        bs = [_rand(G, 32) for _ in range(3)]
+        out = o.double()
+        for w, b, d in zip(ws, bs, (4, 8, 12)):
+            out = out + F.relu(F.conv2d(o.double(), w.double(), b.double(), padding=d, dilation=d))
+        cw = _rand(G, 2, 32) / 6
+        want0 += (out * cw[0].double()[None, :, None, None]).sum(1)
+        want1 += (out * cw[1].double()[None, :, None, None]).sum(1)
+        buf = pl.buf(B, H, W, 32)
+        buf.copy_(o.permute(0, 2, 3, 1).to(DEV))
+        px = Piece(buf, 0, 32)
+        layer = ConvLayer([torch.nn.Parameter(w.to(DEV)) for w in ws], [torch.nn.Parameter(b.to(DEV)) for b in bs], [(32, 32)],
+                          pad=(1, 1), dils=(4, 8, 12), act=1)
+        layer.split = True
+        assert pl.msdil_ok(layer, px, H, W)
+        cwd = cw.to(DEV)
+        pl.keep.append(cwd)
+        pl.conv(layer, [px], px, B, H, W, residual=px, scores=(cwd, ccd, s0, s1, k > 0))
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        for got, want in ((s0, want0), (s1, want1)):
+            err = (got.cpu().double() - want).abs().max().item() / want.abs().max().item()
+            assert err < 3e-6, "relative error %.2e" % err
