@@ -35,6 +35,7 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "0") != "0"     # split-f16 FORWARD convolutions in training plans too (22-bit products)
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
 STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm statistics from the producing conv's epilogue
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
@@ -675,7 +676,13 @@ class Plan:
         if stats:
             self.last_stats = self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2]
         if self.train:
-            self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, d, B, H, W, Ho, Wo, name))
+            # the backward kernels index the exact-fp32 weight layout: undo what a split-f16 forward put into the descriptor
+            db = _lib.ConvDesc()
+            C.memmove(C.byref(db), C.byref(d), C.sizeof(_lib.ConvDesc))
+            db.B, db.Ktot, db.CoutP = B, layer.Ktot, layer.CoutP
+            db.seg[0].ptr, db.out = pieces[0].ptr, dst.ptr
+            self.keep.append(db)
+            self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
         return Ho, Wo
 
     def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False):

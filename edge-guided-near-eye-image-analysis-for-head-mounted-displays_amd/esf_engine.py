@@ -48,8 +48,9 @@ def dec_sizes(chz, growth, add_edge, variant):
 def _cl(conv, layout, pad=(0, 0), act=ACT_NONE, **kw):
     l = ConvLayer([conv.weight], [conv.bias] if conv.bias is not None else None, layout, pad=pad, act=act, **kw)
     from . import engine
-    l.split = engine.ESF_SPLIT and _cl.eval_plan and (l.kh > 1 or l.kw > 1)
-    l.split1 = engine.ESF_SPLIT and _cl.eval_plan and l.kh == 1 and l.kw == 1
+    ok = engine.ESF_SPLIT and (_cl.eval_plan or engine.TRAIN_SPLIT)
+    l.split = ok and (l.kh > 1 or l.kw > 1)
+    l.split1 = ok and l.kh == 1 and l.kw == 1
     return l
 
 

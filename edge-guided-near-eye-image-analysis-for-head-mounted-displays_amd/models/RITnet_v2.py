@@ -225,12 +225,21 @@ class DenseNet2D(nn.Module):
         self._last_plan = pl
         pl.in_img.copy_(x)
         pl.in_edge.copy_(x_edge)
-        pl.t_target.copy_(target)
-        pl.t_pc.copy_(pupil_center)
-        pl.t_eln.copy_(elNorm)
-        pl.t_spat.copy_(spatWts)
-        pl.t_dist.copy_(distMap)
-        pl.t_cond.copy_(cond)
+        # the loss head reads the caller's ground-truth tensors in place when they already have the layout it wants
+        # (contiguous, on this device, int64 / float32): its descriptor is re-read at every launch, so only pointers change
+        ld = pl.loss_desc
+        keep = []
+        for field, buf, src, dt in (("target", pl.t_target, target, torch.int64), ("spatWts", pl.t_spat, spatWts, torch.float32),
+                                    ("distMap", pl.t_dist, distMap, torch.float32), ("cond", pl.t_cond, cond, torch.float32),
+                                    ("pupil_center", pl.t_pc, pupil_center, torch.float32), ("elNorm", pl.t_eln, elNorm, torch.float32)):
+            if (torch.is_tensor(src) and src.dtype == dt and src.device == buf.device and src.is_contiguous()
+                    and tuple(src.shape) == tuple(buf.shape) and not src.requires_grad):
+                setattr(ld, field, src.data_ptr())
+                keep.append(src)
+            else:
+                buf.copy_(src)
+                setattr(ld, field, buf.data_ptr())
+        pl._inputs = keep          # alive until the next forward replaces them (the launches are asynchronous)
         pl.loss_desc.alpha = float(alpha)
         if self.disentangle and torch.is_tensor(ID):
             pl.t_id.copy_(ID.to(torch.long))
