@@ -39,22 +39,68 @@ def parse_args(argv=None):
     return a
 
 
+def resize_lanczos4(img, dsize):
+    """cv2.resize(img, dsize=(width, height), interpolation=cv2.INTER_LANCZOS4) restated in NumPy (evaluate.py:76): separable
+    8-tap Lanczos (a = 4) at source coordinate (dst + 0.5) * scale - 0.5, replicated border, uint8 in -> rounded uint8 out.
+    OpenCV is not installed here, so this is checked against properties only (parity unpinned): OpenCV quantises the tap
+    weights to 1/32-pixel tables in fixed point, which this float restatement does not."""
+    W2, H2 = int(dsize[0]), int(dsize[1])
+    src = np.asarray(img)
+    out = src.astype(np.float64)
+    for axis, n2 in ((0, H2), (1, W2)):
+        n1 = out.shape[axis]
+        if n1 == n2:
+            continue
+        pos = (np.arange(n2) + 0.5) * (n1 / n2) - 0.5
+        base = np.floor(pos).astype(np.int64)
+        frac = pos - base
+        taps = np.arange(-3, 5)                                        # 8 taps around the source position
+        x = frac[:, None] - taps[None, :]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            wts = np.where(np.abs(x) < 1e-12, 1.0, np.sin(np.pi * x) * np.sin(np.pi * x / 4) / (np.pi * np.pi * x * x / 4))
+        wts = np.where(np.abs(x) < 4, wts, 0.0)
+        wts /= wts.sum(1, keepdims=True)
+        idx = np.clip(base[:, None] + taps[None, :], 0, n1 - 1)        # BORDER_REPLICATE
+        g = np.take(out, idx.reshape(-1), axis=axis)
+        shp = list(out.shape)
+        shp[axis:axis + 1] = [n2, 8]
+        g = g.reshape(shp)
+        wshape = [1] * g.ndim
+        wshape[axis], wshape[axis + 1] = n2, 8
+        out = (g * wts.reshape(wshape)).sum(axis + 1)
+    if src.dtype == np.uint8:
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out.astype(src.dtype)
+
+
+def resize_nearest(img, dsize):
+    """cv2.resize(..., interpolation=cv2.INTER_NEAREST): src index = floor(dst * scale) (evaluate.py:190-191)."""
+    W2, H2 = int(dsize[0]), int(dsize[1])
+    a = np.asarray(img)
+    ys = np.minimum((np.arange(H2) * (a.shape[0] / H2)).astype(np.int64), a.shape[0] - 1)
+    xs = np.minimum((np.arange(W2) * (a.shape[1] / W2)).astype(np.int64), a.shape[1] - 1)
+    return a[ys][:, xs]
+
+
 def preprocess_frame(img, op_shape, align_width=True):
-    """evaluate.py:69-104: fit to 240x320 by width, pad/crop rows, z-score.  Resizing needs cv2's Lanczos;
-    frames that already have the target width (the example video: 320 per eye) pass straight through."""
+    """evaluate.py:69-104: scale to the target WIDTH (Lanczos), pad or centre-crop the rows, z-score.  Returns the
+    [1,H,W] float32 tensor and scale_shift = (scale, rows added (+) or removed (-)).  (The reference's crop branch
+    indexes with floats and raises; the centre crop it intends is what runs here.)"""
     if not align_width:
         sys.exit('Height alignment not implemented! Exiting ...')
     scale_shift = (1, 0)
     if op_shape[1] != img.shape[1]:
-        raise RuntimeError('frame width %d != %d: resizing needs OpenCV (INTER_LANCZOS4), not available here' % (img.shape[1], op_shape[1]))
+        sc = op_shape[1] / img.shape[1]
+        img = resize_lanczos4(img, (int(img.shape[1] * sc), int(img.shape[0] * sc)))
+        scale_shift = (sc, 0)
     if op_shape[0] > img.shape[0]:
         pad = op_shape[0] - img.shape[0]
         img = np.pad(img, ((pad // 2, pad - pad // 2), (0, 0)))
-        scale_shift = (1, pad)
+        scale_shift = (scale_shift[0], pad)
     elif op_shape[0] < img.shape[0]:
         cut = img.shape[0] - op_shape[0]
         img = img[cut // 2: cut // 2 + op_shape[0]]
-        scale_shift = (1, -cut)
+        scale_shift = (scale_shift[0], -cut)
     img = img.astype(np.float64)
     img = (img - img.mean()) / img.std()
     return torch.from_numpy(img).unsqueeze(0).to(torch.float32), scale_shift
@@ -82,17 +128,89 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
     return edge[:, 0].cpu().numpy(), mask.cpu().numpy(), fit[:, 1], fit[:, 0]
 
 
-def rescale_to_original(seg_map, pupil_ellipse, iris_ellipse, scale_shift, orig_shape):
-    """evaluate.py:169-192 (nearest-neighbour maps; ellipse centres shifted back by the row padding)."""
-    pupil_ellipse, iris_ellipse = pupil_ellipse.copy(), iris_ellipse.copy()
+def rescale_to_original(seg_map, pupil_ellipse, iris_ellipse, scale_shift, orig_shape, edge_map=None):
+    """evaluate.py:169-192: ellipses back to the source frame (row shift, then 1/scale), class map (and edge map) un-padded /
+    re-padded and resized to the source shape with nearest neighbour.  Returns (seg_map, pupil, iris[, edge_map])."""
+    pupil_ellipse, iris_ellipse = np.array(pupil_ellipse, dtype=np.float64), np.array(iris_ellipse, dtype=np.float64)
     for e in (pupil_ellipse, iris_ellipse):
         e[1] = e[1] - np.floor(scale_shift[1] // 2)
         e[:-1] = e[:-1] * (1 / scale_shift[0])
-    if scale_shift[1] > 0:
-        seg_map = seg_map[scale_shift[1] // 2: seg_map.shape[0] - (scale_shift[1] - scale_shift[1] // 2)]
-    elif scale_shift[1] < 0:
-        seg_map = np.pad(seg_map, ((-scale_shift[1] // 2, -scale_shift[1] - (-scale_shift[1] // 2)), (0, 0)))
-    return seg_map, pupil_ellipse, iris_ellipse
+
+    def fix(m):
+        if m is None:
+            return None
+        if scale_shift[1] > 0:
+            m = m[scale_shift[1] // 2: m.shape[0] - (scale_shift[1] - scale_shift[1] // 2)]
+        elif scale_shift[1] < 0:
+            m = np.pad(m, ((-scale_shift[1] // 2, -scale_shift[1] - (-scale_shift[1] // 2)), (0, 0)))
+        return resize_nearest(m, (orig_shape[1], orig_shape[0])) if tuple(m.shape[:2]) != tuple(orig_shape[:2]) else m
+    seg_map, edge_map = fix(seg_map), fix(edge_map)
+    return (seg_map, pupil_ellipse, iris_ellipse) if edge_map is None else (seg_map, pupil_ellipse, iris_ellipse, edge_map)
+
+
+def _draw_ellipse(img, el, colour):
+    """Outline of the ellipse (cx, cy, a, b, theta) as cv2.ellipse(..., thickness 1) would put it (helperfunctions.py:606-609;
+    integer centre / axes as there), without anti-aliasing: 720 boundary samples rounded to pixels."""
+    if np.all(np.asarray(el) == -1) or not np.all(np.isfinite(el)):
+        return
+    cx, cy, a, b = (int(v) for v in el[:4])
+    t = np.linspace(0, 2 * np.pi, 720, endpoint=False)
+    ang = float(el[4])
+    x = cx + a * np.cos(t) * np.cos(ang) - b * np.sin(t) * np.sin(ang)
+    y = cy + a * np.cos(t) * np.sin(ang) + b * np.sin(t) * np.cos(ang)
+    xi, yi = np.rint(x).astype(np.int64), np.rint(y).astype(np.int64)
+    ok = (xi >= 0) & (xi < img.shape[1]) & (yi >= 0) & (yi < img.shape[0])
+    img[yi[ok], xi[ok]] = colour
+
+
+def plot_segmap_ellpreds(image, seg_map, pupil_ellipse, iris_ellipse):
+    """helperfunctions.py:521-622: grey frame -> BGR, iris pixels (120,183,53), pupil pixels (36,231,253), iris ellipse in
+    (255,0,0) and pupil ellipse in (0,0,255)."""
+    out = np.stack([image] * 3, axis=2).astype(np.uint8)
+    out[seg_map == 1] = np.array([120, 183, 53], np.uint8)
+    out[seg_map == 2] = np.array([36, 231, 253], np.uint8)
+    _draw_ellipse(out, iris_ellipse, np.array([255, 0, 0], np.uint8))
+    _draw_ellipse(out, pupil_ellipse, np.array([0, 0, 255], np.uint8))
+    return out
+
+
+class MJPEGWriter:
+    """Minimal AVI (RIFF) writer with Motion-JPEG frames encoded by PIL -- stands in for cv2.VideoWriter (evaluate.py:219-221;
+    the reference writes mp4v, for which there is no encoder in this image).  Frames are BGR uint8 arrays as OpenCV's are."""
+
+    def __init__(self, path, fps, size):
+        self.path, self.fps, self.size, self.frames = path, max(int(fps), 1), (int(size[0]), int(size[1])), []
+
+    def write(self, frame_bgr):
+        from PIL import Image
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(frame_bgr[..., ::-1])).save(buf, format='JPEG', quality=90)
+        self.frames.append(buf.getvalue())
+
+    def release(self):
+        import struct
+        W, H, n = self.size[0], self.size[1], len(self.frames)
+        chunks, idx, off = [], [], 4
+        for f in self.frames:
+            pad = len(f) & 1
+            chunks.append(b'00dc' + struct.pack('<I', len(f)) + f + b'\0' * pad)
+            idx.append(b'00dc' + struct.pack('<III', 0x10, off, len(f)))
+            off += 8 + len(f) + pad
+        movi = b'movi' + b''.join(chunks)
+        biggest = max((len(f) for f in self.frames), default=0)
+        avih = struct.pack('<IIIIIIIIIIIIII', 1000000 // self.fps, biggest * self.fps, 0, 0x10, n, 0, 1, biggest, W, H, 0, 0, 0, 0)
+        strh = b'vids' + b'MJPG' + struct.pack('<IHHIIIIIIIIhhhh', 0, 0, 0, 0, 1, self.fps, 0, n, biggest, 0xffffffff, 0, 0, 0, W, H)
+        strf = struct.pack('<IiiHHIIiiII', 40, W, H, 1, 24, 0x47504a4d, W * H * 3, 0, 0, 0, 0)
+
+        def ck(tag, data):
+            return tag + struct.pack('<I', len(data)) + data + (b'\0' if len(data) & 1 else b'')
+
+        def lst(tag, data):
+            return b'LIST' + struct.pack('<I', len(data) + 4) + tag + data
+        hdrl = lst(b'hdrl', ck(b'avih', avih) + lst(b'strl', ck(b'strh', strh) + ck(b'strf', strf)))
+        body = b'AVI ' + hdrl + b'LIST' + struct.pack('<I', len(movi)) + movi + ck(b'idx1', b''.join(idx))
+        with open(self.path, 'wb') as f:
+            f.write(b'RIFF' + struct.pack('<I', len(body)) + body)
 
 
 def mjpeg_frames(path):
@@ -115,30 +233,67 @@ def mjpeg_frames(path):
 
 
 def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
-    """evaluate.py:195-308: two 320-wide eyes per 640x240 frame."""
-    out, batch, meta = {}, [], []
+    """evaluate.py:195-308: every frame of the video holds two eyes side by side (320 columns each): per eye preprocess ->
+    edge -> seg -> fitted ellipses -> back to the source geometry; writes <name>_result_<method>.avi (overlay: class colours,
+    both ellipses, frame number) and <name>_edge_<method>.avi (255 - 255*edge), both Motion-JPEG, and the ellipse dictionary
+    <name>_pred2_<method>.npy {frame: (iris, pupil)} -- eyes are batched 32 at a time instead of one by one."""
+    stem = os.path.splitext(path_vid)[0]
+    out, pending = {}, []
+    vid_out = edge_out = None
+
+    def flush():
+        nonlocal vid_out, edge_out
+        if not pending:
+            return
+        eyes = [e for fr in pending for e in fr[2]]
+        x = torch.stack([e[0] for e in eyes]).to(device)
+        edge, seg, pup, iri = evaluate_ellseg_on_image(x, model, edge_model)
+        k = 0
+        for j, frame_bgr, fe in pending:
+            overlay, edge_frame = frame_bgr.copy(), frame_bgr.copy()
+            for i, (_, ss, grey) in enumerate(fe):
+                em = 255.0 - 255.0 * edge[k]                                         # evaluate.py:263-264
+                sm, p, q, em = rescale_to_original(seg[k], pup[k], iri[k], ss, grey.shape, edge_map=em)
+                out[j] = (q, p)                                                      # evaluate.py:269 (the second eye overwrites the first)
+                out[(j, i)] = (q, p)
+                overlay[:, 320 * i: 320 * (i + 1)] = plot_segmap_ellpreds(grey, sm, p, q)
+                edge_frame[:, 320 * i: 320 * (i + 1)] = np.clip(em, 0, 255).astype(np.uint8)[..., None]
+                k += 1
+            _put_frame_number(overlay, j)
+            if vid_out is None:
+                Hh, Ww = frame_bgr.shape[:2]
+                vid_out = MJPEGWriter(stem + '_result_' + args.method + '.avi', 30, (Ww, Hh))
+                edge_out = MJPEGWriter(stem + '_edge_' + args.method + '.avi', 30, (Ww, Hh))
+            vid_out.write(overlay)
+            edge_out.write(edge_frame)
+        pending.clear()
+
     for j, fr in enumerate(mjpeg_frames(path_vid)):
         if args.max_frames and j >= args.max_frames:
             break
+        frame_bgr = np.stack([fr] * 3, axis=2)
+        eyes = []
         for i in range(2):
-            eye = fr[:, 320 * i: 320 * (i + 1)]
-            t, ss = preprocess_frame(eye, (240, 320), args.align_width)
-            batch.append(t); meta.append((j, i, ss, eye.shape))
-        if len(batch) >= 32:
-            _flush(batch, meta, out, model, edge_model, device)
-    if batch:
-        _flush(batch, meta, out, model, edge_model, device)
-    np.save(os.path.splitext(path_vid)[0] + '_ellipses_' + args.method + '.npy', out, allow_pickle=True)
+            grey = fr[:, 320 * i: 320 * (i + 1)]
+            t, ss = preprocess_frame(grey, (240, 320), args.align_width)
+            eyes.append((t, ss, grey))
+        pending.append((j, frame_bgr, eyes))
+        if len(pending) >= 16:
+            flush()
+    flush()
+    for w in (vid_out, edge_out):
+        if w is not None:
+            w.release()
+    np.save(stem + '_pred2_' + args.method + '.npy', out, allow_pickle=True)
     return out
 
 
-def _flush(batch, meta, out, model, edge_model, device):
-    x = torch.stack(batch).to(device)
-    _, seg, pup, iri = evaluate_ellseg_on_image(x, model, edge_model)
-    for k, (j, i, ss, shp) in enumerate(meta):
-        _, p, q = rescale_to_original(seg[k], pup[k], iri[k], ss, shp)
-        out[(j, i)] = (q, p)                                    # (iris, pupil) as evaluate.py:272
-    batch.clear(); meta.clear()
+def _put_frame_number(img, j):
+    """cv2.putText(frame, str(j), (10, 30), FONT_HERSHEY_PLAIN, 2.0, (0, 0, 255), 2) -- PIL's default font instead of Hershey."""
+    from PIL import Image, ImageDraw
+    im = Image.fromarray(np.ascontiguousarray(img[..., ::-1]))
+    ImageDraw.Draw(im).text((10, 12), str(j), fill=(255, 0, 0))
+    img[...] = np.asarray(im)[..., ::-1]
 
 
 def main(argv=None):

@@ -82,3 +82,30 @@ def test_evaluate_on_real_video_frames():
         sum(np.allclose(pup[k], g["fits"][k, 1], atol=1e-2) for k in range(4))
     print("end-to-end fitted ellipses equal to the reference's within 1e-2: %d / 8" % same)
     assert same >= 6
+
+
+def test_evaluate_video_end_to_end(tmp_path):
+    """evaluate.py on a Motion-JPEG video built from the real example frames (two eyes per 640x240 frame): overlay and edge
+    videos are written and can be read back, the ellipse dictionary holds (iris, pupil) per frame and per eye."""
+    from common import bdcn_module, esf_module, gold
+    from egne_amd import evaluate as E
+    g = gold("evaluate_real_frames")
+    vid = tmp_path / "clip.avi"
+    w = E.MJPEGWriter(str(vid), 30, (640, 240))
+    for k in range(2):
+        fr = np.concatenate([g["eyes"][2 * k], g["eyes"][2 * k + 1]], axis=1)
+        for _ in range(2):
+            w.write(np.stack([fr] * 3, axis=2))
+    w.release()
+    dev = torch.device("cuda:0")
+    bd, net = bdcn_module().to(dev), esf_module("baseline_edge").to(dev).eval()
+    args = E.parse_args(["--path2data", str(tmp_path)])
+    res = E.evaluate_ellseg_per_video(str(vid), args, net, bd, dev)
+    assert set(k for k in res if isinstance(k, int)) == {0, 1, 2, 3} and all((j, i) in res for j in range(4) for i in range(2))
+    iri, pup = res[(0, 0)]
+    assert iri.shape == (5,) and pup.shape == (5,) and np.isfinite(iri).all() and np.isfinite(pup).all()
+    np.testing.assert_allclose(iri[:2], g["fits"][0, 0, :2], atol=2.5)       # JPEG re-encoding moves the frame a little
+    for name in ("clip_result_baseline.avi", "clip_edge_baseline.avi"):
+        frames = list(E.mjpeg_frames(str(tmp_path / name)))
+        assert len(frames) == 4 and frames[0].shape == (240, 640)
+    assert os.path.exists(tmp_path / "clip_pred2_baseline.npy")

@@ -240,3 +240,47 @@ def test_bench_refuses_a_world_that_does_not_match_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert p.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in p.stdout
+
+
+def test_evaluate_front_and_back_end(tmp_path):
+    """evaluate.py's host stages that OpenCV did in the reference (resize, overlay, video I/O): properties only -- OpenCV is
+    not installed, so nothing here is pinned against it."""
+    from egne_amd import evaluate as E
+    rng = np.random.RandomState(0)
+    flat = np.full((100, 200), 77, np.uint8)
+    assert np.unique(E.resize_lanczos4(flat, (320, 160))).tolist() == [77]          # weights sum to one
+    ramp = np.tile(np.linspace(0, 255, 640)[None, :], (240, 1)).astype(np.uint8)
+    half = E.resize_lanczos4(ramp, (320, 120))
+    assert half.shape == (120, 320) and half.dtype == np.uint8
+    assert np.abs(half[60].astype(float) - np.linspace(0, 255, 320)).max() < 2.0    # a linear ramp stays linear
+    img = rng.randint(0, 256, (240, 320)).astype(np.uint8)
+    assert np.array_equal(E.resize_lanczos4(img, (320, 240)), img)                  # same size: untouched
+    assert np.array_equal(E.resize_nearest(img, (640, 480))[::2, ::2], img)
+    # 400 wide -> scale 0.8 -> 192 rows -> 24 rows of padding above and below; z-scored
+    t, ss = E.preprocess_frame(rng.randint(0, 256, (240, 400)).astype(np.uint8), (240, 320))
+    assert tuple(t.shape) == (1, 240, 320) and ss == (0.8, 48) and abs(float(t.mean())) < 1e-6 and abs(float(t.std()) - 1) < 1e-3
+    t2, ss2 = E.preprocess_frame(rng.randint(0, 256, (300, 320)).astype(np.uint8), (240, 320))
+    assert tuple(t2.shape) == (1, 240, 320) and ss2 == (1, -60)
+    # back to the source geometry: rows un-padded, ellipse shifted by pad / 2 and scaled by 1 / 0.8
+    seg = np.zeros((240, 320), np.int64)
+    seg[24:216] = 1
+    s2, p, q, e2 = E.rescale_to_original(seg, np.array([160., 120., 20., 10., 0.3]), np.array([160., 120., 60., 50., 0.1]), ss, (240, 400),
+                                         edge_map=np.ones((240, 320)))
+    assert s2.shape == (240, 400) and e2.shape == (240, 400) and (s2 == 1).all()
+    np.testing.assert_allclose(p, [200.0, 120.0, 25.0, 12.5, 0.3])
+    # overlay colours and ellipse outlines
+    segm = np.zeros((240, 320), np.int64)
+    segm[100:140, 100:200] = 1
+    segm[110:130, 140:160] = 2
+    ov = E.plot_segmap_ellpreds(img, segm, np.array([150., 120., 12., 9., 0.]), np.array([150., 120., 55., 35., 0.2]))
+    assert ov.shape == (240, 320, 3) and tuple(ov[105, 105]) == (120, 183, 53) and tuple(ov[125, 145]) == (36, 231, 253)
+    assert tuple(ov[120, 162]) == (0, 0, 255) and (ov == np.array([255, 0, 0], np.uint8)).all(2).sum() > 100
+    # Motion-JPEG AVI round trip through the package's own reader
+    w = E.MJPEGWriter(str(tmp_path / "t.avi"), 30, (320, 240))
+    smooth = np.tile(np.linspace(20, 230, 320)[None, :], (240, 1)).astype(np.uint8)
+    for k in range(3):
+        w.write(np.stack([np.roll(smooth, 10 * k, 1)] * 3, axis=2))
+    w.release()
+    back = list(E.mjpeg_frames(str(tmp_path / "t.avi")))
+    assert len(back) == 3 and back[0].shape == (240, 320)
+    assert np.abs(back[1].astype(int) - np.roll(smooth, 10, 1)).mean() < 3
