@@ -65,9 +65,13 @@ __device__ __forceinline__ void lds_barrier() {
 //     with its 9 taps folded into K as in conv3x3_c4_f16.hip: group s of a pixel = the 4-channel vectors of taps 4s + 2h and
 //     4s + 2h + 1 (h = lane half), three groups, weights from egne_pack_conv3x3_c4_weight_f16; its activation is applied
 //     before the result is split into the LDS image.
+// UPADD: p1.residual names a LOW-resolution tensor [B][p1.Ho][p1.Wo] whose bilinear x2 upsampling (F.interpolate, scale 2,
+//     align_corners False) is added to the 1x1 result: conv11(cat(up(x), skip)) = up(W_up x) + W_skip skip (RITnet_v2.py:84-86;
+//     the 1x1 and the interpolation are both linear and the interpolation weights sum to one), so the up-sampled tensor is
+//     never materialised.  The 6 x 18 low-resolution pixels a tile's halo needs are staged in LDS one tile ahead.
 // p1: the 1x1 (slices, bias, CoutP = 32*NCH); p2: the 3x3 (bias, act, post affine, residual, output).
 // w1hi / w1lo: fragments of egne_pack_conv1x1_weight_f16; f2hi / f2lo: fragments of egne_pack_conv_weight_f16frag.
-template <int NCH, int WN, int TH, int NB, bool C4 = false>
+template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false>
 __global__ __launch_bounds__(512)
 void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, const GroupTab gt, const _Float16* __restrict__ w1hi,
                           const _Float16* __restrict__ w1lo, int G1, const _Float16* __restrict__ f2hi,
@@ -108,6 +112,9 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     const int l = it & 63, hl = (it >> 6) & 1, q = it >> 7;      // q = group * NCH + tile
     *(u32x4*)&lw[(long long)it * 8] = *(const u32x4*)((hl ? w1lo : w1hi) + ((long long)q * 64 + l) * 8);
   }
+  // UPADD: two tiles of the low-resolution addend, [6 rows][18 columns][32 * NCH] floats each
+  constexpr int PROWS = TH / 2 + 2, PCOLS = TW / 2 + 2, PTILE = PROWS * PCOLS * 32 * NCH;
+  float* const lp = (float*)(lw + (WLDS ? G1 * NCH * 2 * 512 : 0));
   __syncthreads();
 
   if (wave < 4) {
@@ -121,6 +128,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     constexpr int JOBS = (NMT + 3) / 4, N = JOBS * NB, NBUF = WLDS ? 3 : 4, DIST = NBUF - 1;
     static_assert(N % NBUF == 0 && (WLDS || N % 2 == 0) && N >= DIST, "buffer index of an item must not depend on the tile");
     u32x4 xa[NBUF][GB], xb[NBUF][GB];
+    const float* ptile = lp;                         // UPADD: the current tile's staged addend
     u32x4 wq[WLDS ? 1 : 2][GB][NCH][2];
     f32x16 acc[NCH];
     const unsigned w1bytes = (unsigned)G1 * NCH * 64u * 16u;
@@ -226,13 +234,33 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         pixel(tl, job, hp, valid, pix);
         if (hp < NPX) {
           const float vs = valid ? a2 : 0.f, vo = valid ? os1 * a2 : 0.f;
+          // UPADD: ATen's area_pixel_compute_source_index(scale 0.5, align_corners false): s = max(0.5 (d + 0.5) - 0.5, 0)
+          int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+          float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+          if constexpr (UPADD) {
+            const int ph = p1.Ho, pw = p1.Wo;
+            float sy = 0.5f * (pyy + 0.5f) - 0.5f, sx = 0.5f * (pxx + 0.5f) - 0.5f;
+            sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < ph - 1 ? 1 : 0), x1 = x0 + (x0 < pw - 1 ? 1 : 0);
+            const float ly = sy - y0, lx = sx - x0;
+            const int ry = tl.y0 / 2 - 1, rx = tl.x0 / 2 - 1;
+            o00 = ((y0 - ry) * PCOLS + x0 - rx) * 32 * NCH; o01 = ((y0 - ry) * PCOLS + x1 - rx) * 32 * NCH;
+            o10 = ((y1 - ry) * PCOLS + x0 - rx) * 32 * NCH; o11 = ((y1 - ry) * PCOLS + x1 - rx) * 32 * NCH;
+            w00 = (1.f - ly) * (1.f - lx) * vs; w01 = (1.f - ly) * lx * vs; w10 = ly * (1.f - lx) * vs; w11 = ly * lx * vs;
+            if (!valid) o00 = o01 = o10 = o11 = 0;
+          }
 #pragma unroll
           for (int tn = 0; tn < NCH; ++tn)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const f32x4 b4 = *(const f32x4*)(lbias + tn * 32 + 8 * j + 4 * lh);
-              f32x2 v0 = {acc[tn][4 * j] * vo + b4[0] * vs, acc[tn][4 * j + 1] * vo + b4[1] * vs};
-              f32x2 v1 = {acc[tn][4 * j + 2] * vo + b4[2] * vs, acc[tn][4 * j + 3] * vo + b4[3] * vs};
+              f32x4 b4 = *(const f32x4*)(lbias + tn * 32 + 8 * j + 4 * lh) * vs;
+              if constexpr (UPADD) {
+                const int c = tn * 32 + 8 * j + 4 * lh;
+                b4 += w00 * *(const f32x4*)(ptile + o00 + c) + w01 * *(const f32x4*)(ptile + o01 + c) +
+                      w10 * *(const f32x4*)(ptile + o10 + c) + w11 * *(const f32x4*)(ptile + o11 + c);
+              }
+              f32x2 v0 = {acc[tn][4 * j] * vo + b4[0], acc[tn][4 * j + 1] * vo + b4[1]};
+              f32x2 v1 = {acc[tn][4 * j + 2] * vo + b4[2], acc[tn][4 * j + 3] * vo + b4[3]};
               if constexpr (C4) {                    // activation of the first convolution (scaling by a2 > 0 commutes with it)
                 const float sl = p1.act == EGNE_ACT_RELU ? 0.f : (p1.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
                 v0[0] = fmaxf(v0[0], v0[0] * sl); v0[1] = fmaxf(v0[1], v0[1] * sl);
@@ -249,16 +277,47 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         }
       }
     };
+    // UPADD staging: the low-resolution rows y0/2 - 1 .. y0/2 + TH/2 and columns x0/2 - 1 .. x0/2 + 16 of the addend (clamped to
+    // the tensor: replicated border, as the interpolation clamps), 16 bytes per lane
+    constexpr int NPI = UPADD ? (PROWS * PCOLS * 8 * NCH + 255) / 256 : 1;
+    u32x4 pst[NPI];
+    auto issue_p = [&](const Tile& tl, bool on) {
+      const int ph = p1.Ho, pw = p1.Wo;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(p1.residual, (unsigned)((long long)p1.B * ph * pw * p1.res_pix_stride * 4));
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        const int it = tid + 256 * i, px = it / (8 * NCH), pc = it - px * (8 * NCH);
+        const int ry = px / PCOLS, rx = px - ry * PCOLS;
+        const int gy = min(max(tl.y0 / 2 - 1 + ry, 0), ph - 1), gx = min(max(tl.x0 / 2 - 1 + rx, 0), pw - 1);
+        const int off = (on && px < PROWS * PCOLS) ? (((tl.b * ph + gy) * pw + gx) * (int)p1.res_pix_stride + p1.res_ch_off + pc * 4) * 4 : (int)OOB;
+        pst[i] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      }
+    };
+    auto store_p = [&](float* dstp) {
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        const int it = tid + 256 * i;
+        if (it < PROWS * PCOLS * 8 * NCH) *(u32x4*)&dstp[it * 4] = pst[i];
+      }
+    };
     auto produce = [&](int i) {           // tile i of this workgroup into image i & 1; prefetches the head of tile i + 1
       const Tile tl = decode(tile_at(i));
       const bool nx_on = i + 1 < nmine;
       const Tile nx = decode(tile_at(nx_on ? i + 1 : i));
       _Float16* img = ldsh + (i & 1) * IMG;
+      if constexpr (UPADD) issue_p(nx, nx_on);            // the next tile's addend: lands long before the store below
+      ptile = lp + (i & 1) * PTILE;
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         (compute(tl, nx, nx_on, img, std::integral_constant<int, Ks>{}), ...);
       }(std::make_integer_sequence<int, N>{});
+      if constexpr (UPADD) store_p(lp + ((i + 1) & 1) * PTILE);
     };
 
+    if constexpr (UPADD) {            // tile 0's addend, visible to all producer waves before they use it
+      issue_p(decode(tile_at(0)), nmine > 0);
+      store_p(lp);
+      lds_barrier();
+    }
     if (nmine > 0) {
       const Tile t0 = decode(tile_at(0));
       if constexpr (!WLDS) load_w(std::integral_constant<int, 0>{});
@@ -304,6 +363,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         wrl[s] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
       }
     }
+    if constexpr (UPADD) lds_barrier();      // matches the producers' staging barrier
     lds_barrier();
     for (int i = 0; i < nmine; ++i) {
       const Tile tl = decode(tile_at(i));
@@ -428,18 +488,19 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   }
 }
 
-template <int NCH, int WN, int TH, int NB, bool C4 = false>
+template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false>
 int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const GroupTab& gt, const _Float16* w1hi, const _Float16* w1lo,
                  int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
-  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0);
-  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0) +
+                     (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * 32 * NCH * sizeof(float) : 0);
+  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024) == hipSuccess;
   if (!once || lds > 160 * 1024) return egne::fail(EGNE_ERR_LAUNCH, "conv_fused_1x1_3x3: %zu bytes of LDS", lds);
   int gx = 256;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
+  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
                      a2, os2, tiles_x, tiles_y, ntiles);
   return egne::check_launch("egne_conv1x1_3x3_fused_f16_fwd");
 }
@@ -458,7 +519,7 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   const egne_conv_desc& d1 = *dp1;
   const egne_conv_desc& d2 = *dp2;
   EGNE_REQUIRE(d1.kh == 1 && d1.kw == 1 && d1.stride == 1 && d1.pad_h == 0 && d1.pad_w == 0 && d1.ngroups == 1 && d1.nseg >= 1 &&
-               d1.nseg <= EGNE_MAXSEG && !d1.residual && !d1.post_scale && d1.act == EGNE_ACT_NONE && (d1.CoutP == 32 || d1.CoutP == 64),
+               d1.nseg <= EGNE_MAXSEG && !d1.post_scale && d1.act == EGNE_ACT_NONE && (d1.CoutP == 32 || d1.CoutP == 64),
                "conv_fused_1x1_3x3: 1x1 descriptor");
   EGNE_REQUIRE(d2.kh == 3 && d2.kw == 3 && d2.stride == 1 && d2.pad_mode == 0 && d2.ngroups == 1 && d2.pad_h == 1 && d2.pad_w == 1 &&
                d2.dil[0] == 1 && d2.Ho == d2.H && d2.Wo == d2.W && d2.B == d1.B && d2.H == d1.H && d2.W == d1.W && d2.Ktot == d1.CoutP &&
@@ -491,6 +552,14 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *a = (const _Float16*)w1hi, *b = (const _Float16*)w1lo, *c = (const _Float16*)f2hi, *e = (const _Float16*)f2lo;
   EGNE_REQUIRE(G <= 12, "conv_fused_1x1_3x3: at most 192 input channels (12 groups of 16) are built, got %d groups", G);
+  if (d1.residual) {
+    EGNE_REQUIRE(d1.CoutP == 32 && d2.CoutP == 32 && G <= 8 && d1.Ho * 2 == d1.H && d1.Wo * 2 == d1.W && d1.res_ch_off % 4 == 0 &&
+                 d1.res_pix_stride % 4 == 0 && ((uintptr_t)d1.residual & 15) == 0 && d1.res_ch_off + 32 <= d1.res_pix_stride &&
+                 (long long)d1.B * d1.Ho * d1.Wo * d1.res_pix_stride * 4 < (1ll << 31),
+                 "conv_fused_1x1_3x3: the up-sampled addend needs 32 -> 32 channels, <= 8 groups and a half-resolution tensor");
+    return G <= 4 ? launch_fused<1, 1, 8, 1, false, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st)
+                  : launch_fused<1, 1, 8, 2, false, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
+  }
   if (d1.CoutP == 32) {
     const int nb = (G + 3) / 4;
 #define EGNE_FUSED(WN_) \

@@ -89,23 +89,23 @@ __global__ void norm_stats_final(const double* __restrict__ ws, int Cp, int Bn, 
 }
 
 // Finish of the statistics whose partial sums came out of a convolution's epilogue: one block per (32 channels, frame),
-// eight partial-sum streams per channel (independent loads in flight), fixed combination order.
-__global__ __launch_bounds__(256) void norm_stats_finish_k(const double* __restrict__ ws, int Cp, int nchunk, long long npix_per_n,
+// 32 partial-sum streams per channel (independent loads in flight), fixed combination order.
+__global__ __launch_bounds__(1024) void norm_stats_finish_k(const double* __restrict__ ws, int Cp, int nchunk, long long npix_per_n,
                                                            float eps, float* __restrict__ scale, float* __restrict__ shift) {
-  const int n = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), kg = threadIdx.x >> 5;
+  const int n = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), kg = threadIdx.x >> 5;       // 32 partial-sum streams
   double s = 0, q = 0;
   if (c < Cp) {
     const double* w = ws + ((long long)n * nchunk * Cp + c) * 2;
-    for (int k = kg; k < nchunk; k += 8) {
+    for (int k = kg; k < nchunk; k += 32) {
       const double2 v = *(const double2*)(w + (long long)k * Cp * 2);
       s += v.x; q += v.y;
     }
   }
-  __shared__ double sh[8][32][2];
+  __shared__ double sh[32][32][2];
   sh[kg][threadIdx.x & 31][0] = s; sh[kg][threadIdx.x & 31][1] = q;
   __syncthreads();
   if (kg == 0 && c < Cp) {
-    for (int g = 1; g < 8; ++g) { s += sh[g][threadIdx.x][0]; q += sh[g][threadIdx.x][1]; }
+    for (int g = 1; g < 32; ++g) { s += sh[g][threadIdx.x][0]; q += sh[g][threadIdx.x][1]; }
     const double mean = s / (double)npix_per_n;
     double var = q / (double)npix_per_n - mean * mean;
     if (var < 0) var = 0;
@@ -341,7 +341,7 @@ extern "C" int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, i
 extern "C" int egne_norm_stats_finish(const void* ws, int Cp, int B, int nchunk, int HW, float eps, float* scale, float* shift,
                                       void* stream) {
   EGNE_REQUIRE(ws && scale && shift && Cp > 0 && B > 0 && nchunk > 0 && HW > 0 && ((uintptr_t)ws & 15) == 0, "norm_stats_finish: bad arguments");
-  hipLaunchKernelGGL(norm_stats_finish_k, dim3((Cp + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, (const double*)ws, Cp, nchunk,
+  hipLaunchKernelGGL(norm_stats_finish_k, dim3((Cp + 31) / 32, B), dim3(1024), 0, (hipStream_t)stream, (const double*)ws, Cp, nchunk,
                      (long long)HW, eps, scale, shift);
   return egne::check_launch("egne_norm_stats_finish");
 }

@@ -685,17 +685,24 @@ class Plan:
             self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
         return Ho, Wo
 
-    def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False):
+    def pair_fusable(self, l1, pieces, l2, dst, H, W):
+        """True if conv_pair will run l2(l1(cat(pieces))) as ONE launch (conv_fused_1x1_3x3_f16.hip)."""
+        return (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split1 and l2.split and l1.kh == 1 and l1.kw == 1
+                and l1.stride == 1 and l1.G == 1 and l1.pad == (0, 0) and l1.act == ACT_NONE and l1.post is None
+                and all(pc.scale is None for pc in pieces) and l1.CoutP in (32, 64) and len(pieces) <= _lib.MAXSEG
+                and sum((pc.Cp + 15) // 16 for pc in pieces) <= 12
+                and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
+                and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP in (32, 64)
+                and W >= FUSE_1X1_MIN_W and all(H * W * pc.stride < 2 ** 29 for pc in pieces) and H * W * dst.stride < 2 ** 29)
+
+    def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False, up_add=None):
         """``l2(l1(cat(pieces)))``: a 1x1 convolution over raw slices followed by the 3x3 that is its only consumer
         (RITnet_v2.py:59-62,84-87).  Inference plans run the pair as ONE launch whose intermediate stays in LDS
         (conv_fused_1x1_3x3_f16.hip); otherwise two launches through ``tmp`` (a Piece, allocated here if None)."""
-        fused = (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split1 and l2.split and l1.kh == 1 and l1.kw == 1
-                 and l1.stride == 1 and l1.G == 1 and l1.pad == (0, 0) and l1.act == ACT_NONE and l1.post is None
-                 and all(pc.scale is None for pc in pieces) and l1.CoutP in (32, 64) and len(pieces) <= _lib.MAXSEG
-                 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 12
-                 and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
-                 and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP in (32, 64)
-                 and W >= FUSE_1X1_MIN_W and all(H * W * pc.stride < 2 ** 29 for pc in pieces) and H * W * dst.stride < 2 ** 29)
+        fused = self.pair_fusable(l1, pieces, l2, dst, H, W)
+        # up_add = (P, ph, pw): a half-resolution tensor whose bilinear x2 upsampling is added to the 1x1 result (the up-sampled
+        # operand of an up block folded through the 1x1; only the fused kernel does this -- callers check pair_fusable first)
+        assert up_add is None or (fused and l1.CoutP == 32 and l2.CoutP == 32 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 8), name
         # convBlock (utils.py:1047-1048): a 3x3 on <= 4 input channels in front of the 3x3 -- same kernel, taps folded into K
         fused_c4 = (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
                     and l1.stride == 1 and l1.G == 1 and l1.pad == (1, 1) and l1.pad_mode == 0 and l1.dils[0] == 1 and l1.Cin <= 4
@@ -733,6 +740,11 @@ class Plan:
             sg = d1.seg[i]
             sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp, sg.act_in = p.ptr, p.stride, p.off, p.Cp, ACT_NONE
         d1.Ktot, d1.CoutP = l1.Ktot, l1.CoutP
+        if up_add is not None:
+            P, ph, pw = up_add
+            assert (2 * ph, 2 * pw) == (H, W) and P.Cp >= 32 and tuple(P.buf.shape[:3]) == (B, ph, pw)
+            d1.Ho, d1.Wo = ph, pw
+            d1.residual, d1.res_pix_stride, d1.res_ch_off = P.ptr, P.stride, P.off
         d2.nseg = 0
         d2.Ktot, d2.CoutP = l1.CoutP, l2.sfrag_coutp()
         if l2.post is not None:
@@ -744,13 +756,16 @@ class Plan:
         assert tuple(dst.buf.shape[1:3]) == (H, W), (name, tuple(dst.buf.shape), H, W)
         self.keep += [d1, d2]
 
-        def rescale(args, vmax, l1=l1):
+        def rescale(args, vmax, l1=l1, up_add=up_add):
             # a1 from the measured max of the slices; a2 from a bound on the 1x1 result: max|in| * max_co sum_c |w| + max|b|
+            # (+ max|P| for an up-sampled addend: an interpolation never exceeds its samples)
             with torch.no_grad():
                 w = l1.weights[0].detach()
                 bound = vmax * float(w.abs().sum(dim=(1, 2, 3)).max())
                 if l1.biases is not None and l1.biases[0] is not None:
                     bound += float(l1.biases[0].detach().abs().max())
+                if up_add is not None:
+                    bound += float(up_add[0].buf[..., up_add[0].off:up_add[0].off + up_add[0].Cp].abs().max())
             return args[:4] + (_a_scale_for(vmax),) + args[5:8] + (_a_scale_for(bound),) + args[9:]
         flops = 2.0 * B * H * W * (l1.Cout * l1.Cin + l2.Cout * l2.Cin * 9)
         fuse_stats = stats and STATS_FUSED and dst.Cp == int(d2.Cout_store)
@@ -930,11 +945,11 @@ class Plan:
         """Replay the launches on torch's current stream.  ``events`` (a list) receives one
         (kernel family, flops, start_event, end_event) per launch -- HIP events recorded on the
         launch stream, used by bench.py to time individual kernels inside the timed region."""
+        for f in self.pre:          # derived tensors first (folded BatchNorm, sliced / concatenated weights): packing reads them
+            f()
         repacked = False
         for layer in self.layers:
             repacked = bool(layer.ensure_packed(self.device)) or repacked
-        for f in self.pre:
-            f()
         st = _lib.stream_ptr()
         if self.cal and (repacked or not self.calibrated):
             return self._run_calibrating(st)

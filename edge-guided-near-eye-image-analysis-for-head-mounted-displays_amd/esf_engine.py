@@ -21,6 +21,11 @@ from . import _lib
 from .engine import ACT_LEAKY, ACT_NONE, ConvLayer, Piece, Plan, VersionGuard, pad8, pad32
 
 
+import os
+
+FOLD_UP = os.environ.get("EGNE_FOLD_UP", "1") != "0"     # up blocks: 1x1 of the up-sampled operand at half resolution
+
+
 def enc_sizes(chz, growth=1.2, blks=4):
     """models/RITnet_v2.py:15-29 getSizes (encoder part)."""
     inter = [chz * (i + 1) for i in range(blks)]
@@ -251,26 +256,53 @@ def build_forward_plan(model, B, H, W, dev, training):
         h, w = res[lvl]
         oc = ds["op"][k]
         nm = "dec.up%d" % (4 - k)
-        upw = sum(p.Cp for p in prev)
-        U = pl.buf(B, h, w, upw + pad8(oc))
-        up_pieces, off = [], 0
-        for p in prev:
-            q = Piece(U, off, p.C, p.Cp)
-            pl.upsample2x(p, q, B, ph, pw, name=nm + ".up")
-            up_pieces.append(q)
-            off += p.Cp
-        x1 = Piece(U, off, oc)
         skip = [D[lvl]["out"], D[lvl]["x"]]
         if variant == "concat":
             skip = skip + [D[lvl]["out"].samples(B), D[lvl]["x"].samples(B)]
-        cat = up_pieces + skip
-        l1 = _cl(ub.conv11, _lay(cat))
-        l2 = _cl(ub.conv12, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
-        pl.conv_pair(l1, cat, l2, x1, B, h, w, name=nm + ".conv1")
-        l1 = _cl(ub.conv21, _lay(cat + [x1]))
+        Cl = sum(p.C for p in prev)                  # channels of the up-sampled operand (first in the reference's torch.cat)
+        x1b = pl.buf(B, h, w, pad8(oc))
+        x1 = Piece(x1b, 0, oc)
         y = pl.buf(B, h, w, pad8(oc))
-        l2 = _cl(ub.conv22, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
-        pl.conv_pair(l1, cat + [x1], l2, Piece(y, 0, oc), B, h, w, name=nm + ".conv2")
+        l12 = _cl(ub.conv12, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
+        l22 = _cl(ub.conv22, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
+        # Inference plans, narrow blocks: conv11(cat(up(x), skip)) = up(W_up x) + W_skip skip -- the 1x1 and the bilinear
+        # interpolation commute, so W_up x is evaluated at HALF resolution (for conv11 and conv21 at once) and the fused
+        # 1x1 -> 3x3 kernel adds its up-sampling on the fly: the up-sampled tensor never exists (RITnet_v2.py:80-88)
+        l11s = ConvLayer([ub.conv11.weight[:, Cl:]], [ub.conv11.bias], _lay(skip))
+        l21s = ConvLayer([ub.conv21.weight[:, Cl:]], [ub.conv21.bias], _lay(skip + [x1]))
+        for l in (l11s, l21s):
+            l.split1 = l12.split1 or l12.split
+        fold_up = (FOLD_UP and not training and oc == 32 and sum((p.Cp + 15) // 16 for p in skip + [x1]) <= 8
+                   and pl.pair_fusable(l11s, skip, l12, x1, h, w) and pl.pair_fusable(l21s, skip + [x1], l22, Piece(y, 0, oc), h, w))
+        if fold_up:
+            wp = torch.zeros(2 * oc, Cl, 1, 1, device=dev)
+
+            def refresh_wp(wp=wp, ub=ub, Cl=Cl, oc=oc):
+                wp[:oc].copy_(ub.conv11.weight.detach()[:, :Cl])
+                wp[oc:].copy_(ub.conv21.weight.detach()[:, :Cl])
+            pl.pre.append(VersionGuard([ub.conv11.weight, ub.conv21.weight], refresh_wp))
+            refresh_wp()
+            lpw = ConvLayer([wp], None, _lay(prev))
+            lpw.split1 = l11s.split1
+            Pb = pl.buf(B, ph, pw, 2 * pad32(oc))
+            pl.conv(lpw, prev, Piece(Pb, 0, 2 * oc), B, ph, pw, name=nm + ".up_w")
+            P1, P2 = Piece(Pb, 0, oc, 32), Piece(Pb, 32, oc, 32)
+            pl.conv_pair(l11s, skip, l12, x1, B, h, w, name=nm + ".conv1", up_add=(P1, ph, pw))
+            pl.conv_pair(l21s, skip + [x1], l22, Piece(y, 0, oc), B, h, w, name=nm + ".conv2", up_add=(P2, ph, pw))
+        else:
+            upw = sum(p.Cp for p in prev)
+            U = pl.buf(B, h, w, upw)
+            up_pieces, off = [], 0
+            for p in prev:
+                q = Piece(U, off, p.C, p.Cp)
+                pl.upsample2x(p, q, B, ph, pw, name=nm + ".up")
+                up_pieces.append(q)
+                off += p.Cp
+            cat = up_pieces + skip
+            l1 = _cl(ub.conv11, _lay(cat))
+            pl.conv_pair(l1, cat, l12, x1, B, h, w, name=nm + ".conv1")
+            l1 = _cl(ub.conv21, _lay(cat + [x1]))
+            pl.conv_pair(l1, cat + [x1], l22, Piece(y, 0, oc), B, h, w, name=nm + ".conv2")
         prev, ph, pw = [Piece(y, 0, oc)], h, w
         pl.dbg[nm] = prev[0]
 
