@@ -249,9 +249,11 @@ class Bench:
             pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
             pl_[0] += sec / steps
         if self.a.layers and self.rank == 0:
+            from egne_amd import engine as _eng
             for lname, (sec, fl, kind) in per_layer.items():
-                print("%-26s %-18s %9.1f us %8.2f GFLOP %7.1f TFLOP/s" % (lname, kind, sec * 1e6, fl / 1e9, fl / sec / 1e12 if sec > 0 else 0),
-                      file=sys.stderr)
+                nb = _eng.LAYER_BYTES.get(lname, 0.0)
+                print("%-26s %-18s %9.1f us %8.2f GFLOP %7.1f TFLOP/s %7.2f GB %5.2f TB/s" %
+                      (lname, kind, sec * 1e6, fl / 1e9, fl / sec / 1e12 if sec > 0 else 0, nb / 1e9, nb / sec / 1e12 if sec > 0 else 0), file=sys.stderr)
         return fam
 
     def rooflines(self, fam, steps, B, dt):

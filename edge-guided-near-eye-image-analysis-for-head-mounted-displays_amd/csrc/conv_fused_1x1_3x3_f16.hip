@@ -19,6 +19,7 @@
 // never covers the latency of a later one, and the HBM latency of tile i+1 hides behind the matrix work of tile i.
 // Tiles are dealt so that the workgroups of one XCD work on neighbouring tiles (halo overlap served by that XCD's L2).
 #include "common.h"
+#include "epilogue32.h"
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,11 +31,16 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+__device__ int g_dbg = 0;
+__device__ unsigned long long g_stamps[256 * 8 * 4];
 
 constexpr int LDH = 40, TW = 32, HWd = TW + 2, MAXG = 48;
 constexpr unsigned OOB = 0x80000000u;
 
-struct GroupTab { int v[MAXG]; };      // per 16-channel group: (slice << 16) | (8-channel tail << 15) | group index inside the slice
+struct GroupTab {
+  int v[MAXG];       // per 16-channel group: (slice << 16) | (8-channel tail << 15) | group index inside the slice
+  int off[MAXG];     // UNI: byte offset of the group's first channel inside a pixel of the common buffer
+};
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -71,7 +77,14 @@ __device__ __forceinline__ void lds_barrier() {
 //     never materialised.  The 6 x 18 low-resolution pixels a tile's halo needs are staged in LDS one tile ahead.
 // p1: the 1x1 (slices, bias, CoutP = 32*NCH); p2: the 3x3 (bias, act, post affine, residual, output).
 // w1hi / w1lo: fragments of egne_pack_conv1x1_weight_f16; f2hi / f2lo: fragments of egne_pack_conv_weight_f16frag.
-template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false>
+// UNI: every slice of the 1x1's input is a channel range of ONE buffer (a dense block's x | x1 | x22: models/RITnet_v2.py:57-62):
+//     one buffer resource per tile instead of one per channel group (whose 64-bit frame pointers, kept across the statically
+//     unrolled item schedule, overflowed the scalar register file: ~350 v_readlane / v_writelane per tile and producer wave).
+// GL: channel groups in the LAST batch when known at compile time (0: decided from G1 at run time, one branch per group).  With
+//     it an item is straight-line code: all its weight fragments are requested from LDS up front and the three MFMAs of group u
+//     are interleaved with the fp32 -> hi / lo split of group u + 1 (sched_group_barrier), instead of a ds_read latency and
+//     three back-to-back MFMAs per group in a wave that issues in order.
+template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false, bool UNI = false, int GL = 0>
 __global__ __launch_bounds__(512)
 void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, const GroupTab gt, const _Float16* __restrict__ w1hi,
                           const _Float16* __restrict__ w1lo, int G1, const _Float16* __restrict__ f2hi,
@@ -85,6 +98,15 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   float* lbias = (float*)(ldsh + 2 * IMG);          // the 1x1's bias: read at every job end through LDS, so that the read is
                                                     // not queued (vmcnt retires in order) behind the next item's prefetch
 
+  const int dbg = g_dbg;
+  unsigned long long t_work = 0, t_wait = 0, t_mma = 0, t_last = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
+  auto stamp = [&](unsigned long long& accum) {
+    if (dbg & 64) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      accum += t - t_last; t_last = t;
+    }
+  };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too: descriptors and loop counters derived from it stay scalar
   const int li = lane & 31, lh = lane >> 5;
@@ -163,7 +185,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       constexpr int K = decltype(kc)::value, BUF = K % NBUF, job = K / NB, bi = K % NB;
       int hp, pix; bool valid;
       pixel(tl, job, hp, valid, pix);
-      valid = valid && on;
+      valid = valid && on && !(dbg & 1);
       if constexpr (C4) {
         const egne_seg sg = p1.seg[0];
         const __amdgpu_buffer_rsrc_t r =
@@ -181,6 +203,21 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
           }
           xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[0], 0, 0);
           xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[1], 0, 0);
+        }
+        return;
+      }
+      if constexpr (UNI) {
+        const egne_seg sg = p1.seg[0];
+        const __amdgpu_buffer_rsrc_t r =
+            make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
+        const int voff = valid ? (pix * (int)sg.pix_stride + 4 * lh) * 4 : (int)OOB;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int gg = bi * GB + u;
+          const bool on_g = gg < G1;
+          const int so = gt.off[gg < MAXG ? gg : 0];
+          xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, on_g ? voff : (int)OOB, so, 0);                                   // channels 16g + 4lh .. +3
+          xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, (on_g && !(gt.v[gg < MAXG ? gg : 0] & 0x8000)) ? voff + 32 : (int)OOB, so, 0);   // 16g + 8 + 4lh .. +3
         }
         return;
       }
@@ -206,6 +243,36 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       if constexpr (!WLDS) load_w(std::integral_constant<int, (K + 1) % N>{});
       if constexpr (K + DIST < N) issue(tl, true, std::integral_constant<int, K + DIST>{});
       else issue(nx, nx_on, std::integral_constant<int, K + DIST - N>{});
+      if constexpr (GL > 0 && WLDS) {
+        constexpr int NG = bi == NB - 1 ? GL : GB;
+        h8 bh[NG][NCH], bl[NG][NCH];
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+#pragma unroll
+          for (int tn = 0; tn < NCH; ++tn) {
+            const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
+            bh[u][tn] = *(const h8*)wp; bl[u][tn] = *(const h8*)(wp + 512);
+          }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+          h8 ah, al;
+          split8(xa[BUF][u], xb[BUF][u], a1, ah, al);
+#pragma unroll
+          for (int tn = 0; tn < NCH; ++tn) {
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[u][tn], al, acc[tn], 0, 0, 0);
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[u][tn], ah, acc[tn], 0, 0, 0);
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[u][tn], ah, acc[tn], 0, 0, 0);
+          }
+        }
+        // desired issue order: split of group 0, then each MFMA followed by a third of the next group's split
+        __builtin_amdgcn_sched_group_barrier(0x100, NG * NCH * 2, 0);     // the LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x002, 30, 0);
+#pragma unroll
+        for (int m = 0; m < NG * NCH * 3; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         if (bi * GB + u < G1) {
@@ -225,6 +292,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[tn], 0, 0, 0);
           }
         }
+      }
       }
       if (bi == NB - 1) {
         // transposed product: the lane holds channels n = 32*tn + 8*j + 4*lh + e (register 4*j + e) of halo pixel hp
@@ -327,9 +395,12 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       produce(0);
     }
     lds_barrier();
+    stamp(t_wait); t_work = 0; t_wait = 0;
     for (int i = 0; i < nmine; ++i) {
       if (i + 1 < nmine) produce(i + 1);
+      stamp(t_work);
       lds_barrier();
+      stamp(t_wait);
     }
   } else {
     // =================================================================== consumers: 9 taps from the LDS image
@@ -352,128 +423,109 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     const int abase = (row0 * HWd + li) * LDH + lh * 8;
     const int out_step = (int)p2.out_pix_stride * 4, res_step = (int)p2.res_pix_stride * 4;
 
-    // 32 -> 32 channels: the 36 weight fragments of the 3x3 (144 registers) stay in registers for the whole launch
+    // One step = 16 intermediate channels of one tap: 3 * WMW * WNW MFMAs.  The operand rows of step j + 1 are requested from LDS
+    // BEFORE the MFMAs of step j are issued (left alone, hipcc sinks every ds_read next to its use and each step pays the LDS
+    // latency: one consumer wave per SIMD has nothing else to hide it with); the 3x3's weights are the same for every tile,
+    // so their register ring runs on across tiles (32 -> 32 channels: all 36 fragments stay in registers for the whole launch).
+    constexpr int NS = NCH * 18;                         // steps per tile
     constexpr bool WREG = NCH == 1 && WNW == 1;
-    u32x4 wrh[WREG ? 18 : 1], wrl[WREG ? 18 : 1];
-    if constexpr (WREG) {
+    constexpr int NR = WREG ? NS : (WNW == 1 ? 6 : (NS % 4 == 0 ? 4 : 3));   // ring slots in steps; NS % NR == 0
+    static_assert(NS % NR == 0, "ring slot of a step must not depend on the tile");
+    auto w_off = [&](int j) { const int ch = j / 18, tap = (j % 18) >> 1, ks = j & 1; return (ch * 2 + ks) * stride_k16 + tap * stride_tap; };
+    auto a_off = [&](int j) { const int ch = j / 18, tap = (j % 18) >> 1, ks = j & 1; return ch * NPX * LDH + ((tap / 3) * HWd + tap % 3) * LDH + ks * 16; };
+    const bool st_on = p2.stats_ws != nullptr;
+    const bool full_epi = p2.post_scale != nullptr || p2.residual != nullptr;
+    egne::EpiLane ek[WNW];                               // per-lane output channel constants
 #pragma unroll
-      for (int s = 0; s < 18; ++s) {
-        const int o = (s >> 1) * stride_tap + (s & 1) * stride_k16;
-        wrh[s] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
-        wrl[s] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
-      }
+    for (int tn = 0; tn < WNW; ++tn) {
+      const int n = (nt0 + tn) * 32 + li;
+      const bool nok = n < p2.Cout_store;
+      ek[tn].bias = (p2.bias && nok) ? p2.bias[n] : 0.f;
+      ek[tn].post_scale = (p2.post_scale && nok) ? p2.post_scale[n] : 1.f;
+      ek[tn].post_shift = (p2.post_scale && nok) ? p2.post_shift[n] : 0.f;
     }
+    u32x4 qh[NR][WNW], ql[NR][WNW];
+#pragma unroll
+    for (int s = 0; s < NR; ++s)
+#pragma unroll
+      for (int tn = 0; tn < WNW; ++tn) {
+        qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, w_off(s) + tn * 1024, 0);
+        ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, w_off(s) + tn * 1024, 0);
+      }
     if constexpr (UPADD) lds_barrier();      // matches the producers' staging barrier
     lds_barrier();
+    stamp(t_wait); t_work = 0; t_wait = 0;
     for (int i = 0; i < nmine; ++i) {
       const Tile tl = decode(tile_at(i));
-      const _Float16* Thi = ldsh + (i & 1) * IMG;
+      const _Float16* Thi = ldsh + (i & 1) * IMG + abase;
       const _Float16* Tlo = Thi + NCH * NPX * LDH;
       f32x16 acc[WMW][WNW];
 #pragma unroll
       for (int a = 0; a < WMW; ++a)
 #pragma unroll
         for (int n = 0; n < WNW; ++n) acc[a][n] = (f32x16)(0.f);
-#pragma unroll 1
-      for (int ch = 0; ch < NCH; ++ch) {
-        const int wchunk = ch * 2 * stride_k16;
-        constexpr int RT = WNW == 1 ? 3 : 2;      // taps of look-ahead of the weight ring (2 loads per tap, k step and output tile)
-        u32x4 qh[2 * RT][WNW], ql[2 * RT][WNW];
-        if constexpr (!WREG) {
+      h8 ah[2][WMW], al[2][WMW];
 #pragma unroll
-          for (int s = 0; s < 2 * RT; ++s)
+      for (int tm = 0; tm < WMW; ++tm) {
+        ah[0][tm] = *(const h8*)&Thi[a_off(0) + tm * HWd * LDH];
+        al[0][tm] = *(const h8*)&Tlo[a_off(0) + tm * HWd * LDH];
+      }
 #pragma unroll
-            for (int tn = 0; tn < WNW; ++tn) {
-              const int o = wchunk + (s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
-              qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
-              ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
-            }
-        }
-        constexpr int TAP_UNROLL = (WMW == 2 && WNW == 2) ? 1 : 9;     // the widest shape only fits 256 registers with the tap loop rolled
-#pragma unroll TAP_UNROLL
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-          const int aoff = abase + ch * NPX * LDH + (ky * HWd + kx) * LDH;
+      for (int j = 0; j < NS; ++j) {
+        if (j + 1 < NS) {
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int slot = (tap % RT) * 2 + ks;
-            h8 ah[WMW], al[WMW], bh[WNW], bl[WNW];
-#pragma unroll
-            for (int tm = 0; tm < WMW; ++tm) {
-              ah[tm] = *(const h8*)&Thi[aoff + tm * HWd * LDH + ks * 16];
-              al[tm] = *(const h8*)&Tlo[aoff + tm * HWd * LDH + ks * 16];
-            }
-#pragma unroll
-            for (int tn = 0; tn < WNW; ++tn) {
-              bh[tn] = __builtin_bit_cast(h8, WREG ? wrh[(tap * 2 + ks) % (WREG ? 18 : 1)] : qh[slot][tn]);
-              bl[tn] = __builtin_bit_cast(h8, WREG ? wrl[(tap * 2 + ks) % (WREG ? 18 : 1)] : ql[slot][tn]);
-            }
-            if (!WREG && tap + RT < 9) {
-#pragma unroll
-              for (int tn = 0; tn < WNW; ++tn) {
-                const int o = wchunk + (tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
-                qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
-                ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
-              }
-            }
-            // keep the refill HERE, RT taps ahead of its use: left alone the scheduler either sinks it next to the use (one
-            // L2 latency per step) or hoists all 36 loads of a chunk to the top (144 registers)
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int tm = 0; tm < WMW; ++tm)
-#pragma unroll
-              for (int tn = 0; tn < WNW; ++tn) {
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-              }
+          for (int tm = 0; tm < WMW; ++tm) {
+            ah[(j + 1) & 1][tm] = *(const h8*)&Thi[a_off(j + 1) + tm * HWd * LDH];
+            al[(j + 1) & 1][tm] = *(const h8*)&Tlo[a_off(j + 1) + tm * HWd * LDH];
           }
         }
+        h8 bh[WNW], bl[WNW];
+#pragma unroll
+        for (int tn = 0; tn < WNW; ++tn) {
+          bh[tn] = __builtin_bit_cast(h8, qh[j % NR][tn]);
+          bl[tn] = __builtin_bit_cast(h8, ql[j % NR][tn]);
+          if constexpr (!WREG) {
+            qh[j % NR][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, w_off((j + NR) % NS) + tn * 1024, 0);
+            ql[j % NR][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, w_off((j + NR) % NS) + tn * 1024, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);              // the reads and refills above are issued before this step's MFMAs
+#pragma unroll
+        for (int tm = 0; tm < WMW; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < WNW; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (dbg & 64) { asm volatile("" : "+v"(acc[0][0])); stamp(t_mma); }
 
-      // ---- epilogue: lane holds channel n of 16 pixels x = x_lane + c_r, c_r = (r&3) + 8*(r>>2), of tile row tm ----
+      // ---- epilogue (epilogue32.h): lane holds channel n of 16 pixels x = x_lane + c_r, c_r = (r&3) + 8*(r>>2), of tile row tm ----
       {
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(p2.out + (long long)tl.b * H * W * p2.out_pix_stride, frame_out);
         const __amdgpu_buffer_rsrc_t rres =
             make_rsrc(p2.residual ? p2.residual + (long long)tl.b * H * W * p2.res_pix_stride : nullptr, p2.residual ? frame_res : 0u);
         const int xl = tl.x0 + 4 * lh;
         const int cmax = xl < W ? W - xl : 0;      // c_r < cmax  <=>  x < W
+        const bool edge = tl.x0 + TW > W || tl.y0 + TH > H || (nt0 + WNW) * 32 > p2.Cout_store;     // wave-uniform
 #pragma unroll
         for (int tn = 0; tn < WNW; ++tn) {
           const int n = (nt0 + tn) * 32 + li;
           const bool nok = n < p2.Cout_store;
-          const float bv = (p2.bias && nok) ? p2.bias[n] : 0.f;
-          float ps = 1.f, pt = 0.f;
-          if (p2.post_scale && nok) { ps = p2.post_scale[n]; pt = p2.post_shift[n]; }
           double st_s = 0., st_q = 0.;       // sum / sum of squares of this wave's stored values of channel n (stats_ws)
 #pragma unroll
           for (int tm = 0; tm < WMW; ++tm) {
             const int y = tl.y0 + row0 + tm;
             const int cm = (nok && y < H) ? cmax : 0;
             const int pix = y * W + xl;
-            const unsigned o0 = (unsigned)((pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4);
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-            if (p2.residual) {
-              const unsigned r0 = (unsigned)((pix * (int)p2.res_pix_stride + p2.res_ch_off + n) * 4);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int c = (r & 3) + 8 * (r >> 2);
-                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0));
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int c = (r & 3) + 8 * (r >> 2);
-              float v = acc[tm][tn][r] * os2 + bv;
-              v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
-              const double vm = c < cm ? (double)v : 0.;
-              st_s += vm; st_q += vm * vm;
-            }
+            const int o0 = (pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4;
+            const int r0 = (pix * (int)p2.res_pix_stride + p2.res_ch_off + n) * 4;
+            if (st_on) egne::epi_row32_select<true>(edge, full_epi, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
+            else egne::epi_row32_select<false>(edge, full_epi, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
           }
-          if (p2.stats_ws) {                 // one chunk = this wave's rows of this tile (fixed order: deterministic)
+          if (st_on) {                 // one chunk = this wave's rows of this tile (fixed order: deterministic)
             st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
             if (lh == 0 && n < p2.Cout_store) {
               const int tile_in_frame = (tl.y0 / TH) * tiles_x + tl.x0 / TW;
@@ -483,24 +535,30 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
           }
         }
       }
+      stamp(t_work);
       lds_barrier();      // image i&1 may be overwritten, image (i+1)&1 is complete
+      stamp(t_wait);
     }
+  }
+  if ((dbg & 64) && lane == 0) {
+    unsigned long long* o = g_stamps + ((long long)blockIdx.x * 8 + wave) * 4;
+    o[0] = t_work; o[1] = t_wait; o[2] = nmine | ((unsigned long long)(t_mma / (nmine ? nmine : 1)) << 32); o[3] = __builtin_amdgcn_s_memrealtime() - r_first;
   }
 }
 
-template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false>
+template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false, bool UNI = false, int GL = 0>
 int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const GroupTab& gt, const _Float16* w1hi, const _Float16* w1lo,
                  int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
   const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0) +
                      (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * 32 * NCH * sizeof(float) : 0);
-  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024) == hipSuccess;
   if (!once || lds > 160 * 1024) return egne::fail(EGNE_ERR_LAUNCH, "conv_fused_1x1_3x3: %zu bytes of LDS", lds);
   int gx = 256;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
+  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
                      a2, os2, tiles_x, tiles_y, ntiles);
   return egne::check_launch("egne_conv1x1_3x3_fused_f16_fwd");
 }
@@ -527,6 +585,7 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   EGNE_REQUIRE(!d1.bias || ((uintptr_t)d1.bias & 15) == 0, "conv_fused_1x1_3x3: bias alignment");
   GroupTab gt;
   int G = 0;
+  bool uni = true;
   for (int s = 0; s < d1.nseg; ++s) {
     const egne_seg& g = d1.seg[s];
     EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && g.Cp % 8 == 0 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
@@ -534,10 +593,14 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                  "conv_fused_1x1_3x3: slice %d", s);
     const int n16 = (g.Cp + 15) / 16;
     EGNE_REQUIRE(G + n16 <= MAXG, "conv_fused_1x1_3x3: more than %d channel groups", MAXG);
-    for (int k = 0; k < n16; ++k) gt.v[G + k] = (s << 16) | ((k == n16 - 1 && (g.Cp & 15)) ? 0x8000 : 0) | k;
+    for (int k = 0; k < n16; ++k) {
+      gt.v[G + k] = (s << 16) | ((k == n16 - 1 && (g.Cp & 15)) ? 0x8000 : 0) | k;
+      gt.off[G + k] = (g.ch_off + 16 * k) * 4;
+    }
+    uni = uni && g.ptr == d1.seg[0].ptr && g.pix_stride == d1.seg[0].pix_stride;
     G += n16;
   }
-  for (int k = G; k < MAXG; ++k) gt.v[k] = 0;
+  for (int k = G; k < MAXG; ++k) gt.v[k] = gt.off[k] = 0;
   EGNE_REQUIRE(d2.out && d2.Cout_store <= d2.CoutP && d2.out_ch_off + d2.Cout_store <= d2.out_pix_stride &&
                (long long)d2.H * d2.W * d2.out_pix_stride * 4 < (1ll << 31) &&
                (!d2.residual || (long long)d2.H * d2.W * d2.res_pix_stride * 4 < (1ll << 31)), "conv_fused_1x1_3x3: output");
@@ -557,16 +620,26 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                  d1.res_pix_stride % 4 == 0 && ((uintptr_t)d1.residual & 15) == 0 && d1.res_ch_off + 32 <= d1.res_pix_stride &&
                  (long long)d1.B * d1.Ho * d1.Wo * d1.res_pix_stride * 4 < (1ll << 31),
                  "conv_fused_1x1_3x3: the up-sampled addend needs 32 -> 32 channels, <= 8 groups and a half-resolution tensor");
+    if (uni && G == 4) return launch_fused<1, 1, 8, 1, false, true, true, 4>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
+    if (uni)
+      return G <= 4 ? launch_fused<1, 1, 8, 1, false, true, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st)
+                    : launch_fused<1, 1, 8, 2, false, true, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
     return G <= 4 ? launch_fused<1, 1, 8, 1, false, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st)
                   : launch_fused<1, 1, 8, 2, false, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
   }
   if (d1.CoutP == 32) {
     const int nb = (G + 3) / 4;
-#define EGNE_FUSED(WN_) \
-  (nb == 1 ? launch_fused<1, WN_, 8, 1>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
-           : nb == 2 ? launch_fused<1, WN_, 8, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
-                     : launch_fused<1, WN_, 8, 3>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
-    return d2.CoutP == 32 ? EGNE_FUSED(1) : EGNE_FUSED(2);
+#define EGNE_FUSED(WN_, U_) \
+  (nb == 1 ? launch_fused<1, WN_, 8, 1, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+           : nb == 2 ? launch_fused<1, WN_, 8, 2, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+                     : launch_fused<1, WN_, 8, 3, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
+    if (uni && d2.CoutP == 32 && (G == 4 || G == 6 || G == 8)) {     // the dense-block shapes: straight-line items
+      if (G == 4) return launch_fused<1, 1, 8, 1, false, false, true, 4>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
+      if (G == 6) return launch_fused<1, 1, 8, 2, false, false, true, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
+      return launch_fused<1, 1, 8, 2, false, false, true, 4>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
+    }
+    if (uni) return d2.CoutP == 32 ? EGNE_FUSED(1, true) : EGNE_FUSED(2, true);
+    return d2.CoutP == 32 ? EGNE_FUSED(1, false) : EGNE_FUSED(2, false);
 #undef EGNE_FUSED
   }
   // 64-channel intermediate: 4-row tiles, items of 2 groups, an even number of batches per 32-pixel block
@@ -605,7 +678,14 @@ extern "C" int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const
   EGNE_REQUIRE(((uintptr_t)c4hi & 15) == 0 && ((uintptr_t)c4lo & 15) == 0 && ((uintptr_t)f2hi & 15) == 0 && ((uintptr_t)f2lo & 15) == 0 &&
                a1 > 0.f && a2 > 0.f && w1_scale > 0.f && w2_scale > 0.f && (!d1.bias || ((uintptr_t)d1.bias & 15) == 0), "conv_fused_c4_3x3: weights / scales");
   GroupTab gt;
-  for (int k = 0; k < MAXG; ++k) gt.v[k] = 0;
+  for (int k = 0; k < MAXG; ++k) gt.v[k] = gt.off[k] = 0;
   return launch_fused<1, 1, 8, 1, true>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 3, (const _Float16*)f2hi, (const _Float16*)f2lo,
                                         a1, 1.0f / (a1 * w1_scale), a2, 1.0f / (a2 * w2_scale), (hipStream_t)stream);
+}
+
+// diagnostics (not part of the product interface): set the debug word of the fused kernel, read its per-wave stamps
+extern "C" int egne_fused_debug(int dbg, void* out_stamps) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg, sizeof(int)) != hipSuccess) return -2;
+  if (out_stamps && hipMemcpyFromSymbol(out_stamps, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256 * 8 * 4) != hipSuccess) return -2;
+  return 0;
 }

@@ -19,6 +19,9 @@ HALO_ENABLED = os.environ.get("EGNE_HALO", "1") != "0"
 F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA for layers that ask for it (BDCN)
 HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
+LAYER_BYTES = {}          # layer name -> algorithmic bytes of its launch(es) (input slices + stored output), for bench.py --layers
+RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
+RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
 MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
@@ -462,6 +465,11 @@ class Plan:
                 and layer.act == ACT_RELU and layer.post is None and H * W * piece.stride < 2 ** 29)
 
     def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None):
+        r = self._conv_impl(layer, pieces, dst, B, H, W, residual, name, stats, scores)
+        LAYER_BYTES[name] = 4.0 * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
+        return r
+
+    def _conv_impl(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None):
         """pieces: input Pieces in concat order; dst: output Piece.  Returns (Ho, Wo); with ``stats`` also leaves the
         per-sample InstanceNorm (scale, shift) of the OUTPUT in ``self.last_stats`` -- from partial sums written by the
         kernel's epilogue where the kernel can do that, from a separate statistics pass otherwise."""
@@ -511,6 +519,14 @@ class Plan:
                  and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29)
         if msdil:
             lattice = False
+        # narrow-input 3x3 layers on wide maps: producer / consumer waves (conv3x3_rs_f16.hip) instead of the all-in-one halo kernel
+        rs = (split and RS_ENABLED and HALO_F16_ENABLED and not lattice and not msdil and layer.kh == 3 and layer.kw == 3
+              and layer.G == 1 and layer.pad == (1, 1) and layer.stride == 1 and layer.pad_mode == 0 and layer.dils[0] == 1
+              and len(pieces) == 1 and W >= RS_MIN_W and H * W * max(pieces[0].stride, dst.stride) < 2 ** 29
+              and 8 <= pieces[0].Cp <= 64 and layer.sfrag_coutp() in (32, 64, 128)
+              and not (pieces[0].Cp <= 32 and layer.sfrag_coutp() == 128)
+              and (residual is None or H * W * residual.stride < 2 ** 29))
+        shalo = shalo or rs
         if lattice or msdil:
             shalo = True
         if split and not shalo and halo and pieces[0].scale is not None and layer.CoutP <= 32 and W >= HALO_F16_MIN_W:
@@ -648,6 +664,17 @@ class Plan:
                 self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(dg), layer.fhi.data_ptr() + 2 * g * perf,
                                                              layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
                           name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice", cal=cal3)
+        elif shalo and rs:
+            th = 8 if pieces[0].Cp <= 32 else 4
+            nchunk = ((W + 31) // 32) * ((H + th - 1) // th) * (2 if (th == 4 and layer.sfrag_coutp() >= 64) else 4)
+            fuse_stats = stats and STATS_FUSED and dst.Cp == int(d.Cout_store)
+            if fuse_stats:
+                ws = self._stats_ws(d, B, nchunk)
+            self._add(self.L.egne_conv3x3_rs_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
+                                                       layer.w_scale), name, flops=flops, kind="conv_f16x3:rs", cal=cal3)
+            if fuse_stats:
+                self.last_stats = self._stats_finish(ws, d, B, H * W, nchunk, name)
+                stats = False
         elif shalo:
             tx, ty = (W + 31) // 32, (H + 7) // 8
             tall = ((H + 31) // 32) * ((W + 7) // 8) < tx * ty          # the kernel would walk the map transposed
@@ -696,6 +723,12 @@ class Plan:
                 and W >= FUSE_1X1_MIN_W and all(H * W * pc.stride < 2 ** 29 for pc in pieces) and H * W * dst.stride < 2 ** 29)
 
     def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False, up_add=None):
+        r = self._conv_pair_impl(l1, pieces, l2, dst, B, H, W, tmp, residual, name, stats, up_add)
+        LAYER_BYTES[name] = 4.0 * B * H * W * (sum(p.Cp for p in pieces) + min(l2.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)
+                                               + (8 if up_add is not None else 0))
+        return r
+
+    def _conv_pair_impl(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False, up_add=None):
         """``l2(l1(cat(pieces)))``: a 1x1 convolution over raw slices followed by the 3x3 that is its only consumer
         (RITnet_v2.py:59-62,84-87).  Inference plans run the pair as ONE launch whose intermediate stays in LDS
         (conv_fused_1x1_3x3_f16.hip); otherwise two launches through ``tmp`` (a Piece, allocated here if None)."""

@@ -150,6 +150,13 @@ int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* d, const void* fhi, co
                                     const float* score_w, const float* score_c, float* s0, float* s1, int accumulate,
                                     void* stream);
 
+/* Role-split variant of egne_conv3x3_halo_f16_fwd for narrow inputs (one slice of <= 64 channels: vgg16_c.py:66-69 conv1_2 /
+ * conv2_1, bdcn_new.py:50 stage-1 MSBlock convs, models/RITnet_v2.py:57 down-block conv1, utils.py:1047-1048 decoder convBlock):
+ * 4 producer waves stage the halo (gather, fused affine, fp32 -> hi / lo) while 4 consumer waves do nothing but LDS reads and
+ * MFMAs.  Same descriptor and weight pack; dilation 1, Ktot 32 or 64, CoutP 32 / 64 / 128; stats_ws allowed. */
+int egne_conv3x3_rs_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
+                            void* stream);
+
 /* Streaming 1x1 convolution over a concatenation of raw NHWC slices (models/RITnet_v2.py:59,61,84,86 conv21 / conv31 /
  * conv11, :38 Transition_down in eval plans) on the split-f16 path: no staging, every lane loads its MFMA operand
  * straight from HBM, weight fragments stay in LDS.  Same descriptor as egne_conv2d_fwd (`w` unused; no fused affine,

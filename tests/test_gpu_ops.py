@@ -664,7 +664,8 @@ def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C
     scale, shift = pl.last_stats
     fused = pl.calls[-1][0] is pl.L.egne_norm_stats_finish
     tall = ((H + 31) // 32) * ((W + 7) // 8) < ((W + 31) // 32) * ((H + 7) // 8)      # the halo kernel walks such maps transposed
-    assert fused == (kind == "pair" or not tall)
+    rs = any(m[0].endswith(":rs") for m in pl.meta)                                    # the role-split kernel never does
+    assert fused == (kind == "pair" or rs or not tall)
     for _ in range(2):
         pl.run()
         torch.cuda.synchronize()
@@ -673,6 +674,52 @@ def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C
         rstd = 1.0 / torch.sqrt(var + 1e-5)
         np.testing.assert_allclose(scale.cpu().numpy()[:, :C2], rstd.numpy(), rtol=2e-6)
         np.testing.assert_allclose(shift.cpu().numpy()[:, :C2], (-mean * rstd).numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,mode", [(2, 64, 64, 61, 83, "plain"), (1, 64, 128, 120, 160, "plain"), (2, 64, 32, 61, 70, "res"),
+                                                  (2, 32, 32, 61, 83, "norm"), (1, 38, 64, 120, 160, "norm"), (3, 56, 30, 33, 64, "plain"),
+                                                  (2, 32, 2, 64, 96, "norm")])
+def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
+    """conv3x3_rs_f16.hip (producer / consumer waves; vgg16_c.py:66-69, bdcn_new.py:50, models/RITnet_v2.py:57, utils.py:1047)
+    against a float64 convolution: plain, with the residual addend, and with the InstanceNorm affine + LeakyReLU applied while
+    the halo is staged (zero padding AFTER the normalisation) plus statistics of the stored output."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = _rand(G, B, Cin, H, W) * 2 + 0.5
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=2)
+    layer.split = True
+    out = pl.buf(B, H, W, pad8(Cout))
+    xin, residual = x.double(), None
+    if mode == "norm":
+        mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+        sc, sh = torch.zeros(B, px.Cp, device=DEV), torch.zeros(B, px.Cp, device=DEV)
+        sc[:, :Cin], sh[:, :Cin] = rstd.to(DEV), (-mean * rstd).to(DEV)
+        pl.keep += [sc, sh]
+        px = px.with_norm(sc, sh, 2)
+        xin = F.leaky_relu(F.instance_norm(x.double()))
+    truth = F.leaky_relu(F.conv2d(xin, w.double(), b.double(), padding=1))
+    if mode == "res":                      # the residual joins AFTER the activation (bdcn_new.py:55: o + relu(conv(o)))
+        r = _rand(G, B, Cout, H, W)
+        (pr,) = to_nhwc_buf(pl, [r], B, H, W)
+        residual = pr
+        truth = truth + r.double()
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W, residual=residual, stats=(mode == "norm"))
+    assert any(m[0] == "conv_f16x3:rs" for m in pl.meta)
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        assert (got[:, :Cout] - truth).abs().max().item() / truth.abs().max().item() < 2e-6
+        assert (got[:, Cout:] == 0).all()
+        if mode == "norm":
+            scale, shift = pl.last_stats
+            y = got[:, :Cout]
+            rstd = 1.0 / torch.sqrt(y.var((2, 3), unbiased=False) + 1e-5)
+            np.testing.assert_allclose(scale.cpu().numpy()[:, :Cout], rstd.numpy(), rtol=2e-6)
+            np.testing.assert_allclose(shift.cpu().numpy()[:, :Cout], (-y.mean((2, 3)) * rstd).numpy(), rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("Cin,B,H,W,post", [(1, 3, 61, 83, True), (2, 2, 240, 320, True), (3, 2, 33, 64, False)])
