@@ -11,9 +11,14 @@
 //   * the product is computed transposed (weights as the A operand), so a lane ends up with 4 consecutive output
 //     channels of one pixel and stores 16 bytes.
 // LDS image of a stage: row r (pixel or output channel) = 128 bytes = 4 granules of 8 channels, granule = [hi x8 | lo x8];
-// the 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7): ds_read_b128 by 16 consecutive rows is conflict free.
+// the 16-byte chunk c of row r sits at chunk c ^ (((r >> 1) + 6) & 7): conflict free for the ds_read_b128 patterns of BOTH MFMA
+// shapes (32 rows x 2 chunk columns for 32x32x16, 16 rows x 4 chunk columns for 16x16x32).
+//
+// M16 computes the same tile with v_mfma_f32_16x16x32_f16 (one instruction per 32-channel step and 16 x 16 block): the same
+// FLOP per cycle, but these kernels run at the power limit and the chip holds a higher clock on this shape (MI355X DVFS).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,14 +39,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 
 // NB = 32-channel blocks per wave along N (2 -> BN = 256 with 4 waves along N, 1 -> BN = 128)
-template <int NB>
+template <int NB, bool M16>
 __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_desc p, const char* __restrict__ wimg, float a_scale,
                                                              float out_scale) {
   constexpr int BN = 128 * NB;
   constexpr int STAGE = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, kq = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;               // 2 x 4 waves; wave tile 128 x (32 * NB)
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const long long m0 = (long long)blockIdx.x * BM;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
   int ldst_hi[4], ldst_lo[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = (tid >> 3) + 64 * i, g = c4 >> 1, sw = (r >> 1) & 7;
+    const int r = (tid >> 3) + 64 * i, g = c4 >> 1, sw = ((r >> 1) + 6) & 7;
     ldst_hi[i] = r * ROWB + (((2 * g) ^ sw) << 4) + (c4 & 1) * 8;
     ldst_lo[i] = r * ROWB + (((2 * g + 1) ^ sw) << 4) + (c4 & 1) * 8;
   }
@@ -129,18 +133,22 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
     if (ky_n == p.kh) { ky_n = 0; c0_n += 32; }
   };
 
-  f32x16 acc[4][NB];
+  // 32x32x16: acc[4][NB] blocks of 32 x 32; 16x16x32: acc[8][2 * NB] blocks of 16 x 16 (same 64 * NB registers)
+  constexpr int MB = M16 ? 16 : 32, NTM = 128 / MB, NTN = 32 * NB / MB;
+  using acc_t = std::conditional_t<M16, f32x4, f32x16>;
+  acc_t acc[NTM][NTN];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NTM; ++a)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[a][b] = (f32x16)(0.f);
+    for (int b = 0; b < NTN; ++b) acc[a][b] = (acc_t)(0.f);
 
-  int aoffs[4], boffs[NB];
+  const int lr = lane & (MB - 1), kg = lane / MB;       // row inside a block, 8-channel group (2 or 4 of them)
+  int aoffs[NTM], boffs[NTN];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) aoffs[t] = (wm * 128 + t * 32 + li) * ROWB;
+  for (int t = 0; t < NTM; ++t) aoffs[t] = (wm * 128 + t * MB + lr) * ROWB;
 #pragma unroll
-  for (int t = 0; t < NB; ++t) boffs[t] = BM * ROWB + (wn * 32 * NB + t * 32 + li) * ROWB;
-  const int sw = (li >> 1) & 7;
+  for (int t = 0; t < NTN; ++t) boffs[t] = BM * ROWB + (wn * 32 * NB + t * MB + lr) * ROWB;
+  const int sw = ((lr >> 1) + 6) & 7;
 
   // prologue: step 0 into stage 0
   load_a(0);
@@ -159,9 +167,36 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
       dma_b(st ^ 1, step + 1);
     }
     const char* base = lds + st * STAGE;
+    if constexpr (M16) {
+      const int ch = ((2 * kg) ^ sw) << 4, cl = ((2 * kg + 1) ^ sw) << 4;
+      h8 bh[NTN], bl[NTN];
+#pragma unroll
+      for (int t = 0; t < NTN; ++t) {
+        bh[t] = *(const h8*)(base + boffs[t] + ch);
+        bl[t] = *(const h8*)(base + boffs[t] + cl);
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        h8 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ah[t] = *(const h8*)(base + aoffs[half * 4 + t] + ch);
+          al[t] = *(const h8*)(base + aoffs[half * 4 + t] + cl);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int tn = 0; tn < NTN; ++tn) {
+            acc_t& c = acc[half * 4 + t][tn];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], al[t], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[tn], ah[t], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], ah[t], c, 0, 0, 0);
+          }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ((2 * (2 * ks + kq)) ^ sw) << 4, cl = ((2 * (2 * ks + kq) + 1) ^ sw) << 4;
+      const int ch = ((2 * (2 * ks + kg)) ^ sw) << 4, cl = ((2 * (2 * ks + kg) + 1) ^ sw) << 4;
       h8 ah[4], al[4], bh[NB], bl[NB];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -177,10 +212,13 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < NB; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tn], al[tm], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[tn], ah[tm], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tn], ah[tm], acc[tm][tn], 0, 0, 0);
+          if constexpr (!M16) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tn], al[tm], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[tn], ah[tm], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tn], ah[tm], acc[tm][tn], 0, 0, 0);
+          }
         }
+    }
     }
     if (more) {
       store_a(st ^ 1);              // the other stage was last read in step-1: every wave passed the barrier since
@@ -191,26 +229,28 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
     __builtin_amdgcn_s_barrier();
   }
 
-  // ---- epilogue: transposed product, lane = pixel li of the block, channels n = 32*blk + 8*j + 4*kq + e ----
+  // ---- epilogue: transposed product, lane = pixel lr of the block; 32x32x16: channels n = 32*blk + 8*j + 4*kg + e (register
+  //      4*j + e); 16x16x32: channels n = 16*blk + 4*kg + e (register e) ----
   const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   const long long left = M - m0;
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * 4));
+  constexpr int NJ = M16 ? 1 : 4;
 #pragma unroll
-  for (int tn = 0; tn < NB; ++tn)
+  for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = ntile * BN + wn * 32 * NB + tn * 32 + 8 * j + 4 * kq;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = ntile * BN + wn * 32 * NB + tn * MB + (M16 ? 4 * kg : 8 * j + 4 * kg);
       const bool nok = n < p.Cout_store;
       const f32x4 bv = (p.bias && nok) ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
+      for (int tm = 0; tm < NTM; ++tm) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float t = acc[tm][tn][4 * j + e] * out_scale + bv[e];
           v[e] = fmaxf(t, t * slope);
         }
-        const int row = wm * 128 + tm * 32 + li;
+        const int row = wm * 128 + tm * MB + lr;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
                                                nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
       }
@@ -218,7 +258,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
 }
 
 // OIHW fp32 -> LDS images [ntile][step = chunk*T + tap][BN rows][128 B]: row j = output channel ntile*BN + j, granule g =
-// channels chunk*32 + 8g .. +7 as [hi x8 | lo x8], 16-byte chunk c stored at chunk c ^ ((j >> 1) & 7)
+// channels chunk*32 + 8g .. +7 as [hi x8 | lo x8], 16-byte chunk c stored at chunk c ^ (((j >> 1) + 6) & 7)
 __global__ void pack_weight_f16img_k(const float* __restrict__ w, int Cout, int Cin, int T, int BN, int ntiles, int nchunk,
                                      float wscale, _Float16* __restrict__ out) {
   const long long total = (long long)ntiles * nchunk * T * BN * 64;     // halfs
@@ -229,7 +269,7 @@ __global__ void pack_weight_f16img_k(const float* __restrict__ w, int Cout, int 
     const int step = (int)(q % (nchunk * T));
     const int nt = (int)(q / (nchunk * T));
     const int chunk = step / T, tap = step - chunk * T;
-    const int lc = pc ^ ((j >> 1) & 7), g = lc >> 1, hl = lc & 1;
+    const int lc = pc ^ (((j >> 1) + 6) & 7), g = lc >> 1, hl = lc & 1;
     const int n = nt * BN + j, ci = chunk * 32 + 8 * g + e;
     const float v = (n < Cout && ci < Cin) ? w[((long long)n * Cin + ci) * T + tap] * wscale : 0.f;
     const _Float16 h = (_Float16)v;
@@ -272,16 +312,21 @@ extern "C" int egne_conv2d_f16x3_big_fwd(const egne_conv_desc* dp, const void* w
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   static bool once = [] {
-    return hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-           hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    return hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
   }();
+  static const bool m16 = !(getenv("EGNE_BIG_M16") && atoi(getenv("EGNE_BIG_M16")) == 0);     // MFMA shape (header)
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv_f16x3_big: cannot raise the dynamic LDS limit");
   if (d.CoutP % 256 == 0) {
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 256));
-    hipLaunchKernelGGL((conv_f16x3_big_kernel<2>), grid, dim3(512), 2 * (BM + 256) * ROWB, st, d, (const char*)wimg, a_scale, os);
+    if (m16) hipLaunchKernelGGL((conv_f16x3_big_kernel<2, true>), grid, dim3(512), 2 * (BM + 256) * ROWB, st, d, (const char*)wimg, a_scale, os);
+    else hipLaunchKernelGGL((conv_f16x3_big_kernel<2, false>), grid, dim3(512), 2 * (BM + 256) * ROWB, st, d, (const char*)wimg, a_scale, os);
   } else {
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 128));
-    hipLaunchKernelGGL((conv_f16x3_big_kernel<1>), grid, dim3(512), 2 * (BM + 128) * ROWB, st, d, (const char*)wimg, a_scale, os);
+    if (m16) hipLaunchKernelGGL((conv_f16x3_big_kernel<1, true>), grid, dim3(512), 2 * (BM + 128) * ROWB, st, d, (const char*)wimg, a_scale, os);
+    else hipLaunchKernelGGL((conv_f16x3_big_kernel<1, false>), grid, dim3(512), 2 * (BM + 128) * ROWB, st, d, (const char*)wimg, a_scale, os);
   }
   return egne::check_launch("egne_conv2d_f16x3_big_fwd");
 }

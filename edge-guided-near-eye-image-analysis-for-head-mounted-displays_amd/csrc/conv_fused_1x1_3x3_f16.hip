@@ -644,11 +644,12 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   }
   // 64-channel intermediate: 4-row tiles, items of 2 groups, an even number of batches per 32-pixel block
   const int nb2 = ((G + 1) / 2 + 1) / 2 * 2;
-#define EGNE_FUSED2(WN_) \
-  (nb2 == 2 ? launch_fused<2, WN_, 4, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
-            : nb2 == 4 ? launch_fused<2, WN_, 4, 4>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
-                       : launch_fused<2, WN_, 4, 6>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
-  return d2.CoutP == 32 ? EGNE_FUSED2(1) : EGNE_FUSED2(2);
+#define EGNE_FUSED2(WN_, U_) \
+  (nb2 == 2 ? launch_fused<2, WN_, 4, 2, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+            : nb2 == 4 ? launch_fused<2, WN_, 4, 4, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
+                       : launch_fused<2, WN_, 4, 6, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
+  if (uni && d2.CoutP == 64) return EGNE_FUSED2(2, true);     // dense block with 64-channel intermediates (one buffer)
+  return d2.CoutP == 32 ? EGNE_FUSED2(1, false) : EGNE_FUSED2(2, false);
 #undef EGNE_FUSED2
 }
 
