@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ("residual", c_fp), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
                 ("out", c_fp), ("out_pix_stride", C.c_int64), ("out_ch_off", C.c_int32),
                 ("Cout_store", C.c_int32),
-                ("stats_ws", c_fp), ("stats_nchunk", C.c_int32)]
+                ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
+                ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32)]
 
 
 class BdcnTailDesc(C.Structure):

@@ -130,14 +130,18 @@ class BDCN(nn.Module):
         pl.raw(L.egne_nchw_to_nhwc, (x_in.data_ptr(), B, 3, H, W, xb.data_ptr(), 8, 0, 8), "bdcn.in")
         cur, ch, hh, ww = Piece(xb, 0, 3), 3, H, W
         feats = []
-        for item in _VGG:
+        pooled = None               # a stride-2 pooling already written by the convolution in front of it
+        for idx, item in enumerate(_VGG):
             if item[0] == "P":
                 s = item[1]
                 ho, wo = maxpool_out(hh, s), maxpool_out(ww, s)
-                ob = pl.buf(B, ho, wo, cur.Cp)
-                dst = Piece(ob, 0, cur.C)
-                pl.maxpool2(cur, dst, B, hh, ww, s, "vgg.pool")
-                cur, hh, ww = dst, ho, wo
+                if pooled is not None:
+                    dst = pooled
+                else:
+                    ob = pl.buf(B, ho, wo, cur.Cp)
+                    dst = Piece(ob, 0, cur.C)
+                    pl.maxpool2(cur, dst, B, hh, ww, s, "vgg.pool")
+                cur, hh, ww, pooled = dst, ho, wo, None
                 continue
             name, cin, cout, d = item
             conv = getattr(f, name)
@@ -146,7 +150,12 @@ class BDCN(nn.Module):
             layer.split_c4 = cin <= 4        # conv1_1: streaming split-f16 first-layer kernel (conv3x3_c4_f16.hip)
             ob = pl.buf(B, hh, ww, cout)
             dst = Piece(ob, 0, cout)
-            pl.conv(layer, [cur], dst, B, hh, ww, name="vgg." + name)
+            nxt = _VGG[idx + 1] if idx + 1 < len(_VGG) else None
+            pq = None
+            if nxt is not None and nxt[0] == "P" and nxt[1] == 2:         # vgg16_c.py:70: pooling right behind this convolution
+                pq = Piece(pl.buf(B, maxpool_out(hh, 2), maxpool_out(ww, 2), pad8(cout)), 0, cout)
+            pl.conv(layer, [cur], dst, B, hh, ww, name="vgg." + name, pool=pq)
+            pooled = pq if pl.last_pooled else None
             cur = dst
             feats.append((dst, cout, hh, ww))
         # MSBlocks + stage scores

@@ -386,6 +386,36 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           }()), ...);
         }(std::make_integer_sequence<int, NS>{});
         phase(ph_mma);
+        // second output: 2x2 / stride 2 / ceil-mode max pooling of the activated result -- the wave owns both rows of a pooling
+        // window (row0 and y0 are even) and the lane both of its columns (registers r, r + 1); act(max) = max(act): monotonic
+        if constexpr (WMW == 2 && !M16) {
+          if (p.pool_out) {
+            const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+            const __amdgpu_buffer_rsrc_t rpo = make_rsrc(p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride,
+                                                         (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * 4u);
+            const int xl = tl.x0 + 4 * kg, y = tl.y0 + row0;
+            const bool y1 = y + 1 < H;
+#pragma unroll
+            for (int tn = 0; tn < WNW; ++tn) {
+              const int n = (nt0 + tn) * 32 + lm;
+              const bool nok = n < p.Cout_store && y < H;
+#pragma unroll
+              for (int r = 0; r < 16; r += 2) {
+                const int c = (r & 3) + 8 * (r >> 2), x = xl + c;
+                float m = acc[0][0][tn][0][r];
+                if (x + 1 < W) m = fmaxf(m, acc[0][0][tn][0][r + 1]);
+                if (y1) {
+                  m = fmaxf(m, acc[1][0][tn][0][r]);
+                  if (x + 1 < W) m = fmaxf(m, acc[1][0][tn][0][r + 1]);
+                }
+                float v = m * out_scale + bvs[tn][0];
+                v = fmaxf(v, v * slope_out);
+                const int off = (nok && x < W) ? ((((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + n) * 4) : (int)OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rpo, off, 0, 0);
+              }
+            }
+          }
+        }
         // hand the tile over to the deferred epilogue
 #pragma unroll
         for (int a = 0; a < WMW * NMH * WNW * NMH; ++a) (&prev[0][0][0][0])[a] = (&acc[0][0][0][0])[a];
@@ -479,6 +509,9 @@ extern "C" int egne_conv3x3_rs_f16_fwd(const egne_conv_desc* dp, const void* fhi
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
                (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv3x3_rs: frame too large for 32-bit byte offsets");
   const int th = d.Ktot == 32 ? 8 : 4, rg = (th == 4 && d.CoutP >= 64) ? 2 : 4;
+  EGNE_REQUIRE(!d.pool_out || (!m16 && !d.post_scale && d.Ktot == 64 && d.CoutP >= 64 && d.pool_ch_off + d.Cout_store <= d.pool_pix_stride &&
+                                (long long)((d.H + 1) / 2) * ((d.W + 1) / 2) * d.pool_pix_stride * 4 < (1ll << 31)),
+               "conv3x3_rs: the pooled output needs a shape with two rows per wave (Ktot 64, CoutP >= 64), no post affine");
   EGNE_REQUIRE((dbg & 32) || !d.stats_ws || (((uintptr_t)d.stats_ws & 15) == 0 && d.stats_nchunk == ((d.W + 31) / 32) * ((d.H + th - 1) / th) * rg),
                "conv3x3_rs: stats_nchunk must be tiles * %d for this shape", rg);
   const float os = 1.0f / (a_scale * w_scale);

@@ -20,6 +20,7 @@ F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA f
 HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LAYER_BYTES = {}          # layer name -> algorithmic bytes of its launch(es) (input slices + stored output), for bench.py --layers
+POOL_FUSED = os.environ.get("EGNE_POOL_FUSED", "1") != "0"     # conv1_2 writes pool1 from its epilogue (conv3x3_rs_f16.hip)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
 MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
@@ -464,8 +465,12 @@ class Plan:
                 and layer.pad == (1, 1) and layer.dils == (4, 8, 12) and layer.CoutP == 32 and piece.Cp == 32 and piece.scale is None
                 and layer.act == ACT_RELU and layer.post is None and H * W * piece.stride < 2 ** 29)
 
-    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None):
+    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None, pool=None):
+        """``pool``: a Piece for the 2x2 / stride-2 ceil-mode max pooling of the result; ``self.last_pooled`` tells the caller
+        whether the convolution kernel wrote it (otherwise the caller runs maxpool2)."""
+        self._pool_req, self.last_pooled = pool, False
         r = self._conv_impl(layer, pieces, dst, B, H, W, residual, name, stats, scores)
+        self._pool_req = None
         LAYER_BYTES[name] = 4.0 * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
         return r
 
@@ -665,6 +670,11 @@ class Plan:
                                                              layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
                           name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice", cal=cal3)
         elif shalo and rs:
+            pq = getattr(self, "_pool_req", None)
+            if (pq is not None and POOL_FUSED and pieces[0].Cp > 32 and layer.sfrag_coutp() >= 64 and layer.post is None
+                    and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and pq.Cp >= int(d.Cout_store)):
+                d.pool_out, d.pool_pix_stride, d.pool_ch_off = pq.ptr, pq.stride, pq.off
+                self.last_pooled = True
             th = 8 if pieces[0].Cp <= 32 else 4
             nchunk = ((W + 31) // 32) * ((H + th - 1) // th) * (2 if (th == 4 and layer.sfrag_coutp() >= 64) else 4)
             fuse_stats = stats and STATS_FUSED and dst.Cp == int(d.Cout_store)

@@ -90,6 +90,12 @@ typedef struct {
    * pass over the tensor.  A chunk is one wave's rows of one tile: stats_nchunk = ceil(W/32) * ceil(H/8) * 4. */
   double* stats_ws;
   int32_t stats_nchunk;
+  /* Optional (egne_conv3x3_rs_f16_fwd, shapes whose consumer waves own two tile rows): second output = the 2x2 / stride 2 /
+   * ceil-mode max pooling of the stored result (vgg16_c.py:70 pool1 behind conv1_2), [B][ceil(H/2)][ceil(W/2)] pixels of
+   * pool_pix_stride floats, Cout_store channels from pool_ch_off; needs a monotonic activation and no post affine. */
+  float* pool_out;
+  int64_t pool_pix_stride;
+  int32_t pool_ch_off;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);

@@ -722,6 +722,32 @@ def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
             np.testing.assert_allclose(shift.cpu().numpy()[:, :Cout], (-y.mean((2, 3)) * rstd).numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (2, 61, 83), (1, 240, 320)])
+def test_conv3x3_role_split_pooled_second_output(G, B, H, W):
+    """vgg16_c.py:69-70: relu(conv1_2(x)) and its 2x2 / stride 2 / ceil-mode max pooling from ONE launch (the pooled tensor is a
+    second output of the role-split kernel's epilogue) -- both against a float64 convolution, odd sizes included."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = F.relu(_rand(G, B, 64, H, W)) * 3
+    w, b = _rand(G, 64, 64, 3, 3) / 24, _rand(G, 64)
+    truth = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    pooled = F.max_pool2d(truth, 2, stride=2, ceil_mode=True)
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(64, 64)], pad=(1, 1), act=1)
+    layer.split = True
+    out, pout = pl.buf(B, H, W, 64), pl.buf(B, (H + 1) // 2, (W + 1) // 2, 64)
+    pl.conv(layer, [px], Piece(out, 0, 64), B, H, W, pool=Piece(pout, 0, 64))
+    assert pl.last_pooled and any(m[0] == "conv_f16x3:rs" for m in pl.meta)
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        got, gp = out.cpu().permute(0, 3, 1, 2).double(), pout.cpu().permute(0, 3, 1, 2).double()
+        scale = truth.abs().max().item()
+        assert (got - truth).abs().max().item() / scale < 2e-6
+        assert (gp - pooled).abs().max().item() / scale < 2e-6
+
+
 @pytest.mark.parametrize("Cin,B,H,W,post", [(1, 3, 61, 83, True), (2, 2, 240, 320, True), (3, 2, 33, 64, False)])
 def test_convblock_pair_fused(G, Cin, B, H, W, post):
     """utils.py:1047-1048 convBlock: conv2(leaky(conv1(x))) with conv1 on 1-3 channels, as ONE launch (the first conv's 9 taps
