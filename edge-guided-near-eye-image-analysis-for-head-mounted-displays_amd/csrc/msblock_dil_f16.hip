@@ -203,19 +203,35 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
             const _Float16* Slo = Shi + NPXMAX * 32;
             const _Float16* wb = lw + ((9 * i + S) & 1) * WBUFH + lane * 8;
             if (ky == 0) { acc[g][0] = (f32x16)(0.f); acc[g][1] = (f32x16)(0.f); }
+            // software pipeline: the fragments of step f + 1 (weights and both rows' operands) are requested from LDS before the
+            // MFMAs of step f are issued -- one consumer wave per SIMD has nothing else to cover the LDS latency with
+            auto offs = [&](int f, int tm) {
+              const int kx = f >> 1, ks = f & 1;
+              const int q = (cw * 2 + tm) * SW + li + kx * d;
+              return q * 32 + (((ks * 2 + lh) ^ ((q >> 2) & 3)) << 3);
+            };
+            h8 bh[2], bl[2], ah[2][2], al[2][2];
+            bh[0] = *(const h8*)&wb[0]; bl[0] = *(const h8*)&wb[512];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) { ah[0][tm] = *(const h8*)&Shi[offs(0, tm)]; al[0][tm] = *(const h8*)&Slo[offs(0, tm)]; }
 #pragma unroll
             for (int f = 0; f < 6; ++f) {
-              const int kx = f >> 1, ks = f & 1;
-              const h8 bh = *(const h8*)&wb[(2 * f) * 512], bl = *(const h8*)&wb[(2 * f + 1) * 512];
+              if (f + 1 < 6) {
+                bh[(f + 1) & 1] = *(const h8*)&wb[(2 * f + 2) * 512]; bl[(f + 1) & 1] = *(const h8*)&wb[(2 * f + 3) * 512];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                  ah[(f + 1) & 1][tm] = *(const h8*)&Shi[offs(f + 1, tm)];
+                  al[(f + 1) & 1][tm] = *(const h8*)&Slo[offs(f + 1, tm)];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int tm = 0; tm < 2; ++tm) {
-                const int q = (cw * 2 + tm) * SW + li + kx * d;
-                const int o = q * 32 + (((ks * 2 + lh) ^ ((q >> 2) & 3)) << 3);
-                const h8 ah = *(const h8*)&Shi[o], al = *(const h8*)&Slo[o];
-                acc[g][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[g][tm], 0, 0, 0);
-                acc[g][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[g][tm], 0, 0, 0);
-                acc[g][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g][tm], 0, 0, 0);
+                acc[g][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[f & 1][tm], bh[f & 1], acc[g][tm], 0, 0, 0);
+                acc[g][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[f & 1][tm], bl[f & 1], acc[g][tm], 0, 0, 0);
+                acc[g][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[f & 1][tm], bh[f & 1], acc[g][tm], 0, 0, 0);
               }
+              __builtin_amdgcn_sched_barrier(0);
             }
           }()
         ), ...);

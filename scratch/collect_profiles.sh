@@ -19,14 +19,17 @@ cp $out/stats/r_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o r -- python3 $R/bench.py --mode train --steps 3 --warmup 2 --train-batch 64 > $out/stats_train.log 2>&1
 cp $out/stats_train/r_kernel_stats.csv $out/kernel_stats_train.csv 2>/dev/null
 fi
+python3 $R/scratch/rs_dbg.py > $out/clock_stamps_rs_64to64.txt 2>&1
+python3 $R/scratch/fused_dbg.py 32,32,32 > $out/clock_stamps_fused_96to32to32.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmc_$c -o r -- python3 $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmct_$c -o r -- python3 $R/bench.py --mode train --steps 1 --warmup 1 --train-batch 64 > $out/pmct_$c.log 2>&1
 done
 python3 - "$out" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, re, sys, collections
 out = sys.argv[1]
 SPLIT = ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel",
-         "fused_1x1_3x3_kernel", "msblock_dil_kernel", "conv3x3_c4_f16_kernel")
+         "fused_1x1_3x3_kernel", "msblock_dil_kernel", "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel")
 FP32 = ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel")
 fam = lambda k: "split_f16" if any(s in k for s in SPLIT) else ("fp32_conv" if any(s in k for s in FP32) else "other")
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
@@ -36,7 +39,8 @@ for c in tot:
     for f in glob.glob(out + "/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
             k = fam(r["Kernel_Name"])
-            short = r["Kernel_Name"].split("(")[0].split("<")[0][-48:]
+            m = re.search(r"(conv\w*kernel|fused_1x1_3x3_kernel|msblock_dil_kernel|\w+_k)\b", r["Kernel_Name"])
+            short = m.group(1) if m else r["Kernel_Name"].split("(")[0][-48:]
             tot[c][k] += float(r["Counter_Value"]); per[c][short] += float(r["Counter_Value"])
             if c == "FETCH_SIZE": cnt[k] += 1; pcnt[short] += 1
 steps = 3
@@ -50,8 +54,18 @@ for k in ("split_f16", "fp32_conv", "other"):
 for k in sorted(per["FETCH_SIZE"], key=lambda k: -per["FETCH_SIZE"][k])[:16]:
     res["kernels"][k] = {"dispatches_per_step": pcnt[k] // steps, "hbm_read_gb_per_step": round(2 * per["FETCH_SIZE"][k] * 1024 / steps / 1e9, 2),
                          "hbm_write_gb_per_step": round(per["WRITE_SIZE"][k] * 1024 / steps / 1e9, 2)}
+# training step (B=64, 2 steps profiled): totals only
+tt = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v = 0.0
+    for f in glob.glob(out + "/pmct_%s/**/*counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            v += float(r["Counter_Value"])
+    tt[c] = v
+res["train_b64"] = {"steps_profiled": 2, "hbm_read_gb_per_step": round(2 * tt["FETCH_SIZE"] * 1024 / 2 / 1e9, 2),
+                    "hbm_write_gb_per_step": round(tt["WRITE_SIZE"] * 1024 / 2 / 1e9, 2)}
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res["families"]))
 PY
-rm -rf $out/stats $out/stats_train $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+rm -rf $out/stats $out/stats_train $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmct_FETCH_SIZE $out/pmct_WRITE_SIZE
 ls -la $out
