@@ -39,7 +39,9 @@ for c in tot:
     for f in glob.glob(out + "/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
             k = fam(r["Kernel_Name"])
-            m = re.search(r"(conv\w*kernel|fused_1x1_3x3_kernel|msblock_dil_kernel|\w+_k)\b", r["Kernel_Name"])
+            if "absmax_k" in r["Kernel_Name"]:      # calibration pass of the first run only (Plan._run_calibrating): not steady state
+                continue
+            m = re.search(r"(fused_1x1_3x3_kernel|msblock_dil_kernel|conv[a-z0-9_]*kernel|[a-z0-9_]+_k(?![a-z0-9_]))", r["Kernel_Name"])
             short = m.group(1) if m else r["Kernel_Name"].split("(")[0][-48:]
             tot[c][k] += float(r["Counter_Value"]); per[c][short] += float(r["Counter_Value"])
             if c == "FETCH_SIZE": cnt[k] += 1; pcnt[short] += 1
