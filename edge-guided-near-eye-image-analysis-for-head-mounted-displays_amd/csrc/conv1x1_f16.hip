@@ -130,6 +130,117 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
   }
 }
 
+
+// Transition_down of an eval plan in ONE pass (models/RITnet_v2.py:32-44: avg_pool2d(conv1x1(leaky(IN(cat(out, x)))), 2); the
+// pooling and the 1x1 are both linear, so the 2x2 average moves in front of the convolution): the lane's MFMA operand is the
+// average over the 2x2 window of leaky(x * scale + shift) -- 8 loads of 16 bytes per 16-channel group instead of 2, no pooled
+// tensor in HBM (it was written by norm_act_pool2_k and read back by the streaming kernel: one launch and 2 x the pooled bytes
+// less).  Same weights and K order as conv1x1_f16x3_kernel; p.H / p.W are the INPUT size, p.Ho / p.Wo = H/2, W/2.
+template <int TN>
+__global__ __launch_bounds__(256) void conv1x1_pool_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
+                                                                 const _Float16* __restrict__ flo, float a_scale, float out_scale,
+                                                                 int G, long long M, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 wl[];   // [G][TN][hi|lo][64][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kq = lane >> 5;
+  const int NT = p.CoutP >> 5, nt0 = blockIdx.y * TN;
+  for (int it = tid; it < G * TN * 2 * 64; it += 256) {        // 16-byte items
+    const int l = it & 63, hl = (it >> 6) & 1;
+    const int tn = (it >> 7) % TN, g = (it >> 7) / TN;
+    const _Float16* src = (hl ? flo : fhi) + (((long long)g * NT + nt0 + tn) * 64 + l) * 8;
+    *(u32x4*)&wl[(long long)it * 8] = *(const u32x4*)src;
+  }
+  __syncthreads();
+
+  const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  f32x4 bias[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = (nt0 + tn) * 32 + 8 * j + 4 * kq;
+      bias[tn][j] = (p.bias && n < p.Cout_store) ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
+    }
+  const int H = p.H, W = p.W, Hp = p.Ho, Wp = p.Wo, hwp = Hp * Wp;
+  const float s4 = 0.25f * a_scale;
+
+  for (int blk = blockIdx.x * 4 + wave; blk < nblocks; blk += gridDim.x * 4) {
+    const long long m0 = (long long)blk * 32;
+    const long long rows = M - m0 < 32 ? M - m0 : 32;
+    const int b0 = (int)(m0 / hwp);                       // frame of the block's first pixel; a block spans at most two frames
+    const long long m = m0 + li;
+    const bool valid = m < M;
+    const int b = valid ? (int)(m / hwp) : b0;
+    const int r = (int)(m - (long long)b * hwp);
+    const int yp = valid ? r / Wp : 0, xp = valid ? r - yp * Wp : 0;
+    const int pin = ((b - b0) * H + 2 * yp) * W + 2 * xp;   // first pixel of the window, relative to frame b0
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) acc[tn] = (f32x16)(0.f);
+    int g = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+      const egne_seg sg = p.seg[s];
+      const long long frame = (long long)H * W * sg.pix_stride;
+      const long long left = ((long long)p.B - b0) * frame * 4;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(sg.ptr + (long long)b0 * frame, (unsigned)(left < 2 * frame * 4 ? left : 2 * frame * 4));
+      const int ps4 = (int)sg.pix_stride * 4;
+      const int voff = valid ? (pin * (int)sg.pix_stride + sg.ch_off + 4 * kq) * 4 : (int)OOB;
+      const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+      const float* tsc = sg.scale + (long long)b * sg.Cp + 4 * kq;
+      const float* tsh = sg.shift + (long long)b * sg.Cp + 4 * kq;
+      const int n16 = (sg.Cp + 15) >> 4;
+      const bool tail8 = (sg.Cp & 15) != 0;                      // last group of the slice holds 8 channels only
+      for (int gg = 0; gg < n16; ++gg) {
+        const bool has_b = !(tail8 && gg == n16 - 1);
+        const int ob = has_b ? voff + 32 : (int)OOB;
+        u32x4 xa[4], xb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int d = ((t >> 1) * W + (t & 1)) * ps4;
+          xa[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff == (int)OOB ? (int)OOB : voff + d, gg * 64, 0);
+          xb[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, ob == (int)OOB ? (int)OOB : ob + d, gg * 64, 0);
+        }
+        const f32x4 sca = *(const f32x4*)(tsc + gg * 16), sha = *(const f32x4*)(tsh + gg * 16);
+        const f32x4 scb = has_b ? *(const f32x4*)(tsc + gg * 16 + 8) : (f32x4)(0.f), shb = has_b ? *(const f32x4*)(tsh + gg * 16 + 8) : (f32x4)(0.f);
+        f32x4 sa = (f32x4)(0.f), sb = (f32x4)(0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 va = __builtin_bit_cast(f32x4, xa[t]) * sca + sha, vb = __builtin_bit_cast(f32x4, xb[t]) * scb + shb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sa[e] += fmaxf(va[e], va[e] * slope_in); sb[e] += fmaxf(vb[e], vb[e] * slope_in); }
+        }
+        if (!valid) { sa = (f32x4)(0.f); sb = (f32x4)(0.f); }
+        h8 ah, al;
+        split8(__builtin_bit_cast(u32x4, sa), __builtin_bit_cast(u32x4, sb), s4, ah, al);
+        const _Float16* wp = wl + ((long long)(g + gg) * TN * 2 * 64 + lane) * 8;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const h8 wh = *(const h8*)(wp + (tn * 2 + 0) * 512), wo = *(const h8*)(wp + (tn * 2 + 1) * 512);
+          acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc[tn], 0, 0, 0);
+          acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wo, ah, acc[tn], 0, 0, 0);
+          acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc[tn], 0, 0, 0);
+        }
+      }
+      g += n16;
+    }
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = (nt0 + tn) * 32 + 8 * j + 4 * kq;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[tn][4 * j + e] * out_scale + bias[tn][j][e];
+          v[e] = fmaxf(t, t * slope);
+        }
+        const int off = n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, off, 0, 0);
+      }
+  }
+}
+
 // OIHW (kh = kw = 1) fp32 -> hi / lo f16 fragments [G][CoutP/32][lane = h*32 + n%32][8]; kmap[g*16 + h*8 + j] names
 // the logical input channel of that K slot (or -1: padding)
 __global__ void pack_w1x1_f16_k(const float* __restrict__ w, int Cout, int Cin, const int* __restrict__ kmap, int G, int CoutP,
@@ -208,4 +319,50 @@ extern "C" int egne_conv1x1_f16x3_fwd(const egne_conv_desc* dp, const void* fhi,
     hipLaunchKernelGGL((conv1x1_f16x3_kernel<2>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
                        a_scale, os, G, M, (int)nb);
   return egne::check_launch("egne_conv1x1_f16x3_fwd");
+}
+
+// Transition_down of an eval plan: avg_pool2d(., 2) folded in front of the 1x1 (see conv1x1_pool_f16x3_kernel).  d: the 1x1 with
+// H / W = the INPUT size, Ho / Wo = H / 2, W / 2 (floor), every slice WITH its per-(frame, channel) scale / shift (InstanceNorm of the
+// consumer, models/RITnet_v2.py:40) and act_in; output [B][Ho][Wo].  Weights as for egne_conv1x1_f16x3_fwd.
+extern "C" int egne_conv1x1_pool2_f16x3_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                            void* stream) {
+  EGNE_REQUIRE(dp && fhi && flo, "conv1x1_pool2_f16: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.Ho == d.H / 2 && d.Wo == d.W / 2 &&
+               d.Ho > 0 && d.Wo > 0 && d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && !d.residual && !d.post_scale, "conv1x1_pool2_f16: unsupported descriptor");
+  EGNE_REQUIRE(d.CoutP % 32 == 0 && d.CoutP <= 96 && d.Cout_store <= d.CoutP && d.Cout_store % 4 == 0 && d.out &&
+               ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
+               d.out_ch_off + d.Cout_store <= d.out_pix_stride && (!d.bias || ((uintptr_t)d.bias & 15) == 0), "conv1x1_pool2_f16: output");
+  int G = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr && g.scale && g.shift && ((uintptr_t)g.scale & 15) == 0 && ((uintptr_t)g.shift & 15) == 0 && g.Cp % 8 == 0 &&
+                 g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 && ((uintptr_t)g.ptr & 15) == 0 && g.ch_off + g.Cp <= g.pix_stride &&
+                 (long long)d.H * d.W * g.pix_stride * 8 < (1ll << 31), "conv1x1_pool2_f16: slice %d", s);
+    G += (g.Cp + 15) / 16;
+  }
+  EGNE_REQUIRE(d.out_pix_stride * 128 < (1ll << 31) && ((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f,
+               "conv1x1_pool2_f16: strides / weights / scales");
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  const long long nb = (M + 31) / 32;
+  EGNE_REQUIRE(nb < (1ll << 31), "conv1x1_pool2_f16: too many pixels");
+  const int TN = d.CoutP / 32;        // all output channels in one workgroup: the (4x larger) input is read once
+  const size_t lds = (size_t)G * TN * 2 * 64 * 8 * sizeof(_Float16);
+  EGNE_REQUIRE(lds <= 80 * 1024, "conv1x1_pool2_f16: K = %d groups of 16 does not fit the LDS weight image", G);
+  static bool once = [] {
+    return hipFuncSetAttribute((const void*)conv1x1_pool_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)conv1x1_pool_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)conv1x1_pool_f16x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+  }();
+  if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_pool2_f16: cannot raise the dynamic LDS limit");
+  const int ny = 1;
+  long long gx = (nb + 3) / 4;
+  const long long cap = 256 * 8;
+  if (gx > cap) gx = cap;
+  const float os = 1.0f / (a_scale * w_scale);
+  hipStream_t st = (hipStream_t)stream;
+  if (TN == 1) hipLaunchKernelGGL((conv1x1_pool_f16x3_kernel<1>), dim3((unsigned)gx, (unsigned)ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo, a_scale, os, G, M, (int)nb);
+  else if (TN == 2) hipLaunchKernelGGL((conv1x1_pool_f16x3_kernel<2>), dim3((unsigned)gx, (unsigned)ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo, a_scale, os, G, M, (int)nb);
+  else hipLaunchKernelGGL((conv1x1_pool_f16x3_kernel<3>), dim3((unsigned)gx, (unsigned)ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo, a_scale, os, G, M, (int)nb);
+  return egne::check_launch("egne_conv1x1_pool2_f16x3_fwd");
 }

@@ -680,7 +680,7 @@ extern "C" int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const
                a1 > 0.f && a2 > 0.f && w1_scale > 0.f && w2_scale > 0.f && (!d1.bias || ((uintptr_t)d1.bias & 15) == 0), "conv_fused_c4_3x3: weights / scales");
   GroupTab gt;
   for (int k = 0; k < MAXG; ++k) gt.v[k] = gt.off[k] = 0;
-  return launch_fused<1, 1, 8, 1, true>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 3, (const _Float16*)f2hi, (const _Float16*)f2lo,
+  return launch_fused<1, 1, 8, 1, true, false, false, 3>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 3, (const _Float16*)f2hi, (const _Float16*)f2lo,
                                         a1, 1.0f / (a1 * w1_scale), a2, 1.0f / (a2 * w2_scale), (hipStream_t)stream);
 }
 

@@ -20,6 +20,7 @@ F16X3_ENABLED = os.environ.get("EGNE_F16X3", "1") != "0"      # split-f16 MFMA f
 HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LAYER_BYTES = {}          # layer name -> algorithmic bytes of its launch(es) (input slices + stored output), for bench.py --layers
+TDPOOL_FUSED = os.environ.get("EGNE_TDPOOL_FUSED", "1") != "0"     # Transition_down: pooling folded into the 1x1's operand load
 POOL_FUSED = os.environ.get("EGNE_POOL_FUSED", "1") != "0"     # conv1_2 writes pool1 from its epilogue (conv3x3_rs_f16.hip)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
@@ -731,6 +732,44 @@ class Plan:
                 and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
                 and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP in (32, 64)
                 and W >= FUSE_1X1_MIN_W and all(H * W * pc.stride < 2 ** 29 for pc in pieces) and H * W * dst.stride < 2 ** 29)
+
+    def td_pool_fusable(self, layer, pieces, dst):
+        """Transition_down of an inference plan as ONE launch (conv1x1_pool_f16x3_kernel): 1x1 over normalised slices with the 2x2
+        average folded in front of it."""
+        G = sum((p.Cp + 15) // 16 for p in pieces)
+        return (TDPOOL_FUSED and F16X3_ENABLED and not self.train and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
+                and layer.G == 1 and layer.post is None and all(p.scale is not None for p in pieces) and len(pieces) <= _lib.MAXSEG
+                and layer.CoutP <= 96 and G * (layer.CoutP // 32) * 2048 <= 80 * 1024 and dst.Cp % 4 == 0)
+
+    def conv1x1_pooled(self, layer, pieces, dst, B, H, W, name="td"):
+        """dst[B][H/2][W/2] = avg_pool2d(conv1x1(act_in(pieces * scale + shift)), 2) (models/RITnet_v2.py:32-44), one launch."""
+        assert self.td_pool_fusable(layer, pieces, dst), name
+        Ho, Wo = H // 2, W // 2
+        layer.need_s1 = layer.need_flat = True
+        if layer not in self.layers:
+            self.layers.append(layer)
+        layer.ensure_packed(self.device)
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
+        d.kh = d.kw = d.stride = d.ngroups = 1
+        d.nseg = len(pieces)
+        for i, p in enumerate(pieces):
+            sg = d.seg[i]
+            sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp = p.ptr, p.stride, p.off, p.Cp
+            sg.scale, sg.shift, sg.act_in = p.scale.data_ptr(), p.shift.data_ptr(), p.act_in
+        d.Ktot, d.CoutP = layer.Ktot, layer.CoutP
+        d.bias = layer.bp.data_ptr() if layer.biases is not None else None
+        d.act = layer.act
+        d.out, d.out_pix_stride, d.out_ch_off = dst.ptr, dst.stride, dst.off
+        d.Cout_store = min(layer.Cout_store, dst.Cp)
+        assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
+        self.keep.append(d)
+        flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin
+        # normalised operands: the fixed pre-scale of the other fused-affine layers (|x| < 4094 after the InstanceNorm affine)
+        self._add(self.L.egne_conv1x1_pool2_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE, layer.w_scale1),
+                  name, flops=flops, kind="conv_f16x3:tdpool1x1")
+        LAYER_BYTES[name] = 4.0 * B * (H * W * sum(p.Cp for p in pieces) + Ho * Wo * int(d.Cout_store))
+        return Ho, Wo
 
     def conv_pair(self, l1, pieces, l2, dst, B, H, W, tmp=None, residual=None, name="pair", stats=False, up_add=None):
         r = self._conv_pair_impl(l1, pieces, l2, dst, B, H, W, tmp, residual, name, stats, up_add)

@@ -219,7 +219,10 @@ def build_forward_plan(model, B, H, W, dev, training):
         sc2, sh2 = pl.last_stats
         tdl = _cl(blk.TD.conv, _lay([d["out"], d["x"]]))
         tin = [d["out"].with_norm(sc2, sh2, ACT_LEAKY), d["x"].with_norm(sc, sh, ACT_LEAKY)]
-        if pools[i] and not training:
+        if pools[i] and not training and pl.td_pool_fusable(tdl, tin, D[i + 1]["x"]) and h % 2 == 0 and w % 2 == 0:
+            # eval plans: the 2x2 average folded into the 1x1's operand load (linear ops commute): one launch, no pooled tensor
+            pl.conv1x1_pooled(tdl, tin, D[i + 1]["x"], NB, h, w, name=nm + ".TD")
+        elif pools[i] and not training:
             # eval plans: pool first, then the 1x1 conv at quarter resolution (linear ops commute)
             pb_ = pl.buf(NB, h // 2, w // 2, d["out"].Cp + d["x"].Cp)
             q_out, q_x = Piece(pb_, 0, d["out"].C, d["out"].Cp), Piece(pb_, d["out"].Cp, d["x"].C, d["x"].Cp)

@@ -156,6 +156,13 @@ int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* d, const void* fhi, co
                                     const float* score_w, const float* score_c, float* s0, float* s1, int accumulate,
                                     void* stream);
 
+/* Transition_down of an inference plan in one pass (models/RITnet_v2.py:32-44: avg_pool2d(conv1x1(leaky(IN(cat(out, x)))), 2) --
+ * pooling and 1x1 are linear, the 2x2 average moves in front): the 1x1's operand is the window average of
+ * act_in(x * scale + shift).  d: kh = kw = 1, H / W = input size, Ho / Wo = H / 2, W / 2, every slice with scale / shift
+ * [B][Cp]; weights as for egne_conv1x1_f16x3_fwd. */
+int egne_conv1x1_pool2_f16x3_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                 void* stream);
+
 /* Role-split variant of egne_conv3x3_halo_f16_fwd for narrow inputs (one slice of <= 64 channels: vgg16_c.py:66-69 conv1_2 /
  * conv2_1, bdcn_new.py:50 stage-1 MSBlock convs, models/RITnet_v2.py:57 down-block conv1, utils.py:1047-1048 decoder convBlock):
  * 4 producer waves stage the halo (gather, fused affine, fp32 -> hi / lo) while 4 consumer waves do nothing but LDS reads and

@@ -722,6 +722,39 @@ def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
             np.testing.assert_allclose(shift.cpu().numpy()[:, :Cout], (-y.mean((2, 3)) * rstd).numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("chans,Cout,B,H,W", [((32, 32), 38, 3, 24, 40), ((64, 38), 76, 2, 30, 50), ((32, 24), 30, 3, 10, 30), ((32, 32), 32, 2, 240, 320)])
+def test_transition_down_pool_folded_into_the_1x1(G, chans, Cout, B, H, W):
+    """models/RITnet_v2.py:32-44 in an eval plan: avg_pool2d(conv1x1(leaky(IN(cat(out, x)))), 2) as ONE launch whose operand is the
+    2x2 window average of the normalised, activated slices (pooling and 1x1 commute) -- against float64; blocks that span two
+    frames (H/2 * W/2 not a multiple of 32) included."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    xs = [_rand(G, B, c, H, W) * 2 + 0.3 for c in chans]
+    w, b = _rand(G, Cout, sum(chans), 1, 1) / sum(chans) ** 0.5, _rand(G, Cout)
+    xin = torch.cat([F.leaky_relu(F.instance_norm(x.double())) for x in xs], 1)
+    truth = F.avg_pool2d(F.conv2d(xin, w.double(), b.double()), 2)
+    pl = Plan(torch.device(DEV))
+    pieces = to_nhwc_buf(pl, xs, B, H, W)
+    normed = []
+    for x, pc in zip(xs, pieces):
+        mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+        sc, sh = torch.zeros(B, pc.Cp, device=DEV), torch.zeros(B, pc.Cp, device=DEV)
+        sc[:, :pc.C], sh[:, :pc.C] = rstd.to(DEV), (-mean * rstd).to(DEV)
+        pl.keep += [sc, sh]
+        normed.append(pc.with_norm(sc, sh, 2))
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(p.C, p.Cp) for p in pieces])
+    layer.split1 = True
+    out = pl.buf(B, H // 2, W // 2, pad8(Cout))
+    dst = Piece(out, 0, Cout)
+    assert pl.td_pool_fusable(layer, normed, dst)
+    pl.conv1x1_pooled(layer, normed, dst, B, H, W)
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()[:, :Cout]
+        assert (got - truth).abs().max().item() / truth.abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (2, 61, 83), (1, 240, 320)])
 def test_conv3x3_role_split_pooled_second_output(G, B, H, W):
     """vgg16_c.py:69-70: relu(conv1_2(x)) and its 2x2 / stride 2 / ceil-mode max pooling from ONE launch (the pooled tensor is a
