@@ -15,6 +15,7 @@
 // pack (egne_pack_conv1x1_weight_f16) uses the same order.  The product is computed transposed (weights as the
 // A operand): a lane ends up with 4 consecutive output channels of one pixel -> 16-byte stores.
 #include "common.h"
+#include "split_f16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -33,11 +34,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 __device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, float s, h8& hi, h8& lo) {
   const f32x4 va = __builtin_bit_cast(f32x4, a), vb = __builtin_bit_cast(f32x4, b);
-  const f32x2 x[4] = {{va[0] * s, va[1] * s}, {va[2] * s, va[3] * s}, {vb[0] * s, vb[1] * s}, {vb[2] * s, vb[3] * s}};
+  const float x[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const h2 h = __builtin_convertvector(x[q], h2);
-    const h2 l = __builtin_convertvector(x[q] - __builtin_convertvector(h, f32x2), h2);
+    h2 h, l;
+    egne::split2(x[2 * q], x[2 * q + 1], s, h, l);     // plain (unpacked) VALU: split_f16.h
     hi[2 * q] = h[0]; hi[2 * q + 1] = h[1];
     lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
   }

@@ -22,6 +22,7 @@
 // the same FLOP per cycle (MI355X DVFS give-back, shape effect); pixel pitch 48 halfs keeps its ds_read_b128 pattern
 // conflict-free (40 for the 32x32x16 pattern).
 #include "common.h"
+#include "split_f16.h"
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -137,10 +138,9 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
           if (!((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) v = (f32x4)(0.f);
         }
-        const f32x2 x0 = {v[0] * a_scale, v[1] * a_scale}, x1 = {v[2] * a_scale, v[3] * a_scale};
-        const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
-        const h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x2), h2);
-        const h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x2), h2);
+        h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
+        egne::split2(v[0], v[1], a_scale, h0, l0);
+        egne::split2(v[2], v[3], a_scale, h1, l1);
         const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
         const int o = chunk * CHS + px * LDH + pc * 4;
         *(h4*)&img[o] = hi;

@@ -17,6 +17,7 @@
 // M16 computes the same tile with v_mfma_f32_16x16x32_f16 (one instruction per 32-channel step and 16 x 16 block): the same
 // FLOP per cycle, but these kernels run at the power limit and the chip holds a higher clock on this shape (MI355X DVFS).
 #include "common.h"
+#include "split_f16.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -119,10 +120,9 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 v = __builtin_bit_cast(f32x4, ra[i]);
-      const f32x2 x0 = {v[0] * a_scale, v[1] * a_scale}, x1 = {v[2] * a_scale, v[3] * a_scale};
-      const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
-      const h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x2), h2);
-      const h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x2), h2);
+      h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
+      egne::split2(v[0], v[1], a_scale, h0, l0);
+      egne::split2(v[2], v[3], a_scale, h1, l1);
       const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
       *(h4*)(base + ldst_hi[i]) = hi;
       *(h4*)(base + ldst_lo[i]) = lo;

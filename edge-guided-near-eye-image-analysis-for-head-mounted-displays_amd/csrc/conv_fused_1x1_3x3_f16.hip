@@ -20,6 +20,7 @@
 // Tiles are dealt so that the workgroups of one XCD work on neighbouring tiles (halo overlap served by that XCD's L2).
 #include "common.h"
 #include "epilogue32.h"
+#include "split_f16.h"
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,11 +49,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 __device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, float s, h8& hi, h8& lo) {
   const f32x4 va = __builtin_bit_cast(f32x4, a), vb = __builtin_bit_cast(f32x4, b);
-  const f32x2 x[4] = {{va[0] * s, va[1] * s}, {va[2] * s, va[3] * s}, {vb[0] * s, vb[1] * s}, {vb[2] * s, vb[3] * s}};
+  const float x[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const h2 h = __builtin_convertvector(x[q], h2);
-    const h2 l = __builtin_convertvector(x[q] - __builtin_convertvector(h, f32x2), h2);
+    h2 h, l;
+    egne::split2(x[2 * q], x[2 * q + 1], s, h, l);     // plain (unpacked) VALU: split_f16.h
     hi[2 * q] = h[0]; hi[2 * q + 1] = h[1];
     lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
   }

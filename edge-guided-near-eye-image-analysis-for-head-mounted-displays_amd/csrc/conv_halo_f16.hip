@@ -8,6 +8,7 @@
 // are address offsets into it.  Weight fragments ([tap][k/16][n/32][lane][8 halfs], hi and lo) come from L2
 // through a 4-slot register ring; workgroups walk tiles grid-stride with the next halo prefetched.
 #include "common.h"
+#include "split_f16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -152,10 +153,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
       if (i < NI - 1 || tid + 256 * i < nitems) {
         const f32x4 v = __builtin_bit_cast(f32x4, st[i]);
         // x*a_scale = hi + lo, two elements per (packed) instruction
-        const f32x2 x0 = {v[0] * a_scale, v[1] * a_scale}, x1 = {v[2] * a_scale, v[3] * a_scale};
-        const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
-        const h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x2), h2);
-        const h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x2), h2);
+        h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
+        egne::split2(v[0], v[1], a_scale, h0, l0);
+        egne::split2(v[2], v[3], a_scale, h1, l1);
         const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
         const int o = lofs0 + i * 32 * LDH;
         *(h4*)&Ahi[o] = hi;

@@ -18,6 +18,7 @@
 //             ninth strip bias + ReLU per dilation, the three are summed, the exact fp32 o is added and the tile stored.
 // One s_barrier per strip.  The conversion work (each element is split 9 times) sits in waves that do nothing else.
 #include "common.h"
+#include "split_f16.h"
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,6 +30,8 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+__device__ int g_mdbg = 0;
+__device__ unsigned long long g_mstamps[256 * 8 * 4];
 
 constexpr int TW = 32, TH = 8;
 constexpr unsigned OOB = 0x80000000u;
@@ -60,6 +63,15 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* const lw = ldsh + 2 * BUFH;
 
+  const int dbg = g_mdbg;
+  unsigned long long t_work = 0, t_wait = 0, t_last = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
+  auto stamp = [&](unsigned long long& accum) {
+    if (dbg & 64) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      accum += t - t_last; t_last = t;
+    }
+  };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -107,7 +119,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       int off = ((y * W + x) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4;
       if (!xin) off = ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? off : (int)OOB;
       if (TH * SW % PPI != 0 && px >= TH * SW) off = (int)OOB;
-      stbuf(std::integral_constant<int, BUF>{})[I] = __builtin_amdgcn_raw_buffer_load_b128(r, on ? off : (int)OOB, 0, 0);
+      stbuf(std::integral_constant<int, BUF>{})[I] = __builtin_amdgcn_raw_buffer_load_b128(r, (on && !(dbg & 1)) ? off : (int)OOB, 0, 0);
     };
     // LDS slot of item I: pixel pg + PPI I, and (pixel >> 2) & 3 = (pg >> 2) & 3 for every I: lane constant + 64 B * PPI * I
     const int lofs = (ptid >> 3) * 32 + (((piece >> 1) ^ ((ptid >> 5) & 3)) << 3) + ((piece & 1) << 2);
@@ -117,10 +129,9 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       constexpr int d = dil_of(g), SW = TW + 2 * d;
       if (TH * SW % PPI == 0 || (ptid >> 3) + PPI * I < TH * SW) {
         const f32x4 v = __builtin_bit_cast(f32x4, stbuf(std::integral_constant<int, BUF>{})[I]);
-        const f32x2 x0 = {v[0] * a_scale, v[1] * a_scale}, x1 = {v[2] * a_scale, v[3] * a_scale};
-        const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
-        const h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x2), h2);
-        const h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x2), h2);
+        h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
+        egne::split2(v[0], v[1], a_scale, h0, l0);
+        egne::split2(v[2], v[3], a_scale, h1, l1);
         const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
         const int o = lofs + 32 * PPI * I;
         *(h4*)&buf[o] = hi;
@@ -155,7 +166,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
         (([&] {
           if constexpr (Is < NIi) issue1(ti, oni, pg, xin, std::integral_constant<int, SI>{}, std::integral_constant<int, Is>{});
-          if constexpr (Is < NIc) convert1(buf, sc, std::integral_constant<int, Is>{});
+          if constexpr (Is < NIc) { if (!(dbg & 2)) convert1(buf, sc, std::integral_constant<int, Is>{}); }
         }()), ...);
       }(std::make_integer_sequence<int, NIm>{});
       _Float16* wb = lw + ((9 * i + S) & 1) * WBUFH;
@@ -180,7 +191,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       const bool nx_on = i + 1 < nmine;
       const Tile nx = decode(tile_at(nx_on ? i + 1 : i));
       [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
-        ((produce_strip(i, tl, nx, nx_on, std::integral_constant<int, Ss>{}), lds_barrier()), ...);
+        ((produce_strip(i, tl, nx, nx_on, std::integral_constant<int, Ss>{}), stamp(t_work), lds_barrier(), stamp(t_wait)), ...);
       }(std::make_integer_sequence<int, NS>{});
     }
     lds_barrier();          // matches the consumers' last step
@@ -198,7 +209,9 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
           [&] {
             constexpr int S = Ss, g = S % 3, ky = S / 3;
             constexpr int d = dil_of(g), SW = TW + 2 * d;
+            stamp(t_work);
             lds_barrier();                               // strip q = 9 i + S and its weights are complete in buffers q & 1
+            stamp(t_wait);
             const _Float16* Shi = ldsh + ((9 * i + S) & 1) * BUFH;
             const _Float16* Slo = Shi + NPXMAX * 32;
             const _Float16* wb = lw + ((9 * i + S) & 1) * WBUFH + lane * 8;
@@ -291,7 +304,12 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
         }
       }
     }
+    stamp(t_work);
     lds_barrier();
+  }
+  if ((dbg & 64) && lane == 0) {
+    unsigned long long* o = g_mstamps + ((long long)blockIdx.x * 8 + wave) * 4;
+    o[0] = t_work; o[1] = t_wait; o[2] = nmine; o[3] = __builtin_amdgcn_s_memrealtime() - r_first;
   }
 }
 
@@ -330,4 +348,10 @@ extern "C" int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* dp, const v
 extern "C" int egne_msblock_dil_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
                                         void* stream) {
   return egne_msblock_dil_scores_f16_fwd(dp, fhi, flo, a_scale, w_scale, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int egne_msdil_debug(int dbg, void* out_stamps) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_mdbg), &dbg, sizeof(int)) != hipSuccess) return -2;
+  if (out_stamps && hipMemcpyFromSymbol(out_stamps, HIP_SYMBOL(g_mstamps), sizeof(unsigned long long) * 256 * 8 * 4) != hipSuccess) return -2;
+  return 0;
 }
