@@ -46,10 +46,13 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int D0, int D1, int D2, int NPW>       // NPW: producer waves (4 or 8); 4 consumer waves follow them
+// XIN: this launch holds only tiles whose widest strip lies inside the image columns (x0 >= 12, x0 + 32 + 12 <= W): item addresses
+// are then a per-lane constant + a wave-uniform term.  A map is covered by an XIN launch over the interior tile columns and a
+// !XIN launch over the two border columns (cols: 0 = all tile columns, 1 = interior, 2 = the two border columns).
+template <int D0, int D1, int D2, int NPW, bool XIN>       // NPW: producer waves (4 or 8); 4 consumer waves follow them
 __global__ __launch_bounds__(64 * (NPW + 4))
 void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
-                        float out_scale, int tiles_x, int tiles_y, int ntiles, const float* __restrict__ score_w,
+                        float out_scale, int tiles_x, int tiles_y, int ntiles, int cols, const float* __restrict__ score_w,
                         const float* __restrict__ score_c, float* __restrict__ s0, float* __restrict__ s1, int accumulate) {
   constexpr int DMAX = D2 > D1 ? (D2 > D0 ? D2 : D0) : (D1 > D0 ? D1 : D0);
   constexpr int SWMAX = TW + 2 * DMAX, NPXMAX = TH * SWMAX;
@@ -83,7 +86,9 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
   struct Tile { int b, y0, x0; };
   auto decode = [&](int t) {
     Tile r;
-    const int tx = t % tiles_x; t /= tiles_x;
+    const int ntx = cols == 0 ? tiles_x : (cols == 1 ? tiles_x - 2 : 2);
+    const int tq = t % ntx; t /= ntx;
+    const int tx = cols == 0 ? tq : (cols == 1 ? tq + 1 : tq * (tiles_x - 1));
     const int ty = t % tiles_y; t /= tiles_y;
     r.b = t; r.y0 = ty * TH; r.x0 = tx * TW;
     return r;
@@ -102,6 +107,22 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
     constexpr int NI0 = (TH * (TW + 2 * D0) + PPI - 1) / PPI, NI1 = (TH * (TW + 2 * D1) + PPI - 1) / PPI, NI2 = (TH * (TW + 2 * D2) + PPI - 1) / PPI;
     constexpr int WPW = 12 / NPW + (12 % NPW != 0);     // weight fragments per producer wave (waves past 12 / WPW repeat earlier ones)
     u32x4 st0[NI0], st1[NI1], st2[NI2], wr[NBUF][WPW];
+    // byte offset of item I of a dilation-g strip relative to the tile's first pixel, ky = 1 (tile- and ky-invariant; the rest of
+    // the address is wave-uniform: one v_add per item instead of a division, two multiplies and the bounds arithmetic)
+    int rel0[XIN ? NI0 : 1], rel1[XIN ? NI1 : 1], rel2[XIN ? NI2 : 1];
+    auto relbuf = [&](auto gc) -> int* { constexpr int Gq = decltype(gc)::value; if constexpr (Gq == 0) return rel0; else if constexpr (Gq == 1) return rel1; else return rel2; };
+    if constexpr (XIN) [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
+      (([&] {
+        constexpr int g = Gs, d = dil_of(g), SW = TW + 2 * d, NIg = (TH * SW + PPI - 1) / PPI;
+#pragma unroll
+        for (int I = 0; I < NIg; ++I) {
+          const int px = (ptid >> 3) + PPI * I;
+          const int rr = px / SW, cc = px - rr * SW;
+          relbuf(std::integral_constant<int, g>{})[I] = (TH * SW % PPI != 0 && px >= TH * SW) ? (int)OOB
+                                                        : ((rr * W + cc - d) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4;
+        }
+      }()), ...);
+    }(std::make_integer_sequence<int, 3>{});
     auto stbuf = [&](auto bc) -> u32x4* { constexpr int Bq = decltype(bc)::value; if constexpr (Bq == 0) return st0; else if constexpr (Bq == 1) return st1; else return st2; };
     const unsigned wbytes = 3u * 9u * 2u * 1024u;
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(fhi, wbytes), rwl = make_rsrc(flo, wbytes);
@@ -113,12 +134,19 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       constexpr int S = decltype(sc)::value, I = decltype(ic)::value, BUF = S % NBUF, g = S % 3, ky = S / 3;
       constexpr int d = dil_of(g), SW = TW + 2 * d;
       const __amdgpu_buffer_rsrc_t r = make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
-      const int px = pg + PPI * I;                       // pixel of the strip, row-major over TH x SW
-      const int rr = px / SW, cc = px - rr * SW;
-      const int y = tl.y0 + (ky - 1) * d + rr, x = tl.x0 - d + cc;
-      int off = ((y * W + x) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4;
-      if (!xin) off = ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? off : (int)OOB;
-      if (TH * SW % PPI != 0 && px >= TH * SW) off = (int)OOB;
+      int off;
+      if constexpr (XIN) {                               // interior columns: rows outside the image fall outside the resource
+        const int sbase = ((tl.y0 + (ky - 1) * d) * W + tl.x0) * (int)sg.pix_stride * 4;       // wave-uniform
+        const int rl = relbuf(std::integral_constant<int, g>{})[I];
+        off = rl == (int)OOB ? (int)OOB : rl + sbase;
+      } else {
+        const int px = pg + PPI * I;                     // pixel of the strip, row-major over TH x SW
+        const int rr = px / SW, cc = px - rr * SW;
+        const int y = tl.y0 + (ky - 1) * d + rr, x = tl.x0 - d + cc;
+        off = ((y * W + x) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4;
+        off = ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? off : (int)OOB;
+        if (TH * SW % PPI != 0 && px >= TH * SW) off = (int)OOB;
+      }
       stbuf(std::integral_constant<int, BUF>{})[I] = __builtin_amdgcn_raw_buffer_load_b128(r, (on && !(dbg & 1)) ? off : (int)OOB, 0, 0);
     };
     // LDS slot of item I: pixel pg + PPI I, and (pixel >> 2) & 3 = (pg >> 2) & 3 for every I: lane constant + 64 B * PPI * I
@@ -336,12 +364,25 @@ extern "C" int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* dp, const v
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B;
   constexpr size_t lds = ((size_t)2 * 2 * TH * (TW + 24) * 32 + 2 * 12 * 512) * sizeof(_Float16);
-  static bool once = hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  static bool once = hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "msblock_dil: cannot raise the dynamic LDS limit to %zu", lds);
-  int gx = 256;
-  if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4>), dim3(gx), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
-                     (const _Float16*)flo, a_scale, 1.0f / (a_scale * w_scale), tiles_x, tiles_y, ntiles, score_w, score_c, s0, s1, accumulate);
+  const float os = 1.0f / (a_scale * w_scale);
+  // interior tile columns (x0 >= 12 and x0 + 44 <= W <=> tile column 1 .. tiles_x - 2 when W >= 32 * (tiles_x - 1) + 12) on the
+  // fast-address kernel, the two border columns (or everything on narrow maps) on the checked one
+  const bool split = tiles_x > 2 && d.W >= TW * (tiles_x - 1) + 12;
+  if (split) {
+    const int nt_in = (tiles_x - 2) * tiles_y * d.B, nt_b = 2 * tiles_y * d.B;
+    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, true>), dim3(nt_in < 256 ? nt_in : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+                       (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, nt_in, 1, score_w, score_c, s0, s1, accumulate);
+    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, false>), dim3(nt_b < 256 ? nt_b : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+                       (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, nt_b, 2, score_w, score_c, s0, s1, accumulate);
+  } else {
+    int gx = 256;
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, false>), dim3(gx), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+                       (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, ntiles, 0, score_w, score_c, s0, s1, accumulate);
+  }
   return egne::check_launch("egne_msblock_dil_f16_fwd");
 }
 
