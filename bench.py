@@ -346,6 +346,17 @@ class Bench:
         return B, dt, ev
 
 
+def _debug_prio():
+    """diagnostic: EGNE_CONS_PRIO=1 raises the issue priority of the consumer waves of the role-split kernels"""
+    if os.environ.get('EGNE_CONS_PRIO'):
+        import ctypes as C
+        from egne_amd import _lib
+        L = _lib.lib()
+        v = int(os.environ['EGNE_CONS_PRIO'])
+        L.egne_fused_debug.argtypes = [C.c_int, C.c_void_p]; L.egne_msdil_debug.argtypes = [C.c_int, C.c_void_p]
+        L.egne_fused_debug(128 * v, None); L.egne_msdil_debug(128 * v, None); L.egne_rs_debug_prio(v)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -355,6 +366,7 @@ def main():
     import torch
     from egne_amd import engine as _engine
     bn = Bench(a)
+    _debug_prio()
     world, rank = bn.world, bn.rank
     res = {"metric": "eye-frames/sec (320x240): inference edge+seg (value), +fit, exact fp32, and train fwd+bwd at %d MI355X" % world,
            "value": None, "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,

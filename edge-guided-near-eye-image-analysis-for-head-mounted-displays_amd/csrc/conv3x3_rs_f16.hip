@@ -34,6 +34,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+__device__ int g_rs_prio = 0;
 
 constexpr int TW = 32, HWd = TW + 2;
 constexpr unsigned OOB = 0x80000000u;
@@ -187,6 +188,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     }
   } else {
     // =================================================================== consumers: 9 taps from the LDS image
+    if (g_rs_prio) __builtin_amdgcn_s_setprio(1);
     constexpr int NSPLIT = (TH == 4 && WN >= 2) ? 2 : 1;
     constexpr int WNW = WN / NSPLIT, WMW = TH * NSPLIT / 4;
     const int cw = wave - 4;
@@ -518,4 +520,8 @@ extern "C" int egne_conv3x3_rs_f16_fwd(const egne_conv_desc* dp, const void* fhi
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *h = (const _Float16*)fhi, *l = (const _Float16*)flo;
   return m16 ? dispatch_rs<true>(d, h, l, a_scale, os, st, dbg) : dispatch_rs<false>(d, h, l, a_scale, os, st, dbg);
+}
+
+extern "C" int egne_rs_debug_prio(int on) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prio), &on, sizeof(int)) == hipSuccess ? 0 : -2;
 }

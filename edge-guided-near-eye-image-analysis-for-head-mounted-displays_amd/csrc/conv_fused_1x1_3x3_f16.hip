@@ -405,6 +405,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     }
   } else {
     // =================================================================== consumers: 9 taps from the LDS image
+    if (dbg & 128) __builtin_amdgcn_s_setprio(1);
     // Wave -> (rows, output tiles): 8-row tiles give every wave two rows and all WN output tiles; with 4-row tiles and
     // 64 output channels a wave takes two rows and ONE of the two output tiles, so that every weight fragment it pulls
     // from L2 feeds two row blocks and the register ring runs two taps ahead (a 64-wide wave tile on one row would

@@ -225,6 +225,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
     lds_barrier();          // matches the consumers' last step
   } else {
     // =================================================================== consumers: 3 taps x 2 k-steps per strip
+    if (dbg & 128) __builtin_amdgcn_s_setprio(1);
     const int cw = wave - NPW;
     const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 4u;
     const unsigned frame_res = (unsigned)H * W * (unsigned)p.res_pix_stride * 4u;
