@@ -67,7 +67,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
   _Float16* const lw = ldsh + 2 * BUFH;
 
   const int dbg = g_mdbg;
-  unsigned long long t_work = 0, t_wait = 0, t_last = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_work = 0, t_wait = 0, t_pa = 0, t_pb = 0, t_pc = 0, t_last = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
   auto stamp = [&](unsigned long long& accum) {
     if (dbg & 64) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -191,15 +191,18 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       asm volatile("" : "+v"(pg));                       // opaque: keeps the tile-invariant (row, column) pairs from being hoisted
                                                          // out of the tile loop into 72 live registers (= spills)
       issue_w(std::integral_constant<int, SI>{});
+      stamp(t_pa);
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
         (([&] {
           if constexpr (Is < NIi) issue1(ti, oni, pg, xin, std::integral_constant<int, SI>{}, std::integral_constant<int, Is>{});
           if constexpr (Is < NIc) { if (!(dbg & 2)) convert1(buf, sc, std::integral_constant<int, Is>{}); }
         }()), ...);
       }(std::make_integer_sequence<int, NIm>{});
+      stamp(t_pb);
       _Float16* wb = lw + ((9 * i + S) & 1) * WBUFH;
 #pragma unroll
       for (int t = 0; t < WPW; ++t) *(u32x4*)&wb[(((wave * WPW + t) % 12) * 64 + lane) * 8] = wr[S % NBUF][t];
+      stamp(t_pc);
     };
 
     auto issue_all = [&](const Tile& tl, auto sc) {      // whole strip at once: only before the first tile
@@ -219,7 +222,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       const bool nx_on = i + 1 < nmine;
       const Tile nx = decode(tile_at(nx_on ? i + 1 : i));
       [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
-        ((produce_strip(i, tl, nx, nx_on, std::integral_constant<int, Ss>{}), stamp(t_work), lds_barrier(), stamp(t_wait)), ...);
+        ((produce_strip(i, tl, nx, nx_on, std::integral_constant<int, Ss>{}), lds_barrier(), stamp(t_wait)), ...);
       }(std::make_integer_sequence<int, NS>{});
     }
     lds_barrier();          // matches the consumers' last step
@@ -311,23 +314,38 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
           sc[r] = v * cw0; sc[16 + r] = v * cw1;
         }
         if (score_w) {
-          // sum over the 32 channels (= lanes of one half): transpose-reduce, 31 exchanges for the 32 (head, pixel) values;
-          // lane li ends up with the total of value li = (head li >> 4, pixel register li & 15)
-          auto stage = [&](auto stc) {
-            constexpr int ST = decltype(stc)::value;
-            const bool up = (li & ST) != 0;
+          // sum over the 32 channels (= lanes of one half): transpose-reduce, 31 exchanges for the 32 (head, pixel) values.  The
+          // partner of a lane is chosen per stage so that 30 of the 31 exchanges are DPP moves (4 cycles of VALU, no LDS
+          // crossbar and no wait): lane ^ 1 and lane ^ 2 (quad_perm), lane ^ 7 (row_half_mirror), lane ^ 15 (row_mirror);
+          // only the last, single exchange crosses the 16-lane row (lane ^ 16).  A chain of 31 ds_bpermute round trips took
+          // ~7 k of the consumer's 21 k cycles per tile.  Stage k halves the value index (bit VB) by lane bit LB, so
+          // lane li ends up with value index v = ((li & 15) << 1) | (li >> 4): (head v >> 4, pixel register v & 15).
+          auto stage = [&](auto vbc, auto lbc, auto ctlc) {
+            constexpr int VB = decltype(vbc)::value, LB = decltype(lbc)::value, CTL = decltype(ctlc)::value;
+            const bool up = (li & LB) != 0;
 #pragma unroll
-            for (int j = 0; j < ST; ++j) {
-              const float send = up ? sc[j] : sc[j + ST], keep = up ? sc[j + ST] : sc[j];
-              sc[j] = keep + __shfl_xor(send, ST);
+            for (int j = 0; j < VB; ++j) {
+              const float send = up ? sc[j] : sc[j + VB], keep = up ? sc[j + VB] : sc[j];
+              float got;
+              if constexpr (CTL >= 0) got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTL, 0xf, 0xf, false));
+              else got = __shfl_xor(send, 16);
+              sc[j] = keep + got;
             }
           };
-          stage(std::integral_constant<int, 16>{}); stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 4>{});
-          stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 1>{});
-          const int r = li & 15, c = (r & 3) + 8 * (r >> 2), x = xl + c;
+          using IC = std::integral_constant<int, 0>;
+          // a partner must hold the SAME value subset (agree in the lane bits of earlier stages) and a disjoint set of summed lanes:
+          // the mirrors (which flip all lower bits) therefore come first
+          stage(std::integral_constant<int, 16>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 0x140>{});     // lane ^ 15: row_mirror
+          stage(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 0x141>{});      // lane ^ 7: row_half_mirror
+          stage(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0x4E>{});       // lane ^ 2: quad_perm [2,3,0,1]
+          stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0xB1>{});       // lane ^ 1: quad_perm [1,0,3,2]
+          stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, -1>{});        // lane ^ 16: across the rows
+          (void)sizeof(IC);
+          const int vi = ((li & 15) << 1) | (li >> 4);      // value index of this lane: bits (8, 4, 2, 1, 16) of li select value bits (16, 8, 4, 2, 1)
+          const int r = vi & 15, c = (r & 3) + 8 * (r >> 2), x = xl + c;
           if (y < H && x < W) {
-            float* dstp = ((li >> 4) ? s1 : s0) + ((long long)tl.b * H + y) * W + x;
-            const float t = sc[0] + (accumulate ? *dstp : score_c[li >> 4]);
+            float* dstp = ((vi >> 4) ? s1 : s0) + ((long long)tl.b * H + y) * W + x;
+            const float t = sc[0] + (accumulate ? *dstp : score_c[vi >> 4]);
             *dstp = t;
           }
         }
@@ -338,7 +356,8 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
   }
   if ((dbg & 64) && lane == 0) {
     unsigned long long* o = g_mstamps + ((long long)blockIdx.x * 8 + wave) * 4;
-    o[0] = t_work; o[1] = t_wait; o[2] = nmine; o[3] = __builtin_amdgcn_s_memrealtime() - r_first;
+    o[0] = wave < NPW ? t_pa : t_work; o[1] = wave < NPW ? t_pb : t_wait; o[2] = nmine; o[3] = wave < NPW ? t_pc : 0;
+    if (wave < NPW) o[2] |= (unsigned long long)(t_wait / (nmine ? nmine : 1)) << 32;
   }
 }
 
@@ -376,7 +395,8 @@ extern "C" int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* dp, const v
     const int nt_in = (tiles_x - 2) * tiles_y * d.B, nt_b = 2 * tiles_y * d.B;
     hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, true>), dim3(nt_in < 256 ? nt_in : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
                        (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, nt_in, 1, score_w, score_c, s0, s1, accumulate);
-    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, false>), dim3(nt_b < 256 ? nt_b : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+    static const bool only_interior = getenv("EGNE_MSDIL_ONLY_INTERIOR") != nullptr;      // diagnostics: stamps of the interior launch
+    if (!only_interior) hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, false>), dim3(nt_b < 256 ? nt_b : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
                        (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, nt_b, 2, score_w, score_c, s0, s1, accumulate);
   } else {
     int gx = 256;

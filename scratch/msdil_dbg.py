@@ -21,7 +21,7 @@ pl.conv(layer, [Piece(ob, 0, 32)], Piece(out, 0, 32), B, H, W, residual=Piece(ob
 L = pl.L
 L.egne_msdil_debug.restype = C.c_int
 L.egne_msdil_debug.argtypes = [C.c_int, C.c_void_p]
-for dbg in (0, 64, 65, 66, 67, 64):
+for dbg in (64, 66, 67):
     L.egne_msdil_debug(dbg, None)
     for _ in range(3): pl.run()
     torch.cuda.synchronize()
@@ -33,8 +33,13 @@ for dbg in (0, 64, 65, 66, 67, 64):
     us = e0.elapsed_time(e1) * 1000 / n
     st = np.zeros(256 * 8 * 4, dtype=np.uint64)
     L.egne_msdil_debug(dbg, st.ctypes.data)
-    st = st.reshape(256, 8, 4).astype(np.float64)
+    raw = st.reshape(256, 8, 4)
+    pwait = np.median((raw[:, :4, 2] >> np.uint64(32)).astype(np.float64))
+    raw[:, :, 2] &= np.uint64(0xffffffff)
+    st = raw.astype(np.float64)
     tiles = np.maximum(st[:, :, 2], 1)
+    print("   producer per tile: setup+weights issue %.0f | item loop %.0f | weights to LDS %.0f | barrier wait %.0f" % (
+          np.median(st[:, :4, 0] / tiles[:, :4]), np.median(st[:, :4, 1] / tiles[:, :4]), np.median(st[:, :4, 3] / tiles[:, :4]), pwait))
     clk = np.median((st[:, :, 0] + st[:, :, 1]) / np.maximum(st[:, :, 3], 1)) * 100
     print("dbg %d: %.0f us clock %.0f MHz | per tile: producer work %.0f wait %.0f | consumer work %.0f wait %.0f cycles" % (dbg, us, clk,
           np.median(st[:, :4, 0] / tiles[:, :4]), np.median(st[:, :4, 1] / tiles[:, :4]), np.median(st[:, 4:, 0] / tiles[:, 4:]),
