@@ -41,6 +41,7 @@ constexpr unsigned OOB = 0x80000000u;
 struct GroupTab {
   int v[MAXG];       // per 16-channel group: (slice << 16) | (8-channel tail << 15) | group index inside the slice
   int off[MAXG];     // UNI: byte offset of the group's first channel inside a pixel of the common buffer
+  int dn;            // UNI: groups flagged 0x4000 in v[] start dn samples further into that buffer (the edge pass' half of a 2B batch)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -209,16 +210,19 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       }
       if constexpr (UNI) {
         const egne_seg sg = p1.seg[0];
-        const __amdgpu_buffer_rsrc_t r =
-            make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
+        const unsigned fbytes = (unsigned)H * W * (unsigned)sg.pix_stride * 4u;
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, fbytes);
+        const __amdgpu_buffer_rsrc_t r1 = make_rsrc(sg.ptr + (long long)(tl.b + gt.dn) * H * W * sg.pix_stride, fbytes);
         const int voff = valid ? (pix * (int)sg.pix_stride + 4 * lh) * 4 : (int)OOB;
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
           const int gg = bi * GB + u;
           const bool on_g = gg < G1;
+          const int e = gt.v[gg < MAXG ? gg : 0];
           const int so = gt.off[gg < MAXG ? gg : 0];
+          const __amdgpu_buffer_rsrc_t r = (e & 0x4000) ? r1 : r0;          // wave-uniform select
           xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, on_g ? voff : (int)OOB, so, 0);                                   // channels 16g + 4lh .. +3
-          xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, (on_g && !(gt.v[gg < MAXG ? gg : 0] & 0x8000)) ? voff + 32 : (int)OOB, so, 0);   // 16g + 8 + 4lh .. +3
+          xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, (on_g && !(e & 0x8000)) ? voff + 32 : (int)OOB, so, 0);   // 16g + 8 + 4lh .. +3
         }
         return;
       }
@@ -230,7 +234,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         const __amdgpu_buffer_rsrc_t r =
             make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
         const int voff = (valid && gg < G1) ? (pix * (int)sg.pix_stride + sg.ch_off + 4 * lh) * 4 : (int)OOB;
-        const int lg = e & 0x7fff;
+        const int lg = e & 0x3fff;
         xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff, lg * 64, 0);                              // channels 16g + 4lh .. +3
         xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, (e & 0x8000) ? (int)OOB : voff + 32, lg * 64, 0);   // 16g + 8 + 4lh .. +3
       }
@@ -586,6 +590,7 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                (d2.CoutP == 32 || d2.CoutP == 64), "conv_fused_1x1_3x3: 3x3 descriptor");
   EGNE_REQUIRE(!d1.bias || ((uintptr_t)d1.bias & 15) == 0, "conv_fused_1x1_3x3: bias alignment");
   GroupTab gt;
+  gt.dn = 0;
   int G = 0;
   bool uni = true;
   for (int s = 0; s < d1.nseg; ++s) {
@@ -595,11 +600,19 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                  "conv_fused_1x1_3x3: slice %d", s);
     const int n16 = (g.Cp + 15) / 16;
     EGNE_REQUIRE(G + n16 <= MAXG, "conv_fused_1x1_3x3: more than %d channel groups", MAXG);
+    // UNI: same buffer = same pixel pitch and a start that is a whole number of frames (0 or ONE common count dn) after seg[0]'s
+    const long long fbytes = (long long)d1.H * d1.W * d1.seg[0].pix_stride * 4, delta = (const char*)g.ptr - (const char*)d1.seg[0].ptr;
+    int far = 0;
+    if (g.pix_stride != d1.seg[0].pix_stride || delta < 0 || delta % fbytes != 0) uni = false;
+    else if (delta > 0) {
+      const long long q = delta / fbytes;
+      if (q > 0x7fffffff || (gt.dn != 0 && gt.dn != (int)q)) uni = false;
+      else { gt.dn = (int)q; far = 0x4000; }
+    }
     for (int k = 0; k < n16; ++k) {
-      gt.v[G + k] = (s << 16) | ((k == n16 - 1 && (g.Cp & 15)) ? 0x8000 : 0) | k;
+      gt.v[G + k] = (s << 16) | ((k == n16 - 1 && (g.Cp & 15)) ? 0x8000 : 0) | far | k;
       gt.off[G + k] = (g.ch_off + 16 * k) * 4;
     }
-    uni = uni && g.ptr == d1.seg[0].ptr && g.pix_stride == d1.seg[0].pix_stride;
     G += n16;
   }
   for (int k = G; k < MAXG; ++k) gt.v[k] = gt.off[k] = 0;
@@ -623,6 +636,7 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
                  (long long)d1.B * d1.Ho * d1.Wo * d1.res_pix_stride * 4 < (1ll << 31),
                  "conv_fused_1x1_3x3: the up-sampled addend needs 32 -> 32 channels, <= 8 groups and a half-resolution tensor");
     if (uni && G == 4) return launch_fused<1, 1, 8, 1, false, true, true, 4>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
+    if (uni && G == 6) return launch_fused<1, 1, 8, 2, false, true, true, 2>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
     if (uni)
       return G <= 4 ? launch_fused<1, 1, 8, 1, false, true, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st)
                     : launch_fused<1, 1, 8, 2, false, true, true>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);
@@ -681,6 +695,7 @@ extern "C" int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const
   EGNE_REQUIRE(((uintptr_t)c4hi & 15) == 0 && ((uintptr_t)c4lo & 15) == 0 && ((uintptr_t)f2hi & 15) == 0 && ((uintptr_t)f2lo & 15) == 0 &&
                a1 > 0.f && a2 > 0.f && w1_scale > 0.f && w2_scale > 0.f && (!d1.bias || ((uintptr_t)d1.bias & 15) == 0), "conv_fused_c4_3x3: weights / scales");
   GroupTab gt;
+  gt.dn = 0;
   for (int k = 0; k < MAXG; ++k) gt.v[k] = gt.off[k] = 0;
   return launch_fused<1, 1, 8, 1, true, false, false, 3>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 3, (const _Float16*)f2hi, (const _Float16*)f2lo,
                                         a1, 1.0f / (a1 * w1_scale), a2, 1.0f / (a2 * w2_scale), (hipStream_t)stream);

@@ -263,8 +263,13 @@ def build_forward_plan(model, B, H, W, dev, training):
         if variant == "concat":
             skip = skip + [D[lvl]["out"].samples(B), D[lvl]["x"].samples(B)]
         Cl = sum(p.C for p in prev)                  # channels of the up-sampled operand (first in the reference's torch.cat)
-        x1b = pl.buf(B, h, w, pad8(oc))
-        x1 = Piece(x1b, 0, oc)
+        if FOLD_UP and not training and variant != "concat" and D[lvl]["x1"].C == oc:
+            # inference: the encoder is finished, its x1 slice of this level is dead -- the up block's x1 takes its place, so that
+            # conv21 reads skip and x1 from ONE buffer (the fused kernel's uniform-buffer path)
+            x1 = Piece(D[lvl]["x1"].buf, D[lvl]["x1"].off, oc)
+        else:
+            x1b = pl.buf(B, h, w, pad8(oc))
+            x1 = Piece(x1b, 0, oc)
         y = pl.buf(B, h, w, pad8(oc))
         l12 = _cl(ub.conv12, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
         l22 = _cl(ub.conv22, [(oc, pad8(oc))], pad=(1, 1), act=ACT_LEAKY)
