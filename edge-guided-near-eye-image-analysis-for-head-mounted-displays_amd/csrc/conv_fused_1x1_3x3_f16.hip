@@ -203,8 +203,13 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             const bool ok = valid && tap < 9 && gg < G1 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
             offs[t] = ok ? ((yy * W + xx) * (int)sg.pix_stride + sg.ch_off) * 4 : (int)OOB;
           }
-          xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[0], 0, 0);
-          xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[1], 0, 0);
+          if (sg.pix_stride == 1) {      // one-channel planar input ([B][H][W] = NCHW with C = 1): a dword per tap, channels 1-3 are zero
+            xa[BUF][u] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(r, offs[0], 0, 0), 0u, 0u, 0u};
+            xb[BUF][u] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(r, offs[1], 0, 0), 0u, 0u, 0u};
+          } else {
+            xa[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[0], 0, 0);
+            xb[BUF][u] = __builtin_amdgcn_raw_buffer_load_b128(r, offs[1], 0, 0);
+          }
         }
         return;
       }
@@ -681,9 +686,10 @@ extern "C" int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const
   EGNE_REQUIRE(d1.kh == 3 && d1.kw == 3 && d1.stride == 1 && d1.pad_h == 1 && d1.pad_w == 1 && d1.pad_mode == 0 && d1.ngroups == 1 &&
                d1.dil[0] == 1 && d1.nseg == 1 && !d1.residual && !d1.post_scale && d1.CoutP == 32, "conv_fused_c4_3x3: first descriptor");
   const egne_seg& g = d1.seg[0];
-  EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && g.Cp >= 4 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
-               ((uintptr_t)g.ptr & 15) == 0 && g.ch_off + 4 <= g.pix_stride && (long long)d1.H * d1.W * g.pix_stride * 4 < (1ll << 31),
-               "conv_fused_c4_3x3: input slice");
+  const bool planar = g.pix_stride == 1;      // [B][H][W] one-channel input read in place (no NHWC staging copy)
+  EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.act_in == EGNE_ACT_NONE && ((uintptr_t)g.ptr & 15) == 0 &&
+               (planar ? g.ch_off == 0 : (g.Cp >= 4 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 && g.ch_off + 4 <= g.pix_stride)) &&
+               (long long)d1.H * d1.W * g.pix_stride * 4 < (1ll << 31), "conv_fused_c4_3x3: input slice");
   EGNE_REQUIRE(d2.kh == 3 && d2.kw == 3 && d2.stride == 1 && d2.pad_mode == 0 && d2.ngroups == 1 && d2.pad_h == 1 && d2.pad_w == 1 &&
                d2.dil[0] == 1 && d2.Ho == d2.H && d2.Wo == d2.W && d2.B == d1.B && d2.H == d1.H && d2.W == d1.W && d2.Ktot == 32 &&
                d2.CoutP == 32, "conv_fused_c4_3x3: 3x3 descriptor");

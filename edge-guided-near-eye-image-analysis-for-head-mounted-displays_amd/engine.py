@@ -294,6 +294,25 @@ class ConvLayer:
         return ho, wo
 
 
+class PlanarPiece(Piece):
+    """A ONE-channel tensor [N][H][W] read in place (NCHW with C = 1) by the kernels that take it (the fused convBlock head):
+    pixel pitch 1 float, no NHWC staging copy.  Presents the layout (1, 8) of the padded slice it replaces."""
+
+    def __init__(self, buf):
+        assert buf.dim() == 4 and buf.shape[-1] == 1 and buf.is_contiguous()
+        self.buf, self.off, self.C, self.Cp, self.n0 = buf, 0, 1, 8, 0
+        self.scale = self.shift = None
+        self.act_in = ACT_NONE
+        self.nograd = True
+
+    @property
+    def stride(self):
+        return 1
+
+    def with_norm(self, *a, **k):
+        raise RuntimeError("a planar one-channel input cannot carry a fused normalisation")
+
+
 class DgradLayer(ConvLayer):
     """Data gradient of ``fwd`` w.r.t. its input slice ``idx`` as a forward convolution: the weights
     are the flipped / transposed pack of egne_pack_conv_weight_dgrad, the input is the gradient
@@ -791,7 +810,9 @@ class Plan:
                     and l1.post is None and len(pieces) == 1 and pieces[0].scale is None and pieces[0].Cp >= 4 and l1.CoutP == 32
                     and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
                     and l2.pad_mode == 0 and len(l2.in_layout) == 1 and l2.in_layout[0][0] == l1.Cout and l2.CoutP == 32
-                    and W >= FUSE_1X1_MIN_W and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29)
+                    and W >= FUSE_1X1_MIN_W and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29
+                    and (not isinstance(pieces[0], PlanarPiece) or l1.Cin == 1))
+        assert fused_c4 or not isinstance(pieces[0], PlanarPiece), "%s: only the fused convBlock kernel reads planar inputs" % name
         if fused_c4:
             return self._conv_pair_c4(l1, pieces[0], l2, dst, B, H, W, residual, name, stats)
         if not fused:
@@ -1078,6 +1099,10 @@ def _run_calibrating(self, st):
             ai, pieces, npix = ent
             mx.zero_()
             for pc in pieces:
+                if isinstance(pc, PlanarPiece):        # [N][H][W] floats: measured as rows of four
+                    assert npix % 4 == 0
+                    _lib.check(self.L.egne_absmax(pc.ptr, 4, 0, 4, npix // 4, mx.data_ptr(), st), "absmax")
+                    continue
                 _lib.check(self.L.egne_absmax(pc.ptr, pc.stride, pc.off, pc.Cp, npix, mx.data_ptr(), st), "absmax")
             v = float(mx.view(torch.float32).item())
             if not math.isfinite(v):

@@ -18,11 +18,13 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import ACT_LEAKY, ACT_NONE, ConvLayer, Piece, Plan, VersionGuard, pad8, pad32
+from . import engine as _eng
+from .engine import ACT_LEAKY, ACT_NONE, ConvLayer, Piece, PlanarPiece, Plan, VersionGuard, pad8, pad32
 
 
 import os
 
+PLANAR_IN = os.environ.get("EGNE_PLANAR_IN", "1") != "0"   # one-channel inputs read in place by the fused head (no NHWC staging)
 FOLD_UP = os.environ.get("EGNE_FOLD_UP", "1") != "0"     # up blocks: 1x1 of the up-sampled operand at half resolution
 
 
@@ -147,16 +149,27 @@ def build_forward_plan(model, B, H, W, dev, training):
     _cl.eval_plan = not training
 
     # ---- inputs (persistent; forward() copies the caller's tensors in) -----------------------------
-    pl.in_img = pl.vec(B, 1, H, W)
-    pl.in_edge = pl.vec(B, 1, H, W)
-    xin = pl.buf(NB, H, W, 8)
-    first = pl.in_edge if only_edge else pl.in_img
-    pl.raw(L.egne_nchw_to_nhwc, (first.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 0, 8), "in.img")
-    if in_c == 2:
-        pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 1, 1), "in.edge_ch")
-    if add_edge:
-        pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr() + 4 * B * H * W * 8, 8, 0, 8),
-               "in.edge")
+    # Inference with one input channel: the image and edge batches sit back to back in ONE [NB][H][W] tensor that the fused
+    # convBlock head reads in place (NCHW with C = 1 is NHWC with a pixel pitch of one float) -- no layout kernels, no 8-channel
+    # padded staging copy (2 x 315 MB written and read back per step at B = 64).
+    planar_in = (PLANAR_IN and not training and in_c == 1 and _eng.ESF_SPLIT and _eng.FUSE_1X1 and _eng.F16X3_ENABLED
+                 and W >= _eng.FUSE_1X1_MIN_W and chz == 32)
+    if planar_in:
+        pin = pl.vec(NB, 1, H, W)
+        first = pin[:B]
+        pl.in_img, pl.in_edge = (pl.vec(B, 1, H, W), first) if only_edge else (first, pin[B:] if add_edge else pl.vec(B, 1, H, W))
+        xin = None
+    else:
+        pl.in_img = pl.vec(B, 1, H, W)
+        pl.in_edge = pl.vec(B, 1, H, W)
+        xin = pl.buf(NB, H, W, 8)
+        first = pl.in_edge if only_edge else pl.in_img
+        pl.raw(L.egne_nchw_to_nhwc, (first.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 0, 8), "in.img")
+        if in_c == 2:
+            pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 1, 1), "in.edge_ch")
+        if add_edge:
+            pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr() + 4 * B * H * W * 8, 8, 0, 8),
+                   "in.edge")
 
     # ---- encoder on NB samples -------------------------------------------------------------------
     enc = model.enc
@@ -177,8 +190,11 @@ def build_forward_plan(model, B, H, W, dev, training):
 
     t0 = pl.buf(NB, H, W, pad8(chz))
     l1 = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
-    xin_p = Piece(xin, 0, in_c, 8)
-    xin_p.nograd = True
+    if planar_in:
+        xin_p = PlanarPiece(pin.view(NB, H, W, 1))
+    else:
+        xin_p = Piece(xin, 0, in_c, 8)
+        xin_p.nograd = True
     l = _cl(enc.head.conv2, [(chz, pad8(chz))], pad=(1, 1), act=ACT_LEAKY)
     x_stats = None
     if not training:

@@ -194,7 +194,8 @@ int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* d1, const egne_conv_des
 
 /* The same with a 3x3 / pad 1 convolution on <= 4 input channels in front (utils.py:1047-1048 convBlock: conv1 -> LeakyReLU ->
  * conv2 -> LeakyReLU [-> eval BatchNorm = d2's post affine]): d1 = that convolution (one slice with >= 4 padded channels,
- * CoutP = 32; its activation is applied before the 3x3), c4hi / c4lo = egne_pack_conv3x3_c4_weight_f16 (CoutP 32). */
+ * CoutP = 32; its activation is applied before the 3x3), c4hi / c4lo = egne_pack_conv3x3_c4_weight_f16 (CoutP 32).
+ * A one-channel input may be given in place as [B][H][W] floats (= NCHW with C = 1): seg[0].pix_stride = 1, ch_off = 0. */
 int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* d1, const egne_conv_desc* d2, const void* c4hi, const void* c4lo,
                                      float a1, float w1_scale, const void* f2hi, const void* f2lo, float a2, float w2_scale,
                                      void* stream);

@@ -33,6 +33,9 @@ def timed(pre):
         e0.record(); pl.run(); e1.record(); torch.cuda.synchronize()
         tot += e0.elapsed_time(e1)
     return tot * 100
+src = torch.randn_like(xb)
+print("after rewriting its input (315 MB copy) %.0f us" % timed(lambda: xb.copy_(src)))
+print("after rewriting input + 5 trunk convs before %.0f us" % timed(lambda: ([pb.run() for _ in range(5)], xb.copy_(src))))
 print("back to back            %.0f us" % timed(lambda: None))
 print("after 5 trunk convs     %.0f us" % timed(lambda: [pb.run() for _ in range(5)]))
 print("after a 1 GiB fill      %.0f us" % timed(lambda: big.fill_(1.0)))
