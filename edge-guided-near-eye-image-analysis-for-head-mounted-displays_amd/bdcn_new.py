@@ -16,10 +16,12 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import ACT_RELU, ConvLayer, Piece, Plan, VersionGuard, maxpool_out, pad8, require_cuda
+from . import engine
+from .engine import ACT_RELU, ConvLayer, Piece, PlanarPiece, Plan, VersionGuard, maxpool_out, pad8, require_cuda
 
 import os
 
+PLANAR_IN = os.environ.get("EGNE_PLANAR_IN", "1") != "0"     # conv1_1 reads the NCHW frames in place
 SCORES_FUSED = os.environ.get("EGNE_SCORES_FUSED", "1") != "0"     # stage score heads in the epilogue of the MSBlock kernel
 
 # (name, cin, cout, dilation) / pool markers; vgg16_c.py:11-39
@@ -126,9 +128,13 @@ class BDCN(nn.Module):
         L = pl.L
         f = self.features
         x_in = pl.vec(B, 3, H, W)
-        xb = pl.buf(B, H, W, 8)
-        pl.raw(L.egne_nchw_to_nhwc, (x_in.data_ptr(), B, 3, H, W, xb.data_ptr(), 8, 0, 8), "bdcn.in")
-        cur, ch, hh, ww = Piece(xb, 0, 3), 3, H, W
+        if PLANAR_IN and engine.F16X3_ENABLED and engine.C4H_MODE != "off":
+            cur = PlanarPiece(x_in)        # conv1_1 reads the NCHW frames in place (conv3x3_c4_f16.hip): no layout kernel
+        else:
+            xb = pl.buf(B, H, W, 8)
+            pl.raw(L.egne_nchw_to_nhwc, (x_in.data_ptr(), B, 3, H, W, xb.data_ptr(), 8, 0, 8), "bdcn.in")
+            cur = Piece(xb, 0, 3)
+        ch, hh, ww = 3, H, W
         feats = []
         pooled = None               # a stride-2 pooling already written by the convolution in front of it
         for idx, item in enumerate(_VGG):

@@ -73,9 +73,12 @@ __global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(const egne_conv_des
     const int y = r / p.W, x = r - y * p.W;
     // the block may straddle two frames: per-lane frame in the offset, resource over the rest of the tensor from the block's first frame
     const int b0 = (int)(((long long)blk * 32) / hw);
-    const long long left = ((long long)p.B - b0) * hw * sg.pix_stride * 4;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * hw * sg.pix_stride, (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
-    const int base = (((b - b0) * hw + r) * (int)sg.pix_stride + sg.ch_off) * 4;
+    // planar: the input is [B][C][H][W] (NCHW, C = seg.Cp <= 4 planes) read in place: pix_stride 1, one dword per tap and plane
+    const bool planar = sg.pix_stride == 1;
+    const int fstride = planar ? hw * sg.Cp : hw * (int)sg.pix_stride;         // floats per frame
+    const long long left = ((long long)p.B - b0) * fstride * 4;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * fstride, (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+    const int base = planar ? ((b - b0) * fstride + r) * 4 : (((b - b0) * hw + r) * (int)sg.pix_stride + sg.ch_off) * 4;
     (void)frame_in;
     f32x16 acc[TN];
 #pragma unroll
@@ -87,8 +90,20 @@ __global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(const egne_conv_des
       const int dy0 = t0 / 3 - 1, dx0 = t0 % 3 - 1, dy1 = t1 / 3 - 1, dx1 = t1 % 3 - 1;
       const bool ok0 = m < M && t0 < 9 && (unsigned)(y + dy0) < (unsigned)p.H && (unsigned)(x + dx0) < (unsigned)p.W;
       const bool ok1 = m < M && t1 < 9 && (unsigned)(y + dy1) < (unsigned)p.H && (unsigned)(x + dx1) < (unsigned)p.W;
-      xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok0 ? base + (dy0 * p.W + dx0) * ps4 : (int)OOB, 0, 0);
-      xb[s] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok1 ? base + (dy1 * p.W + dx1) * ps4 : (int)OOB, 0, 0);
+      if (planar) {
+        const int o0 = ok0 ? base + (dy0 * p.W + dx0) * 4 : (int)OOB, o1 = ok1 ? base + (dy1 * p.W + dx1) * 4 : (int)OOB;
+        u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+          if (ch < sg.Cp) {
+            a[ch] = __builtin_amdgcn_raw_buffer_load_b32(rin, o0, ch * hw * 4, 0);
+            c[ch] = __builtin_amdgcn_raw_buffer_load_b32(rin, o1, ch * hw * 4, 0);
+          }
+        xa[s] = a; xb[s] = c;
+      } else {
+        xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok0 ? base + (dy0 * p.W + dx0) * ps4 : (int)OOB, 0, 0);
+        xb[s] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok1 ? base + (dy1 * p.W + dx1) * ps4 : (int)OOB, 0, 0);
+      }
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -157,8 +172,11 @@ extern "C" int egne_conv3x3_smallcin_f16_fwd(const egne_conv_desc* dp, const voi
   EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_h == 1 && d.pad_w == 1 && d.pad_mode == 0 && d.ngroups == 1 &&
                d.dil[0] == 1 && d.nseg == 1 && d.Ho == d.H && d.Wo == d.W && !d.residual, "conv_smallcin_f16: geometry not supported");
   const egne_seg& g = d.seg[0];
-  EGNE_REQUIRE(g.ptr && g.Cp >= 4 && !g.scale && ((uintptr_t)g.ptr & 15) == 0 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
-               2ll * d.H * d.W * g.pix_stride * 4 < (1ll << 31), "conv_smallcin_f16: input slice");
+  const bool planar = g.pix_stride == 1;      // [B][Cp][H][W] (NCHW, Cp <= 4 planes) read in place
+  EGNE_REQUIRE(g.ptr && !g.scale && ((uintptr_t)g.ptr & 15) == 0 &&
+               (planar ? (g.Cp >= 1 && g.Cp <= 4 && g.ch_off == 0 && 2ll * d.H * d.W * g.Cp * 4 < (1ll << 31))
+                       : (g.Cp >= 4 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 && 2ll * d.H * d.W * g.pix_stride * 4 < (1ll << 31))),
+               "conv_smallcin_f16: input slice");
   EGNE_REQUIRE((d.CoutP == 32 || d.CoutP == 64) && d.Cout_store <= d.CoutP && d.Cout_store % 4 == 0 && d.out && ((uintptr_t)d.out & 15) == 0 &&
                d.out_ch_off % 4 == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off + d.Cout_store <= d.out_pix_stride &&
                d.out_pix_stride * 128 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&

@@ -295,12 +295,13 @@ class ConvLayer:
 
 
 class PlanarPiece(Piece):
-    """A ONE-channel tensor [N][H][W] read in place (NCHW with C = 1) by the kernels that take it (the fused convBlock head):
-    pixel pitch 1 float, no NHWC staging copy.  Presents the layout (1, 8) of the padded slice it replaces."""
+    """An NCHW tensor [N][C][H][W] with C <= 4 read in place by the kernels that take it (first layers: conv3x3_c4_f16.hip; the
+    fused convBlock head with C = 1): pixel pitch 1 float, no NHWC staging copy.  Presents the layout (C, 8) of the padded
+    slice it replaces."""
 
     def __init__(self, buf):
-        assert buf.dim() == 4 and buf.shape[-1] == 1 and buf.is_contiguous()
-        self.buf, self.off, self.C, self.Cp, self.n0 = buf, 0, 1, 8, 0
+        assert buf.dim() == 4 and buf.shape[1] <= 4 and buf.is_contiguous()
+        self.buf, self.off, self.C, self.Cp, self.n0 = buf, 0, int(buf.shape[1]), 8, 0
         self.scale = self.shift = None
         self.act_in = ACT_NONE
         self.nograd = True
@@ -308,6 +309,10 @@ class PlanarPiece(Piece):
     @property
     def stride(self):
         return 1
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
 
     def with_norm(self, *a, **k):
         raise RuntimeError("a planar one-channel input cannot carry a fused normalisation")
@@ -587,6 +592,9 @@ class Plan:
         elif smallcin and c4h:
             layer.need_c4h = True
             layer.need_flat = True
+        assert not isinstance(pieces[0], PlanarPiece) or (smallcin and c4h), "%s: only the first-layer streaming kernel reads planar inputs" % name
+        if False:
+            pass
         elif smallcin:
             layer.need_c4 = True
             layer.need_flat = True   # the generic pack is still what the backward (wgrad) paths index with kinv
@@ -611,7 +619,7 @@ class Plan:
         d.nseg = len(pieces)
         for i, p in enumerate(pieces):
             s = d.seg[i]
-            s.ptr, s.pix_stride, s.ch_off, s.Cp = p.ptr, p.stride, p.off, p.Cp
+            s.ptr, s.pix_stride, s.ch_off, s.Cp = p.ptr, p.stride, p.off, (p.C if isinstance(p, PlanarPiece) else p.Cp)
             s.scale = p.scale.data_ptr() if p.scale is not None else None
             s.shift = p.shift.data_ptr() if p.shift is not None else None
             s.act_in = p.act_in
@@ -1099,9 +1107,9 @@ def _run_calibrating(self, st):
             ai, pieces, npix = ent
             mx.zero_()
             for pc in pieces:
-                if isinstance(pc, PlanarPiece):        # [N][H][W] floats: measured as rows of four
-                    assert npix % 4 == 0
-                    _lib.check(self.L.egne_absmax(pc.ptr, 4, 0, 4, npix // 4, mx.data_ptr(), st), "absmax")
+                if isinstance(pc, PlanarPiece):        # [N][C][H][W] floats: measured as rows of four
+                    assert npix * pc.C % 4 == 0
+                    _lib.check(self.L.egne_absmax(pc.ptr, 4, 0, 4, npix * pc.C // 4, mx.data_ptr(), st), "absmax")
                     continue
                 _lib.check(self.L.egne_absmax(pc.ptr, pc.stride, pc.off, pc.Cp, npix, mx.data_ptr(), st), "absmax")
             v = float(mx.view(torch.float32).item())

@@ -191,7 +191,7 @@ def build_forward_plan(model, B, H, W, dev, training):
     t0 = pl.buf(NB, H, W, pad8(chz))
     l1 = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
     if planar_in:
-        xin_p = PlanarPiece(pin.view(NB, H, W, 1))
+        xin_p = PlanarPiece(pin)
     else:
         xin_p = Piece(xin, 0, in_c, 8)
         xin_p.nograd = True
