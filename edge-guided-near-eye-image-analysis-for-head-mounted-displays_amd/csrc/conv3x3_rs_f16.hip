@@ -276,6 +276,11 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     int pbase[WMW], pcm[WMW];                            // previous tile: first pixel of the lane per row, valid pixels from it
 #pragma unroll
     for (int tm = 0; tm < WMW; ++tm) { pbase[tm] = 0; pcm[tm] = 0; }
+    int pvo[WMW][WNW][NMH], pvr[WMW][WNW][NMH];            // previous tile: byte offsets of (row, channel) in the output / residual
+    bool pedge = true;                                   // ... and whether it needs per-value range checks (nothing stored before the first tile)
+    const bool full_epi = p.post_scale != nullptr || p.residual != nullptr;
+#pragma unroll
+    for (int a = 0; a < WMW * WNW * NMH; ++a) { (&pvo[0][0][0])[a] = (int)OOB; (&pvr[0][0][0])[a] = (int)OOB; }
     int pchunk = -1;                                     // no previous tile yet: nothing to write
     double st_s[WNW][NMH], st_q[WNW][NMH];
     int n4[WNW][NMH];
@@ -294,14 +299,21 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                     tn = V / (NRV * NMH * WMW * NMH);
       constexpr int c = M16 ? mh * 16 + r : (r & 3) + 8 * (r >> 2);
       constexpr bool first = r == 0 && mh == 0 && tm == 0, last = r == NRV - 1 && mh == NMH - 1 && tm == WMW - 1;
-      const bool ok = nokv[tn][nh] && c < pcm[tm];
+      // interior tiles: the lane's byte offset of the row is fixed at hand-over and the pixel step goes into the instruction's
+      // scalar offset -- 3 VALU + the store per value; edge tiles mask value by value
+      bool ok = true;
+      int vo = pvo[tm][tn][nh], vr = pvr[tm][tn][nh];
+      if (pedge) {
+        ok = nokv[tn][nh] && c < pcm[tm];
+        vo = ok ? vo : (int)OOB; vr = ok ? vr : (int)OOB;
+      }
       float v = prev[tm][mh][tn][nh][r] * out_scale + bvs[tn][nh];
-      v = fmaxf(v, v * slope_out) * pss[tn][nh] + pts[tn][nh];
-      if (p.residual)
-        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                 rres, ok ? ((pbase[tm] + c) * (int)p.res_pix_stride + p.res_ch_off + n4[tn][nh]) * 4 : (int)OOB, 0, 0));
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
-                                            ok ? ((pbase[tm] + c) * (int)p.out_pix_stride + p.out_ch_off + n4[tn][nh]) * 4 : (int)OOB, 0, 0);
+      v = fmaxf(v, v * slope_out);
+      if (full_epi) {
+        v = v * pss[tn][nh] + pts[tn][nh];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr, c * res_step, 0));
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, c * out_step, 0);
       if (st_on) {
         if constexpr (first) { st_s[tn][nh] = 0.; st_q[tn][nh] = 0.; }
         const double vm = ok ? (double)v : 0.;
@@ -429,7 +441,15 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           const int y = tl.y0 + row0 + tm;
           pbase[tm] = y * W + xl;
           pcm[tm] = (y < H && xl < W) ? W - xl : 0;
+#pragma unroll
+          for (int tn = 0; tn < WNW; ++tn)
+#pragma unroll
+            for (int nh = 0; nh < NMH; ++nh) {
+              pvo[tm][tn][nh] = (pbase[tm] * (int)p.out_pix_stride + p.out_ch_off + n4[tn][nh]) * 4;
+              pvr[tm][tn][nh] = (pbase[tm] * (int)p.res_pix_stride + p.res_ch_off + n4[tn][nh]) * 4;
+            }
         }
+        pedge = tl.x0 + TW > W || tl.y0 + TH > H || (nt0 + WNW) * 32 > p.Cout_store;       // wave-uniform
         pchunk = tl.b * p.stats_nchunk + ((tl.y0 / TH) * tiles_x + tl.x0 / TW) * (4 / NSPLIT) + cw / NSPLIT;
         have_prev = DEFER;
         if constexpr (!DEFER)
@@ -481,6 +501,8 @@ int dispatch_rs(const egne_conv_desc& d, const _Float16* h, const _Float16* l, f
       case 36: return launch_rs<2, 2, 4, M16, 36>(d, h, l, a_scale, os, st);
       case 52: return launch_rs<2, 2, 4, M16, 52>(d, h, l, a_scale, os, st);
       case 55: return launch_rs<2, 2, 4, M16, 55>(d, h, l, a_scale, os, st);
+      case 40: return launch_rs<2, 2, 4, M16, 40>(d, h, l, a_scale, os, st);
+      case 41: return launch_rs<2, 2, 4, M16, 41>(d, h, l, a_scale, os, st);
       default: return launch_rs<2, 2, 4, M16>(d, h, l, a_scale, os, st);
     }
   }

@@ -2,7 +2,7 @@
 1 no weight refills, 2 no LDS operand reads, 4 no conversion, 16 no halo loads, 8 no output stores, 32 clock stamps)."""
 import os, sys, subprocess
 if len(sys.argv) == 1:
-    for m16, dbg in ((0, 32), (1, 32), (0, 32), (1, 32)):
+    for m16, dbg in ((0, 32), (0, 33)):
         env = dict(os.environ, EGNE_RS_DBG=str(dbg), EGNE_RS_M16=str(m16))
         print("m16=%d dbg=%d" % (m16, dbg), subprocess.run([sys.executable, __file__, "x"], env=env, capture_output=True, text=True).stdout.strip(), flush=True)
     sys.exit(0)
