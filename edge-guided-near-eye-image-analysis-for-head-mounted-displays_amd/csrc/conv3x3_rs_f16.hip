@@ -66,7 +66,11 @@ struct RsGeom {
 #ifndef RINGX
 #define RINGX 1
 #endif
-template <int NCH, int WN, int TH, bool M16, int DBG = 0>
+// TPO: transposed product (weight fragment as the A operand): a lane ends up with 16 channels (4 runs of 4) of ONE pixel and stores
+// 16 bytes per instruction -- 8 stores per 32 x 32 block instead of 32.  Beside MFMAs a vector-memory instruction costs the wave
+// ~100 cycles of issue whatever its width (measured: 32 dword stores per tile = 3.6 k of 12.2 k cycles); needs all 32 * WN channels
+// stored and no statistics (channel sums would need cross-lane reductions).
+template <int NCH, int WN, int TH, bool M16, int DBG = 0, bool TPO = false>
 __global__ __launch_bounds__(512)
 void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
                        float out_scale, int tiles_x, int tiles_y, int ntiles) {
@@ -333,6 +337,41 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         (([&] { if constexpr (Vs * NS / NV == J || (NV > NS && Vs / ((NV + NS - 1) / NS) == J)) epi_value(std::integral_constant<int, Vs>{}); }()), ...);
       }(std::make_integer_sequence<int, NV>{});
     };
+    // ---- TPO: lane = pixel lm of the row, registers 4 j + e = channels 32 tn + 8 j + 4 kg + e: one 16-byte store per (row, tn, j)
+    constexpr int NGRP = WMW * WNW * 4;                  // store groups per lane and tile
+    f32x4 tb4[TPO ? WNW : 1][4];                         // bias of the lane's 16 channels per output tile
+    int tvo[WMW], tvr[WMW];                              // previous tile: byte offset of the lane's pixel per row (OOB: outside the image)
+    if constexpr (TPO) {
+#pragma unroll
+      for (int tn = 0; tn < WNW; ++tn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          tb4[tn][j] = p.bias ? *(const f32x4*)(p.bias + (nt0 + tn) * 32 + 8 * j + 4 * kg) : (f32x4)(0.f);
+#pragma unroll
+      for (int tm = 0; tm < WMW; ++tm) { tvo[tm] = (int)OOB; tvr[tm] = (int)OOB; }
+    }
+    auto tpo_group = [&](auto gc) {
+      constexpr int Gi = decltype(gc)::value, j = Gi % 4, tm = (Gi / 4) % WMW, tn = Gi / (4 * WMW);
+      constexpr int choff = (tn * 32 + 8 * j) * 4;       // immediate offset of the run inside the pixel
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = prev[tm][0][tn][0][4 * j + e] * out_scale + tb4[tn][j][e];
+        v[e] = fmaxf(t, t * slope_out);
+      }
+      if (full_epi) {                                    // rare in these layers: post affine / residual straight from memory
+        const int n = (nt0 + tn) * 32 + 8 * j + 4 * kg;
+        if (p.post_scale) v = v * *(const f32x4*)(p.post_scale + n) + *(const f32x4*)(p.post_shift + n);
+        if (p.residual) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, tvr[tm], choff, 0));
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, tvo[tm], choff, 0);
+    };
+    auto tpo_step = [&](auto jc) {            // the groups handed to step j
+      constexpr int J = decltype(jc)::value;
+      [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
+        (([&] { if constexpr (Gs * NS / NGRP == J) tpo_group(std::integral_constant<int, Gs>{}); }()), ...);
+      }(std::make_integer_sequence<int, NGRP>{});
+    };
     bool have_prev = false;
 
     for (int i = 0; i < nloop; ++i) {
@@ -375,7 +414,8 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                   ql[j % NR][tn][nh] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, w_off((j + NR) % NS, tn, nh), 0);
                 }
               }
-            if constexpr (DEFER && !(DBG & 8)) epi_step(std::integral_constant<int, j>{});
+            if constexpr (TPO) { if constexpr (DEFER && !(DBG & 8)) tpo_step(std::integral_constant<int, j>{}); }
+            else if constexpr (DEFER && !(DBG & 8)) epi_step(std::integral_constant<int, j>{});
             __builtin_amdgcn_sched_barrier(0);          // the reads, refills and stores above are issued before this step's MFMAs
 #pragma unroll
             for (int tm = 0; tm < WMW; ++tm)
@@ -390,6 +430,10 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[j & 1][tm][mh], bh[tn][nh], c, 0, 0, 0);
                       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j & 1][tm][mh], bl[tn][nh], c, 0, 0, 0);
                       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j & 1][tm][mh], bh[tn][nh], c, 0, 0, 0);
+                    } else if constexpr (TPO) {
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tn][nh], al[j & 1][tm][mh], c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[tn][nh], ah[j & 1][tm][mh], c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tn][nh], ah[j & 1][tm][mh], c, 0, 0, 0);
                     } else {
                       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][tm][mh], bh[tn][nh], c, 0, 0, 0);
                       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][tm][mh], bl[tn][nh], c, 0, 0, 0);
@@ -402,7 +446,33 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         phase(ph_mma);
         // second output: 2x2 / stride 2 / ceil-mode max pooling of the activated result -- the wave owns both rows of a pooling
         // window (row0 and y0 are even) and the lane both of its columns (registers r, r + 1); act(max) = max(act): monotonic
-        if constexpr (WMW == 2 && !M16) {
+        if constexpr (WMW == 2 && TPO) {
+          if (p.pool_out) {                                // lane = pixel: the column partner is lane ^ 1 (DPP quad_perm), the row partner register tm ^ 1
+            const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+            const __amdgpu_buffer_rsrc_t rpo = make_rsrc(p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride,
+                                                         (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * 4u);
+            const int x = tl.x0 + lm, y = tl.y0 + row0;
+            const bool y1 = y + 1 < H, x1 = x + 1 < W;
+            const int poff = (!(lm & 1) && x < W && y < H) ? (((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + nt0 * 32 + 4 * kg) * 4 : (int)OOB;
+#pragma unroll
+            for (int tn = 0; tn < WNW; ++tn)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float m = acc[0][0][tn][0][4 * j + e];
+                  if (y1) m = fmaxf(m, acc[1][0][tn][0][4 * j + e]);
+                  const float q = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+                  if (x1) m = fmaxf(m, q);
+                  const float t = m * out_scale + tb4[tn][j][e];
+                  v[e] = fmaxf(t, t * slope_out);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rpo, poff, (tn * 32 + 8 * j) * 4, 0);
+              }
+          }
+        }
+        if constexpr (WMW == 2 && !M16 && !TPO) {
           if (p.pool_out) {
             const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
             const __amdgpu_buffer_rsrc_t rpo = make_rsrc(p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride,
@@ -450,17 +520,29 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
             }
         }
         pedge = tl.x0 + TW > W || tl.y0 + TH > H || (nt0 + WNW) * 32 > p.Cout_store;       // wave-uniform
+        if constexpr (TPO) {
+#pragma unroll
+          for (int tm = 0; tm < WMW; ++tm) {
+            const int y = tl.y0 + row0 + tm, x = tl.x0 + lm;
+            const bool okp = y < H && x < W;
+            tvo[tm] = okp ? ((y * W + x) * (int)p.out_pix_stride + p.out_ch_off + nt0 * 32 + 4 * kg) * 4 : (int)OOB;
+            tvr[tm] = okp ? ((y * W + x) * (int)p.res_pix_stride + p.res_ch_off + nt0 * 32 + 4 * kg) * 4 : (int)OOB;
+          }
+        }
         pchunk = tl.b * p.stats_nchunk + ((tl.y0 / TH) * tiles_x + tl.x0 / TW) * (4 / NSPLIT) + cw / NSPLIT;
         have_prev = DEFER;
-        if constexpr (!DEFER)
-          [&]<int... Vs>(std::integer_sequence<int, Vs...>) { (epi_value(std::integral_constant<int, Vs>{}), ...); }(std::make_integer_sequence<int, NV>{});
+        if constexpr (!DEFER) {
+          if constexpr (TPO) [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (tpo_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
+          else [&]<int... Vs>(std::integer_sequence<int, Vs...>) { (epi_value(std::integral_constant<int, Vs>{}), ...); }(std::make_integer_sequence<int, NV>{});
+        }
         phase(ph_epi);
       }
       lds_barrier();
       phase(ph_bar);
     }
     if (have_prev) {                            // the last tile's results
-      [&]<int... Vs>(std::integer_sequence<int, Vs...>) { (epi_value(std::integral_constant<int, Vs>{}), ...); }(std::make_integer_sequence<int, NV>{});
+      if constexpr (TPO) [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (tpo_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
+      else [&]<int... Vs>(std::integer_sequence<int, Vs...>) { (epi_value(std::integral_constant<int, Vs>{}), ...); }(std::make_integer_sequence<int, NV>{});
     }
     if constexpr (DBG & 32) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -472,21 +554,32 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
   }
 }
 
-template <int NCH, int WN, int TH, bool M16, int DBG = 0>
+template <int NCH, int WN, int TH, bool M16, int DBG = 0, bool TPO = false>
 int launch_rs(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B;
   constexpr size_t lds = RsGeom<NCH, TH, M16>::LDS_BYTES;
-  static bool once = hipFuncSetAttribute((const void*)conv3x3_rs_kernel<NCH, WN, TH, M16, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  static bool once = hipFuncSetAttribute((const void*)conv3x3_rs_kernel<NCH, WN, TH, M16, DBG, TPO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_rs: cannot raise the dynamic LDS limit to %zu", lds);
   int gx = 256;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, WN, TH, M16, DBG>), dim3(gx), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, WN, TH, M16, DBG, TPO>), dim3(gx), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles);
   return egne::check_launch("egne_conv3x3_rs_f16_fwd");
 }
 
 template <bool M16>
-int dispatch_rs(const egne_conv_desc& d, const _Float16* h, const _Float16* l, float a_scale, float os, hipStream_t st, int dbg) {
+int dispatch_rs(const egne_conv_desc& d, const _Float16* h, const _Float16* l, float a_scale, float os, hipStream_t st, int dbg, bool tpo) {
+  if constexpr (!M16) {
+    if (tpo) {                  // transposed product, 16-byte stores: shapes with one output tile per consumer wave
+      if (d.Ktot == 32 && d.CoutP == 32) return launch_rs<1, 1, 8, false, 0, true>(d, h, l, a_scale, os, st);
+      if (d.Ktot == 64 && d.CoutP == 32) return launch_rs<2, 1, 4, false, 0, true>(d, h, l, a_scale, os, st);
+      if (d.Ktot == 64 && d.CoutP == 64) {
+        if (dbg == 32) return launch_rs<2, 2, 4, false, 32, true>(d, h, l, a_scale, os, st);
+        if (dbg == 33) return launch_rs<2, 2, 4, false, 33, true>(d, h, l, a_scale, os, st);
+        return launch_rs<2, 2, 4, false, 0, true>(d, h, l, a_scale, os, st);
+      }
+    }
+  }
   if (d.Ktot == 32) {
     if (d.CoutP == 32) return launch_rs<1, 1, 8, M16>(d, h, l, a_scale, os, st);
     if (d.CoutP == 64) return launch_rs<1, 2, 8, false>(d, h, l, a_scale, os, st);      // 16x16x32 build of this shape spills
@@ -497,12 +590,7 @@ int dispatch_rs(const egne_conv_desc& d, const _Float16* h, const _Float16* l, f
     switch (dbg) {
       case 32: return launch_rs<2, 2, 4, M16, 32>(d, h, l, a_scale, os, st);
       case 33: return launch_rs<2, 2, 4, M16, 33>(d, h, l, a_scale, os, st);
-      case 34: return launch_rs<2, 2, 4, M16, 34>(d, h, l, a_scale, os, st);
-      case 36: return launch_rs<2, 2, 4, M16, 36>(d, h, l, a_scale, os, st);
-      case 52: return launch_rs<2, 2, 4, M16, 52>(d, h, l, a_scale, os, st);
-      case 55: return launch_rs<2, 2, 4, M16, 55>(d, h, l, a_scale, os, st);
       case 40: return launch_rs<2, 2, 4, M16, 40>(d, h, l, a_scale, os, st);
-      case 41: return launch_rs<2, 2, 4, M16, 41>(d, h, l, a_scale, os, st);
       default: return launch_rs<2, 2, 4, M16>(d, h, l, a_scale, os, st);
     }
   }
@@ -541,7 +629,13 @@ extern "C" int egne_conv3x3_rs_f16_fwd(const egne_conv_desc* dp, const void* fhi
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *h = (const _Float16*)fhi, *l = (const _Float16*)flo;
-  return m16 ? dispatch_rs<true>(d, h, l, a_scale, os, st, dbg) : dispatch_rs<false>(d, h, l, a_scale, os, st, dbg);
+  static const bool tpo_on = !(getenv("EGNE_RS_TPO") && atoi(getenv("EGNE_RS_TPO")) == 0);
+  const bool tpo = tpo_on && !m16 && (!d.stats_ws || (dbg & 32)) && d.Cout_store == d.CoutP && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
+                   ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
+                   (!d.residual || (((uintptr_t)d.residual & 15) == 0 && d.res_pix_stride % 4 == 0 && d.res_ch_off % 4 == 0)) &&
+                   (!d.pool_out || (((uintptr_t)d.pool_out & 15) == 0 && d.pool_pix_stride % 4 == 0 && d.pool_ch_off % 4 == 0)) &&
+                   (!d.post_scale || (((uintptr_t)d.post_scale & 15) == 0 && ((uintptr_t)d.post_shift & 15) == 0));
+  return m16 ? dispatch_rs<true>(d, h, l, a_scale, os, st, dbg, false) : dispatch_rs<false>(d, h, l, a_scale, os, st, dbg, tpo);
 }
 
 extern "C" int egne_rs_debug_prio(int on) {
