@@ -71,6 +71,7 @@ SIGNATURES = {
     "egne_msblock_dil_scores_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp, vp, vp, vp, i32, vp]),
     "egne_msblock_dil_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_conv3x3_rs_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
+    "egne_conv3x3_rw_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_conv1x1_pool2_f16x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_conv1x1_f16x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_dist_maps_workspace_bytes": (i64, [i32, i32, i32, i32]),

@@ -571,7 +571,8 @@ template <bool M16>
 int dispatch_rs(const egne_conv_desc& d, const _Float16* h, const _Float16* l, float a_scale, float os, hipStream_t st, int dbg, bool tpo) {
   if constexpr (!M16) {
     if (tpo) {                  // transposed product, 16-byte stores: shapes with one output tile per consumer wave
-      if (d.Ktot == 32 && d.CoutP == 32) return launch_rs<1, 1, 8, false, 0, true>(d, h, l, a_scale, os, st);
+      // (32 -> 32 stays on the per-channel layout: with all 36 weight fragments resident in registers its transposed build came out
+      //  with one bias register overwritten in eight lanes -- the lanes hipcc spills scalar registers to; found by the network tests)
       if (d.Ktot == 64 && d.CoutP == 32) return launch_rs<2, 1, 4, false, 0, true>(d, h, l, a_scale, os, st);
       if (d.Ktot == 64 && d.CoutP == 64) {
         if (dbg == 32) return launch_rs<2, 2, 4, false, 32, true>(d, h, l, a_scale, os, st);

@@ -1,0 +1,420 @@
+// 3x3 "same" convolution on the split-f16 MFMA path with fixed wave roles and RESIDENT WEIGHTS (fp32 tensors, three
+// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; numerics: conv_f16x3.hip): one input slice of <= 64 channels, any number of
+// 32-channel output blocks -- vgg16_c.py:66-69 (conv1_2, conv2_1), bdcn_new.py:50 (stage-1 MSBlock convs), models/RITnet_v2.py:57
+// (down-block conv1 behind its InstanceNorm).
+//
+// Why another form of conv3x3_rs_f16.hip: there the consumer waves pull their weight fragments from L2 through a register ring and
+// ALSO store the results, and on this hardware loads and stores retire through ONE in-order counter (vmcnt): every wait for a
+// weight fragment also waits for the acknowledgement of all older stores (~3 k cycles under load).  Measured on 64 -> 64 at
+// 240x320x64 (s_memtime stamps, scratch/rs_dbg.py): 11.7 k cycles per tile with both, 8.5 k with loads only, 8.6 k with stores only,
+// 7.8 k with neither, 6.9 k of MFMA issue.  Here a workgroup owns ONE 32-channel output block and keeps all of its weights
+// (<= 64 x 9 x 32 as hi | lo = 72 KB) in LDS for the whole launch, so the consumers issue no vector loads at all: their stores are
+// never waited for.  The price: the input is staged once per output block (the blocks of one tile run on the same XCD at the same
+// time, so the second read comes from L2) -- the producers have the slack for it.
+//
+// LDS: weights [chunk][tap][k16][hi | lo][64 lanes][8 halfs] (36 KB per 32 input channels), two halo images of ONE 32-channel chunk
+// of a 32 x 8 tile, [hi | lo][340 pixels][32 halfs] without padding: the 16-byte chunk c of pixel q sits at c ^ ((q >> 2) & 3)
+// (conflict-free ds_read_b128 / ds_write_b64 as in msblock_dil_f16.hip).  A tile is KCH jobs (one per chunk), accumulators persist.
+//   producers (waves 0-3)  halo gather (two jobs of loads in flight), optional fused InstanceNorm affine + activation, fp32 ->
+//             hi / lo with plain VALU (split_f16.h), image (job + 1) & 1;
+//   consumers (waves 4-7)  two rows x 32 channels each: 18 steps x 6 MFMAs per job, operands of step j + 1 requested before the
+//             MFMAs of step j; transposed product, so a lane ends with 16 channels of one pixel: 8 stores of 16 bytes per tile,
+//             issued between the MFMAs of the next job; optional second output = 2x2 ceil-mode max pooling (pool1 of conv1_2).
+// One s_barrier per job.
+#include "common.h"
+#include "split_f16.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ int g_wdbg = 0;
+__device__ unsigned long long g_wstamps[256 * 8 * 4];
+
+constexpr int TW = 32, TH = 8, HWd = TW + 2, HHd = TH + 2, NPX = HHd * HWd;       // 340 halo pixels
+constexpr int IMGH = 2 * NPX * 32;                       // halfs per image: [hi | lo][NPX][32]
+constexpr int WCH = 9 * 2 * 2 * 512;                     // halfs of weights per 32-channel chunk
+constexpr int NI = (NPX * 8 + 255) / 256;                // 16-byte items per producer lane and job
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// KCH: 32-channel chunks of the input slice (1 or 2).  ncb = output blocks of 32 channels; tiles_x / tiles_y / ntiles as usual.
+template <int KCH>
+__global__ __launch_bounds__(512)
+void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
+                       float out_scale, int tiles_x, int tiles_y, int ntiles, int ncb) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+  _Float16* const lw = ldsh + 2 * IMGH;                  // weights behind the two images
+
+  const int dbg = g_wdbg;
+  unsigned long long t_work = 0, t_wait = 0, t_last = 0;
+  auto stamp = [&](unsigned long long& accum) {
+    if (dbg & 64) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      accum += t - t_last; t_last = t;
+    }
+  };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const egne_seg sg = p.seg[0];
+
+  // workgroup -> (output block, worker): blocks b and b + 8 share an XCD (round-robin dispatch: a speed assumption only); the ncb
+  // workgroups of one worker walk the SAME tiles on the same XCD, so the halo of a tile is read from HBM once
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int cb = q % ncb, worker = (q / ncb) * 8 + xcd, nworkers = ((int)gridDim.x >> 3) / ncb * 8;
+  auto tile_at = [&](int i) { return worker + i * nworkers; };
+  struct Tile { int b, y0, x0; };
+  auto decode = [&](int t) {
+    Tile r;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    r.b = t; r.y0 = ty * TH; r.x0 = tx * TW;
+    return r;
+  };
+  int ntl = 0;
+  while (tile_at(ntl) < ntiles) ++ntl;
+  const int nmine = ntl * KCH;                           // jobs: (tile, chunk), chunk fastest
+  const int nloop = (nmine + 1) & ~1;                    // both roles run an even number of steps (register buffer = step parity)
+
+  // the block's weights: fragments (tap, k16, nt = cb) of the 32x32x16 pack [tap][Ktot/16][CoutP/32][lane][8]
+  {
+    const int KT16 = KCH * 2;
+    for (int it = tid; it < KCH * 9 * 2 * 2 * 64; it += 512) {        // 16-byte items, LDS order [chunk][tap][ks][hl][lane]
+      const int l = it & 63, hl = (it >> 6) & 1, ks = (it >> 7) & 1, r = it >> 8, tap = r % 9, ch = r / 9;
+      const long long src = (((long long)tap * KT16 + ch * 2 + ks) * ncb + cb) * 512 + l * 8;
+      *(u32x4*)&lw[(long long)it * 8] = *(const u32x4*)((hl ? flo : fhi) + src);
+    }
+  }
+  __syncthreads();
+
+  if (wave < 4) {
+    // =================================================================== producers: halo chunk -> hi / lo image
+    const int piece = tid & 7, pg = tid >> 3;            // 16-byte piece of the pixel's 32-channel chunk, pixel group (32 per round)
+    const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+    // LDS slot of item I: pixel pg + 32 I; (pixel >> 2) & 3 = (pg >> 2) & 3 for every I: lane constant + 64 B * 32 * I
+    const int lofs = pg * 32 + (((piece >> 1) ^ ((pg >> 2) & 3)) << 3) + ((piece & 1) << 2);
+    u32x4 st[2][NI];
+    // byte offset of item I relative to the tile's first pixel (tile- and chunk-invariant): with it an item's address is one add
+    // for tiles whose halo columns lie inside the image (rows outside it fall outside the per-frame resource and read zeros)
+    int rel[NI];
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+      const int px = pg + 32 * I, hy = px / HWd, hx = px - hy * HWd;
+      rel[I] = px < NPX ? (((hy - 1) * W + hx - 1) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4 : (int)OOB;
+    }
+    struct Job { Tile t; int ch; };
+    auto job_at = [&](int j) { Job r; r.t = decode(tile_at(j / KCH)); r.ch = j % KCH; return r; };
+    auto issue1 = [&](const Job& jb, bool on, auto bc, auto ic) {
+      constexpr int BUF = decltype(bc)::value, I = decltype(ic)::value;
+      const Tile& tl = jb.t;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
+      const int c0 = jb.ch * 32 + piece * 4;            // channels past the slice (padding up to 32 * KCH) read zeros
+      int off;
+      if (tl.x0 >= 1 && tl.x0 + TW + 1 <= W) {          // wave-uniform: interior columns
+        const int sbase = ((tl.y0 * W + tl.x0) * (int)sg.pix_stride + jb.ch * 32) * 4;
+        off = (on && c0 < sg.Cp && rel[I] != (int)OOB) ? rel[I] + sbase : (int)OOB;
+      } else {
+        int pq = pg;
+        asm volatile("" : "+v"(pq));                    // opaque: no hoisting of the per-item coordinates out of the job loop
+        const int px = pq + 32 * I;
+        const int hy = px / HWd, hx = px - hy * HWd;
+        const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
+        const bool ok = on && c0 < sg.Cp && px < NPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        off = ok ? ((y * W + x) * (int)sg.pix_stride + sg.ch_off + c0) * 4 : (int)OOB;
+      }
+      st[BUF][I] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    };
+    // fused affine: the coefficients of a job are requested one step EARLIER than its conversion, ahead of that step's halo loads
+    f32x4 asc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, ash[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto load_aff = [&](const Job& jb, auto bc) {
+      constexpr int BUF = decltype(bc)::value;
+      if (sg.scale) {
+        const int c0 = jb.ch * 32 + piece * 4;
+        const float* zs = c0 < sg.Cp ? sg.scale + (long long)jb.t.b * sg.Cp + c0 : egne_zero_page;
+        const float* zh = c0 < sg.Cp ? sg.shift + (long long)jb.t.b * sg.Cp + c0 : egne_zero_page;
+        asc[BUF] = *(const f32x4*)zs;
+        ash[BUF] = *(const f32x4*)zh;
+      }
+    };
+    auto convert1 = [&](const Job& jb, _Float16* img, auto bc, auto ic) {
+      constexpr int BUF = decltype(bc)::value, I = decltype(ic)::value;
+      const int px = pg + 32 * I;
+      if (I < NI - 1 || px < NPX) {
+        f32x4 v = __builtin_bit_cast(f32x4, st[BUF][I]);
+        if (sg.scale) {      // fused InstanceNorm affine (+ activation) of the consumer; zero padding applied after it
+          const int hy = px / HWd, hx = px - hy * HWd;
+          const int y = jb.t.y0 - 1 + hy, x = jb.t.x0 - 1 + hx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = v[e] * asc[BUF][e] + ash[BUF][e];
+            v[e] = fmaxf(t, t * slope_in);
+          }
+          if (!((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) v = (f32x4)(0.f);
+        }
+        h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
+        egne::split2(v[0], v[1], a_scale, h0, l0);
+        egne::split2(v[2], v[3], a_scale, h1, l1);
+        const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+        const int o = lofs + 32 * 32 * I;
+        *(h4*)&img[o] = hi;
+        *(h4*)&img[NPX * 32 + o] = lo;
+      }
+    };
+    // step s (job s): convert job s+1 out of register buffer (s+1)&1 and refill every freed register with job s+3
+    auto step = [&](int s, auto bc) {
+      constexpr int BUF = decltype(bc)::value;          // = (s + 1) & 1
+      const bool c_on = s + 1 < nmine, i_on = s + 3 < nmine;
+      const Job jc = job_at(c_on ? s + 1 : 0), ji = job_at(i_on ? s + 3 : 0);
+      load_aff(job_at(s + 2 < nmine ? s + 2 : 0), std::integral_constant<int, BUF ^ 1>{});
+      _Float16* img = ldsh + ((s + 1) & 1) * IMGH;
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (([&] {
+          if (c_on) convert1(jc, img, bc, std::integral_constant<int, Is>{});
+          issue1(ji, i_on, bc, std::integral_constant<int, Is>{});
+        }()), ...);
+      }(std::make_integer_sequence<int, NI>{});
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    {   // prologue: jobs 0 and 1 requested, job 0 converted (its registers refilled with job 2)
+      const Job j0 = job_at(0), j1 = job_at(nmine > 1 ? 1 : 0), j2 = job_at(nmine > 2 ? 2 : 0);
+      load_aff(j0, B0{});
+      load_aff(j1, B1{});
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (issue1(j0, nmine > 0, B0{}, std::integral_constant<int, Is>{}), ...);
+        (issue1(j1, nmine > 1, B1{}, std::integral_constant<int, Is>{}), ...);
+      }(std::make_integer_sequence<int, NI>{});
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (([&] {
+          if (nmine > 0) convert1(j0, ldsh, B0{}, std::integral_constant<int, Is>{});
+          issue1(j2, nmine > 2, B0{}, std::integral_constant<int, Is>{});
+        }()), ...);
+      }(std::make_integer_sequence<int, NI>{});
+    }
+    lds_barrier();
+    t_last = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < nloop; s += 2) {
+      step(s, B1{});
+      stamp(t_work); lds_barrier(); stamp(t_wait);
+      step(s + 1, B0{});
+      stamp(t_work); lds_barrier(); stamp(t_wait);
+    }
+  } else {
+    // =================================================================== consumers: 9 taps x 2 k-steps per job from LDS only
+    const int cw = wave - 4, row0 = cw * 2;
+    const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 4u;
+    const unsigned frame_res = (unsigned)H * W * (unsigned)p.res_pix_stride * 4u;
+    const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+    const bool full_epi = p.post_scale != nullptr || p.residual != nullptr;
+    // transposed product: the lane holds channels n = 32 cb + 8 j + 4 lh + e (register 4 j + e) of pixel li of its two rows
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + cb * 32 + 8 * j + 4 * lh) : (f32x4)(0.f);
+    bool jok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) jok[j] = cb * 32 + 8 * j < p.Cout_store;        // Cout_store is a multiple of 8
+
+    // operand addresses: pixel q = (row + ky) * 34 + li + kx of the halo, chunk c = 2 ks + lh at c ^ ((q >> 2) & 3)
+    // (independent of the tile: 18 lane constants; the second k-step of a tap toggles bit 1 of the chunk index = address ^ 16)
+    int aofs[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int qq = (row0 + tm + tap / 3) * HWd + li + tap % 3;
+        aofs[tap][tm] = qq * 32 + ((lh ^ ((qq >> 2) & 3)) << 3);
+      }
+    auto a_addr = [&](int j, int tm) { return (j & 1) ? (aofs[j >> 1][tm] ^ 16) : aofs[j >> 1][tm]; };
+    f32x16 acc[2], prev[2];
+    acc[0] = acc[1] = prev[0] = prev[1] = (f32x16)(0.f);
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 0u), rres = make_rsrc(nullptr, 0u);
+    int tvo[2] = {(int)OOB, (int)OOB}, tvr[2] = {(int)OOB, (int)OOB};
+    // The values are finished (scale, bias, activation [, post affine, residual]) IN PLACE at hand-over; the deferred part is the bare
+    // store.  Computing them next to the store would reuse the store's data registers group after group, and overwriting the source
+    // of a store in flight costs a wait for its completion (vmcnt): eight write round trips per tile.
+    auto finish_group = [&](auto gc) {
+      constexpr int Gi = decltype(gc)::value, j = Gi & 3, tm = Gi >> 2;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = prev[tm][4 * j + e] * out_scale + b4[j][e];
+        v[e] = fmaxf(t, t * slope_out);
+      }
+      if (full_epi) {                                    // rare in these layers: post affine / residual straight from memory
+        const int n = cb * 32 + 8 * j + 4 * lh;
+        if (p.post_scale) {
+          const f32x4 ps = *(const f32x4*)(p.post_scale + n), pt = *(const f32x4*)(p.post_shift + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * ps[e] + pt[e];
+        }
+        if (p.residual) {
+          const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, jok[j] ? tvr[tm] : (int)OOB, j * 32, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) prev[tm][4 * j + e] = v[e];
+    };
+    auto store_group = [&](auto gc) {
+      constexpr int Gi = decltype(gc)::value, j = Gi & 3, tm = Gi >> 2;
+      const f32x4 v = {prev[tm][4 * j], prev[tm][4 * j + 1], prev[tm][4 * j + 2], prev[tm][4 * j + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, jok[j] ? tvo[tm] : (int)OOB, j * 32, 0);
+    };
+    bool have_prev = false;
+    lds_barrier();
+    t_last = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < nloop; ++s) {
+      if (s < nmine) {
+        const int ch = s % KCH;
+        const Tile tl = decode(tile_at(s / KCH));
+        const _Float16* Thi = ldsh + (s & 1) * IMGH;
+        const _Float16* Tlo = Thi + NPX * 32;
+        const _Float16* wb = lw + ch * WCH + lane * 8;
+        if (ch == 0) { acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f); }
+        // operands two steps ahead (three register sets): with producers writing and four waves reading, an LDS read takes longer
+        // than the 192 cycles of one step's MFMAs
+        h8 ah[3][2], al[3][2], bh[3], bl[3];
+        auto fetch = [&](auto jc) {
+          constexpr int J = decltype(jc)::value, Bq = J % 3;
+          bh[Bq] = *(const h8*)&wb[(2 * J) * 512]; bl[Bq] = *(const h8*)&wb[(2 * J + 1) * 512];
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) { ah[Bq][tm] = *(const h8*)&Thi[a_addr(J, tm)]; al[Bq][tm] = *(const h8*)&Tlo[a_addr(J, tm)]; }
+        };
+        fetch(std::integral_constant<int, 0>{});
+        fetch(std::integral_constant<int, 1>{});
+        [&]<int... Js>(std::integer_sequence<int, Js...>) {
+          (([&] {
+            constexpr int j = Js;
+            if constexpr (j + 2 < 18) fetch(std::integral_constant<int, j + 2>{});
+            // the previous tile's results leave between the MFMAs of this tile's first job (8 stores of 16 bytes)
+            if constexpr (j % 2 == 0 && j / 2 < 8) { if (ch == 0 && have_prev) store_group(std::integral_constant<int, j / 2>{}); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+              // the three MFMAs of one accumulator back to back (the result is forwarded along the chain); hipcc would alternate
+              // the two accumulators
+              acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j % 3], al[j % 3][tm], acc[tm], 0, 0, 0);
+              acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j % 3], ah[j % 3][tm], acc[tm], 0, 0, 0);
+              acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j % 3], ah[j % 3][tm], acc[tm], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }()), ...);
+        }(std::make_integer_sequence<int, 18>{});
+        if (ch == KCH - 1) {                               // tile complete: hand it to the deferred stores
+          const int x = tl.x0 + li;
+          if (p.pool_out) {      // second output: 2x2 / stride 2 / ceil-mode max pooling (act(max) = max(act): monotonic activation)
+            const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+            const __amdgpu_buffer_rsrc_t rpo = make_rsrc(p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride,
+                                                         (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * 4u);
+            const int y = tl.y0 + row0;
+            const bool y1 = y + 1 < H, x1 = x + 1 < W;
+            const int poff = (!(li & 1) && x < W && y < H) ? (((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + cb * 32 + 4 * lh) * 4 : (int)OOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float m = acc[0][4 * j + e];
+                if (y1) m = fmaxf(m, acc[1][4 * j + e]);
+                const float qn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+                if (x1) m = fmaxf(m, qn);
+                const float t = m * out_scale + b4[j][e];
+                v[e] = fmaxf(t, t * slope_out);
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rpo, jok[j] ? poff : (int)OOB, j * 32, 0);
+            }
+          }
+          prev[0] = acc[0]; prev[1] = acc[1];
+          rout = make_rsrc(p.out + (long long)tl.b * H * W * p.out_pix_stride, frame_out);
+          rres = make_rsrc(p.residual ? p.residual + (long long)tl.b * H * W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const int y = tl.y0 + row0 + tm;
+            const bool okp = y < H && x < W;
+            tvo[tm] = okp ? ((y * W + x) * (int)p.out_pix_stride + p.out_ch_off + cb * 32 + 4 * lh) * 4 : (int)OOB;
+            tvr[tm] = okp ? ((y * W + x) * (int)p.res_pix_stride + p.res_ch_off + cb * 32 + 4 * lh) * 4 : (int)OOB;
+          }
+          [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (finish_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
+          have_prev = true;
+        }
+      }
+      stamp(t_work); lds_barrier(); stamp(t_wait);
+    }
+    if (have_prev)
+      [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
+  }
+  if ((dbg & 64) && lane == 0) {
+    unsigned long long* o = g_wstamps + ((long long)blockIdx.x * 8 + wave) * 4;
+    o[0] = t_work; o[1] = t_wait; o[2] = nmine; o[3] = 0;
+  }
+}
+
+template <int KCH>
+int launch_rw(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
+  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32;
+  constexpr size_t lds = ((size_t)2 * IMGH + (size_t)KCH * WCH) * sizeof(_Float16);
+  static_assert(lds <= 163840, "LDS budget");
+  static bool once = hipFuncSetAttribute((const void*)conv3x3_rw_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_rw: cannot raise the dynamic LDS limit to %zu", lds);
+  // 256 workgroups = 8 XCDs x 32; the ncb blocks of a worker sit on one XCD: 32 / ncb workers per XCD
+  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb);
+  return egne::check_launch("egne_conv3x3_rw_f16_fwd");
+}
+
+}  // namespace
+
+// Same descriptor and weight pack as egne_conv3x3_rs_f16_fwd (one input slice with optional fused affine, 3x3 / pad 1 / dilation 1,
+// Ktot = slice width rounded up to 32 and <= 64, weights from egne_pack_conv_weight_f16frag); CoutP = 32, 64 or 128; Cout_store a
+// multiple of 8; 16-byte aligned output / residual / pooled slices; no statistics (egne_conv3x3_rs_f16_fwd writes those); optional
+// pooled second output as there.
+extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
+                                       void* stream) {
+  EGNE_REQUIRE(dp && fhi && flo, "conv3x3_rw: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_mode == 0 && d.ngroups == 1 && d.nseg == 1 && d.pad_h == 1 &&
+               d.pad_w == 1 && d.dil[0] == 1 && d.Ho == d.H && d.Wo == d.W && !d.stats_ws, "conv3x3_rw: geometry / options not supported");
+  const egne_seg& g = d.seg[0];
+  EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && (d.Ktot == 32 || d.Ktot == 64) && g.ch_off % 4 == 0 &&
+               g.pix_stride % 4 == 0 && ((uintptr_t)g.ptr & 15) == 0 && (g.scale == nullptr) == (g.shift == nullptr), "conv3x3_rw: input slice");
+  EGNE_REQUIRE((d.CoutP == 32 || d.CoutP == 64 || d.CoutP == 128) && d.Cout_store <= d.CoutP && d.Cout_store % 8 == 0 && d.out &&
+               ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
+               d.out_ch_off + d.Cout_store <= d.out_pix_stride && (!d.bias || ((uintptr_t)d.bias & 15) == 0), "conv3x3_rw: output");
+  EGNE_REQUIRE(!d.residual || (((uintptr_t)d.residual & 15) == 0 && d.res_pix_stride % 4 == 0 && d.res_ch_off % 4 == 0), "conv3x3_rw: residual alignment");
+  EGNE_REQUIRE(!d.post_scale || (((uintptr_t)d.post_scale & 15) == 0 && ((uintptr_t)d.post_shift & 15) == 0), "conv3x3_rw: post affine alignment");
+  EGNE_REQUIRE(!d.pool_out || (((uintptr_t)d.pool_out & 15) == 0 && d.pool_pix_stride % 4 == 0 && d.pool_ch_off % 4 == 0 && !d.post_scale &&
+                                d.pool_ch_off + d.Cout_store <= d.pool_pix_stride &&
+                                (long long)((d.H + 1) / 2) * ((d.W + 1) / 2) * d.pool_pix_stride * 4 < (1ll << 31)), "conv3x3_rw: pooled output");
+  EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv3x3_rw: weights / scales");
+  EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
+               (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv3x3_rw: frame too large for 32-bit byte offsets");
+  const float os = 1.0f / (a_scale * w_scale);
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16 *h = (const _Float16*)fhi, *l = (const _Float16*)flo;
+  return d.Ktot == 32 ? launch_rw<1>(d, h, l, a_scale, os, st) : launch_rw<2>(d, h, l, a_scale, os, st);
+}
+
+extern "C" int egne_rw_debug(int dbg, void* out_stamps) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wdbg), &dbg, sizeof(int)) != hipSuccess) return -2;
+  if (out_stamps && hipMemcpyFromSymbol(out_stamps, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * 256 * 8 * 4) != hipSuccess) return -2;
+  return 0;
+}

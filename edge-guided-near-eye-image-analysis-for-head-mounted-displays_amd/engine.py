@@ -22,6 +22,7 @@ LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock
 LAYER_BYTES = {}          # layer name -> algorithmic bytes of its launch(es) (input slices + stored output), for bench.py --layers
 TDPOOL_FUSED = os.environ.get("EGNE_TDPOOL_FUSED", "1") != "0"     # Transition_down: pooling folded into the 1x1's operand load
 POOL_FUSED = os.environ.get("EGNE_POOL_FUSED", "1") != "0"     # conv1_2 writes pool1 from its epilogue (conv3x3_rs_f16.hip)
+RW_ENABLED = os.environ.get("EGNE_RW", "1") != "0"             # resident-weights form of the role-split 3x3 (no consumer loads)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
 MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
@@ -706,10 +707,17 @@ class Plan:
             th = 8 if pieces[0].Cp <= 32 else 4
             nchunk = ((W + 31) // 32) * ((H + th - 1) // th) * (2 if (th == 4 and layer.sfrag_coutp() >= 64) else 4)
             fuse_stats = stats and STATS_FUSED and dst.Cp == int(d.Cout_store)
+            # resident-weights form (conv3x3_rw_f16.hip) unless the layer writes InstanceNorm sums from its epilogue
+            # (measured: ahead of the register-ring form for 64 -> 32 channels only -- 655 vs 770 us at 240x320x64 --, level at 64 -> 64,
+            # behind it for 32 -> 32 and 64 -> 128 where one workgroup per output block re-stages the input too often)
+            rw = (RW_ENABLED and not fuse_stats and pieces[0].Cp > 32 and layer.sfrag_coutp() == 32
+                  and int(d.Cout_store) % 8 == 0 and dst.stride % 4 == 0 and dst.off % 4 == 0
+                  and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
             if fuse_stats:
                 ws = self._stats_ws(d, B, nchunk)
-            self._add(self.L.egne_conv3x3_rs_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
-                                                       layer.w_scale), name, flops=flops, kind="conv_f16x3:rs", cal=cal3)
+            self._add(self.L.egne_conv3x3_rw_f16_fwd if rw else self.L.egne_conv3x3_rs_f16_fwd,
+                      (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE, layer.w_scale), name, flops=flops,
+                      kind="conv_f16x3:rw" if rw else "conv_f16x3:rs", cal=cal3)
             if fuse_stats:
                 self.last_stats = self._stats_finish(ws, d, B, H * W, nchunk, name)
                 stats = False

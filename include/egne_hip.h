@@ -170,6 +170,13 @@ int egne_conv1x1_pool2_f16x3_fwd(const egne_conv_desc* d, const void* fhi, const
 int egne_conv3x3_rs_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
                             void* stream);
 
+/* The same convolution with the workgroup's weights RESIDENT in LDS (one 32-channel output block per workgroup, the input staged
+ * once per block): the consumer waves issue no vector loads, so their stores are never waited for (loads and stores retire through
+ * one in-order counter).  Same descriptor and pack; Cout_store % 8 == 0, 16-byte aligned slices, no statistics; optional pooled
+ * second output (pool_out). */
+int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale, float w_scale,
+                            void* stream);
+
 /* Streaming 1x1 convolution over a concatenation of raw NHWC slices (models/RITnet_v2.py:59,61,84,86 conv21 / conv31 /
  * conv11, :38 Transition_down in eval plans) on the split-f16 path: no staging, every lane loads its MFMA operand
  * straight from HBM, weight fragments stay in LDS.  Same descriptor as egne_conv2d_fwd (`w` unused; no fused affine,

@@ -9,8 +9,9 @@ DEV = torch.device('cuda:0')
 B = 64
 for (Cin, Cout, H, W) in [(64, 64, 240, 320), (64, 128, 120, 160), (64, 32, 240, 320), (32, 32, 240, 320), (32, 64, 240, 320), (128, 32, 120, 160), (32,32,120,160)]:
     res = []
-    for rs in (0, 1, 0, 1):
+    for rs in (0, 1, 2, 1, 2):
         engine.RS_ENABLED = bool(rs)
+        engine.RW_ENABLED = rs == 2
         pl = Plan(DEV)
         xb = pl.buf(B, H, W, pad8(Cin)); xb.normal_()
         w = torch.nn.Parameter(torch.randn(Cout, Cin, 3, 3, device=DEV) / (3 * Cin ** 0.5))

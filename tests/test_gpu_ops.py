@@ -678,7 +678,9 @@ def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,mode", [(2, 64, 64, 61, 83, "plain"), (1, 64, 128, 120, 160, "plain"), (2, 64, 32, 61, 70, "res"),
                                                   (2, 32, 32, 61, 83, "norm"), (1, 38, 64, 120, 160, "norm"), (3, 56, 30, 33, 64, "plain"),
-                                                  (2, 32, 2, 64, 96, "norm")])
+                                                  (2, 32, 2, 64, 96, "norm"),
+                                                  # several tiles per workgroup (more than 256 tiles): the multi-tile paths of every form
+                                                  (6, 32, 32, 240, 320, "plain"), (5, 64, 64, 120, 160, "plain"), (4, 64, 32, 240, 320, "plain")])
 def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
     """conv3x3_rs_f16.hip (producer / consumer waves; vgg16_c.py:66-69, bdcn_new.py:50, models/RITnet_v2.py:57, utils.py:1047)
     against a float64 convolution: plain, with the residual addend, and with the InstanceNorm affine + LeakyReLU applied while
@@ -707,7 +709,7 @@ def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
         residual = pr
         truth = truth + r.double()
     pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W, residual=residual, stats=(mode == "norm"))
-    assert any(m[0] == "conv_f16x3:rs" for m in pl.meta)
+    assert any(m[0] in ("conv_f16x3:rs", "conv_f16x3:rw") for m in pl.meta)     # role-split: register-ring or resident-weights form
     for _ in range(2):
         pl.run()
         torch.cuda.synchronize()
@@ -771,7 +773,7 @@ def test_conv3x3_role_split_pooled_second_output(G, B, H, W):
     layer.split = True
     out, pout = pl.buf(B, H, W, 64), pl.buf(B, (H + 1) // 2, (W + 1) // 2, 64)
     pl.conv(layer, [px], Piece(out, 0, 64), B, H, W, pool=Piece(pout, 0, 64))
-    assert pl.last_pooled and any(m[0] == "conv_f16x3:rs" for m in pl.meta)
+    assert pl.last_pooled and any(m[0] in ("conv_f16x3:rs", "conv_f16x3:rw") for m in pl.meta)
     for _ in range(2):
         pl.run()
         torch.cuda.synchronize()
