@@ -350,9 +350,11 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
 #pragma unroll
       for (int tm = 0; tm < WMW; ++tm) { tvo[tm] = (int)OOB; tvr[tm] = (int)OOB; }
     }
-    auto tpo_group = [&](auto gc) {
+    // the values are finished in place at hand-over (tpo_finish); the deferred part is the bare store: computing next to the store
+    // would reuse its data registers group after group, and overwriting the source of a store in flight costs a vmcnt(0)
+    auto tpo_finish = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, j = Gi % 4, tm = (Gi / 4) % WMW, tn = Gi / (4 * WMW);
-      constexpr int choff = (tn * 32 + 8 * j) * 4;       // immediate offset of the run inside the pixel
+      constexpr int choff = (tn * 32 + 8 * j) * 4;
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -361,9 +363,24 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       }
       if (full_epi) {                                    // rare in these layers: post affine / residual straight from memory
         const int n = (nt0 + tn) * 32 + 8 * j + 4 * kg;
-        if (p.post_scale) v = v * *(const f32x4*)(p.post_scale + n) + *(const f32x4*)(p.post_shift + n);
-        if (p.residual) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, tvr[tm], choff, 0));
+        if (p.post_scale) {
+          const f32x4 ps = *(const f32x4*)(p.post_scale + n), pt = *(const f32x4*)(p.post_shift + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * ps[e] + pt[e];
+        }
+        if (p.residual) {
+          const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, tvr[tm], choff, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) prev[tm][0][tn][0][4 * j + e] = v[e];
+    };
+    auto tpo_group = [&](auto gc) {
+      constexpr int Gi = decltype(gc)::value, j = Gi % 4, tm = (Gi / 4) % WMW, tn = Gi / (4 * WMW);
+      constexpr int choff = (tn * 32 + 8 * j) * 4;       // immediate offset of the run inside the pixel
+      const f32x4 v = {prev[tm][0][tn][0][4 * j], prev[tm][0][tn][0][4 * j + 1], prev[tm][0][tn][0][4 * j + 2], prev[tm][0][tn][0][4 * j + 3]};
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, tvo[tm], choff, 0);
     };
     auto tpo_step = [&](auto jc) {            // the groups handed to step j
@@ -530,6 +547,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           }
         }
         pchunk = tl.b * p.stats_nchunk + ((tl.y0 / TH) * tiles_x + tl.x0 / TW) * (4 / NSPLIT) + cw / NSPLIT;
+        if constexpr (TPO) [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (tpo_finish(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
         have_prev = DEFER;
         if constexpr (!DEFER) {
           if constexpr (TPO) [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (tpo_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
