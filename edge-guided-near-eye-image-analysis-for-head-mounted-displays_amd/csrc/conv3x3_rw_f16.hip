@@ -13,19 +13,18 @@
 // time, so the second read comes from L2) -- the producers have the slack for it.
 //
 // LDS: weights [chunk][tap][k16][hi | lo][64 lanes][8 halfs] (36 KB per 32 input channels), two halo images of ONE 32-channel chunk
-// of a 32 x 8 tile, [hi | lo][340 pixels][32 halfs] without padding: the 16-byte chunk c of pixel q sits at c ^ ((q >> 2) & 3)
-// (conflict-free ds_read_b128 / ds_write_b64 as in msblock_dil_f16.hip).  A tile is KCH jobs (one per chunk), accumulators persist.
+// of a 32 x 8 tile, [hi | lo][340 pixels][32 halfs] without padding: the 16-byte chunk c of pixel q sits at c ^ ((q >> 1) & 3)
+// (conflict-free for the 16-pixel x 4-chunk ds_read_b128 pattern of the 16x16x32 MFMA at every alignment, and for ds_write_b64).  A tile is KCH jobs (one per chunk), accumulators persist.
 //   producers (waves 0-3)  halo gather (two jobs of loads in flight), optional fused InstanceNorm affine + activation, fp32 ->
 //             hi / lo with plain VALU (split_f16.h), image (job + 1) & 1;
-//   consumers (waves 4-7)  two rows x 32 channels each: 18 steps x 6 MFMAs per job, operands of step j + 1 requested before the
-//             MFMAs of step j; transposed product, so a lane ends with 16 channels of one pixel: 8 stores of 16 bytes per tile,
+//   consumers (waves 4-7)  two rows x 32 channels each on v_mfma_f32_16x16x32_f16 (eight independent accumulators): 9 taps x 24
+//             MFMAs per job, operands of tap t + 1 requested before the MFMAs of tap t; transposed product, so a lane ends with 16 channels of one pixel: 8 stores of 16 bytes per tile,
 //             issued between the MFMAs of the next job; optional second output = 2x2 ceil-mode max pooling (pool1 of conv1_2).
 // One s_barrier per job.
 #include "common.h"
 #include "split_f16.h"
 #include <type_traits>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -108,8 +107,8 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     // =================================================================== producers: halo chunk -> hi / lo image
     const int piece = tid & 7, pg = tid >> 3;            // 16-byte piece of the pixel's 32-channel chunk, pixel group (32 per round)
     const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
-    // LDS slot of item I: pixel pg + 32 I; (pixel >> 2) & 3 = (pg >> 2) & 3 for every I: lane constant + 64 B * 32 * I
-    const int lofs = pg * 32 + (((piece >> 1) ^ ((pg >> 2) & 3)) << 3) + ((piece & 1) << 2);
+    // LDS slot of item I: pixel pg + 32 I; (pixel >> 1) & 3 = (pg >> 1) & 3 for every I: lane constant + 64 B * 32 * I
+    const int lofs = pg * 32 + (((piece >> 1) ^ ((pg >> 1) & 3)) << 3) + ((piece & 1) << 2);
     u32x4 st[2][NI];
     // byte offset of item I relative to the tile's first pixel (tile- and chunk-invariant): with it an item's address is one add
     // for tiles whose halo columns lie inside the image (rows outside it fall outside the per-frame resource and read zeros)
@@ -217,66 +216,75 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       stamp(t_work); lds_barrier(); stamp(t_wait);
     }
   } else {
-    // =================================================================== consumers: 9 taps x 2 k-steps per job from LDS only
+    // =================================================================== consumers: 9 taps per job from LDS only
+    // v_mfma_f32_16x16x32_f16: one instruction per (16 channels, 16 pixels, 32 input channels of a tap); a wave's two rows x 32
+    // pixels x 32 channels are EIGHT independent accumulators -- with the 32x32x16 form the same work is two dependent chains,
+    // which issued at ~42 cycles per MFMA instead of 32 (and the chip holds a higher clock on this shape).
     const int cw = wave - 4, row0 = cw * 2;
+    const int l15 = lane & 15, kg = lane >> 4;
     const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 4u;
     const unsigned frame_res = (unsigned)H * W * (unsigned)p.res_pix_stride * 4u;
     const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
     const bool full_epi = p.post_scale != nullptr || p.residual != nullptr;
-    // transposed product: the lane holds channels n = 32 cb + 8 j + 4 lh + e (register 4 j + e) of pixel li of its two rows
-    f32x4 b4[4];
+    // transposed product (weights as the A operand): the lane holds channels n = 32 cb + 16 nh + 4 kg + r of pixel 16 ph + l15
+    f32x4 b4[2];
+    bool jok[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + cb * 32 + 8 * j + 4 * lh) : (f32x4)(0.f);
-    bool jok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) jok[j] = cb * 32 + 8 * j < p.Cout_store;        // Cout_store is a multiple of 8
-
-    // operand addresses: pixel q = (row + ky) * 34 + li + kx of the halo, chunk c = 2 ks + lh at c ^ ((q >> 2) & 3)
-    // (independent of the tile: 18 lane constants; the second k-step of a tap toggles bit 1 of the chunk index = address ^ 16)
-    int aofs[9][2];
+    for (int nh = 0; nh < 2; ++nh) {
+      const int n = cb * 32 + nh * 16 + 4 * kg;
+      b4[nh] = p.bias ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
+      jok[nh] = n < p.Cout_store;                        // Cout_store is a multiple of 4
+    }
+    // operand addresses (independent of the tile).  Activations: pixel q = (row + ky) * 34 + 16 ph + l15 + kx, 8-channel group kg at
+    // chunk kg ^ ((q >> 1) & 3); weights: the 32x32x16 fragments hold k-group kg of output channel m at fragment k16 = kg >> 1, lane
+    // position (kg & 1) * 32 + m
+    int aofs[9][2][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const int qq = (row0 + tm + tap / 3) * HWd + li + tap % 3;
-        aofs[tap][tm] = qq * 32 + ((lh ^ ((qq >> 2) & 3)) << 3);
-      }
-    auto a_addr = [&](int j, int tm) { return (j & 1) ? (aofs[j >> 1][tm] ^ 16) : aofs[j >> 1][tm]; };
-    f32x16 acc[2], prev[2];
-    acc[0] = acc[1] = prev[0] = prev[1] = (f32x16)(0.f);
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          const int qq = (row0 + tm + tap / 3) * HWd + ph * 16 + l15 + tap % 3;
+          aofs[tap][tm][ph] = qq * 32 + ((kg ^ ((qq >> 1) & 3)) << 3);
+        }
+    const int wl = (kg >> 1) * 1024 + ((kg & 1) * 32 + l15) * 8;       // + tap * 2048 + hl * 512 + nh * 128 (halfs)
+    f32x4 acc[2][2][2], prev[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { (&acc[0][0][0])[a] = (f32x4)(0.f); (&prev[0][0][0])[a] = (f32x4)(0.f); }
     __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 0u), rres = make_rsrc(nullptr, 0u);
-    int tvo[2] = {(int)OOB, (int)OOB}, tvr[2] = {(int)OOB, (int)OOB};
+    int tvo[2][2], tvr[2][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { (&tvo[0][0])[a] = (int)OOB; (&tvr[0][0])[a] = (int)OOB; }
     // The values are finished (scale, bias, activation [, post affine, residual]) IN PLACE at hand-over; the deferred part is the bare
     // store.  Computing them next to the store would reuse the store's data registers group after group, and overwriting the source
     // of a store in flight costs a wait for its completion (vmcnt): eight write round trips per tile.
     auto finish_group = [&](auto gc) {
-      constexpr int Gi = decltype(gc)::value, j = Gi & 3, tm = Gi >> 2;
+      constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float t = prev[tm][4 * j + e] * out_scale + b4[j][e];
+        const float t = prev[tm][ph][nh][e] * out_scale + b4[nh][e];
         v[e] = fmaxf(t, t * slope_out);
       }
       if (full_epi) {                                    // rare in these layers: post affine / residual straight from memory
-        const int n = cb * 32 + 8 * j + 4 * lh;
+        const int n = cb * 32 + nh * 16 + 4 * kg;
         if (p.post_scale) {
           const f32x4 ps = *(const f32x4*)(p.post_scale + n), pt = *(const f32x4*)(p.post_shift + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] * ps[e] + pt[e];
         }
         if (p.residual) {
-          const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, jok[j] ? tvr[tm] : (int)OOB, j * 32, 0));
+          const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, jok[nh] ? tvr[tm][ph] : (int)OOB, nh * 64, 0));
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += rv[e];
         }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) prev[tm][4 * j + e] = v[e];
+      prev[tm][ph][nh] = v;
     };
     auto store_group = [&](auto gc) {
-      constexpr int Gi = decltype(gc)::value, j = Gi & 3, tm = Gi >> 2;
-      const f32x4 v = {prev[tm][4 * j], prev[tm][4 * j + 1], prev[tm][4 * j + 2], prev[tm][4 * j + 3]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, jok[j] ? tvo[tm] : (int)OOB, j * 32, 0);
+      constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, prev[tm][ph][nh]), rout, jok[nh] ? tvo[tm][ph] : (int)OOB, nh * 64, 0);
     };
     bool have_prev = false;
     lds_barrier();
@@ -287,72 +295,91 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         const Tile tl = decode(tile_at(s / KCH));
         const _Float16* Thi = ldsh + (s & 1) * IMGH;
         const _Float16* Tlo = Thi + NPX * 32;
-        const _Float16* wb = lw + ch * WCH + lane * 8;
-        if (ch == 0) { acc[0] = (f32x16)(0.f); acc[1] = (f32x16)(0.f); }
-        // operands two steps ahead (three register sets): with producers writing and four waves reading, an LDS read takes longer
-        // than the 192 cycles of one step's MFMAs
-        h8 ah[3][2], al[3][2], bh[3], bl[3];
-        auto fetch = [&](auto jc) {
-          constexpr int J = decltype(jc)::value, Bq = J % 3;
-          bh[Bq] = *(const h8*)&wb[(2 * J) * 512]; bl[Bq] = *(const h8*)&wb[(2 * J + 1) * 512];
+        const _Float16* wb = lw + ch * WCH + wl;
+        if (ch == 0) {
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm) { ah[Bq][tm] = *(const h8*)&Thi[a_addr(J, tm)]; al[Bq][tm] = *(const h8*)&Tlo[a_addr(J, tm)]; }
+          for (int a = 0; a < 8; ++a) (&acc[0][0][0])[a] = (f32x4)(0.f);
+        }
+        // operands of tap t + 1 are requested before the MFMAs of tap t (two register sets)
+        h8 wh[2][2], wo[2][2], ah[2][2][2], al[2][2][2];
+        auto fetch = [&](auto tc) {
+          constexpr int T = decltype(tc)::value, Bq = T & 1;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            wh[Bq][nh] = *(const h8*)&wb[T * 2048 + nh * 128];
+            wo[Bq][nh] = *(const h8*)&wb[T * 2048 + 512 + nh * 128];
+          }
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+              ah[Bq][tm][ph] = *(const h8*)&Thi[aofs[T][tm][ph]];
+              al[Bq][tm][ph] = *(const h8*)&Tlo[aofs[T][tm][ph]];
+            }
         };
         fetch(std::integral_constant<int, 0>{});
-        fetch(std::integral_constant<int, 1>{});
-        [&]<int... Js>(std::integer_sequence<int, Js...>) {
+        [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
           (([&] {
-            constexpr int j = Js;
-            if constexpr (j + 2 < 18) fetch(std::integral_constant<int, j + 2>{});
+            constexpr int t = Ts, Bq = t & 1;
+            if constexpr (t + 1 < 9) fetch(std::integral_constant<int, t + 1>{});
             // the previous tile's results leave between the MFMAs of this tile's first job (8 stores of 16 bytes)
-            if constexpr (j % 2 == 0 && j / 2 < 8) { if (ch == 0 && have_prev) store_group(std::integral_constant<int, j / 2>{}); }
+            if constexpr (t < 8) { if (ch == 0 && have_prev) store_group(std::integral_constant<int, t>{}); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-              // the three MFMAs of one accumulator back to back (the result is forwarded along the chain); hipcc would alternate
-              // the two accumulators
-              acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j % 3], al[j % 3][tm], acc[tm], 0, 0, 0);
-              acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j % 3], ah[j % 3][tm], acc[tm], 0, 0, 0);
-              acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j % 3], ah[j % 3][tm], acc[tm], 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+              for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                  f32x4& c = acc[tm][ph][nh];
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[Bq][nh], al[Bq][tm][ph], c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[Bq][nh], ah[Bq][tm][ph], c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[Bq][nh], ah[Bq][tm][ph], c, 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
           }()), ...);
-        }(std::make_integer_sequence<int, 18>{});
+        }(std::make_integer_sequence<int, 9>{});
         if (ch == KCH - 1) {                               // tile complete: hand it to the deferred stores
-          const int x = tl.x0 + li;
+          const int y = tl.y0 + row0;
           if (p.pool_out) {      // second output: 2x2 / stride 2 / ceil-mode max pooling (act(max) = max(act): monotonic activation)
             const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
             const __amdgpu_buffer_rsrc_t rpo = make_rsrc(p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride,
                                                          (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * 4u);
-            const int y = tl.y0 + row0;
-            const bool y1 = y + 1 < H, x1 = x + 1 < W;
-            const int poff = (!(li & 1) && x < W && y < H) ? (((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + cb * 32 + 4 * lh) * 4 : (int)OOB;
+            const bool y1 = y + 1 < H;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              f32x4 v;
+            for (int ph = 0; ph < 2; ++ph) {
+              const int x = tl.x0 + ph * 16 + l15;
+              const bool x1 = x + 1 < W;
+              const int poff = (!(l15 & 1) && x < W && y < H) ? (((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + cb * 32 + 4 * kg) * 4 : (int)OOB;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float m = acc[0][4 * j + e];
-                if (y1) m = fmaxf(m, acc[1][4 * j + e]);
-                const float qn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, false));   // lane ^ 1
-                if (x1) m = fmaxf(m, qn);
-                const float t = m * out_scale + b4[j][e];
-                v[e] = fmaxf(t, t * slope_out);
+              for (int nh = 0; nh < 2; ++nh) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float m = acc[0][ph][nh][e];
+                  if (y1) m = fmaxf(m, acc[1][ph][nh][e]);
+                  const float qn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+                  if (x1) m = fmaxf(m, qn);
+                  const float t = m * out_scale + b4[nh][e];
+                  v[e] = fmaxf(t, t * slope_out);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rpo, jok[nh] ? poff : (int)OOB, nh * 64, 0);
               }
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rpo, jok[j] ? poff : (int)OOB, j * 32, 0);
             }
           }
-          prev[0] = acc[0]; prev[1] = acc[1];
+#pragma unroll
+          for (int a = 0; a < 8; ++a) (&prev[0][0][0])[a] = (&acc[0][0][0])[a];
           rout = make_rsrc(p.out + (long long)tl.b * H * W * p.out_pix_stride, frame_out);
           rres = make_rsrc(p.residual ? p.residual + (long long)tl.b * H * W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm) {
-            const int y = tl.y0 + row0 + tm;
-            const bool okp = y < H && x < W;
-            tvo[tm] = okp ? ((y * W + x) * (int)p.out_pix_stride + p.out_ch_off + cb * 32 + 4 * lh) * 4 : (int)OOB;
-            tvr[tm] = okp ? ((y * W + x) * (int)p.res_pix_stride + p.res_ch_off + cb * 32 + 4 * lh) * 4 : (int)OOB;
-          }
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+              const int yy = y + tm, x = tl.x0 + ph * 16 + l15;
+              const bool okp = yy < H && x < W;
+              tvo[tm][ph] = okp ? ((yy * W + x) * (int)p.out_pix_stride + p.out_ch_off + cb * 32 + 4 * kg) * 4 : (int)OOB;
+              tvr[tm][ph] = okp ? ((yy * W + x) * (int)p.res_pix_stride + p.res_ch_off + cb * 32 + 4 * kg) * 4 : (int)OOB;
+            }
           [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (finish_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
           have_prev = true;
         }

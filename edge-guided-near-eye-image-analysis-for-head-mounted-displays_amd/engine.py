@@ -708,9 +708,9 @@ class Plan:
             nchunk = ((W + 31) // 32) * ((H + th - 1) // th) * (2 if (th == 4 and layer.sfrag_coutp() >= 64) else 4)
             fuse_stats = stats and STATS_FUSED and dst.Cp == int(d.Cout_store)
             # resident-weights form (conv3x3_rw_f16.hip) unless the layer writes InstanceNorm sums from its epilogue
-            # (measured: ahead of the register-ring form for 64 -> 32 channels only -- 655 vs 770 us at 240x320x64 --, level at 64 -> 64,
-            # behind it for 32 -> 32 and 64 -> 128 where one workgroup per output block re-stages the input too often)
-            rw = (RW_ENABLED and not fuse_stats and pieces[0].Cp > 32 and layer.sfrag_coutp() == 32
+            # (measured at 240x320x64 against the register-ring form: 64 -> 32 566 vs 777 us, 64 -> 64 1070 vs 1170, 32 -> 32 318 vs 356,
+            #  32 -> 64 622 vs 740; 64 -> 128 at 120x160 525 vs 560)
+            rw = (RW_ENABLED and not fuse_stats
                   and int(d.Cout_store) % 8 == 0 and dst.stride % 4 == 0 and dst.off % 4 == 0
                   and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
             if fuse_stats:
