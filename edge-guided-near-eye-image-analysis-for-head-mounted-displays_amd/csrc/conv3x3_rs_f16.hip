@@ -123,7 +123,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     f32x4 asc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, ash[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     auto load_aff = [&](const Tile& tl, auto bc) {
       constexpr int BUF = decltype(bc)::value;
-      if (sg.scale) {
+      if (sg.scale && nmine > 0) {       // (a workgroup without tiles decodes a frame past the batch: no table row to read)
         const float* zs = cok ? sg.scale + (long long)tl.b * sg.Cp + piece * 4 : egne_zero_page;
         const float* zh = cok ? sg.shift + (long long)tl.b * sg.Cp + piece * 4 : egne_zero_page;
         asc[BUF] = *(const f32x4*)zs;

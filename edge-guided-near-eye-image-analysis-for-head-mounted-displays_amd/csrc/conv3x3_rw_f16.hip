@@ -51,11 +51,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// KCH: 32-channel chunks of the input slice (1 or 2).  ncb = output blocks of 32 channels; tiles_x / tiles_y / ntiles as usual.
+// KCH: 32-channel chunks of the input slice (1 or 2: all weights resident) or 0: any number of chunks (p.Ktot / 32), the weights of
+// a job's chunk (36 KB) STREAMED into one of two LDS weight buffers by the producers one job ahead -- the wider layers
+// (conv2_2, the MSBlock convs of stages 2-5, the dense blocks at 60x80) on the same consumer loop.
+// ncb = output blocks of 32 channels; tiles_x / tiles_y / ntiles as usual.
 template <int KCH>
 __global__ __launch_bounds__(512)
 void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
-                       float out_scale, int tiles_x, int tiles_y, int ntiles, int ncb) {
+                       float out_scale, int tiles_x, int tiles_y, int ntiles, int ncb, int nrun) {
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* const lw = ldsh + 2 * IMGH;                  // weights behind the two images
 
@@ -77,7 +80,10 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
   // workgroup -> (output block, worker): blocks b and b + 8 share an XCD (round-robin dispatch: a speed assumption only); the ncb
   // workgroups of one worker walk the SAME tiles on the same XCD, so the halo of a tile is read from HBM once
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int cb = q % ncb, worker = (q / ncb) * 8 + xcd, nworkers = ((int)gridDim.x >> 3) / ncb * 8;
+  // ncb: output blocks in the weight pack, nrun <= ncb: blocks that hold stored channels (the others are never computed)
+  const int wpx = ((int)gridDim.x >> 3) / nrun;          // workers per XCD
+  if (q >= wpx * nrun) return;                           // 32 is not a multiple of nrun: the spare workgroups of each XCD stay idle
+  const int cb = q % nrun, worker = (q / nrun) * 8 + xcd, nworkers = wpx * 8;
   auto tile_at = [&](int i) { return worker + i * nworkers; };
   struct Tile { int b, y0, x0; };
   auto decode = [&](int t) {
@@ -89,12 +95,14 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
   };
   int ntl = 0;
   while (tile_at(ntl) < ntiles) ++ntl;
-  const int nmine = ntl * KCH;                           // jobs: (tile, chunk), chunk fastest
+  constexpr bool STREAM = KCH == 0;
+  const int nk = STREAM ? p.Ktot / 32 : KCH;             // chunks per tile
+  const int nmine = ntl * nk;                            // jobs: (tile, chunk), chunk fastest
   const int nloop = (nmine + 1) & ~1;                    // both roles run an even number of steps (register buffer = step parity)
 
   // the block's weights: fragments (tap, k16, nt = cb) of the 32x32x16 pack [tap][Ktot/16][CoutP/32][lane][8]
-  {
-    const int KT16 = KCH * 2;
+  const int KT16 = nk * 2;
+  if constexpr (!STREAM) {
     for (int it = tid; it < KCH * 9 * 2 * 2 * 64; it += 512) {        // 16-byte items, LDS order [chunk][tap][ks][hl][lane]
       const int l = it & 63, hl = (it >> 6) & 1, ks = (it >> 7) & 1, r = it >> 8, tap = r % 9, ch = r / 9;
       const long long src = (((long long)tap * KT16 + ch * 2 + ks) * ncb + cb) * 512 + l * 8;
@@ -119,7 +127,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       rel[I] = px < NPX ? (((hy - 1) * W + hx - 1) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4 : (int)OOB;
     }
     struct Job { Tile t; int ch; };
-    auto job_at = [&](int j) { Job r; r.t = decode(tile_at(j / KCH)); r.ch = j % KCH; return r; };
+    auto job_at = [&](int j) { Job r; r.t = decode(tile_at(j / nk)); r.ch = j % nk; return r; };
     auto issue1 = [&](const Job& jb, bool on, auto bc, auto ic) {
       constexpr int BUF = decltype(bc)::value, I = decltype(ic)::value;
       const Tile& tl = jb.t;
@@ -144,7 +152,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     f32x4 asc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, ash[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     auto load_aff = [&](const Job& jb, auto bc) {
       constexpr int BUF = decltype(bc)::value;
-      if (sg.scale) {
+      if (sg.scale && nmine > 0) {       // (a workgroup without tiles decodes a frame past the batch: no table row to read)
         const int c0 = jb.ch * 32 + piece * 4;
         const float* zs = c0 < sg.Cp ? sg.scale + (long long)jb.t.b * sg.Cp + c0 : egne_zero_page;
         const float* zh = c0 < sg.Cp ? sg.shift + (long long)jb.t.b * sg.Cp + c0 : egne_zero_page;
@@ -176,11 +184,32 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         *(h4*)&img[NPX * 32 + o] = lo;
       }
     };
+    // STREAM: the 2304 16-byte pieces of a chunk's weights (LDS order [tap][ks][hl][lane]), nine per producer lane, requested one
+    // job ahead at the START of a step (in front of that step's halo loads in the in-order queue) and written at the start of the next
+    u32x4 wreg[STREAM ? 9 : 1];
+    const unsigned wbytes = 9u * (unsigned)KT16 * (unsigned)ncb * 1024u;
+    const __amdgpu_buffer_rsrc_t rwh = make_rsrc(fhi, wbytes), rwl = make_rsrc(flo, wbytes);
+    auto w_issue = [&](int ch, bool on) {
+#pragma unroll
+      for (int i = 0; i < (STREAM ? 9 : 0); ++i) {
+        const int it = tid + 256 * i, l = it & 63, hl = (it >> 6) & 1, ks = (it >> 7) & 1, tap = it >> 8;
+        const int off = on ? ((((tap * KT16 + ch * 2 + ks) * ncb + cb) * 512 + l * 8) * 2) : (int)OOB;
+        wreg[i] = hl ? __builtin_amdgcn_raw_buffer_load_b128(rwl, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rwh, off, 0, 0);
+      }
+    };
+    auto w_store = [&](int parity) {
+#pragma unroll
+      for (int i = 0; i < (STREAM ? 9 : 0); ++i) *(u32x4*)&lw[parity * WCH + (tid + 256 * i) * 8] = wreg[i];
+    };
     // step s (job s): convert job s+1 out of register buffer (s+1)&1 and refill every freed register with job s+3
     auto step = [&](int s, auto bc) {
       constexpr int BUF = decltype(bc)::value;          // = (s + 1) & 1
       const bool c_on = s + 1 < nmine, i_on = s + 3 < nmine;
       const Job jc = job_at(c_on ? s + 1 : 0), ji = job_at(i_on ? s + 3 : 0);
+      if constexpr (STREAM) {
+        w_store((s + 1) & 1);                             // weights of job s+1 (requested in step s-1)
+        w_issue(job_at(s + 2 < nmine ? s + 2 : 0).ch, s + 2 < nmine);
+      }
       load_aff(job_at(s + 2 < nmine ? s + 2 : 0), std::integral_constant<int, BUF ^ 1>{});
       _Float16* img = ldsh + ((s + 1) & 1) * IMGH;
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
@@ -194,6 +223,11 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     using B1 = std::integral_constant<int, 1>;
     {   // prologue: jobs 0 and 1 requested, job 0 converted (its registers refilled with job 2)
       const Job j0 = job_at(0), j1 = job_at(nmine > 1 ? 1 : 0), j2 = job_at(nmine > 2 ? 2 : 0);
+      if constexpr (STREAM) {
+        w_issue(j0.ch, nmine > 0);
+        w_store(0);
+        w_issue(j1.ch, nmine > 1);
+      }
       load_aff(j0, B0{});
       load_aff(j1, B1{});
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
@@ -291,11 +325,11 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     t_last = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < nloop; ++s) {
       if (s < nmine) {
-        const int ch = s % KCH;
-        const Tile tl = decode(tile_at(s / KCH));
+        const int ch = s % nk;
+        const Tile tl = decode(tile_at(s / nk));
         const _Float16* Thi = ldsh + (s & 1) * IMGH;
         const _Float16* Tlo = Thi + NPX * 32;
-        const _Float16* wb = lw + ch * WCH + wl;
+        const _Float16* wb = lw + (STREAM ? (s & 1) : ch) * WCH + wl;
         if (ch == 0) {
 #pragma unroll
           for (int a = 0; a < 8; ++a) (&acc[0][0][0])[a] = (f32x4)(0.f);
@@ -339,7 +373,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
             __builtin_amdgcn_sched_barrier(0);
           }()), ...);
         }(std::make_integer_sequence<int, 9>{});
-        if (ch == KCH - 1) {                               // tile complete: hand it to the deferred stores
+        if (ch == nk - 1) {                                // tile complete: hand it to the deferred stores
           const int y = tl.y0 + row0;
           if (p.pool_out) {      // second output: 2x2 / stride 2 / ceil-mode max pooling (act(max) = max(act): monotonic activation)
             const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
@@ -398,20 +432,21 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
 template <int KCH>
 int launch_rw(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
-  const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32;
-  constexpr size_t lds = ((size_t)2 * IMGH + (size_t)KCH * WCH) * sizeof(_Float16);
+  const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32, nrun = (d.Cout_store + 31) / 32;
+  constexpr size_t lds = ((size_t)2 * IMGH + (size_t)(KCH == 0 ? 2 : KCH) * WCH) * sizeof(_Float16);
   static_assert(lds <= 163840, "LDS budget");
   static bool once = hipFuncSetAttribute((const void*)conv3x3_rw_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_rw: cannot raise the dynamic LDS limit to %zu", lds);
   // 256 workgroups = 8 XCDs x 32; the ncb blocks of a worker sit on one XCD: 32 / ncb workers per XCD
-  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb);
+  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb, nrun);
   return egne::check_launch("egne_conv3x3_rw_f16_fwd");
 }
 
 }  // namespace
 
 // Same descriptor and weight pack as egne_conv3x3_rs_f16_fwd (one input slice with optional fused affine, 3x3 / pad 1 / dilation 1,
-// Ktot = slice width rounded up to 32 and <= 64, weights from egne_pack_conv_weight_f16frag); CoutP = 32, 64 or 128; Cout_store a
+// Ktot = slice width rounded up to 32 (resident weights up to 64, streamed per chunk above), weights from
+// egne_pack_conv_weight_f16frag); CoutP = 32, 64, 128 or 256; Cout_store a
 // multiple of 8; 16-byte aligned output / residual / pooled slices; no statistics (egne_conv3x3_rs_f16_fwd writes those); optional
 // pooled second output as there.
 extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
@@ -421,9 +456,9 @@ extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi
   EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_mode == 0 && d.ngroups == 1 && d.nseg == 1 && d.pad_h == 1 &&
                d.pad_w == 1 && d.dil[0] == 1 && d.Ho == d.H && d.Wo == d.W && !d.stats_ws, "conv3x3_rw: geometry / options not supported");
   const egne_seg& g = d.seg[0];
-  EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && (d.Ktot == 32 || d.Ktot == 64) && g.ch_off % 4 == 0 &&
+  EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && d.Ktot >= 32 && d.Ktot <= 1024 && g.ch_off % 4 == 0 &&
                g.pix_stride % 4 == 0 && ((uintptr_t)g.ptr & 15) == 0 && (g.scale == nullptr) == (g.shift == nullptr), "conv3x3_rw: input slice");
-  EGNE_REQUIRE((d.CoutP == 32 || d.CoutP == 64 || d.CoutP == 128) && d.Cout_store <= d.CoutP && d.Cout_store % 8 == 0 && d.out &&
+  EGNE_REQUIRE(d.CoutP % 32 == 0 && d.CoutP <= 256 && d.Cout_store >= 8 && d.Cout_store <= d.CoutP && d.Cout_store % 8 == 0 && d.out &&
                ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
                d.out_ch_off + d.Cout_store <= d.out_pix_stride && (!d.bias || ((uintptr_t)d.bias & 15) == 0), "conv3x3_rw: output");
   EGNE_REQUIRE(!d.residual || (((uintptr_t)d.residual & 15) == 0 && d.res_pix_stride % 4 == 0 && d.res_ch_off % 4 == 0), "conv3x3_rw: residual alignment");
@@ -437,7 +472,9 @@ extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *h = (const _Float16*)fhi, *l = (const _Float16*)flo;
-  return d.Ktot == 32 ? launch_rw<1>(d, h, l, a_scale, os, st) : launch_rw<2>(d, h, l, a_scale, os, st);
+  if (d.Ktot == 32) return launch_rw<1>(d, h, l, a_scale, os, st);
+  if (d.Ktot == 64) return launch_rw<2>(d, h, l, a_scale, os, st);
+  return launch_rw<0>(d, h, l, a_scale, os, st);
 }
 
 extern "C" int egne_rw_debug(int dbg, void* out_stamps) {

@@ -22,6 +22,9 @@ LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock
 LAYER_BYTES = {}          # layer name -> algorithmic bytes of its launch(es) (input slices + stored output), for bench.py --layers
 TDPOOL_FUSED = os.environ.get("EGNE_TDPOOL_FUSED", "1") != "0"     # Transition_down: pooling folded into the 1x1's operand load
 POOL_FUSED = os.environ.get("EGNE_POOL_FUSED", "1") != "0"     # conv1_2 writes pool1 from its epilogue (conv3x3_rs_f16.hip)
+RW_MIN_W = int(os.environ.get("EGNE_RW_MIN_W", "120"))         # streamed-weights form: narrowest map
+RW_MAX_COUTP = int(os.environ.get("EGNE_RW_MAX_COUTP", "32"))   # ... widest output
+RW_MAX_CP = int(os.environ.get("EGNE_RW_MAX_CP", "512"))        # ... and widest input slice
 RW_ENABLED = os.environ.get("EGNE_RW", "1") != "0"             # resident-weights form of the role-split 3x3 (no consumer loads)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
@@ -554,9 +557,15 @@ class Plan:
         rs = (split and RS_ENABLED and HALO_F16_ENABLED and not lattice and not msdil and layer.kh == 3 and layer.kw == 3
               and layer.G == 1 and layer.pad == (1, 1) and layer.stride == 1 and layer.pad_mode == 0 and layer.dils[0] == 1
               and len(pieces) == 1 and W >= RS_MIN_W and H * W * max(pieces[0].stride, dst.stride) < 2 ** 29
-              and 8 <= pieces[0].Cp <= 64 and layer.sfrag_coutp() in (32, 64, 128)
-              and not (pieces[0].Cp <= 32 and layer.sfrag_coutp() == 128)
               and (residual is None or H * W * residual.stride < 2 ** 29))
+        # wider inputs: the resident-weights kernel with its weights streamed chunk by chunk (no statistics from its epilogue)
+        # (measured against the halo kernel: ahead for 128 -> 32 at 120x160 (290 vs 318 us), level or behind at 60x80 and for wide
+        #  outputs -- every output block stages the input again --, so only single-block layers on wide maps take it by default)
+        rw_wide = (rs and RW_ENABLED and 64 < pieces[0].Cp <= RW_MAX_CP and layer.sfrag_coutp() <= RW_MAX_COUTP and not stats
+                   and W >= RW_MIN_W and min(layer.Cout_store, dst.Cp) % 8 == 0 and dst.stride % 4 == 0 and dst.off % 4 == 0
+                   and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
+        rs = rw_wide or (rs and 8 <= pieces[0].Cp <= 64 and layer.sfrag_coutp() in (32, 64, 128)
+                         and not (pieces[0].Cp <= 32 and layer.sfrag_coutp() == 128))
         shalo = shalo or rs
         if lattice or msdil:
             shalo = True
@@ -710,7 +719,7 @@ class Plan:
             # resident-weights form (conv3x3_rw_f16.hip) unless the layer writes InstanceNorm sums from its epilogue
             # (measured at 240x320x64 against the register-ring form: 64 -> 32 566 vs 777 us, 64 -> 64 1070 vs 1170, 32 -> 32 318 vs 356,
             #  32 -> 64 622 vs 740; 64 -> 128 at 120x160 525 vs 560)
-            rw = (RW_ENABLED and not fuse_stats
+            rw = rw_wide or (RW_ENABLED and not fuse_stats
                   and int(d.Cout_store) % 8 == 0 and dst.stride % 4 == 0 and dst.off % 4 == 0
                   and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
             if fuse_stats:

@@ -680,7 +680,11 @@ def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C
                                                   (2, 32, 32, 61, 83, "norm"), (1, 38, 64, 120, 160, "norm"), (3, 56, 30, 33, 64, "plain"),
                                                   (2, 32, 2, 64, 96, "norm"),
                                                   # several tiles per workgroup (more than 256 tiles): the multi-tile paths of every form
-                                                  (6, 32, 32, 240, 320, "plain"), (5, 64, 64, 120, 160, "plain"), (4, 64, 32, 240, 320, "plain")])
+                                                  (6, 32, 32, 240, 320, "plain"), (5, 64, 64, 120, 160, "plain"), (4, 64, 32, 240, 320, "plain"),
+                                                  # wider inputs: weights streamed chunk by chunk into LDS (vgg conv2_2, MSBlock convs of
+                                                  # stages 2-3, the 60x80 dense block); 96 channels = three output blocks, one of four idle
+                                                  (3, 128, 32, 120, 160, "plain"), (2, 128, 32, 120, 130, "res"),
+                                                  (1, 256, 32, 120, 160, "plain"), (2, 80, 32, 120, 128, "norm_nostats")])
 def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
     """conv3x3_rs_f16.hip (producer / consumer waves; vgg16_c.py:66-69, bdcn_new.py:50, models/RITnet_v2.py:57, utils.py:1047)
     against a float64 convolution: plain, with the residual addend, and with the InstanceNorm affine + LeakyReLU applied while
@@ -695,7 +699,7 @@ def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
     layer.split = True
     out = pl.buf(B, H, W, pad8(Cout))
     xin, residual = x.double(), None
-    if mode == "norm":
+    if mode.startswith("norm"):
         mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
         sc, sh = torch.zeros(B, px.Cp, device=DEV), torch.zeros(B, px.Cp, device=DEV)
         sc[:, :Cin], sh[:, :Cin] = rstd.to(DEV), (-mean * rstd).to(DEV)
