@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ("out", c_fp), ("out_pix_stride", C.c_int64), ("out_ch_off", C.c_int32),
                 ("Cout_store", C.c_int32),
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
-                ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32)]
+                ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
+                ("dyn_scale", C.c_void_p)]
 
 
 class BdcnTailDesc(C.Structure):

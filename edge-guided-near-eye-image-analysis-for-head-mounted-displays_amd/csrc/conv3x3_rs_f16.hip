@@ -74,6 +74,7 @@ template <int NCH, int WN, int TH, bool M16, int DBG = 0, bool TPO = false>
 __global__ __launch_bounds__(512)
 void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
                        float out_scale, int tiles_x, int tiles_y, int ntiles) {
+  egne::dyn_scales(p.dyn_scale, a_scale, out_scale);
   using Geo = RsGeom<NCH, TH, M16>;
   constexpr int LDH = Geo::LDH, NPX = Geo::NPX, CHS = Geo::CHS, IMG = Geo::IMG;
   constexpr int PPP = 8 * NCH;                          // 16-byte pieces per pixel

@@ -59,6 +59,7 @@ template <int KCH>
 __global__ __launch_bounds__(512)
 void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
                        float out_scale, int tiles_x, int tiles_y, int ntiles, int ncb, int nrun) {
+  egne::dyn_scales(p.dyn_scale, a_scale, out_scale);
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* const lw = ldsh + 2 * IMGH;                  // weights behind the two images
 

@@ -53,6 +53,7 @@ template <int WGM, int WGN, int TM, int TN, bool GROUPED>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ whi,
                                                          const _Float16* __restrict__ wlo, float a_scale,
                                                          float out_scale) {
+  egne::dyn_scales(p.dyn_scale, a_scale, out_scale);
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int AR = BM / 32;                  // A rows staged per thread (float4 each)
   constexpr int BI = (BN * 4 + 255) / 256;     // B 16-byte items per thread and array

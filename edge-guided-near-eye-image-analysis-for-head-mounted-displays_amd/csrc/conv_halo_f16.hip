@@ -52,6 +52,7 @@ template <int WM, int WN, int D, bool LAT, int NW, int PF = 0, bool TP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
+  egne::dyn_scales(p.dyn_scale, a_scale, out_scale);
   // (vH, vW, rstep, cstep): the image as the kernel walks it.  Normal: (H, W, W, 1).  TP = transposed ("tall tiles", for maps
   // that 8 x 32 tiles fit badly): (W, H, 1, W) -- the 32-long MFMA rows then run along image y.  A template parameter: as
   // run-time values the extra address arithmetic cost the normal path 5 %.

@@ -25,4 +25,18 @@ __device__ __forceinline__ void split2(float x0, float x1, float s, sp_h2& h, sp
   l = __builtin_convertvector(d, sp_h2);
 }
 
+// Device-side pre-scale (egne_conv_desc.dyn_scale): `dyn` holds the bit pattern of max |x| of the input; a_scale becomes the
+// power of two that puts that maximum in [1024, 2048) (what engine._a_scale_for computes on the host for frozen networks)
+// and out_scale takes its inverse.  Scalar loads and scalar ALU only; both stay in SGPRs.
+__device__ __forceinline__ void dyn_scales(const unsigned* dyn, float& a_scale, float& out_scale) {
+  if (dyn) {
+    unsigned eb = (unsigned)__builtin_amdgcn_readfirstlane((int)*dyn) >> 23;
+    if (eb) {
+      eb = eb < 27u ? 27u : (eb > 227u ? 227u : eb);
+      out_scale *= a_scale * __builtin_bit_cast(float, (eb - 10u) << 23);     // (the host folded ITS a_scale into out_scale)
+      a_scale = __builtin_bit_cast(float, (264u - eb) << 23);
+    }
+  }
+}
+
 }  // namespace egne

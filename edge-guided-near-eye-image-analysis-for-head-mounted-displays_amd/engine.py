@@ -44,7 +44,8 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
-TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "0") != "0"     # split-f16 FORWARD convolutions in training plans too (22-bit products)
+WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans: steps between re-measuring max |w| of a split-f16 pack (one host sync each)
+TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "1") != "0"     # training plans: split-f16 (22-bit products) 3x3 forward convolutions and data gradients, pre-scales taken on the device
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
 STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm statistics from the producing conv's epilogue
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
@@ -257,8 +258,11 @@ class ConvLayer:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
             ws = [w.detach().contiguous() for w in self.weights]
-            mx = max(float(w.abs().max()) for w in ws)          # host sync, at (re)pack time only
-            self.w_scale = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
+            age = getattr(self, "_ws_age", 0)
+            if not getattr(self, "stale_scale_ok", False) or age % WSCALE_EVERY == 0:
+                mx = max(float(w.abs().max()) for w in ws)          # host sync, at (re)pack time only
+                self.w_scale = 2.0 ** math.floor(math.log2(2048.0 / mx)) if mx > 0 else 1.0
+            self._ws_age = age + 1       # (training plans re-pack every step: the scale has 32x of headroom and is re-measured every WSCALE_EVERY steps)
             cps = self.split_coutp()
             kts = pad32(self.Ktot)           # single slice: logical channels first, zero columns up to a multiple of 32
             per = T * cps * kts
@@ -414,6 +418,28 @@ class TransposedLayer(ConvLayer):
             self.derived.copy_(w.flip(2).flip(3).transpose(0, 1))
 
 
+class SplitDgradLayer(ConvLayer):
+    """Data gradient of a stride-1 zero-padded k x k convolution w.r.t. input slice ``idx`` as an ORDINARY convolution over the
+    output gradient -- W'[ci][co][j][i] = w[co][ci0 + ci][k-1-j][k-1-i], pad k-1-p -- so that every split-f16 forward kernel
+    (role-split, resident-weights, halo, flat) serves the backward pass too.  ``guard`` re-derives the tensor when the forward
+    weight changed (one strided copy); the usual packing reads it."""
+
+    def __init__(self, fwd, idx, dev):
+        assert fwd.stride == 1 and fwd.pad_mode == 0 and fwd.G == 1
+        C_, Cp_ = fwd.in_layout[idx]
+        self.fwd, self.c0, self.cn = fwd, sum(c for c, _ in fwd.in_layout[:idx]), C_
+        self.derived = torch.zeros((C_, fwd.Cout, fwd.kh, fwd.kw), dtype=torch.float32, device=dev)
+        super().__init__([self.derived], None, [(fwd.Cout, fwd.Cout_store)], stride=1, dils=fwd.dils,
+                         pad=(fwd.kh - 1 - fwd.pad[0], fwd.kw - 1 - fwd.pad[1]), kernel_hw=(fwd.kh, fwd.kw), cout_pad=Cp_)
+        self.split = True
+        self.guard = VersionGuard([fwd.weights[0]], self.refresh)
+
+    def refresh(self):
+        w = self.fwd.weights[0].detach()
+        self.derived.copy_(w[:, self.c0:self.c0 + self.cn].flip(2).flip(3).transpose(0, 1))
+        self.derived._version  # (copy_ bumps the version: ensure_packed re-packs)
+
+
 class Plan:
     """Buffers + prepared launches for one network at one shape."""
 
@@ -429,6 +455,8 @@ class Plan:
         self.meta = []      # per call: (kernel family, algorithmic FLOPs) for bench.py's roofline
         self.cal = {}       # call index -> (index of the a_scale argument, raw input Pieces, pixels): split-f16 pre-scale calibration
         self.calibrated = False
+        self.dyn_scales = bool(train) and TRAIN_SPLIT     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
+        self.dynbuf, self.ndyn = None, 0
         self.L = _lib.lib()
 
     # ---- memory ------------------------------------------------------------------------------
@@ -458,6 +486,7 @@ class Plan:
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
         bw = Plan(self.device)
         bw.fwd = self
+        bw.dyn_scales = self.dyn_scales
         for emit in reversed(self.tape):
             emit(bw)
         self.bw = bw
@@ -469,6 +498,21 @@ class Plan:
             torch._foreach_zero_(ts)
 
     # ---- launches ----------------------------------------------------------------------------
+    DYN_SLOTS = 512
+
+    def _dyn_slot(self, d, pieces, npix, name):
+        """Training plans: max |x| of the raw input slices measured on the device right before the launch (egne_absmax into one
+        word of ``dynbuf``, cleared at the start of every run); the kernel derives its pre-scale from that word."""
+        if self.dynbuf is None:
+            self.dynbuf = self.vec(self.DYN_SLOTS, dtype=torch.int32)
+            self.pre.append(self.dynbuf.zero_)
+        assert self.ndyn < self.DYN_SLOTS, "too many device-scaled launches in one plan"
+        ptr = self.dynbuf.data_ptr() + 4 * self.ndyn
+        self.ndyn += 1
+        for pc in pieces:
+            self._add(self.L.egne_absmax, (pc.ptr, pc.stride, pc.off, pc.Cp, npix, ptr), name + ".absmax", kind="absmax")
+        d.dyn_scale = ptr
+
     def _add(self, fn, args, name, flops=0.0, kind=None, cal=None):
         if cal is not None and CALIBRATE:
             self.cal[len(self.calls)] = cal
@@ -553,6 +597,8 @@ class Plan:
                  and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29)
         if msdil:
             lattice = False
+        if self.dyn_scales:     # kernels that read egne_conv_desc.dyn_scale: role-split / resident-weights / halo / flat
+            s1x1 = ms1x1 = big = lattice = msdil = c4h = False
         # narrow-input 3x3 layers on wide maps: producer / consumer waves (conv3x3_rs_f16.hip) instead of the all-in-one halo kernel
         rs = (split and RS_ENABLED and HALO_F16_ENABLED and not lattice and not msdil and layer.kh == 3 and layer.kw == 3
               and layer.G == 1 and layer.pad == (1, 1) and layer.stride == 1 and layer.pad_mode == 0 and layer.dils[0] == 1
@@ -655,6 +701,11 @@ class Plan:
         raw = all(pc.scale is None for pc in pieces)
         cal3 = (3, list(pieces), B * H * W) if raw else None
         cal2 = (2, list(pieces), B * H * W) if raw else None
+        if self.dyn_scales:
+            layer.stale_scale_ok = True
+        if self.dyn_scales and raw and split and not (smallcin and c4h):
+            self._dyn_slot(d, pieces, B * H * W, name)
+            cal3 = cal2 = None
         if big and big_tail:
             # two launches over disjoint frame ranges: [0, B - tail) on the 256-wide kernel, the rest on the 128x128 kernel
             layer.ensure_packed(self.device)
@@ -1005,7 +1056,13 @@ class Plan:
                 bw.raw(L.egne_reflect_pad_bwd, (tmp.data_ptr(), tmp.shape[-1], 0, tl.phase, pc.Cp, tgt.ptr, tgt.stride, tgt.off,
                                                 B, H, W, P), name + ".pad_bwd")
                 continue
-            dl = DgradLayer(layer, i)
+            if (bw.dyn_scales and F16X3_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
+                    and layer.Cout_store >= 32):
+                dl = SplitDgradLayer(layer, i, self.device)     # split-f16 arithmetic for the data gradient too
+                dl.stale_scale_ok = True
+                self.pre.append(dl.guard)
+            else:
+                dl = DgradLayer(layer, i)
             tgt = self.gp(pc)
             if pc.scale is None:
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=tgt, name=name + ".dgrad%d" % i)

@@ -96,6 +96,12 @@ typedef struct {
   float* pool_out;
   int64_t pool_pix_stride;
   int32_t pool_ch_off;
+  /* Optional (egne_conv3x3_halo_f16_fwd, egne_conv3x3_rs_f16_fwd, egne_conv3x3_rw_f16_fwd, egne_conv2d_f16x3_fwd): the
+   * activation pre-scale of the split taken ON THE DEVICE from this word = bit pattern of max |x| of the input (written by
+   * egne_absmax on the same stream): a_scale = the power of two that puts it in [1024, 2048); the a_scale argument is then
+   * ignored (pass 1).  Training plans use it: their weights move every step, so a host-side calibration would cost a
+   * synchronisation per launch and step.  Zero / denormal maxima leave a_scale = 1. */
+  const uint32_t* dyn_scale;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
