@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("Cout_store", C.c_int32),
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
                 ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
-                ("dyn_scale", C.c_void_p)]
+                ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p)]
 
 
 class BdcnTailDesc(C.Structure):
@@ -110,6 +110,7 @@ SIGNATURES = {
     "egne_loss_bwd": (i32, [C.POINTER(LossDesc), vp, vp, i64, i32, vp, vp]),
     "egne_act_bwd_bias_workspace_bytes": (i64, [i64, i32]),
     "egne_act_bwd_bias": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp]),
+    "egne_act_bwd_bias_absmax": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp, vp]),
     "egne_norm_bwd_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "egne_norm_bwd": (i32, [vp, i64, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp,
                             i32, vp, vp]),

@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ g, long long gs, int go,
                                                             const float* __restrict__ y, long long ys, int yo, int act,
-                                                            int Cp, long long npix, int nchunk, double* __restrict__ ws) {
+                                                            int Cp, long long npix, int nchunk, double* __restrict__ ws,
+                                                            unsigned* __restrict__ absmax_bits) {
   const int chunk = blockIdx.x, cg = blockIdx.y;
+  unsigned mb = 0;
   const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
   const int c = cg * 32 + v * 4;
   const long long per = (npix + nchunk - 1) / nchunk;
@@ -111,8 +113,19 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ 
         *gp = t;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += t[e];
+      for (int e = 0; e < 4; ++e) {
+        s[e] += t[e];
+        const unsigned b = __float_as_uint(t[e]) & 0x7fffffffu;
+        mb = b > mb ? b : mb;
+      }
     }
+  }
+  if (absmax_bits) {
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned t = (unsigned)__shfl_xor((int)mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if ((threadIdx.x & 63) == 0 && mb > __hip_atomic_load(absmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(absmax_bits, mb);
   }
   __shared__ double sh[32][8][4];
 #pragma unroll
@@ -552,18 +565,24 @@ extern "C" int64_t egne_act_bwd_bias_workspace_bytes(int64_t npix, int Cp) {
   return (int64_t)chunks_for(npix, Cp, 1) * Cp * sizeof(double);
 }
 
-extern "C" int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
-                                 int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream) {
+extern "C" int egne_act_bwd_bias_absmax(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
+                                        int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits,
+                                        void* stream) {
   EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && npix > 0 && ws, "act_bwd_bias: bad gradient slice");
   EGNE_REQUIRE(act == EGNE_ACT_NONE || slice_ok(y, ys, yo, Cp), "act_bwd_bias: bad output slice");
   const int nchunk = chunks_for(npix, Cp, 1);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(act_bwd_bias_partial, dim3(nchunk, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, y,
-                     (long long)ys, yo, act, Cp, (long long)npix, nchunk, (double*)ws);
+                     (long long)ys, yo, act, Cp, (long long)npix, nchunk, (double*)ws, (unsigned*)absmax_bits);
   if (dbias)
     hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 31) / 32), dim3(256), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
                        nchunk, dbias, accumulate);
   return egne::check_launch("egne_act_bwd_bias");
+}
+
+extern "C" int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
+                                 int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream) {
+  return egne_act_bwd_bias_absmax(g, gs, go, y, ys, yo, act, Cp, npix, dbias, C, accumulate, ws, nullptr, stream);
 }
 
 extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_sample) {

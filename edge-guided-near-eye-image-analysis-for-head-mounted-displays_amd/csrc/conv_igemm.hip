@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
                                                 p.residual ? (unsigned)(rows * p.res_pix_stride * 4) : 0u);
   const int ostep = (int)p.out_pix_stride * 4, rstep = (int)p.res_pix_stride * 4;
+  unsigned mb = 0;           // max bit pattern of |stored value| (egne_conv_desc.absmax_out)
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn) {
     const int n = n0 + tn * 32 + li;
@@ -302,8 +303,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
         else { v = acc[tm][tn][r] + bv; v = fmaxf(v, v * slope_out); }
         v = v * ps + pt + rv[r];
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
+        const unsigned b = (nok && mrow + (r & 3) + 8 * (r >> 2) < rows) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u;
+        mb = b > mb ? b : mb;
       }
     }
+  }
+  if (p.absmax_out) {
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned t = (unsigned)__shfl_xor((int)mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0 && mb > __hip_atomic_load(p.absmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.absmax_out, mb);   // (same-address atomics serialise: most waves find a larger value already there)
   }
 }
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, lon
     const unsigned t = (unsigned)__shfl_xor((int)m, o);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_bits, m);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -457,6 +457,7 @@ class Plan:
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
+        self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _lib.lib()
 
     # ---- memory ------------------------------------------------------------------------------
@@ -500,15 +501,34 @@ class Plan:
     # ---- launches ----------------------------------------------------------------------------
     DYN_SLOTS = 512
 
-    def _dyn_slot(self, d, pieces, npix, name):
-        """Training plans: max |x| of the raw input slices measured on the device right before the launch (egne_absmax into one
-        word of ``dynbuf``, cleared at the start of every run); the kernel derives its pre-scale from that word."""
+    def _new_slot(self):
         if self.dynbuf is None:
             self.dynbuf = self.vec(self.DYN_SLOTS, dtype=torch.int32)
             self.pre.append(self.dynbuf.zero_)
         assert self.ndyn < self.DYN_SLOTS, "too many device-scaled launches in one plan"
-        ptr = self.dynbuf.data_ptr() + 4 * self.ndyn
         self.ndyn += 1
+        return self.dynbuf.data_ptr() + 4 * (self.ndyn - 1)
+
+    def _publish_absmax(self, piece, B):
+        """A producer writes max |x| of the slice it stores into the returned word (cleared at the start of every run)."""
+        ptr = self._new_slot()
+        self._absmax_of[(id(piece.buf), piece.off, piece.Cp, piece.n0, B)] = (ptr, len(self.calls))
+        return ptr
+
+    def _dyn_slot(self, d, pieces, B, npix, name):
+        """Training plans: the split-f16 pre-scale comes from max |x| of the raw input slices, on the device (the kernel derives
+        it from one word of ``dynbuf``): the word its producer published (act_bwd_bias, the fp32 implicit GEMM's epilogue) if
+        there is one, else measured by egne_absmax right before the launch."""
+        if self._dyn_hint is not None:
+            d.dyn_scale = self._dyn_hint
+            return
+        if len(pieces) == 1:
+            pc = pieces[0]
+            ent = self._absmax_of.get((id(pc.buf), pc.off, pc.Cp, pc.n0, B))
+            if ent is not None and len(self.calls) - ent[1] <= 4:
+                d.dyn_scale = ent[0]
+                return
+        ptr = self._new_slot()
         for pc in pieces:
             self._add(self.L.egne_absmax, (pc.ptr, pc.stride, pc.off, pc.Cp, npix, ptr), name + ".absmax", kind="absmax")
         d.dyn_scale = ptr
@@ -704,7 +724,7 @@ class Plan:
         if self.dyn_scales:
             layer.stale_scale_ok = True
         if self.dyn_scales and raw and split and not (smallcin and c4h):
-            self._dyn_slot(d, pieces, B * H * W, name)
+            self._dyn_slot(d, pieces, B, B * H * W, name)
             cal3 = cal2 = None
         if big and big_tail:
             # two launches over disjoint frame ranges: [0, B - tail) on the 256-wide kernel, the rest on the 128x128 kernel
@@ -804,6 +824,8 @@ class Plan:
         elif halo:
             self._add(self.L.egne_conv3x3_halo_fwd, (C.byref(d),), name, flops=flops, kind="conv3x3_halo")
         else:
+            if self.dyn_scales and residual is None and int(d.Cout_store) >= dst.Cp:
+                d.absmax_out = self._publish_absmax(dst, B)       # a split-f16 3x3 usually reads this next
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
         assert scores is None or msdil, "score fusion needs the one-launch MSBlock kernel (check Plan.msdil_ok first)"
         if stats:
@@ -1023,8 +1045,11 @@ class Plan:
         npix = B * Ho * Wo
         ws = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(npix, Cs)) + 7) // 8, dtype=torch.float64)
         bias = layer.biases[0] if layer.biases is not None else None
-        bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
-                                     bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr()),
+        split_dgrad = (bw.dyn_scales and F16X3_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
+                       and layer.stride == 1 and layer.pad_mode == 0 and layer.G == 1 and layer.Cout_store >= 32)
+        gz_max = bw._new_slot() if split_dgrad else None          # max |gz| for the split-f16 data gradients, from this pass
+        bw.raw(L.egne_act_bwd_bias_absmax, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
+                                            bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr(), gz_max),
                name + ".act_bwd")
         w = layer.weights[0]
         assert layer.G == 1 and w.grad is not None and w.grad.is_contiguous()
@@ -1056,19 +1081,21 @@ class Plan:
                 bw.raw(L.egne_reflect_pad_bwd, (tmp.data_ptr(), tmp.shape[-1], 0, tl.phase, pc.Cp, tgt.ptr, tgt.stride, tgt.off,
                                                 B, H, W, P), name + ".pad_bwd")
                 continue
-            if (bw.dyn_scales and F16X3_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
-                    and layer.Cout_store >= 32):
+            if split_dgrad:
                 dl = SplitDgradLayer(layer, i, self.device)     # split-f16 arithmetic for the data gradient too
                 dl.stale_scale_ok = True
                 self.pre.append(dl.guard)
+                bw._dyn_hint = gz_max
             else:
                 dl = DgradLayer(layer, i)
             tgt = self.gp(pc)
             if pc.scale is None:
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=tgt, name=name + ".dgrad%d" % i)
+                bw._dyn_hint = None
             else:
                 tmp = bw.buf(B, H, W, pc.Cp)
                 bw.conv(dl, [gin], Piece(tmp, 0, pc.C, pc.Cp), B, Ho, Wo, name=name + ".dgrad%d" % i)
+                bw._dyn_hint = None
                 sums = bw.vec(B * pc.Cp * 2)
                 wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, H * W, pc.Cp, 1)) + 7) // 8, dtype=torch.float64)
                 bw.raw(L.egne_norm_bwd, (pc.ptr, pc.stride, pc.off, pc.scale.data_ptr(), pc.shift.data_ptr(), None,

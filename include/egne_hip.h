@@ -102,6 +102,10 @@ typedef struct {
    * ignored (pass 1).  Training plans use it: their weights move every step, so a host-side calibration would cost a
    * synchronisation per launch and step.  Zero / denormal maxima leave a_scale = 1. */
   const uint32_t* dyn_scale;
+  /* Optional (egne_conv2d_fwd, the exact-fp32 implicit GEMM): atomic max of the bit patterns of |stored value| into this word
+   * (cleared by the caller) -- the dyn_scale word of the split-f16 launch that reads this output next, without another pass
+   * over the tensor. */
+  uint32_t* absmax_out;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
@@ -400,6 +404,10 @@ int egne_loss_bwd(const egne_loss_desc* d, const float* gscale /* device, 1 floa
 /* In place g <- g * act'(y) over an NHWC slice (y = forward output of the conv) and the bias gradient
  * dbias[c] (+)= sum over pixels of the masked g, c < C. */
 int64_t egne_act_bwd_bias_workspace_bytes(int64_t npix, int Cp);
+/* egne_act_bwd_bias_absmax: the same, plus the atomic max of the bit patterns of |gz| into *absmax_bits (the dyn_scale word
+ * of the split-f16 data-gradient launches that read gz next). */
+int egne_act_bwd_bias_absmax(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
+                             int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits, void* stream);
 int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
                       int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream);
 
