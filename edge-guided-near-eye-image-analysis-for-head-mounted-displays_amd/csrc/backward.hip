@@ -103,20 +103,29 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ 
   const long long p0 = (long long)chunk * per, p1 = p0 + per < npix ? p0 + per : npix;
   double s[4] = {0, 0, 0, 0};
   if (c < Cp) {
-    for (long long p = p0 + row; p < p1; p += 32) {
-      f32x4* gp = (f32x4*)(g + p * gs + go + c);
-      f32x4 t = *gp;
-      if (act != EGNE_ACT_NONE) {
-        const f32x4 yy = *(const f32x4*)(y + p * ys + yo + c);
+    // four pixel rows per trip, all eight loads issued before the first use (one row at a time ran at 3.0 TB/s: latency bound)
+    for (long long p = p0 + row; p < p1; p += 128) {
+      f32x4 t[4], yy[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = yy[e] > 0.f ? t[e] : (act == EGNE_ACT_LEAKY ? 0.01f * t[e] : 0.f);
-        *gp = t;
+      for (int u = 0; u < 4; ++u) {
+        const long long q = p + 32 * u;
+        t[u] = q < p1 ? *(const f32x4*)(g + q * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        yy[u] = (q < p1 && act != EGNE_ACT_NONE) ? *(const f32x4*)(y + q * ys + yo + c) : f32x4{1.f, 1.f, 1.f, 1.f};
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s[e] += t[e];
-        const unsigned b = __float_as_uint(t[e]) & 0x7fffffffu;
-        mb = b > mb ? b : mb;
+      for (int u = 0; u < 4; ++u) {
+        const long long q = p + 32 * u;
+        if (act != EGNE_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[u][e] = yy[u][e] > 0.f ? t[u][e] : (act == EGNE_ACT_LEAKY ? 0.01f * t[u][e] : 0.f);
+          if (q < p1) *(f32x4*)(g + q * gs + go + c) = t[u];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[e] += t[u][e];
+          const unsigned b = __float_as_uint(t[u][e]) & 0x7fffffffu;
+          mb = b > mb ? b : mb;
+        }
       }
     }
   }
@@ -167,7 +176,9 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float* __restrict_
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ gy, long long gs, int go, int act_in,
                                                         int Cp, long long npix_per_n, int nchunk, int per_sample,
-                                                        double* __restrict__ ws) {
+                                                        double* __restrict__ ws, int poolW) {
+  // poolW > 0: gy is the gradient of the 2x2-average-POOLED tensor ([n][H/2][W/2]); pixel p = (y, x) of a W = poolW wide map
+  // receives a quarter of its pooled cell's gradient (egne_norm_pool2_bwd)
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
   const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
   const int c = cg * 32 + v * 4;
@@ -178,15 +189,31 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float* __restrict_
     const f32x4 sc = *(const f32x4*)(scale + (long long)(per_sample ? n : 0) * Cp + c);
     const f32x4 sh = *(const f32x4*)(shift + (long long)(per_sample ? n : 0) * Cp + c);
     const long long nb = (long long)n * npix_per_n;
-    for (long long p = p0 + row; p < p1; p += 32) {
-      const f32x4 xv = *(const f32x4*)(x + (nb + p) * xs + xo + c);
-      f32x4 g = *(const f32x4*)(gy + (nb + p) * gs + go + c);
-      const f32x4 xh = xv * sc + sh;
+    for (long long p = p0 + row; p < p1; p += 128) {        // four rows per trip: loads issued together (same summation order)
+      f32x4 xv4[4], g4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
-        else if (act_in == EGNE_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
-        s1[e] += g[e]; s2[e] += (double)g[e] * xh[e];
+      for (int u = 0; u < 4; ++u) {
+        const long long q = p + 32 * u;
+        const bool ok = q < p1;
+        xv4[u] = ok ? *(const f32x4*)(x + (nb + q) * xs + xo + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (poolW) {
+          const int py = (int)(q / poolW), px = (int)(q - (long long)py * poolW);
+          g4[u] = ok ? 0.25f * *(const f32x4*)(gy + ((nb >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c)
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          g4[u] = ok ? *(const f32x4*)(gy + (nb + q) * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 g = g4[u];
+        const f32x4 xh = xv4[u] * sc + sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
+          else if (act_in == EGNE_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+          s1[e] += g[e]; s2[e] += (double)g[e] * xh[e];
+        }
       }
     }
   }
@@ -221,7 +248,7 @@ __global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo
                                const float* __restrict__ shift, const float* __restrict__ gamma,
                                const float* __restrict__ gy, long long gs, int go, int act_in, int Cp,
                                long long npix_per_n, int Bn, int per_sample, const float* __restrict__ sums,
-                               float* __restrict__ gx, long long gxs, int gxo) {
+                               float* __restrict__ gx, long long gxs, int gxo, int poolW) {
   const int nv = Cp >> 2;
   const long long total = (long long)Bn * npix_per_n * nv;
   const float invN = 1.f / (float)npix_per_n;
@@ -232,7 +259,14 @@ __global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo
     const f32x4 sc = *(const f32x4*)(scale + (long long)n * Cp + c);
     const f32x4 sh = *(const f32x4*)(shift + (long long)n * Cp + c);
     const f32x4 xv = *(const f32x4*)(x + pp * xs + xo + c);
-    f32x4 g = *(const f32x4*)(gy + pp * gs + go + c);
+    f32x4 g;
+    if (poolW) {      // per_sample mode, even H and W (checked by the entry point)
+      const long long p = pp - (long long)n * npix_per_n;
+      const int py = (int)(p / poolW), px = (int)(p - (long long)py * poolW);
+      g = 0.25f * *(const f32x4*)(gy + (((long long)n * npix_per_n >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c);
+    } else {
+      g = *(const f32x4*)(gy + pp * gs + go + c);
+    }
     const f32x4 xh = xv * sc + sh;
     f32x4* dst = (f32x4*)(gx + pp * gxs + gxo + c);
     f32x4 o = *dst;
@@ -591,10 +625,10 @@ extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_
   return (int64_t)Bn * chunks_for(npix, Cp, Bn) * Cp * 2 * sizeof(double);
 }
 
-extern "C" int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
-                             const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
-                             int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
-                             int C, void* ws, void* stream) {
+static int norm_bwd_impl(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                         const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                         int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                         int C, void* ws, void* stream, int poolW) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(gy, gs, go, Cp) && slice_ok(gx, gxs, gxo, Cp), "norm_bwd: bad slices");
   EGNE_REQUIRE(scale && shift && sums && ws && B > 0 && HW > 0, "norm_bwd: null pointer");
   EGNE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || !per_sample), "norm_bwd: dgamma/dbeta only for batch statistics");
@@ -603,13 +637,31 @@ extern "C" int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* sc
   const int nchunk = chunks_for(npix, Cp, Bn);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(norm_bwd_partial, dim3(nchunk, (Cp + 31) / 32, Bn), dim3(256), 0, st, x, (long long)xs, xo, scale, shift,
-                     gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws);
+                     gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws, poolW);
   hipLaunchKernelGGL(norm_bwd_final, dim3((Bn * Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
                      dgamma, dbeta, C);
   hipLaunchKernelGGL(norm_bwd_apply, dim3(grid_for((long long)Bn * npix * (Cp / 4))), dim3(256), 0, st, x, (long long)xs, xo,
                      scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,
-                     gxo);
+                     gxo, poolW);
   return egne::check_launch("egne_norm_bwd");
+}
+
+extern "C" int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                             const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                             int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                             int C, void* ws, void* stream) {
+  return norm_bwd_impl(x, xs, xo, scale, shift, gamma, gy, gs, go, act_in, Cp, B, HW, per_sample, gx, gxs, gxo, sums, dgamma, dbeta,
+                       C, ws, stream, 0);
+}
+
+// Backward of egne_norm_act_pool2 (zp = avg_pool2d(act(x*scale + shift), 2), per-sample statistics): the InstanceNorm backward
+// with gy[n][y][x] = gzp[n][y/2][x/2] / 4 read straight from the pooled gradient.  H and W even.
+extern "C" int egne_norm_pool2_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                                   const float* gzp, int64_t gs, int go, int act_in, int Cp, int B, int H, int W,
+                                   float* gx, int64_t gxs, int gxo, float* sums, void* ws, void* stream) {
+  EGNE_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "norm_pool2_bwd: even map sizes only (got %dx%d)", H, W);
+  return norm_bwd_impl(x, xs, xo, scale, shift, nullptr, gzp, gs, go, act_in, Cp, B, H * W, 1, gx, gxs, gxo, sums, nullptr, nullptr,
+                       0, ws, stream, W);
 }
 
 extern "C" int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,

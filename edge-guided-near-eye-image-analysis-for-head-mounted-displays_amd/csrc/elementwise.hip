@@ -48,10 +48,14 @@ __global__ __launch_bounds__(256) void norm_stats_partial(const float* __restric
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < Cp) {
     const float* base = x + (long long)n * npix_per_n * pix_stride + ch_off + c;
-    for (long long p = p0 + row; p < p1; p += 32) {
-      const f32x4 t = *(const f32x4*)(base + p * pix_stride);
+    for (long long p = p0 + row; p < p1; p += 128) {        // four rows per trip: loads issued together (same summation order)
+      f32x4 t[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s[e] += t[e]; q[e] += (double)t[e] * t[e]; }
+      for (int u = 0; u < 4; ++u) t[u] = p + 32 * u < p1 ? *(const f32x4*)(base + (p + 32 * u) * pix_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += t[u][e]; q[e] += (double)t[u][e] * t[u][e]; }
     }
   }
   __shared__ double sh[32][8][8];

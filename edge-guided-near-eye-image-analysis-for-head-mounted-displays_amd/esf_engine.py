@@ -52,6 +52,9 @@ def dec_sizes(chz, growth, add_edge, variant):
     return dict(ip=plain_ip, op=plain_op, skip=skip)
 
 
+TD_POOL_FIRST_TRAIN = os.environ.get("EGNE_TD_POOL_FIRST_TRAIN", "1") != "0"
+
+
 def _cl(conv, layout, pad=(0, 0), act=ACT_NONE, **kw):
     l = ConvLayer([conv.weight], [conv.bias] if conv.bias is not None else None, layout, pad=pad, act=act, **kw)
     from . import engine
@@ -238,13 +241,24 @@ def build_forward_plan(model, B, H, W, dev, training):
         if pools[i] and not training and pl.td_pool_fusable(tdl, tin, D[i + 1]["x"]) and h % 2 == 0 and w % 2 == 0:
             # eval plans: the 2x2 average folded into the 1x1's operand load (linear ops commute): one launch, no pooled tensor
             pl.conv1x1_pooled(tdl, tin, D[i + 1]["x"], NB, h, w, name=nm + ".TD")
-        elif pools[i] and not training:
-            # eval plans: pool first, then the 1x1 conv at quarter resolution (linear ops commute)
+        elif pools[i] and (not training or (TD_POOL_FIRST_TRAIN and h % 2 == 0 and w % 2 == 0)):
+            # pool first, then the 1x1 conv at quarter resolution (linear ops commute; avg_pool2d drops an odd last row / column
+            # on both routes).  Training plans too: the 1x1, its weight and data gradients all run on a quarter of the pixels, and
+            # the InstanceNorm backward takes a quarter of the pooled cell's gradient (egne_norm_pool2_bwd)
             pb_ = pl.buf(NB, h // 2, w // 2, d["out"].Cp + d["x"].Cp)
             q_out, q_x = Piece(pb_, 0, d["out"].C, d["out"].Cp), Piece(pb_, d["out"].Cp, d["x"].C, d["x"].Cp)
             for src, dstp, (a_, b_) in ((d["out"], q_out, (sc2, sh2)), (d["x"], q_x, (sc, sh))):
                 pl.raw(L.egne_norm_act_pool2, (src.ptr, src.stride, src.off, a_.data_ptr(), b_.data_ptr(), ACT_LEAKY,
                                                dstp.ptr, dstp.stride, dstp.off, NB, h, w, src.Cp), nm + ".TDpool")
+                if training:
+                    def emit_pool(bw, src=src, dstp=dstp, a_=a_, b_=b_, h=h, w=w, nm=nm):
+                        gq, gs_ = pl.gp(dstp), pl.gp(src)
+                        sums = bw.vec(NB * src.Cp * 2)
+                        wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(NB, h * w, src.Cp, 1)) + 7) // 8, dtype=torch.float64)
+                        bw.raw(L.egne_norm_pool2_bwd, (src.ptr, src.stride, src.off, a_.data_ptr(), b_.data_ptr(), gq.ptr, gq.stride,
+                                                       gq.off, ACT_LEAKY, src.Cp, NB, h, w, gs_.ptr, gs_.stride, gs_.off,
+                                                       sums.data_ptr(), wsn.data_ptr()), nm + ".TDpool.bwd")
+                    pl.tape.append(emit_pool)
             pl.conv(tdl, [q_out, q_x], D[i + 1]["x"], NB, h // 2, w // 2, name=nm + ".TD")
         elif pools[i]:
             td = pl.buf(NB, h, w, pad8(outs[i]))
