@@ -44,6 +44,7 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "0") != "0"   # weight gradients on a second stream (measured: no gain, 433.6 vs 434.0 frames/s at B=64 -- either kernel fills the LDS of every CU, so they do not co-reside)
 WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans: steps between re-measuring max |w| of a split-f16 pack (one host sync each)
 TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "1") != "0"     # training plans: split-f16 (22-bit products) 3x3 forward convolutions and data gradients, pre-scales taken on the device
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
@@ -457,6 +458,7 @@ class Plan:
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
+        self.side_calls, self.side_stream = {}, None   # call index -> event: weight-gradient launches overlapped with the data path
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _lib.lib()
 
@@ -533,9 +535,11 @@ class Plan:
             self._add(self.L.egne_absmax, (pc.ptr, pc.stride, pc.off, pc.Cp, npix, ptr), name + ".absmax", kind="absmax")
         d.dyn_scale = ptr
 
-    def _add(self, fn, args, name, flops=0.0, kind=None, cal=None):
+    def _add(self, fn, args, name, flops=0.0, kind=None, cal=None, side=False):
         if cal is not None and CALIBRATE:
             self.cal[len(self.calls)] = cal
+        if side:      # launched on the plan's second stream behind an event of the main one (Plan.run); joined at the end of the run
+            self.side_calls[len(self.calls)] = None
         self.calls.append((fn, args, name))
         self.meta.append((kind or name.split(".")[0], flops))
 
@@ -1058,7 +1062,7 @@ class Plan:
         bw.keep.append(gw)
         flops = 2.0 * npix * layer.Cout * layer.Cin * layer.kh * layer.kw
         bw._add(L.egne_conv2d_wgrad, (C.byref(d), gy.ptr, gy.stride, gy.off, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
-                                      gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad")
+                                      gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad", side=WGRAD_SIDE_STREAM)
         gin = Piece(gy.buf, gy.off, layer.Cout, Cs, gy.n0)
         for i, pc in enumerate(pieces):
             if pc.nograd:
@@ -1165,6 +1169,8 @@ class Plan:
         st = _lib.stream_ptr()
         if self.cal and (repacked or not self.calibrated):
             return self._run_calibrating(st)
+        if self.side_calls:
+            return self._run_two_streams(st, events)
         if events is None:
             for fn, args, name in self.calls:
                 rc = fn(*args, st)
@@ -1184,6 +1190,37 @@ class Plan:
             if rc != 0:
                 _lib.check(rc, name)
             events.append((kind, flops, e0, e1, name))
+
+    def _run_two_streams(self, st, events):
+        """Backward plans: the weight-gradient launches (MFMA bound, reading gz and the saved input) go to a second stream so
+        that they overlap the HBM-bound data path that follows them on the main one (activation / normalisation backward, data
+        gradients with their read-modify-write).  A side launch waits for an event recorded on the main stream where the plan
+        placed it (gz is final there; nothing later in the run writes what it reads); the main stream joins the side stream
+        at the end of the run, before the optimiser or the gradient all-reduce can see the weight gradients."""
+        main = torch.cuda.current_stream()
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+            for i in self.side_calls:
+                self.side_calls[i] = torch.cuda.Event()
+        side = self.side_stream
+        sp = C.c_void_p(side.cuda_stream)
+        for i, ((fn, args, name), (kind, flops)) in enumerate(zip(self.calls, self.meta)):
+            on_side = i in self.side_calls
+            if on_side:
+                ev = self.side_calls[i]
+                ev.record(main)
+                side.wait_event(ev)
+            timed = events is not None and (EVENT_KINDS is None or kind.split(":")[0] in EVENT_KINDS)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side if on_side else main)
+            rc = fn(*args, sp if on_side else st)
+            if timed:
+                e1.record(side if on_side else main)
+                events.append((kind, flops, e0, e1, name))
+            if rc != 0:
+                _lib.check(rc, name)
+        main.wait_stream(side)
 
 
 def _a_scale_for(vmax):
