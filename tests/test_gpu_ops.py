@@ -871,3 +871,89 @@ def test_msblock_dilated_group_with_fused_scores(G, B, H, W):
         for got, want in ((s0, want0), (s1, want1)):
             err = (got.cpu().double() - want).abs().max().item() / want.abs().max().item()
             assert err < 3e-6, "relative error %.2e" % err
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,mag", [(32, 32, 64, 96, 1.0), (64, 32, 61, 83, 3.0e3), (64, 64, 120, 160, 2.0e-6), (128, 128, 30, 40, 40.0),
+                                                (48, 40, 20, 24, 1.0e4)])
+def test_device_side_prescale_matches_the_host_calibration(G, Cin, Cout, H, W, mag):
+    """Training plans (engine.Plan.dyn_scales): the split-f16 pre-scale is derived inside the kernel from the bit pattern of
+    max|x| (egne_conv_desc.dyn_scale, written by egne_absmax on the stream) instead of a host-side calibration.  Both choose the
+    power of two that puts max|x| in [1024, 2048), so the two plans must produce THE SAME BITS at any activation magnitude
+    (gradient tensors of 1e-6, activations of 1e4), on the role-split / resident-weights, halo and flat kernels."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    B = 2
+    x = _rand(G, B, Cin, H, W) * mag
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout) * mag
+    outs = []
+    for dyn in (False, True):
+        pl = Plan(torch.device(DEV))
+        pl.dyn_scales = dyn
+        (px,) = to_nhwc_buf(pl, [x], B, H, W)
+        layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=2)
+        layer.split = True
+        out = pl.buf(B, H, W, pad8(Cout))
+        pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+        kinds = [m[0] for m in pl.meta]
+        assert any(k.startswith("conv_f16x3:") for k in kinds), kinds
+        assert ("absmax" in kinds) == dyn and bool(pl.cal) == (not dyn)
+        for _ in range(2):
+            pl.run()
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    truth = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    got = outs[1].permute(0, 3, 1, 2).double()[:, :Cout]
+    assert torch.isfinite(got).all()
+    assert (got - truth).abs().max().item() / truth.abs().max().item() < 2e-6
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(32, 32, 64, 96), (38, 64, 61, 83), (96, 96, 30, 40)])
+def test_split_data_gradient_layer(G, Cin, Cout, H, W):
+    """engine.SplitDgradLayer (backward of models/RITnet_v2.py:57-62's 3x3 convs, train.py:285): the data gradient as an ordinary
+    split-f16 3x3 over gz with flipped / transposed weights, accumulated onto what the slice already holds -- against
+    float64 autograd; the pre-scale comes from the device-side max|gz| word (gradient magnitudes of 1e-4)."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, SplitDgradLayer, pad8
+    B = 2
+    w = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
+    gz, acc0 = _rand(G, B, Cout, H, W) * 1e-4, _rand(G, B, Cin, H, W) * 1e-4
+    xd = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, w.double(), padding=1).backward(gz.double())
+    truth = xd.grad + acc0.double()
+    pl = Plan(torch.device(DEV))
+    pl.dyn_scales = True
+    fwd = ConvLayer([torch.nn.Parameter(w.to(DEV))], None, [(Cin, pad8(Cin))], pad=(1, 1))
+    dl = SplitDgradLayer(fwd, 0, torch.device(DEV))
+    pl.pre.append(dl.guard)
+    pg, pa = to_nhwc_buf(pl, [gz, acc0], B, H, W)
+    pl.conv(dl, [Piece(pg.buf, pg.off, Cout, pad8(Cout))], pa, B, H, W, residual=pa)
+    assert any(k.startswith("conv_f16x3:") for k, _ in pl.meta)
+    pl.run()
+    torch.cuda.synchronize()
+    got = pa.buf.cpu().permute(0, 3, 1, 2).double()[:, pa.off:pa.off + Cin]
+    assert (got - truth).abs().max().item() / truth.abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 24, 40), (40, 3, 30, 50), (64, 2, 120, 160)])
+def test_norm_pool2_bwd(G, C, B, H, W):
+    """egne_norm_pool2_bwd: backward of zp = avg_pool2d(leaky_relu(instance_norm(x)), 2) (Transition_down pooled in front of its
+    1x1, models/RITnet_v2.py:32-44) w.r.t. x, accumulated onto gx, against float64 autograd."""
+    from gpu_util import DEV
+    from egne_amd import _lib
+    L = _lib.lib()
+    x, gzp, g0 = _rand(G, B, C, H, W) * 2 + 0.3, _rand(G, B, C, H // 2, W // 2), _rand(G, B, C, H, W)
+    xd = x.double().requires_grad_(True)
+    F.avg_pool2d(F.leaky_relu(F.instance_norm(xd)), 2).backward(gzp.double())
+    truth = xd.grad + g0.double()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)       # noqa: E731
+    xn, gn, gx = nhwc(x), nhwc(gzp), nhwc(g0)
+    mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+    sc, sh = rstd.to(DEV).contiguous(), (-mean * rstd).to(DEV).contiguous()
+    sums = torch.zeros(B * C * 2, device=DEV)
+    ws = torch.zeros((int(L.egne_norm_bwd_workspace_bytes(B, H * W, C, 1)) + 7) // 8, dtype=torch.float64, device=DEV)
+    _lib.check(L.egne_norm_pool2_bwd(xn.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), gn.data_ptr(), C, 0, 2, C, B, H, W,
+                                     gx.data_ptr(), C, 0, sums.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), "norm_pool2_bwd")
+    torch.cuda.synchronize()
+    got = gx.cpu().permute(0, 3, 1, 2).double()
+    assert (got - truth).abs().max().item() / truth.abs().max().item() < 5e-6
