@@ -127,6 +127,7 @@ SIGNATURES = {
     "egne_conv2d_wgrad_splits": (i32, [C.POINTER(ConvDesc)]),
     "egne_conv2d_wgrad_workspace_bytes": (i64, [C.POINTER(ConvDesc)]),
     "egne_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, i64, i32, i32, i32, vp, C.POINTER(vp), vp, vp]),
+    "egne_conv2d_wgrad_f16": (i32, [C.POINTER(ConvDesc), vp, i64, i32, vp, i32, i32, vp, C.POINTER(vp), vp, vp]),
     "egne_pack_conv_weight_dgrad": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "egne_ellipse_fit": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "egne_ellipse_init_from_pred": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),

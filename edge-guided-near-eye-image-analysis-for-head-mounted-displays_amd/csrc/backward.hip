@@ -731,8 +731,8 @@ extern "C" int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* dp) {
 
 // gz: gradient w.r.t. the pre-activation output (Cout_store channels).  gw[g]: OIHW gradient tensors,
 // accumulated into.  kinv as in egne_pack_conv_weight.  ws: egne_conv2d_wgrad_workspace_bytes.
-extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,
-                                 const int32_t* kinv, float* const* gw, void* ws, void* stream) {
+static int wgrad_impl(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, const uint32_t* gz_dyn, int Cout, int Cin,
+                      const int32_t* kinv, float* const* gw, void* ws, void* stream) {
   EGNE_REQUIRE(dp && gz && kinv && gw && ws, "wgrad: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP, "wgrad: bad descriptor");
@@ -750,7 +750,11 @@ extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int6
   if (egne::wgrad_halo_supported(d, d.out_pix_stride)) {
     // the gradient buffer mirrors the output buffer (same pixel stride): the split count above assumed it
     EGNE_REQUIRE(gzs == d.out_pix_stride, "wgrad: gz stride %lld differs from the output stride %lld", (long long)gzs, (long long)d.out_pix_stride);
-    const int rc = egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
+    // split-f16 products when the caller supplies max|gz| on the device AND x has a pre-scale (normalised on load or the
+    // forward launch's device word); exact fp32 otherwise
+    const bool f16 = gz_dyn && (d.seg[0].scale || d.dyn_scale);
+    const int rc = f16 ? egne::wgrad_halo_f16_launch(d, gz, (long long)gzs, gzo, (const unsigned*)gz_dyn, (float*)ws, st)
+                       : egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
     if (rc != EGNE_OK) return rc;
   } else {
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
@@ -764,6 +768,16 @@ extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int6
                        Cin, kinv, d.CoutP, d.Ktot, gw[g]);
   }
   return egne::check_launch("egne_conv2d_wgrad");
+}
+
+extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,
+                                 const int32_t* kinv, float* const* gw, void* ws, void* stream) {
+  return wgrad_impl(dp, gz, gzs, gzo, nullptr, Cout, Cin, kinv, gw, ws, stream);
+}
+
+extern "C" int egne_conv2d_wgrad_f16(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, const uint32_t* gz_absmax_bits,
+                                     int Cout, int Cin, const int32_t* kinv, float* const* gw, void* ws, void* stream) {
+  return wgrad_impl(dp, gz, gzs, gzo, gz_absmax_bits, Cout, Cin, kinv, gw, ws, stream);
 }
 
 extern "C" int egne_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int kh, int kw, int ci0, int Cpiece,

@@ -37,6 +37,7 @@ int halo3_launch(const egne_conv_desc& d, hipStream_t st);
 bool wgrad_halo_supported(const egne_conv_desc& d, long long gzs);   // wgrad_halo.hip
 int wgrad_halo_splits(const egne_conv_desc& d);
 int wgrad_halo_launch(const egne_conv_desc& d, const float* gz, long long gzs, int gzo, float* ws, hipStream_t st);
+int wgrad_halo_f16_launch(const egne_conv_desc& d, const float* gz, long long gzs, int gzo, const unsigned* gz_dyn, float* ws, hipStream_t st);
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -44,6 +44,7 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
 WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "0") != "0"   # weight gradients on a second stream (measured: no gain, 433.6 vs 434.0 frames/s at B=64 -- either kernel fills the LDS of every CU, so they do not co-reside)
 WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans: steps between re-measuring max |w| of a split-f16 pack (one host sync each)
 TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "1") != "0"     # training plans: split-f16 (22-bit products) 3x3 forward convolutions and data gradients, pre-scales taken on the device
@@ -1051,7 +1052,11 @@ class Plan:
         bias = layer.biases[0] if layer.biases is not None else None
         split_dgrad = (bw.dyn_scales and F16X3_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
                        and layer.stride == 1 and layer.pad_mode == 0 and layer.G == 1 and layer.Cout_store >= 32)
-        gz_max = bw._new_slot() if split_dgrad else None          # max |gz| for the split-f16 data gradients, from this pass
+        # weight gradient on split-f16 products too where the halo form applies and the input has a pre-scale (wgrad_halo.hip)
+        split_wgrad = (bw.dyn_scales and F16X3_ENABLED and WGRAD_SPLIT and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1)
+                       and layer.dils[0] == 1 and layer.stride == 1 and layer.pad_mode == 0 and layer.G == 1 and len(pieces) == 1
+                       and (pieces[0].scale is not None or bool(d.dyn_scale)))
+        gz_max = bw._new_slot() if (split_dgrad or split_wgrad) else None     # max |gz| for the split-f16 gradients, from this pass
         bw.raw(L.egne_act_bwd_bias_absmax, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
                                             bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr(), gz_max),
                name + ".act_bwd")
@@ -1061,8 +1066,12 @@ class Plan:
         wsw = bw.vec((int(L.egne_conv2d_wgrad_workspace_bytes(C.byref(d))) + 3) // 4)
         bw.keep.append(gw)
         flops = 2.0 * npix * layer.Cout * layer.Cin * layer.kh * layer.kw
-        bw._add(L.egne_conv2d_wgrad, (C.byref(d), gy.ptr, gy.stride, gy.off, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
-                                      gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad", side=WGRAD_SIDE_STREAM)
+        if split_wgrad:
+            bw._add(L.egne_conv2d_wgrad_f16, (C.byref(d), gy.ptr, gy.stride, gy.off, gz_max, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
+                                              gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_f16x3:wgrad", side=WGRAD_SIDE_STREAM)
+        else:
+            bw._add(L.egne_conv2d_wgrad, (C.byref(d), gy.ptr, gy.stride, gy.off, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
+                                          gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad", side=WGRAD_SIDE_STREAM)
         gin = Piece(gy.buf, gy.off, layer.Cout, Cs, gy.n0)
         for i, pc in enumerate(pieces):
             if pc.nograd:

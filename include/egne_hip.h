@@ -458,6 +458,11 @@ int egne_conv2d_wgrad_splits(const egne_conv_desc* d);
 int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* d);
 int egne_conv2d_wgrad(const egne_conv_desc* d, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,
                       const int32_t* kinv, float* const* gw, void* ws, void* stream);
+/* egne_conv2d_wgrad_f16: the same with split-f16 products (3 x v_mfma_f32_32x32x16_f16, fp32 accumulation) for the 3x3 / stride 1 /
+ * pad 1 single-slice shapes when gz_absmax_bits (device word: bit pattern of max|gz|, written by egne_act_bwd_bias_absmax) is given
+ * and the input carries a pre-scale (normalised on load, or d->dyn_scale from the forward launch); exact fp32 otherwise. */
+int egne_conv2d_wgrad_f16(const egne_conv_desc* d, const float* gz, int64_t gzs, int gzo, const uint32_t* gz_absmax_bits,
+                          int Cout, int Cin, const int32_t* kinv, float* const* gw, void* ws, void* stream);
 int egne_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int kh, int kw, int ci0, int Cpiece,
                                 int CoutPp, int Ktotp, int frag, float* out, void* stream);
 

@@ -957,3 +957,51 @@ def test_norm_pool2_bwd(G, C, B, H, W):
     torch.cuda.synchronize()
     got = gx.cpu().permute(0, 3, 1, 2).double()
     assert (got - truth).abs().max().item() / truth.abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,norm,mag", [(2, 32, 32, 64, 96, False, 1.0), (2, 38, 64, 61, 83, True, 1.0), (1, 96, 96, 30, 40, False, 1e-5),
+                                                       (3, 64, 32, 120, 160, False, 300.0), (2, 32, 32, 240, 320, True, 1e-6)])
+def test_conv3x3_weight_gradient_split_f16(G, B, Cin, Cout, H, W, norm, mag):
+    """wgrad_halo.hip, split-f16 form (training plans; train.py:285-286's loss.backward() for models/RITnet_v2.py:57-62): the
+    weight gradient of a 3x3 convolution on 3 f16 MFMAs per product, x pre-scaled by the forward launch's device word (or the
+    fixed scale of inputs normalised on load), gz by the word of act_bwd_bias_absmax -- against float64 autograd at gradient
+    magnitudes from 1e-6 to 300, ragged tiles and channel tails included."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = _rand(G, B, Cin, H, W) * 2 + 0.25
+    w = (_rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5)).double().requires_grad_(True)
+    b = _rand(G, Cout).double().requires_grad_(True)
+    gy = _rand(G, B, Cout, H, W) * mag
+    xe = x.double()
+    if norm:
+        mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+        xe = F.leaky_relu(F.instance_norm(x.double()))
+    y = F.leaky_relu(F.conv2d(xe, w, b, padding=1))
+    y.backward(gy.double())
+    pl = Plan(torch.device(DEV), train=True)
+    assert pl.dyn_scales
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    px.nograd = True
+    if norm:
+        scp, shp = torch.zeros(B, px.Cp, device=DEV), torch.zeros(B, px.Cp, device=DEV)
+        scp[:, :Cin], shp[:, :Cin] = rstd.to(DEV), (-mean * rstd).to(DEV)
+        pl.keep += [scp, shp]
+        px = px.with_norm(scp, shp, 2)
+        px.nograd = True
+    wd, bd = torch.nn.Parameter(w.detach().float().to(DEV)), torch.nn.Parameter(b.detach().float().to(DEV))
+    wd.grad, bd.grad = torch.zeros_like(wd), torch.zeros_like(bd)
+    layer = ConvLayer([wd], [bd], [(Cin, pad8(Cin))], pad=(1, 1), act=2)
+    layer.split = True
+    out = pl.buf(B, H, W, pad8(Cout))
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+    bw = pl.build_backward()
+    assert any(k == "conv_f16x3:wgrad" for k, _ in bw.meta), [k for k, _ in bw.meta]
+    for _ in range(2):                      # the second pass accumulates onto the first
+        pl.run()
+        pl.gbuf(out).zero_()
+        pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV)
+        bw.run()
+    torch.cuda.synchronize()
+    ew = (wd.grad.cpu().double() / 2 - w.grad).abs().max().item() / w.grad.abs().max().item()
+    eb = (bd.grad.cpu().double() / 2 - b.grad).abs().max().item() / b.grad.abs().max().item()
+    assert ew < 1e-5 and eb < 1e-5, (ew, eb)       # fp32 accumulation over up to 150 000 pixels per weight
