@@ -510,6 +510,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 weight gradient with every (32 co, 32 k) block of the layer in ONE workgroup (dense-block conv21 / conv31,
+// decoder conv11 / conv21, Transition_down: models/RITnet_v2.py:38,59,61,86).  The tile-per-workgroup kernel above restages gz for
+// every input chunk and x for every output block (12 blocks: 24 tile loads per pixel chunk where 8 would do, L2-bound at ~30
+// TFLOP/s).  Here a workgroup walks its pixel range in chunks of CH pixels, stages all nco gz tiles and all nkc x tiles of the chunk
+// once ([pixel][36] floats each, the fused InstanceNorm affine + activation applied while staging), and its four waves share
+// the (co block, k chunk) pairs: wave w owns pairs w, w+4, ... for ALL pixels, so there is no cross-wave reduction and every HBM
+// byte is read once.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Partials: ws[split][CoutP][Ktot] as for the other forms.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int W1_MAXT = 12;      // tiles (gz + x) of a chunk
+constexpr int W1LD = 36;         // LDS row pitch (floats): 16-byte stores, conflict-free operand reads
+struct W1Tab { short seg[W1_MAXT]; short c0[W1_MAXT]; short kofs[W1_MAXT]; };
+
+template <int PPW, int CH>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_allpairs_kernel(const egne_conv_desc p, const float* __restrict__ gz, long long gzs,
+                                                                     int gzo, int nsplit, int nco, int nkc, W1Tab tab,
+                                                                     float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float w1lds[];     // [nco + nkc][CH][W1LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nt = nco + nkc, npairs = nco * nkc;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long per = ((M + nsplit - 1) / nsplit + CH - 1) / CH * CH;
+  const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
+  const int hw = p.Ho * p.Wo;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
+  constexpr int NR = CH / 32;       // pixel rows of a tile per thread
+  f32x16 acc[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) acc[i] = (f32x16)(0.f);
+
+  f32x4 v[W1_MAXT][NR];
+  auto load_chunk = [&](long long mc) {
+#pragma unroll
+    for (int j = 0; j < W1_MAXT; ++j) {
+      if (j < nt) {
+        const bool isg = j < nco;
+        const egne_seg& sg = p.seg[isg ? 0 : tab.seg[j]];
+        const int c = (isg ? j * 32 : tab.c0[j]) + lc;
+        const bool cok = isg ? c < p.Cout_store : c < sg.Cp;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const long long m = mc + lr + 32 * i;
+          const bool ok = cok && m < m_end;
+          const float* ptr = !ok ? egne_zero_page : (isg ? gz + m * gzs + gzo + c : sg.ptr + m * sg.pix_stride + sg.ch_off + c);
+          v[j][i] = *(const f32x4*)ptr;
+        }
+      }
+    }
+  };
+  if (m_begin < m_end) load_chunk(m_begin);
+  for (long long mc = m_begin; mc < m_end; mc += CH) {
+    // fused load transform of the x tiles (as in the forward convolution)
+#pragma unroll
+    for (int j = 0; j < W1_MAXT; ++j) {
+      if (j >= nco && j < nt) {
+        const egne_seg& sg = p.seg[tab.seg[j]];
+        const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+        const int c = tab.c0[j] + lc;
+        if (sg.scale) {
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const long long m = mc + lr + 32 * i;
+            const bool ok = c < sg.Cp && m < m_end;
+            const int bb = ok ? (int)(m / hw) : 0;
+            const f32x4 sc = *(const f32x4*)(ok ? sg.scale + (long long)bb * sg.Cp + c : egne_zero_page);
+            const f32x4 sh = *(const f32x4*)(ok ? sg.shift + (long long)bb * sg.Cp + c : egne_zero_page);
+            f32x4 t = v[j][i] * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], t[e] * slope_in);
+            v[j][i] = ok ? t : (f32x4)(0.f);
+          }
+        } else if (slope_in != 1.f) {
+#pragma unroll
+          for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][i][e] = fmaxf(v[j][i][e], v[j][i][e] * slope_in);
+        }
+      }
+    }
+    __syncthreads();      // every wave is done with the previous chunk's tiles
+#pragma unroll
+    for (int j = 0; j < W1_MAXT; ++j)
+      if (j < nt) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) *(f32x4*)&w1lds[(j * CH + lr + 32 * i) * W1LD + lc] = v[j][i];
+      }
+    __syncthreads();
+    if (mc + CH < m_end) load_chunk(mc + CH);       // next chunk's loads fly during this chunk's MFMAs
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = wave + 4 * i;
+      if (q < npairs) {
+        const int kc = q / nco, ct = q - kc * nco;
+        const float* As = w1lds + (ct * CH) * W1LD;
+        const float* Bs = w1lds + ((nco + kc) * CH) * W1LD;
+#pragma unroll 8
+        for (int s = 0; s < CH / 2; ++s)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * s + lh) * W1LD + li], Bs[(2 * s + lh) * W1LD + li], acc[i], 0, 0, 0);
+      }
+    }
+  }
+  // lane holds column k = li of rows co = (r&3) + 8*(r>>2) + 4*lh of its pairs' blocks
+  float* dst = ws + (long long)blockIdx.x * p.ngroups * (long long)p.CoutP * p.Ktot;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int q = wave + 4 * i;
+    if (q < npairs) {
+      const int kc = q / nco, ct = q - kc * nco;
+      const int j = nco + kc;
+      const int k = tab.c0[j] + li;
+      if (k < p.seg[tab.seg[j]].Cp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          dst[(long long)co * p.Ktot + tab.kofs[j] + k] = acc[i][r];
+        }
+      }
+    }
+  }
+}
+
 // sum the split partials and add into the OIHW gradient of group g
 // sum the split partials and add into the OIHW gradient of group g: a block = 32 elements x 8 interleaved split ranges,
 // combined through LDS in a fixed order (deterministic)
@@ -707,10 +829,33 @@ extern "C" int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, 
   return egne::check_launch("egne_conf_loss_bwd");
 }
 
+// all-pairs 1x1 form: shapes it takes, chunk length and pairs per wave
+static bool w1_supported(const egne_conv_desc& d, int* nco_, int* nkc_, int* ch_) {
+  static const bool off = [] { const char* e = getenv("EGNE_WGRAD_1X1"); return e && e[0] == '0'; }();
+  if (off || d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad_h != 0 || d.pad_w != 0 || d.ngroups != 1 || d.H != d.Ho || d.W != d.Wo) return false;
+  int nkc = 0;
+  for (int s = 0; s < d.nseg; ++s) nkc += (d.seg[s].Cp + 31) / 32;
+  const int nco = d.CoutP / 32;
+  // (two or three blocks: the tile-per-workgroup kernel already runs near the HBM rate and keeps all four waves busy -- measured
+  //  921 vs 1151 us for 64 -> 32 at 240x320; from six blocks on the restaging dominates: 12 blocks at 120x160 1596 -> 1224 us)
+  if (nco + nkc > W1_MAXT || nco * nkc > 32 || nco * nkc < 6 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
+  *nco_ = nco; *nkc_ = nkc;
+  *ch_ = (nco + nkc) * 64 * W1LD * 4 <= 72 * 1024 ? 64 : 32;      // two workgroups per CU where the tiles allow
+  return true;
+}
+
+static int w1_splits(const egne_conv_desc& d, int ch) {
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  long long ns = (M + ch * 4 - 1) / (ch * 4);      // at least four chunks per workgroup
+  if (ns > 512) ns = 512;
+  return (int)(ns < 1 ? 1 : ns);
+}
+
 extern "C" int egne_conv2d_wgrad_splits(const egne_conv_desc* dp) {
   if (!dp) return 0;
   const egne_conv_desc& d = *dp;
   if (egne::wgrad_halo_supported(d, d.out_pix_stride)) return egne::wgrad_halo_splits(d);
+  { int a, b2, ch; if (w1_supported(d, &a, &b2, &ch)) return w1_splits(d, ch); }
   int per_tap = 0;
   for (int s = 0; s < d.nseg; ++s) per_tap += (d.seg[s].Cp + 31) / 32;
   const long long tiles = (long long)(d.CoutP / 32) * per_tap * d.kh * d.kw * d.ngroups;
@@ -755,6 +900,29 @@ static int wgrad_impl(const egne_conv_desc* dp, const float* gz, int64_t gzs, in
     const bool f16 = gz_dyn && (d.seg[0].scale || d.dyn_scale);
     const int rc = f16 ? egne::wgrad_halo_f16_launch(d, gz, (long long)gzs, gzo, (const unsigned*)gz_dyn, (float*)ws, st)
                        : egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
+    if (rc != EGNE_OK) return rc;
+  } else if (int nco = 0, nkc = 0, ch = 0; w1_supported(d, &nco, &nkc, &ch)) {
+    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
+    W1Tab tab{};
+    int j = nco, kofs = 0;
+    for (int s = 0; s < d.nseg; ++s) {
+      for (int c0 = 0; c0 < d.seg[s].Cp; c0 += 32, ++j) { tab.seg[j] = (short)s; tab.c0[j] = (short)c0; tab.kofs[j] = (short)kofs; }
+      kofs += d.seg[s].Cp;
+    }
+    const int ppw = (nco * nkc + 3) / 4;
+    const size_t lds = (size_t)(nco + nkc) * ch * W1LD * sizeof(float);
+    auto go = [&](auto kern) -> int {
+      static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+      if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "wgrad 1x1: cannot raise the dynamic LDS limit");
+      hipLaunchKernelGGL(kern, dim3(nsplit), dim3(256), lds, st, d, gz, (long long)gzs, gzo, nsplit, nco, nkc, tab, (float*)ws);
+      return EGNE_OK;
+    };
+    int rc;
+    if (ch == 64) rc = ppw <= 1 ? go(conv1x1_wgrad_allpairs_kernel<1, 64>) : ppw <= 2 ? go(conv1x1_wgrad_allpairs_kernel<2, 64>)
+                     : ppw <= 3 ? go(conv1x1_wgrad_allpairs_kernel<3, 64>) : ppw <= 4 ? go(conv1x1_wgrad_allpairs_kernel<4, 64>)
+                     : go(conv1x1_wgrad_allpairs_kernel<8, 64>);
+    else rc = ppw <= 2 ? go(conv1x1_wgrad_allpairs_kernel<2, 32>) : ppw <= 4 ? go(conv1x1_wgrad_allpairs_kernel<4, 32>)
+              : go(conv1x1_wgrad_allpairs_kernel<8, 32>);
     if (rc != EGNE_OK) return rc;
   } else {
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");

@@ -1005,3 +1005,52 @@ def test_conv3x3_weight_gradient_split_f16(G, B, Cin, Cout, H, W, norm, mag):
     ew = (wd.grad.cpu().double() / 2 - w.grad).abs().max().item() / w.grad.abs().max().item()
     eb = (bd.grad.cpu().double() / 2 - b.grad).abs().max().item() / b.grad.abs().max().item()
     assert ew < 1e-5 and eb < 1e-5, (ew, eb)       # fp32 accumulation over up to 150 000 pixels per weight
+
+
+@pytest.mark.parametrize("chans,normed,Cout,B,H,W", [((32, 32), (), 32, 2, 64, 96), ((38, 64, 64), (0,), 64, 2, 61, 83),
+                                                       ((76, 96, 96), (0, 2), 96, 3, 30, 50), ((64, 38), (0, 1), 76, 2, 60, 80),
+                                                       ((32,), (), 38, 2, 24, 40)])
+def test_conv1x1_weight_gradient_all_blocks_in_one_workgroup(G, chans, normed, Cout, B, H, W):
+    """backward.hip conv1x1_wgrad_allpairs_kernel (weight gradient of the 1x1 convs over concatenated slices: models/RITnet_v2.py
+    :38,59,61,86 under train.py:285-286): all (32 co, 32 k) blocks from one staging of the pixel chunk, InstanceNorm affine +
+    LeakyReLU fused on the slices that carry one, channel tails (38, 76), chunk tails and the small-map fallback to the
+    tile-per-workgroup kernel -- weight, bias and data gradients against float64 autograd."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    xs = [_rand(G, B, c, H, W) * 1.5 + 0.2 for c in chans]
+    w = (_rand(G, Cout, sum(chans), 1, 1) / sum(chans) ** 0.5).double().requires_grad_(True)
+    b = _rand(G, Cout).double().requires_grad_(True)
+    gy = _rand(G, B, Cout, H, W)
+    xd = [x.double().requires_grad_(True) for x in xs]
+    xe = [F.leaky_relu(F.instance_norm(x)) if i in normed else x for i, x in enumerate(xd)]
+    F.conv2d(torch.cat(xe, 1), w, b).backward(gy.double())
+    pl = Plan(torch.device(DEV), train=True)
+    pieces = to_nhwc_buf(pl, xs, B, H, W)
+    pin = []
+    for i, (x, pc) in enumerate(zip(xs, pieces)):
+        if i in normed:
+            mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+            sc, sh = torch.zeros(B, pc.Cp, device=DEV), torch.zeros(B, pc.Cp, device=DEV)
+            sc[:, :pc.C], sh[:, :pc.C] = rstd.to(DEV), (-mean * rstd).to(DEV)
+            pl.keep += [sc, sh]
+            pc = pc.with_norm(sc, sh, 2)
+            pc.nograd = True        # (the normalisation backward is covered by the network fixtures)
+        pin.append(pc)
+    wd, bd = torch.nn.Parameter(w.detach().float().to(DEV)), torch.nn.Parameter(b.detach().float().to(DEV))
+    wd.grad, bd.grad = torch.zeros_like(wd), torch.zeros_like(bd)
+    layer = ConvLayer([wd], [bd], [(p.C, p.Cp) for p in pin])
+    out = pl.buf(B, H, W, pad8(Cout))
+    pl.conv(layer, pin, Piece(out, 0, Cout), B, H, W)
+    bw = pl.build_backward()
+    pl.run()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV)
+    bw.run()
+    torch.cuda.synchronize()
+    ew = (wd.grad.cpu().double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    eb = (bd.grad.cpu().double() - b.grad).abs().max().item() / b.grad.abs().max().item()
+    assert ew < 1e-5 and eb < 1e-5, (ew, eb)
+    for i, (pc, x) in enumerate(zip(pieces, xd)):
+        if i in normed:
+            continue
+        gx = pl.gbuf(pc.buf).cpu()[..., pc.off:pc.off + pc.C].permute(0, 3, 1, 2).double()
+        assert (gx - x.grad).abs().max().item() / x.grad.abs().max().item() < 1e-5
