@@ -13,7 +13,7 @@ measures every leg BASELINE.json's metric / north_star name and prints ONE JSON 
   exact_fp32           the same step with the split-f16 products switched off (every conv on v_mfma_f32_32x32x2_f32);
   train                fwd+bwd: frozen edge net forward, ESF-Net forward + backward, gradient all-reduce (N>1), Adam
                        step, batch 256 per GPU (BASELINE.json configs[2] shape; fp32 storage, fp32 accumulation; 3x3 forward
-                       convolutions and their data gradients on split-f16 products, weight gradients and 1x1 exact fp32).
+                       convolutions, their data and weight gradients on split-f16 products, 1x1 convolutions exact fp32).
 
 For N>1 the driver launches one process per GPU (torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE in the env);
 `python bench.py --gpus N` without that environment spawns the N rank processes itself (before anything touches the
@@ -272,7 +272,7 @@ class Bench:
         r_split = {"bound": "mfma", "kernel": "split-f16 conv family (fp32 tensors, 3 x v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 per product, fp32 "
                    "accumulate): conv_f16x3_big_kernel, conv3x3_rw_kernel, conv3x3_rs_kernel, fused_1x1_3x3_kernel, msblock_dil_kernel, "
                    "conv3x3_halo_f16_kernel, conv_f16x3_kernel, conv1x1 kernels; inference plans of BDCN and ESF-Net, 3x3 forward convolutions "
-                   "and data gradients of training plans",
+                   "data and weight gradients of training plans",
                    "achieved": round(sp_ach, 2), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1),
                    "unit": "TFLOP/s (algorithmic, fp32-equivalent; peak = 2500 dense f16 MFMA / 3 MFMAs per product)",
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": None,
@@ -375,10 +375,10 @@ def main():
            "value": None, "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 storage; inference products split into f16 hi/lo pairs (3 f16 MFMAs per product, 22-bit significand), "
-                    "f32 accumulate; training: the same products for 3x3 forward convolutions and data gradients, exact f32 MFMA for weight gradients and 1x1", "data": "synthetic"}
+                    "f32 accumulate; training: the same products for 3x3 forward convolutions, data and weight gradients, exact f32 MFMA for 1x1", "data": "synthetic"}
     arith = ("fp32 tensors everywhere; inference: split-f16 MFMA products (22-bit significand) with fp32 accumulation where eligible, "
-             "exact fp32 elsewhere; training: split-f16 products for the 3x3 forward convolutions and their data gradients (pre-scales "
-             "measured on the device every step), exact fp32 MFMA for weight gradients, 1x1 convolutions and everything else")
+             "exact fp32 elsewhere; training: split-f16 products for the 3x3 forward convolutions, their data and weight gradients (pre-scales "
+             "measured on the device every step), exact fp32 MFMA for 1x1 convolutions and everything else")
 
     if a.mode in ("all", "infer"):
         B, dt, ev = bn.leg_infer(a.steps, a.warmup, fit=a.fit and a.mode == "infer")
@@ -442,8 +442,8 @@ def main():
         tr = {"value": round(B * steps * world / dt, 2), "unit": "eye-frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
               "warmup": warm, "frames_per_gpu_per_step": B, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
               "what": "BASELINE.json configs[2] shape: %s.yaml (chz=%d) train step = frozen BDCN forward + ESF-Net forward + backward + "
-                      "gradient all-reduce + Adam, batch=%d/GPU, fp32 storage and accumulation (3x3 forward convs and data gradients on "
-                      "split-f16 products, weight gradients and 1x1 exact fp32; EGNE_TRAIN_SPLIT=0 for all-fp32)" % (a.config, a.chz, B),
+                      "gradient all-reduce + Adam, batch=%d/GPU, fp32 storage and accumulation (3x3 forward convs, data and weight gradients on "
+                      "split-f16 products, 1x1 exact fp32; EGNE_TRAIN_SPLIT=0 for all-fp32)" % (a.config, a.chz, B),
               "parallelism": "dp%d (one flat RCCL all-reduce of the gradient arena per step)" % world,
               "roofline": {k: r32[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms",
                                                "algorithmic_gflop_per_frame", "time_share")},

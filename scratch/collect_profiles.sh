@@ -29,8 +29,8 @@ python3 - "$out" <<'PY'
 import csv, glob, json, re, sys, collections
 out = sys.argv[1]
 SPLIT = ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel",
-         "fused_1x1_3x3_kernel", "msblock_dil_kernel", "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel", "conv3x3_rw_kernel", "conv1x1_pool_f16x3_kernel")
-FP32 = ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel")
+         "fused_1x1_3x3_kernel", "msblock_dil_kernel", "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel", "conv3x3_rw_kernel", "conv1x1_pool_f16x3_kernel", "conv3x3_wgrad_halo_f16_kernel")
+FP32 = ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel", "conv1x1_wgrad_allpairs_kernel")
 fam = lambda k: "split_f16" if any(s in k for s in SPLIT) else ("fp32_conv" if any(s in k for s in FP32) else "other")
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 per = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
