@@ -44,6 +44,7 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
 WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
 WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "0") != "0"   # weight gradients on a second stream (measured: no gain, 433.6 vs 434.0 frames/s at B=64 -- either kernel fills the LDS of every CU, so they do not co-reside)
 WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans: steps between re-measuring max |w| of a split-f16 pack (one host sync each)
@@ -333,11 +334,13 @@ class DgradLayer(ConvLayer):
     are the flipped / transposed pack of egne_pack_conv_weight_dgrad, the input is the gradient
     w.r.t. the pre-activation output (Cout_store channels)."""
 
-    def __init__(self, fwd, idx):
+    def __init__(self, fwd, idx, span=1):
         assert fwd.stride == 1 and fwd.pad_mode == 0 and fwd.G == 1, "dgrad: stride-1 zero-padded convs only"
         self.fwd, self.idx = fwd, idx
         self.ci0 = sum(c for c, _ in fwd.in_layout[:idx])
-        C_, Cp_ = fwd.in_layout[idx]
+        # ``span`` > 1: adjacent un-padded slices of one buffer taken as ONE output slice (gz is then read once for all of them)
+        assert span == 1 or all(c == cp for c, cp in fwd.in_layout[idx:idx + span])
+        C_, Cp_ = sum(c for c, _ in fwd.in_layout[idx:idx + span]), sum(cp for _, cp in fwd.in_layout[idx:idx + span])
         self.weights, self.biases = fwd.weights, None
         self.in_layout = [(fwd.Cout, fwd.Cout_store)]
         self.Cout, self.Cin = C_, fwd.Cout
@@ -1087,8 +1090,31 @@ class Plan:
             bw._add(L.egne_conv2d_wgrad, (C.byref(d), gy.ptr, gy.stride, gy.off, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
                                           gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad", side=WGRAD_SIDE_STREAM)
         gin = Piece(gy.buf, gy.off, layer.Cout, Cs, gy.n0)
+        # 1x1 over adjacent raw slices of one buffer (dense-block conv21 / conv31 over [x | x1 | x22]): one data-gradient launch
+        # for the whole run of slices instead of one per slice, each re-reading gz
+        merged, skip = {}, set()
+        if MERGE_DGRAD and layer.kh == 1 and layer.kw == 1 and layer.stride == 1 and layer.pad == (0, 0) and layer.pad_mode == 0 and layer.G == 1:
+            i = 0
+            while i < len(pieces):
+                j = i
+                ok = lambda q: not q.nograd and q.scale is None and q.C == q.Cp and not isinstance(q, PlanarPiece)   # noqa: E731
+                while (ok(pieces[i]) and j + 1 < len(pieces) and ok(pieces[j + 1]) and pieces[j + 1].buf is pieces[i].buf
+                       and pieces[j + 1].n0 == pieces[i].n0 and pieces[j + 1].off == pieces[j].off + pieces[j].Cp
+                       and sum(q.Cp for q in pieces[i:j + 2]) <= 128):
+                    j += 1
+                if j > i:
+                    merged[i] = j - i + 1
+                    skip.update(range(i + 1, j + 1))
+                i = j + 1
         for i, pc in enumerate(pieces):
-            if pc.nograd:
+            if pc.nograd or i in skip:
+                continue
+            if i in merged:
+                n = merged[i]
+                ctot = sum(q.Cp for q in pieces[i:i + n])
+                dl = DgradLayer(layer, i, span=n)
+                tgt = self.gp(Piece(pc.buf, pc.off, ctot, ctot, pc.n0))
+                bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=tgt, name=name + ".dgrad%d-%d" % (i, i + n - 1))
                 continue
             if layer.stride != 1 or layer.pad_mode == 1:
                 # reflect-padded / strided blocks: gradient w.r.t. the padded input, then fold the padding back
