@@ -44,6 +44,7 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+FIRST_WRITER = os.environ.get("EGNE_FIRST_WRITER", "1") != "0"     # data gradients: the first writer of a gradient slice stores instead of accumulating
 MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
 WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
 WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "0") != "0"   # weight gradients on a second stream (measured: no gain, 433.6 vs 434.0 frames/s at B=64 -- either kernel fills the LDS of every CU, so they do not co-reside)
@@ -462,6 +463,7 @@ class Plan:
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
+        self._touching, self._touched = False, {}     # build_backward: channel ranges of gradient twins already handed out
         self.side_calls, self.side_stream = {}, None   # call index -> event: weight-gradient launches overlapped with the data path
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _lib.lib()
@@ -478,24 +480,36 @@ class Plan:
         return t
 
     # ---- gradients (training plans) ------------------------------------------------------------
-    def gbuf(self, buf):
+    def gbuf(self, buf, _whole=True):
         t = self.gtwins.get(id(buf))
         if t is None:
             t = torch.zeros_like(buf)
             self.gtwins[id(buf)] = t
             self.keep.append(buf)
+        if _whole and self._touching:
+            self._touched[id(buf)] = [(0, int(buf.shape[-1]))]
         return t
 
     def gp(self, piece):
-        return Piece(self.gbuf(piece.buf), piece.off, piece.C, piece.Cp, piece.n0)
+        if self._touching:
+            self._touched.setdefault(id(piece.buf), []).append((piece.off, piece.off + piece.Cp))
+        return Piece(self.gbuf(piece.buf, False), piece.off, piece.C, piece.Cp, piece.n0)
+
+    def first_touch(self, buf, off, Cp):
+        """While the backward plan is built: True if no emitter before this one has asked for any of the channels [off, off+Cp) of
+        ``buf``'s gradient twin (gp / gbuf are the only ways to reach a twin, and emitters run in execution order).  The twin was
+        zeroed before the backward pass, so the first writer may STORE instead of accumulate (no read of the slice)."""
+        return FIRST_WRITER and self._touching and all(b <= off or a >= off + Cp for a, b in self._touched.get(id(buf), ()))
 
     def build_backward(self):
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
         bw = Plan(self.device)
         bw.fwd = self
         bw.dyn_scales = self.dyn_scales
+        self._touching, self._touched = True, {}
         for emit in reversed(self.tape):
             emit(bw)
+        self._touching = False
         self.bw = bw
         return bw
 
@@ -588,7 +602,8 @@ class Plan:
                 and W >= HALO_MIN_W and layer.CoutP <= HALO_MAX_COUTP and H * W * pieces[0].stride < 2 ** 31)
         smallcin = (SMALLCIN_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                     and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] == 1
-                    and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None)
+                    and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None
+                    and not isinstance(layer, (DgradLayer, SplitDgradLayer)))      # (a first-writer data gradient has no residual either)
         # frozen nets: streaming split-f16 form (both forms run at the HBM write rate; measured 12 % faster for 64 output
         # channels, 7 % slower for 32)
         c4h = (smallcin and F16X3_ENABLED and (layer.split or getattr(layer, "split_c4", False))
@@ -1113,8 +1128,9 @@ class Plan:
                 n = merged[i]
                 ctot = sum(q.Cp for q in pieces[i:i + n])
                 dl = DgradLayer(layer, i, span=n)
+                first = self.first_touch(pc.buf, pc.off, ctot)
                 tgt = self.gp(Piece(pc.buf, pc.off, ctot, ctot, pc.n0))
-                bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=tgt, name=name + ".dgrad%d-%d" % (i, i + n - 1))
+                bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d-%d" % (i, i + n - 1))
                 continue
             if layer.stride != 1 or layer.pad_mode == 1:
                 # reflect-padded / strided blocks: gradient w.r.t. the padded input, then fold the padding back
@@ -1141,9 +1157,11 @@ class Plan:
                 bw._dyn_hint = gz_max
             else:
                 dl = DgradLayer(layer, i)
+            first = self.first_touch(pc.buf, pc.off, pc.Cp)
             tgt = self.gp(pc)
             if pc.scale is None:
-                bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=tgt, name=name + ".dgrad%d" % i)
+                # the first writer of a gradient slice stores, later ones accumulate (the twin is zero before the backward pass)
+                bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d" % i)
                 bw._dyn_hint = None
             else:
                 tmp = bw.buf(B, H, W, pc.Cp)
