@@ -1115,7 +1115,7 @@ class Plan:
                 ok = lambda q: not q.nograd and q.scale is None and q.C == q.Cp and not isinstance(q, PlanarPiece)   # noqa: E731
                 while (ok(pieces[i]) and j + 1 < len(pieces) and ok(pieces[j + 1]) and pieces[j + 1].buf is pieces[i].buf
                        and pieces[j + 1].n0 == pieces[i].n0 and pieces[j + 1].off == pieces[j].off + pieces[j].Cp
-                       and sum(q.Cp for q in pieces[i:j + 2]) <= 128):
+                       and sum(q.Cp for q in pieces[i:j + 2]) <= 64):        # (96 outputs in one launch ran no faster than three launches)
                     j += 1
                 if j > i:
                     merged[i] = j - i + 1
