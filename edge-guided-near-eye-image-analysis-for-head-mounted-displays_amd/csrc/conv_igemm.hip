@@ -481,6 +481,9 @@ extern "C" int egne_conv2d_fwd(const egne_conv_desc* dp, void* stream) {
   // tile choice: the widest N tile that does not add padding beyond the 32-multiple
   const int c = d.CoutP;
   static const int big = [] { const char* e = getenv("EGNE_FLAT_BIG"); return e ? atoi(e) : 0; }();
+  // 1x1 convolutions (HBM-bound, two or three K steps per tile): the 128-pixel tile doubles the workgroups in flight per CU
+  static const int small1 = [] { const char* e = getenv("EGNE_IGEMM_SMALL1X1"); return e ? atoi(e) : 1; }();
+  if (small1 && d.kh == 1 && d.kw == 1 && d.ngroups == 1 && c % 128 != 0) return c % 64 == 0 ? launch<1, 2>(d, st) : launch<1, 1>(d, st);
   if (c % 128 == 0 && big) return launch<2, 4>(d, st);
   if (c % 128 == 0) return launch<1, 4>(d, st);
   if (c % 64 == 0) return launch<2, 2>(d, st);
