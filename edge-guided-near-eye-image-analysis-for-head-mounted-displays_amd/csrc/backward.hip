@@ -840,7 +840,7 @@ static bool w1_supported(const egne_conv_desc& d, int* nco_, int* nkc_, int* ch_
   //  921 vs 1151 us for 64 -> 32 at 240x320; from six blocks on the restaging dominates: 12 blocks at 120x160 1596 -> 1224 us)
   if (nco + nkc > W1_MAXT || nco * nkc > 32 || nco * nkc < 6 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
   *nco_ = nco; *nkc_ = nkc;
-  *ch_ = (nco + nkc) * 64 * W1LD * 4 <= 72 * 1024 ? 64 : 32;      // two workgroups per CU where the tiles allow
+  *ch_ = (nco + nkc) * 64 * W1LD * 4 <= 78 * 1024 ? 64 : 32;      // two workgroups per CU where the tiles allow
   return true;
 }
 
