@@ -284,3 +284,32 @@ def test_evaluate_front_and_back_end(tmp_path):
     back = list(E.mjpeg_frames(str(tmp_path / "t.avi")))
     assert len(back) == 3 and back[0].shape == (240, 320)
     assert np.abs(back[1].astype(int) - np.roll(smooth, 10, 1)).mean() < 3
+
+
+def test_first_writer_bookkeeping_of_gradient_slices():
+    """engine.Plan.first_touch (host logic of the backward plan, train.py:285-286): while the backward plan is built every access to
+    a gradient twin goes through gp / gbuf, which record channel ranges in execution order; a data gradient may STORE (instead of
+    accumulate) only into channels nobody asked for before it.  Also the device-side pre-scale words: one per call, published
+    words found again by (buffer, slice, samples)."""
+    from egne_amd.engine import Piece, Plan
+    pl = Plan(torch.device("cpu"), train=True)
+    a, b = pl.buf(2, 4, 4, 96), pl.buf(2, 4, 4, 32)
+    x, x1, x22 = Piece(a, 0, 32), Piece(a, 32, 32), Piece(a, 64, 30)
+    assert not pl.first_touch(a, 0, 32)            # outside build_backward nothing is a first touch
+    pl._touching, pl._touched = True, {}
+    assert pl.first_touch(a, 32, 32) and pl.first_touch(a, 0, 96)
+    g1 = pl.gp(x1)
+    assert g1.buf is pl.gbuf(a, False) and (g1.off, g1.Cp) == (32, 32)
+    assert not pl.first_touch(a, 32, 32) and not pl.first_touch(a, 0, 64) and not pl.first_touch(a, 56, 16)
+    assert pl.first_touch(a, 0, 32) and pl.first_touch(a, 64, 32)      # neighbours on both sides are still untouched
+    pl.gp(x22)
+    assert not pl.first_touch(a, 64, 8) and pl.first_touch(a, 0, 32)
+    assert pl.first_touch(b, 0, 32)
+    pl.gbuf(b)                                     # a whole-buffer access (loss / softmax backward) touches every channel
+    assert not pl.first_touch(b, 8, 8)
+    pl._touching = False
+    # device-side pre-scale words
+    w0 = pl._publish_absmax(x, 2)
+    w1 = pl._new_slot()
+    assert w1 == w0 + 4 and pl.ndyn == 2 and pl.dynbuf.dtype == torch.int32
+    assert pl._absmax_of[(id(a), 0, 32, 0, 2)][0] == w0
