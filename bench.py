@@ -336,7 +336,7 @@ class Bench:
 
         def step():   # train.py:262-287: frozen edge net, forward, loss.backward(), (DP) gradient all-reduce, Adam
             edge = calc_edge(args, t["img"], bd, dev)
-            opt.zero_grad(set_to_none=False)
+            opt.zero_grad()          # (train.py:284; PyTorch's default drops the gradient views, the model re-attaches its flat arena with one fill)
             out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
                       t["ID"], t["alpha"])
             out[3].backward()

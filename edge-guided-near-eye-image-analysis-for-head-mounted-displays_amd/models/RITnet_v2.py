@@ -196,10 +196,15 @@ class DenseNet2D(nn.Module):
                 o += p.numel()
             self._grad_sig = sig
             self._plans = {k: v for k, v in self._plans.items() if not k[4]}  # training plans hold grad pointers
-        for p, v in zip(params, self._grad_views):
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                v.zero_()
+        stale = [i for i, (p, v) in enumerate(zip(params, self._grad_views)) if p.grad is None or p.grad.data_ptr() != v.data_ptr()]
+        if len(stale) == len(params):
+            self._grad_flat.zero_()           # optimizer.zero_grad() dropped every view: ONE fill instead of one per parameter
+            for p, v in zip(params, self._grad_views):
                 p.grad = v
+        else:
+            for i in stale:
+                self._grad_views[i].zero_()
+                params[i].grad = self._grad_views[i]
         return self._grad_flat
 
     def _plan(self, B, H, W, dev):

@@ -122,7 +122,7 @@ def main(argv=None):
             torch.cuda.synchronize(); ta = time.time()
             edge = calc_edge(args, img.to(device), edge_net, device)               # frozen, no_grad (train.py:266)
             torch.cuda.synchronize(); tb = time.time()
-            optimizer.zero_grad(set_to_none=False)
+            optimizer.zero_grad()
             if args.device_prep:    # bit-identical to the Dataset's one_hot2dist maps, 54k frames/s instead of 123 per host core
                 from egne_amd import dataprep
                 dm = dataprep.dist_maps(labels.to(device).long())
