@@ -112,7 +112,9 @@ SIGNATURES = {
     "egne_act_bwd_bias": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp]),
     "egne_act_bwd_bias_absmax": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp, vp]),
     "egne_norm_bwd_workspace_bytes": (i64, [i32, i32, i32, i32]),
-    "egne_norm_pool2_bwd": (i32, [vp, i64, i32, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]),
+    "egne_norm_pool2_bwd": (i32, [vp, i64, i32, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, i32, vp, vp, vp]),
+    "egne_norm_bwd_store": (i32, [vp, i64, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp,
+                                  i32, vp, vp]),
     "egne_norm_bwd": (i32, [vp, i64, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp,
                             i32, vp, vp]),
     "egne_avgpool2_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),

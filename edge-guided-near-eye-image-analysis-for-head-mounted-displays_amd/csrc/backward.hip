@@ -248,7 +248,7 @@ __global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo
                                const float* __restrict__ shift, const float* __restrict__ gamma,
                                const float* __restrict__ gy, long long gs, int go, int act_in, int Cp,
                                long long npix_per_n, int Bn, int per_sample, const float* __restrict__ sums,
-                               float* __restrict__ gx, long long gxs, int gxo, int poolW) {
+                               float* __restrict__ gx, long long gxs, int gxo, int poolW, int accumulate) {
   const int nv = Cp >> 2;
   const long long total = (long long)Bn * npix_per_n * nv;
   const float invN = 1.f / (float)npix_per_n;
@@ -269,7 +269,8 @@ __global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo
     }
     const f32x4 xh = xv * sc + sh;
     f32x4* dst = (f32x4*)(gx + pp * gxs + gxo + c);
-    f32x4 o = *dst;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) o = *dst;          // (the first writer of a gradient slice stores: no read)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
@@ -750,7 +751,7 @@ extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_
 static int norm_bwd_impl(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
                          const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
                          int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
-                         int C, void* ws, void* stream, int poolW) {
+                         int C, void* ws, void* stream, int poolW, int accumulate) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(gy, gs, go, Cp) && slice_ok(gx, gxs, gxo, Cp), "norm_bwd: bad slices");
   EGNE_REQUIRE(scale && shift && sums && ws && B > 0 && HW > 0, "norm_bwd: null pointer");
   EGNE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || !per_sample), "norm_bwd: dgamma/dbeta only for batch statistics");
@@ -764,7 +765,7 @@ static int norm_bwd_impl(const float* x, int64_t xs, int xo, const float* scale,
                      dgamma, dbeta, C);
   hipLaunchKernelGGL(norm_bwd_apply, dim3(grid_for((long long)Bn * npix * (Cp / 4))), dim3(256), 0, st, x, (long long)xs, xo,
                      scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,
-                     gxo, poolW);
+                     gxo, poolW, accumulate);
   return egne::check_launch("egne_norm_bwd");
 }
 
@@ -773,17 +774,26 @@ extern "C" int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* sc
                              int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
                              int C, void* ws, void* stream) {
   return norm_bwd_impl(x, xs, xo, scale, shift, gamma, gy, gs, go, act_in, Cp, B, HW, per_sample, gx, gxs, gxo, sums, dgamma, dbeta,
-                       C, ws, stream, 0);
+                       C, ws, stream, 0, 1);
+}
+
+// The same with gx STORED instead of accumulated (first writer of a gradient slice: engine.Plan.first_touch).
+extern "C" int egne_norm_bwd_store(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                                   const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                                   int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                                   int C, void* ws, void* stream) {
+  return norm_bwd_impl(x, xs, xo, scale, shift, gamma, gy, gs, go, act_in, Cp, B, HW, per_sample, gx, gxs, gxo, sums, dgamma, dbeta,
+                       C, ws, stream, 0, 0);
 }
 
 // Backward of egne_norm_act_pool2 (zp = avg_pool2d(act(x*scale + shift), 2), per-sample statistics): the InstanceNorm backward
 // with gy[n][y][x] = gzp[n][y/2][x/2] / 4 read straight from the pooled gradient.  H and W even.
 extern "C" int egne_norm_pool2_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
                                    const float* gzp, int64_t gs, int go, int act_in, int Cp, int B, int H, int W,
-                                   float* gx, int64_t gxs, int gxo, float* sums, void* ws, void* stream) {
+                                   float* gx, int64_t gxs, int gxo, int accumulate, float* sums, void* ws, void* stream) {
   EGNE_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "norm_pool2_bwd: even map sizes only (got %dx%d)", H, W);
   return norm_bwd_impl(x, xs, xo, scale, shift, nullptr, gzp, gs, go, act_in, Cp, B, H * W, 1, gx, gxs, gxo, sums, nullptr, nullptr,
-                       0, ws, stream, W);
+                       0, ws, stream, W, accumulate);
 }
 
 extern "C" int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,

@@ -44,6 +44,7 @@ S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
 #   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+ZERO_SKIP = os.environ.get("EGNE_ZERO_SKIP", "1") != "0"           # no zero pass for gradient buffers whose accesses are all covered by full-batch stores
 FIRST_WRITER = os.environ.get("EGNE_FIRST_WRITER", "1") != "0"     # data gradients: the first writer of a gradient slice stores instead of accumulating
 MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
 WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
@@ -487,19 +488,28 @@ class Plan:
             self.gtwins[id(buf)] = t
             self.keep.append(buf)
         if _whole and self._touching:
-            self._touched[id(buf)] = [(0, int(buf.shape[-1]))]
+            self._touched.setdefault(id(buf), []).append([0, int(buf.shape[-1]), False])
         return t
 
     def gp(self, piece):
         if self._touching:
-            self._touched.setdefault(id(piece.buf), []).append((piece.off, piece.off + piece.Cp))
+            self._touched.setdefault(id(piece.buf), []).append([piece.off, piece.off + piece.Cp, False])
         return Piece(self.gbuf(piece.buf, False), piece.off, piece.C, piece.Cp, piece.n0)
+
+    def mark_stored(self, piece, B):
+        """The access just recorded for ``piece`` (the last gp call) is a STORE of every sample of the buffer: reads of these
+        channels later in the backward pass see this pass' values, whatever the twin held before (zero_grads can skip the
+        buffer if that holds for all of its accesses)."""
+        if self._touching and piece.n0 == 0 and B == piece.buf.shape[0]:
+            ent = self._touched[id(piece.buf)][-1]
+            assert ent[0] == piece.off and ent[1] == piece.off + piece.Cp
+            ent[2] = True
 
     def first_touch(self, buf, off, Cp):
         """While the backward plan is built: True if no emitter before this one has asked for any of the channels [off, off+Cp) of
         ``buf``'s gradient twin (gp / gbuf are the only ways to reach a twin, and emitters run in execution order).  The twin was
         zeroed before the backward pass, so the first writer may STORE instead of accumulate (no read of the slice)."""
-        return FIRST_WRITER and self._touching and all(b <= off or a >= off + Cp for a, b in self._touched.get(id(buf), ()))
+        return FIRST_WRITER and self._touching and all(b <= off or a >= off + Cp for a, b, _ in self._touched.get(id(buf), ()))
 
     def build_backward(self):
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
@@ -510,11 +520,29 @@ class Plan:
         for emit in reversed(self.tape):
             emit(bw)
         self._touching = False
+        # gradient twins that need no zero pass: every access is a full-batch store or touches only channels stored earlier
+        self._zero_free = set()
+        if ZERO_SKIP:
+            for bid, ents in self._touched.items():
+                cov, ok = [], True
+                for a, b_, st in ents:
+                    if st:
+                        cov.append((a, b_))
+                        continue
+                    need = [(a, b_)]
+                    for ca, cb in cov:       # subtract the covered ranges
+                        need = [r for x0, x1 in need for r in ((x0, min(x1, ca)), (max(x0, cb), x1)) if r[0] < r[1]]
+                    if need:
+                        ok = False
+                        break
+                if ok:
+                    self._zero_free.add(bid)
         self.bw = bw
         return bw
 
     def zero_grads(self):
-        ts = list(self.gtwins.values())
+        free = getattr(self, "_zero_free", ())
+        ts = [t for bid, t in self.gtwins.items() if bid not in free]
         if ts:
             torch._foreach_zero_(ts)
 
@@ -1129,7 +1157,10 @@ class Plan:
                 ctot = sum(q.Cp for q in pieces[i:i + n])
                 dl = DgradLayer(layer, i, span=n)
                 first = self.first_touch(pc.buf, pc.off, ctot)
-                tgt = self.gp(Piece(pc.buf, pc.off, ctot, ctot, pc.n0))
+                mp = Piece(pc.buf, pc.off, ctot, ctot, pc.n0)
+                tgt = self.gp(mp)
+                if first:
+                    self.mark_stored(mp, B)
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d-%d" % (i, i + n - 1))
                 continue
             if layer.stride != 1 or layer.pad_mode == 1:
@@ -1159,6 +1190,8 @@ class Plan:
                 dl = DgradLayer(layer, i)
             first = self.first_touch(pc.buf, pc.off, pc.Cp)
             tgt = self.gp(pc)
+            if first and dl.Cout_store == pc.Cp:
+                self.mark_stored(pc, B)       # (both routes below store every channel of the slice when they come first)
             if pc.scale is None:
                 # the first writer of a gradient slice stores, later ones accumulate (the twin is zero before the backward pass)
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d" % i)
@@ -1169,7 +1202,8 @@ class Plan:
                 bw._dyn_hint = None
                 sums = bw.vec(B * pc.Cp * 2)
                 wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, H * W, pc.Cp, 1)) + 7) // 8, dtype=torch.float64)
-                bw.raw(L.egne_norm_bwd, (pc.ptr, pc.stride, pc.off, pc.scale.data_ptr(), pc.shift.data_ptr(), None,
+                bw.raw(L.egne_norm_bwd_store if first else L.egne_norm_bwd,
+                                        (pc.ptr, pc.stride, pc.off, pc.scale.data_ptr(), pc.shift.data_ptr(), None,
                                          tmp.data_ptr(), tmp.shape[-1], 0, pc.act_in, pc.Cp, B, H * W, 1,
                                          tgt.ptr, tgt.stride, tgt.off, sums.data_ptr(), None, None, 0, wsn.data_ptr()),
                        name + ".in_bwd%d" % i)

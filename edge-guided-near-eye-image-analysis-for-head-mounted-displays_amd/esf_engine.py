@@ -252,12 +252,16 @@ def build_forward_plan(model, B, H, W, dev, training):
                                                dstp.ptr, dstp.stride, dstp.off, NB, h, w, src.Cp), nm + ".TDpool")
                 if training:
                     def emit_pool(bw, src=src, dstp=dstp, a_=a_, b_=b_, h=h, w=w, nm=nm):
-                        gq, gs_ = pl.gp(dstp), pl.gp(src)
+                        gq = pl.gp(dstp)
+                        first = pl.first_touch(src.buf, src.off, src.Cp)       # the first writer of a gradient slice stores
+                        gs_ = pl.gp(src)
+                        if first:
+                            pl.mark_stored(src, NB)
                         sums = bw.vec(NB * src.Cp * 2)
                         wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(NB, h * w, src.Cp, 1)) + 7) // 8, dtype=torch.float64)
                         bw.raw(L.egne_norm_pool2_bwd, (src.ptr, src.stride, src.off, a_.data_ptr(), b_.data_ptr(), gq.ptr, gq.stride,
                                                        gq.off, ACT_LEAKY, src.Cp, NB, h, w, gs_.ptr, gs_.stride, gs_.off,
-                                                       sums.data_ptr(), wsn.data_ptr()), nm + ".TDpool.bwd")
+                                                       0 if first else 1, sums.data_ptr(), wsn.data_ptr()), nm + ".TDpool.bwd")
                     pl.tape.append(emit_pool)
             pl.conv(tdl, [q_out, q_x], D[i + 1]["x"], NB, h // 2, w // 2, name=nm + ".TD")
         elif pools[i]:

@@ -422,10 +422,15 @@ int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* scale, const 
 
 /* Backward of egne_norm_act_pool2 (training-mode Transition_down with the pooling in front of the 1x1, models/RITnet_v2.py:32-44):
  * egne_norm_bwd (per-sample statistics) whose gy is a quarter of the pooled cell's gradient gzp [B][H/2][W/2]; H, W even;
- * workspace as egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1). */
+ * accumulate = 0 stores gx instead of adding to it; workspace as egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1). */
 int egne_norm_pool2_bwd(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
                         const float* gzp, int64_t gs, int go, int act_in, int Cp, int B, int H, int W,
-                        float* gx, int64_t gxs, int gxo, float* sums, void* ws, void* stream);
+                        float* gx, int64_t gxs, int gxo, int accumulate, float* sums, void* ws, void* stream);
+/* egne_norm_bwd_store: egne_norm_bwd with gx stored (=) instead of accumulated (+=): the first writer of a gradient slice. */
+int egne_norm_bwd_store(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
+                        const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                        int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                        int C, void* ws, void* stream);
 int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo,
                       int B, int H, int W, int Cp, void* stream);       /* gx += ; H,W = input size */
 int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo,

@@ -390,6 +390,30 @@ def test_adam_step_matches_reference(edge_of):
     assert torch.isfinite(loss2).all() and abs(loss2.item() - loss.item()) > 0
 
 
+@pytest.mark.parametrize("cfg", ["baseline_edge", "baseline_adain_edge"])
+def test_training_steps_replay_bit_identically(edge_of, cfg):
+    """Three forward + backward passes over the same batch with the weights untouched (train.py:284-286 without the optimiser
+    step) must leave THE SAME BITS in every parameter gradient: nothing may survive from one backward pass into the next --
+    gradient buffers that skip the zero pass because their first writer stores (engine.Plan.first_touch / mark_stored),
+    device-side pre-scale words, split-K workspaces -- and nothing may depend on launch order or atomics."""
+    from common import batch_args, esf_module
+    b, edge = edge_of(B=2, seed=4321)
+    m = esf_module(cfg).to(DEV).train()
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    runs = []
+    for it in range(3):
+        m.zero_grad()              # set_to_none: the model re-attaches its flat arena with one fill
+        loss = m(*args)[3].sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert len(runs[0][1]) > 50
+    for it in (1, 2):
+        assert runs[it][0] == runs[0][0]
+        for n, g in runs[0][1].items():
+            assert torch.equal(g, runs[it][1][n]), (it, n)
+
+
 def test_backward_only_supports_the_loss(edge_of):
     from common import batch_args, esf_module
     b, edge = edge_of(B=2, seed=1234)

@@ -953,10 +953,17 @@ def test_norm_pool2_bwd(G, C, B, H, W):
     sums = torch.zeros(B * C * 2, device=DEV)
     ws = torch.zeros((int(L.egne_norm_bwd_workspace_bytes(B, H * W, C, 1)) + 7) // 8, dtype=torch.float64, device=DEV)
     _lib.check(L.egne_norm_pool2_bwd(xn.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), gn.data_ptr(), C, 0, 2, C, B, H, W,
-                                     gx.data_ptr(), C, 0, sums.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), "norm_pool2_bwd")
+                                     gx.data_ptr(), C, 0, 1, sums.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), "norm_pool2_bwd")
     torch.cuda.synchronize()
     got = gx.cpu().permute(0, 3, 1, 2).double()
     assert (got - truth).abs().max().item() / truth.abs().max().item() < 5e-6
+    # accumulate = 0: the first writer of a gradient slice stores (whatever the slice held before)
+    gx.fill_(123.0)
+    _lib.check(L.egne_norm_pool2_bwd(xn.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), gn.data_ptr(), C, 0, 2, C, B, H, W,
+                                     gx.data_ptr(), C, 0, 0, sums.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), "norm_pool2_bwd")
+    torch.cuda.synchronize()
+    got = gx.cpu().permute(0, 3, 1, 2).double()
+    assert (got - xd.grad).abs().max().item() / xd.grad.abs().max().item() < 5e-6
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,norm,mag", [(2, 32, 32, 64, 96, False, 1.0), (2, 38, 64, 61, 83, True, 1.0), (1, 96, 96, 30, 40, False, 1e-5),
