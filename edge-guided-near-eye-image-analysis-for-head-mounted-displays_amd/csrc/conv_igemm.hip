@@ -484,6 +484,11 @@ extern "C" int egne_conv2d_fwd(const egne_conv_desc* dp, void* stream) {
   // 1x1 convolutions (HBM-bound, two or three K steps per tile): the 128-pixel tile doubles the workgroups in flight per CU
   static const int small1 = [] { const char* e = getenv("EGNE_IGEMM_SMALL1X1"); return e ? atoi(e) : 1; }();
   if (small1 && d.kh == 1 && d.kw == 1 && d.ngroups == 1 && c % 128 != 0) return c % 64 == 0 ? launch<1, 2>(d, st) : launch<1, 1>(d, st);
+  // small maps (regression module, bottleneck): narrower N tiles until the launch has a workgroup for every CU
+  {
+    const long long mt = ((long long)d.B * d.Ho * d.Wo + 127) / 128;
+    if (small1 && d.ngroups == 1 && c % 128 == 0 && mt * (c / 128) < 256) return mt * (c / 64) >= 256 ? launch<1, 2>(d, st) : launch<1, 1>(d, st);
+  }
   if (c % 128 == 0 && big) return launch<2, 4>(d, st);
   if (c % 128 == 0) return launch<1, 4>(d, st);
   if (c % 64 == 0) return launch<2, 2>(d, st);
