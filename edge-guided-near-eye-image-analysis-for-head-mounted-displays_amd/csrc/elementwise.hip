@@ -282,7 +282,15 @@ __global__ void spatial_mean_k(const float* __restrict__ x, long long pix_stride
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float* s = x + (long long)b * HW * pix_stride + ch_off + c;
     double a = 0;
-    for (int p = 0; p < HW; ++p) a += s[(long long)p * pix_stride];
+    int p = 0;
+    for (; p + 8 <= HW; p += 8) {          // eight loads in flight, summed in pixel order (one dependent load at a time took 76 us)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = s[(long long)(p + u) * pix_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += t[u];
+    }
+    for (; p < HW; ++p) a += s[(long long)p * pix_stride];
     out[(long long)b * C + c] = (float)(a / HW);
   }
 }
