@@ -41,7 +41,8 @@ _DATA = (
     ("test_mode", str, "leaveoneout", "evaluation split strategy"),
     ("synthetic", int, 0, "N > 0: run on N synthetic TEyeD-shaped frames (no dataset / checkpoint needed)"),
     ("device_prep", int, 0, "1: distance maps computed from the labels on the GPU (egne_amd.dataprep) instead of taken "
-                            "from the Dataset (CurriculumLib.py:131-136)"),
+                            "from the Dataset (CurriculumLib.py:131-136); 2: the boundary weights of CurriculumLib.py:128-129 too "
+                            "(parity unpinned: restated from OpenCV's published Canny / dilate)"),
 )
 _OUTPUT = (
     ("expname", str, "dev", "sub-directory of logs/<model>/"),

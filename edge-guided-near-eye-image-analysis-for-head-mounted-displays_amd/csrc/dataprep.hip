@@ -132,3 +132,103 @@ extern "C" int egne_zscore(const float* x, float* y, int B, int n, void* stream)
   hipLaunchKernelGGL(zscore_k, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, n);
   return egne::check_launch("egne_zscore");
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Spatial weights of a sample (CurriculumLib.py:128-129): 1 + 20 * dilate(Canny(label, 0, 1) / 255, (3, 3)).
+// PARITY UNPINNED (no OpenCV in the build container, no fixture in the reference): the kernel implements the restatement in
+// oracle/dataprep.py (OpenCV's published Canny: 3x3 Sobel with replicated borders, L1 magnitude, fixed-point sector test,
+// non-maximum suppression, hysteresis with thresholds 0 / 1; cv2.dilate with the tuple (3, 3) = a two-row, one-column element)
+// and is tested bit for bit against THAT.  One workgroup per frame; magnitude and state maps (one byte per pixel each) in LDS;
+// hysteresis = monotone growth of the edge set through the surviving pixels until a pass changes nothing.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int lab_at(const long long* __restrict__ l, int H, int W, int y, int x) {
+  y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+  x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+  return (int)(unsigned char)l[(long long)y * W + x];
+}
+
+__device__ __forceinline__ void sobel_at(const long long* __restrict__ l, int H, int W, int y, int x, int& dx, int& dy) {
+  const int a = lab_at(l, H, W, y - 1, x - 1), b = lab_at(l, H, W, y - 1, x), c = lab_at(l, H, W, y - 1, x + 1);
+  const int d = lab_at(l, H, W, y, x - 1), f = lab_at(l, H, W, y, x + 1);
+  const int g = lab_at(l, H, W, y + 1, x - 1), h = lab_at(l, H, W, y + 1, x), i = lab_at(l, H, W, y + 1, x + 1);
+  dx = (c - a) + 2 * (f - d) + (i - g);
+  dy = (g - a) + 2 * (h - b) + (i - c);
+}
+
+__global__ __launch_bounds__(1024) void spatial_weights_k(const long long* __restrict__ label, int H, int W, float* __restrict__ out) {
+  extern __shared__ unsigned char sw_lds[];
+  const int HW = H * W;
+  unsigned char* mag = sw_lds;            // |dx| + |dy| (<= 16 for class labels; saturated at 255)
+  unsigned char* st = sw_lds + HW;        // 0 nothing, 1 survivor of the suppression (m > low), 2 edge
+  __shared__ int changed;
+  const long long* l = label + (long long)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    int dx, dy;
+    sobel_at(l, H, W, y, x, dx, dy);
+    const int m = abs(dx) + abs(dy);
+    mag[i] = (unsigned char)(m > 255 ? 255 : m);
+  }
+  __syncthreads();
+  auto M = [&](int y, int x) -> int { return (y < 0 || y >= H || x < 0 || x >= W) ? 0 : (int)mag[y * W + x]; };
+  constexpr int TG22 = 13573;             // round(tan(22.5 deg) * 2^15)
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    const int m = mag[i];
+    unsigned char s = 0;
+    if (m > 0) {
+      int dx, dy;
+      sobel_at(l, H, W, y, x, dx, dy);
+      const long long ax = abs(dx), ay = (long long)abs(dy) << 15;
+      const long long tg22x = ax * TG22, tg67x = tg22x + (ax << 16);
+      bool keep;
+      if (ay < tg22x) keep = m > M(y, x - 1) && m >= M(y, x + 1);
+      else if (ay > tg67x) keep = m > M(y - 1, x) && m >= M(y + 1, x);
+      else {
+        const int sg = ((dx ^ dy) < 0) ? -1 : 1;
+        keep = m > M(y - 1, x - sg) && m > M(y + 1, x + sg);
+      }
+      if (keep) s = m > 1 ? 2 : 1;
+    }
+    st[i] = s;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < HW; ++pass) {
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      if (st[i] != 1) continue;
+      const int y = i / W, x = i - y * W;
+      bool e = false;
+      for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox) {
+          const int yy = y + oy, xx = x + ox;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W && st[yy * W + xx] == 2) e = true;
+        }
+      if (e) { st[i] = 2; changed = 1; }
+    }
+    __syncthreads();
+    const int c = changed;
+    __syncthreads();
+    if (!c) break;
+  }
+  float* o = out + (long long)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const bool e = st[i] == 2 || (i >= W && st[i - W] == 2);     // two-row structuring element anchored at its lower row
+    o[i] = e ? 21.f : 1.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int egne_spatial_weights(const int64_t* label, int B, int H, int W, float* out, void* stream) {
+  EGNE_REQUIRE(label && out && B > 0 && H > 1 && W > 1, "spatial_weights: bad arguments");
+  const size_t lds = (size_t)2 * H * W;
+  EGNE_REQUIRE(lds <= 156 * 1024, "spatial_weights: a %dx%d map does not fit the LDS (2 bytes per pixel, 156 KB)", H, W);
+  static bool once = hipFuncSetAttribute((const void*)spatial_weights_k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+  if (!once) return egne::fail(EGNE_ERR_LAUNCH, "spatial_weights: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(spatial_weights_k, dim3(B), dim3(1024), lds, (hipStream_t)stream, (const long long*)label, H, W, out);
+  return egne::check_launch("egne_spatial_weights");
+}

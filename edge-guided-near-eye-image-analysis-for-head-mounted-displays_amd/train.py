@@ -126,6 +126,8 @@ def main(argv=None):
             if args.device_prep:    # bit-identical to the Dataset's one_hot2dist maps, 54k frames/s instead of 123 per host core
                 from egne_amd import dataprep
                 dm = dataprep.dist_maps(labels.to(device).long())
+                if args.device_prep >= 2:   # the boundary weights too (CurriculumLib.py:128-129; parity unpinned: no OpenCV to check against)
+                    sw = dataprep.spatial_weights(labels.to(device).long())
             out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
                         dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
             loss = out[3].mean()                                                   # train.py:285

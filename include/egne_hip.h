@@ -503,6 +503,10 @@ int egne_ellipse_init_from_pred(const float* elPred, int nframes, int H, int W, 
 int64_t egne_dist_maps_workspace_bytes(int B, int H, int W, int ncls);
 int egne_dist_maps(const int64_t* label, int B, int H, int W, int ncls, float* out, void* ws, void* stream);
 int egne_zscore(const float* x, float* y, int B, int n, void* stream);
+/* egne_spatial_weights: 1 + 20 * cv2.dilate(cv2.Canny(label, 0, 1) / 255, (3, 3)) per frame (CurriculumLib.py:128-129); label int64
+ *   [B,H,W] (class indices), out float32 [B,H,W].  PARITY UNPINNED: neither OpenCV nor a fixture of this function exists in the
+ *   build container; the kernel is bit-identical to the restatement of OpenCV's published algorithm in oracle/dataprep.py. */
+int egne_spatial_weights(const int64_t* label, int B, int H, int W, float* out, void* stream);
 
 const char* egne_last_error(void);
 int egne_version(void);

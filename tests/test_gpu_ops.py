@@ -1061,3 +1061,30 @@ def test_conv1x1_weight_gradient_all_blocks_in_one_workgroup(G, chans, normed, C
             continue
         gx = pl.gbuf(pc.buf).cpu()[..., pc.off:pc.off + pc.C].permute(0, 3, 1, 2).double()
         assert (gx - x.grad).abs().max().item() / x.grad.abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(4, 240, 320), (2, 61, 83), (3, 100, 100)])
+def test_dataprep_spatial_weights_matches_its_restatement(G, B, H, W):
+    """dataprep.hip egne_spatial_weights (CurriculumLib.py:128-129) against oracle.dataprep.spatial_weights, bit
+    for bit, on synthetic eye labels (nested ellipses, some classes absent) and on random blobs.  PARITY UNPINNED: the oracle
+    restates OpenCV's published Canny / dilate and could not be run against OpenCV itself."""
+    from gpu_util import DEV
+    from egne_amd import dataprep, synth
+    from oracle import dataprep as oprep
+    labs = []
+    if (H, W) == (240, 320):
+        b = synth.make_batch(B, seed=7, mask_absent_every=3)
+        labs.append(b["label"].numpy().astype(np.int64))
+    rng = np.random.RandomState(5)
+    yy, xx = np.mgrid[0:H, 0:W]
+    blobs = np.zeros((B, H, W), np.int64)
+    for i in range(B):
+        for k in range(6):
+            cy, cx, ry, rx = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(3, H / 3), rng.uniform(3, W / 3)
+            blobs[i][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1] = rng.randint(0, 3)
+    labs.append(blobs)
+    labs.append((rng.rand(B, H, W) < 0.5).astype(np.int64) * 2)          # salt and pepper: every branch of the suppression, long chains
+    for lab in labs:
+        want = oprep.spatial_weights(lab)
+        got = dataprep.spatial_weights(torch.from_numpy(lab).to(DEV)).cpu().numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, want)

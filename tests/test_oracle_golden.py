@@ -204,3 +204,24 @@ def test_dataprep_dist_maps_and_zscore():
     assert np.array_equal(got, g["dist"])
     assert (g["dist"][2, 1:] == 0).all() and (g["dist"][2, 0] < 0).any()        # absent classes: zeros; full-frame class: scipy's quirk
     np.testing.assert_array_equal(oprep.zscore(g["img"]), g["z"])
+
+
+def test_spatial_weights_restatement_properties():
+    """oracle.dataprep.spatial_weights (CurriculumLib.py:128-129; PARITY UNPINNED - no OpenCV and no fixture in the build container):
+    what can be checked without the reference - values are 1 or 21, a constant label has no edges, the edge set is one pixel
+    thick across a straight class boundary and sits on its lower-valued side, the two-row dilation extends every edge one
+    row down, and the result only depends on the label map of the frame itself."""
+    from oracle import dataprep as oprep
+    lab = np.zeros((3, 40, 48), np.int64)
+    lab[1, :, 20:] = 1                      # vertical boundary between columns 19 | 20
+    lab[2, 12:, :] = 2                      # horizontal boundary between rows 11 | 12
+    w = oprep.spatial_weights(lab)
+    assert w.dtype == np.float32 and set(np.unique(w)) <= {1.0, 21.0}
+    assert (w[0] == 1).all()
+    e1 = oprep.canny_label_edges(lab[1])
+    assert e1[:, 19].all() and e1.sum() == 40            # m > left and m >= right: the left one of the two equal-magnitude columns
+    assert (w[1][:, 19] == 21).all() and (w[1] == 21).sum() == 40
+    e2 = oprep.canny_label_edges(lab[2])
+    assert e2[11, :].all() and e2.sum() == 48
+    assert (w[2][11] == 21).all() and (w[2][12] == 21).all() and (w[2] == 21).sum() == 96      # dilated one row down
+    assert (oprep.spatial_weights(lab[1:2]) == w[1:2]).all()
