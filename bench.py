@@ -109,7 +109,7 @@ def cpu_baseline(setting, bd_sd, net_sd, B, iters):
 
 
 def bench_prep(a):
-    """--mode prep: distance maps (exact EDT x 3 classes) + z-score of B frames per step, inputs resident in HBM."""
+    """--mode prep: distance maps (exact EDT x 3 classes) + z-score + boundary weights of B frames per step, inputs resident in HBM."""
     import torch
     import egne_amd  # noqa: F401
     from egne_amd import _lib, dataprep, synth
@@ -122,7 +122,7 @@ def bench_prep(a):
     img = torch.cat([base["img"]] * rep)[:B].cuda()
 
     def step():
-        return dataprep.dist_maps(lab), dataprep.zscore(img)
+        return dataprep.dist_maps(lab), dataprep.zscore(img), dataprep.spatial_weights(lab)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -135,13 +135,13 @@ def bench_prep(a):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     H, W = lab.shape[1:]
-    nbytes = B * H * W * (8 + 3 * 4 + 4 + 4)          # label read, 3 maps written, image read + written
+    nbytes = B * H * W * (8 + 3 * 4 + 4 + 4 + 8 + 4)  # label read, 3 maps written, image read + written, label read again + weights written
     ach = nbytes * a.steps / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    res = {"metric": "eye-frames/sec (320x240) device-side batch preparation: 3 signed distance maps (exact EDT) + z-score",
+    res = {"metric": "eye-frames/sec (320x240) device-side batch preparation: 3 signed distance maps (exact EDT) + z-score + boundary weights",
            "value": round(B * a.steps / dt, 1), "unit": "eye-frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int32 squared distances, f64 sqrt / statistics, f32 out", "data": "synthetic",
-           "config": {"workload": "SURVEY.md 8f N1: CurriculumLib.py:131-139 for a batch of %d label maps / frames" % B,
+           "config": {"workload": "SURVEY.md 8f N1: CurriculumLib.py:128-139 for a batch of %d label maps / frames (the boundary weights are parity-unpinned)" % B,
                       "frames_per_gpu_per_step": B},
            "roofline": {"bound": "hbm", "kernel": "edt_rows_k (brute-force row minimum from LDS: 320 candidates per pixel; latency / "
                                                    "issue bound, far below the HBM roof by design - it is 40x faster than the network)",
@@ -152,8 +152,9 @@ def bench_prep(a):
         t0 = time.perf_counter()
         oprep.dist_maps(lab[:n].cpu().numpy())
         oprep.zscore(img[:n].cpu().numpy())
+        oprep.spatial_weights(lab[:n].cpu().numpy())
         res["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 2), "unit": "eye-frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d frames, scipy.ndimage.distance_transform_edt x 6 per frame + numpy z-score, one core" % n}
+                               "sample": "%d frames, scipy.ndimage.distance_transform_edt x 6 per frame + numpy z-score + numpy Canny restatement, one core" % n}
     print(json.dumps(res), flush=True)
 
 
