@@ -443,8 +443,7 @@ class SplitDgradLayer(ConvLayer):
 
     def refresh(self):
         w = self.fwd.weights[0].detach()
-        self.derived.copy_(w[:, self.c0:self.c0 + self.cn].flip(2).flip(3).transpose(0, 1))
-        self.derived._version  # (copy_ bumps the version: ensure_packed re-packs)
+        self.derived.copy_(w[:, self.c0:self.c0 + self.cn].flip(2).flip(3).transpose(0, 1))     # (copy_ bumps the version: re-packed)
 
 
 class Plan:
