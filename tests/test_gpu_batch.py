@@ -121,13 +121,35 @@ def test_esf_train_b32_vs_reference(name):
     """Training plan at B=32 (bench.py's shape family) on the golden batch tiled x16: batch-statistic BatchNorm sees the
     same mean / biased variance, every loss term is a mean over valid samples, so loss and parameter gradients equal the
     B=2 reference values."""
+    _train_tiled_vs_reference(name, 16)
+
+
+def test_esf_train_b256_vs_reference():
+    """BASELINE.json configs[2]'s shape as bench.py's train leg runs it: the training plan at B=256 (golden batch tiled x128,
+    ~220 GB of HBM) against the B=2 reference loss, logits, BatchNorm statistics and parameter gradients.  Skipped when the card
+    does not have the memory free (other tests' cached plans) - never a failure for lack of memory."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    if free < 240e9:
+        pytest.skip("needs ~225 GB of free HBM, %.0f GB available" % (free / 1e9))
+    try:
+        _train_tiled_vs_reference("esf_edge_b2", 128)
+    except torch.cuda.OutOfMemoryError:
+        pytest.skip("out of HBM while building the B=256 training plan")
+    finally:
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def _train_tiled_vs_reference(name, rep):
     from common import ESF_CASES, bdcn_module, esf_module, gold
     from egne_amd import engine, synth
     from egne_amd.utils import calc_edge
     cfg, variant, kw = ESF_CASES[name]
     kw = dict(kw)
     g = gold(name)
-    rep = 16
     b = synth.make_batch(kw.pop("B"), **kw)
     old = engine.F16X3_ENABLED
     engine.F16X3_ENABLED = False          # exact-fp32 edge maps: the gradient fixtures are sensitive to 1e-6 input changes
