@@ -57,6 +57,7 @@ def parse():
                     help="all: every leg in one JSON line (default); infer / train: that leg only; "
                          "prep: device-side batch preparation (distance maps + z-score, SURVEY.md 8f N1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="inference legs: edge network and ESF-Net of a batch back to back on one stream")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--config", default="baseline_edge", help="configs/<name>.yaml (baseline_adain_edge = BASELINE.json configs[3])")
@@ -220,8 +221,10 @@ class Bench:
         """W untimed steps, then exactly K steps between two barrier + synchronize brackets; MAX over ranks."""
         torch = self.torch
         from egne_amd import engine as _engine
+        flush = getattr(step, "flush", lambda: None)
         for _ in range(warmup):
             step()
+        flush()                     # (a pipelined step: nothing in flight when the timed region starts)
         ev = []
         self.bd._events = self.net._events = (ev if events and not os.environ.get("EGNE_BENCH_NO_EVENTS") else None)
         # HIP events around every conv launch (the roofline families); all ~600 launches of a step only with --layers:
@@ -231,6 +234,8 @@ class Bench:
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
+        last = flush()              # ... and drained inside it: exactly K batches take the whole path
+        out = last if last is not None else out
         self.barrier()
         dt = time.perf_counter() - t0
         self.bd._events = self.net._events = None
@@ -284,7 +289,7 @@ class Bench:
         return r_split, r_fp32, sp_t, conv_t
 
     # ------------------------------------------------------------------------------------------------------------
-    def infer_step(self, B, fit):
+    def infer_step(self, B, fit, pipeline=None):
         torch = self.torch
         from egne_amd.utils import calc_edge, fit_ellipses_from_pred
         t, bd, net, args, dev = self.batch(B), self.bd, self.net, self.args, self.dev
@@ -295,33 +300,54 @@ class Bench:
         side = torch.cuda.Stream(device=dev) if fit else None
         state = {"n": 0, "done": [None, None]}
 
+        # Two-stage pipeline across batches (unless --no-pipeline): the frozen edge network of batch i runs on stream A while
+        # ESF-Net (+ loss / argmax) of batch i-1 runs on stream B.  ESF-Net's small levels (30x40 and 15x20 maps, the regression
+        # module, ~100 short launches) leave CUs idle that the edge network's kernels fill: +3.5 % (scratch/overlap.py).  Every
+        # batch still takes the whole path; the pipeline is empty when the timed region starts and is drained inside it.
+        from egne_amd.pipeline import TwoStagePipeline
+        use_pipe = (not self.a.no_pipeline) if pipeline is None else pipeline
+        pipe = TwoStagePipeline(args, bd, dev) if use_pipe else None
+
+        def esf(edge):
+            out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
+                      t["ID"], t["alpha"])
+            if fit:
+                k = state["n"] & 1
+                mask, elp = net.predictions(), out[1]
+                ready_f = torch.cuda.Event()
+                ready_f.record()
+                if state["done"][k] is not None:
+                    state["done"][k].synchronize()          # the ellipses of two batches ago have landed in host[k]
+                side.wait_event(ready_f)
+                with torch.cuda.stream(side):
+                    mask.record_stream(side)
+                    elp.record_stream(side)
+                    host[k].copy_(fit_ellipses_from_pred(mask, elp), non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                state["done"][k] = done
+                state["n"] += 1
+            return out
+
         def step():
             with torch.no_grad():
-                edge = calc_edge(args, t["img"], bd, dev)
-                out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
-                          t["ID"], t["alpha"])
-                if fit:
-                    k = state["n"] & 1
-                    mask, elp = net.predictions(), out[1]
-                    ready = torch.cuda.Event()
-                    ready.record()
-                    if state["done"][k] is not None:
-                        state["done"][k].synchronize()          # the ellipses of two batches ago have landed in host[k]
-                    side.wait_event(ready)
-                    with torch.cuda.stream(side):
-                        mask.record_stream(side)
-                        elp.record_stream(side)
-                        host[k].copy_(fit_ellipses_from_pred(mask, elp), non_blocking=True)
-                        done = torch.cuda.Event()
-                        done.record(side)
-                    state["done"][k] = done
-                    state["n"] += 1
-                return out
+                if pipe is None:
+                    return esf(calc_edge(args, t["img"], bd, dev))
+                r = pipe.submit(t["img"], esf)
+                return r[0] if r is not None else None
+
+        def flush():
+            if pipe is None:
+                return None
+            with torch.no_grad():
+                r = pipe.flush()
+            return r[0] if r is not None else None
+        step.flush = flush
         return step
 
-    def leg_infer(self, steps, warmup, fit=False, events=True):
+    def leg_infer(self, steps, warmup, fit=False, events=True, pipeline=None):
         B = self.a.batch or 64
-        dt, ev, out = self.timed(self.infer_step(B, fit), steps, warmup, events)
+        dt, ev, out = self.timed(self.infer_step(B, fit, pipeline), steps, warmup, events)
         assert self.torch.isfinite(out[3]).all()
         return B, dt, ev
 
@@ -382,9 +408,22 @@ def main():
              "measured on the device every step), exact fp32 MFMA for 1x1 convolutions and everything else")
 
     if a.mode in ("all", "infer"):
-        B, dt, ev = bn.leg_infer(a.steps, a.warmup, fit=a.fit and a.mode == "infer")
-        fam = bn.families(ev, a.steps, dt)
-        r_split, r_fp32, sp_t, conv_t = bn.rooflines(fam, a.steps, B, dt)
+        fit_ = a.fit and a.mode == "infer"
+        if a.no_pipeline:
+            B, dt, ev = bn.leg_infer(a.steps, a.warmup, fit=fit_)
+            dt_k = dt
+        else:
+            # `value`: the pipelined loop.  Kernel durations for `roofline`: a second timed region of the same run with the two
+            # stages of a batch back to back on ONE stream -- under the pipeline an event pair on one stream also spans the other
+            # stream's kernels (their sum was 1.75x the step), which says nothing about the kernel between them.
+            B, dt, _ = bn.leg_infer(a.steps, a.warmup, fit=fit_, events=False)
+            _, dt_k, ev = bn.leg_infer(a.steps, 1, fit=fit_, pipeline=False)
+        fam = bn.families(ev, a.steps, dt_k)
+        r_split, r_fp32, sp_t, conv_t = bn.rooflines(fam, a.steps, B, dt_k)
+        for r in (r_split, r_fp32):
+            r["measured_in"] = ("the timed region itself" if a.no_pipeline else
+                                "second timed region of this run, stages back to back on one stream: %.3f ms per step "
+                                "(time_share refers to it)" % (1e3 * dt_k / a.steps))
         try:   # HBM traffic per launch from the committed PMC passes of this round (bench.py cannot run rocprofv3 on itself)
             with open(os.path.join(ROOT, "profiles", ROUND + "_pmc_traffic.json")) as f:
                 tr = json.load(f)["families"]
@@ -400,16 +439,20 @@ def main():
                                    "frames, seeded random-init weights" % (a.config, a.chz, B),
                        "frames_per_gpu_per_step": B, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "ellipse_fit_stage": bool(a.fit and a.mode == "infer"), "arithmetic": arith,
-                       "parallelism": "replicas x%d (frames sharded, no collective)" % world},
+                       "parallelism": "replicas x%d (frames sharded, no collective)" % world,
+                       "pipeline": ("none: edge network and ESF-Net of a batch back to back on one stream" if a.no_pipeline else
+                                    "two stages across batches: the frozen edge network of batch i on one HIP stream while ESF-Net + loss "
+                                    "/ argmax of batch i-1 runs on another; empty when the timed region starts, drained inside it "
+                                    "(`roofline` / kernel_time_share: see roofline.measured_in)")},
             "roofline": r_split if sp_t >= conv_t else r_fp32, "roofline_secondary": r_fp32 if sp_t >= conv_t else r_split,
             "algorithmic_gflop_per_frame_total": round((r_split["algorithmic_gflop_per_frame"] + r_fp32["algorithmic_gflop_per_frame"]), 2),
             "kernel_time_share": dict({k.split(":")[0]: 0.0 for k in fam}),
         })
         share = {}
         for k, v in fam.items():
-            share[k.split(":")[0]] = share.get(k.split(":")[0], 0.0) + v[0] / dt
+            share[k.split(":")[0]] = share.get(k.split(":")[0], 0.0) + v[0] / dt_k
         if not a.layers:
-            share["untimed (elementwise, reductions, layout, loss, host gaps)"] = 1.0 - timed_t / dt
+            share["untimed (elementwise, reductions, layout, loss, host gaps)"] = 1.0 - timed_t / dt_k
         res["kernel_time_share"] = {k: round(v, 4) for k, v in sorted(share.items())}
 
     if a.mode == "all":
@@ -424,7 +467,7 @@ def main():
         _engine.F16X3_ENABLED = _engine.ESF_SPLIT = False
         bn.free_plans()
         ks = max(2, a.steps // 2)
-        B, dt, ev = bn.leg_infer(ks, 2)
+        B, dt, ev = bn.leg_infer(ks, 2, pipeline=False)       # (reference leg: stages back to back, kernel durations undisturbed)
         fam = bn.families(ev, ks, dt) if not a.layers else {}
         _, r32, _, _ = bn.rooflines(fam, ks, B, dt)
         res["exact_fp32"] = {"value": round(B * ks * world / dt, 2), "ms_per_step": round(1e3 * dt / ks, 3), "steps": ks,

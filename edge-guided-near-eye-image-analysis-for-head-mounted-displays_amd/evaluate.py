@@ -111,21 +111,35 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
     Returns edge maps [N,H,W], class maps [N,H,W], pupil ellipses [N,5], iris ellipses [N,5] (pixels)."""
     from egne_amd.utils import calc_edge
     assert frames.dim() == 4, 'Frame must be [N,1,H,W]'
-    dev = frames.device
-    N, _, H, W = frames.shape
     ns = argparse.Namespace(prec=torch.float32, edge_thres=0)
     with torch.no_grad():
-        edge = calc_edge(ns, frames, edge_model, dev)
-        labels = torch.zeros((N, H, W), device=dev)
-        labels[..., 0, 2] = 1                                  # evaluate.py:118-120: make all 3 classes present
-        labels[..., 2, 2] = 2
-        z = lambda *s: torch.zeros(s, device=dev)              # noqa: E731
-        out = model(frames, edge, labels.long(), z(N, 2), z(N, 2, 5), z(N, H, W), z(N, 3, H, W), z(N, 4),
-                    torch.zeros(N, dtype=torch.long, device=dev), 0)
-        fit = fit_ellipses_from_pred(model.predictions(), out[1])     # [N,2,5] on the device: (iris, pupil)
-        mask = model.predictions()
+        edge = calc_edge(ns, frames, edge_model, frames.device)
+    return _to_host(_seg_and_fit(frames, model)(edge))
+
+
+def _seg_and_fit(frames, model):
+    """Second stage of a batch (evaluate.py:117-166): ESF-Net on the frames and their edge maps, argmax mask, both ellipses
+    fitted on the device.  Returns a callable of the edge maps (egne_amd.pipeline.TwoStagePipeline runs it on its second stream)."""
+    dev = frames.device
+    N, _, H, W = frames.shape
+
+    def run(edge):
+        with torch.no_grad():
+            labels = torch.zeros((N, H, W), device=dev)
+            labels[..., 0, 2] = 1                                  # evaluate.py:118-120: make all 3 classes present
+            labels[..., 2, 2] = 2
+            z = lambda *s: torch.zeros(s, device=dev)              # noqa: E731
+            out = model(frames, edge, labels.long(), z(N, 2), z(N, 2, 5), z(N, H, W), z(N, 3, H, W), z(N, 4),
+                        torch.zeros(N, dtype=torch.long, device=dev), 0)
+            fit = fit_ellipses_from_pred(model.predictions(), out[1])     # [N,2,5] on the device: (iris, pupil)
+            return edge[:, 0].clone(), model.predictions().clone(), fit
+    return run
+
+
+def _to_host(res):
+    edge, mask, fit = res
     fit = fit.cpu().numpy()
-    return edge[:, 0].cpu().numpy(), mask.cpu().numpy(), fit[:, 1], fit[:, 0]
+    return edge.cpu().numpy(), mask.cpu().numpy(), fit[:, 1], fit[:, 0]
 
 
 def rescale_to_original(seg_map, pupil_ellipse, iris_ellipse, scale_shift, orig_shape, edge_map=None):
@@ -237,19 +251,38 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
     edge -> seg -> fitted ellipses -> back to the source geometry; writes <name>_result_<method>.avi (overlay: class colours,
     both ellipses, frame number) and <name>_edge_<method>.avi (255 - 255*edge), both Motion-JPEG, and the ellipse dictionary
     <name>_pred2_<method>.npy {frame: (iris, pupil)} -- eyes are batched 32 at a time instead of one by one."""
+    from egne_amd.pipeline import TwoStagePipeline
     stem = os.path.splitext(path_vid)[0]
     out, pending = {}, []
     vid_out = edge_out = None
+    # the edge network of batch i+1 runs next to ESF-Net + fit of batch i (two HIP streams), and the host draws / encodes batch
+    # i-1 meanwhile: results come back one batch late
+    pipe = TwoStagePipeline(argparse.Namespace(prec=torch.float32, edge_thres=0), edge_model, torch.device(device))
+    queued = []                                  # frames of the batches whose results are still on the device
 
     def flush():
-        nonlocal vid_out, edge_out
         if not pending:
             return
         eyes = [e for fr in pending for e in fr[2]]
         x = torch.stack([e[0] for e in eyes]).to(device)
-        edge, seg, pup, iri = evaluate_ellseg_on_image(x, model, edge_model)
+        queued.append(list(pending))
+        pending.clear()
+        r = pipe.submit(x, _seg_and_fit(x, model))
+        if r is not None:
+            draw(queued.pop(0), r)
+
+    def drain():
+        r = pipe.flush()
+        if r is not None and queued:
+            draw(queued.pop(0), r)
+
+    def draw(frames_of_batch, r):
+        nonlocal vid_out, edge_out
+        res, done = r
+        done.synchronize()
+        edge, seg, pup, iri = _to_host(res)
         k = 0
-        for j, frame_bgr, fe in pending:
+        for j, frame_bgr, fe in frames_of_batch:
             overlay, edge_frame = frame_bgr.copy(), frame_bgr.copy()
             for i, (_, ss, grey) in enumerate(fe):
                 em = 255.0 - 255.0 * edge[k]                                         # evaluate.py:263-264
@@ -266,7 +299,6 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
                 edge_out = MJPEGWriter(stem + '_edge_' + args.method + '.avi', 30, (Ww, Hh))
             vid_out.write(overlay)
             edge_out.write(edge_frame)
-        pending.clear()
 
     for j, fr in enumerate(mjpeg_frames(path_vid)):
         if args.max_frames and j >= args.max_frames:
@@ -281,6 +313,8 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
         if len(pending) >= 16:
             flush()
     flush()
+    drain()
+    assert not queued
     for w in (vid_out, edge_out):
         if w is not None:
             w.release()

@@ -414,6 +414,43 @@ def test_training_steps_replay_bit_identically(edge_of, cfg):
             assert torch.equal(g, runs[it][1][n]), (it, n)
 
 
+def test_pipelined_inference_is_bit_identical(bdcn):
+    """egne_amd.pipeline.TwoStagePipeline (the edge network of batch i+1 on one stream while ESF-Net of batch i runs on another:
+    test.py / evaluate.py's calc_edge -> model loop, pipelined across batches) returns, batch for batch, the bits of the
+    sequential loop -- five batches of different content and two batch sizes, results read only after their event."""
+    from common import batch_args, esf_module
+    from egne_amd import synth
+    from egne_amd.pipeline import TwoStagePipeline
+    from egne_amd.utils import calc_edge
+    ns = types.SimpleNamespace(prec=torch.float32, edge_thres=0)
+    m = esf_module("baseline_edge").to(DEV).eval()
+    batches = [synth.make_batch(B, seed=100 + i) for i, B in enumerate((2, 2, 3, 2, 3))]
+    dev_b = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+
+    def second(b):
+        def run(edge):
+            with torch.no_grad():
+                out = m(*batch_args(b, edge))
+                return [o.clone() for o in out] + [m.predictions().clone(), edge.clone()]
+        return run
+    want = []
+    for b in dev_b:
+        want.append(second(b)(calc_edge(ns, b["img"], bdcn, DEV)))
+    torch.cuda.synchronize()
+    pipe = TwoStagePipeline(ns, bdcn, DEV)
+    got = []
+    for b in dev_b:
+        r = pipe.submit(b["img"], second(b))
+        if r is not None:
+            got.append(r)
+    got.append(pipe.flush())
+    assert len(got) == len(want)
+    for (res, done), ref in zip(got, want):
+        done.synchronize()
+        for a, c in zip(res, ref):
+            assert torch.equal(a, c)
+
+
 def test_backward_only_supports_the_loss(edge_of):
     from common import batch_args, esf_module
     b, edge = edge_of(B=2, seed=1234)
