@@ -109,6 +109,10 @@ def main(argv=None):
                              drop_last=True)
     validloader = DataLoader(validObj, batch_size=args.batchsize, shuffle=False, sampler=vsamp, num_workers=args.workers,
                              drop_last=True)
+    pipe = None
+    if getattr(args, "pipeline", 0):
+        from egne_amd.pipeline import TwoStagePipeline
+        pipe = TwoStagePipeline(args, edge_net, device)
     for epoch in range(startEp, args.epochs):
         alpha = epoch / args.epochs                                                 # helperfunctions.linVal, train.py:248
         if tsamp is not None:
@@ -119,28 +123,43 @@ def main(argv=None):
             if (args.overfit and bt >= args.overfit) or (args.test_normal and bt > 20):
                 break
             img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
-            torch.cuda.synchronize(); ta = time.time()
-            edge = calc_edge(args, img.to(device), edge_net, device)               # frozen, no_grad (train.py:266)
-            torch.cuda.synchronize(); tb = time.time()
-            optimizer.zero_grad()
-            if args.device_prep:    # bit-identical to the Dataset's one_hot2dist maps, 54k frames/s instead of 123 per host core
-                from egne_amd import dataprep
-                dm = dataprep.dist_maps(labels.to(device).long())
-                if args.device_prep >= 2:   # the boundary weights too (CurriculumLib.py:128-129; parity unpinned: no OpenCV to check against)
-                    sw = dataprep.spatial_weights(labels.to(device).long())
-            out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
-                        dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
-            loss = out[3].mean()                                                   # train.py:285
-            loss.backward()
-            parallel.allreduce_grads(model)
-            optimizer.step()
-            torch.cuda.synchronize(); tc = time.time()
-            t_edge += tb - ta; t_net += tc - tb
+
+            def rest(edge, img=img, labels=labels, sw=sw, dm=dm, pc=pc, eln=eln, cond=cond, imInfo=imInfo):
+                optimizer.zero_grad()
+                if args.device_prep:    # bit-identical to the Dataset's one_hot2dist maps, 54k frames/s instead of 123 per host core
+                    from egne_amd import dataprep
+                    dm = dataprep.dist_maps(labels.to(device).long())
+                    if args.device_prep >= 2:   # the boundary weights too (CurriculumLib.py:128-129; parity unpinned: no OpenCV to check against)
+                        sw = dataprep.spatial_weights(labels.to(device).long())
+                out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
+                            dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
+                loss = out[3].mean()                                                   # train.py:285
+                loss.backward()
+                parallel.allreduce_grads(model)
+                optimizer.step()
+                return loss.detach()
+
+            if pipe is not None:
+                # --pipeline 1: the frozen edge network of this batch runs on a second stream next to the previous batch's
+                # forward / backward / optimiser step (egne_amd.pipeline); the logged loss is the previous batch's
+                r = pipe.submit(img.to(device), rest)
+                if r is None:
+                    continue
+                loss = r[0]
+            else:
+                torch.cuda.synchronize(); ta = time.time()
+                edge = calc_edge(args, img.to(device), edge_net, device)               # frozen, no_grad (train.py:266)
+                torch.cuda.synchronize(); tb = time.time()
+                loss = rest(edge)
+                torch.cuda.synchronize(); tc = time.time()
+                t_edge += tb - ta; t_net += tc - tb
             if rank == 0 and bt % 30 == 0:
                 print('Epoch:{} [{}/{}], Loss: {:.3f} edge {:.3f}s net {:.3f}s'.format(epoch, bt, len(trainloader),
                                                                                   parallel.mean_loss(loss.detach()).item(), t_edge, t_net))
             elif world > 1 and bt % 30 == 0:
                 parallel.mean_loss(loss.detach())
+        if pipe is not None:
+            pipe.flush()                       # the last batch of the epoch
         parallel.broadcast_buffers(model)      # validate with rank 0's BatchNorm statistics (DataParallel keeps replica 0's)
         vloss, viou = lossandaccuracy(args, validloader, model, edge_net, alpha, device)
         if rank == 0:

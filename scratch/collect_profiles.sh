@@ -14,7 +14,7 @@ python3 $R/bench.py --mode train --steps 5 --warmup 2 --train-batch 256 --config
 python3 $R/bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --chz 64 > $out/bench_infer_chz64.json 2>/dev/null
 python3 $R/bench.py --mode infer --steps 5 --warmup 2 --no-cpu-baseline --layers > $out/bench_layers.json 2> $out/per_layer_table.txt
 python3 $R/bench.py --mode train --steps 3 --warmup 2 --train-batch 64 --layers > $out/bench_layers_train.json 2> $out/per_layer_table_train.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --mode infer --steps 5 --warmup 2 --no-cpu-baseline > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --mode infer --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > $out/stats.log 2>&1
 cp $out/stats/r_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o r -- python3 $R/bench.py --mode train --steps 3 --warmup 2 --train-batch 64 > $out/stats_train.log 2>&1
 cp $out/stats_train/r_kernel_stats.csv $out/kernel_stats_train.csv 2>/dev/null
@@ -22,7 +22,7 @@ fi
 python3 $R/scratch/rs_dbg.py > $out/clock_stamps_rs_64to64.txt 2>&1
 python3 $R/scratch/fused_dbg.py 32,32,32 > $out/clock_stamps_fused_96to32to32.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmc_$c -o r -- python3 $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmc_$c -o r -- python3 $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > $out/pmc_$c.log 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmct_$c -o r -- python3 $R/bench.py --mode train --steps 1 --warmup 1 --train-batch 64 > $out/pmct_$c.log 2>&1
 done
 python3 - "$out" <<'PY'
@@ -46,7 +46,7 @@ for c in tot:
             tot[c][k] += float(r["Counter_Value"]); per[c][short] += float(r["Counter_Value"])
             if c == "FETCH_SIZE": cnt[k] += 1; pcnt[short] += 1
 steps = 3
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --mode infer --steps 2 --warmup 1, B=64 inference",
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --mode infer --steps 2 --warmup 1 --no-pipeline, B=64 inference",
        "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; counters are in KB",
        "steps_profiled": steps, "families": {}, "kernels": {}}
 for k in ("split_f16", "fp32_conv", "other"):

@@ -41,6 +41,22 @@ def test_train_py_device_prep(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join("logs", "ritnet_v2", "p", "weights", "ritnet_v2_0.pkl"))
 
 
+def test_train_py_pipeline_and_device_weights(tmp_path, monkeypatch):
+    """--pipeline 1 (edge network of a batch next to the previous batch's training step, egne_amd.pipeline) and --device_prep 2
+    (distance maps and boundary weights on the device): the same checkpoints appear, and with the pipeline the weights after an
+    epoch are THE SAME BITS as without it (same batches, same order, same arithmetic)."""
+    monkeypatch.chdir(tmp_path)
+    from egne_amd import train as TR
+    base = ["--synthetic", "4", "--batchsize", "2", "--epochs", "1", "--setting", "configs/baseline_edge.yaml", "--device_prep", "2"]
+    TR.main(base + ["--expname", "a"])
+    TR.main(base + ["--expname", "b", "--pipeline", "1"])
+    sa = torch.load(os.path.join("logs", "ritnet_v2", "a", "weights", "ritnet_v2_0.pkl"), map_location="cpu")["state_dict"]
+    sb = torch.load(os.path.join("logs", "ritnet_v2", "b", "weights", "ritnet_v2_0.pkl"), map_location="cpu")["state_dict"]
+    assert set(sa) == set(sb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_evaluate_py_synthetic():
     from egne_amd import evaluate as E
     pup, iri = E.main(["--synthetic", "2"])
