@@ -16,14 +16,14 @@ python3 $R/bench.py --mode infer --steps 5 --warmup 2 --no-cpu-baseline --layers
 python3 $R/bench.py --mode train --steps 3 --warmup 2 --train-batch 64 --layers > $out/bench_layers_train.json 2> $out/per_layer_table_train.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --mode infer --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > $out/stats.log 2>&1
 cp $out/stats/r_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o r -- python3 $R/bench.py --mode train --steps 3 --warmup 2 --train-batch 64 > $out/stats_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o r -- python3 $R/bench.py --mode train --steps 3 --warmup 2 --train-batch 64 --no-pipeline > $out/stats_train.log 2>&1
 cp $out/stats_train/r_kernel_stats.csv $out/kernel_stats_train.csv 2>/dev/null
 fi
 python3 $R/scratch/rs_dbg.py > $out/clock_stamps_rs_64to64.txt 2>&1
 python3 $R/scratch/fused_dbg.py 32,32,32 > $out/clock_stamps_fused_96to32to32.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmc_$c -o r -- python3 $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > $out/pmc_$c.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmct_$c -o r -- python3 $R/bench.py --mode train --steps 1 --warmup 1 --train-batch 64 > $out/pmct_$c.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $out/pmct_$c -o r -- python3 $R/bench.py --mode train --steps 1 --warmup 1 --train-batch 64 --no-pipeline > $out/pmct_$c.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, re, sys, collections
