@@ -24,17 +24,29 @@ def calc_acc(args, testloader, model, edge_model, device):
     """test.py:31-252 without the visualisation: per batch edge -> model -> argmax -> metrics."""
     ious, dists_pupil_latent, dists_pupil_seg, dists_iris_latent, dists_iris_seg, losses = [], [], [], [], [], []
     model.eval()
-    for bt, batch in enumerate(testloader):
-        if args.test_normal and bt > 20:       # test.py:76
-            break
+    # the edge network of batch i+1 runs next to the model of batch i (egne_amd.pipeline), and the host computes the metrics of
+    # batch i-1 meanwhile: same numbers, one batch later
+    from egne_amd.pipeline import TwoStagePipeline
+    pipe = TwoStagePipeline(args, edge_model, torch.device(device))
+    waiting = []
+
+    def second(batch):
         img, labels, spatialWeights, distMap, pupil_center, iris_center, elNorm, cond, imInfo = batch
-        with torch.no_grad():
-            img_edge = calc_edge(args, img.to(device), edge_model, device)
-            op, elPred, _, loss, elOut = model(img.to(device).to(args.prec), img_edge, labels.to(device).long(),
-                                               pupil_center.to(device).to(args.prec), elNorm.to(device).to(args.prec),
-                                               spatialWeights.to(device).to(args.prec), distMap.to(device).to(args.prec),
-                                               cond.to(device).to(args.prec), imInfo[:, 2].to(device).to(torch.long), 0.5)
-        predict = model.predictions().cpu().numpy()          # device argmax == get_predictions(op) (utils.py:65-81)
+
+        def run(img_edge):
+            with torch.no_grad():
+                op, elPred, _, loss, elOut = model(img.to(device).to(args.prec), img_edge, labels.to(device).long(),
+                                                   pupil_center.to(device).to(args.prec), elNorm.to(device).to(args.prec),
+                                                   spatialWeights.to(device).to(args.prec), distMap.to(device).to(args.prec),
+                                                   cond.to(device).to(args.prec), imInfo[:, 2].to(device).to(torch.long), 0.5)
+                return model.predictions().clone(), elPred, elOut, loss      # device argmax == get_predictions(op) (utils.py:65-81)
+        return run
+
+    def metrics(batch, r):
+        (mask, elPred, elOut, loss), done = r
+        done.synchronize()
+        img, labels, spatialWeights, distMap, pupil_center, iris_center, elNorm, cond, imInfo = batch
+        predict = mask.cpu().numpy()
         cnp = cond.numpy().astype(np.float32)
         iou, _, _ = getSeg_metrics(labels.numpy(), predict, cnp[:, 1])
         H, W = labels.shape[1:]
@@ -46,6 +58,18 @@ def calc_acc(args, testloader, model, edge_model, device):
         dists_pupil_latent.append(lat_p); dists_pupil_seg.append(seg_p)
         dists_iris_latent.append(lat_i); dists_iris_seg.append(seg_i)
         losses.append(loss.mean().item())
+
+    for bt, batch in enumerate(testloader):
+        if args.test_normal and bt > 20:       # test.py:76
+            break
+        waiting.append(batch)
+        r = pipe.submit(batch[0].to(device), second(batch))
+        if r is not None:
+            metrics(waiting.pop(0), r)
+    r = pipe.flush()
+    if r is not None and waiting:
+        metrics(waiting.pop(0), r)
+    assert not waiting
     if parallel.world_size() > 1:     # frames shard over ranks (no data-path collective); only the per-batch metrics are gathered
         ious, dists_pupil_latent, dists_pupil_seg, dists_iris_latent, dists_iris_seg, losses = (
             parallel.gather_lists(v) for v in (ious, dists_pupil_latent, dists_pupil_seg, dists_iris_latent, dists_iris_seg, losses))
