@@ -27,7 +27,8 @@ def seq(n):
     return out
 
 def pipe(n):
-    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    pa, pb = [int(v) for v in os.environ.get('PRIO', '0,0').split(',')]
+    sa, sb = torch.cuda.Stream(priority=pa), torch.cuda.Stream(priority=pb)
     cur = torch.cuda.current_stream()
     sa.wait_stream(cur); sb.wait_stream(cur)
     edges = [torch.empty(B, 1, 240, 320, device=dev) for _ in range(2)]
