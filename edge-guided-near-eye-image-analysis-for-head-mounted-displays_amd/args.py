@@ -40,8 +40,9 @@ _DATA = (
     ("path2data", str, "/media/rakshit/Monster", "dataset root"),
     ("test_mode", str, "leaveoneout", "evaluation split strategy"),
     ("synthetic", int, 0, "N > 0: run on N synthetic TEyeD-shaped frames (no dataset / checkpoint needed)"),
-    ("pipeline", int, 0, "1: the frozen edge network of a batch on a second HIP stream next to the previous batch's training step "
-                         "(egne_amd.pipeline; the logged loss is then the previous batch's)"),
+    ("pipeline", int, 1, "1 (default): the frozen edge network of a batch on a second HIP stream next to the previous batch's training "
+                         "step (egne_amd.pipeline; the logged loss is then the previous batch's); 0: back to back, with the reference's "
+                         "per-stage timers"),
     ("device_prep", int, 0, "1: distance maps computed from the labels on the GPU (egne_amd.dataprep) instead of taken "
                             "from the Dataset (CurriculumLib.py:131-136); 2: the boundary weights of CurriculumLib.py:128-129 too "
                             "(parity unpinned: restated from OpenCV's published Canny / dilate)"),

@@ -48,7 +48,7 @@ def test_train_py_pipeline_and_device_weights(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from egne_amd import train as TR
     base = ["--synthetic", "4", "--batchsize", "2", "--epochs", "1", "--setting", "configs/baseline_edge.yaml", "--device_prep", "2"]
-    TR.main(base + ["--expname", "a"])
+    TR.main(base + ["--expname", "a", "--pipeline", "0"])
     TR.main(base + ["--expname", "b", "--pipeline", "1"])
     sa = torch.load(os.path.join("logs", "ritnet_v2", "a", "weights", "ritnet_v2_0.pkl"), map_location="cpu")["state_dict"]
     sb = torch.load(os.path.join("logs", "ritnet_v2", "b", "weights", "ritnet_v2_0.pkl"), map_location="cpu")["state_dict"]
