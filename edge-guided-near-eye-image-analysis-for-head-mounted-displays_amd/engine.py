@@ -43,7 +43,8 @@ EVENT_KINDS = None   # bench.py: restrict the per-launch HIP events of Plan.run(
 S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
 ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel for the single-slice convs of ESF-Net EVAL plans
-#   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32; training plans stay exact fp32)
+#   (measured: logits error vs the reference unchanged, 1.4e-4 vs 1.6e-4 with exact fp32); training plans take the same products for their
+#   3x3 forward convolutions, data and weight gradients under TRAIN_SPLIT (pre-scales from device-side maxima)
 ZERO_SKIP = os.environ.get("EGNE_ZERO_SKIP", "1") != "0"           # no zero pass for gradient buffers whose accesses are all covered by full-batch stores
 FIRST_WRITER = os.environ.get("EGNE_FIRST_WRITER", "1") != "0"     # data gradients: the first writer of a gradient slice stores instead of accumulating
 MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
@@ -56,6 +57,9 @@ STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
 FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
 CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
+RECAL_EVERY = int(os.environ.get("EGNE_RECAL_EVERY", "1024"))     # inference plans: runs between two calibrations (0: first run only).  The scales
+#   leave 32x of head-room over the calibration batch; a later batch beyond that would overflow f16 silently, so the maxima are re-measured
+#   on a schedule (one short sync per split launch, ~0.1 % of the runs in between)
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 maps: 253 -> 194 us for 120 -> 128 channels against the flat kernel)
@@ -459,6 +463,7 @@ class Plan:
         self.layers = []    # ConvLayers to (re)pack before running
         self.pre = []       # python callables run before the launches (BN folding etc.)
         self.meta = []      # per call: (kernel family, algorithmic FLOPs) for bench.py's roofline
+        self.wscale_refs = []   # (call index, argument index, layer, attribute): weight-pack scales baked into launch arguments
         self.cal = {}       # call index -> (index of the a_scale argument, raw input Pieces, pixels): split-f16 pre-scale calibration
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
@@ -580,7 +585,12 @@ class Plan:
             self._add(self.L.egne_absmax, (pc.ptr, pc.stride, pc.off, pc.Cp, npix, ptr), name + ".absmax", kind="absmax")
         d.dyn_scale = ptr
 
-    def _add(self, fn, args, name, flops=0.0, kind=None, cal=None, side=False):
+    def _add(self, fn, args, name, flops=0.0, kind=None, cal=None, side=False, ws=()):
+        """``ws``: (argument index, layer, attribute) for every weight-pack scale passed BY VALUE in ``args``: ensure_packed may
+        re-measure max |w| and repack with another power of two, and Plan.run then rewrites these arguments (_refresh_wscales)."""
+        for ai, layer, attr in ws:
+            assert args[ai] == getattr(layer, attr), (name, ai, attr)
+            self.wscale_refs.append((len(self.calls), ai, layer, attr))
         if cal is not None and CALIBRATE:
             self.cal[len(self.calls)] = cal
         if side:      # launched on the plan's second stream behind an event of the main one (Plan.run); joined at the end of the run
@@ -789,19 +799,19 @@ class Plan:
             d2.Ktot, d2.CoutP = pad32(layer.Ktot), layer.split_coutp()
             self.keep.append(d2)
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
-                      flops=flops * b1 / B, kind="conv_f16x3:big", cal=cal2)
+                      flops=flops * b1 / B, kind="conv_f16x3:big", cal=cal2, ws=[(3, layer, "w_scale_big")])
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d2), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE, layer.w_scale),
-                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat", cal=cal3)
+                      name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat", cal=cal3, ws=[(4, layer, "w_scale")])
         elif big:
             self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
-                      flops=flops, kind="conv_f16x3:big", cal=cal2)
+                      flops=flops, kind="conv_f16x3:big", cal=cal2, ws=[(3, layer, "w_scale_big")])
         elif ms1x1:
             d.Ktot, d.CoutP = layer.m1_ktot, layer.m1_coutp
             self._add(self.L.egne_conv1x1_ms_f16x3_fwd, (C.byref(d), layer.m1hi.data_ptr(), layer.m1lo.data_ptr(), F16X3_ASCALE,
-                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3:gemm1x1", cal=cal3)
+                                                         layer.w_scale_m1), name, flops=flops, kind="conv_f16x3:gemm1x1", cal=cal3, ws=[(4, layer, "w_scale_m1")])
         elif s1x1:
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
-                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1", cal=cal3)
+                                                      layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1", cal=cal3, ws=[(4, layer, "w_scale1")])
         elif msdil and scores is not None:
             # the block's output is consumed by the stage's score heads only: they are evaluated in the epilogue and the
             # 32-channel map is never stored (scores = (weights [2][32], constants [2], s, s1, accumulate))
@@ -810,10 +820,10 @@ class Plan:
             self._add(self.L.egne_msblock_dil_scores_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
                                                                layer.w_scale, cw_.data_ptr(), cc_.data_ptr(), s0_.data_ptr(),
                                                                s1_.data_ptr(), int(accum)), name, flops=flops,
-                      kind="conv_f16x3:msdil", cal=cal3)
+                      kind="conv_f16x3:msdil", cal=cal3, ws=[(4, layer, "w_scale")])
         elif msdil:
             self._add(self.L.egne_msblock_dil_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
-                                                        layer.w_scale), name, flops=flops, kind="conv_f16x3:msdil", cal=cal3)
+                                                        layer.w_scale), name, flops=flops, kind="conv_f16x3:msdil", cal=cal3, ws=[(4, layer, "w_scale")])
         elif lattice:
             perf = 9 * layer.sfrag_coutp() * pad32(layer.Ktot)
             for g in range(3):
@@ -827,7 +837,7 @@ class Plan:
                 self.keep.append(dg)
                 self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(dg), layer.fhi.data_ptr() + 2 * g * perf,
                                                              layer.flo.data_ptr() + 2 * g * perf, F16X3_ASCALE, layer.w_scale),
-                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice", cal=cal3)
+                          name + ".g%d" % g, flops=flops / 3, kind="conv_f16x3:lattice", cal=cal3, ws=[(4, layer, "w_scale")])
         elif shalo and rs:
             pq = getattr(self, "_pool_req", None)
             if (pq is not None and POOL_FUSED and pieces[0].Cp > 32 and layer.sfrag_coutp() >= 64 and layer.post is None
@@ -847,7 +857,7 @@ class Plan:
                 ws = self._stats_ws(d, B, nchunk)
             self._add(self.L.egne_conv3x3_rw_f16_fwd if rw else self.L.egne_conv3x3_rs_f16_fwd,
                       (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE, layer.w_scale), name, flops=flops,
-                      kind="conv_f16x3:rw" if rw else "conv_f16x3:rs", cal=cal3)
+                      kind="conv_f16x3:rw" if rw else "conv_f16x3:rs", cal=cal3, ws=[(4, layer, "w_scale")])
             if fuse_stats:
                 self.last_stats = self._stats_finish(ws, d, B, H * W, nchunk, name)
                 stats = False
@@ -858,17 +868,17 @@ class Plan:
             if fuse_stats:
                 ws = self._stats_ws(d, B, tx * ty * 4)
             self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
-                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:halo", cal=cal3)
+                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:halo", cal=cal3, ws=[(4, layer, "w_scale")])
             if fuse_stats:
                 self.last_stats = self._stats_finish(ws, d, B, H * W, tx * ty * 4, name)
                 stats = False
         elif split:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
-                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3:flat", cal=cal3)
+                                                     layer.w_scale), name, flops=flops, kind="conv_f16x3:flat", cal=cal3, ws=[(4, layer, "w_scale")])
         elif smallcin and c4h:
             d.CoutP = layer.c4_coutp
             self._add(self.L.egne_conv3x3_smallcin_f16_fwd, (C.byref(d), layer.c4hi.data_ptr(), layer.c4lo.data_ptr(), F16X3_ASCALE,
-                                                             layer.w_scale_c4), name, flops=flops, kind="conv_f16x3:first", cal=cal3)
+                                                             layer.w_scale_c4), name, flops=flops, kind="conv_f16x3:first", cal=cal3, ws=[(4, layer, "w_scale_c4")])
         elif smallcin:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif halo:
@@ -934,7 +944,7 @@ class Plan:
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin
         # normalised operands: the fixed pre-scale of the other fused-affine layers (|x| < 4094 after the InstanceNorm affine)
         self._add(self.L.egne_conv1x1_pool2_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE, layer.w_scale1),
-                  name, flops=flops, kind="conv_f16x3:tdpool1x1")
+                  name, flops=flops, kind="conv_f16x3:tdpool1x1", ws=[(4, layer, "w_scale1")])
         LAYER_BYTES[name] = 4.0 * B * (H * W * sum(p.Cp for p in pieces) + Ho * Wo * int(d.Cout_store))
         return Ho, Wo
 
@@ -1027,7 +1037,7 @@ class Plan:
         self._add(self.L.egne_conv1x1_3x3_fused_f16_fwd,
                   (C.byref(d1), C.byref(d2), l1.s1hi.data_ptr(), l1.s1lo.data_ptr(), F16X3_ASCALE, l1.w_scale1,
                    l2.fhi.data_ptr(), l2.flo.data_ptr(), F16X3_ASCALE, l2.w_scale), name, flops=flops, kind="conv_f16x3:fused1x1",
-                  cal=(rescale, list(pieces), B * H * W))
+                  cal=(rescale, list(pieces), B * H * W), ws=[(5, l1, "w_scale1"), (9, l2, "w_scale")])
         if fuse_stats:
             self.last_stats = self._stats_finish(ws, d2, B, H * W, nchunk, name)
         elif stats:
@@ -1080,7 +1090,7 @@ class Plan:
         self._add(self.L.egne_conv3x3c4_3x3_fused_f16_fwd,
                   (C.byref(d1), C.byref(d2), l1.c4hi.data_ptr(), l1.c4lo.data_ptr(), F16X3_ASCALE, l1.w_scale_c4,
                    l2.fhi.data_ptr(), l2.flo.data_ptr(), F16X3_ASCALE, l2.w_scale), name, flops=flops, kind="conv_f16x3:fused3x3c4",
-                  cal=(rescale, [src], B * H * W))
+                  cal=(rescale, [src], B * H * W), ws=[(5, l1, "w_scale_c4"), (9, l2, "w_scale")])
         if fuse_stats:
             self.last_stats = self._stats_finish(ws, d2, B, H * W, nchunk, name)
         elif stats:
@@ -1266,8 +1276,12 @@ class Plan:
         repacked = False
         for layer in self.layers:
             repacked = bool(layer.ensure_packed(self.device)) or repacked
+        if repacked:
+            self._refresh_wscales()
         st = _lib.stream_ptr()
-        if self.cal and (repacked or not self.calibrated):
+        self._runs_since_cal = getattr(self, "_runs_since_cal", 0) + 1
+        if self.cal and (repacked or not self.calibrated or (RECAL_EVERY and self._runs_since_cal >= RECAL_EVERY)):
+            self._runs_since_cal = 0
             return self._run_calibrating(st)
         if self.side_calls:
             return self._run_two_streams(st, events)
@@ -1290,6 +1304,15 @@ class Plan:
             if rc != 0:
                 _lib.check(rc, name)
             events.append((kind, flops, e0, e1, name))
+
+    def _refresh_wscales(self):
+        """A repack may have chosen another power-of-two weight scale (ensure_packed re-measures max |w|): the launches carry the
+        scale by value, so rewrite the arguments that no longer match the pack."""
+        for ci, ai, layer, attr in self.wscale_refs:
+            v = getattr(layer, attr)
+            fn, args, name = self.calls[ci]
+            if args[ai] != v:
+                self.calls[ci] = (fn, args[:ai] + (v,) + args[ai + 1:], name)
 
     def _run_two_streams(self, st, events):
         """Backward plans: the weight-gradient launches (MFMA bound, reading gz and the saved input) go to a second stream so

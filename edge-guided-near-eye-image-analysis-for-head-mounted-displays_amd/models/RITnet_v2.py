@@ -256,6 +256,23 @@ class DenseNet2D(nn.Module):
         loss = pl.terms[0:1].clone()
         return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), loss, pl.elOut.clone()
 
+    def loss_flags(self):
+        """Device scalar: the number of samples of the last forward whose ground-truth mask lacks TWO classes.  The reference's
+        wCE dies there (``rmIdx.item()`` on a two-element tensor, loss.py:132); a kernel cannot raise, so the loss head counts
+        such samples (out_terms[6]) and the entry scripts call ``raise_on_loss_flags`` where they synchronise anyway."""
+        last = getattr(self, "_last_plan", None)
+        if last is None:
+            raise RuntimeError("loss_flags(): no forward pass has run yet")
+        return last.terms[6:7].clone()
+
+    @staticmethod
+    def raise_on_loss_flags(flags):
+        """``flags``: what loss_flags() returned for a batch.  Synchronises (``.item()``)."""
+        n = int(flags.item())
+        if n:
+            raise RuntimeError("%d sample(s) of the batch have a segmentation mask with two absent classes: the weighted "
+                               "cross-entropy of loss.py:127-135 supports at most one (the reference raises here too)" % n)
+
     def predictions(self):
         """Argmax mask [B,H,W] int64 of the last forward (device-side get_predictions, utils.py:65-81).
         A copy: the plan buffer it comes from is overwritten by the next forward of the same shape."""

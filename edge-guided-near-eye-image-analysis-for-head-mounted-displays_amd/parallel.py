@@ -31,6 +31,10 @@ def init(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -73,15 +77,34 @@ def gather_lists(values):
     return [v for part in out for v in part]
 
 
+class _StridedShard(torch.utils.data.Sampler):
+    """Validation shard of one rank: items rank, rank + world, ... in order -- every item exactly once over the ranks, nothing
+    dropped or repeated (a DistributedSampler either drops the remainder or pads by repeating items)."""
+
+    def __init__(self, n_items, rank, world):
+        self.idx = list(range(rank, n_items, world))
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+
 def samplers(train_set, valid_set, rank, world, seed=0):
-    """(train sampler, validation sampler) that give every rank a disjoint shard: one permutation per epoch shared
-    by all ranks (``set_epoch``), drop_last so that every rank sees the same number of batches.  (None, None) for
-    a single process."""
+    """(train sampler, validation sampler) that give every rank a disjoint shard.  Training: one permutation per epoch
+    shared by all ranks (``set_epoch``), drop_last so that every rank takes the same number of optimiser steps (a rank with
+    one step more would hang in the gradient all-reduce).  Validation: a strided shard that drops NOTHING -- the validation
+    loader must keep its partial last batch too (train.py), the caller weights per-rank sums by sample counts
+    (sum_over_ranks), and a rank left without any validation item is an error.  (None, None) for a single process."""
     if world == 1:
         return None, None
     from torch.utils.data.distributed import DistributedSampler
+    if len(valid_set) < world:
+        raise RuntimeError("validation set of %d items cannot be sharded over %d ranks: a rank would validate nothing"
+                           % (len(valid_set), world))
     return (DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=seed, drop_last=True),
-            DistributedSampler(valid_set, num_replicas=world, rank=rank, shuffle=False, drop_last=True))
+            _StridedShard(len(valid_set), rank, world))
 
 
 def grad_arena(model):

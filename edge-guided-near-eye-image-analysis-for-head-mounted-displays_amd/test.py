@@ -39,12 +39,13 @@ def calc_acc(args, testloader, model, edge_model, device):
                                                    pupil_center.to(device).to(args.prec), elNorm.to(device).to(args.prec),
                                                    spatialWeights.to(device).to(args.prec), distMap.to(device).to(args.prec),
                                                    cond.to(device).to(args.prec), imInfo[:, 2].to(device).to(torch.long), 0.5)
-                return model.predictions().clone(), elPred, elOut, loss      # device argmax == get_predictions(op) (utils.py:65-81)
+                return model.predictions().clone(), elPred, elOut, loss, model.loss_flags()      # device argmax == get_predictions(op) (utils.py:65-81)
         return run
 
     def metrics(batch, r):
-        (mask, elPred, elOut, loss), done = r
+        (mask, elPred, elOut, loss, flags), done = r
         done.synchronize()
+        model.raise_on_loss_flags(flags)           # two absent classes: loss.py:132 raises in the reference
         img, labels, spatialWeights, distMap, pupil_center, iris_center, elNorm, cond, imInfo = batch
         predict = mask.cpu().numpy()
         cnp = cond.numpy().astype(np.float32)

@@ -45,7 +45,7 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
     Under torchrun every rank validates ITS shard of the loader; the means are combined over ranks so that all
     ranks feed the same numbers to the LR scheduler / early stopping."""
     model.eval()
-    losses, ious = [], []
+    lsum = nsamp = isum = icnt = 0.0
     for bt, batch in enumerate(loader):
         if args.test_normal and bt > 20:
             break
@@ -54,12 +54,20 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
             edge = calc_edge(args, img.to(device), edge_model, device)
             out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
                         dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
-        losses.append(out[3].mean().item())
-        ious.append(getSeg_metrics(labels.numpy(), model.predictions().cpu().numpy(), cond.numpy().astype(np.float32)[:, 1])[0])
+        # batches are weighted by their sample count: under torchrun the shards (and their last batches) differ in size
+        n = float(img.shape[0])
+        model.raise_on_loss_flags(model.loss_flags())       # two absent classes: loss.py:132 raises in the reference
+        lsum += out[3].mean().item() * n
+        nsamp += n
+        iou = getSeg_metrics(labels.numpy(), model.predictions().cpu().numpy(), cond.numpy().astype(np.float32)[:, 1])[0]
+        if iou == iou:
+            isum += float(iou) * n
+            icnt += n
     model.train()
-    ious = [v for v in ious if v == v]
-    sums = parallel.sum_over_ranks([float(np.sum(losses)), float(len(losses)), float(np.sum(ious)), float(len(ious))], device)
-    return (sums[0] / sums[1] if sums[1] else float('nan')), (sums[2] / sums[3] if sums[3] else float('nan'))
+    if nsamp == 0:
+        raise RuntimeError("rank %d validated no batch (validation set too small for %d ranks?)" % (parallel.rank(), parallel.world_size()))
+    sums = parallel.sum_over_ranks([lsum, nsamp, isum, icnt], device)
+    return sums[0] / sums[1], (sums[2] / sums[3] if sums[3] else float('nan'))
 
 
 def main(argv=None):
@@ -107,8 +115,9 @@ def main(argv=None):
     tsamp, vsamp = parallel.samplers(trainObj, validObj, rank, world)
     trainloader = DataLoader(trainObj, batch_size=args.batchsize, shuffle=tsamp is None, sampler=tsamp, num_workers=args.workers,
                              drop_last=True)
+    # validation keeps its partial last batch (nothing is dropped, parallel.samplers); one process: as train.py:110-121
     validloader = DataLoader(validObj, batch_size=args.batchsize, shuffle=False, sampler=vsamp, num_workers=args.workers,
-                             drop_last=True)
+                             drop_last=vsamp is None and len(validObj) >= args.batchsize)
     pipe = None
     if getattr(args, "pipeline", 0):
         from egne_amd.pipeline import TwoStagePipeline
@@ -137,7 +146,7 @@ def main(argv=None):
                 loss.backward()
                 parallel.allreduce_grads(model)
                 optimizer.step()
-                return loss.detach()
+                return loss.detach(), model.loss_flags()
 
             if pipe is not None:
                 # --pipeline 1: the frozen edge network of this batch runs on a second stream next to the previous batch's
@@ -145,17 +154,21 @@ def main(argv=None):
                 r = pipe.submit(img.to(device), rest)
                 if r is None:
                     continue
-                loss = r[0]
+                torch.cuda.current_stream().wait_event(r[1])    # the step ran on the pipeline's stream: its loss is final behind this event
+                loss, flags = r[0]
             else:
                 torch.cuda.synchronize(); ta = time.time()
                 edge = calc_edge(args, img.to(device), edge_net, device)               # frozen, no_grad (train.py:266)
                 torch.cuda.synchronize(); tb = time.time()
-                loss = rest(edge)
+                loss, flags = rest(edge)
                 torch.cuda.synchronize(); tc = time.time()
                 t_edge += tb - ta; t_net += tc - tb
+            if bt % 30 == 0:
+                model.raise_on_loss_flags(flags)       # (checked where the loop synchronises anyway: loss.py:132 raises in the reference)
             if rank == 0 and bt % 30 == 0:
-                print('Epoch:{} [{}/{}], Loss: {:.3f} edge {:.3f}s net {:.3f}s'.format(epoch, bt, len(trainloader),
-                                                                                  parallel.mean_loss(loss.detach()).item(), t_edge, t_net))
+                # (per-stage timers need the stages back to back: --pipeline 0)
+                timers = '' if pipe is not None else ' edge {:.3f}s net {:.3f}s'.format(t_edge, t_net)
+                print('Epoch:{} [{}/{}], Loss: {:.3f}{}'.format(epoch, bt, len(trainloader), parallel.mean_loss(loss.detach()).item(), timers))
             elif world > 1 and bt % 30 == 0:
                 parallel.mean_loss(loss.detach())
         if pipe is not None:

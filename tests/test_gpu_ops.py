@@ -908,6 +908,48 @@ def test_device_side_prescale_matches_the_host_calibration(G, Cin, Cout, H, W, m
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dyn", [False, True])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(32, 32, 64, 96), (64, 64, 30, 40), (256, 256, 30, 40), (3, 64, 40, 64)])
+def test_weight_scale_follows_a_repack(G, Cin, Cout, H, W, dyn):
+    """The split-f16 launches carry the weight pack's power-of-two scale BY VALUE.  ensure_packed re-measures max |w| when the
+    weights change (optimizer step, load_state_dict) and may repack with another power of two: Plan.run must then rewrite the
+    baked argument (Plan._refresh_wscales), or the layer's output is off by 2^k for the rest of the run.  Weights are moved
+    across several powers of two between runs of ONE plan and every run is compared with float64."""
+    from gpu_util import DEV, to_nhwc_buf
+    import egne_amd.engine as eng
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    if dyn and Cin < 8:
+        pytest.skip("training plans run the first layer in exact fp32")
+    B = 2
+    x = _rand(G, B, Cin, H, W)
+    w0, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    pl = Plan(torch.device(DEV))
+    pl.dyn_scales = dyn
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    wp = torch.nn.Parameter(w0.to(DEV))
+    layer = ConvLayer([wp], [torch.nn.Parameter(b.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=2)
+    layer.split = True
+    out = pl.buf(B, H, W, pad8(Cout))
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W)
+    assert any(k.startswith("conv_f16x3:") for k, _ in pl.meta) and pl.wscale_refs
+    old_every, eng.WSCALE_EVERY = eng.WSCALE_EVERY, 1        # re-measure at every repack (training plans: every 16th otherwise)
+    try:
+        seen = set()
+        for f in (1.0, 4.0, 0.03, 300.0):
+            with torch.no_grad():
+                wp.copy_(w0.to(DEV) * f)
+            pl.run()
+            torch.cuda.synchronize()
+            seen.add(getattr(layer, pl.wscale_refs[0][3]))
+            truth = F.leaky_relu(F.conv2d(x.double(), (w0 * f).double(), b.double(), padding=1))
+            got = out.cpu().permute(0, 3, 1, 2).double()[:, :Cout]
+            err = (got - truth).abs().max().item() / truth.abs().max().item()
+            assert err < 3e-6, "weights x%g: relative error %.2e" % (f, err)
+        assert len(seen) >= 3, seen          # the pack's scale did change
+    finally:
+        eng.WSCALE_EVERY = old_every
+
+
 @pytest.mark.parametrize("Cin,Cout,H,W", [(32, 32, 64, 96), (38, 64, 61, 83), (96, 96, 30, 40)])
 def test_split_data_gradient_layer(G, Cin, Cout, H, W):
     """engine.SplitDgradLayer (backward of models/RITnet_v2.py:57-62's 3x3 convs, train.py:285): the data gradient as an ordinary

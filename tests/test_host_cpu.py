@@ -186,6 +186,16 @@ for ep in range(2):
     if ep == 0: first = idx.clone()
 assert not torch.equal(first, idx)
 assert sorted(list(vs)) == list(range(rank, 10, 2))
+# validation shards drop nothing and repeat nothing, also when the set does not divide by the world size
+_, vs11 = parallel.samplers(ds, _entry.SyntheticEyes(11, seed=1), rank, world)
+cnt = torch.tensor([len(vs11)]); both_n = [torch.zeros_like(cnt) for _ in range(2)]
+dist.all_gather(both_n, cnt)
+assert list(vs11) == list(range(rank, 11, 2)) and int(both_n[0] + both_n[1]) == 11
+try:
+    parallel.samplers(ds, _entry.SyntheticEyes(1, seed=1), rank, world)
+    raise SystemExit("a validation set smaller than the world must be refused")
+except RuntimeError:
+    pass
 s = parallel.sum_over_ranks([1.0 + rank, 10.0])
 assert s == [3.0, 20.0]
 m.enc.head.bn.running_mean.fill_(float(rank + 7))
