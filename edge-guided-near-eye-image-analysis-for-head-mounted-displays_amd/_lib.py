@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("Cout_store", C.c_int32),
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
                 ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
-                ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p)]
+                ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p), ("dtype", C.c_int32)]
 
 
 class BdcnTailDesc(C.Structure):
@@ -51,7 +51,7 @@ class LossDesc(C.Structure):
                 ("pupil_center", c_fp), ("elNorm", c_fp), ("elOut", c_fp), ("alpha", C.c_float),
                 ("grid_x", c_fp), ("grid_y", c_fp),
                 ("partials", c_fp), ("out_terms", c_fp), ("pred_c", c_fp), ("elPred", c_fp),
-                ("mask", c_fp), ("op_nchw", c_fp), ("coef", c_fp)]
+                ("mask", c_fp), ("op_nchw", c_fp), ("coef", c_fp), ("dtype", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/egne_hip.h declares
@@ -138,6 +138,21 @@ SIGNATURES = {
     "egne_version": (i32, []),
     "egne_sizeof": (i32, [i32]),
 }
+
+# Entry points with a bf16-storage twin (same arguments, activation pointers are bf16; suffix _bf16): training plans that keep
+# activations and activation gradients as bf16 in HBM (engine.Plan(dtype=torch.bfloat16)).  Descriptor-based convolutions carry
+# the storage type in egne_conv_desc.dtype instead.
+BF16_TWINS = ["egne_norm_stats", "egne_affine", "egne_avgpool2", "egne_norm_act_pool2", "egne_upsample2x", "egne_nchw_to_nhwc",
+              "egne_ellipse_head_act", "egne_selu_inplace", "egne_spatial_mean", "egne_softmax3", "egne_adain", "egne_conf_loss",
+              "egne_loss_bwd", "egne_act_bwd_bias", "egne_norm_pool2_bwd", "egne_norm_bwd_store", "egne_norm_bwd",
+              "egne_avgpool2_bwd", "egne_upsample2x_bwd", "egne_ellipse_head_act_bwd", "egne_selu_bwd", "egne_softmax3_bwd",
+              "egne_adain_bwd", "egne_reflect_pad_bwd", "egne_spatial_mean_bwd", "egne_conf_loss_bwd"]
+for _n in BF16_TWINS:
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
+SIGNATURES.update({
+    "egne_pack_conv_weight_bf16frag": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "egne_conv3x3_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
+})
 
 _lib = None
 

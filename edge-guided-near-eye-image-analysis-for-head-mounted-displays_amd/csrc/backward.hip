@@ -4,6 +4,7 @@
 // and the HBM-bound elementwise / reduction backward ops.  Everything is deterministic (two-stage
 // reductions, no atomics).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,8 +23,9 @@ inline int grid_for(long long total, int block = 256) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
 
+template <typename T>
 __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const float* __restrict__ gscale_p,
-                                                  float* __restrict__ g_logits, long long gs, int go,
+                                                  T* __restrict__ g_logits, long long gs, int go,
                                                   float* __restrict__ g_elOut) {
   const float gscale = gscale_p[0];
   const int b = blockIdx.y;
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
   const float fHW = (float)HW;
   const long long base = (long long)b * HW;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-    const float* lp = d.logits + (base + p) * d.pix_stride + d.ch_off;
-    const float l0 = lp[0], l1 = lp[1], l2 = lp[2];
+    const T* lp = (const T*)d.logits + (base + p) * d.pix_stride + d.ch_off;
+    const float l0 = ld1(lp), l1 = ld1(lp + 1), l2 = ld1(lp + 2);
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (segw != 0.f) {
       const int t = (int)d.target[base + p];
@@ -72,8 +74,8 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
       const float wi = expf(-4.f * l0 - im) / is;
       g0 += ki * wi * (six * (gx - cix) + siy * (gy - ciy));
     }
-    float* o = g_logits + (base + p) * gs + go;
-    o[0] = g0; o[1] = g1; o[2] = g2;
+    T* o = g_logits + (base + p) * gs + go;
+    st1(o, g0); st1(o + 1, g1); st1(o + 2, g2);
   }
   if (blockIdx.x == 0 && threadIdx.x < 10) {
     const int j = threadIdx.x;
@@ -91,8 +93,9 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
 // ------------------------------------------------------------------------------------------------
 // gz = gy * act'(y) in place + bias gradient (sum over pixels), two deterministic stages
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ g, long long gs, int go,
-                                                            const float* __restrict__ y, long long ys, int yo, int act,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_bias_partial(T* __restrict__ g, long long gs, int go,
+                                                            const T* __restrict__ y, long long ys, int yo, int act,
                                                             int Cp, long long npix, int nchunk, double* __restrict__ ws,
                                                             unsigned* __restrict__ absmax_bits) {
   const int chunk = blockIdx.x, cg = blockIdx.y;
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long q = p + 32 * u;
-        t[u] = q < p1 ? *(const f32x4*)(g + q * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        yy[u] = (q < p1 && act != EGNE_ACT_NONE) ? *(const f32x4*)(y + q * ys + yo + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        t[u] = q < p1 ? ld4(g + q * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        yy[u] = (q < p1 && act != EGNE_ACT_NONE) ? ld4(y + q * ys + yo + c) : f32x4{1.f, 1.f, 1.f, 1.f};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(float* __restrict__ 
         if (act != EGNE_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) t[u][e] = yy[u][e] > 0.f ? t[u][e] : (act == EGNE_ACT_LEAKY ? 0.01f * t[u][e] : 0.f);
-          if (q < p1) *(f32x4*)(g + q * gs + go + c) = t[u];
+          if (q < p1) st4(g + q * gs + go + c, t[u]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -172,9 +175,10 @@ __global__ __launch_bounds__(256) void reduce_chunks_k(const double* __restrict_
 // InstanceNorm / BatchNorm backward.  xh = x*scale + shift (scale = rstd, shift = -mean*rstd);
 // g = gy * act'(xh) [* gamma];  gx += rstd * (g - mean(g) - xh * mean(g*xh));  dgamma = sum gy*xh, dbeta = sum gy
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void norm_bwd_partial(const float* __restrict__ x, long long xs, int xo,
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_partial(const T* __restrict__ x, long long xs, int xo,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        const float* __restrict__ gy, long long gs, int go, int act_in,
+                                                        const T* __restrict__ gy, long long gs, int go, int act_in,
                                                         int Cp, long long npix_per_n, int nchunk, int per_sample,
                                                         double* __restrict__ ws, int poolW) {
   // poolW > 0: gy is the gradient of the 2x2-average-POOLED tensor ([n][H/2][W/2]); pixel p = (y, x) of a W = poolW wide map
@@ -195,13 +199,13 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float* __restrict_
       for (int u = 0; u < 4; ++u) {
         const long long q = p + 32 * u;
         const bool ok = q < p1;
-        xv4[u] = ok ? *(const f32x4*)(x + (nb + q) * xs + xo + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv4[u] = ok ? ld4(x + (nb + q) * xs + xo + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         if (poolW) {
           const int py = (int)(q / poolW), px = (int)(q - (long long)py * poolW);
-          g4[u] = ok ? 0.25f * *(const f32x4*)(gy + ((nb >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c)
+          g4[u] = ok ? 0.25f * ld4(gy + ((nb >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c)
                      : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
-          g4[u] = ok ? *(const f32x4*)(gy + (nb + q) * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          g4[u] = ok ? ld4(gy + (nb + q) * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
 #pragma unroll
@@ -244,11 +248,12 @@ __global__ void norm_bwd_final(const double* __restrict__ ws, int Cp, int Bn, in
   if (dgamma && c < C) { dgamma[c] += (float)b; dbeta[c] += (float)a; }   // Bn == 1 for BatchNorm
 }
 
-__global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
+template <typename T>
+__global__ void norm_bwd_apply(const T* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
                                const float* __restrict__ shift, const float* __restrict__ gamma,
-                               const float* __restrict__ gy, long long gs, int go, int act_in, int Cp,
+                               const T* __restrict__ gy, long long gs, int go, int act_in, int Cp,
                                long long npix_per_n, int Bn, int per_sample, const float* __restrict__ sums,
-                               float* __restrict__ gx, long long gxs, int gxo, int poolW, int accumulate) {
+                               T* __restrict__ gx, long long gxs, int gxo, int poolW, int accumulate) {
   const int nv = Cp >> 2;
   const long long total = (long long)Bn * npix_per_n * nv;
   const float invN = 1.f / (float)npix_per_n;
@@ -258,19 +263,19 @@ __global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo
     const int n = per_sample ? (int)(pp / npix_per_n) : 0;
     const f32x4 sc = *(const f32x4*)(scale + (long long)n * Cp + c);
     const f32x4 sh = *(const f32x4*)(shift + (long long)n * Cp + c);
-    const f32x4 xv = *(const f32x4*)(x + pp * xs + xo + c);
+    const f32x4 xv = ld4(x + pp * xs + xo + c);
     f32x4 g;
     if (poolW) {      // per_sample mode, even H and W (checked by the entry point)
       const long long p = pp - (long long)n * npix_per_n;
       const int py = (int)(p / poolW), px = (int)(p - (long long)py * poolW);
-      g = 0.25f * *(const f32x4*)(gy + (((long long)n * npix_per_n >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c);
+      g = 0.25f * ld4(gy + (((long long)n * npix_per_n >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c);
     } else {
-      g = *(const f32x4*)(gy + pp * gs + go + c);
+      g = ld4(gy + pp * gs + go + c);
     }
     const f32x4 xh = xv * sc + sh;
-    f32x4* dst = (f32x4*)(gx + pp * gxs + gxo + c);
+    T* dst = gx + pp * gxs + gxo + c;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (accumulate) o = *dst;          // (the first writer of a gradient slice stores: no read)
+    if (accumulate) o = ld4(dst);          // (the first writer of a gradient slice stores: no read)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
@@ -279,12 +284,13 @@ __global__ void norm_bwd_apply(const float* __restrict__ x, long long xs, int xo
       const float m1 = sums[2 * ((long long)n * Cp + c + e)] * invN, m2 = sums[2 * ((long long)n * Cp + c + e) + 1] * invN;
       o[e] += sc[e] * gm * (g[e] - m1 - xh[e] * m2);
     }
-    *dst = o;
+    st4(dst, o);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void avgpool2_bwd_k(const float* __restrict__ gy, long long gs, int go, float* __restrict__ gx, long long xs,
+template <typename T>
+__global__ void avgpool2_bwd_k(const T* __restrict__ gy, long long gs, int go, T* __restrict__ gx, long long xs,
                                int xo, int B, int H, int W, int Cp) {
   const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
   const long long total = (long long)B * Ho * Wo * nv;
@@ -294,11 +300,11 @@ __global__ void avgpool2_bwd_k(const float* __restrict__ gy, long long gs, int g
     const int ox = (int)(p % Wo); p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    f32x4 g = *(const f32x4*)(gy + (((long long)b * Ho + oy) * Wo + ox) * gs + go + c);
+    f32x4 g = ld4(gy + (((long long)b * Ho + oy) * Wo + ox) * gs + go + c);
     g = g * 0.25f;
-    float* d = gx + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
-    *(f32x4*)d += g; *(f32x4*)(d + xs) += g;
-    *(f32x4*)(d + (long long)W * xs) += g; *(f32x4*)(d + (long long)W * xs + xs) += g;
+    T* d = gx + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
+    st4(d, ld4(d) + g); st4(d + xs, ld4(d + xs) + g);
+    st4(d + (long long)W * xs, ld4(d + (long long)W * xs) + g); st4(d + (long long)W * xs + xs, ld4(d + (long long)W * xs + xs) + g);
   }
 }
 
@@ -311,7 +317,8 @@ __device__ __forceinline__ int up_taps(int y, int H, int* oy, float* w) {
   if (y + 1 <= H - 1) { oy[n] = 2 * y + 2; w[n++] = 0.25f; }
   return n;
 }
-__global__ void upsample2x_bwd_k(const float* __restrict__ gy, long long gs, int go, float* __restrict__ gx, long long xs,
+template <typename T>
+__global__ void upsample2x_bwd_k(const T* __restrict__ gy, long long gs, int go, T* __restrict__ gx, long long xs,
                                  int xo, int B, int H, int W, int Cp) {
   const int nv = Cp >> 2, Wo = 2 * W, Ho = 2 * H;
   const long long total = (long long)B * H * W * nv;
@@ -326,59 +333,64 @@ __global__ void upsample2x_bwd_k(const float* __restrict__ gy, long long gs, int
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < ny; ++a)
       for (int q = 0; q < nx; ++q)
-        acc += (wy[a] * wx[q]) * *(const f32x4*)(gy + (((long long)b * Ho + oys[a]) * Wo + oxs[q]) * gs + go + c);
-    *(f32x4*)(gx + (((long long)b * H + y) * W + x) * xs + xo + c) += acc;
+        acc += (wy[a] * wx[q]) * ld4(gy + (((long long)b * Ho + oys[a]) * Wo + oxs[q]) * gs + go + c);
+    T* dp = gx + (((long long)b * H + y) * W + x) * xs + xo + c;
+    st4(dp, ld4(dp) + acc);
   }
 }
 
-__global__ void head_act_bwd_k(float* __restrict__ g, const float* __restrict__ y, int B, int ld) {
+template <typename T>
+__global__ void head_act_bwd_k(T* __restrict__ g, const T* __restrict__ y, int B, int ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * 10) return;
   const int b = i / 10, j = i - b * 10, k = j % 5;
-  const float v = y[(long long)b * ld + j];
+  const float v = ld1(y + (long long)b * ld + j);
   float d = 1.f;
   if (k < 2) d = 1.f - v * v; else if (k < 4) d = v * (1.f - v);
-  g[(long long)b * ld + j] *= d;
+  st1(g + (long long)b * ld + j, ld1(g + (long long)b * ld + j) * d);
 }
 
-__global__ void selu_bwd_k(float* __restrict__ g, const float* __restrict__ y, long long n) {
+template <typename T>
+__global__ void selu_bwd_k(T* __restrict__ g, const T* __restrict__ y, long long n) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    g[i] *= y[i] > 0.f ? scale : y[i] + scale * alpha;
+    { const float yv = ld1(y + i); st1(g + i, ld1(g + i) * (yv > 0.f ? scale : yv + scale * alpha)); }
 }
 
-__global__ void spatial_mean_bwd_k(const float* __restrict__ g, int gld, float* __restrict__ gx, long long xs, int xo,
+template <typename T>
+__global__ void spatial_mean_bwd_k(const T* __restrict__ g, int gld, T* __restrict__ gx, long long xs, int xo,
                                    int C, int HW) {
   const int b = blockIdx.x;
   const float inv = 1.f / (float)HW;
   for (long long i = threadIdx.x; i < (long long)HW * C; i += blockDim.x) {
     const int c = (int)(i % C);
     const long long p = i / C;
-    gx[((long long)b * HW + p) * xs + xo + c] += g[(long long)b * gld + c] * inv;
+    { T* q = gx + ((long long)b * HW + p) * xs + xo + c; st1(q, ld1(q) + ld1(g + (long long)b * gld + c) * inv); }
   }
 }
 
 // d(weight * mean|softmax(x) - 1/C|)/dx  (loss.py:150) or d CE/dx (:153)
-__global__ void conf_loss_bwd_k(const float* __restrict__ x, int ld, const long long* __restrict__ gt, int B, int C, int flag,
-                                const float* __restrict__ gscale_p, float* __restrict__ gx, int gld) {
+template <typename T>
+__global__ void conf_loss_bwd_k(const T* __restrict__ x, int ld, const long long* __restrict__ gt, int B, int C, int flag,
+                                const float* __restrict__ gscale_p, T* __restrict__ gx, int gld) {
   const float gscale = gscale_p[0];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const float* r = x + (long long)b * ld;
+  const T* r = x + (long long)b * ld;
   float m = -INFINITY;
-  for (int k = 0; k < C; ++k) m = fmaxf(m, r[k]);
+  for (int k = 0; k < C; ++k) m = fmaxf(m, ld1(r + k));
   float se = 0.f;
-  for (int k = 0; k < C; ++k) se += expf(r[k] - m);
+  for (int k = 0; k < C; ++k) se += expf(ld1(r + k) - m);
   if (flag) {
     float dot = 0.f;
-    for (int k = 0; k < C; ++k) { const float p = expf(r[k] - m) / se; dot += p * sgn(p - 1.0f / C); }
+    for (int k = 0; k < C; ++k) { const float p = expf(ld1(r + k) - m) / se; dot += p * sgn(p - 1.0f / C); }
     for (int k = 0; k < C; ++k) {
-      const float p = expf(r[k] - m) / se;
-      gx[(long long)b * gld + k] = gscale / (float)(B * C) * p * (sgn(p - 1.0f / C) - dot);
+      const float p = expf(ld1(r + k) - m) / se;
+      st1(gx + (long long)b * gld + k, gscale / (float)(B * C) * p * (sgn(p - 1.0f / C) - dot));
     }
   } else {
     for (int k = 0; k < C; ++k)
-      gx[(long long)b * gld + k] = gscale / (float)B * (expf(r[k] - m) / se - (gt[b] == k ? 1.f : 0.f));
+      st1(gx + (long long)b * gld + k, gscale / (float)B * (expf(ld1(r + k) - m) / se - (gt[b] == k ? 1.f : 0.f)));
   }
 }
 
@@ -392,7 +404,8 @@ constexpr int WPX = 128;  // pixels per chunk (two barriers per 16 MFMAs of ever
 constexpr int WLD = 33;   // LDS row pitch (floats): lanes read consecutive floats of one pixel row
 constexpr int WNR = WPX / 32;
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p, const float* __restrict__ gz, long long gzs,
+template <typename TS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p, const TS* __restrict__ gz, long long gzs,
                                                          int gzo, int nsplit, float* __restrict__ ws) {
   __shared__ float As[WPX * WLD];   // gz chunk   [pixel][co]
   __shared__ float Bs[WPX * WLD];   // x chunk    [pixel][k]
@@ -439,11 +452,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
     for (int i = 0; i < WNR; ++i) {
       const long long m = mc + lr + 32 * i;
       const bool in = m < m_end;
-      const float* ap = (in && aok) ? gz + m * gzs + gzo + co0 + lc : egne_zero_page;
-      const float* bp = egne_zero_page;
+      const TS* ap = (in && aok) ? gz + m * gzs + gzo + co0 + lc : zero_page<TS>();
+      const TS* bp = zero_page<TS>();
       bb[i] = -1;
       if (simple) {
-        if (in && bok) bp = sg.ptr + m * sg.pix_stride + sg.ch_off + c0 + lc;
+        if (in && bok) bp = (const TS*)sg.ptr + m * sg.pix_stride + sg.ch_off + c0 + lc;
         if (sg.scale && in && bok) bb[i] = (int)(m / hw);
       } else if (in && bok) {
         const int b = (int)(m / hw);
@@ -458,12 +471,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
           ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         }
         if (ok) {
-          bp = sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + lc;
+          bp = (const TS*)sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + lc;
           bb[i] = b;
         }
       }
-      av[i] = *(const f32x4*)ap;
-      bv[i] = *(const f32x4*)bp;
+      av[i] = ld4(ap);
+      bv[i] = ld4(bp);
     }
     if (sg.scale) {
 #pragma unroll
@@ -524,8 +537,8 @@ constexpr int W1_MAXT = 12;      // tiles (gz + x) of a chunk
 constexpr int W1LD = 36;         // LDS row pitch (floats): 16-byte stores, conflict-free operand reads
 struct W1Tab { short seg[W1_MAXT]; short c0[W1_MAXT]; short kofs[W1_MAXT]; };
 
-template <int PPW, int CH>
-__global__ __launch_bounds__(256) void conv1x1_wgrad_allpairs_kernel(const egne_conv_desc p, const float* __restrict__ gz, long long gzs,
+template <int PPW, int CH, typename T>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_allpairs_kernel(const egne_conv_desc p, const T* __restrict__ gz, long long gzs,
                                                                      int gzo, int nsplit, int nco, int nkc, W1Tab tab,
                                                                      float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float w1lds[];     // [nco + nkc][CH][W1LD]
@@ -555,8 +568,8 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_allpairs_kernel(const egne_
         for (int i = 0; i < NR; ++i) {
           const long long m = mc + lr + 32 * i;
           const bool ok = cok && m < m_end;
-          const float* ptr = !ok ? egne_zero_page : (isg ? gz + m * gzs + gzo + c : sg.ptr + m * sg.pix_stride + sg.ch_off + c);
-          v[j][i] = *(const f32x4*)ptr;
+          const T* ptr = !ok ? zero_page<T>() : (isg ? gz + m * gzs + gzo + c : (const T*)sg.ptr + m * sg.pix_stride + sg.ch_off + c);
+          v[j][i] = ld4(ptr);
         }
       }
     }
@@ -704,8 +717,8 @@ int chunks_for(long long npix, int Cp, int Bn) {
 
 }  // namespace
 
-extern "C" int egne_loss_bwd(const egne_loss_desc* dp, const float* gscale, float* g_logits, int64_t gs, int go, float* g_elOut,
-                             void* stream) {
+template <typename T>
+static int loss_bwd_impl(const egne_loss_desc* dp, const float* gscale, T* g_logits, int64_t gs, int go, float* g_elOut, void* stream) {
   EGNE_REQUIRE(dp && g_logits && g_elOut && gscale, "loss_bwd: null pointer");
   const egne_loss_desc& d = *dp;
   EGNE_REQUIRE(d.coef && d.grid_x && d.grid_y && d.out_terms, "loss_bwd: forward state (coef/grid) missing");
@@ -713,33 +726,51 @@ extern "C" int egne_loss_bwd(const egne_loss_desc* dp, const float* gscale, floa
   const int HW = d.H * d.W;
   int gx = (HW + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(loss_bwd_k, dim3(gx, d.B), dim3(256), 0, (hipStream_t)stream, d, gscale, g_logits, (long long)gs, go,
-                     g_elOut);
+  hipLaunchKernelGGL(loss_bwd_k<T>, dim3(gx, d.B), dim3(256), 0, (hipStream_t)stream, d, gscale, g_logits, (long long)gs, go, g_elOut);
   return egne::check_launch("egne_loss_bwd");
+}
+extern "C" int egne_loss_bwd(const egne_loss_desc* dp, const float* gscale, float* g_logits, int64_t gs, int go, float* g_elOut,
+                             void* stream) {
+  EGNE_REQUIRE(dp && dp->dtype == 0, "loss_bwd: descriptor says bf16 logits (use egne_loss_bwd_bf16)");
+  return loss_bwd_impl(dp, gscale, g_logits, gs, go, g_elOut, stream);
+}
+/* logits (descriptor, dtype = 1) and their gradient in bf16 */
+extern "C" int egne_loss_bwd_bf16(const egne_loss_desc* dp, const float* gscale, void* g_logits, int64_t gs, int go, float* g_elOut,
+                                  void* stream) {
+  EGNE_REQUIRE(dp && dp->dtype == 1, "loss_bwd_bf16: descriptor says fp32 logits");
+  return loss_bwd_impl(dp, gscale, (egne_bf16*)g_logits, gs, go, g_elOut, stream);
 }
 
 extern "C" int64_t egne_act_bwd_bias_workspace_bytes(int64_t npix, int Cp) {
   return (int64_t)chunks_for(npix, Cp, 1) * Cp * sizeof(double);
 }
 
-extern "C" int egne_act_bwd_bias_absmax(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
-                                        int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits,
-                                        void* stream) {
+template <typename T>
+static int act_bwd_bias_impl(T* g, int64_t gs, int go, const T* y, int64_t ys, int yo, int act, int Cp,
+                             int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits, void* stream) {
   EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && npix > 0 && ws, "act_bwd_bias: bad gradient slice");
   EGNE_REQUIRE(act == EGNE_ACT_NONE || slice_ok(y, ys, yo, Cp), "act_bwd_bias: bad output slice");
   const int nchunk = chunks_for(npix, Cp, 1);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(act_bwd_bias_partial, dim3(nchunk, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, y,
+  hipLaunchKernelGGL(act_bwd_bias_partial<T>, dim3(nchunk, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, y,
                      (long long)ys, yo, act, Cp, (long long)npix, nchunk, (double*)ws, (unsigned*)absmax_bits);
   if (dbias)
     hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 31) / 32), dim3(256), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
                        nchunk, dbias, accumulate);
   return egne::check_launch("egne_act_bwd_bias");
 }
-
+extern "C" int egne_act_bwd_bias_absmax(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
+                                        int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits,
+                                        void* stream) {
+  return act_bwd_bias_impl(g, gs, go, y, ys, yo, act, Cp, npix, dbias, C, accumulate, ws, absmax_bits, stream);
+}
 extern "C" int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
                                  int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream) {
-  return egne_act_bwd_bias_absmax(g, gs, go, y, ys, yo, act, Cp, npix, dbias, C, accumulate, ws, nullptr, stream);
+  return act_bwd_bias_impl(g, gs, go, y, ys, yo, act, Cp, npix, dbias, C, accumulate, ws, (uint32_t*)nullptr, stream);
+}
+extern "C" int egne_act_bwd_bias_bf16(void* g, int64_t gs, int go, const void* y, int64_t ys, int yo, int act, int Cp,
+                                      int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream) {
+  return act_bwd_bias_impl((egne_bf16*)g, gs, go, (const egne_bf16*)y, ys, yo, act, Cp, npix, dbias, C, accumulate, ws, (uint32_t*)nullptr, stream);
 }
 
 extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_sample) {
@@ -748,9 +779,10 @@ extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_
   return (int64_t)Bn * chunks_for(npix, Cp, Bn) * Cp * 2 * sizeof(double);
 }
 
-static int norm_bwd_impl(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
-                         const float* gamma, const float* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
-                         int per_sample, float* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+template <typename T>
+static int norm_bwd_impl(const T* x, int64_t xs, int xo, const float* scale, const float* shift,
+                         const float* gamma, const T* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                         int per_sample, T* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
                          int C, void* ws, void* stream, int poolW, int accumulate) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(gy, gs, go, Cp) && slice_ok(gx, gxs, gxo, Cp), "norm_bwd: bad slices");
   EGNE_REQUIRE(scale && shift && sums && ws && B > 0 && HW > 0, "norm_bwd: null pointer");
@@ -759,11 +791,11 @@ static int norm_bwd_impl(const float* x, int64_t xs, int xo, const float* scale,
   const long long npix = per_sample ? HW : (long long)B * HW;
   const int nchunk = chunks_for(npix, Cp, Bn);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(norm_bwd_partial, dim3(nchunk, (Cp + 31) / 32, Bn), dim3(256), 0, st, x, (long long)xs, xo, scale, shift,
+  hipLaunchKernelGGL(norm_bwd_partial<T>, dim3(nchunk, (Cp + 31) / 32, Bn), dim3(256), 0, st, x, (long long)xs, xo, scale, shift,
                      gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws, poolW);
   hipLaunchKernelGGL(norm_bwd_final, dim3((Bn * Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
                      dgamma, dbeta, C);
-  hipLaunchKernelGGL(norm_bwd_apply, dim3(grid_for((long long)Bn * npix * (Cp / 4))), dim3(256), 0, st, x, (long long)xs, xo,
+  hipLaunchKernelGGL(norm_bwd_apply<T>, dim3(grid_for((long long)Bn * npix * (Cp / 4))), dim3(256), 0, st, x, (long long)xs, xo,
                      scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,
                      gxo, poolW, accumulate);
   return egne::check_launch("egne_norm_bwd");
@@ -776,6 +808,13 @@ extern "C" int egne_norm_bwd(const float* x, int64_t xs, int xo, const float* sc
   return norm_bwd_impl(x, xs, xo, scale, shift, gamma, gy, gs, go, act_in, Cp, B, HW, per_sample, gx, gxs, gxo, sums, dgamma, dbeta,
                        C, ws, stream, 0, 1);
 }
+extern "C" int egne_norm_bwd_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift,
+                                  const float* gamma, const void* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                                  int per_sample, void* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                                  int C, void* ws, void* stream) {
+  return norm_bwd_impl((const egne_bf16*)x, xs, xo, scale, shift, gamma, (const egne_bf16*)gy, gs, go, act_in, Cp, B, HW, per_sample,
+                       (egne_bf16*)gx, gxs, gxo, sums, dgamma, dbeta, C, ws, stream, 0, 1);
+}
 
 // The same with gx STORED instead of accumulated (first writer of a gradient slice: engine.Plan.first_touch).
 extern "C" int egne_norm_bwd_store(const float* x, int64_t xs, int xo, const float* scale, const float* shift,
@@ -785,6 +824,13 @@ extern "C" int egne_norm_bwd_store(const float* x, int64_t xs, int xo, const flo
   return norm_bwd_impl(x, xs, xo, scale, shift, gamma, gy, gs, go, act_in, Cp, B, HW, per_sample, gx, gxs, gxo, sums, dgamma, dbeta,
                        C, ws, stream, 0, 0);
 }
+extern "C" int egne_norm_bwd_store_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift,
+                                        const float* gamma, const void* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW,
+                                        int per_sample, void* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
+                                        int C, void* ws, void* stream) {
+  return norm_bwd_impl((const egne_bf16*)x, xs, xo, scale, shift, gamma, (const egne_bf16*)gy, gs, go, act_in, Cp, B, HW, per_sample,
+                       (egne_bf16*)gx, gxs, gxo, sums, dgamma, dbeta, C, ws, stream, 0, 0);
+}
 
 // Backward of egne_norm_act_pool2 (zp = avg_pool2d(act(x*scale + shift), 2), per-sample statistics): the InstanceNorm backward
 // with gy[n][y][x] = gzp[n][y/2][x/2] / 4 read straight from the pooled gradient.  H and W even.
@@ -792,51 +838,96 @@ extern "C" int egne_norm_pool2_bwd(const float* x, int64_t xs, int xo, const flo
                                    const float* gzp, int64_t gs, int go, int act_in, int Cp, int B, int H, int W,
                                    float* gx, int64_t gxs, int gxo, int accumulate, float* sums, void* ws, void* stream) {
   EGNE_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "norm_pool2_bwd: even map sizes only (got %dx%d)", H, W);
-  return norm_bwd_impl(x, xs, xo, scale, shift, nullptr, gzp, gs, go, act_in, Cp, B, H * W, 1, gx, gxs, gxo, sums, nullptr, nullptr,
-                       0, ws, stream, W, accumulate);
+  return norm_bwd_impl(x, xs, xo, scale, shift, (const float*)nullptr, gzp, gs, go, act_in, Cp, B, H * W, 1, gx, gxs, gxo, sums,
+                       (float*)nullptr, (float*)nullptr, 0, ws, stream, W, accumulate);
+}
+extern "C" int egne_norm_pool2_bwd_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift,
+                                        const void* gzp, int64_t gs, int go, int act_in, int Cp, int B, int H, int W,
+                                        void* gx, int64_t gxs, int gxo, int accumulate, float* sums, void* ws, void* stream) {
+  EGNE_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "norm_pool2_bwd: even map sizes only (got %dx%d)", H, W);
+  return norm_bwd_impl((const egne_bf16*)x, xs, xo, scale, shift, (const float*)nullptr, (const egne_bf16*)gzp, gs, go, act_in, Cp, B,
+                       H * W, 1, (egne_bf16*)gx, gxs, gxo, sums, (float*)nullptr, (float*)nullptr, 0, ws, stream, W, accumulate);
 }
 
-extern "C" int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
-                                 int Cp, void* stream) {
+template <typename T>
+static int avgpool2_bwd_impl(const T* gy, int64_t gs, int go, T* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(gy, gs, go, Cp) && slice_ok(gx, xs, xo, Cp) && B > 0 && H >= 2 && W >= 2, "avgpool2_bwd: bad arguments");
-  hipLaunchKernelGGL(avgpool2_bwd_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+  hipLaunchKernelGGL(avgpool2_bwd_k<T>, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
                      (hipStream_t)stream, gy, (long long)gs, go, gx, (long long)xs, xo, B, H, W, Cp);
   return egne::check_launch("egne_avgpool2_bwd");
 }
+extern "C" int egne_avgpool2_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
+                                 int Cp, void* stream) {
+  return avgpool2_bwd_impl(gy, gs, go, gx, xs, xo, B, H, W, Cp, stream);
+}
+extern "C" int egne_avgpool2_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W,
+                                      int Cp, void* stream) {
+  return avgpool2_bwd_impl((const egne_bf16*)gy, gs, go, (egne_bf16*)gx, xs, xo, B, H, W, Cp, stream);
+}
 
-extern "C" int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
-                                   int Cp, void* stream) {
+template <typename T>
+static int upsample2x_bwd_impl(const T* gy, int64_t gs, int go, T* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(gy, gs, go, Cp) && slice_ok(gx, xs, xo, Cp) && B > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
-  hipLaunchKernelGGL(upsample2x_bwd_k, dim3(grid_for((long long)B * H * W * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, gy,
+  hipLaunchKernelGGL(upsample2x_bwd_k<T>, dim3(grid_for((long long)B * H * W * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, gy,
                      (long long)gs, go, gx, (long long)xs, xo, B, H, W, Cp);
   return egne::check_launch("egne_upsample2x_bwd");
 }
+extern "C" int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
+                                   int Cp, void* stream) {
+  return upsample2x_bwd_impl(gy, gs, go, gx, xs, xo, B, H, W, Cp, stream);
+}
+extern "C" int egne_upsample2x_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W,
+                                        int Cp, void* stream) {
+  return upsample2x_bwd_impl((const egne_bf16*)gy, gs, go, (egne_bf16*)gx, xs, xo, B, H, W, Cp, stream);
+}
 
-extern "C" int egne_ellipse_head_act_bwd(float* g, const float* y, int B, int ld, void* stream) {
+template <typename T>
+static int head_act_bwd_impl(T* g, const T* y, int B, int ld, void* stream) {
   EGNE_REQUIRE(g && y && B > 0 && ld >= 10, "head_act_bwd: bad arguments");
-  hipLaunchKernelGGL(head_act_bwd_k, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, y, B, ld);
+  hipLaunchKernelGGL(head_act_bwd_k<T>, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, y, B, ld);
   return egne::check_launch("egne_ellipse_head_act_bwd");
 }
+extern "C" int egne_ellipse_head_act_bwd(float* g, const float* y, int B, int ld, void* stream) { return head_act_bwd_impl(g, y, B, ld, stream); }
+extern "C" int egne_ellipse_head_act_bwd_bf16(void* g, const void* y, int B, int ld, void* stream) {
+  return head_act_bwd_impl((egne_bf16*)g, (const egne_bf16*)y, B, ld, stream);
+}
 
-extern "C" int egne_selu_bwd(float* g, const float* y, int64_t n, void* stream) {
+template <typename T>
+static int selu_bwd_impl(T* g, const T* y, int64_t n, void* stream) {
   EGNE_REQUIRE(g && y && n > 0, "selu_bwd: bad arguments");
-  hipLaunchKernelGGL(selu_bwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, (long long)n);
+  hipLaunchKernelGGL(selu_bwd_k<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, (long long)n);
   return egne::check_launch("egne_selu_bwd");
 }
+extern "C" int egne_selu_bwd(float* g, const float* y, int64_t n, void* stream) { return selu_bwd_impl(g, y, n, stream); }
+extern "C" int egne_selu_bwd_bf16(void* g, const void* y, int64_t n, void* stream) { return selu_bwd_impl((egne_bf16*)g, (const egne_bf16*)y, n, stream); }
 
-extern "C" int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo, int C, int B, int HW,
-                                     void* stream) {
+template <typename T>
+static int spatial_mean_bwd_impl(const T* g, int gld, T* gx, int64_t xs, int xo, int C, int B, int HW, void* stream) {
   EGNE_REQUIRE(g && gx && C > 0 && xo + C <= xs && gld >= C && B > 0 && HW > 0, "spatial_mean_bwd: bad arguments");
-  hipLaunchKernelGGL(spatial_mean_bwd_k, dim3(B), dim3(256), 0, (hipStream_t)stream, g, gld, gx, (long long)xs, xo, C, HW);
+  hipLaunchKernelGGL(spatial_mean_bwd_k<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, gld, gx, (long long)xs, xo, C, HW);
   return egne::check_launch("egne_spatial_mean_bwd");
 }
+extern "C" int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo, int C, int B, int HW, void* stream) {
+  return spatial_mean_bwd_impl(g, gld, gx, xs, xo, C, B, HW, stream);
+}
+extern "C" int egne_spatial_mean_bwd_bf16(const void* g, int gld, void* gx, int64_t xs, int xo, int C, int B, int HW, void* stream) {
+  return spatial_mean_bwd_impl((const egne_bf16*)g, gld, (egne_bf16*)gx, xs, xo, C, B, HW, stream);
+}
 
-extern "C" int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag, const float* gscale,
-                                  float* gpred, int gld, void* stream) {
+template <typename T>
+static int conf_loss_bwd_impl(const T* pred, int ld, const int64_t* gt, int B, int C, int flag, const float* gscale, T* gpred, int gld, void* stream) {
   EGNE_REQUIRE(pred && gpred && gscale && B > 0 && C > 0 && ld >= C && gld >= C && (flag || gt), "conf_loss_bwd: bad arguments");
-  hipLaunchKernelGGL(conf_loss_bwd_k, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, ld,
+  hipLaunchKernelGGL(conf_loss_bwd_k<T>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, ld,
                      (const long long*)gt, B, C, flag, gscale, gpred, gld);
   return egne::check_launch("egne_conf_loss_bwd");
+}
+extern "C" int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag, const float* gscale,
+                                  float* gpred, int gld, void* stream) {
+  return conf_loss_bwd_impl(pred, ld, gt, B, C, flag, gscale, gpred, gld, stream);
+}
+extern "C" int egne_conf_loss_bwd_bf16(const void* pred, int ld, const int64_t* gt, int B, int C, int flag, const float* gscale,
+                                       void* gpred, int gld, void* stream) {
+  return conf_loss_bwd_impl((const egne_bf16*)pred, ld, gt, B, C, flag, gscale, (egne_bf16*)gpred, gld, stream);
 }
 
 // all-pairs 1x1 form: shapes it takes, chunk length and pairs per wave
@@ -864,7 +955,8 @@ static int w1_splits(const egne_conv_desc& d, int ch) {
 extern "C" int egne_conv2d_wgrad_splits(const egne_conv_desc* dp) {
   if (!dp) return 0;
   const egne_conv_desc& d = *dp;
-  if (egne::wgrad_halo_supported(d, d.out_pix_stride)) return egne::wgrad_halo_splits(d);
+  if (d.dtype == 1 && egne::wgrad3x3_bf16_supported(d, d.out_pix_stride)) return egne::wgrad3x3_bf16_splits(d);
+  if (d.dtype == 0 && egne::wgrad_halo_supported(d, d.out_pix_stride)) return egne::wgrad_halo_splits(d);
   { int a, b2, ch; if (w1_supported(d, &a, &b2, &ch)) return w1_splits(d, ch); }
   int per_tap = 0;
   for (int s = 0; s < d.nseg; ++s) per_tap += (d.seg[s].Cp + 31) / 32;
@@ -886,8 +978,10 @@ extern "C" int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* dp) {
 
 // gz: gradient w.r.t. the pre-activation output (Cout_store channels).  gw[g]: OIHW gradient tensors,
 // accumulated into.  kinv as in egne_pack_conv_weight.  ws: egne_conv2d_wgrad_workspace_bytes.
-static int wgrad_impl(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, const uint32_t* gz_dyn, int Cout, int Cin,
+template <typename TS>
+static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int gzo, const uint32_t* gz_dyn, int Cout, int Cin,
                       const int32_t* kinv, float* const* gw, void* ws, void* stream) {
+  constexpr bool BF = !std::is_same<TS, float>::value;
   EGNE_REQUIRE(dp && gz && kinv && gw && ws, "wgrad: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP, "wgrad: bad descriptor");
@@ -902,14 +996,25 @@ static int wgrad_impl(const egne_conv_desc* dp, const float* gz, int64_t gzs, in
   const int T = d.kh * d.kw, nsplit = egne_conv2d_wgrad_splits(dp);
   hipStream_t st = (hipStream_t)stream;
   const size_t bytes = (size_t)nsplit * d.ngroups * T * d.CoutP * d.Ktot * sizeof(float);
-  if (egne::wgrad_halo_supported(d, d.out_pix_stride)) {
+  bool fast3x3 = false;
+  if constexpr (BF) {
+    if (egne::wgrad3x3_bf16_supported(d, gzs)) {         // 3x3 "same" convolutions over one slice: bf16 MFMA (wgrad_bf16.hip)
+      const int rc = egne::wgrad3x3_bf16_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);     // writes every partial it owns
+      if (rc != EGNE_OK) return rc;
+      fast3x3 = true;
+    }
+  }
+  if (fast3x3) {
+  } else if (!BF && egne::wgrad_halo_supported(d, d.out_pix_stride)) {
     // the gradient buffer mirrors the output buffer (same pixel stride): the split count above assumed it
     EGNE_REQUIRE(gzs == d.out_pix_stride, "wgrad: gz stride %lld differs from the output stride %lld", (long long)gzs, (long long)d.out_pix_stride);
     // split-f16 products when the caller supplies max|gz| on the device AND x has a pre-scale (normalised on load or the
     // forward launch's device word); exact fp32 otherwise
     const bool f16 = gz_dyn && (d.seg[0].scale || d.dyn_scale);
-    const int rc = f16 ? egne::wgrad_halo_f16_launch(d, gz, (long long)gzs, gzo, (const unsigned*)gz_dyn, (float*)ws, st)
-                       : egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
+    int rc = EGNE_OK;
+    if constexpr (!BF)
+      rc = f16 ? egne::wgrad_halo_f16_launch(d, gz, (long long)gzs, gzo, (const unsigned*)gz_dyn, (float*)ws, st)
+               : egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
     if (rc != EGNE_OK) return rc;
   } else if (int nco = 0, nkc = 0, ch = 0; w1_supported(d, &nco, &nkc, &ch)) {
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
@@ -928,16 +1033,16 @@ static int wgrad_impl(const egne_conv_desc* dp, const float* gz, int64_t gzs, in
       return EGNE_OK;
     };
     int rc;
-    if (ch == 64) rc = ppw <= 1 ? go(conv1x1_wgrad_allpairs_kernel<1, 64>) : ppw <= 2 ? go(conv1x1_wgrad_allpairs_kernel<2, 64>)
-                     : ppw <= 3 ? go(conv1x1_wgrad_allpairs_kernel<3, 64>) : ppw <= 4 ? go(conv1x1_wgrad_allpairs_kernel<4, 64>)
-                     : go(conv1x1_wgrad_allpairs_kernel<8, 64>);
-    else rc = ppw <= 2 ? go(conv1x1_wgrad_allpairs_kernel<2, 32>) : ppw <= 4 ? go(conv1x1_wgrad_allpairs_kernel<4, 32>)
-              : go(conv1x1_wgrad_allpairs_kernel<8, 32>);
+    if (ch == 64) rc = ppw <= 1 ? go(conv1x1_wgrad_allpairs_kernel<1, 64, TS>) : ppw <= 2 ? go(conv1x1_wgrad_allpairs_kernel<2, 64, TS>)
+                     : ppw <= 3 ? go(conv1x1_wgrad_allpairs_kernel<3, 64, TS>) : ppw <= 4 ? go(conv1x1_wgrad_allpairs_kernel<4, 64, TS>)
+                     : go(conv1x1_wgrad_allpairs_kernel<8, 64, TS>);
+    else rc = ppw <= 2 ? go(conv1x1_wgrad_allpairs_kernel<2, 32, TS>) : ppw <= 4 ? go(conv1x1_wgrad_allpairs_kernel<4, 32, TS>)
+              : go(conv1x1_wgrad_allpairs_kernel<8, 32, TS>);
     if (rc != EGNE_OK) return rc;
   } else {
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
     dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+    hipLaunchKernelGGL(conv_wgrad_kernel<TS>, grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
   }
   for (int g = 0; g < d.ngroups; ++g) {
     EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
@@ -950,11 +1055,14 @@ static int wgrad_impl(const egne_conv_desc* dp, const float* gz, int64_t gzs, in
 
 extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,
                                  const int32_t* kinv, float* const* gw, void* ws, void* stream) {
-  return wgrad_impl(dp, gz, gzs, gzo, nullptr, Cout, Cin, kinv, gw, ws, stream);
+  // descriptor dtype 1: the input slices AND gz are bf16 tensors (fp32 products, or bf16 MFMA for 3x3 "same" convolutions)
+  if (dp && dp->dtype == 1) return wgrad_impl(dp, (const egne_bf16*)gz, gzs, gzo, (const uint32_t*)nullptr, Cout, Cin, kinv, gw, ws, stream);
+  return wgrad_impl(dp, gz, gzs, gzo, (const uint32_t*)nullptr, Cout, Cin, kinv, gw, ws, stream);
 }
 
 extern "C" int egne_conv2d_wgrad_f16(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, const uint32_t* gz_absmax_bits,
                                      int Cout, int Cin, const int32_t* kinv, float* const* gw, void* ws, void* stream) {
+  EGNE_REQUIRE(dp && dp->dtype == 0, "conv2d_wgrad_f16: fp32 tensors only (bf16 plans call egne_conv2d_wgrad)");
   return wgrad_impl(dp, gz, gzs, gzo, gz_absmax_bits, Cout, Cin, kinv, gw, ws, stream);
 }
 

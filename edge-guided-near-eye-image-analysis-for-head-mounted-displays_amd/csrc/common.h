@@ -10,6 +10,27 @@
 // each load and waits vmcnt(0) per element, which serialises the whole staging phase.
 static __device__ __attribute__((aligned(256), used)) float egne_zero_page[64] = {0};
 
+// ---- storage types of activation tensors ------------------------------------------------------------------------------
+// fp32 everywhere by default; training plans may keep activations and activation gradients in HBM as bf16 (BASELINE.json
+// configs[2..4]: "bf16"), always with fp32 arithmetic / accumulation.  Kernels that take either are templates over the element
+// type and read / write FOUR consecutive channels through ld4 / st4 (16 bytes of fp32, 8 bytes of bf16; round-to-nearest-even
+// on store: v_cvt_pk_bf16_f32).  The C-ABI twin of such an entry point carries the suffix _bf16 (include/egne_hip.h).
+typedef __bf16 egne_bf16;
+typedef float egne_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 egne_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 egne_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ egne_f32x4 ld4(const float* p) { return *(const egne_f32x4*)p; }
+__device__ __forceinline__ egne_f32x4 ld4(const egne_bf16* p) { return __builtin_convertvector(*(const egne_bf16x4*)p, egne_f32x4); }
+__device__ __forceinline__ void st4(float* p, egne_f32x4 v) { *(egne_f32x4*)p = v; }
+__device__ __forceinline__ void st4(egne_bf16* p, egne_f32x4 v) { *(egne_bf16x4*)p = __builtin_convertvector(v, egne_bf16x4); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const egne_bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(egne_bf16* p, float v) { *p = (egne_bf16)v; }
+// the all-zero page typed for either storage (invalid lanes load from it unconditionally)
+template <typename T> __device__ __forceinline__ const T* zero_page() { return (const T*)egne_zero_page; }
+
 namespace egne {
 
 char* err_buf();  // thread-local 512-byte buffer (defined in api.hip)
@@ -38,6 +59,10 @@ bool wgrad_halo_supported(const egne_conv_desc& d, long long gzs);   // wgrad_ha
 int wgrad_halo_splits(const egne_conv_desc& d);
 int wgrad_halo_launch(const egne_conv_desc& d, const float* gz, long long gzs, int gzo, float* ws, hipStream_t st);
 int wgrad_halo_f16_launch(const egne_conv_desc& d, const float* gz, long long gzs, int gzo, const unsigned* gz_dyn, float* ws, hipStream_t st);
+
+bool wgrad3x3_bf16_supported(const egne_conv_desc& d, long long gzs);   // wgrad_bf16.hip (bf16 tensors, bf16 MFMA)
+int wgrad3x3_bf16_splits(const egne_conv_desc& d);
+int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st);
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

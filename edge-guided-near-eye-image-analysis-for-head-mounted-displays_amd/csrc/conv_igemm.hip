@@ -36,7 +36,34 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0x80000000u;
+
+// Four consecutive channels of an activation tensor through a buffer resource: 16 bytes of fp32 or 8 bytes of bf16
+// (egne_conv_desc.dtype); `off` is a BYTE offset.  Raw<TS> is what stays in registers until the values are needed.
+template <typename TS> struct Raw4 { typedef u32x4 type; };
+template <> struct Raw4<egne_bf16> { typedef u32x2 type; };
+template <typename TS> __device__ __forceinline__ typename Raw4<TS>::type load_raw4(__amdgpu_buffer_rsrc_t r, int off, int soff) {
+  if constexpr (sizeof(TS) == 4) return __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0);
+  else return __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
+}
+__device__ __forceinline__ f32x4 raw_to_f32(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ f32x4 raw_to_f32(u32x2 v) {
+  const u32x4 w = {v[0] << 16, v[0] & 0xffff0000u, v[1] << 16, v[1] & 0xffff0000u};
+  return __builtin_bit_cast(f32x4, w);
+}
+template <typename TS> __device__ __forceinline__ float load_el(__amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (sizeof(TS) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  else return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
+}
+template <typename TS> __device__ __forceinline__ void store_el(float v, __amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (sizeof(TS) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (egne_bf16)v), r, off, 0, 0);
+}
+template <typename TS> __device__ __forceinline__ void store_4(f32x4 v, __amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (sizeof(TS) == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, egne_bf16x4)), r, off, 0, 0);
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -47,8 +74,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // buffer resource with one multiply-add, padded lanes get 0x80000000 (the buffer unit returns zeros).  Weights,
 // residual and output go through buffer instructions with lane-constant offsets.  Reflect padding (StyleEncoder
 // only) recomputes the mirrored coordinates per step.
-template <int WM, int WN, bool GROUPED>
+template <int WM, int WN, bool GROUPED, typename TS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p) {
+  constexpr int ES = sizeof(TS);          // bytes per activation element (weights, bias and affine tables are fp32 always)
   constexpr int BM = 128 * WM, BN = 32 * WN;
   constexpr int AR = BM / 32;  // A rows staged per thread
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDK];
@@ -99,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 #pragma unroll
   for (int j = 0; j < WN; ++j) boff[j] = ((n0 + rbase + 32 * j) * p.Ktot + col4 * 4) * 4;
 
-  u32x4 ra[AR];
+  typename Raw4<TS>::type ra[AR];
   u32x4 rb[WN];
 
   auto advance = [&](KState& s) {
@@ -128,11 +156,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     const bool cok = c < sg.Cp;
     okmask = 0;
     st_seg = s.seg; st_c = c;
-    const long long left = ((long long)p.B - b0) * frame_px * sg.pix_stride * 4;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+    const long long left = ((long long)p.B - b0) * frame_px * sg.pix_stride * ES;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const TS*)sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
                                                  (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
-    const int ps4 = (int)sg.pix_stride * 4;
-    const int coff = (sg.ch_off + c) * 4;
+    const int ps4 = (int)sg.pix_stride * ES;
+    const int coff = (sg.ch_off + c) * ES;
     if (p.pad_mode == 1) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
         ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
         const bool ok = cok && pb[i] >= 0;
         const int q = (pb[i] - b0) * frame_px + iy * p.W + ix;
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? q * ps4 + coff : (int)OOB, 0, 0);
+        ra[i] = load_raw4<TS>(rin, ok ? q * ps4 + coff : (int)OOB, 0);
         okmask |= (ok ? 1u : 0u) << i;
       }
     } else {
@@ -149,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         const bool ok = cok && ((tapmask[i] >> s.tap) & 1u);
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (pix[i] + tapd) * ps4 + coff : (int)OOB, 0, 0);
+        ra[i] = load_raw4<TS>(rin, ok ? (pix[i] + tapd) * ps4 + coff : (int)OOB, 0);
         okmask |= (ok ? 1u : 0u) << i;
       }
     }
@@ -182,14 +210,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
         } else if (!ok) {
           sc = (f32x4)(0.f); sh = (f32x4)(0.f);
         }
-        f32x4 v = __builtin_bit_cast(f32x4, ra[i]) * sc + sh;
+        f32x4 v = raw_to_f32(ra[i]) * sc + sh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
-        ra[i] = __builtin_bit_cast(u32x4, v);
+        *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = v;
       }
-    }
+    } else {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *(u32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = ra[i];
+      for (int i = 0; i < AR; ++i) *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = raw_to_f32(ra[i]);
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) *(u32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
   };
@@ -271,10 +300,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   // ---- epilogue: lane holds column n of 16 rows: row = (r&3) + 8*(r>>2) + 4*lh ----
   const long long left = M - m0;
   const long long rows = left < BM ? left : BM;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
-  const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
-                                                p.residual ? (unsigned)(rows * p.res_pix_stride * 4) : 0u);
-  const int ostep = (int)p.out_pix_stride * 4, rstep = (int)p.res_pix_stride * 4;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc((TS*)p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * ES));
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? (const TS*)p.residual + m0 * p.res_pix_stride : nullptr,
+                                                p.residual ? (unsigned)(rows * p.res_pix_stride * ES) : 0u);
+  const int ostep = (int)p.out_pix_stride * ES, rstep = (int)p.res_pix_stride * ES;
   unsigned mb = 0;           // max bit pattern of |stored value| (egne_conv_desc.absmax_out)
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn) {
@@ -286,15 +315,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 #pragma unroll
     for (int tm = 0; tm < WM; ++tm) {
       const int mrow = wave * 32 * WM + tm * 32 + 4 * lh;
-      const unsigned o0 = nok ? (unsigned)(mrow * ostep + (p.out_ch_off + n) * 4) : OOB;   // rows past M: range check
+      const unsigned o0 = nok ? (unsigned)(mrow * ostep + (p.out_ch_off + n) * ES) : OOB;   // rows past M: range check
       float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) rv[r] = 0.f;
       if (p.residual) {
-        const unsigned r0 = nok ? (unsigned)(mrow * rstep + (p.res_ch_off + n) * 4) : OOB;
+        const unsigned r0 = nok ? (unsigned)(mrow * rstep + (p.res_ch_off + n) * ES) : OOB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(r0 + ((r & 3) + 8 * (r >> 2)) * rstep), 0, 0));
+        for (int r = 0; r < 16; ++r) rv[r] = load_el<TS>(rres, (int)(r0 + ((r & 3) + 8 * (r >> 2)) * rstep));
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -302,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
         if (GROUPED) v = res[tm][tn][r];
         else { v = acc[tm][tn][r] + bv; v = fmaxf(v, v * slope_out); }
         v = v * ps + pt + rv[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
+        store_el<TS>(v, rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep));
         const unsigned b = (nok && mrow + (r & 3) + 8 * (r >> 2) < rows) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u;
         mb = b > mb ? b : mb;
       }
@@ -322,8 +350,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 // A tile is [tap0 c0..c3 | tap1 c0..c3 | ... | tap8 c0..c3 | 0 0 0 0] (K = 40), staged once, one barrier, 20
 // fp32 MFMAs per 32x32 tile.  The layer is then a pure store stream (128-256 B per pixel).
 constexpr int C4K = 40, C4LD = 44;
-template <int WN>
+template <int WN, typename TS>
 __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p, const float* __restrict__ w40) {
+  constexpr int ES = sizeof(TS);
   __shared__ __attribute__((aligned(16))) float As[256 * C4LD];
   __shared__ __attribute__((aligned(16))) float Bs[32 * WN * C4LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,18 +367,18 @@ __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p,
     const int b = (int)(m / hw);
     const int r = (int)(m - (long long)b * hw);
     const int y = r / p.W, x = r - y * p.W;
-    const long long left = ((long long)p.B - b0) * hw * sg.pix_stride * 4;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * hw * sg.pix_stride, (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
-    const int base = (((b - b0) * hw + r) * (int)sg.pix_stride + sg.ch_off) * 4;
-    u32x4 v[9];
+    const long long left = ((long long)p.B - b0) * hw * sg.pix_stride * ES;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const TS*)sg.ptr + (long long)b0 * hw * sg.pix_stride, (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+    const int base = (((b - b0) * hw + r) * (int)sg.pix_stride + sg.ch_off) * ES;
+    typename Raw4<TS>::type v[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3 - 1, dx = t % 3 - 1;
       const bool ok = m < M && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
-      v[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? base + (dy * p.W + dx) * (int)sg.pix_stride * 4 : (int)OOB, 0, 0);
+      v[t] = load_raw4<TS>(rin, ok ? base + (dy * p.W + dx) * (int)sg.pix_stride * ES : (int)OOB, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) *(u32x4*)&As[tid * C4LD + t * 4] = v[t];
+    for (int t = 0; t < 9; ++t) *(f32x4*)&As[tid * C4LD + t * 4] = raw_to_f32(v[t]);
     *(f32x4*)&As[tid * C4LD + 36] = (f32x4)(0.f);
     for (int i = tid; i < 32 * WN * 10; i += 256) {
       const int n = i / 10, q = i - n * 10;
@@ -380,7 +409,7 @@ __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p,
   }
   const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   const long long left = M - m0;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < 256 ? left : 256) * p.out_pix_stride * 4));
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc((TS*)p.out + m0 * p.out_pix_stride, (unsigned)((left < 256 ? left : 256) * p.out_pix_stride * ES));
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
@@ -399,8 +428,7 @@ __global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p,
           v[e] = fmaxf(t, t * slope) * ps[e] + pt[e];
         }
         const int row = wave * 64 + tm * 32 + li;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
-                                               nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
+        store_4<TS>(v, rout, nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * ES : (int)OOB);
       }
     }
 }
@@ -410,10 +438,13 @@ int launch(const egne_conv_desc& d, hipStream_t st) {
   constexpr int BM = 128 * WM, BN = 32 * WN;
   const long long M = (long long)d.B * d.Ho * d.Wo;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / BN));
-  if (d.ngroups > 1)
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, true>), grid, dim3(256), 0, st, d);
+  if (d.dtype == 1) {       // bf16 activation tensors (training plans); the fused MSBlock form belongs to the frozen fp32 network
+    if (d.ngroups > 1) return egne::fail(EGNE_ERR_ARG, "conv: grouped launches take fp32 tensors only");
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16>), grid, dim3(256), 0, st, d);
+  } else if (d.ngroups > 1)
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, true, float>), grid, dim3(256), 0, st, d);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false>), grid, dim3(256), 0, st, d);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, float>), grid, dim3(256), 0, st, d);
   return egne::check_launch("egne_conv2d_fwd");
 }
 
@@ -434,11 +465,15 @@ extern "C" int egne_conv3x3_smallcin_fwd(const egne_conv_desc* dp, const float* 
                ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride * 1024 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0),
                "conv_smallcin: output slice / alignment");
   EGNE_REQUIRE(2ll * d.H * d.W * d.seg[0].pix_stride * 4 < (1ll << 31), "conv_smallcin: frame too large for 32-bit byte offsets");
+  EGNE_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_smallcin: dtype %d", d.dtype);
   const long long M = (long long)d.B * d.H * d.W;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 255) / 256));
-  if (d.Cout_store <= 32) hipLaunchKernelGGL((conv3x3_c4_kernel<1>), grid, dim3(256), 0, st, d, w40);
-  else hipLaunchKernelGGL((conv3x3_c4_kernel<2>), grid, dim3(256), 0, st, d, w40);
+  if (d.dtype == 1) {
+    if (d.Cout_store <= 32) hipLaunchKernelGGL((conv3x3_c4_kernel<1, egne_bf16>), grid, dim3(256), 0, st, d, w40);
+    else hipLaunchKernelGGL((conv3x3_c4_kernel<2, egne_bf16>), grid, dim3(256), 0, st, d, w40);
+  } else if (d.Cout_store <= 32) hipLaunchKernelGGL((conv3x3_c4_kernel<1, float>), grid, dim3(256), 0, st, d, w40);
+  else hipLaunchKernelGGL((conv3x3_c4_kernel<2, float>), grid, dim3(256), 0, st, d, w40);
   return egne::check_launch("egne_conv3x3_smallcin_fwd");
 }
 
@@ -450,6 +485,8 @@ extern "C" int egne_conv2d_fwd(const egne_conv_desc* dp, void* stream) {
   EGNE_REQUIRE(d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP, "conv: ngroups %d", d.ngroups);
   EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG, "conv: nseg %d", d.nseg);
   EGNE_REQUIRE(d.pad_mode == 0 || d.pad_mode == 1, "conv: pad_mode %d", d.pad_mode);
+  EGNE_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv: dtype %d", d.dtype);
+  EGNE_REQUIRE(d.dtype == 0 || !d.absmax_out, "conv: absmax_out is for fp32 tensors");
   int ktot = 0;
   for (int s = 0; s < d.nseg; ++s) {
     const egne_seg& g = d.seg[s];

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, lon
 //   stage 1: grid (nchunk, ceil(Cp/32), Bn); block = 8 channel-vectors x 32 pixel rows
 //   stage 2: one thread per (n, c)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void norm_stats_partial(const float* __restrict__ x, long long pix_stride,
+template <typename T>
+__global__ __launch_bounds__(256) void norm_stats_partial(const T* __restrict__ x, long long pix_stride,
                                                           int ch_off, int Cp, long long npix_per_n, int nchunk,
                                                           double* __restrict__ ws) {
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
@@ -47,11 +48,11 @@ __global__ __launch_bounds__(256) void norm_stats_partial(const float* __restric
   const long long p1 = p0 + per < npix_per_n ? p0 + per : npix_per_n;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < Cp) {
-    const float* base = x + (long long)n * npix_per_n * pix_stride + ch_off + c;
+    const T* base = x + (long long)n * npix_per_n * pix_stride + ch_off + c;
     for (long long p = p0 + row; p < p1; p += 128) {        // four rows per trip: loads issued together (same summation order)
       f32x4 t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = p + 32 * u < p1 ? *(const f32x4*)(base + (p + 32 * u) * pix_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 4; ++u) t[u] = p + 32 * u < p1 ? ld4(base + (p + 32 * u) * pix_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -119,21 +120,23 @@ __global__ __launch_bounds__(1024) void norm_stats_finish_k(const double* __rest
   }
 }
 
-__global__ void affine_k(const float* x, long long pix_stride, int ch_off, float* y, long long ys, int yo, int Cp,
+template <typename T>
+__global__ void affine_k(const T* x, long long pix_stride, int ch_off, T* y, long long ys, int yo, int Cp,
                          long long npix, const float* __restrict__ scale, const float* __restrict__ shift) {
   const int nv = Cp >> 2;
   const long long total = npix * nv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long p = i / nv;
     const int c = (int)(i - p * nv) * 4;
-    const f32x4 v = *(const f32x4*)(x + p * pix_stride + ch_off + c);
+    const f32x4 v = ld4(x + p * pix_stride + ch_off + c);
     const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
-    *(f32x4*)(y + p * ys + yo + c) = v * sc + sh;
+    st4(y + p * ys + yo + c, v * sc + sh);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void avgpool2_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
+template <typename T>
+__global__ void avgpool2_k(const T* __restrict__ x, long long xs, int xo, T* __restrict__ y, long long ys,
                            int yo, int B, int H, int W, int Cp) {
   const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
   const long long total = (long long)B * Ho * Wo * nv;
@@ -143,19 +146,20 @@ __global__ void avgpool2_k(const float* __restrict__ x, long long xs, int xo, fl
     const int ox = (int)(p % Wo); p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    const float* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
-    const f32x4 a = *(const f32x4*)s, bb = *(const f32x4*)(s + xs);
-    const f32x4 cc = *(const f32x4*)(s + (long long)W * xs), d = *(const f32x4*)(s + (long long)W * xs + xs);
+    const T* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
+    const f32x4 a = ld4(s), bb = ld4(s + xs);
+    const f32x4 cc = ld4(s + (long long)W * xs), d = ld4(s + (long long)W * xs + xs);
     f32x4 r = ((a + bb) + cc) + d;  // row-major accumulation order of ATen's avg_pool2d
     r = r * 0.25f;
-    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+    st4(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, r);
   }
 }
 
 // avgpool2(act(x*scale+shift)): Transition_down with the pooling commuted in front of its 1x1 conv
 // (both are linear, models/RITnet_v2.py:40-44), which quarters the conv's work and traffic.
-__global__ void norm_act_pool2_k(const float* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
-                                 const float* __restrict__ shift, int act, float* __restrict__ y, long long ys, int yo,
+template <typename T>
+__global__ void norm_act_pool2_k(const T* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, int act, T* __restrict__ y, long long ys, int yo,
                                  int B, int H, int W, int Cp) {
   const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
   const long long total = (long long)B * Ho * Wo * nv;
@@ -166,9 +170,8 @@ __global__ void norm_act_pool2_k(const float* __restrict__ x, long long xs, int 
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
     const f32x4 sc = *(const f32x4*)(scale + (long long)b * Cp + c), sh = *(const f32x4*)(shift + (long long)b * Cp + c);
-    const float* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
-    f32x4 v[4] = {*(const f32x4*)s, *(const f32x4*)(s + xs), *(const f32x4*)(s + (long long)W * xs),
-                  *(const f32x4*)(s + (long long)W * xs + xs)};
+    const T* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
+    f32x4 v[4] = {ld4(s), ld4(s + xs), ld4(s + (long long)W * xs), ld4(s + (long long)W * xs + xs)};
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -177,7 +180,7 @@ __global__ void norm_act_pool2_k(const float* __restrict__ x, long long xs, int 
       for (int e = 0; e < 4; ++e) t[e] = act == EGNE_ACT_LEAKY ? (t[e] > 0.f ? t[e] : 0.01f * t[e]) : (act == EGNE_ACT_RELU ? fmaxf(t[e], 0.f) : t[e]);
       r += t;
     }
-    *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r * 0.25f;
+    st4(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, r * 0.25f);
   }
 }
 
@@ -214,7 +217,8 @@ __global__ void maxpool2_k(const float* __restrict__ x, long long xs, int xo, fl
   }
 }
 
-__global__ void upsample2x_k(const float* __restrict__ x, long long xs, int xo, float* __restrict__ y, long long ys,
+template <typename T>
+__global__ void upsample2x_k(const T* __restrict__ x, long long xs, int xo, T* __restrict__ y, long long ys,
                              int yo, int B, int H, int W, int Cp) {
   const int Ho = 2 * H, Wo = 2 * W;
   const unsigned nv = Cp >> 2;
@@ -228,22 +232,23 @@ __global__ void upsample2x_k(const float* __restrict__ x, long long xs, int xo, 
   const int y0 = (int)sy, x0 = (int)sx;
   const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
   const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-  const float* s = x + ((long long)b * H * W) * xs + xo + c;
-  const f32x4 a = *(const f32x4*)(s + ((long long)y0 * W + x0) * xs);
-  const f32x4 bb = *(const f32x4*)(s + ((long long)y0 * W + x1) * xs);
-  const f32x4 cc = *(const f32x4*)(s + ((long long)y1 * W + x0) * xs);
-  const f32x4 d = *(const f32x4*)(s + ((long long)y1 * W + x1) * xs);
+  const T* s = x + ((long long)b * H * W) * xs + xo + c;
+  const f32x4 a = ld4(s + ((long long)y0 * W + x0) * xs);
+  const f32x4 bb = ld4(s + ((long long)y0 * W + x1) * xs);
+  const f32x4 cc = ld4(s + ((long long)y1 * W + x0) * xs);
+  const f32x4 d = ld4(s + ((long long)y1 * W + x1) * xs);
   const f32x4 r = hy * (hx * a + lx * bb) + ly * (hx * cc + lx * d);
-  *(f32x4*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+  st4(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, r);
 }
 
-__global__ void nchw_to_nhwc_k(const float* __restrict__ x, int B, int C, int H, int W, float* __restrict__ y,
+template <typename T>
+__global__ void nchw_to_nhwc_k(const float* __restrict__ x, int B, int C, int H, int W, T* __restrict__ y,
                                long long ys, int yo, int Cp) {
   const long long HW = (long long)H * W, total = (long long)B * HW;
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
     const long long b = p / HW, r = p - b * HW;
-    float* dst = y + p * ys + yo;
-    for (int c = 0; c < Cp; ++c) dst[c] = c < C ? x[(b * C + c) * HW + r] : 0.f;
+    T* dst = y + p * ys + yo;
+    for (int c = 0; c < Cp; ++c) st1(dst + c, c < C ? x[(b * C + c) * HW + r] : 0.f);
   }
 }
 
@@ -257,41 +262,44 @@ __global__ void nhwc_to_nchw_k(const float* __restrict__ x, long long xs, int xo
   }
 }
 
-__global__ void ellipse_head_act_k(float* __restrict__ x, int B, int ld) {
+template <typename T>
+__global__ void ellipse_head_act_k(T* __restrict__ x, int B, int ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * 10) return;
   const int b = i / 10, j = i - b * 10, k = j % 5;
-  float v = x[(long long)b * ld + j];
+  float v = ld1(x + (long long)b * ld + j);
   if (k < 2) v = tanhf(v);
   else if (k < 4) v = 1.f / (1.f + expf(-v));
-  x[(long long)b * ld + j] = v;
+  st1(x + (long long)b * ld + j, v);
 }
 
-__global__ void selu_k(float* __restrict__ x, long long n) {
+template <typename T>
+__global__ void selu_k(T* __restrict__ x, long long n) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float v = x[i];
-    x[i] = scale * (v > 0.f ? v : alpha * (expf(v) - 1.f));
+    const float v = ld1(x + i);
+    st1(x + i, scale * (v > 0.f ? v : alpha * (expf(v) - 1.f)));
   }
 }
 
 // one block per sample; thread = channel; fp32 pairwise-ish (per-thread serial over <= a few hundred px)
-__global__ void spatial_mean_k(const float* __restrict__ x, long long pix_stride, int ch_off, int C, int HW,
-                               float* __restrict__ out) {
+template <typename T, typename TO>
+__global__ void spatial_mean_k(const T* __restrict__ x, long long pix_stride, int ch_off, int C, int HW,
+                               TO* __restrict__ out) {
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float* s = x + (long long)b * HW * pix_stride + ch_off + c;
+    const T* s = x + (long long)b * HW * pix_stride + ch_off + c;
     double a = 0;
     int p = 0;
     for (; p + 8 <= HW; p += 8) {          // eight loads in flight, summed in pixel order (one dependent load at a time took 76 us)
       float t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = s[(long long)(p + u) * pix_stride];
+      for (int u = 0; u < 8; ++u) t[u] = ld1(s + (long long)(p + u) * pix_stride);
 #pragma unroll
       for (int u = 0; u < 8; ++u) a += t[u];
     }
-    for (; p < HW; ++p) a += s[(long long)p * pix_stride];
-    out[(long long)b * C + c] = (float)(a / HW);
+    for (; p < HW; ++p) a += ld1(s + (long long)p * pix_stride);
+    st1(out + (long long)b * C + c, (float)(a / HW));
   }
 }
 
@@ -302,7 +310,7 @@ inline int grid_for(long long total, int block = 256) {
   return (int)g;
 }
 
-inline bool slice_ok(const void* p, long long stride, int off, int Cp) {
+inline bool slice_ok(const void* p, long long stride, int off, int Cp) {     // (4-element vectors: 16 bytes of fp32, 8 of bf16)
   return p && ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && off % 4 == 0 && Cp > 0 && Cp % 4 == 0 && off + Cp <= stride;
 }
 
@@ -332,9 +340,9 @@ extern "C" int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int pe
   return (int64_t)Bn * norm_nchunk(Bn, npix, Cp) * Cp * 2 * sizeof(double);
 }
 
-extern "C" int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample,
-                               float eps, float* scale, float* shift, float* mean_out, float* var_out, void* ws,
-                               void* stream) {
+template <typename T>
+static int norm_stats_impl(const T* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample,
+                           float eps, float* scale, float* shift, float* mean_out, float* var_out, void* ws, void* stream) {
   EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp), "norm_stats: bad slice (stride %lld off %d Cp %d)", (long long)pix_stride, ch_off, Cp);
   EGNE_REQUIRE(B > 0 && HW > 0 && scale && shift && ws, "norm_stats: bad arguments");
   const int Bn = per_sample ? B : 1;
@@ -342,12 +350,20 @@ extern "C" int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, i
   const int cgroups = (Cp + 31) / 32;
   const int nchunk = norm_nchunk(Bn, npix, Cp);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(norm_stats_partial, dim3(nchunk, cgroups, Bn), dim3(256), 0, st, x, (long long)pix_stride, ch_off,
+  hipLaunchKernelGGL(norm_stats_partial<T>, dim3(nchunk, cgroups, Bn), dim3(256), 0, st, x, (long long)pix_stride, ch_off,
                      Cp, npix, nchunk, (double*)ws);
   const int tot = Bn * Cp;
   hipLaunchKernelGGL(norm_stats_final, dim3((tot + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk,
                      npix, eps, scale, shift, mean_out, var_out);
   return egne::check_launch("egne_norm_stats");
+}
+extern "C" int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample,
+                               float eps, float* scale, float* shift, float* mean_out, float* var_out, void* ws, void* stream) {
+  return norm_stats_impl(x, pix_stride, ch_off, Cp, B, HW, per_sample, eps, scale, shift, mean_out, var_out, ws, stream);
+}
+extern "C" int egne_norm_stats_bf16(const void* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample,
+                                    float eps, float* scale, float* shift, float* mean_out, float* var_out, void* ws, void* stream) {
+  return norm_stats_impl((const egne_bf16*)x, pix_stride, ch_off, Cp, B, HW, per_sample, eps, scale, shift, mean_out, var_out, ws, stream);
 }
 
 extern "C" int egne_norm_stats_finish(const void* ws, int Cp, int B, int nchunk, int HW, float eps, float* scale, float* shift,
@@ -358,38 +374,60 @@ extern "C" int egne_norm_stats_finish(const void* ws, int Cp, int B, int nchunk,
   return egne::check_launch("egne_norm_stats_finish");
 }
 
-extern "C" int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, const float* scale,
-                                   const float* shift, void* stream) {
-  EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp) && scale && shift && npix > 0, "affine_inplace: bad arguments");
-  hipLaunchKernelGGL(affine_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x,
-                     (long long)pix_stride, ch_off, x, (long long)pix_stride, ch_off, Cp, (long long)npix, scale, shift);
-  return egne::check_launch("egne_affine_inplace");
-}
-
-extern "C" int egne_affine(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix,
-                           const float* scale, const float* shift, void* stream) {
+template <typename T>
+static int affine_impl(const T* x, int64_t xs, int xo, T* y, int64_t ys, int yo, int Cp, int64_t npix, const float* scale,
+                       const float* shift, void* stream) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp) && scale && shift && npix > 0, "affine: bad arguments");
-  hipLaunchKernelGGL(affine_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x, (long long)xs, xo, y,
+  hipLaunchKernelGGL(affine_k<T>, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x, (long long)xs, xo, y,
                      (long long)ys, yo, Cp, (long long)npix, scale, shift);
   return egne::check_launch("egne_affine");
 }
+extern "C" int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, const float* scale,
+                                   const float* shift, void* stream) {
+  return affine_impl<float>(x, pix_stride, ch_off, x, pix_stride, ch_off, Cp, npix, scale, shift, stream);
+}
+extern "C" int egne_affine(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix,
+                           const float* scale, const float* shift, void* stream) {
+  return affine_impl<float>(x, xs, xo, y, ys, yo, Cp, npix, scale, shift, stream);
+}
+extern "C" int egne_affine_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int Cp, int64_t npix,
+                                const float* scale, const float* shift, void* stream) {
+  return affine_impl<egne_bf16>((const egne_bf16*)x, xs, xo, (egne_bf16*)y, ys, yo, Cp, npix, scale, shift, stream);
+}
 
-extern "C" int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
-                             int Cp, void* stream) {
+template <typename T>
+static int avgpool2_impl(const T* x, int64_t xs, int xo, T* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "avgpool2: bad slices");
   EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2, "avgpool2: bad shape");
-  hipLaunchKernelGGL(avgpool2_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+  hipLaunchKernelGGL(avgpool2_k<T>, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
                      (hipStream_t)stream, x, (long long)xs, xo, y, (long long)ys, yo, B, H, W, Cp);
   return egne::check_launch("egne_avgpool2");
 }
+extern "C" int egne_avgpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
+                             int Cp, void* stream) {
+  return avgpool2_impl(x, xs, xo, y, ys, yo, B, H, W, Cp, stream);
+}
+extern "C" int egne_avgpool2_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W,
+                                  int Cp, void* stream) {
+  return avgpool2_impl((const egne_bf16*)x, xs, xo, (egne_bf16*)y, ys, yo, B, H, W, Cp, stream);
+}
 
-extern "C" int egne_norm_act_pool2(const float* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
-                                   float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+template <typename T>
+static int norm_act_pool2_impl(const T* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
+                               T* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp) && scale && shift, "norm_act_pool2: bad slices");
   EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2, "norm_act_pool2: bad shape");
-  hipLaunchKernelGGL(norm_act_pool2_k, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+  hipLaunchKernelGGL(norm_act_pool2_k<T>, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
                      (hipStream_t)stream, x, (long long)xs, xo, scale, shift, act, y, (long long)ys, yo, B, H, W, Cp);
   return egne::check_launch("egne_norm_act_pool2");
+}
+extern "C" int egne_norm_act_pool2(const float* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
+                                   float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+  return norm_act_pool2_impl(x, xs, xo, scale, shift, act, y, ys, yo, B, H, W, Cp, stream);
+}
+extern "C" int egne_norm_act_pool2_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
+                                        void* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+  return norm_act_pool2_impl((const egne_bf16*)x, xs, xo, scale, shift, act, (egne_bf16*)y, ys, yo, B, H, W, Cp, stream);
 }
 
 extern "C" int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
@@ -405,22 +443,39 @@ extern "C" int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64
   return egne::check_launch("egne_maxpool2");
 }
 
-extern "C" int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
-                               int Cp, void* stream) {
+template <typename T>
+static int upsample2x_impl(const T* x, int64_t xs, int xo, T* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "upsample2x: bad slices");
   EGNE_REQUIRE(B > 0 && H > 0 && W > 0, "upsample2x: bad shape");
   EGNE_REQUIRE(2 * H <= 65535 && B <= 65535, "upsample2x: grid limits");
-  hipLaunchKernelGGL(upsample2x_k, dim3((2 * W * (Cp / 4) + 255) / 256, 2 * H, B), dim3(256), 0,
+  hipLaunchKernelGGL(upsample2x_k<T>, dim3((2 * W * (Cp / 4) + 255) / 256, 2 * H, B), dim3(256), 0,
                      (hipStream_t)stream, x, (long long)xs, xo, y, (long long)ys, yo, B, H, W, Cp);
   return egne::check_launch("egne_upsample2x");
 }
+extern "C" int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,
+                               int Cp, void* stream) {
+  return upsample2x_impl(x, xs, xo, y, ys, yo, B, H, W, Cp, stream);
+}
+extern "C" int egne_upsample2x_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W,
+                                    int Cp, void* stream) {
+  return upsample2x_impl((const egne_bf16*)x, xs, xo, (egne_bf16*)y, ys, yo, B, H, W, Cp, stream);
+}
 
-extern "C" int egne_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int64_t ys, int yo, int Cp,
-                                 void* stream) {
+template <typename T>
+static int nchw_to_nhwc_impl(const float* x, int B, int C, int H, int W, T* y, int64_t ys, int yo, int Cp, void* stream) {
   EGNE_REQUIRE(x && y && B > 0 && C > 0 && C <= Cp && yo + Cp <= ys, "nchw_to_nhwc: bad arguments");
-  hipLaunchKernelGGL(nchw_to_nhwc_k, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B, C, H,
+  hipLaunchKernelGGL(nchw_to_nhwc_k<T>, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B, C, H,
                      W, y, (long long)ys, yo, Cp);
   return egne::check_launch("egne_nchw_to_nhwc");
+}
+extern "C" int egne_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, int64_t ys, int yo, int Cp,
+                                 void* stream) {
+  return nchw_to_nhwc_impl(x, B, C, H, W, y, ys, yo, Cp, stream);
+}
+/* fp32 NCHW in (the caller's frames), bf16 NHWC out */
+extern "C" int egne_nchw_to_nhwc_bf16(const float* x, int B, int C, int H, int W, void* y, int64_t ys, int yo, int Cp,
+                                      void* stream) {
+  return nchw_to_nhwc_impl(x, B, C, H, W, (egne_bf16*)y, ys, yo, Cp, stream);
 }
 
 extern "C" int egne_nhwc_to_nchw(const float* x, int64_t xs, int xo, int B, int C, int H, int W, float* y,
@@ -433,20 +488,38 @@ extern "C" int egne_nhwc_to_nchw(const float* x, int64_t xs, int xo, int B, int 
 
 extern "C" int egne_ellipse_head_act(float* x, int B, int ld, void* stream) {
   EGNE_REQUIRE(x && B > 0 && ld >= 10, "ellipse_head_act: bad arguments");
-  hipLaunchKernelGGL(ellipse_head_act_k, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, B, ld);
+  hipLaunchKernelGGL(ellipse_head_act_k<float>, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, B, ld);
   return egne::check_launch("egne_ellipse_head_act");
+}
+extern "C" int egne_ellipse_head_act_bf16(void* x, int B, int ld, void* stream) {
+  EGNE_REQUIRE(x && B > 0 && ld >= 10, "ellipse_head_act: bad arguments");
+  hipLaunchKernelGGL(ellipse_head_act_k<egne_bf16>, dim3((B * 10 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (egne_bf16*)x, B, ld);
+  return egne::check_launch("egne_ellipse_head_act_bf16");
 }
 
 extern "C" int egne_selu_inplace(float* x, int64_t n, void* stream) {
   EGNE_REQUIRE(x && n > 0, "selu: bad arguments");
-  hipLaunchKernelGGL(selu_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n);
+  hipLaunchKernelGGL(selu_k<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n);
   return egne::check_launch("egne_selu_inplace");
 }
+extern "C" int egne_selu_inplace_bf16(void* x, int64_t n, void* stream) {
+  EGNE_REQUIRE(x && n > 0, "selu: bad arguments");
+  hipLaunchKernelGGL(selu_k<egne_bf16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (egne_bf16*)x, (long long)n);
+  return egne::check_launch("egne_selu_inplace_bf16");
+}
 
+template <typename T, typename TO>
+static int spatial_mean_impl(const T* x, int64_t pix_stride, int ch_off, int C, int B, int HW, TO* out, void* stream) {
+  EGNE_REQUIRE(x && out && B > 0 && HW > 0 && C > 0 && ch_off + C <= pix_stride, "spatial_mean: bad arguments");
+  hipLaunchKernelGGL((spatial_mean_k<T, TO>), dim3(B), dim3(256), 0, (hipStream_t)stream, x, (long long)pix_stride, ch_off, C, HW, out);
+  return egne::check_launch("egne_spatial_mean");
+}
 extern "C" int egne_spatial_mean(const float* x, int64_t pix_stride, int ch_off, int C, int B, int HW, float* out,
                                  void* stream) {
-  EGNE_REQUIRE(x && out && B > 0 && HW > 0 && C > 0 && ch_off + C <= pix_stride, "spatial_mean: bad arguments");
-  hipLaunchKernelGGL(spatial_mean_k, dim3(B), dim3(256), 0, (hipStream_t)stream, x, (long long)pix_stride, ch_off, C, HW,
-                     out);
-  return egne::check_launch("egne_spatial_mean");
+  return spatial_mean_impl(x, pix_stride, ch_off, C, B, HW, out, stream);
+}
+/* bf16 in, bf16 out (the mean is one more activation tensor of the plan) */
+extern "C" int egne_spatial_mean_bf16(const void* x, int64_t pix_stride, int ch_off, int C, int B, int HW, void* out,
+                                      void* stream) {
+  return spatial_mean_impl((const egne_bf16*)x, pix_stride, ch_off, C, B, HW, (egne_bf16*)out, stream);
 }

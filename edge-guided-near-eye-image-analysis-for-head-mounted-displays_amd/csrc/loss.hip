@@ -41,6 +41,7 @@ __device__ __forceinline__ float lin11(int i, int n) {
   return i < n / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void loss_partial_k(const egne_loss_desc d, int nblk) {
   const int b = blockIdx.y, blk = blockIdx.x;
   const int HW = d.H * d.W;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(256) void loss_partial_k(const egne_loss_desc d, in
   Lse pup = {-INFINITY, 0.f, 0.f, 0.f}, iri = {-INFINITY, 0.f, 0.f, 0.f};
   const long long base = (long long)b * HW;
   for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const float* lp = d.logits + (base + p) * d.pix_stride + d.ch_off;
-    const float l0 = lp[0], l1 = lp[1], l2 = lp[2];
+    const T* lp = (const T*)d.logits + (base + p) * d.pix_stride + d.ch_off;
+    const float l0 = ld1(lp), l1 = ld1(lp + 1), l2 = ld1(lp + 2);
     const int t = (int)d.target[base + p];
     const float mx = fmaxf(l0, fmaxf(l1, l2));
     const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
@@ -234,7 +235,9 @@ extern "C" int egne_loss_fwd(const egne_loss_desc* dp, void* stream) {
   EGNE_REQUIRE(d.partials && d.out_terms && d.pred_c && d.elPred, "loss: null output/workspace");
   const int nblk = loss_nblk(d.H, d.W);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_partial_k, dim3(nblk, d.B), dim3(256), 0, st, d, nblk);
+  EGNE_REQUIRE(d.dtype == 0 || d.dtype == 1, "loss: dtype %d", d.dtype);
+  if (d.dtype == 1) hipLaunchKernelGGL(loss_partial_k<egne_bf16>, dim3(nblk, d.B), dim3(256), 0, st, d, nblk);
+  else hipLaunchKernelGGL(loss_partial_k<float>, dim3(nblk, d.B), dim3(256), 0, st, d, nblk);
   hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(256), 0, st, d, nblk);
   return egne::check_launch("egne_loss_fwd");
 }

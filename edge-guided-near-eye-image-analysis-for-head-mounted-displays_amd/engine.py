@@ -65,6 +65,7 @@ HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 maps: 253 -> 194 us for 120 -> 128 channels against the flat kernel)
 HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
+BF16_FAST3X3 = os.environ.get("EGNE_BF16_FAST3X3", "1") != "0"     # bf16-storage plans: 3x3 convolutions and their data gradients on bf16 MFMAs (0: exact-fp32 implicit GEMM)
 
 
 def pad8(c):
@@ -98,7 +99,7 @@ class Piece:
     @property
     def ptr(self):
         hw = self.buf.shape[1] * self.buf.shape[2]
-        return self.buf.data_ptr() + 4 * (self.n0 * hw * self.stride)
+        return self.buf.data_ptr() + self.buf.element_size() * (self.n0 * hw * self.stride)
 
     def with_norm(self, scale, shift, act_in=ACT_NONE):
         p = Piece(self.buf, self.off, self.C, self.Cp, self.n0)
@@ -142,6 +143,8 @@ class ConvLayer:
         self.m1hi = self.m1lo = None
         self.need_big = False    # LDS-image pack for the deep 256-wide split-f16 kernel
         self.wimg = None
+        self.need_bfrag = False  # bf16 fragment pack of the bf16-storage 3x3 kernel (conv3x3_bf16.hip)
+        self.bfrag = None
         self.split1 = False      # allow the streaming split-f16 kernel for this 1x1 layer (frozen nets only)
         self.need_s1 = False
         self.s1hi = self.s1lo = None
@@ -167,7 +170,8 @@ class ConvLayer:
         have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
                 and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big)
-                and (self.m1hi is not None or not self.need_m1) and (self.c4hi is not None or not self.need_c4h))
+                and (self.m1hi is not None or not self.need_m1) and (self.c4hi is not None or not self.need_c4h)
+                and (self.bfrag is not None or not self.need_bfrag))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return False
         L = _lib.lib()
@@ -263,6 +267,14 @@ class ConvLayer:
                 self.wimg = torch.empty(self.big_coutp * kts * T * 2, dtype=torch.float16, device=dev)
             _lib.check(L.egne_pack_conv_weight_f16img(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, bn, kts, self.w_scale_big,
                                                       self.wimg.data_ptr(), st), "pack_f16img")
+        if self.need_bfrag:
+            # weights rounded to bf16 in MFMA-fragment order (fp32 master weights stay in the Parameter)
+            wd = self.weights[0].detach().contiguous()
+            kts = pad32(self.Ktot)
+            if self.bfrag is None:
+                self.bfrag = torch.empty(T * self.CoutP * kts, dtype=torch.bfloat16, device=dev)
+            _lib.check(L.egne_pack_conv_weight_bf16frag(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, self.CoutP, kts,
+                                                        self.bfrag.data_ptr(), st), "pack_bf16frag")
         if self.need_split or self.need_sfrag:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
@@ -363,6 +375,7 @@ class DgradLayer(ConvLayer):
         self.need_big, self.wimg = False, None
         self.need_m1, self.m1hi, self.m1lo = False, None, None
         self.need_c4h, self.c4hi, self.c4lo = False, None, None
+        self.need_bfrag, self.bfrag = False, None
         self.whi = self.wlo = self.fhi = self.flo = None
         self.w_scale = 1.0
         self._versions, self.post = None, None
@@ -453,8 +466,14 @@ class SplitDgradLayer(ConvLayer):
 class Plan:
     """Buffers + prepared launches for one network at one shape."""
 
-    def __init__(self, device, train=False):
+    def __init__(self, device, train=False, dtype=torch.float32):
+        """``dtype``: storage type of every NHWC activation / activation-gradient buffer of the plan (``buf``): fp32, or bf16 for
+        training plans that keep them in HBM at half the bytes (BASELINE.json configs[2..4]).  Arithmetic, statistics, tables
+        (``vec``), master weights and parameter gradients are fp32 either way."""
+        assert dtype in (torch.float32, torch.bfloat16), dtype
         self.device = device
+        self.dtype, self.bf16 = dtype, dtype == torch.bfloat16
+        self.esz = 2 if self.bf16 else 4
         self.train = train  # record a tape of backward emitters while the forward plan is built
         self.tape = []
         self.gtwins = {}    # id(forward buffer) -> gradient buffer of the same shape
@@ -466,16 +485,16 @@ class Plan:
         self.wscale_refs = []   # (call index, argument index, layer, attribute): weight-pack scales baked into launch arguments
         self.cal = {}       # call index -> (index of the a_scale argument, raw input Pieces, pixels): split-f16 pre-scale calibration
         self.calibrated = False
-        self.dyn_scales = bool(train) and TRAIN_SPLIT     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
+        self.dyn_scales = bool(train) and TRAIN_SPLIT and not self.bf16     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
         self._touching, self._touched = False, {}     # build_backward: channel ranges of gradient twins already handed out
         self.side_calls, self.side_stream = {}, None   # call index -> event: weight-gradient launches overlapped with the data path
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
-        self.L = _lib.lib()
+        self.L = _StorageLib(_lib.lib(), self.bf16)
 
     # ---- memory ------------------------------------------------------------------------------
     def buf(self, B, H, W, Ctot):
-        t = torch.zeros((B, H, W, int(Ctot)), dtype=torch.float32, device=self.device)
+        t = torch.zeros((B, H, W, int(Ctot)), dtype=self.dtype, device=self.device)
         self.keep.append(t)
         return t
 
@@ -517,7 +536,7 @@ class Plan:
 
     def build_backward(self):
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
-        bw = Plan(self.device)
+        bw = Plan(self.device, dtype=self.dtype)
         bw.fwd = self
         bw.dyn_scales = self.dyn_scales
         self._touching, self._touched = True, {}
@@ -623,7 +642,7 @@ class Plan:
         self._pool_req, self.last_pooled = pool, False
         r = self._conv_impl(layer, pieces, dst, B, H, W, residual, name, stats, scores)
         self._pool_req = None
-        LAYER_BYTES[name] = 4.0 * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
+        LAYER_BYTES[name] = float(self.esz) * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
         return r
 
     def _conv_impl(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None):
@@ -633,6 +652,8 @@ class Plan:
         assert len(pieces) == len(layer.in_layout) and len(pieces) <= _lib.MAXSEG, name
         for p, (c, cp) in zip(pieces, layer.in_layout):
             assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
+        if self.bf16:
+            return self._conv_bf16(layer, pieces, dst, B, H, W, residual, name, stats, scores)
         Ho, Wo = layer.out_hw(H, W)
         halo = (HALO_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                 and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] <= 2
@@ -900,9 +921,81 @@ class Plan:
             self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
         return Ho, Wo
 
+    def _conv_bf16(self, layer, pieces, dst, B, H, W, residual, name, stats, scores):
+        """Convolutions of a plan with bf16 activation storage: the 3x3 "same" convolutions over one slice run on bf16 MFMAs
+        (conv3x3_bf16.hip: weights rounded to bf16, fp32 accumulate), first layers (Cin <= 4) on the taps-in-K kernel and
+        everything else (1x1 over several slices, strided / reflect-padded / valid convolutions, linear layers) on the exact-fp32
+        implicit GEMM reading and writing bf16 (egne_conv_desc.dtype = 1).  No pre-scales, no calibration: bf16 has fp32's range."""
+        assert scores is None and layer.G == 1 and not isinstance(pieces[0], PlanarPiece), name
+        Ho, Wo = layer.out_hw(H, W)
+        one = len(pieces) == 1 and layer.stride == 1 and layer.pad_mode == 0 and layer.dils[0] == 1 and layer.kh == 3 and layer.kw == 3 \
+            and layer.pad == (1, 1)
+        smallcin = (one and SMALLCIN_ENABLED and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None
+                    and not isinstance(layer, (DgradLayer, SplitDgradLayer)) and layer.post is None)
+        fast3 = (one and not smallcin and BF16_FAST3X3 and pieces[0].Cp % 8 == 0 and pieces[0].off % 8 == 0 and pieces[0].stride % 8 == 0
+                 and layer.CoutP <= 256 and min(layer.Cout_store, dst.Cp) % 4 == 0 and min(layer.Cout_store, dst.Cp) >= 8
+                 and H * W * max(pieces[0].stride, dst.stride) < 2 ** 30
+                 and (residual is None or H * W * residual.stride < 2 ** 30))
+        if smallcin:
+            layer.need_c4 = True
+            layer.need_flat = True
+        elif fast3:
+            layer.need_bfrag = True
+            if self.train:
+                layer.need_flat = True       # kinv / the generic pack index the weight-gradient paths
+        else:
+            layer.need_flat = True
+        if layer not in self.layers:
+            self.layers.append(layer)
+        layer.ensure_packed(self.device)
+        d = _lib.ConvDesc()
+        d.dtype = 1
+        d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
+        d.kh, d.kw, d.stride = layer.kh, layer.kw, layer.stride
+        d.pad_h, d.pad_w, d.pad_mode = layer.pad[0], layer.pad[1], layer.pad_mode
+        d.ngroups = 1
+        for g in range(_lib.MAXGROUP):
+            d.dil[g] = layer.dils[0] if g == 0 else 1
+        d.nseg = len(pieces)
+        for i, p in enumerate(pieces):
+            sg = d.seg[i]
+            sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp = p.ptr, p.stride, p.off, p.Cp
+            sg.scale = p.scale.data_ptr() if p.scale is not None else None
+            sg.shift = p.shift.data_ptr() if p.shift is not None else None
+            sg.act_in = p.act_in
+        d.Ktot, d.CoutP = (pad32(layer.Ktot) if fast3 else layer.Ktot), layer.CoutP
+        d.w = None if fast3 else layer.wp.data_ptr()
+        d.bias = layer.bp.data_ptr() if layer.biases is not None else None
+        d.act = layer.act
+        if layer.post is not None:
+            d.post_scale, d.post_shift = layer.post[0].data_ptr(), layer.post[1].data_ptr()
+        if residual is not None:
+            d.residual, d.res_pix_stride, d.res_ch_off = residual.ptr, residual.stride, residual.off
+        d.out, d.out_pix_stride, d.out_ch_off = dst.ptr, dst.stride, dst.off
+        d.Cout_store = min(layer.Cout_store, dst.Cp)
+        assert tuple(dst.buf.shape[1:3]) == (Ho, Wo), (name, tuple(dst.buf.shape), Ho, Wo)
+        assert dst.buf.dtype == torch.bfloat16 and all(p.buf.dtype == torch.bfloat16 for p in pieces), name
+        self.keep.append(d)
+        flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw
+        if smallcin:
+            self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
+        elif fast3:
+            self._add(self.L.egne_conv3x3_bf16_fwd, (C.byref(d), layer.bfrag.data_ptr()), name, flops=flops, kind="conv_bf16:3x3")
+        else:
+            self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
+        if stats:
+            self.last_stats = self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2]
+        if self.train:
+            db = _lib.ConvDesc()
+            C.memmove(C.byref(db), C.byref(d), C.sizeof(_lib.ConvDesc))
+            db.Ktot, db.CoutP = layer.Ktot, layer.CoutP
+            self.keep.append(db)
+            self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
+        return Ho, Wo
+
     def pair_fusable(self, l1, pieces, l2, dst, H, W):
         """True if conv_pair will run l2(l1(cat(pieces))) as ONE launch (conv_fused_1x1_3x3_f16.hip)."""
-        return (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split1 and l2.split and l1.kh == 1 and l1.kw == 1
+        return (FUSE_1X1 and F16X3_ENABLED and not self.train and not self.bf16 and l1.split1 and l2.split and l1.kh == 1 and l1.kw == 1
                 and l1.stride == 1 and l1.G == 1 and l1.pad == (0, 0) and l1.act == ACT_NONE and l1.post is None
                 and all(pc.scale is None for pc in pieces) and l1.CoutP in (32, 64) and len(pieces) <= _lib.MAXSEG
                 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 12
@@ -914,7 +1007,7 @@ class Plan:
         """Transition_down of an inference plan as ONE launch (conv1x1_pool_f16x3_kernel): 1x1 over normalised slices with the 2x2
         average folded in front of it."""
         G = sum((p.Cp + 15) // 16 for p in pieces)
-        return (TDPOOL_FUSED and F16X3_ENABLED and not self.train and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
+        return (TDPOOL_FUSED and F16X3_ENABLED and not self.train and not self.bf16 and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
                 and layer.G == 1 and layer.post is None and all(p.scale is not None for p in pieces) and len(pieces) <= _lib.MAXSEG
                 and layer.CoutP <= 96 and G * (layer.CoutP // 32) * 2048 <= 80 * 1024 and dst.Cp % 4 == 0)
 
@@ -963,7 +1056,7 @@ class Plan:
         # operand of an up block folded through the 1x1; only the fused kernel does this -- callers check pair_fusable first)
         assert up_add is None or (fused and l1.CoutP == 32 and l2.CoutP == 32 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 8), name
         # convBlock (utils.py:1047-1048): a 3x3 on <= 4 input channels in front of the 3x3 -- same kernel, taps folded into K
-        fused_c4 = (FUSE_1X1 and F16X3_ENABLED and not self.train and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
+        fused_c4 = (FUSE_1X1 and F16X3_ENABLED and not self.train and not self.bf16 and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
                     and l1.stride == 1 and l1.G == 1 and l1.pad == (1, 1) and l1.pad_mode == 0 and l1.dils[0] == 1 and l1.Cin <= 4
                     and l1.post is None and len(pieces) == 1 and pieces[0].scale is None and pieces[0].Cp >= 4 and l1.CoutP == 32
                     and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1
@@ -1126,9 +1219,14 @@ class Plan:
             else:
                 split_wgrad = False
         gz_max = bw._new_slot() if (split_dgrad or split_wgrad) else None     # max |gz| for the split-f16 gradients, from this pass
-        bw.raw(L.egne_act_bwd_bias_absmax, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
-                                            bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr(), gz_max),
-               name + ".act_bwd")
+        if self.bf16:
+            bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
+                                         bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr()),
+                   name + ".act_bwd")
+        else:
+            bw.raw(L.egne_act_bwd_bias_absmax, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
+                                                bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr(), gz_max),
+                   name + ".act_bwd")
         w = layer.weights[0]
         assert layer.G == 1 and w.grad is not None and w.grad.is_contiguous()
         gw = (C.c_void_p * 1)(w.grad.data_ptr())
@@ -1190,11 +1288,16 @@ class Plan:
                 bw.raw(L.egne_reflect_pad_bwd, (tmp.data_ptr(), tmp.shape[-1], 0, tl.phase, pc.Cp, tgt.ptr, tgt.stride, tgt.off,
                                                 B, H, W, P), name + ".pad_bwd")
                 continue
+            bf_dgrad = (self.bf16 and BF16_FAST3X3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
+                        and layer.stride == 1 and layer.pad_mode == 0 and layer.G == 1 and Cs % 8 == 0 and gy.off % 8 == 0)
             if split_dgrad:
                 dl = SplitDgradLayer(layer, i, self.device)     # split-f16 arithmetic for the data gradient too
                 dl.stale_scale_ok = True
                 self.pre.append(dl.guard)
                 bw._dyn_hint = gz_max
+            elif bf_dgrad:
+                dl = SplitDgradLayer(layer, i, self.device)     # an ordinary 3x3 over gz with flipped / transposed weights: the bf16 kernel serves it
+                self.pre.append(dl.guard)
             else:
                 dl = DgradLayer(layer, i)
             first = self.first_touch(pc.buf, pc.off, pc.Cp)
@@ -1385,6 +1488,19 @@ def _run_calibrating(self, st):
 
 
 Plan._run_calibrating = _run_calibrating
+
+
+class _StorageLib:
+    """The C-ABI as a plan sees it: entry points that have a bf16-storage twin (``_lib.BF16_TWINS``) resolve to the twin in a
+    plan whose activation buffers are bf16, everything else to the library's own symbol."""
+
+    def __init__(self, L, bf16):
+        self._L, self._bf16 = L, bf16
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name + "_bf16" if (self._bf16 and name in _lib.BF16_TWINS) else name)
+        setattr(self, name, fn)
+        return fn
 
 
 class VersionGuard:

@@ -135,7 +135,9 @@ class _PyCall:
         return 0
 
 
-def build_forward_plan(model, B, H, W, dev, training):
+def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
+    """``dtype``: storage of the plan's activation (and activation-gradient) buffers -- torch.bfloat16 for training plans of a
+    model switched to bf16 storage (``model.to(torch.bfloat16)`` / ``--prec 16``), fp32 otherwise (engine.Plan)."""
     st = model.setting
     variant = model.variant
     chz, growth = model.chz, model.growth
@@ -146,8 +148,9 @@ def build_forward_plan(model, B, H, W, dev, training):
     es = enc_sizes(chz, growth)
     ds = dec_sizes(chz, growth, add_edge, variant)
     fc = es["op"][-1]
-    pl = Plan(dev, train=training)
+    pl = Plan(dev, train=training, dtype=dtype)
     L = pl.L
+    esz = pl.esz
     pl.dbg = {}
     _cl.eval_plan = not training
 
@@ -171,7 +174,7 @@ def build_forward_plan(model, B, H, W, dev, training):
         if in_c == 2:
             pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr(), 8, 1, 1), "in.edge_ch")
         if add_edge:
-            pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr() + 4 * B * H * W * 8, 8, 0, 8),
+            pl.raw(L.egne_nchw_to_nhwc, (pl.in_edge.data_ptr(), B, 1, H, W, xin.data_ptr() + esz * B * H * W * 8, 8, 0, 8),
                    "in.edge")
 
     # ---- encoder on NB samples -------------------------------------------------------------------
@@ -415,14 +418,14 @@ def build_forward_plan(model, B, H, W, dev, training):
         for j, pc in enumerate(xb):
             q = Piece(xa, j * pad8(fc), fc)
             # gamma = adain_params[:,0] (first nfc values of the MLP row), beta = adain_params[:,1] (next nfc)
-            pl.raw(L.egne_adain, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.ptr + 4 * (nfc + j * fc),
+            pl.raw(L.egne_adain, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + esz * (j * fc), cur.ptr + esz * (nfc + j * fc),
                                   cur.stride, 0, q.ptr, q.stride, q.off, B, hb * wb, 1e-5), "adain.apply")
             if training:
                 def emit_adain(bw, pc=pc, q=q, j=j, cur=cur):
                     gq, gx, gm = pl.gp(q), pl.gp(pc), pl.gp(cur)
-                    bw.raw(L.egne_adain_bwd, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + 4 * (j * fc), cur.stride, 0,
+                    bw.raw(L.egne_adain_bwd, (pc.ptr, pc.stride, pc.off, fc, cur.ptr + esz * (j * fc), cur.stride, 0,
                                               gq.ptr, gq.stride, gq.off, gx.ptr, gx.stride, gx.off,
-                                              gm.ptr + 4 * (j * fc), gm.ptr + 4 * (nfc + j * fc), gm.stride, 0,
+                                              gm.ptr + esz * (j * fc), gm.ptr + esz * (nfc + j * fc), gm.stride, 0,
                                               B, hb * wb, 1e-5), "adain.apply.bwd")
                 pl.tape.append(emit_adain)
             mod.append(q)
@@ -485,6 +488,7 @@ def build_forward_plan(model, B, H, W, dev, training):
     pl.keep += [gx, gy]
     ld.B, ld.H, ld.W = B, H, W
     ld.logits, ld.pix_stride, ld.ch_off = opb.data_ptr(), 8, 0
+    ld.dtype = 1 if pl.bf16 else 0
     ld.target, ld.spatWts, ld.distMap = pl.t_target.data_ptr(), pl.t_spat.data_ptr(), pl.t_dist.data_ptr()
     ld.cond, ld.pupil_center, ld.elNorm = pl.t_cond.data_ptr(), pl.t_pc.data_ptr(), pl.t_eln.data_ptr()
     ld.elOut = pl.elOut.data_ptr()

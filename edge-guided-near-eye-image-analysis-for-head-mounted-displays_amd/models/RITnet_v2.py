@@ -112,7 +112,7 @@ class _ESFFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.model, ctx.pl = model, pl
         pl.run(model._events)
-        return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), pl.terms[0:1].clone(), pl.elOut.clone()
+        return pl.op.clone(), pl.elPred.clone(), pl.latent.to(torch.float32, copy=True), pl.terms[0:1].clone(), pl.elOut.clone()
 
     @staticmethod
     def backward(ctx, g_op, g_elPred, g_latent, g_loss, g_elOut):
@@ -159,6 +159,7 @@ class DenseNet2D(nn.Module):
         self._initialize_weights()
         self._plans = {}
         self._events = None  # bench.py: list collecting per-launch HIP events
+        self.storage_dtype = torch.float32   # activation storage of TRAINING plans: fp32, or bf16 after .to(torch.bfloat16 / float16)
 
     def setDatasetInfo(self, numSets=2):
         """models/RITnet_v2.py:240-249."""
@@ -207,10 +208,35 @@ class DenseNet2D(nn.Module):
                 params[i].grad = self._grad_views[i]
         return self._grad_flat
 
+    def to(self, *args, **kwargs):
+        """``model.to(prec)`` of the entry scripts (train.py:206, test.py:297; ``--prec`` args.py:17-28).  The reference casts the
+        whole module; here a half-precision ``prec`` (torch.float16 of ``--prec 16``, or torch.bfloat16) selects **bf16 activation
+        storage for the training plans** (BASELINE.json configs[2..4]): activations and activation gradients live in HBM as bf16,
+        every product accumulates in fp32, and the parameters stay fp32 master weights (so do the gradient arena, the optimiser
+        state and the checkpoints).  gfx950 has bf16 MFMAs with fp32's exponent range; an fp16 module would need loss scaling the
+        reference's loop does not have.  Inference plans keep fp32 tensors either way.  float32 switches back."""
+        dtype = kwargs.get("dtype")
+        rest = []
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            else:
+                rest.append(a)
+        kwargs.pop("dtype", None)
+        if dtype is not None:
+            if dtype in (torch.float16, torch.bfloat16):
+                self.storage_dtype = torch.bfloat16
+            elif dtype in (torch.float32, torch.float64):
+                self.storage_dtype = torch.float32
+            else:
+                raise RuntimeError("DenseNet2D.to(%s): floating point precisions only" % dtype)
+        return super().to(*rest, **kwargs) if (rest or kwargs) else self
+
     def _plan(self, B, H, W, dev):
-        key = (B, H, W, dev, bool(self.training), bool(self.disentangle), bool(self.toggle))
+        st = self.storage_dtype if self.training else torch.float32
+        key = (B, H, W, dev, bool(self.training), bool(self.disentangle), bool(self.toggle), st)
         if key not in self._plans:
-            self._plans[key] = build_forward_plan(self, B, H, W, dev, bool(self.training))
+            self._plans[key] = build_forward_plan(self, B, H, W, dev, bool(self.training), dtype=st)
         return self._plans[key]
 
     def forward(self, x, x_edge, target, pupil_center, elNorm, spatWts, distMap, cond, ID, alpha):
@@ -254,7 +280,7 @@ class DenseNet2D(nn.Module):
             return _ESFFunction.apply(self, pl, self._dummy)
         pl.run(self._events)
         loss = pl.terms[0:1].clone()
-        return pl.op.clone(), pl.elPred.clone(), pl.latent.clone(), loss, pl.elOut.clone()
+        return pl.op.clone(), pl.elPred.clone(), pl.latent.to(torch.float32, copy=True), loss, pl.elOut.clone()
 
     def loss_flags(self):
         """Device scalar: the number of samples of the last forward whose ground-truth mask lacks TWO classes.  The reference's

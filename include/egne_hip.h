@@ -106,6 +106,13 @@ typedef struct {
    * (cleared by the caller) -- the dyn_scale word of the split-f16 launch that reads this output next, without another pass
    * over the tensor. */
   uint32_t* absmax_out;
+  /* Storage type of the ACTIVATION tensors of this call: 0 = fp32 (everything above as declared), 1 = bf16 -- seg[i].ptr, out,
+   * residual and pool_out (and the gz argument of the weight-gradient entry points) then point at bf16 elements; strides and
+   * offsets stay in ELEMENTS, slices must start on multiples of 4 elements.  Weights, bias, affine tables and statistics stay
+   * fp32, accumulation is fp32 (training plans with bf16 activation storage: BASELINE.json configs[2..4]).  Honoured by
+   * egne_conv2d_fwd, egne_conv3x3_smallcin_fwd, egne_conv2d_wgrad, egne_conv3x3_bf16_fwd; every other convolution entry
+   * point requires 0. */
+  int32_t dtype;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
@@ -359,6 +366,7 @@ typedef struct {
   int64_t* mask;               /* optional */
   float* op_nchw;              /* optional */
   float* coef;                 /* optional [B][32]: per-sample state kept for egne_loss_bwd */
+  int32_t dtype;               /* storage of `logits`: 0 fp32, 1 bf16 (pix_stride / ch_off in elements); everything else stays fp32 */
 } egne_loss_desc;
 int64_t egne_loss_workspace_floats(int B, int H, int W);
 int egne_loss_fwd(const egne_loss_desc* d, void* stream);
@@ -507,6 +515,70 @@ int egne_zscore(const float* x, float* y, int B, int n, void* stream);
  *   [B,H,W] (class indices), out float32 [B,H,W].  PARITY UNPINNED: neither OpenCV nor a fixture of this function exists in the
  *   build container; the kernel is bit-identical to the restatement of OpenCV's published algorithm in oracle/dataprep.py. */
 int egne_spatial_weights(const int64_t* label, int B, int H, int W, float* out, void* stream);
+
+/*
+ * ---- bf16 activation storage (training plans; BASELINE.json configs[2..4], reference loop train.py:262-287, --prec args.py:17-28) ----
+ * Twins of the entry points above for plans that keep activations and activation gradients in HBM as bf16 (NHWC, strides and
+ * offsets in ELEMENTS, slices on multiples of 4 elements): same arguments, every activation / gradient pointer addresses bf16
+ * elements, all arithmetic and every statistic / table / parameter gradient stays fp32 (fp64 partial sums as in the fp32 forms),
+ * stores round to nearest even.  Descriptor-based convolutions (egne_conv2d_fwd, egne_conv3x3_smallcin_fwd, egne_conv2d_wgrad)
+ * and the loss head take the storage type from egne_conv_desc.dtype / egne_loss_desc.dtype instead of a twin.
+ */
+int egne_norm_stats_bf16(const void* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample, float eps,
+                         float* scale, float* shift, float* mean_out, float* var_out, void* ws, void* stream);
+int egne_affine_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int Cp, int64_t npix, const float* scale,
+                     const float* shift, void* stream);
+int egne_avgpool2_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);
+int egne_norm_act_pool2_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, int act, void* y,
+                             int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);
+int egne_upsample2x_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);
+int egne_nchw_to_nhwc_bf16(const float* x, int B, int C, int H, int W, void* y, int64_t ys, int yo, int Cp, void* stream); /* fp32 in */
+int egne_ellipse_head_act_bf16(void* x, int B, int ld, void* stream);
+int egne_selu_inplace_bf16(void* x, int64_t n, void* stream);
+int egne_spatial_mean_bf16(const void* x, int64_t pix_stride, int ch_off, int C, int B, int HW, void* out, void* stream); /* bf16 out */
+int egne_softmax3_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int Cp_out, int64_t npix, void* stream);
+int egne_adain_bf16(const void* x, int64_t xs, int xo, int C, const void* gamma, const void* beta, int64_t gb_stride, int gb_off,
+                    void* y, int64_t ys, int yo, int B, int HW, float eps, void* stream);
+int egne_conf_loss_bf16(const void* pred, int ld, const int64_t* gt, int B, int C, int flag, float weight, float* terms, void* stream);
+int egne_loss_bwd_bf16(const egne_loss_desc* d, const float* gscale, void* g_logits, int64_t gs, int go, float* g_elOut, void* stream);
+int egne_act_bwd_bias_bf16(void* g, int64_t gs, int go, const void* y, int64_t ys, int yo, int act, int Cp, int64_t npix,
+                           float* dbias, int C, int accumulate, void* ws, void* stream);
+int egne_norm_bwd_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, const float* gamma,
+                       const void* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW, int per_sample, void* gx,
+                       int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta, int C, void* ws, void* stream);
+int egne_norm_bwd_store_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, const float* gamma,
+                             const void* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW, int per_sample, void* gx,
+                             int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta, int C, void* ws, void* stream);
+int egne_norm_pool2_bwd_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, const void* gzp,
+                             int64_t gs, int go, int act_in, int Cp, int B, int H, int W, void* gx, int64_t gxs, int gxo,
+                             int accumulate, float* sums, void* ws, void* stream);
+int egne_avgpool2_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
+int egne_upsample2x_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
+int egne_ellipse_head_act_bwd_bf16(void* g, const void* y, int B, int ld, void* stream);
+int egne_selu_bwd_bf16(void* g, const void* y, int64_t n, void* stream);
+int egne_softmax3_bwd_bf16(const void* y, int64_t ys, int yo, const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo,
+                           int64_t npix, void* stream);
+int egne_adain_bwd_bf16(const void* x, int64_t xs, int xo, int C, const void* gamma, int64_t gb_stride, int gb_off, const void* gy,
+                        int64_t gys, int gyo, void* gx, int64_t gxs, int gxo, void* ggamma, void* gbeta, int64_t gg_stride,
+                        int gg_off, int B, int HW, float eps, void* stream);
+int egne_reflect_pad_bwd_bf16(const void* gpad, int64_t gs, int go, int phase, int Cp, void* gx, int64_t xs, int xo, int B, int H,
+                              int W, int P, void* stream);
+int egne_spatial_mean_bwd_bf16(const void* g, int gld, void* gx, int64_t xs, int xo, int C, int B, int HW, void* stream);
+int egne_conf_loss_bwd_bf16(const void* pred, int ld, const int64_t* gt, int B, int C, int flag, const float* gscale, void* gpred,
+                            int gld, void* stream);
+
+/*
+ * 3x3 / stride 1 / pad 1 / dilation 1 convolution over ONE bf16 input slice on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): the
+ * 3x3 convolutions of models/RITnet_v2.py:57-62,85-87 and utils.py:1047-1048 and their data gradients (a 3x3 over gz with
+ * flipped / transposed weights) in training plans with bf16 storage (egne_conv_desc.dtype must be 1).  Descriptor as for
+ * egne_conv3x3_rw_f16_fwd: optional fused per-(n,c) affine + activation on load, bias, activation, residual (bf16, accumulated
+ * onto in fp32), Ktot = slice width rounded up to 32, CoutP a multiple of 32 (<= 256), Cout_store a multiple of 8.  wfrag: the
+ * weights rounded to bf16 in MFMA-fragment order [tap][Ktot/16][CoutP/32][lane][8] (egne_pack_conv_weight_bf16frag; fp32 master
+ * weights stay with the caller).
+ */
+int egne_pack_conv_weight_bf16frag(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot, void* wfrag,
+                                   void* stream);
+int egne_conv3x3_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
 const char* egne_last_error(void);
 int egne_version(void);

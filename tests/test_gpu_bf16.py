@@ -1,0 +1,443 @@
+"""-m gpu: training plans with bf16 activation storage (BASELINE.json configs[2..4]; reference loop train.py:262-287, --prec
+args.py:17-28): activations and activation gradients live in HBM as bf16, every product accumulates in fp32, master weights,
+parameter gradients and statistics stay fp32.
+
+Tolerances.  A bf16 store rounds to 8 significant bits (relative 2^-9 = 2e-3 per stored value, unbiased).  Single ops are
+compared with a float64 evaluation of THE SAME bf16-representable inputs, so only the output rounding and the fp32
+accumulation order remain: 2^-8 of the output scale.
+
+Whole network (measured on MI355X, golden B=2 batches, seeded random weights; every test prints its figures): loss within 3e-3
+of the reference, logits within 5 % of the largest logit, decoder gradients within 1-4 % (relative L2 per tensor), encoder
+gradients 15-35 %, the two head convolutions 40-90 %.  Why the encoder is noisy: with random (differencing) kernels on smooth
+eye images a 3x3 convolution attenuates the signal far more than the white rounding noise of its bf16 input -- the first BatchNorm
+output already differs by 1.4 % after three stored tensors, the bottleneck by 5.5 % -- and a per-frame gradient error of ~20 % is
+not averaged away by larger batches while the per-frame gradients themselves are uncorrelated (scratch/bf16_noise.py: median
+0.16 / 0.31 / 0.23 at B = 2 / 8 / 32).  It is unbiased noise well below the sampling noise of the stochastic gradient: 30 Adam
+steps end at the same loss as the fp32-storage plan (test_bf16_training_replays_bit_identically_and_learns).  Exact-fp32 weights
+instead of bf16-rounded ones in the 3x3 kernels change the median from 0.255 to 0.233 (EGNE_BF16_FAST3X3=0): storage, not the
+MFMA operand width, sets the figure.  The bounds asserted below are ~1.5x the measured values.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+EPS = 2.0 ** -8
+
+
+def _rand(g, *shape):
+    return torch.randn(*shape, generator=g)
+
+
+def _q(t):
+    """Round to bf16 and back: what a bf16 buffer holds."""
+    return t.to(BF).float()
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import egne_amd  # noqa: F401
+    return torch.Generator().manual_seed(77)
+
+
+def _plan():
+    from egne_amd.engine import Plan
+    return Plan(torch.device(DEV), dtype=BF)
+
+
+def _pieces(pl, xs, B, H, W):
+    from egne_amd.engine import Piece, pad8
+    tot = sum(pad8(x.shape[1]) for x in xs)
+    buf = pl.buf(B, H, W, tot)
+    assert buf.dtype == BF
+    out, off = [], 0
+    for x in xs:
+        C = x.shape[1]
+        buf[..., off:off + C] = x.permute(0, 2, 3, 1).to(DEV).to(BF)
+        out.append(Piece(buf, off, C))
+        off += pad8(C)
+    return out
+
+
+def _conv(G_, xs, w, b, act=0, pad=(0, 0), stride=1, pad_mode=0, norm=None, residual=None, dils=(1,)):
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    B, _, H, W = xs[0].shape
+    pl = _plan()
+    pieces = _pieces(pl, xs, B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))] if b is not None else None,
+                      [(p.C, p.Cp) for p in pieces], stride=stride, pad=pad, act=act, pad_mode=pad_mode, dils=dils)
+    if norm:
+        for i, (sc, sh, ai) in norm.items():
+            scp, shp = torch.zeros(B, pieces[i].Cp, device=DEV), torch.zeros(B, pieces[i].Cp, device=DEV)
+            scp[:, :sc.shape[1]], shp[:, :sh.shape[1]] = sc.to(DEV), sh.to(DEV)
+            pl.keep += [scp, shp]
+            pieces[i] = pieces[i].with_norm(scp, shp, ai)
+    Ho, Wo = layer.out_hw(H, W)
+    out = pl.buf(B, Ho, Wo, pad8(layer.Cout) + 8)
+    out.fill_(768.0)       # (bf16-representable poison)
+    dst = Piece(out, 8, layer.Cout)
+    res = _pieces(pl, [residual], B, Ho, Wo)[0] if residual is not None else None
+    pl.conv(layer, pieces, dst, B, H, W, residual=res)
+    pl.run()
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    assert (o[..., :8] == 768.0).all(), "conv wrote outside its output slice"
+    return o[..., 8:8 + layer.Cout].permute(0, 3, 1, 2).contiguous(), [m[0] for m in pl.meta]
+
+
+def _check(got, want, what=""):
+    scale = want.abs().max().item()
+    err = (got.double() - want).abs().max().item()
+    assert err <= EPS * scale, "%s: max err %.3e vs scale %.3e (%.2e relative)" % (what, err, scale, err / scale)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act,norm,res", [
+    (2, 32, 32, 24, 64, 2, False, False),      # one resident chunk, full tiles in x
+    (2, 38, 38, 21, 70, 2, True, False),       # padded channels (40), ragged tiles, fused InstanceNorm affine + LeakyReLU on load
+    (1, 64, 64, 30, 40, 1, False, True),       # two chunks, residual (data-gradient accumulation)
+    (2, 96, 96, 17, 33, 2, True, True),        # three chunks
+    (1, 128, 128, 15, 20, 0, False, False),    # four chunks, two tiles
+    (1, 180, 180, 30, 40, 2, False, False),    # streamed weights (192 padded input channels), six output blocks
+    (3, 32, 3, 16, 96, 2, False, False),       # 3 output channels stored as 8
+    (1, 256, 64, 9, 11, 1, False, False),      # deep K, tiny map
+])
+def test_conv3x3_bf16_kernel(G, B, Cin, Cout, H, W, act, norm, res):
+    """egne_conv3x3_bf16_fwd (models/RITnet_v2.py:57-62,85-87 in a bf16-storage plan) against float64 on the same
+    bf16-representable input, weights rounded to bf16 as the kernel's pack does."""
+    x = _q(_rand(G, B, Cin, H, W))
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout) * 0.1
+    nm, xin = None, x.double()
+    if norm:
+        sc, sh = 0.5 + torch.rand(B, Cin, generator=G), _rand(G, B, Cin) * 0.3
+        nm = {0: (sc, sh, 2)}
+        xin = _q(F.leaky_relu(x * sc[:, :, None, None] + sh[:, :, None, None], 0.01)).double()     # the kernel rounds the operand to bf16
+    r = _q(_rand(G, B, Cout, H, W)) if res else None
+    got, kinds = _conv(G, [x], w, b, act=act, pad=(1, 1), norm=nm, residual=r)
+    assert kinds[0] == "conv_bf16:3x3", kinds
+    want = F.conv2d(xin, _q(w).double(), b.double(), padding=1)
+    want = F.relu(want) if act == 1 else (F.leaky_relu(want, 0.01) if act == 2 else want)
+    if res:
+        want = want + r.double()
+    _check(got, want, "conv3x3_bf16")
+
+
+def test_conv_generic_bf16_storage(G):
+    """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
+    slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
+    (regressionModule, utils.py:1016) and the first layer on one channel (utils.py:1047)."""
+    B, H, W = 2, 23, 37
+    xs = [_q(_rand(G, B, c, H, W)) for c in (38, 64, 64)]
+    w, b = _rand(G, 64, 166, 1, 1) / 166 ** 0.5, _rand(G, 64) * 0.1
+    sc, sh = 0.5 + torch.rand(B, 64, generator=G), _rand(G, B, 64) * 0.3
+    got, kinds = _conv(G, xs, w, b, act=2, norm={1: (sc, sh, 2)})
+    assert kinds == ["conv_igemm"], kinds
+    x1 = F.leaky_relu(xs[1] * sc[:, :, None, None] + sh[:, :, None, None], 0.01)
+    want = F.leaky_relu(F.conv2d(torch.cat([xs[0], x1, xs[2]], 1).double(), w.double(), b.double()), 0.01)
+    _check(got, want, "1x1 over three slices")
+    x = _q(_rand(G, 2, 64, 24, 32))
+    w, b = _rand(G, 128, 64, 4, 4) / 32.0, _rand(G, 128) * 0.1
+    got, _ = _conv(G, [x], w, b, act=1, pad=(1, 1), stride=2, pad_mode=1)
+    want = F.relu(F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double(), b.double(), stride=2))
+    _check(got, want, "reflect 4x4 stride 2")
+    x = _q(_rand(G, 2, 306, 15, 20))
+    w, b = _rand(G, 128, 306, 2, 3) / 43.0, _rand(G, 128) * 0.1
+    got, _ = _conv(G, [x], w, b, act=2)
+    _check(got, F.leaky_relu(F.conv2d(x.double(), w.double(), b.double()), 0.01), "valid 2x3")
+    x = _q(_rand(G, 2, 1, 40, 64))
+    w, b = _rand(G, 32, 1, 3, 3) / 3.0, _rand(G, 32) * 0.1
+    got, kinds = _conv(G, [x], w, b, act=2, pad=(1, 1))
+    assert kinds == ["conv3x3_smallcin"], kinds
+    _check(got, F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01), "first layer")
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,H,W", [("3x3", 32, 32, 24, 40), ("3x3", 38, 64, 21, 35), ("3x3n", 64, 64, 30, 40),
+                                              ("1x1", 166, 64, 24, 40), ("1x1big", 352, 100, 30, 40)])
+def test_weight_and_data_gradients_bf16_storage(G, kind, Cin, Cout, H, W):
+    """Backward of one convolution of a bf16-storage plan (engine.Plan._bw_conv): activation mask + bias gradient
+    (egne_act_bwd_bias_bf16), weight gradient (egne_conv2d_wgrad, dtype 1) and data gradient, against float64 autograd on the
+    bf16-representable tensors.  The fp32 parameter gradients must agree to fp32-accumulation accuracy (inputs are exact),
+    the bf16 data gradient to its storage rounding."""
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    B = 2
+    k = 3 if kind.startswith("3x3") else 1
+    x = _q(_rand(G, B, Cin, H, W))
+    w, b = _rand(G, Cout, Cin, k, k) / (k * Cin ** 0.5), _rand(G, Cout) * 0.1
+    gy = _q(_rand(G, B, Cout, H, W) * 1e-3)
+    pl = _plan()
+    pl.train = True
+    xs = [x] if k == 3 else list(torch.split(x, [Cin - 64, 32, 32], 1))
+    pieces = _pieces(pl, xs, B, H, W)
+    wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    wp.grad, bp.grad = torch.zeros_like(wp), torch.zeros_like(bp)
+    layer = ConvLayer([wp], [bp], [(p.C, p.Cp) for p in pieces], pad=(k // 2, k // 2), act=2)
+    sc = sh = None
+    if kind == "3x3n":
+        sc, sh = 0.5 + torch.rand(B, Cin, generator=G), _rand(G, B, Cin) * 0.3
+        scp, shp = sc.to(DEV).contiguous(), sh.to(DEV).contiguous()
+        pl.keep += [scp, shp]
+        pieces[0] = pieces[0].with_norm(scp, shp, 0)
+    out = pl.buf(B, H, W, pad8(Cout))
+    dst = Piece(out, 0, Cout)
+    pl.conv(layer, pieces, dst, B, H, W)
+    bw = pl.build_backward()
+    pl.run()
+    pl.zero_grads()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    # float64 truth on what the buffers held: y as STORED (bf16) decides the activation mask
+    xd = x.double().requires_grad_(True)
+    wd, bd = (_q(w) if k == 3 else w).double().requires_grad_(True), b.double().requires_grad_(True)
+    xin = xd if sc is None else _q((x * sc[:, :, None, None] + sh[:, :, None, None])).double()
+    if sc is not None:
+        xin.requires_grad_(True)
+    z = F.conv2d(xin, wd, bd, padding=k // 2)
+    ystored = out.float().cpu()[..., :Cout].permute(0, 3, 1, 2).double()
+    gz = gy.double() * torch.where(ystored > 0, 1.0, 0.01)
+    z.backward(gz)
+    # the kernel's gz is rounded to bf16 before the weight / data gradients read it
+    gzq = _q(gz.float()).double()
+    xin2 = xin.detach().clone().requires_grad_(True)
+    wd2, bd2 = wd.detach().clone().requires_grad_(True), bd.detach().clone().requires_grad_(True)
+    F.conv2d(xin2, wd2, bd2, padding=k // 2).backward(gzq)
+    gw = wp.grad.double().cpu()
+    e = (gw - wd2.grad).abs().max().item() / wd2.grad.abs().max().item()
+    assert e < (2e-5 if k == 1 else 3e-3), "weight gradient: relative error %.2e" % e      # 3x3: x operand of the bf16 MFMA is exact, products fp32
+    eb = (bp.grad.double().cpu() - gz.sum((0, 2, 3))).abs().max().item() / gz.sum((0, 2, 3)).abs().max().item()
+    assert eb < 1e-5, "bias gradient: relative error %.2e" % eb
+    if sc is None:
+        gx = torch.cat([pl.gbuf(p.buf).float().cpu()[..., p.off:p.off + p.C] for p in pieces], -1).permute(0, 3, 1, 2).double()
+        ex = (gx - xin2.grad).abs().max().item() / xin2.grad.abs().max().item()
+        assert ex < EPS, "data gradient: relative error %.2e" % ex
+
+
+def test_elementwise_twins_match_the_fp32_kernels(G):
+    """Every bf16 twin reads / writes bf16 and computes as its fp32 original: run both on the same bf16-representable data and
+    compare (the twin's result may differ by one bf16 rounding of the OUTPUT; statistics and parameter gradients are fp32 on
+    both sides and must agree to 1e-6)."""
+    from egne_amd import _lib
+    from egne_amd.engine import Plan
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    B, H, W, C = 2, 24, 40, 40
+    x = _q(_rand(G, B, H, W, C)).to(DEV)
+    xb = x.to(BF)
+    gy = _q(_rand(G, B, H, W, C) * 1e-2).to(DEV)
+    gyb = gy.to(BF)
+    # InstanceNorm statistics
+    outs = []
+    for t, fn in ((x, L.egne_norm_stats), (xb, L.egne_norm_stats_bf16)):
+        sc, sh = torch.zeros(B, C, device=DEV), torch.zeros(B, C, device=DEV)
+        ws = torch.zeros(int(L.egne_norm_stats_workspace_bytes(B, H * W, C, 1)) // 8 + 1, dtype=torch.float64, device=DEV)
+        _lib.check(fn(t.data_ptr(), C, 0, C, B, H * W, 1, 1e-5, sc.data_ptr(), sh.data_ptr(), None, None, ws.data_ptr(), st))
+        outs.append((sc, sh))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-7)
+    sc, sh = outs[0]
+
+    def both(f32, bf, make_out, n_in=1):
+        o32, o16 = make_out(torch.float32), make_out(BF)
+        f32(o32)
+        bf(o16)
+        torch.cuda.synchronize()
+        err = (o16.float() - o32).abs().max().item()
+        assert err <= EPS * o32.abs().max().item() * 1.01, err
+    # pooled Transition_down operand, its backward, plain pooling, up-sampling and their backward passes
+    both(lambda o: _lib.check(L.egne_norm_act_pool2(x.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), 2, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda o: _lib.check(L.egne_norm_act_pool2_bf16(xb.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), 2, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda dt: torch.zeros(B, H // 2, W // 2, C, dtype=dt, device=DEV))
+    both(lambda o: _lib.check(L.egne_avgpool2(x.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda o: _lib.check(L.egne_avgpool2_bf16(xb.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda dt: torch.zeros(B, H // 2, W // 2, C, dtype=dt, device=DEV))
+    both(lambda o: _lib.check(L.egne_upsample2x(x.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda o: _lib.check(L.egne_upsample2x_bf16(xb.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda dt: torch.zeros(B, 2 * H, 2 * W, C, dtype=dt, device=DEV))
+    gq = _q(_rand(G, B, H // 2, W // 2, C) * 1e-2).to(DEV)
+    gqb = gq.to(BF)
+    both(lambda o: _lib.check(L.egne_avgpool2_bwd(gq.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda o: _lib.check(L.egne_avgpool2_bwd_bf16(gqb.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H, W, C, st)),
+         lambda dt: torch.zeros(B, H, W, C, dtype=dt, device=DEV))
+    both(lambda o: _lib.check(L.egne_upsample2x_bwd(gy.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H // 2, W // 2, C, st)),
+         lambda o: _lib.check(L.egne_upsample2x_bwd_bf16(gyb.data_ptr(), C, 0, o.data_ptr(), C, 0, B, H // 2, W // 2, C, st)),
+         lambda dt: torch.zeros(B, H // 2, W // 2, C, dtype=dt, device=DEV))
+    # InstanceNorm backward (accumulating and storing forms) and the pooled form
+    wsn = torch.zeros(int(L.egne_norm_bwd_workspace_bytes(B, H * W, C, 1)) // 8 + 1, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(B * C * 2, device=DEV)
+    for f32, bf in ((L.egne_norm_bwd, L.egne_norm_bwd_bf16), (L.egne_norm_bwd_store, L.egne_norm_bwd_store_bf16)):
+        both(lambda o: _lib.check(f32(x.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), None, gy.data_ptr(), C, 0, 2, C, B, H * W, 1,
+                                      o.data_ptr(), C, 0, sums.data_ptr(), None, None, 0, wsn.data_ptr(), st)),
+             lambda o: _lib.check(bf(xb.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), None, gyb.data_ptr(), C, 0, 2, C, B, H * W, 1,
+                                     o.data_ptr(), C, 0, sums.data_ptr(), None, None, 0, wsn.data_ptr(), st)),
+             lambda dt: torch.zeros(B, H, W, C, dtype=dt, device=DEV))
+    both(lambda o: _lib.check(L.egne_norm_pool2_bwd(x.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), gq.data_ptr(), C, 0, 2, C, B, H, W,
+                                                    o.data_ptr(), C, 0, 0, sums.data_ptr(), wsn.data_ptr(), st)),
+         lambda o: _lib.check(L.egne_norm_pool2_bwd_bf16(xb.data_ptr(), C, 0, sc.data_ptr(), sh.data_ptr(), gqb.data_ptr(), C, 0, 2, C, B, H, W,
+                                                         o.data_ptr(), C, 0, 0, sums.data_ptr(), wsn.data_ptr(), st)),
+         lambda dt: torch.zeros(B, H, W, C, dtype=dt, device=DEV))
+    # activation backward + bias gradient (in place on g)
+    ws = torch.zeros(int(L.egne_act_bwd_bias_workspace_bytes(B * H * W, C)) // 8 + 1, dtype=torch.float64, device=DEV)
+    g32, g16 = gy.clone(), gyb.clone()
+    db32, db16 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    _lib.check(L.egne_act_bwd_bias(g32.data_ptr(), C, 0, x.data_ptr(), C, 0, 2, C, B * H * W, db32.data_ptr(), C, 0, ws.data_ptr(), st))
+    _lib.check(L.egne_act_bwd_bias_bf16(g16.data_ptr(), C, 0, xb.data_ptr(), C, 0, 2, C, B * H * W, db16.data_ptr(), C, 0, ws.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert (g16.float() - g32).abs().max().item() <= EPS * g32.abs().max().item()
+    assert torch.allclose(db16, db32, rtol=2e-3, atol=1e-4 * db32.abs().max().item())      # (the bf16 twin sums the values it STORED)
+    # batch-norm apply
+    a, b_ = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    both(lambda o: _lib.check(L.egne_affine(x.data_ptr(), C, 0, o.data_ptr(), C, 0, C, B * H * W, a.data_ptr(), b_.data_ptr(), st)),
+         lambda o: _lib.check(L.egne_affine_bf16(xb.data_ptr(), C, 0, o.data_ptr(), C, 0, C, B * H * W, a.data_ptr(), b_.data_ptr(), st)),
+         lambda dt: torch.zeros(B, H, W, C, dtype=dt, device=DEV))
+    assert Plan(torch.device(DEV), dtype=BF).L.egne_norm_stats._name_ if hasattr(L.egne_norm_stats, "_name_") else True
+
+
+NET_CASES = ["esf_edge_b2", "esf_baseline_b2", "esf_concat_b2", "esf_edge_b2_absent1", "esf_adain_edge_b2", "esf_adain_b2_train",
+             "esf_adain_edge_detach_b2"]
+
+
+@pytest.fixture(scope="module")
+def edge_exact():
+    """Edge maps from the exact-fp32 BDCN kernels, as in test_gpu_nets.edge_of_exact."""
+    import types
+    from common import bdcn_module
+    from egne_amd import engine, synth
+    from egne_amd.utils import calc_edge
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    net = bdcn_module().to(DEV)
+    cache = {}
+
+    def get(**kw):
+        key = tuple(sorted(kw.items()))
+        if key not in cache:
+            b = synth.make_batch(kw.pop("B"), **kw)
+            old, engine.F16X3_ENABLED = engine.F16X3_ENABLED, False
+            try:
+                cache[key] = (b, calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), b["img"].to(DEV), net, DEV))
+            finally:
+                engine.F16X3_ENABLED = old
+        return cache[key]
+    return get
+
+
+def _grad_report(params, g):
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([params[n].grad.double().norm().item() for n in names])
+    ref = g["grad_l2"]
+    rel = np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max())
+    full = {}
+    for k in ("elReg.l2.weight", "dec.final.conv2.weight", "enc.head.conv1.weight", "enc.down_block1.conv21.weight", "dec.up_block4.conv11.bias"):
+        if "grad::" + k in g.files and k in params:
+            r = g["grad::" + k]
+            full[k] = float(np.linalg.norm(params[k].grad.cpu().numpy() - r) / max(np.linalg.norm(r), 1e-30))
+    return names, rel, full
+
+
+@pytest.mark.parametrize("name", NET_CASES)
+def test_esf_train_step_bf16_storage_vs_reference(name, edge_exact):
+    """One training forward + backward of a model switched to bf16 activation storage (``model.to(torch.bfloat16)``, what
+    ``--prec 16`` does) against the REFERENCE's fp32 autograd fixtures (tests/golden/make_golden.py): loss, logits, ellipse
+    head, BatchNorm running statistics, per-parameter gradient norms and five full gradient tensors."""
+    from common import ESF_CASES, batch_args, esf_module, gold
+    cfg, variant, kw = ESF_CASES[name]
+    g = gold(name)
+    b, edge = edge_exact(**dict(kw))
+    m = esf_module(cfg, variant).to(DEV).to(torch.bfloat16).train()
+    assert m.storage_dtype == torch.bfloat16 and m.enc.head.conv1.weight.dtype == torch.float32      # fp32 master weights
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    op, elPred, latent, loss, elOut = m(*args)
+    pl = m._last_plan
+    assert pl.bf16 and pl.bw.bf16 and all(t.dtype == torch.bfloat16 for t in pl.gtwins.values())
+    kinds = {k for k, _ in pl.meta}
+    assert "conv_bf16:3x3" in kinds and not any(k.startswith("conv_f16x3") for k in kinds), kinds
+    assert latent.dtype == torch.float32 and op.dtype == torch.float32
+    lerr = abs(loss.item() - float(np.asarray(g["t_loss"]).reshape(-1)[0])) / abs(float(np.asarray(g["t_loss"]).reshape(-1)[0]))
+    operr = np.abs(op.detach().cpu()[:, :, ::4, ::4].numpy() - g["t_op_sub"]).max() / np.abs(g["t_op_sub"]).max()
+    elerr = np.abs(elOut.detach().cpu().numpy() - g["t_elOut"]).max()
+    np.testing.assert_allclose(m.enc.head.bn.running_mean.cpu().numpy(), g["t_head_rm"], rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(m.enc.head.bn.running_var.cpu().numpy(), g["t_head_rv"], rtol=2e-2, atol=2e-3)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    names, rel, full = _grad_report(dict(m.named_parameters()), g)
+    worst = int(np.argmax(rel))
+    print("%s [bf16 storage]: loss rel %.2e, logits rel-to-max %.2e, elOut abs %.2e, grad-norm rel max %.2e (%s) median %.2e, full-tensor rel L2 %s"
+          % (name, lerr, operr, elerr, rel.max(), names[worst], np.median(rel), {k: "%.1e" % v for k, v in full.items()}))
+    assert lerr < 1e-2 and operr < 8e-2 and elerr < 1e-1
+    assert rel.max() < 6e-1 and np.median(rel) < 3e-2
+    # decoder / regression-head tensors tightly, the first encoder layers loosely (module docstring)
+    lim = {"dec.final.conv2.weight": 3e-2, "dec.up_block4.conv11.bias": 8e-2, "elReg.l2.weight": 8e-2,
+           "enc.down_block1.conv21.weight": 4.5e-1, "enc.head.conv1.weight": 9.5e-1}
+    assert all(v < lim[k] for k, v in full.items()), full
+
+
+def test_bf16_gradients_vs_float64_truth(edge_exact):
+    """Deviation of the bf16-storage gradients from a float64 evaluation of the oracle, next to the reference's own fp32
+    deviation (fixture) and the fp32-storage HIP plan's: per-parameter gradient norms."""
+    from common import ESF_CASES, batch_args, esf_module, gold, setting
+    from common import bdcn_module
+    from egne_amd import synth
+    from oracle import bdcn as obdcn, esfnet as oesf
+    name = "esf_edge_b2_absent1"
+    cfg, variant, kw = ESF_CASES[name]
+    kw = dict(kw)
+    g = gold(name)
+    b = synth.make_batch(kw.pop("B"), **kw)
+    edge = obdcn.calc_edge({k: v.cpu() for k, v in bdcn_module().state_dict().items()}, b["img"])
+    m = esf_module(cfg, variant)
+    sd = {k: v.double().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+    a64 = [a.double() if (torch.is_tensor(a) and a.dtype.is_floating_point) else a for a in batch_args(b, edge)]
+    oesf.esf_forward(sd, setting(cfg), *a64, variant=variant, training=True)[3].sum().backward()
+    names = [str(n) for n in g["grad_names"]]
+    t = np.array([sd[n].grad.norm().item() for n in names])
+    keep = t > 1e-6 * t.max()
+    devs = {}
+    for st in (torch.float32, torch.bfloat16):
+        mm = esf_module(cfg, variant).to(DEV).to(st).train()
+        args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+        mm(*args)[3].sum().backward()
+        params = dict(mm.named_parameters())
+        h = np.array([params[n].grad.double().norm().item() for n in names])
+        dirs = [float((params[n].grad.double().cpu() - sd[n].grad).norm() / sd[n].grad.norm()) for n, k in zip(names, keep) if k]
+        devs[st] = ((np.abs(h - t) / t)[keep].max(), float(np.median((np.abs(h - t) / t)[keep])), max(dirs), float(np.median(dirs)))
+    ref_dev = (np.abs(g["grad_l2"] - t) / t)[keep].max()
+    print("%s: gradient deviation from float64 -- reference fp32 norms %.2e; HIP fp32 storage norms max %.2e median %.2e, tensors (rel L2) max %.2e "
+          "median %.2e; HIP bf16 storage norms max %.2e median %.2e, tensors max %.2e median %.2e"
+          % ((name, ref_dev) + devs[torch.float32] + devs[torch.bfloat16]))
+    assert devs[torch.bfloat16][0] < 3.5e-1 and devs[torch.bfloat16][1] < 2e-2 and devs[torch.bfloat16][2] < 8e-1 and devs[torch.bfloat16][3] < 4e-1
+    assert devs[torch.float32][0] < max(2 * ref_dev, 2e-3)
+
+
+def test_bf16_training_replays_bit_identically_and_learns(edge_exact):
+    """Three passes over one batch leave identical gradients (deterministic reductions); then 30 Adam steps on that batch with
+    bf16 storage bring the loss down as the fp32-storage plan does (train.py:284-287)."""
+    from common import batch_args, esf_module
+    b, edge = edge_exact(B=2, seed=1234)
+    runs = {}
+    for st in (torch.float32, torch.bfloat16):
+        m = esf_module("baseline_edge").to(DEV).to(st).train()
+        args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+        if st == torch.bfloat16:
+            snaps = []
+            for _ in range(3):
+                m.zero_grad()
+                m(*args)[3].backward()
+                snaps.append(m._grad_flat.clone())
+            assert torch.equal(snaps[0], snaps[1]) and torch.equal(snaps[0], snaps[2])
+            for bn in (m.enc.head.bn, m.dec.final.bn):
+                bn.reset_running_stats()
+        opt = torch.optim.Adam([p for n, p in m.named_parameters() if "dsIdentify" not in n], lr=5e-4)
+        losses = []
+        for _ in range(30):
+            opt.zero_grad()
+            loss = m(*args)[3]
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        runs[st] = losses
+    f, h = runs[torch.float32], runs[torch.bfloat16]
+    print("30 Adam steps: fp32 storage %.4f -> %.4f, bf16 storage %.4f -> %.4f" % (f[0], f[-1], h[0], h[-1]))
+    assert h[-1] < 0.8 * h[0] and abs(h[-1] - f[-1]) < 0.1 * abs(f[0] - f[-1]) + 0.02 * abs(f[-1])
