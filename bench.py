@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per inference step (default 64)")
     ap.add_argument("--train-batch", type=int, default=256, help="frames per GPU per training step (BASELINE.json configs[2]: 256)")
     ap.add_argument("--train-steps", type=int, default=4)
+    ap.add_argument("--train-storage", choices=("fp32", "bf16", "both"), default="both",
+                    help="activation / activation-gradient storage of the training leg: bf16 (what BASELINE.json configs[2..4] name; "
+                         "fp32 accumulation, fp32 master weights), fp32 (the parity anchor), or both legs (default)")
     ap.add_argument("--mode", choices=("all", "infer", "train", "prep"), default="all",
                     help="all: every leg in one JSON line (default); infer / train: that leg only; "
                          "prep: device-side batch preparation (distance maps + z-score, SURVEY.md 8f N1)")
@@ -229,7 +232,7 @@ class Bench:
         self.bd._events = self.net._events = (ev if events and not os.environ.get("EGNE_BENCH_NO_EVENTS") else None)
         # HIP events around every conv launch (the roofline families); all ~600 launches of a step only with --layers:
         # an event pair costs ~2 us of GPU time, 2.5 % of the step when every launch carries one
-        _engine.EVENT_KINDS = None if self.a.layers else {"conv_f16x3", "conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad"}
+        _engine.EVENT_KINDS = None if self.a.layers else {"conv_f16x3", "conv_bf16", "conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad"}
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -351,12 +354,13 @@ class Bench:
         assert self.torch.isfinite(out[3]).all()
         return B, dt, ev
 
-    def leg_train(self, steps, warmup, events=True, pipeline=None):
+    def leg_train(self, steps, warmup, events=True, pipeline=None, storage="fp32"):
         torch = self.torch
         from egne_amd import parallel
         from egne_amd.utils import calc_edge
         B = self.a.train_batch
         t, bd, net, args, dev = self.batch(B), self.bd, self.net, self.args, self.dev
+        net.to(torch.bfloat16 if storage == "bf16" else torch.float32)       # storage of the training plan's activations (models/RITnet_v2.py: DenseNet2D.to)
         net.train()
         parallel.broadcast_state(net)
         opt = torch.optim.Adam([p for n, p in net.named_parameters() if "dsIdentify" not in n], lr=5e-4)
@@ -389,6 +393,7 @@ class Bench:
         dt, ev, out = self.timed(step, steps, warmup, events)
         assert torch.isfinite(out[3]).all()
         net.eval()
+        net.to(torch.float32)
         return B, dt, ev
 
 
@@ -497,12 +502,13 @@ def main():
         steps = a.train_steps if a.mode == "all" else a.steps
         warm = 2 if a.mode == "all" else a.warmup
         torch.cuda.reset_peak_memory_stats()
+        sto = "bf16" if a.train_storage in ("bf16", "both") else "fp32"
         if a.no_pipeline:
-            B, dt, ev = bn.leg_train(steps, warm)
+            B, dt, ev = bn.leg_train(steps, warm, storage=sto)
             dt_k = dt
         else:       # value from the pipelined loop, kernel durations from a second region with the stages back to back (as for inference)
-            B, dt, _ = bn.leg_train(steps, warm, events=False)
-            _, dt_k, ev = bn.leg_train(steps, 1, pipeline=False)
+            B, dt, _ = bn.leg_train(steps, warm, events=False, storage=sto)
+            _, dt_k, ev = bn.leg_train(steps, 1, pipeline=False, storage=sto)
         fam = bn.families(ev, steps, dt_k)
         rsp, r32, sp_t, conv_t = bn.rooflines(fam, steps, B, dt_k)
         for r in (rsp, r32):

@@ -98,35 +98,38 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(T* __restrict__ g, l
                                                             const T* __restrict__ y, long long ys, int yo, int act,
                                                             int Cp, long long npix, int nchunk, double* __restrict__ ws,
                                                             unsigned* __restrict__ absmax_bits) {
+  constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;      // 16-byte vectors: 8 x 32 rows (fp32) or 4 x 64 rows (bf16)
   const int chunk = blockIdx.x, cg = blockIdx.y;
   unsigned mb = 0;
-  const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
-  const int c = cg * 32 + v * 4;
+  const int v = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int c = cg * 32 + v * N;
   const long long per = (npix + nchunk - 1) / nchunk;
   const long long p0 = (long long)chunk * per, p1 = p0 + per < npix ? p0 + per : npix;
-  double s[4] = {0, 0, 0, 0};
+  double s[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s[e] = 0;
   if (c < Cp) {
     // four pixel rows per trip, all eight loads issued before the first use (one row at a time ran at 3.0 TB/s: latency bound)
-    for (long long p = p0 + row; p < p1; p += 128) {
-      f32x4 t[4], yy[4];
+    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {
+      egne_fv<N> t[4], yy[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long long q = p + 32 * u;
-        t[u] = q < p1 ? ld4(g + q * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        yy[u] = (q < p1 && act != EGNE_ACT_NONE) ? ld4(y + q * ys + yo + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const long long q = p + ROWS * u;
+        t[u] = q < p1 ? ldv(g + q * gs + go + c) : fv_fill<N>(0.f);
+        yy[u] = (q < p1 && act != EGNE_ACT_NONE) ? ldv(y + q * ys + yo + c) : fv_fill<N>(1.f);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long long q = p + 32 * u;
+        const long long q = p + ROWS * u;
         if (act != EGNE_ACT_NONE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t[u][e] = yy[u][e] > 0.f ? t[u][e] : (act == EGNE_ACT_LEAKY ? 0.01f * t[u][e] : 0.f);
-          if (q < p1) st4(g + q * gs + go + c, t[u]);
+          for (int e = 0; e < N; ++e) t[u].v[e] = yy[u].v[e] > 0.f ? t[u].v[e] : (act == EGNE_ACT_LEAKY ? 0.01f * t[u].v[e] : 0.f);
+          if (q < p1) stv(g + q * gs + go + c, t[u]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s[e] += t[u][e];
-          const unsigned b = __float_as_uint(t[u][e]) & 0x7fffffffu;
+        for (int e = 0; e < N; ++e) {
+          s[e] += t[u].v[e];
+          const unsigned b = __float_as_uint(t[u].v[e]) & 0x7fffffffu;
           mb = b > mb ? b : mb;
         }
       }
@@ -139,15 +142,14 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(T* __restrict__ g, l
     }
     if ((threadIdx.x & 63) == 0 && mb > __hip_atomic_load(absmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(absmax_bits, mb);
   }
-  __shared__ double sh[32][8][4];
+  __shared__ double sh[ROWS][32];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) sh[row][v][e] = s[e];
+  for (int e = 0; e < N; ++e) sh[row][v * N + e] = s[e];
   __syncthreads();
   if (threadIdx.x < 32) {
-    const int vv = threadIdx.x >> 2, e = threadIdx.x & 3;
     double a = 0;
-    for (int r = 0; r < 32; ++r) a += sh[r][vv][e];
-    const int cc = cg * 32 + vv * 4 + e;
+    for (int r = 0; r < ROWS; ++r) a += sh[r][threadIdx.x];
+    const int cc = cg * 32 + threadIdx.x;
     if (cc < Cp) ws[(long long)chunk * Cp + cc] = a;
   }
 }
@@ -183,54 +185,58 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const T* __restrict__ x,
                                                         double* __restrict__ ws, int poolW) {
   // poolW > 0: gy is the gradient of the 2x2-average-POOLED tensor ([n][H/2][W/2]); pixel p = (y, x) of a W = poolW wide map
   // receives a quarter of its pooled cell's gradient (egne_norm_pool2_bwd)
+  constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
-  const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
-  const int c = cg * 32 + v * 4;
+  const int v = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int c = cg * 32 + v * N;
   const long long per = (npix_per_n + nchunk - 1) / nchunk;
   const long long p0 = (long long)chunk * per, p1 = p0 + per < npix_per_n ? p0 + per : npix_per_n;
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  double s1[N], s2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { s1[e] = 0; s2[e] = 0; }
   if (c < Cp) {
-    const f32x4 sc = *(const f32x4*)(scale + (long long)(per_sample ? n : 0) * Cp + c);
-    const f32x4 sh = *(const f32x4*)(shift + (long long)(per_sample ? n : 0) * Cp + c);
+    const egne_fv<N> sc = ldf<N>(scale + (long long)(per_sample ? n : 0) * Cp + c);
+    const egne_fv<N> sh = ldf<N>(shift + (long long)(per_sample ? n : 0) * Cp + c);
     const long long nb = (long long)n * npix_per_n;
-    for (long long p = p0 + row; p < p1; p += 128) {        // four rows per trip: loads issued together (same summation order)
-      f32x4 xv4[4], g4[4];
+    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {        // four rows per trip: loads issued together (same summation order)
+      egne_fv<N> xv4[4], g4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long long q = p + 32 * u;
+        const long long q = p + ROWS * u;
         const bool ok = q < p1;
-        xv4[u] = ok ? ld4(x + (nb + q) * xs + xo + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv4[u] = ok ? ldv(x + (nb + q) * xs + xo + c) : fv_fill<N>(0.f);
         if (poolW) {
           const int py = (int)(q / poolW), px = (int)(q - (long long)py * poolW);
-          g4[u] = ok ? 0.25f * ld4(gy + ((nb >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c)
-                     : f32x4{0.f, 0.f, 0.f, 0.f};
+          g4[u] = ok ? ldv(gy + ((nb >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c) : fv_fill<N>(0.f);
+#pragma unroll
+          for (int e = 0; e < N; ++e) g4[u].v[e] *= 0.25f;
         } else {
-          g4[u] = ok ? ld4(gy + (nb + q) * gs + go + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          g4[u] = ok ? ldv(gy + (nb + q) * gs + go + c) : fv_fill<N>(0.f);
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        f32x4 g = g4[u];
-        const f32x4 xh = xv4[u] * sc + sh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
-          else if (act_in == EGNE_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
-          s1[e] += g[e]; s2[e] += (double)g[e] * xh[e];
+        for (int e = 0; e < N; ++e) {
+          float g = g4[u].v[e];
+          const float xh = xv4[u].v[e] * sc.v[e] + sh.v[e];
+          if (act_in == EGNE_ACT_LEAKY) g = xh > 0.f ? g : 0.01f * g;
+          else if (act_in == EGNE_ACT_RELU) g = xh > 0.f ? g : 0.f;
+          s1[e] += g; s2[e] += (double)g * xh;
         }
       }
     }
   }
-  __shared__ double sh_[32][8][8];
+  __shared__ double sh_[ROWS][32][2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { sh_[row][v][e] = s1[e]; sh_[row][v][4 + e] = s2[e]; }
+  for (int e = 0; e < N; ++e) { sh_[row][v * N + e][0] = s1[e]; sh_[row][v * N + e][1] = s2[e]; }
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int vv = threadIdx.x >> 3, e = threadIdx.x & 7;
+    const int cc_ = threadIdx.x >> 1, w_ = threadIdx.x & 1;
     double a = 0;
-    for (int r = 0; r < 32; ++r) a += sh_[r][vv][e];
-    const int cc = cg * 32 + vv * 4 + (e & 3);
-    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + (e >> 2)] = a;
+    for (int r = 0; r < ROWS; ++r) a += sh_[r][cc_][w_];
+    const int cc = cg * 32 + cc_;
+    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + w_] = a;
   }
 }
 
@@ -254,37 +260,41 @@ __global__ void norm_bwd_apply(const T* __restrict__ x, long long xs, int xo, co
                                const T* __restrict__ gy, long long gs, int go, int act_in, int Cp,
                                long long npix_per_n, int Bn, int per_sample, const float* __restrict__ sums,
                                T* __restrict__ gx, long long gxs, int gxo, int poolW, int accumulate) {
-  const int nv = Cp >> 2;
+  constexpr int N = egne_vt<T>::N;
+  const int nv = Cp / N;
   const long long total = (long long)Bn * npix_per_n * nv;
   const float invN = 1.f / (float)npix_per_n;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % nv) * 4;
+    const int c = (int)(i % nv) * N;
     const long long pp = i / nv;               // global pixel index over (n, p)
     const int n = per_sample ? (int)(pp / npix_per_n) : 0;
-    const f32x4 sc = *(const f32x4*)(scale + (long long)n * Cp + c);
-    const f32x4 sh = *(const f32x4*)(shift + (long long)n * Cp + c);
-    const f32x4 xv = ld4(x + pp * xs + xo + c);
-    f32x4 g;
+    const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c);
+    const egne_fv<N> sh = ldf<N>(shift + (long long)n * Cp + c);
+    const egne_fv<N> xv = ldv(x + pp * xs + xo + c);
+    egne_fv<N> g;
+    float gsc = 1.f;
     if (poolW) {      // per_sample mode, even H and W (checked by the entry point)
       const long long p = pp - (long long)n * npix_per_n;
       const int py = (int)(p / poolW), px = (int)(p - (long long)py * poolW);
-      g = 0.25f * ld4(gy + (((long long)n * npix_per_n >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c);
+      g = ldv(gy + (((long long)n * npix_per_n >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c);
+      gsc = 0.25f;
     } else {
-      g = ld4(gy + pp * gs + go + c);
+      g = ldv(gy + pp * gs + go + c);
     }
-    const f32x4 xh = xv * sc + sh;
     T* dst = gx + pp * gxs + gxo + c;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (accumulate) o = ld4(dst);          // (the first writer of a gradient slice stores: no read)
+    egne_fv<N> o = fv_fill<N>(0.f);
+    if (accumulate) o = ldv(dst);          // (the first writer of a gradient slice stores: no read)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (act_in == EGNE_ACT_LEAKY) g[e] = xh[e] > 0.f ? g[e] : 0.01f * g[e];
-      else if (act_in == EGNE_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+    for (int e = 0; e < N; ++e) {
+      const float xh = xv.v[e] * sc.v[e] + sh.v[e];
+      float ge = g.v[e] * gsc;
+      if (act_in == EGNE_ACT_LEAKY) ge = xh > 0.f ? ge : 0.01f * ge;
+      else if (act_in == EGNE_ACT_RELU) ge = xh > 0.f ? ge : 0.f;
       const float gm = gamma ? gamma[c + e] : 1.f;
       const float m1 = sums[2 * ((long long)n * Cp + c + e)] * invN, m2 = sums[2 * ((long long)n * Cp + c + e) + 1] * invN;
-      o[e] += sc[e] * gm * (g[e] - m1 - xh[e] * m2);
+      o.v[e] += sc.v[e] * gm * (ge - m1 - xh * m2);
     }
-    st4(dst, o);
+    stv(dst, o);
   }
 }
 
@@ -706,6 +716,10 @@ __global__ void pack_weight_dgrad_k(const float* __restrict__ w, int Cout, int C
 inline bool slice_ok(const void* p, long long stride, int off, int Cp) {
   return p && ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && off % 4 == 0 && Cp > 0 && Cp % 4 == 0 && off + Cp <= stride;
 }
+template <typename T> inline bool vec_ok(long long stride, int off, int Cp) {     // 16-byte vectors of T
+  constexpr int N = egne_vt<T>::N;
+  return stride % N == 0 && off % N == 0 && Cp % N == 0;
+}
 int chunks_for(long long npix, int Cp, int Bn) {
   const int cgroups = (Cp + 31) / 32;
   long long want = 2048 / ((long long)Bn * cgroups);
@@ -749,6 +763,7 @@ template <typename T>
 static int act_bwd_bias_impl(T* g, int64_t gs, int go, const T* y, int64_t ys, int yo, int act, int Cp,
                              int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits, void* stream) {
   EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && npix > 0 && ws, "act_bwd_bias: bad gradient slice");
+  EGNE_REQUIRE(vec_ok<T>(gs, go, Cp) && (act == EGNE_ACT_NONE || vec_ok<T>(ys, yo, Cp)), "act_bwd_bias: slices must be 16-byte vectors (8 bf16 channels)");
   EGNE_REQUIRE(act == EGNE_ACT_NONE || slice_ok(y, ys, yo, Cp), "act_bwd_bias: bad output slice");
   const int nchunk = chunks_for(npix, Cp, 1);
   hipStream_t st = (hipStream_t)stream;
@@ -785,6 +800,7 @@ static int norm_bwd_impl(const T* x, int64_t xs, int xo, const float* scale, con
                          int per_sample, T* gx, int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta,
                          int C, void* ws, void* stream, int poolW, int accumulate) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(gy, gs, go, Cp) && slice_ok(gx, gxs, gxo, Cp), "norm_bwd: bad slices");
+  EGNE_REQUIRE(vec_ok<T>(xs, xo, Cp) && vec_ok<T>(gs, go, Cp) && vec_ok<T>(gxs, gxo, Cp), "norm_bwd: slices must be 16-byte vectors (8 bf16 channels)");
   EGNE_REQUIRE(scale && shift && sums && ws && B > 0 && HW > 0, "norm_bwd: null pointer");
   EGNE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || !per_sample), "norm_bwd: dgamma/dbeta only for batch statistics");
   const int Bn = per_sample ? B : 1;
@@ -795,7 +811,7 @@ static int norm_bwd_impl(const T* x, int64_t xs, int xo, const float* scale, con
                      gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws, poolW);
   hipLaunchKernelGGL(norm_bwd_final, dim3((Bn * Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
                      dgamma, dbeta, C);
-  hipLaunchKernelGGL(norm_bwd_apply<T>, dim3(grid_for((long long)Bn * npix * (Cp / 4))), dim3(256), 0, st, x, (long long)xs, xo,
+  hipLaunchKernelGGL(norm_bwd_apply<T>, dim3(grid_for((long long)Bn * npix * (Cp / egne_vt<T>::N))), dim3(256), 0, st, x, (long long)xs, xo,
                      scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,
                      gxo, poolW, accumulate);
   return egne::check_launch("egne_norm_bwd");
@@ -998,7 +1014,9 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
   const size_t bytes = (size_t)nsplit * d.ngroups * T * d.CoutP * d.Ktot * sizeof(float);
   bool fast3x3 = false;
   if constexpr (BF) {
-    if (egne::wgrad3x3_bf16_supported(d, gzs)) {         // 3x3 "same" convolutions over one slice: bf16 MFMA (wgrad_bf16.hip)
+    if (egne::wgrad3x3_bf16_supported(d, d.out_pix_stride)) {         // 3x3 "same" convolutions over one slice: bf16 MFMA (wgrad_bf16.hip)
+      // the gradient buffer mirrors the output buffer (same pixel stride): the split count above assumed it
+      EGNE_REQUIRE(gzs == d.out_pix_stride, "wgrad: gz stride %lld differs from the output stride %lld", (long long)gzs, (long long)d.out_pix_stride);
       const int rc = egne::wgrad3x3_bf16_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);     // writes every partial it owns
       if (rc != EGNE_OK) return rc;
       fast3x3 = true;

@@ -28,6 +28,44 @@ __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const egne_bf16* p) { return (float)*p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(egne_bf16* p, float v) { *p = (egne_bf16)v; }
+// Widest aligned vector of a storage type: 16 bytes = 4 fp32 or 8 bf16 channels.  The HBM-heavy element-wise / reduction kernels
+// move one such vector per lane and access (8-byte loads of 4 bf16 ran at 1.4-1.6 TB/s where 16-byte ones reach 4+).
+template <typename T> struct egne_vt { static constexpr int N = 4; };
+template <> struct egne_vt<egne_bf16> { static constexpr int N = 8; };
+template <int N> struct egne_fv { float v[N]; };
+__device__ __forceinline__ egne_fv<4> ldv(const float* p) {
+  const egne_f32x4 t = *(const egne_f32x4*)p;
+  return egne_fv<4>{{t[0], t[1], t[2], t[3]}};
+}
+__device__ __forceinline__ egne_fv<8> ldv(const egne_bf16* p) {
+  typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+  const u4_ w = *(const u4_*)p;
+  egne_fv<8> r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+    r.v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+  }
+  return r;
+}
+__device__ __forceinline__ void stv(float* p, const egne_fv<4>& a) { *(egne_f32x4*)p = egne_f32x4{a.v[0], a.v[1], a.v[2], a.v[3]}; }
+__device__ __forceinline__ void stv(egne_bf16* p, const egne_fv<8>& a) {
+  const egne_f32x4 lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+  const egne_bf16x4 l = __builtin_convertvector(lo, egne_bf16x4), h = __builtin_convertvector(hi, egne_bf16x4);
+  *(egne_bf16x8*)p = egne_bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+}
+template <int N> __device__ __forceinline__ egne_fv<N> ldf(const float* p) {      // N consecutive fp32 table entries
+  egne_fv<N> r;
+#pragma unroll
+  for (int i = 0; i < N; i += 4) { const egne_f32x4 t = *(const egne_f32x4*)(p + i); r.v[i] = t[0]; r.v[i + 1] = t[1]; r.v[i + 2] = t[2]; r.v[i + 3] = t[3]; }
+  return r;
+}
+template <int N> __device__ __forceinline__ egne_fv<N> fv_fill(float x) {
+  egne_fv<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = x;
+  return r;
+}
 // the all-zero page typed for either storage (invalid lanes load from it unconditionally)
 template <typename T> __device__ __forceinline__ const T* zero_page() { return (const T*)egne_zero_page; }
 

@@ -40,35 +40,38 @@ template <typename T>
 __global__ __launch_bounds__(256) void norm_stats_partial(const T* __restrict__ x, long long pix_stride,
                                                           int ch_off, int Cp, long long npix_per_n, int nchunk,
                                                           double* __restrict__ ws) {
+  constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;      // 16-byte vectors: 8 x 32 rows (fp32) or 4 x 64 rows (bf16)
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
-  const int v = threadIdx.x & 7, row = threadIdx.x >> 3;
-  const int c = cg * 32 + v * 4;
+  const int v = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int c = cg * 32 + v * N;
   const long long per = (npix_per_n + nchunk - 1) / nchunk;
   const long long p0 = (long long)chunk * per;
   const long long p1 = p0 + per < npix_per_n ? p0 + per : npix_per_n;
-  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  double s[N], q[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { s[e] = 0; q[e] = 0; }
   if (c < Cp) {
     const T* base = x + (long long)n * npix_per_n * pix_stride + ch_off + c;
-    for (long long p = p0 + row; p < p1; p += 128) {        // four rows per trip: loads issued together (same summation order)
-      f32x4 t[4];
+    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {        // four rows per trip: loads issued together (same summation order)
+      egne_fv<N> t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = p + 32 * u < p1 ? ld4(base + (p + 32 * u) * pix_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 4; ++u) t[u] = p + ROWS * u < p1 ? ldv(base + (p + ROWS * u) * pix_stride) : fv_fill<N>(0.f);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[e] += t[u][e]; q[e] += (double)t[u][e] * t[u][e]; }
+        for (int e = 0; e < N; ++e) { s[e] += t[u].v[e]; q[e] += (double)t[u].v[e] * t[u].v[e]; }
     }
   }
-  __shared__ double sh[32][8][8];
+  __shared__ double sh[ROWS][32][2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { sh[row][v][e] = s[e]; sh[row][v][4 + e] = q[e]; }
+  for (int e = 0; e < N; ++e) { sh[row][v * N + e][0] = s[e]; sh[row][v * N + e][1] = q[e]; }
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int vv = threadIdx.x >> 3, e = threadIdx.x & 7;  // e<4: sum of channel e, else sumsq
+    const int cc_ = threadIdx.x >> 1, w_ = threadIdx.x & 1;
     double a = 0;
-    for (int r = 0; r < 32; ++r) a += sh[r][vv][e];
-    const int cc = cg * 32 + vv * 4 + (e & 3);
-    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + (e >> 2)] = a;
+    for (int r = 0; r < ROWS; ++r) a += sh[r][cc_][w_];
+    const int cc = cg * 32 + cc_;
+    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + w_] = a;
   }
 }
 
@@ -161,26 +164,29 @@ template <typename T>
 __global__ void norm_act_pool2_k(const T* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
                                  const float* __restrict__ shift, int act, T* __restrict__ y, long long ys, int yo,
                                  int B, int H, int W, int Cp) {
-  const int Ho = H >> 1, Wo = W >> 1, nv = Cp >> 2;
+  constexpr int N = egne_vt<T>::N;
+  const int Ho = H >> 1, Wo = W >> 1, nv = Cp / N;
   const long long total = (long long)B * Ho * Wo * nv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % nv) * 4;
+    const int c = (int)(i % nv) * N;
     long long p = i / nv;
     const int ox = (int)(p % Wo); p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    const f32x4 sc = *(const f32x4*)(scale + (long long)b * Cp + c), sh = *(const f32x4*)(shift + (long long)b * Cp + c);
+    const egne_fv<N> sc = ldf<N>(scale + (long long)b * Cp + c), sh = ldf<N>(shift + (long long)b * Cp + c);
     const T* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * xs + xo + c;
-    f32x4 v[4] = {ld4(s), ld4(s + xs), ld4(s + (long long)W * xs), ld4(s + (long long)W * xs + xs)};
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    const egne_fv<N> v[4] = {ldv(s), ldv(s + xs), ldv(s + (long long)W * xs), ldv(s + (long long)W * xs + xs)};
+    egne_fv<N> r = fv_fill<N>(0.f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      f32x4 t = v[k] * sc + sh;
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = act == EGNE_ACT_LEAKY ? (t[e] > 0.f ? t[e] : 0.01f * t[e]) : (act == EGNE_ACT_RELU ? fmaxf(t[e], 0.f) : t[e]);
-      r += t;
-    }
-    st4(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, r * 0.25f);
+      for (int e = 0; e < N; ++e) {
+        const float t = v[k].v[e] * sc.v[e] + sh.v[e];
+        r.v[e] += act == EGNE_ACT_LEAKY ? (t > 0.f ? t : 0.01f * t) : (act == EGNE_ACT_RELU ? fmaxf(t, 0.f) : t);
+      }
+#pragma unroll
+    for (int e = 0; e < N; ++e) r.v[e] *= 0.25f;
+    stv(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, r);
   }
 }
 
@@ -310,6 +316,10 @@ inline int grid_for(long long total, int block = 256) {
   return (int)g;
 }
 
+template <typename T> inline bool vec_ok(long long stride, int off, int Cp) {     // 16-byte vectors of T
+  constexpr int N = egne_vt<T>::N;
+  return stride % N == 0 && off % N == 0 && Cp % N == 0;
+}
 inline bool slice_ok(const void* p, long long stride, int off, int Cp) {     // (4-element vectors: 16 bytes of fp32, 8 of bf16)
   return p && ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && off % 4 == 0 && Cp > 0 && Cp % 4 == 0 && off + Cp <= stride;
 }
@@ -343,7 +353,7 @@ extern "C" int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int pe
 template <typename T>
 static int norm_stats_impl(const T* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW, int per_sample,
                            float eps, float* scale, float* shift, float* mean_out, float* var_out, void* ws, void* stream) {
-  EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp), "norm_stats: bad slice (stride %lld off %d Cp %d)", (long long)pix_stride, ch_off, Cp);
+  EGNE_REQUIRE(slice_ok(x, pix_stride, ch_off, Cp) && vec_ok<T>(pix_stride, ch_off, Cp), "norm_stats: bad slice (stride %lld off %d Cp %d)", (long long)pix_stride, ch_off, Cp);
   EGNE_REQUIRE(B > 0 && HW > 0 && scale && shift && ws, "norm_stats: bad arguments");
   const int Bn = per_sample ? B : 1;
   const long long npix = per_sample ? HW : (long long)B * HW;
@@ -416,8 +426,9 @@ template <typename T>
 static int norm_act_pool2_impl(const T* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
                                T* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp) && scale && shift, "norm_act_pool2: bad slices");
+  EGNE_REQUIRE(vec_ok<T>(xs, xo, Cp) && vec_ok<T>(ys, yo, Cp), "norm_act_pool2: slices must be 16-byte vectors (8 bf16 channels)");
   EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2, "norm_act_pool2: bad shape");
-  hipLaunchKernelGGL(norm_act_pool2_k<T>, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / 4))), dim3(256), 0,
+  hipLaunchKernelGGL(norm_act_pool2_k<T>, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (Cp / egne_vt<T>::N))), dim3(256), 0,
                      (hipStream_t)stream, x, (long long)xs, xo, scale, shift, act, y, (long long)ys, yo, B, H, W, Cp);
   return egne::check_launch("egne_norm_act_pool2");
 }

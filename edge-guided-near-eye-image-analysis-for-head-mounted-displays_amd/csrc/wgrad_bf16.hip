@@ -1,13 +1,214 @@
-// Weight gradient of the 3x3 "same" convolutions over one bf16 slice (training plans with bf16 activation storage).
+// Weight gradient of the 3x3 "same" convolutions over one bf16 slice on v_mfma_f32_32x32x16_bf16 (training plans with bf16
+// activation storage; backward of models/RITnet_v2.py:57-62,85-87 and utils.py:1047-1048 under train.py:285-286):
+//
+//   dW[tap][co][ci] = sum over pixels  gz[n, y, x, co] * xin[n, y + dy, x + dx, ci]
+//
+// A workgroup owns one (32 co, 32 ci) block for ALL nine taps and walks 8 x 32 pixel tiles (every nsplit-th one): the gz tile
+// [256 px][32 co] and the x halo [340 px][32 ci] are staged once per tile as plain 64-byte pixel rows of bf16, and both MFMA
+// operands -- "eight consecutive PIXELS of one channel" -- come out of those images with ds_read_b64_tr_b16 (the 4 x 16
+// transposing LDS read of gfx950: conflict-free on 64-byte rows), so a tap is nothing but an address offset into the halo.
+// Wave w of eight contracts tile row w: 2 k-steps x 9 taps = 18 MFMAs per tile into 9 x 16 accumulator registers (with four waves
+// of two rows each the 144 accumulators + 40 staging registers spilled).
+// The layer is HBM-bound by a factor of ~6 (1.26 GB per 240x320x32 layer and 64 frames against 0.18 TFLOP), so the loop is a plain
+// "load tile t+1 into registers, contract tile t, swap" with two barriers per tile.
+// The optional per-(n, c) affine + activation of the forward launch (InstanceNorm fused on load) is applied while staging x.
+// Partials: ws[split][tap][CoutP][Ktot] fp32, every element written (the caller reduces them into the OIHW gradient).
 #include "common.h"
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TW = 32, TH = 8, HWd = TW + 2, HHd = TH + 2, NPX = HHd * HWd;      // 340 halo pixels
+constexpr int GPX = TW * TH;                                                      // 256 gz pixels
+constexpr int NT = 512;                                                           // threads: eight waves, one tile row each
+constexpr int NG = GPX * 4 / NT, NX = (NPX * 4 + NT - 1) / NT;                   // 16-byte items per thread: 2 + 3
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) egne_bf16x4* lds_bf4_ptr;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 unpack4(unsigned a, unsigned b) {
+  const u32x4 w = {a << 16, a & 0xffff0000u, b << 16, b & 0xffff0000u};
+  return __builtin_bit_cast(f32x4, w);
+}
+
+__global__ __launch_bounds__(NT)
+void wgrad3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ gz, long long gzs, int gzo, int nsplit, int nco,
+                          int tiles_x, int tiles_y, int ntiles, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) egne_bf16 lds[(GPX + NPX) * 32];        // 37.25 KB; reused for the final cross-wave sum
+  egne_bf16* const Gi = lds;
+  egne_bf16* const Xi = lds + GPX * 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W;
+  const egne_seg sg = p.seg[0];
+  const egne_bf16* const xin = (const egne_bf16*)sg.ptr;
+  const int cb = blockIdx.y % nco, kb = blockIdx.y / nco;
+  const int co0 = cb * 32, ci0 = kb * 32;
+  const int piece = tid & 3;                              // this thread's 8-channel group of a staged pixel (item = tid + 256 I: same piece)
+  const bool gch_ok = co0 + piece * 8 < p.Cout_store, xch_ok = ci0 + piece * 8 < sg.Cp;
+  const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const unsigned frame_g = (unsigned)H * W * (unsigned)gzs * 2u, frame_x = (unsigned)H * W * (unsigned)sg.pix_stride * 2u;
+
+  struct Tile { int b, y0, x0; };
+  auto decode = [&](int t) {
+    Tile r;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    r.b = t; r.y0 = ty * TH; r.x0 = tx * TW;
+    return r;
+  };
+  u32x4 rg[NG], rx[NX];
+  f32x4 asc[2] = {(f32x4)(1.f), (f32x4)(1.f)}, ash[2] = {(f32x4)(0.f), (f32x4)(0.f)};
+  auto issue = [&](int t) {
+    const Tile tl = decode(t);
+    const __amdgpu_buffer_rsrc_t rgz = make_rsrc(gz + (long long)tl.b * H * W * gzs, frame_g);
+    const __amdgpu_buffer_rsrc_t rxi = make_rsrc(xin + (long long)tl.b * H * W * sg.pix_stride, frame_x);
+#pragma unroll
+    for (int I = 0; I < NG; ++I) {
+      const int px = (tid >> 2) + (NT / 4) * I, ty = px >> 5, tx = px & 31;
+      const int y = tl.y0 + ty, x = tl.x0 + tx;
+      const bool ok = gch_ok && y < H && x < W;
+      rg[I] = __builtin_amdgcn_raw_buffer_load_b128(rgz, ok ? (int)(((long long)(y * W + x) * gzs + gzo + co0 + piece * 8) * 2) : (int)OOB, 0, 0);
+    }
+#pragma unroll
+    for (int I = 0; I < NX; ++I) {
+      const int q = (tid >> 2) + (NT / 4) * I, hy = q / HWd, hx = q - hy * HWd;
+      const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
+      const bool ok = xch_ok && q < NPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      rx[I] = __builtin_amdgcn_raw_buffer_load_b128(rxi, ok ? (int)(((long long)(y * W + x) * sg.pix_stride + sg.ch_off + ci0 + piece * 8) * 2) : (int)OOB, 0, 0);
+    }
+    if (sg.scale) {
+      const int c = ci0 + piece * 8;
+      const float* zs = xch_ok ? sg.scale + (long long)tl.b * sg.Cp + c : egne_zero_page;
+      const float* zh = xch_ok ? sg.shift + (long long)tl.b * sg.Cp + c : egne_zero_page;
+      asc[0] = *(const f32x4*)zs; asc[1] = *(const f32x4*)(zs + 4);
+      ash[0] = *(const f32x4*)zh; ash[1] = *(const f32x4*)(zh + 4);
+    }
+  };
+  auto stage = [&](int t) {       // registers -> LDS (plain [pixel][32] rows); the fused affine of the forward launch applied to x
+    const Tile tl = decode(t);
+#pragma unroll
+    for (int I = 0; I < NG; ++I) *(u32x4*)&Gi[((tid >> 2) + (NT / 4) * I) * 32 + piece * 8] = rg[I];
+#pragma unroll
+    for (int I = 0; I < NX; ++I) {
+      const int q = (tid >> 2) + (NT / 4) * I;
+      if (I < NX - 1 || q < NPX) {
+        u32x4 raw = rx[I];
+        if (sg.scale) {
+          const int hy = q / HWd, hx = q - hy * HWd;
+          const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
+          f32x4 v0 = unpack4(raw[0], raw[1]), v1 = unpack4(raw[2], raw[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t0 = v0[e] * asc[0][e] + ash[0][e], t1 = v1[e] * asc[1][e] + ash[1][e];
+            v0[e] = fmaxf(t0, t0 * slope_in); v1[e] = fmaxf(t1, t1 * slope_in);
+          }
+          if (!(xch_ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) { v0 = (f32x4)(0.f); v1 = (f32x4)(0.f); }
+          const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(v0, egne_bf16x4));
+          const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(v1, egne_bf16x4));
+          raw = u32x4{p0[0], p0[1], p1[0], p1[1]};
+        }
+        *(u32x4*)&Xi[q * 32 + piece * 8] = raw;
+      }
+    }
+  };
+
+  // transposing-read address of this lane: 16-lane group g = lane >> 4 takes channels 16 (g & 1) .. + 15 and the pixel octet
+  // h = g >> 1 of a 16-pixel k-step; lane 4 q + p of the group supplies pixel q, channels 4 p .. 4 p + 3 (cdna guide, T10)
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int lbase = ((8 * (g16 >> 1) + (i16 >> 2)) * 32 + 16 * (g16 & 1) + 4 * (i16 & 3));      // elements
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16)(0.f);
+
+  int t = blockIdx.x;
+  if (t < ntiles) issue(t);
+  for (; t < ntiles; t += nsplit) {
+    __syncthreads();                 // every wave is done with the previous tile's images
+    stage(t);
+    __syncthreads();
+    if (t + nsplit < ntiles) issue(t + nsplit);       // next tile's loads fly during this tile's MFMAs
+    {
+      const int ty = wave;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const egne_bf16* ga = Gi + lbase + (ty * 32 + 16 * s) * 32;
+        const egne_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)ga);
+        const egne_bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(ga + 4 * 32));
+        const egne_bf16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+          const egne_bf16* xa = Xi + lbase + ((ty + 1 + dy) * HWd + 16 * s + 1 + dx) * 32;
+          const egne_bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)xa);
+          const egne_bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(xa + 4 * 32));
+          const egne_bf16x8 bq = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[tap], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // cross-wave sum through LDS, one tap at a time (32 KB), then the workgroup's 32 x 32 block of every tap goes to its partial:
+  // lane holds column k = lane & 31 of rows co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* const red = (float*)lds;        // [8 waves][16][64]
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tap][r];
+    __syncthreads();
+    float* dst = ws + ((long long)blockIdx.x * 9 + tap) * (long long)p.CoutP * p.Ktot;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + NT * j, r = e >> 6, l2 = e & 63;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 16 + r) * 64 + l2];
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5), k = ci0 + (l2 & 31);
+      if (k < p.Ktot && co < p.CoutP) dst[(long long)co * p.Ktot + k] = v;
+    }
+  }
+}
+
+}  // namespace
 
 namespace egne {
 
-bool wgrad3x3_bf16_supported(const egne_conv_desc& d, long long gzs) { (void)d; (void)gzs; return false; }
-int wgrad3x3_bf16_splits(const egne_conv_desc& d) { (void)d; return 1; }
+bool wgrad3x3_bf16_supported(const egne_conv_desc& d, long long gzs) {
+  static const bool off = [] { const char* e = getenv("EGNE_WGRAD_BF16"); return e && e[0] == '0'; }();
+  if (off || d.dtype != 1) return false;
+  if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad_h != 1 || d.pad_w != 1 || d.pad_mode != 0 || d.ngroups != 1 || d.nseg != 1 ||
+      d.dil[0] != 1 || d.H != d.Ho || d.W != d.Wo) return false;
+  const egne_seg& g = d.seg[0];
+  if (!g.ptr || g.Cp % 8 || g.ch_off % 8 || g.pix_stride % 8 || ((uintptr_t)g.ptr & 15) || gzs % 8 || d.out_ch_off % 8 || d.Cout_store % 8) return false;
+  if ((long long)d.H * d.W * g.pix_stride * 2 >= (1ll << 31) || (long long)d.H * d.W * gzs * 2 >= (1ll << 31)) return false;
+  if (d.Ktot != g.Cp || d.CoutP % 32 || d.W < 16) return false;
+  return true;
+}
+
+static int npairs_of(const egne_conv_desc& d) { return (d.CoutP / 32) * ((d.Ktot + 31) / 32); }
+
+int wgrad3x3_bf16_splits(const egne_conv_desc& d) {
+  const long long tiles = (long long)((d.W + TW - 1) / TW) * ((d.H + TH - 1) / TH) * d.B;
+  long long ns = 256 / npairs_of(d);          // one 8-wave workgroup per CU
+  if (ns < 1) ns = 1;
+  if (ns > tiles) ns = tiles;
+  return (int)ns;
+}
+
 int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st) {
-  (void)d; (void)gz; (void)gzs; (void)gzo; (void)ws; (void)st;
-  return fail(EGNE_ERR_ARG, "wgrad3x3_bf16: not supported");
+  if (gzo % 8 || ((uintptr_t)gz & 15)) return fail(EGNE_ERR_ARG, "wgrad3x3_bf16: gz slice must start on a multiple of 8 channels (offset %d)", gzo);
+  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH, ntiles = tiles_x * tiles_y * d.B;
+  const int nsplit = wgrad3x3_bf16_splits(d), nco = d.CoutP / 32;
+  hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(nsplit, npairs_of(d)), dim3(NT), 0, st, d, gz, gzs, gzo, nsplit, nco, tiles_x, tiles_y, ntiles, ws);
+  return check_launch("egne_conv2d_wgrad (3x3, bf16)");
 }
 
 }  // namespace egne
