@@ -328,11 +328,12 @@ inline bool slice_ok(const void* p, long long stride, int off, int Cp) {     // 
 
 static int norm_nchunk(int Bn, long long npix, int Cp) {
   const int cgroups = (Cp + 31) / 32;
-  long long want = 2048 / ((long long)Bn * cgroups);
+  // ~4096 workgroups of four waves: sixteen per CU (256 chunks of a 32-channel tensor = one workgroup per CU ran at 2.7 TB/s)
+  long long want = 4096 / ((long long)Bn * cgroups);
   if (want < 1) want = 1;
-  long long maxchunk = npix / 64 > 0 ? npix / 64 : 1;
+  long long maxchunk = npix / 256 > 0 ? npix / 256 : 1;
   long long n = want < maxchunk ? want : maxchunk;
-  return (int)(n > 256 ? 256 : n);
+  return (int)(n > 1024 ? 1024 : n);
 }
 
 extern "C" int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, void* out_bits, void* stream) {

@@ -65,6 +65,7 @@ HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 maps: 253 -> 194 us for 120 -> 128 channels against the flat kernel)
 HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
+BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
 BF16_FAST3X3 = os.environ.get("EGNE_BF16_FAST3X3", "1") != "0"     # bf16-storage plans: 3x3 convolutions and their data gradients on bf16 MFMAs (0: exact-fp32 implicit GEMM)
 
 
@@ -171,7 +172,8 @@ class ConvLayer:
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
                 and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big)
                 and (self.m1hi is not None or not self.need_m1) and (self.c4hi is not None or not self.need_c4h)
-                and (self.bfrag is not None or not self.need_bfrag))
+                and (self.bfrag is not None or not self.need_bfrag)
+                and (getattr(self, "b1frag", None) is not None or not getattr(self, "need_b1", False)))
         if self.bp is not None and have and vers == self._versions and self.bp.device == dev:
             return False
         L = _lib.lib()
@@ -267,6 +269,8 @@ class ConvLayer:
                 self.wimg = torch.empty(self.big_coutp * kts * T * 2, dtype=torch.float16, device=dev)
             _lib.check(L.egne_pack_conv_weight_f16img(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, bn, kts, self.w_scale_big,
                                                       self.wimg.data_ptr(), st), "pack_f16img")
+        if getattr(self, "need_b1", False):
+            _pack_b1(self, dev, st)
         if self.need_bfrag:
             # weights rounded to bf16 in MFMA-fragment order (fp32 master weights stay in the Parameter)
             wd = self.weights[0].detach().contiguous()
@@ -321,6 +325,26 @@ class ConvLayer:
         ho = (H + 2 * self.pad[0] * d - d * (self.kh - 1) - 1) // self.stride + 1
         wo = (W + 2 * self.pad[1] * d - d * (self.kw - 1) - 1) // self.stride + 1
         return ho, wo
+
+
+def _pack_b1(layer, dev, st):
+    """bf16 fragments of a 1x1 layer for the streaming bf16 kernel (conv1x1_bf16.hip), derived from the layer's fp32 flat pack
+    ``wp`` [CoutP][Ktot] (forward weights or a data-gradient pack alike); every slice padded to whole 16-channel k-steps."""
+    L = _lib.lib()
+    d = _lib.ConvDesc()
+    d.nseg, d.CoutP, d.Ktot = len(layer.in_layout), layer.CoutP, layer.Ktot
+    for i, (_, cp) in enumerate(layer.in_layout):
+        d.seg[i].Cp = cp
+    if getattr(layer, "b1frag", None) is None:
+        n = int(L.egne_conv1x1_bf16_pack_elems(C.byref(d)))
+        assert n > 0, "too many k-steps for the streaming 1x1 kernel"
+        layer.b1frag = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        kofs, o = [], 0
+        for _, cp in layer.in_layout:
+            kofs.append(o)
+            o += cp
+        layer.b1info = torch.tensor(kofs + [cp for _, cp in layer.in_layout], dtype=torch.int32, device=dev)
+    _lib.check(L.egne_pack_conv1x1_bf16(C.byref(d), layer.wp.data_ptr(), layer.b1info.data_ptr(), layer.b1frag.data_ptr(), st), "pack_conv1x1_bf16")
 
 
 class PlanarPiece(Piece):
@@ -383,7 +407,8 @@ class DgradLayer(ConvLayer):
     def ensure_packed(self, dev):
         w = self.weights[0]
         vers = (w._version, w.data_ptr())
-        have = (self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+        have = ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
+                and (getattr(self, "b1frag", None) is not None or not getattr(self, "need_b1", False)))
         if have and vers == self._versions:
             return False
         L = _lib.lib()
@@ -400,6 +425,8 @@ class DgradLayer(ConvLayer):
                 self.wf = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(L.egne_pack_conv_weight_dgrad(wd.data_ptr(), self.fwd.Cout, self.fwd.Cin, self.kh, self.kw, self.ci0,
                                                      self.Cout, self.CoutP, self.Ktot, 1, self.wf.data_ptr(), st), "pack_dgrad")
+        if getattr(self, "need_b1", False):
+            _pack_b1(self, dev, st)
         self._versions = vers
         return True
 
@@ -936,6 +963,17 @@ class Plan:
                  and layer.CoutP <= 256 and min(layer.Cout_store, dst.Cp) % 4 == 0 and min(layer.Cout_store, dst.Cp) >= 8
                  and H * W * max(pieces[0].stride, dst.stride) < 2 ** 30
                  and (residual is None or H * W * residual.stride < 2 ** 30))
+        # 1x1 over raw slices: streaming bf16-MFMA kernel (conv1x1_bf16.hip); its weights must fit LDS (k-steps x blocks x 1 KB)
+        fast1 = (BF16_FAST1X1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1 and layer.pad == (0, 0) and layer.post is None
+                 and all(p.scale is None and p.Cp % 8 == 0 and p.off % 8 == 0 and p.stride % 8 == 0 for p in pieces)
+                 and B * H * W >= 4096 and min(layer.Cout_store, dst.Cp) % 8 == 0 and dst.off % 8 == 0 and dst.stride % 8 == 0
+                 and (residual is None or (residual.off % 8 == 0 and residual.stride % 8 == 0)))
+        if fast1:
+            dq = _lib.ConvDesc()
+            dq.nseg, dq.CoutP, dq.Ktot = len(pieces), layer.CoutP, layer.Ktot
+            for i, p in enumerate(pieces):
+                dq.seg[i].Cp = p.Cp
+            fast1 = int(self.L.egne_conv1x1_bf16_pack_elems(C.byref(dq))) > 0
         if smallcin:
             layer.need_c4 = True
             layer.need_flat = True
@@ -943,6 +981,9 @@ class Plan:
             layer.need_bfrag = True
             if self.train:
                 layer.need_flat = True       # kinv / the generic pack index the weight-gradient paths
+        elif fast1:
+            layer.need_flat = True
+            layer.need_b1 = True
         else:
             layer.need_flat = True
         if layer not in self.layers:
@@ -981,6 +1022,8 @@ class Plan:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif fast3:
             self._add(self.L.egne_conv3x3_bf16_fwd, (C.byref(d), layer.bfrag.data_ptr()), name, flops=flops, kind="conv_bf16:3x3")
+        elif fast1:
+            self._add(self.L.egne_conv1x1_bf16_fwd, (C.byref(d), layer.b1frag.data_ptr()), name, flops=flops, kind="conv_bf16:1x1")
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
         if stats:

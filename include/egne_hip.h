@@ -580,6 +580,19 @@ int egne_pack_conv_weight_bf16frag(const float* w_oihw, int Cout, int Cin, int k
                                    void* stream);
 int egne_conv3x3_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
+/*
+ * 1x1 convolution over up to EGNE_MAXSEG RAW bf16 slices on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, bf16 output): conv21 / conv31
+ * of the dense blocks, Transition_down behind its pooling, conv11 / conv21 of the up blocks (models/RITnet_v2.py:38-41,59-61,85-86)
+ * and their merged data gradients in training plans with bf16 storage (dtype 1).  Streaming: a lane's operand of a 16-channel
+ * k-step is one 16-byte load of 8 channels of its pixel, the weights (bf16 fragments [k-step][CoutP/32][lane][8], every slice
+ * padded to whole k-steps; egne_pack_conv1x1_bf16 builds them from the fp32 pack [CoutP][Ktot] of the same descriptor) stay in
+ * LDS.  Bias, activation and an accumulated bf16 residual as for egne_conv2d_fwd; no fused affine, no post affine.
+ * egne_conv1x1_bf16_pack_elems: bf16 elements of the fragment pack (-1: too many k-steps).
+ */
+int64_t egne_conv1x1_bf16_pack_elems(const egne_conv_desc* d);
+int egne_pack_conv1x1_bf16(const egne_conv_desc* d, const float* wflat, const int32_t* seginfo, void* wfrag, void* stream);
+int egne_conv1x1_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
+
 const char* egne_last_error(void);
 int egne_version(void);
 int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc */
