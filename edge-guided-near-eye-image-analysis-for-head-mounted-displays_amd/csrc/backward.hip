@@ -973,6 +973,7 @@ extern "C" int egne_conv2d_wgrad_splits(const egne_conv_desc* dp) {
   if (!dp) return 0;
   const egne_conv_desc& d = *dp;
   if (d.dtype == 1 && egne::wgrad3x3_bf16_supported(d, d.out_pix_stride)) return egne::wgrad3x3_bf16_splits(d);
+  if (d.dtype == 1 && egne::wgrad1x1_bf16_supported(d, d.out_pix_stride)) return egne::wgrad1x1_bf16_splits(d);
   if (d.dtype == 0 && egne::wgrad_halo_supported(d, d.out_pix_stride)) return egne::wgrad_halo_splits(d);
   { int a, b2, ch; if (w1_supported(d, &a, &b2, &ch)) return w1_splits(d, ch); }
   int per_tap = 0;
@@ -1019,6 +1020,11 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
       // the gradient buffer mirrors the output buffer (same pixel stride): the split count above assumed it
       EGNE_REQUIRE(gzs == d.out_pix_stride, "wgrad: gz stride %lld differs from the output stride %lld", (long long)gzs, (long long)d.out_pix_stride);
       const int rc = egne::wgrad3x3_bf16_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);     // writes every partial it owns
+      if (rc != EGNE_OK) return rc;
+      fast3x3 = true;
+    } else if (egne::wgrad1x1_bf16_supported(d, d.out_pix_stride)) {     // 1x1 over raw slices: every block pair in one workgroup, bf16 MFMA
+      EGNE_REQUIRE(gzs == d.out_pix_stride, "wgrad: gz stride %lld differs from the output stride %lld", (long long)gzs, (long long)d.out_pix_stride);
+      const int rc = egne::wgrad1x1_bf16_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);
       if (rc != EGNE_OK) return rc;
       fast3x3 = true;
     }

@@ -101,6 +101,9 @@ int wgrad_halo_f16_launch(const egne_conv_desc& d, const float* gz, long long gz
 bool wgrad3x3_bf16_supported(const egne_conv_desc& d, long long gzs);   // wgrad_bf16.hip (bf16 tensors, bf16 MFMA)
 int wgrad3x3_bf16_splits(const egne_conv_desc& d);
 int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st);
+bool wgrad1x1_bf16_supported(const egne_conv_desc& d, long long gzs);   // 1x1 over raw bf16 slices, all block pairs in one workgroup
+int wgrad1x1_bf16_splits(const egne_conv_desc& d);
+int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st);
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -177,6 +177,104 @@ void wgrad3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 weight gradient over raw bf16 slices with every (32 co, 32 k) block pair of the layer in ONE workgroup (the bf16
+// form of conv1x1_wgrad_allpairs_kernel, backward.hip): a workgroup walks its pixel range in chunks of 64 pixels, stages all gz
+// tiles and all x tiles of the chunk once as [64 px][32 ch] bf16 rows (16-byte loads, 4 neighbouring lanes = the 64 contiguous
+// bytes of a pixel's block), and its eight waves share the pairs: wave w owns pairs w, w + 8, ... for ALL pixels -- no cross-wave
+// reduction, every HBM byte read once.  Operands by ds_read_b64_tr_b16 as above.  Partials: ws[split][CoutP][Ktot].
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int W1_MAXT = 16;      // tiles (gz + x) of a chunk
+constexpr int W1_CH = 64;        // pixels per chunk
+struct W1Tab { short seg[W1_MAXT]; short c0[W1_MAXT]; short kofs[W1_MAXT]; };
+
+template <int PPW>
+__global__ __launch_bounds__(512)
+void wgrad1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ gz, long long gzs, int gzo, int nsplit, int nco, int nkc,
+                          W1Tab tab, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) egne_bf16 w1lds[];     // [nco + nkc][64 px][32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = nco + nkc, npairs = nco * nkc;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long per = ((M + nsplit - 1) / nsplit + W1_CH - 1) / W1_CH * W1_CH;
+  const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
+  const int piece = tid & 3, px = (tid & 255) >> 2, jh = tid >> 8;      // item I of a thread: tile 2 I + jh, pixel px, 8-channel group piece
+  u32x4 rv[W1_MAXT / 2];
+  auto issue = [&](long long mc) {
+    const int rows = (int)(m_end - mc < W1_CH ? m_end - mc : W1_CH);
+#pragma unroll
+    for (int I = 0; I < W1_MAXT / 2; ++I) {
+      const int j = 2 * I + jh;
+      if (2 * I < nt) {                 // (uniform; the odd tile of the last pair may not exist: its lanes read nothing)
+        const bool isg = j < nco, on = j < nt;
+        const egne_seg& sg = p.seg[(isg || !on) ? 0 : tab.seg[j]];
+        const int c = (isg ? 32 * j : (on ? tab.c0[j] : 0)) + 8 * piece;
+        const bool cok = on && (isg ? c < p.Cout_store : c < sg.Cp);
+        const long long stride = isg ? gzs : sg.pix_stride;
+        const egne_bf16* base = (isg ? gz : (const egne_bf16*)sg.ptr) + mc * stride;
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, (unsigned)rows * (unsigned)stride * 2u);       // pixels past the range read zeros
+        const int off = cok ? (int)((px * stride + (isg ? gzo : sg.ch_off) + c) * 2) : (int)OOB;
+        rv[I] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      }
+    }
+  };
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int lbase = ((8 * (g16 >> 1) + (i16 >> 2)) * 32 + 16 * (g16 & 1) + 4 * (i16 & 3));      // elements (transposing read, see above)
+  f32x16 acc[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) acc[i] = (f32x16)(0.f);
+  if (m_begin < m_end) issue(m_begin);
+  for (long long mc = m_begin; mc < m_end; mc += W1_CH) {
+    __syncthreads();                 // every wave is done with the previous chunk's tiles
+#pragma unroll
+    for (int I = 0; I < W1_MAXT / 2; ++I) {
+      const int j = 2 * I + jh;
+      if (j < nt) *(u32x4*)&w1lds[(j * W1_CH + px) * 32 + piece * 8] = rv[I];
+    }
+    __syncthreads();
+    if (mc + W1_CH < m_end) issue(mc + W1_CH);       // next chunk's loads fly during this chunk's MFMAs
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = wave + 8 * i;
+      if (q < npairs) {               // (wave-uniform: the transposing reads below run with all lanes enabled)
+        const int kc = q / nco, ct = q - kc * nco;
+        const egne_bf16* As = w1lds + (ct * W1_CH) * 32 + lbase;
+        const egne_bf16* Bs = w1lds + ((nco + kc) * W1_CH) * 32 + lbase;
+#pragma unroll
+        for (int s = 0; s < W1_CH / 16; ++s) {
+          const egne_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(As + 16 * s * 32));
+          const egne_bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(As + (16 * s + 4) * 32));
+          const egne_bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(Bs + 16 * s * 32));
+          const egne_bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(Bs + (16 * s + 4) * 32));
+          const egne_bf16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          const egne_bf16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // lane holds column k = lane & 31 of rows co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of its pairs' blocks
+  float* dst = ws + (long long)blockIdx.x * (long long)p.CoutP * p.Ktot;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int q = wave + 8 * i;
+    if (q < npairs) {
+      const int kc = q / nco, ct = q - kc * nco;
+      const int j = nco + kc;
+      const int k = tab.c0[j] + (lane & 31);
+      if (k < p.seg[tab.seg[j]].Cp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          dst[(long long)co * p.Ktot + tab.kofs[j] + k] = acc[i][r];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace egne {
@@ -201,6 +299,52 @@ int wgrad3x3_bf16_splits(const egne_conv_desc& d) {
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   return (int)ns;
+}
+
+bool wgrad1x1_bf16_supported(const egne_conv_desc& d, long long gzs) {
+  static const bool off = [] { const char* e = getenv("EGNE_WGRAD_BF16"); return e && e[0] == '0'; }();
+  if (off || d.dtype != 1) return false;
+  if (d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad_h != 0 || d.pad_w != 0 || d.ngroups != 1 || d.H != d.Ho || d.W != d.Wo) return false;
+  int nkc = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    if (!g.ptr || g.scale || g.act_in != EGNE_ACT_NONE || g.Cp % 8 || g.ch_off % 8 || g.pix_stride % 8 || ((uintptr_t)g.ptr & 15) ||
+        g.pix_stride * W1_CH * 2 >= (1ll << 31)) return false;
+    nkc += (g.Cp + 31) / 32;
+  }
+  const int nco = d.CoutP / 32;
+  if (gzs % 8 || d.out_ch_off % 8 || d.Cout_store % 8 || gzs * W1_CH * 2 >= (1ll << 31)) return false;
+  if (nco + nkc > W1_MAXT || nco * nkc > 32 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
+  return true;
+}
+
+int wgrad1x1_bf16_splits(const egne_conv_desc& d) {
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  long long ns = (M + W1_CH * 4 - 1) / (W1_CH * 4);      // at least four chunks per workgroup
+  if (ns > 512) ns = 512;
+  return (int)(ns < 1 ? 1 : ns);
+}
+
+int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st) {
+  if (gzo % 8 || ((uintptr_t)gz & 15)) return fail(EGNE_ERR_ARG, "wgrad1x1_bf16: gz slice must start on a multiple of 8 channels (offset %d)", gzo);
+  const int nco = d.CoutP / 32, nsplit = wgrad1x1_bf16_splits(d);
+  W1Tab tab{};
+  int j = nco, kofs = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    for (int c0 = 0; c0 < d.seg[s].Cp; c0 += 32, ++j) { tab.seg[j] = (short)s; tab.c0[j] = (short)c0; tab.kofs[j] = (short)kofs; }
+    kofs += d.seg[s].Cp;
+  }
+  const int nkc = j - nco, ppw = (nco * nkc + 7) / 8;
+  const size_t bytes = (size_t)nsplit * d.CoutP * d.Ktot * sizeof(float);
+  if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: memset failed");     // channels beyond a slice's blocks
+  const size_t lds = (size_t)(nco + nkc) * W1_CH * 32 * sizeof(egne_bf16);
+  auto go = [&](auto kern) -> int {
+    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
+    if (!raised) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(kern, dim3(nsplit), dim3(512), lds, st, d, gz, gzs, gzo, nsplit, nco, nkc, tab, ws);
+    return check_launch("egne_conv2d_wgrad (1x1, bf16)");
+  };
+  return ppw <= 1 ? go(wgrad1x1_bf16_kernel<1>) : ppw <= 2 ? go(wgrad1x1_bf16_kernel<2>) : ppw <= 3 ? go(wgrad1x1_bf16_kernel<3>) : go(wgrad1x1_bf16_kernel<4>);
 }
 
 int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st) {

@@ -186,12 +186,23 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     pools = [2, 2, 2, 2, 0]
     res = [(H >> i, W >> i) for i in range(5)]
 
+    def slices(nb, h, w, chans):
+        """Pieces for the members of a would-be torch.cat.  fp32 plans: channel slices of ONE buffer (a 32-channel slice is 128
+        contiguous bytes per pixel: a whole cache line).  bf16 plans: a buffer per member -- the memory system fetches 128-byte
+        lines, so a 64-byte slice of a wider pixel row streams at half rate (measured: 2.55 vs 5.04 TB/s, scratch/bf16_stride.py),
+        while a tensor of its own is contiguous from pixel to pixel."""
+        if pl.bf16:
+            return [Piece(pl.buf(nb, h, w, pad8(c)), 0, c) for c in chans]
+        b, out, off = pl.buf(nb, h, w, sum(pad8(c) for c in chans)), [], 0
+        for c in chans:
+            out.append(Piece(b, off, c))
+            off += pad8(c)
+        return out
+
     def dbuf(i):
         h, w = res[i]
-        it, ic = pad8(inters[i]), pad8(ins[i])
-        b = pl.buf(NB, h, w, it + ic + 2 * it)
-        return dict(out=Piece(b, 0, inters[i]), x=Piece(b, it, ins[i]), x1=Piece(b, it + ic, inters[i]),
-                    x22=Piece(b, it + ic + it, inters[i]))
+        o, x, x1, x22 = slices(NB, h, w, [inters[i], ins[i], inters[i], inters[i]])
+        return dict(out=o, x=x, x1=x1, x22=x22)
     D = [dbuf(i) for i in range(5)]
 
     t0 = pl.buf(NB, H, W, pad8(chz))
@@ -248,8 +259,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
             # pool first, then the 1x1 conv at quarter resolution (linear ops commute; avg_pool2d drops an odd last row / column
             # on both routes).  Training plans too: the 1x1, its weight and data gradients all run on a quarter of the pixels, and
             # the InstanceNorm backward takes a quarter of the pooled cell's gradient (egne_norm_pool2_bwd)
-            pb_ = pl.buf(NB, h // 2, w // 2, d["out"].Cp + d["x"].Cp)
-            q_out, q_x = Piece(pb_, 0, d["out"].C, d["out"].Cp), Piece(pb_, d["out"].Cp, d["x"].C, d["x"].Cp)
+            q_out, q_x = slices(NB, h // 2, w // 2, [d["out"].C, d["x"].C])
             for src, dstp, (a_, b_) in ((d["out"], q_out, (sc2, sh2)), (d["x"], q_x, (sc, sh))):
                 pl.raw(L.egne_norm_act_pool2, (src.ptr, src.stride, src.off, a_.data_ptr(), b_.data_ptr(), ACT_LEAKY,
                                                dstp.ptr, dstp.stride, dstp.off, NB, h, w, src.Cp), nm + ".TDpool")
@@ -335,14 +345,9 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
             pl.conv_pair(l11s, skip, l12, x1, B, h, w, name=nm + ".conv1", up_add=(P1, ph, pw))
             pl.conv_pair(l21s, skip + [x1], l22, Piece(y, 0, oc), B, h, w, name=nm + ".conv2", up_add=(P2, ph, pw))
         else:
-            upw = sum(p.Cp for p in prev)
-            U = pl.buf(B, h, w, upw)
-            up_pieces, off = [], 0
-            for p in prev:
-                q = Piece(U, off, p.C, p.Cp)
+            up_pieces = slices(B, h, w, [p.C for p in prev])
+            for p, q in zip(prev, up_pieces):
                 pl.upsample2x(p, q, B, ph, pw, name=nm + ".up")
-                up_pieces.append(q)
-                off += p.Cp
             cat = up_pieces + skip
             l1 = _cl(ub.conv11, _lay(cat))
             pl.conv_pair(l1, cat, l12, x1, B, h, w, name=nm + ".conv1")
