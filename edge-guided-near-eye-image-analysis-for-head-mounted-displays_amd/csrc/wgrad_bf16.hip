@@ -180,34 +180,36 @@ void wgrad3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------------------------------
 // 1x1 / stride 1 weight gradient over raw bf16 slices with every (32 co, 32 k) block pair of the layer in ONE workgroup (the bf16
-// form of conv1x1_wgrad_allpairs_kernel, backward.hip): a workgroup walks its pixel range in chunks of 64 pixels, stages all gz
+// form of conv1x1_wgrad_allpairs_kernel, backward.hip): a workgroup walks its pixel range in chunks of CH pixels (64 with up to 16
+// tiles, 128 up to 8, 256 up to 4: always 64 KB of loads in flight per workgroup -- with 64-pixel chunks the 4-tile layers of the
+// full-resolution dense block had 16 KB in flight between two barriers and ran at 2.2 TB/s), stages all gz
 // tiles and all x tiles of the chunk once as [64 px][32 ch] bf16 rows (16-byte loads, 4 neighbouring lanes = the 64 contiguous
 // bytes of a pixel's block), and its eight waves share the pairs: wave w owns pairs w, w + 8, ... for ALL pixels -- no cross-wave
 // reduction, every HBM byte read once.  Operands by ds_read_b64_tr_b16 as above.  Partials: ws[split][CoutP][Ktot].
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int W1_MAXT = 16;      // tiles (gz + x) of a chunk
-constexpr int W1_CH = 64;        // pixels per chunk
+constexpr int W1_NI = 8;         // 16-byte items per thread and chunk: tiles x CH / 128
 struct W1Tab { short seg[W1_MAXT]; short c0[W1_MAXT]; short kofs[W1_MAXT]; };
 
-template <int PPW>
+template <int PPW, int W1_CH>
 __global__ __launch_bounds__(512)
 void wgrad1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ gz, long long gzs, int gzo, int nsplit, int nco, int nkc,
                           W1Tab tab, float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) egne_bf16 w1lds[];     // [nco + nkc][64 px][32]
+  extern __shared__ __attribute__((aligned(16))) egne_bf16 w1lds[];     // [nco + nkc][CH px][32]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = nco + nkc, npairs = nco * nkc;
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const long long per = ((M + nsplit - 1) / nsplit + W1_CH - 1) / W1_CH * W1_CH;
   const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
-  const int piece = tid & 3, px = (tid & 255) >> 2, jh = tid >> 8;      // item I of a thread: tile 2 I + jh, pixel px, 8-channel group piece
-  u32x4 rv[W1_MAXT / 2];
+  const int piece = tid & 3;                                            // item I of a thread: linear index tid + 512 I over (tile, pixel, 8-channel group)
+  u32x4 rv[W1_NI];
   auto issue = [&](long long mc) {
     const int rows = (int)(m_end - mc < W1_CH ? m_end - mc : W1_CH);
 #pragma unroll
-    for (int I = 0; I < W1_MAXT / 2; ++I) {
-      const int j = 2 * I + jh;
-      if (2 * I < nt) {                 // (uniform; the odd tile of the last pair may not exist: its lanes read nothing)
+    for (int I = 0; I < W1_NI; ++I) {
+      const int lin = tid + 512 * I, j = lin / (4 * W1_CH), px = (lin % (4 * W1_CH)) >> 2;
+      if (512 * I < nt * 4 * W1_CH) {                 // (uniform; the lanes past the last tile read nothing)
         const bool isg = j < nco, on = j < nt;
         const egne_seg& sg = p.seg[(isg || !on) ? 0 : tab.seg[j]];
         const int c = (isg ? 32 * j : (on ? tab.c0[j] : 0)) + 8 * piece;
@@ -229,8 +231,8 @@ void wgrad1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ 
   for (long long mc = m_begin; mc < m_end; mc += W1_CH) {
     __syncthreads();                 // every wave is done with the previous chunk's tiles
 #pragma unroll
-    for (int I = 0; I < W1_MAXT / 2; ++I) {
-      const int j = 2 * I + jh;
+    for (int I = 0; I < W1_NI; ++I) {
+      const int lin = tid + 512 * I, j = lin / (4 * W1_CH), px = (lin % (4 * W1_CH)) >> 2;
       if (j < nt) *(u32x4*)&w1lds[(j * W1_CH + px) * 32 + piece * 8] = rv[I];
     }
     __syncthreads();
@@ -309,18 +311,26 @@ bool wgrad1x1_bf16_supported(const egne_conv_desc& d, long long gzs) {
   for (int s = 0; s < d.nseg; ++s) {
     const egne_seg& g = d.seg[s];
     if (!g.ptr || g.scale || g.act_in != EGNE_ACT_NONE || g.Cp % 8 || g.ch_off % 8 || g.pix_stride % 8 || ((uintptr_t)g.ptr & 15) ||
-        g.pix_stride * W1_CH * 2 >= (1ll << 31)) return false;
+        g.pix_stride * 256 * 2 >= (1ll << 31)) return false;
     nkc += (g.Cp + 31) / 32;
   }
   const int nco = d.CoutP / 32;
-  if (gzs % 8 || d.out_ch_off % 8 || d.Cout_store % 8 || gzs * W1_CH * 2 >= (1ll << 31)) return false;
-  if (nco + nkc > W1_MAXT || nco * nkc > 32 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
+  if (gzs % 8 || d.out_ch_off % 8 || d.Cout_store % 8 || gzs * 256 * 2 >= (1ll << 31)) return false;
+  if (nco + nkc > W1_MAXT || nco * nkc > 64 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
   return true;
 }
 
+static int w1_tiles(const egne_conv_desc& d) {
+  int nt = d.CoutP / 32;
+  for (int s = 0; s < d.nseg; ++s) nt += (d.seg[s].Cp + 31) / 32;
+  return nt;
+}
+static int w1_chunk(const egne_conv_desc& d) { const int nt = w1_tiles(d); return nt <= 4 ? 256 : (nt <= 8 ? 128 : 64); }
+
 int wgrad1x1_bf16_splits(const egne_conv_desc& d) {
   const long long M = (long long)d.B * d.Ho * d.Wo;
-  long long ns = (M + W1_CH * 4 - 1) / (W1_CH * 4);      // at least four chunks per workgroup
+  const int ch = w1_chunk(d);
+  long long ns = (M + ch * 4 - 1) / (ch * 4);      // at least four chunks per workgroup
   if (ns > 512) ns = 512;
   return (int)(ns < 1 ? 1 : ns);
 }
@@ -334,17 +344,19 @@ int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long
     for (int c0 = 0; c0 < d.seg[s].Cp; c0 += 32, ++j) { tab.seg[j] = (short)s; tab.c0[j] = (short)c0; tab.kofs[j] = (short)kofs; }
     kofs += d.seg[s].Cp;
   }
-  const int nkc = j - nco, ppw = (nco * nkc + 7) / 8;
+  const int nkc = j - nco, ppw = (nco * nkc + 7) / 8, ch = w1_chunk(d);
   const size_t bytes = (size_t)nsplit * d.CoutP * d.Ktot * sizeof(float);
   if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: memset failed");     // channels beyond a slice's blocks
-  const size_t lds = (size_t)(nco + nkc) * W1_CH * 32 * sizeof(egne_bf16);
+  const size_t lds = (size_t)(nco + nkc) * ch * 32 * sizeof(egne_bf16);
   auto go = [&](auto kern) -> int {
     static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
     if (!raised) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(kern, dim3(nsplit), dim3(512), lds, st, d, gz, gzs, gzo, nsplit, nco, nkc, tab, ws);
     return check_launch("egne_conv2d_wgrad (1x1, bf16)");
   };
-  return ppw <= 1 ? go(wgrad1x1_bf16_kernel<1>) : ppw <= 2 ? go(wgrad1x1_bf16_kernel<2>) : ppw <= 3 ? go(wgrad1x1_bf16_kernel<3>) : go(wgrad1x1_bf16_kernel<4>);
+  if (ch == 256) return go(wgrad1x1_bf16_kernel<1, 256>);                               // <= 4 tiles: <= 4 pairs
+  if (ch == 128) return ppw <= 1 ? go(wgrad1x1_bf16_kernel<1, 128>) : go(wgrad1x1_bf16_kernel<2, 128>);     // <= 8 tiles: <= 16 pairs
+  return ppw <= 2 ? go(wgrad1x1_bf16_kernel<2, 64>) : ppw <= 4 ? go(wgrad1x1_bf16_kernel<4, 64>) : go(wgrad1x1_bf16_kernel<8, 64>);
 }
 
 int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st) {
