@@ -12,8 +12,10 @@ measures every leg BASELINE.json's metric / north_star name and prints ONE JSON 
                        device, fitted ellipses copied to the host every step): the north-star "edge+seg+fit";
   exact_fp32           the same step with the split-f16 products switched off (every conv on v_mfma_f32_32x32x2_f32);
   train                fwd+bwd: frozen edge net forward, ESF-Net forward + backward, gradient all-reduce (N>1), Adam
-                       step, batch 256 per GPU (BASELINE.json configs[2] shape; fp32 storage, fp32 accumulation; 3x3 forward
-                       convolutions, their data and weight gradients on split-f16 products, 1x1 convolutions exact fp32).
+                       step, batch 256 per GPU (BASELINE.json configs[2] shape) with bf16 STORAGE of activations and activation
+                       gradients (fp32 accumulation, fp32 master weights: what configs[2..4] name); `train.fp32_storage` is the
+                       same step with fp32 storage (the plan the gradient fixtures pin to the reference).  --config
+                       baseline_adain_edge / --chz 64 with --mode train select the configs[3] / configs[4] shapes.
 
 For N>1 the driver launches one process per GPU (torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE in the env);
 `python bench.py --gpus N` without that environment spawns the N rank processes itself (before anything touches the
@@ -24,8 +26,11 @@ The JSON line also carries
   roofline      the dominant kernel family of the inference step (split-f16 convolutions: 3 x v_mfma_f32_32x32x16_f16
                 per product): algorithmic conv FLOPs of one step / summed duration of its launches, measured with HIP
                 events on the launch stream inside the timed region, against 2500 / 3 TFLOP/s;
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference's PyTorch path) timed on the host cores on a bounded
-                sample (B=2, rank 0 at N=1 only).
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's PyTorch path) timed on the host cores per BASELINE.md
+                section 3: BDCN forward, ESF forward, ESF forward+backward+Adam and the fit on their own, B=2 and B=8, bounded
+                samples (rank 0 at N=1 only); `parity_sample` compares the GPU path with the oracle on that B=2 sample;
+  ranks         ranks seen, every rank's own frames/s (min / max) and the whole-job value per GPU (= `value` at --gpus 1);
+                training legs add `allreduce_ms_per_step` (HIP events around the RCCL call).
 """
 import argparse
 import json
@@ -41,7 +46,7 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"; the split kernel issues 3 MFMAs per product
-ROUND = "r02"
+ROUND = "r03"
 FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad")
 
 
@@ -61,8 +66,7 @@ def parse():
                          "prep: device-side batch preparation (distance maps + z-score, SURVEY.md 8f N1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="inference legs: edge network and ESF-Net of a batch back to back on one stream")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-budget", type=float, default=7.0, help="seconds per timed part of the CPU baseline (4 parts x 2 batch sizes)")
     ap.add_argument("--config", default="baseline_edge", help="configs/<name>.yaml (baseline_adain_edge = BASELINE.json configs[3])")
     ap.add_argument("--chz", type=int, default=32, help="ESF-Net base width (64 = BASELINE.json configs[4]'s wider model)")
     ap.add_argument("--fit", action="store_true", help="--mode infer: the headline step includes the ellipse-fit stage")
@@ -86,30 +90,104 @@ def spawn_ranks(a):
     sys.exit(max(abs(rc) for rc in rcs))
 
 
-def cpu_baseline(setting, bd_sd, net_sd, B, iters):
-    """The oracle (CPU port of the reference path: edge + seg + loss, eval, no_grad) on host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _timeit(fn, budget_s, warm=2, lo=2, hi=5):
+    """``warm`` untimed calls, then between ``lo`` and ``hi`` timed ones -- as many as fit ``budget_s`` judging by the last warm-up.
+    Returns (median, min, timed calls, warm-ups) in seconds."""
+    last = None
+    for _ in range(warm):
+        t0 = time.perf_counter()
+        fn()
+        last = time.perf_counter() - t0
+    n = max(lo, min(hi, int(budget_s / max(last, 1e-9))))
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0], n, warm
+
+
+def cpu_baseline(setting, bd_sd, net_sd, batches=(2, 8), budget_s=7.0, parity=None):
+    """the oracle (CPU restatement of the reference path, pinned by the reference-generated fixtures) timed on
+    this box's host cores, on bounded samples: BDCN forward, ESF-Net forward (+ loss), ESF-Net forward + backward + Adam, and the
+    ellipse fit, each on its own; B = 2 (BASELINE.json configs[0]) and B = 8; 2 warm-ups and up to 5 timed iterations per part (as
+    many as fit ~7 s per part: the whole leg stays near a minute), median and minimum.  ``value`` = frames/s of edge + seg at B = 2
+    (the sum of the two medians), what round 1 / 2 reported.  ``parity``: callable(batch, edge, logits) -> dict, run on the B = 2
+    sample so that the line also says how the GPU path compares with the oracle on it."""
+    import numpy as np
     import torch
     import egne_amd  # noqa: F401
     from egne_amd import synth
-    from oracle import bdcn as obdcn, esfnet as oesf
-    # the box exposes 256 logical cores but over-subscribing torch's intra-op pool is pathologically slow
+    from oracle import bdcn as obdcn, esfnet as oesf, fit as ofit
+    # the box exposes far more logical cores than torch's intra-op pool uses well (over-subscription was pathologically slow)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(min(ncores, 32))
-    b = synth.make_batch(B, seed=1234)
-    times = []
-    with torch.no_grad():
-        for i in range(iters + 1):
-            t0 = time.perf_counter()
-            e = obdcn.calc_edge(bd_sd, b["img"])
-            oesf.esf_forward(net_sd, setting, b["img"], e, b["label"], b["pupil_center"], b["elNorm"], b["spatWts"],
-                             b["distMap"], b["cond"], b["ID"], b["alpha"])
-            if i > 0:  # first iteration is warm-up
-                times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 4), "unit": "eye-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "B=%d edge+seg+loss fp32 eval, %d timed iterations (median), torch CPU %d threads of %s logical cores"
-                      % (B, iters, torch.get_num_threads(), os.cpu_count())}
+    out = {"kind": "port", "unit": "eye-frames/s", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(),
+           "affinity_cores": ncores, "cpu_model": _cpu_model(), "torch_threads": torch.get_num_threads(),
+           "protocol": "BASELINE.md section 3: 2 warm-ups, 2-5 timed iterations per part (~%.0f s budget each), median and min" % budget_s,
+           "parts": {}}
+    t_all = time.perf_counter()
+    for B in batches:
+        b = synth.make_batch(B, seed=1234)
+        keep = {}
+
+        def f_bdcn():
+            with torch.no_grad():
+                keep["e"] = obdcn.calc_edge(bd_sd, b["img"])
+
+        def f_esf():
+            with torch.no_grad():
+                keep["o"] = oesf.esf_forward(net_sd, setting, b["img"], keep["e"], b["label"], b["pupil_center"], b["elNorm"], b["spatWts"],
+                                             b["distMap"], b["cond"], b["ID"], b["alpha"])
+        sd = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v.clone()) for k, v in net_sd.items()}
+        opt = torch.optim.Adam([v for k, v in sd.items() if v.requires_grad and "dsIdentify" not in k], lr=5e-4)
+
+        def f_train():          # train.py:284-287 on the oracle: zero_grad, forward (training mode), backward, Adam
+            opt.zero_grad()
+            oesf.esf_forward(sd, setting, b["img"], keep["e"], b["label"], b["pupil_center"], b["elNorm"], b["spatWts"],
+                             b["distMap"], b["cond"], b["ID"], b["alpha"], training=True)[3].sum().backward()
+            opt.step()
+        rec = {}
+        for name, fn in (("bdcn_forward", f_bdcn), ("esf_forward_loss", f_esf), ("esf_forward_backward_adam", f_train)):
+            med, mn, n, w = _timeit(fn, budget_s, warm=2 if name != "esf_forward_backward_adam" else 1)
+            rec[name] = {"median_s": round(med, 4), "min_s": round(mn, 4), "frames_per_s": round(B / med, 3), "timed": n, "warmups": w}
+        if B == batches[0]:
+            # evaluate.py:148-151: two ellipse searches per frame from the network's own mask and ellipse head
+            mask = keep["o"][0].argmax(1).numpy()
+            H, W = mask.shape[1:]
+            Hm = np.array([[W / 2, 0, W / 2], [0, H / 2, H / 2], [0, 0, 1]])
+            elp = keep["o"][1].numpy()
+
+            def f_fit():
+                for c, sl in ((1, slice(0, 5)), (2, slice(5, 10))):
+                    ofit.fit_ellipse(mask[0] == c, list(ofit.transform(elp[0, sl].astype(np.float64), Hm)))
+            med, mn, n, w = _timeit(f_fit, budget_s, warm=1)
+            rec["ellipse_fit_one_frame"] = {"median_s": round(med, 4), "min_s": round(mn, 4), "frames_per_s": round(1.0 / med, 3), "timed": n,
+                                            "warmups": w, "what": "2 ellipse searches (iris, pupil) of ONE frame, one core (sequential numpy search)"}
+            if parity is not None:
+                out["parity_sample"] = parity(b, keep["e"], keep["o"])
+        rec["edge_seg_frames_per_s"] = round(B / (rec["bdcn_forward"]["median_s"] + rec["esf_forward_loss"]["median_s"]), 3)
+        out["parts"]["B=%d" % B] = rec
+    first = out["parts"]["B=%d" % batches[0]]
+    out["value"] = first["edge_seg_frames_per_s"]
+    out["sample"] = ("edge + seg + loss, fp32, eval, B=%d: sum of the median BDCN and ESF-Net forward times; parts (BDCN forward, ESF forward, "
+                     "ESF forward+backward+Adam, fit) at B=%s in `parts`; torch CPU %d threads of %s logical cores (%s); whole leg %.0f s"
+                     % (batches[0], "/".join(str(x) for x in batches), torch.get_num_threads(), os.cpu_count(), out["cpu_model"],
+                        time.perf_counter() - t_all))
+    return out
 
 
 def bench_prep(a):
@@ -207,6 +285,28 @@ class Bench:
             self._batches = {B: {k: (torch.cat([v] * rep)[:B].to(self.dev) if torch.is_tensor(v) else v) for k, v in base.items()}}
         return self._batches[B]
 
+    def parity_sample(self, b, edge_ref, ref):
+        """The GPU path on the CPU baseline's B = 2 sample against what the oracle just computed there (the oracle as the checker,
+        inside the cpu_baseline leg only): edge map and logit errors, and the argmax masks pixel by pixel -- mismatches are
+        counted, and so are the pixels whose two largest reference logits lie within 2e-3 (the only ones allowed to differ)."""
+        torch = self.torch
+        from egne_amd.utils import calc_edge
+        dev = self.dev
+        self.net.load_state_dict(self.net_sd)            # (the training legs have stepped the weights and the BatchNorm statistics)
+        self.net.eval()
+        with torch.no_grad():
+            edge = calc_edge(self.args, b["img"].to(dev), self.bd, dev)
+            out = self.net(b["img"].to(dev), edge, b["label"].to(dev), b["pupil_center"].to(dev), b["elNorm"].to(dev), b["spatWts"].to(dev),
+                           b["distMap"].to(dev), b["cond"].to(dev), b["ID"].to(dev), b["alpha"])
+            mask = self.net.predictions().cpu()
+        top2 = ref[0].topk(2, dim=1).values
+        near = (top2[:, 0] - top2[:, 1]) < 2e-3
+        diff = mask != ref[0].argmax(1)
+        return {"frames": int(b["img"].shape[0]), "edge_max_abs_err": float((edge.cpu() - edge_ref).abs().max()),
+                "logits_max_abs_err": float((out[0].cpu() - ref[0]).abs().max()), "loss_rel_err": float(abs(out[3].item() - ref[3].item()) / abs(ref[3].item())),
+                "mask_mismatch_pixels": int(diff.sum()), "mask_mismatch_pixels_outside_near_ties": int((diff & ~near).sum()),
+                "near_tie_pixels_lt_2e-3": int(near.sum()), "pixels": int(mask.numel())}
+
     def barrier(self):
         if self.world > 1:
             self.torch.distributed.barrier()
@@ -217,6 +317,8 @@ class Bench:
         self.net._plans.clear()
         self.net._last_plan = None
         self._batches = {}
+        import gc
+        gc.collect()                # a training plan and its backward plan refer to each other: only the cycle collector frees their buffers
         self.torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -242,20 +344,33 @@ class Bench:
         self.barrier()
         dt = time.perf_counter() - t0
         self.bd._events = self.net._events = None
+        self.rank_dts = [dt]
         if self.world > 1:
             tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = tt.item()
+            every = [torch.zeros_like(tt) for _ in range(self.world)]
+            torch.distributed.all_gather(every, tt)             # every rank's own clock around its K steps (both barriers inside)
+            self.rank_dts = [float(x.item()) for x in every]
+            dt = max(self.rank_dts)                              # the job's time: the slowest rank
         return dt, ev, out
 
+    def rank_report(self, B, steps):
+        """What the multi-GPU scaling run needs to be read without guessing: how many ranks took part, each rank's own rate, and
+        the whole-job value per GPU (at --gpus 1 this IS `value`)."""
+        rates = [B * steps / t for t in self.rank_dts]
+        return {"ranks_seen": self.world if self.world == 1 else int(self.torch.distributed.get_world_size()),
+                "per_rank_frames_per_s_min": round(min(rates), 2), "per_rank_frames_per_s_max": round(max(rates), 2),
+                "value_per_gpu": round(B * steps / max(self.rank_dts), 2)}
+
     def families(self, events, steps, dt):
+        from egne_amd.engine import LAYER_BYTES as _LB
         fam, per_layer = {}, {}
         for kind, flops, e0, e1, lname in events:
-            d = fam.setdefault(kind, [0.0, 0.0, 0])
+            d = fam.setdefault(kind, [0.0, 0.0, 0, 0.0])
             sec = e0.elapsed_time(e1) * 1e-3
             d[0] += sec
             d[1] += flops
             d[2] += 1
+            d[3] += _LB.get(lname, 0.0)          # algorithmic bytes of the launch (engine.LAYER_BYTES: inputs read once, output written once)
             pl_ = per_layer.setdefault(lname, [0.0, flops, kind])
             pl_[0] += sec / steps
         if self.a.layers and self.rank == 0:
@@ -289,6 +404,22 @@ class Bench:
                    "algorithmic_gflop_per_frame": round(sp_f / steps / B / 1e9, 2), "time_share": round(sp_t / dt, 4),
                    "by_kernel": {k: {"tflops": round(v[1] / v[0] / 1e12, 1) if v[0] > 0 else 0.0, "time_share": round(v[0] / dt, 4),
                                      "launches_per_step": v[2] // max(steps, 1)} for k, v in sorted(sub.items())}}
+        bf = {k.split(":")[1]: v for k, v in fam.items() if k.startswith("conv_bf16:")}
+        self.r_bf16 = None
+        if bf:
+            bt, bfl, bn_, bby = [sum(v[i] for v in bf.values()) for i in range(4)]
+            gbs = bby / bt / 1e9 if bt > 0 else 0.0
+            self.r_bf16 = {"bound": "hbm", "kernel": "bf16-storage conv family of the training plan (bf16 tensors, one v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 "
+                           "per product, fp32 accumulate): conv3x3_bf16_kernel (3x3 forward + data gradients), conv1x1_bf16_kernel (1x1 over raw "
+                           "slices, forward + data gradients), wgrad3x3_bf16_kernel, wgrad1x1_bf16_kernel",
+                           "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s (algorithmic bytes: every input slice read once, the output "
+                           "written once, the accumulated slice of a data gradient read once more; bf16)",
+                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "traffic_source": "not measured in this run",
+                           "launches_per_step": bn_ // max(steps, 1), "avg_launch_ms": round(1e3 * bt / max(bn_, 1), 4),
+                           "algorithmic_gb_per_frame": round(bby / steps / B / 1e9, 4), "algorithmic_gflop_per_frame": round(bfl / steps / B / 1e9, 2),
+                           "tflops": round(bfl / bt / 1e12, 1) if bt > 0 else 0.0, "time_share": round(bt / dt, 4),
+                           "by_kernel": {k: {"gb_per_s": round(v[3] / v[0] / 1e9, 1) if v[0] > 0 else 0.0, "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] > 0 else 0.0,
+                                             "time_share": round(v[0] / dt, 4), "launches_per_step": v[2] // max(steps, 1)} for k, v in sorted(bf.items())}}
         return r_split, r_fp32, sp_t, conv_t
 
     # ------------------------------------------------------------------------------------------------------------
@@ -370,7 +501,12 @@ class Bench:
             out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
                       t["ID"], t["alpha"])
             out[3].backward()
-            parallel.allreduce_grads(net)
+            if self.world > 1:       # one flat RCCL all-reduce of the gradient arena (13.45 MB for baseline_edge), timed with HIP events on the stream it runs on
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                parallel.allreduce_grads(net)
+                e1.record()
+                self.ar_events.append((e0, e1))
             opt.step()
             return [o.detach() for o in out]
 
@@ -390,8 +526,12 @@ class Bench:
             r = pipe.flush() if pipe is not None else None
             return r[0] if r is not None else None
         step.flush = flush
+        self.ar_events = []
         dt, ev, out = self.timed(step, steps, warmup, events)
         assert torch.isfinite(out[3]).all()
+        ar = [a.elapsed_time(b) for a, b in self.ar_events[-steps:]] if self.ar_events else []
+        self.allreduce_ms = round(sum(ar) / len(ar), 4) if ar else 0.0
+        self.grad_bytes = int(net._grad_flat.numel() * 4) if getattr(net, "_grad_flat", None) is not None else 0
         net.eval()
         net.to(torch.float32)
         return B, dt, ev
@@ -422,8 +562,9 @@ def main():
     res = {"metric": "eye-frames/sec (320x240): inference edge+seg (value), +fit, exact fp32, and train fwd+bwd at %d MI355X" % world,
            "value": None, "unit": "eye-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 storage; inference products split into f16 hi/lo pairs (3 f16 MFMAs per product, 22-bit significand), "
-                    "f32 accumulate; training: the same products for 3x3 forward convolutions, data and weight gradients, exact f32 MFMA for 1x1", "data": "synthetic"}
+           "dtype": "f32 tensors; inference products split into f16 hi/lo pairs (3 f16 MFMAs per product, 22-bit significand), f32 accumulate "
+                    "(`exact_fp32`: every product on the f32 MFMA); `train`: bf16 storage, f32 accumulate, f32 master weights (and an f32-storage leg)",
+           "data": "synthetic"}
     arith = ("fp32 tensors everywhere; inference: split-f16 MFMA products (22-bit significand) with fp32 accumulation where eligible, "
              "exact fp32 elsewhere; training: split-f16 products for the 3x3 forward convolutions, their data and weight gradients (pre-scales "
              "measured on the device every step), exact fp32 MFMA for 1x1 convolutions and everything else")
@@ -433,11 +574,13 @@ def main():
         if a.no_pipeline:
             B, dt, ev = bn.leg_infer(a.steps, a.warmup, fit=fit_)
             dt_k = dt
+            ranks_inf = bn.rank_report(B, a.steps)
         else:
             # `value`: the pipelined loop.  Kernel durations for `roofline`: a second timed region of the same run with the two
             # stages of a batch back to back on ONE stream -- under the pipeline an event pair on one stream also spans the other
             # stream's kernels (their sum was 1.75x the step), which says nothing about the kernel between them.
             B, dt, _ = bn.leg_infer(a.steps, a.warmup, fit=fit_, events=False)
+            ranks_inf = bn.rank_report(B, a.steps)
             _, dt_k, ev = bn.leg_infer(a.steps, 1, fit=fit_, pipeline=False)
         fam = bn.families(ev, a.steps, dt_k)
         r_split, r_fp32, sp_t, conv_t = bn.rooflines(fam, a.steps, B, dt_k)
@@ -446,14 +589,23 @@ def main():
             r["measured_in"] = ("the timed region itself" if a.no_pipeline else
                                 "second timed region of this run, stages back to back on one stream: %.3f ms per step "
                                 "(time_share refers to it)" % (1e3 * dt_k / a.steps))
-        try:   # HBM traffic per launch from the committed PMC passes of this round (bench.py cannot run rocprofv3 on itself)
-            with open(os.path.join(ROOT, "profiles", ROUND + "_pmc_traffic.json")) as f:
-                tr = json.load(f)["families"]
-            if B == 64:
-                r_split["traffic"] = tr["split_f16"]["hbm_bytes_per_launch"]
-                r_fp32["traffic"] = tr["fp32_conv"]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        # HBM traffic per launch: bench.py cannot run rocprofv3 on itself, so the figure is COPIED from the committed PMC passes of the
+        # latest round that has them (profiles/rNN_pmc_traffic.json, same command, B = 64) and labelled as such
+        for r in (r_split, r_fp32):
+            r["traffic_source"] = "not measured in this run"
+        for rnd in (ROUND, "r02"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
+                    tr = json.load(f)["families"]
+                if B == 64:
+                    r_split["traffic"] = tr["split_f16"]["hbm_bytes_per_launch"]
+                    r_fp32["traffic"] = tr["fp32_conv"]["hbm_bytes_per_launch"]
+                    for r in (r_split, r_fp32):
+                        r["traffic_source"] = ("copied from profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes over `bench.py --mode infer --no-pipeline`, "
+                                               "FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run" % rnd)
+                break
+            except Exception:
+                continue
         timed_t = sum(v[0] for v in fam.values())
         res.update({
             "value": round(B * a.steps * world / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3),
@@ -469,6 +621,7 @@ def main():
             "roofline": r_split if sp_t >= conv_t else r_fp32, "roofline_secondary": r_fp32 if sp_t >= conv_t else r_split,
             "algorithmic_gflop_per_frame_total": round((r_split["algorithmic_gflop_per_frame"] + r_fp32["algorithmic_gflop_per_frame"]), 2),
             "kernel_time_share": dict({k.split(":")[0]: 0.0 for k in fam}),
+            "ranks": ranks_inf,
         })
         share = {}
         for k, v in fam.items():
@@ -498,49 +651,81 @@ def main():
         _engine.F16X3_ENABLED, _engine.ESF_SPLIT = old
         bn.free_plans()
 
-    if a.mode in ("all", "train"):
+    def train_leg(storage):
         steps = a.train_steps if a.mode == "all" else a.steps
         warm = 2 if a.mode == "all" else a.warmup
+        bn.free_plans()
         torch.cuda.reset_peak_memory_stats()
-        sto = "bf16" if a.train_storage in ("bf16", "both") else "fp32"
         if a.no_pipeline:
-            B, dt, ev = bn.leg_train(steps, warm, storage=sto)
+            B, dt, ev = bn.leg_train(steps, warm, storage=storage)
             dt_k = dt
+            ranks = bn.rank_report(B, steps)
         else:       # value from the pipelined loop, kernel durations from a second region with the stages back to back (as for inference)
-            B, dt, _ = bn.leg_train(steps, warm, events=False, storage=sto)
-            _, dt_k, ev = bn.leg_train(steps, 1, pipeline=False, storage=sto)
+            B, dt, _ = bn.leg_train(steps, warm, events=False, storage=storage)
+            ranks = bn.rank_report(B, steps)
+            _, dt_k, ev = bn.leg_train(steps, 1, pipeline=False, storage=storage)
         fam = bn.families(ev, steps, dt_k)
         rsp, r32, sp_t, conv_t = bn.rooflines(fam, steps, B, dt_k)
-        for r in (rsp, r32):
+        rbf = bn.r_bf16
+        meas = ("the timed region itself" if a.no_pipeline else
+                "second timed region of this run, stages back to back on one stream: %.3f ms per step (time_share refers to it)" % (1e3 * dt_k / steps))
+        for r in (rsp, r32) + ((rbf,) if rbf else ()):
             r["region_ms_per_step"] = round(1e3 * dt_k / steps, 3)
-            r["measured_in"] = ("the timed region itself" if a.no_pipeline else
-                                "second timed region of this run, stages back to back on one stream: %.3f ms per step "
-                                "(time_share refers to it)" % (1e3 * dt_k / steps))
-        rdom, rsec = (rsp, r32) if sp_t >= conv_t else (r32, rsp)        # the family with the larger share of the step first
+            r["measured_in"] = meas
+            r.setdefault("traffic_source", "not measured in this run")
+        cands = sorted([r for r in (rbf, rsp, r32) if r and r["time_share"] > 0], key=lambda r: -r["time_share"])
+        rdom, rsec = cands[0], (cands[1] if len(cands) > 1 else None)        # the family with the larger share of the step first
+        which = {"baseline_edge": "configs[2]", "baseline_adain_edge": "configs[3] (per-GPU shard: 256 of the global 1024)"}.get(a.config, a.config)
+        if a.chz == 64:
+            which = "configs[4] (the 64-channel model, per-GPU shard: 256 of the global 2048)"
+        if storage == "bf16":
+            what = ("BASELINE.json %s shape: %s.yaml (chz=%d) train step = frozen BDCN forward + ESF-Net forward + backward + gradient all-reduce + "
+                    "Adam, batch=%d/GPU, bf16 STORAGE of activations and activation gradients in HBM, fp32 accumulation, fp32 master weights / "
+                    "gradient arena / optimiser (3x3 and raw-slice 1x1 convolutions, their data and weight gradients on bf16 MFMAs with weights "
+                    "rounded to bf16; everything else fp32 arithmetic on bf16 tensors)" % (which, a.config, a.chz, B))
+            dty = "bf16 storage, f32 accumulate, f32 master weights (frozen edge network: f32 tensors, split-f16 products)"
+        else:
+            what = ("BASELINE.json %s shape with FP32 storage (the parity anchor): %s.yaml (chz=%d) train step = frozen BDCN forward + ESF-Net "
+                    "forward + backward + gradient all-reduce + Adam, batch=%d/GPU, fp32 storage and accumulation (3x3 forward convs, data and "
+                    "weight gradients on split-f16 products, 1x1 exact fp32; EGNE_TRAIN_SPLIT=0 for all-fp32)" % (which, a.config, a.chz, B))
+            dty = "f32 storage; 3x3 products split into f16 hi/lo pairs (22-bit significand), f32 accumulate; 1x1 exact f32 MFMA"
+        keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches_per_step", "avg_launch_ms",
+                "algorithmic_gflop_per_frame", "time_share", "region_ms_per_step", "measured_in", "by_kernel", "algorithmic_gb_per_frame", "tflops")
         tr = {"value": round(B * steps * world / dt, 2), "unit": "eye-frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
-              "warmup": warm, "frames_per_gpu_per_step": B, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-              "what": "BASELINE.json configs[2] shape: %s.yaml (chz=%d) train step = frozen BDCN forward + ESF-Net forward + backward + "
-                      "gradient all-reduce + Adam, batch=%d/GPU, fp32 storage and accumulation (3x3 forward convs, data and weight gradients on "
-                      "split-f16 products, 1x1 exact fp32; EGNE_TRAIN_SPLIT=0 for all-fp32)" % (a.config, a.chz, B),
-              "parallelism": "dp%d (one flat RCCL all-reduce of the gradient arena per step)" % world,
+              "warmup": warm, "frames_per_gpu_per_step": B, "dtype": dty, "storage": storage,
+              "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "what": what,
+              "parallelism": "dp%d (one flat RCCL all-reduce of the %.2f MB gradient arena per step)" % (world, bn.grad_bytes / 1e6),
+              "allreduce_ms_per_step": bn.allreduce_ms, "ranks": ranks,
               "pipeline": ("none" if a.no_pipeline else "the frozen edge network of batch i+1 on a second HIP stream next to forward / backward / "
                            "Adam of batch i; empty when the timed region starts, drained inside it"),
-              "roofline": {k: rdom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms",
-                                                "algorithmic_gflop_per_frame", "time_share", "region_ms_per_step", "measured_in")},
-              "roofline_secondary": {k: rsec[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step",
-                                                          "avg_launch_ms", "algorithmic_gflop_per_frame", "time_share", "region_ms_per_step", "measured_in")}}
+              "roofline": {k: rdom[k] for k in keys if k in rdom}}
+        if rsec is not None:
+            tr["roofline_secondary"] = {k: rsec[k] for k in keys if k in rsec}
+        bn.free_plans()
+        return tr, rdom, rsec
+
+    if a.mode in ("all", "train"):
+        first = "bf16" if a.train_storage in ("bf16", "both") else "fp32"
+        tr, rdom, rsec = train_leg(first)
+        if a.train_storage == "both":
+            tr["fp32_storage"], _, _ = train_leg("fp32")        # the parity anchor (the gradient fixtures pin THIS plan to the reference's fp32 gradients)
+            tr["fp32_storage"].pop("roofline_secondary", None)
         if a.mode == "train":
             res.update({"metric": "eye-frames/sec (320x240) train step: edge fwd + ESF-Net fwd+bwd + grad all-reduce + Adam",
-                        "value": tr["value"], "ms_per_step": tr["ms_per_step"], "roofline": rdom, "roofline_secondary": rsec,
-                        "config": {"workload": tr["what"], "frames_per_gpu_per_step": B, "peak_hbm_gb": tr["peak_hbm_gb"],
-                                   "parallelism": tr["parallelism"], "arithmetic": arith}})
+                        "value": tr["value"], "ms_per_step": tr["ms_per_step"], "dtype": tr["dtype"], "roofline": rdom,
+                        "config": {"workload": tr["what"], "frames_per_gpu_per_step": tr["frames_per_gpu_per_step"], "peak_hbm_gb": tr["peak_hbm_gb"],
+                                   "parallelism": tr["parallelism"], "storage": tr["storage"]},
+                        "allreduce_ms_per_step": tr["allreduce_ms_per_step"], "ranks": tr["ranks"]})
+            if rsec is not None:
+                res["roofline_secondary"] = rsec
+            if "fp32_storage" in tr:
+                res["fp32_storage"] = tr["fp32_storage"]
         else:
             res["train"] = tr
-        bn.free_plans()
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and a.mode != "train":
-            res["cpu_baseline"] = cpu_baseline(bn.setting, bn.bd_sd, bn.net_sd, a.cpu_batch, a.cpu_iters)
+            res["cpu_baseline"] = cpu_baseline(bn.setting, bn.bd_sd, bn.net_sd, budget_s=a.cpu_budget, parity=bn.parity_sample)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

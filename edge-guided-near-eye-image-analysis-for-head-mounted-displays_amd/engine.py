@@ -1276,12 +1276,14 @@ class Plan:
         wsw = bw.vec((int(L.egne_conv2d_wgrad_workspace_bytes(C.byref(d))) + 3) // 4)
         bw.keep.append(gw)
         flops = 2.0 * npix * layer.Cout * layer.Cin * layer.kh * layer.kw
+        LAYER_BYTES[name + ".wgrad"] = float(self.esz) * (B * H * W * sum(q.Cp for q in pieces) + npix * Cs)      # x and gz read once
         if split_wgrad:
             bw._add(L.egne_conv2d_wgrad_f16, (C.byref(d), gy.ptr, gy.stride, gy.off, gz_max, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
                                               gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_f16x3:wgrad", side=WGRAD_SIDE_STREAM)
         else:
             bw._add(L.egne_conv2d_wgrad, (C.byref(d), gy.ptr, gy.stride, gy.off, layer.Cout, layer.Cin, layer.kinv.data_ptr(),
-                                          gw, wsw.data_ptr()), name + ".wgrad", flops=flops, kind="conv_wgrad", side=WGRAD_SIDE_STREAM)
+                                          gw, wsw.data_ptr()), name + ".wgrad", flops=flops,
+                    kind="conv_bf16:wgrad" if self.bf16 else "conv_wgrad", side=WGRAD_SIDE_STREAM)
         gin = Piece(gy.buf, gy.off, layer.Cout, Cs, gy.n0)
         # 1x1 over adjacent raw slices of one buffer (dense-block conv21 / conv31 over [x | x1 | x22]): one data-gradient launch
         # for the whole run of slices instead of one per slice, each re-reading gz
