@@ -2,9 +2,10 @@
 // with utils.py:176-204 (IoU of the class mask with a rasterised ellipse on the [-1,1] mesh) and the
 // float64 conic algebra of helperfunctions.py:13-63,102-129.
 //
-// One workgroup per (frame, class).  The class mask is bit-packed into LDS once; every IoU evaluation
-// is then a popcount pass over those words, so the <=281 sequential evaluations of the search never
-// leave the CU (the reference builds each map on the host, copies it and calls .item() three times).
+// One wave per (frame, class).  The class mask is bit-packed into LDS once; every IoU evaluation is then a pass
+// over the rows of the ellipse's bounding box (exact end points of the inside interval + a popcount), so the
+// <=281 sequential evaluations of the search never leave the CU (the reference builds each map on the host,
+// copies it and calls .item() three times).
 //
 // Numerics follow the reference bit for bit: float32 mesh supplied by the host (torch.linspace, the
 // same call create_meshgrid makes), float32 map arithmetic with one rounding per operation (built with
@@ -13,7 +14,6 @@
 
 namespace {
 
-constexpr int NT = 512;
 constexpr double PI_REF = 3.14159;
 constexpr double EPS_B = 1e-40;  // helperfunctions.py:10
 
@@ -69,153 +69,186 @@ __device__ void normalise(const double* el, int Hh, int Ww, double* out) {
   out[4] = theta;
 }
 
-struct Shared {
-  float prm[6];          // cx, cy, a, b, cos, sin on the mesh (float32)
-  unsigned red[2][NT / 64];
-  float score;
-  double now[3], d[3], rt;
-  int flag, nseg;
-};
+// ------------------------------------------------------------------------------------------------------------------------
+// One WAVE per (frame, class), four searches per workgroup, no barriers.
+//
+// Why not a workgroup per search (rounds 1-2: 512 threads, the mask scanned word by word): the 128 searches of a 64-frame batch
+// then sit on 128 CUs for 3.2 ms with ~12 KB of LDS each, and while they do, the network's persistent kernels on the other
+// stream (one 100-160 KB workgroup per CU) can only be placed on the remaining CUs -- the fit stage cost the step 3.4 ms although it
+// is 1.4 % of its work.  Here a batch's searches occupy 32 CUs for about a millisecond.
+//
+// What makes one wave enough: an evaluation no longer tests every pixel of the ellipse's bounding box.  On a row the inside set
+// of the reference's float32 predicate  ((dx ct + dy st)/a)^2 + ((-dx st + dy ct)/b)^2 - 1 <= 0  is an interval; lane = row solves
+// the row's quadratic for approximate end points and then walks each end with the EXACT predicate (same operations, one rounding
+// each) until pixel il is inside and il - 1 is not (likewise ir): the count is ir - il + 1 and the overlap a popcount of the
+// row's mask bits under the interval.  Rows whose interval is short (tangent rows, where round-off could matter over more than a
+// pixel) or empty are tested pixel by pixel around it; walks that do not settle within a few steps and degenerate ellipses fall
+// back to testing every pixel of the row -- so the result is the reference's bit for bit (tests/golden/fit_cases.npz,
+// evaluate_real_frames.npz).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int FIT_WAVES = 4;
 
-__global__ __launch_bounds__(NT) void ellipse_fit_k(const long long* __restrict__ mask, int nframes, const int* __restrict__ frame_of,
-                                                    const int* __restrict__ cls, int H, int W,
-                                                    const float* __restrict__ xs, const float* __restrict__ ys,
-                                                    const double* __restrict__ init, double* __restrict__ out,
-                                                    int* __restrict__ evals) {
-  extern __shared__ unsigned bits[];  // [H][wpr] packed mask, then xs[W], ys[H]
-  __shared__ Shared sh;
-  const int e = blockIdx.x, tid = threadIdx.x;
+struct Ell { float cx, cy, a, b, ct, st; };
+
+__device__ __forceinline__ bool inside_px(const Ell& e, float xv, float dyst, float dyct) {
+  const float dx = __fsub_rn(xv, e.cx);
+  const float X = __fadd_rn(__fmul_rn(dx, e.ct), dyst);
+  const float Y = __fadd_rn(__fmul_rn(-dx, e.st), dyct);
+  const float u = __fdiv_rn(X, e.a), v = __fdiv_rn(Y, e.b);
+  const float wt = __fsub_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)), 1.0f);
+  return wt <= 0.f;
+}
+
+// bits of row `rowbits` (wpr words) in pixel range [x0, x1] (inclusive, 0 <= x0 <= x1 < W): popcount
+__device__ __forceinline__ unsigned row_pop(const unsigned* rowbits, int x0, int x1) {
+  unsigned n = 0;
+  for (int w = x0 >> 5; w <= (x1 >> 5); ++w) {
+    unsigned m = 0xffffffffu;
+    if (w == (x0 >> 5)) m &= 0xffffffffu << (x0 & 31);
+    if (w == (x1 >> 5)) m &= 0xffffffffu >> (31 - (x1 & 31));
+    n += __popc(rowbits[w] & m);
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long* __restrict__ mask, int nframes, const int* __restrict__ frame_of,
+                                                                const int* __restrict__ cls, int n, int H, int W,
+                                                                const float* __restrict__ xs, const float* __restrict__ ys,
+                                                                const double* __restrict__ init, double* __restrict__ out,
+                                                                int* __restrict__ evals) {
+  extern __shared__ unsigned fit_lds[];  // xs[W], ys[H], then per wave [H][wpr] packed mask
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wpr = (W + 31) >> 5, nwords = H * wpr;
-  float* lxs = (float*)(bits + nwords);
+  float* lxs = (float*)fit_lds;
   float* lys = lxs + W;
+  unsigned* bits = fit_lds + W + H + wave * nwords;
+  for (int i = threadIdx.x; i < W; i += blockDim.x) lxs[i] = xs[i];
+  for (int i = threadIdx.x; i < H; i += blockDim.x) lys[i] = ys[i];
+  __syncthreads();                        // the only barrier: every wave reaches it before anything can end it
+  const int e = blockIdx.x * FIT_WAVES + wave;
+  if (e >= n) return;                     // (whole waves: no lane of a live wave is switched off)
   const int fr = frame_of[e];
   if (fr < 0 || fr >= nframes) {   // a fit that names a frame the mask tensor does not hold: report NaN, read nothing
-    if (tid < 5) out[e * 5 + tid] = __longlong_as_double(0x7ff8000000000000ll);
-    if (tid == 0 && evals) evals[e] = 0;
+    if (lane < 5) out[e * 5 + lane] = __longlong_as_double(0x7ff8000000000000ll);
+    if (lane == 0 && evals) evals[e] = 0;
     return;
   }
   const long long* m = mask + (long long)fr * H * W;
   const int k = cls[e];
-  unsigned cnt = 0;
-  for (int w = tid; w < nwords; w += NT) {
-    const int y = w / wpr, x0 = (w - y * wpr) << 5;
-    unsigned word = 0;
-    for (int j = 0; j < 32; ++j) {
-      const int x = x0 + j;
-      if (x < W && m[(long long)y * W + x] == k) word |= 1u << j;
+  unsigned cnt = 0;            // (wave-uniform: ballots)
+  for (int y = 0; y < H; ++y)
+    for (int x0 = 0; x0 < W; x0 += 64) {          // one coalesced 512-byte load per step, the class test of 64 pixels as one ballot
+      const int x = x0 + lane;
+      const unsigned long long bal = __ballot(x < W && m[(long long)y * W + x] == k);
+      cnt += (unsigned)__popcll(bal);
+      if (lane == 0) bits[y * wpr + (x0 >> 5)] = (unsigned)bal;
+      if (lane == 1 && (x0 >> 5) + 1 < wpr) bits[y * wpr + (x0 >> 5) + 1] = (unsigned)(bal >> 32);
     }
-    bits[w] = word;
-    cnt += __popc(word);
-  }
-  for (int i = tid; i < W; i += NT) lxs[i] = xs[i];
-  for (int i = tid; i < H; i += NT) lys[i] = ys[i];
-  // block sum of cnt
-  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if ((tid & 63) == 0) sh.red[0][tid >> 6] = cnt;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned s = 0;
-    for (int i = 0; i < NT / 64; ++i) s += sh.red[0][i];
-    sh.nseg = (int)s;
-  }
-  __syncthreads();
+  const int nseg = (int)cnt;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's mask words are in LDS before its lanes read each other's
 
   const double cx = init[e * 5 + 0], cy = init[e * 5 + 1];
+  double now[3] = {init[e * 5 + 2], init[e * 5 + 3], init[e * 5 + 4] * 180. / PI_REF}, d[3] = {1.0, 1.0, 1.0};
 
-  // IoU of the packed mask with the ellipse (cx, cy, now[0], now[1], now[2] degrees): all threads call it
+  // IoU of the packed mask with the ellipse (cx, cy, now[0], now[1], now[2] degrees); every lane computes the same parameters
   auto evaluate = [&]() -> float {
-    if (tid == 0) {
-      double el[5] = {cx, cy, sh.now[0], sh.now[1], sh.now[2] / 180. * PI_REF};
-      double nm[5];
-      normalise(el, H, W, nm);
-      sh.prm[0] = (float)nm[0]; sh.prm[1] = (float)nm[1]; sh.prm[2] = (float)nm[2]; sh.prm[3] = (float)nm[3];
-      sh.prm[4] = (float)cos(nm[4]); sh.prm[5] = (float)sin(nm[4]);
-    }
-    __syncthreads();
-    const float ecx = sh.prm[0], ecy = sh.prm[1], ea = sh.prm[2], eb = sh.prm[3], ct = sh.prm[4], st = sh.prm[5];
-    // Only pixels inside the ellipse count (ne, ni), and the ellipse lies within max(a, b) of its centre: scan the
+    double el[5] = {cx, cy, now[0], now[1], now[2] / 180. * PI_REF};
+    double nm[5];
+    normalise(el, H, W, nm);
+    const Ell E = {(float)nm[0], (float)nm[1], (float)nm[2], (float)nm[3], (float)cos(nm[4]), (float)sin(nm[4])};
+    // Only pixels inside the ellipse count (ne, ni), and the ellipse lies within max(a, b) of its centre: rows of the
     // bounding box (0.1 % + 2 pixels of slack, orders of magnitude above float32 round-off) instead of the frame.
-    // Degenerate parameters (NaN / huge axes) fall back to the full frame, where the map is evaluated as before.
-    int y_lo = 0, y_hi = H - 1, w_lo = 0, w_hi = wpr - 1;
-    const float rr = fmaxf(ea, eb) * 1.001f;
-    if (rr < 4.f && fabsf(ecx) < 4.f && fabsf(ecy) < 4.f) {
-      const float sx = 0.5f * (float)(W - 1), sy = 0.5f * (float)(H - 1);
-      const int xl = (int)floorf((ecx - rr + 1.f) * sx) - 2, xh = (int)ceilf((ecx + rr + 1.f) * sx) + 2;
-      const int yl = (int)floorf((ecy - rr + 1.f) * sy) - 2, yh = (int)ceilf((ecy + rr + 1.f) * sy) + 2;
+    // Degenerate parameters (NaN / huge axes) fall back to the full frame, every pixel tested.
+    int y_lo = 0, y_hi = H - 1, x_lo = 0, x_hi = W - 1;
+    const float rr = fmaxf(E.a, E.b) * 1.001f;
+    const bool tame = rr < 4.f && fabsf(E.cx) < 4.f && fabsf(E.cy) < 4.f && fminf(E.a, E.b) > 1e-3f;
+    const float sx = 0.5f * (float)(W - 1), sy = 0.5f * (float)(H - 1);
+    if (tame) {
+      const int xl = (int)floorf((E.cx - rr + 1.f) * sx) - 2, xh = (int)ceilf((E.cx + rr + 1.f) * sx) + 2;
+      const int yl = (int)floorf((E.cy - rr + 1.f) * sy) - 2, yh = (int)ceilf((E.cy + rr + 1.f) * sy) + 2;
       y_lo = max(yl, 0); y_hi = min(yh, H - 1);
-      w_lo = max(xl, 0) >> 5; w_hi = min(xh, W - 1) >> 5;
+      x_lo = max(xl, 0); x_hi = min(xh, W - 1);
     }
-    const int bw = w_hi - w_lo + 1, nbox = (y_hi >= y_lo && bw > 0) ? (y_hi - y_lo + 1) * bw : 0;
     unsigned ne = 0, ni = 0;
-    for (int q = tid; q < nbox; q += NT) {
-      const int yq = q / bw, y = y_lo + yq, wx = w_lo + (q - yq * bw), w = y * wpr + wx, x0 = wx << 5;
-      const float dy = __fsub_rn(lys[y], ecy);
-      const float dyst = __fmul_rn(dy, st), dyct = __fmul_rn(dy, ct);
-      unsigned word = 0;
-      for (int j = 0; j < 32; ++j) {
-        const int x = x0 + j;
-        if (x < W) {
-          const float dx = __fsub_rn(lxs[x], ecx);
-          const float X = __fadd_rn(__fmul_rn(dx, ct), dyst);
-          const float Y = __fadd_rn(__fmul_rn(-dx, st), dyct);
-          const float u = __fdiv_rn(X, ea), v = __fdiv_rn(Y, eb);
-          const float wt = __fsub_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)), 1.0f);
-          if (wt <= 0.f) word |= 1u << j;
+    if (y_hi >= y_lo && x_hi >= x_lo) {
+      // the row quadratic A dx^2 + Bq dx + C <= 0 (approximate arithmetic: it only seeds the exact walk)
+      const float ia = 1.f / (E.a * E.a), ib = 1.f / (E.b * E.b);
+      const float A = E.ct * E.ct * ia + E.st * E.st * ib, Bc = 2.f * E.st * E.ct * (ia - ib), Cc = E.st * E.st * ia + E.ct * E.ct * ib;
+      for (int y = y_lo + lane; y <= y_hi; y += 64) {
+        const float dy = __fsub_rn(lys[y], E.cy);
+        const float dyst = __fmul_rn(dy, E.st), dyct = __fmul_rn(dy, E.ct);
+        const unsigned* rowbits = bits + y * wpr;
+        // pixels [t0, t1] of the row tested one by one; an interval [il, ir] counted as a whole
+        int t0 = 0, t1 = -1, il = 0, ir = -1;
+        if (!tame) {
+          t0 = x_lo; t1 = x_hi;
+        } else {
+          const float Bq = Bc * dy, C = Cc * dy * dy - 1.f, disc = Bq * Bq - 4.f * A * C;
+          const int xv = (int)floorf((-Bq / (2.f * A) + E.cx + 1.f) * sx);        // pixel next to the row's closest approach
+          bool whole = false;
+          if (!(disc > 0.f)) {
+            // the row misses the ellipse (or grazes it): round-off can only matter next to the closest approach
+            t0 = max(xv - 4, 0); t1 = min(xv + 5, W - 1);
+            whole = t1 >= t0 && (inside_px(E, lxs[t0], dyst, dyct) || inside_px(E, lxs[t1], dyst, dyct));
+          } else {
+            const float sq = sqrtf(disc), dl = (-Bq - sq) / (2.f * A), dr = (-Bq + sq) / (2.f * A);
+            il = (int)ceilf((dl + E.cx + 1.f) * sx);
+            ir = (int)floorf((dr + E.cx + 1.f) * sx);
+            if (ir - il < 12) {
+              // short interval (tangent rows): its pixels and four more on either side, one by one; the outermost must be outside
+              t0 = max(il - 4, 0); t1 = min(ir + 4, W - 1);
+              whole = t1 >= t0 && ((t0 > 0 && inside_px(E, lxs[t0], dyst, dyct)) || (t1 < W - 1 && inside_px(E, lxs[t1], dyst, dyct)));
+              il = 0; ir = -1;
+            } else {
+              // walk each end with the exact predicate: il inside and il - 1 outside (or il = 0), ir inside and ir + 1 outside (or ir = W - 1)
+              il = min(max(il, 0), W - 1); ir = min(max(ir, 0), W - 1);
+              int steps = 0;
+              while (steps < 8 && il > 0 && inside_px(E, lxs[il - 1], dyst, dyct)) { --il; ++steps; }
+              while (steps < 8 && il < W - 1 && !inside_px(E, lxs[il], dyst, dyct)) { ++il; ++steps; }
+              steps = 0;
+              while (steps < 8 && ir < W - 1 && inside_px(E, lxs[ir + 1], dyst, dyct)) { ++ir; ++steps; }
+              while (steps < 8 && ir > 0 && !inside_px(E, lxs[ir], dyst, dyct)) { --ir; ++steps; }
+              const bool settled = il <= ir && inside_px(E, lxs[il], dyst, dyct) && (il == 0 || !inside_px(E, lxs[il - 1], dyst, dyct)) &&
+                                   inside_px(E, lxs[ir], dyst, dyct) && (ir == W - 1 || !inside_px(E, lxs[ir + 1], dyst, dyct));
+              if (!settled) { whole = true; il = 0; ir = -1; }
+            }
+          }
+          if (whole) { t0 = 0; t1 = W - 1; }          // something unexpected: every pixel of the row, as the reference does
+        }
+        for (int x = t0; x <= t1; ++x)
+          if (inside_px(E, lxs[x], dyst, dyct)) { ++ne; ni += (rowbits[x >> 5] >> (x & 31)) & 1u; }
+        if (ir >= il) {
+          ne += (unsigned)(ir - il + 1);
+          ni += row_pop(rowbits, il, ir);
         }
       }
-      ne += __popc(word);
-      ni += __popc(word & bits[w]);
     }
     for (int o = 32; o >= 1; o >>= 1) { ne += __shfl_xor(ne, o); ni += __shfl_xor(ni, o); }
-    if ((tid & 63) == 0) { sh.red[0][tid >> 6] = ne; sh.red[1][tid >> 6] = ni; }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned a = 0, b = 0;
-      for (int i = 0; i < NT / 64; ++i) { a += sh.red[0][i]; b += sh.red[1][i]; }
-      const float fi = (float)b;
-      sh.score = __fdiv_rn(fi, __fsub_rn(__fadd_rn((float)sh.nseg, (float)a), fi));
-    }
-    __syncthreads();
-    return sh.score;
+    const float fi = (float)ni;
+    return __fdiv_rn(fi, __fsub_rn(__fadd_rn((float)nseg, (float)ne), fi));
   };
 
-  if (tid == 0) {
-    sh.now[0] = init[e * 5 + 2]; sh.now[1] = init[e * 5 + 3]; sh.now[2] = init[e * 5 + 4] * 180. / PI_REF;
-    sh.d[0] = sh.d[1] = sh.d[2] = 1.0;
-  }
-  __syncthreads();
   int nev = 1;
-  float s0 = evaluate();
-  if (tid == 0) sh.rt = (double)s0;
-  __syncthreads();
+  double rt = (double)evaluate();
   for (int sweep = 0; sweep < 40; ++sweep) {
-    if (tid == 0) sh.flag = 0;
-    __syncthreads();
+    int flag = 0;
     for (int j = 0; j < 3; ++j) {
-      if (tid == 0) sh.now[j] -= sh.d[j];
-      __syncthreads();
+      now[j] -= d[j];
       float sc = evaluate(); ++nev;
-      bool better = (double)sc > sh.rt;  // uniform: sh.rt only changes between sweeps
-      if (better) { if (tid == 0) sh.flag = 1; __syncthreads(); continue; }
-      if (tid == 0) sh.now[j] += 2. * sh.d[j];
-      __syncthreads();
+      if ((double)sc > rt) { flag = 1; continue; }          // (rt only changes between sweeps)
+      now[j] += 2. * d[j];
       sc = evaluate(); ++nev;
-      better = (double)sc > sh.rt;
-      if (better) { if (tid == 0) sh.flag = 1; __syncthreads(); continue; }
-      if (tid == 0) { sh.now[j] -= sh.d[j]; sh.d[j] *= 0.8; }
-      __syncthreads();
+      if ((double)sc > rt) { flag = 1; continue; }
+      now[j] -= d[j]; d[j] *= 0.8;
     }
     const float sc = evaluate(); ++nev;
-    __syncthreads();
-    const int flag = sh.flag;
-    __syncthreads();
-    if (tid == 0 && (double)sc > sh.rt) sh.rt = (double)sc;
-    __syncthreads();
+    if ((double)sc > rt) rt = (double)sc;
     if (!flag) break;
   }
-  if (tid == 0) {
-    out[e * 5 + 0] = cx; out[e * 5 + 1] = cy; out[e * 5 + 2] = sh.now[0]; out[e * 5 + 3] = sh.now[1];
-    out[e * 5 + 4] = sh.now[2] / 180.0 * PI_REF;
+  if (lane == 0) {
+    out[e * 5 + 0] = cx; out[e * 5 + 1] = cy; out[e * 5 + 2] = now[0]; out[e * 5 + 3] = now[1];
+    out[e * 5 + 4] = now[2] / 180.0 * PI_REF;
     if (evals) evals[e] = nev;
   }
 }
@@ -266,9 +299,9 @@ extern "C" int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t*
                                 void* stream) {
   EGNE_REQUIRE(mask && frame_of && cls && xs && ys && init && out, "ellipse_fit: null pointer");
   EGNE_REQUIRE(n > 0 && nframes > 0 && H > 1 && W > 1, "ellipse_fit: bad shape");
-  const size_t lds = ((size_t)H * ((W + 31) / 32) + W + H) * 4;
-  EGNE_REQUIRE(lds <= 120 * 1024, "ellipse_fit: %dx%d mask does not fit LDS", H, W);
-  hipLaunchKernelGGL(ellipse_fit_k, dim3(n), dim3(NT), lds, (hipStream_t)stream, (const long long*)mask, nframes, frame_of, cls, H,
-                     W, xs, ys, init, out, evals);
+  const size_t lds = ((size_t)FIT_WAVES * H * ((W + 31) / 32) + W + H) * 4;
+  EGNE_REQUIRE(lds <= 60 * 1024, "ellipse_fit: %dx%d masks do not fit LDS", H, W);
+  hipLaunchKernelGGL(ellipse_fit_k, dim3((n + FIT_WAVES - 1) / FIT_WAVES), dim3(64 * FIT_WAVES), lds, (hipStream_t)stream, (const long long*)mask,
+                     nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
   return egne::check_launch("egne_ellipse_fit");
 }

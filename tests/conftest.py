@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (as egne_amd/__init__.py: before the first HIP call of the process)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
