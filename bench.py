@@ -432,6 +432,7 @@ class Bench:
         # the host.  The fit of batch i runs on a second HIP stream next to the network of batch i+1 (a sequential search on
         # 2B workgroups leaves most of the chip idle); the host takes delivery of batch i-1's ellipses before it queues batch i+1.
         host = [torch.empty((B, 2, 5), dtype=torch.float64).pin_memory() for _ in range(2)] if fit else None
+        # (EGNE_FIT_PRIO=1: the network's two streams at high priority, the fit stream at normal priority -- measured)
         side = torch.cuda.Stream(device=dev) if fit else None
         state = {"n": 0, "done": [None, None]}
 

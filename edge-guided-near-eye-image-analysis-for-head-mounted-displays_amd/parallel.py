@@ -26,7 +26,9 @@ def init(backend=None):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # nccl = RCCL over xGMI, one rank per GPU.  EGNE_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) --
+        # what the two-rank test of tests/test_gpu_scripts.py uses on a one-GPU box
+        backend = backend or os.environ.get("EGNE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world)
     return dist.get_rank(), dist.get_world_size()
 

@@ -21,7 +21,9 @@ class TwoStagePipeline:
 
     def __init__(self, args, edge_model, device):
         self.args, self.edge_model, self.device = args, edge_model, device
-        self.sa, self.sb = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        import os
+        prio = -1 if os.environ.get("EGNE_FIT_PRIO") == "1" else 0
+        self.sa, self.sb = torch.cuda.Stream(device=device, priority=prio), torch.cuda.Stream(device=device, priority=prio)
         self.slots, self.ready, self.freed = [None, None], [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
         self.pending = []           # (slot, second_stage) of batches whose edge maps are queued
         self.keep = []              # (done event, closure, frames): kept alive until the second stream has finished with them

@@ -86,3 +86,27 @@ def eval_b1_batch():
               spatWts=torch.zeros(1, H, W), distMap=torch.zeros(1, 3, H, W), cond=torch.zeros(1, 4),
               ID=torch.zeros(1, dtype=torch.long), alpha=0)
     return b1
+
+
+def mask_mismatch(mask, g, what, budget_key="gap_lt_2e3"):
+    """Argmax-mask identity against a fixture, PIXEL by pixel (BASELINE.json: "argmax masks bit-identical"): ``mask`` [B,H,W] class
+    indices, fixture ``mask`` / ``mask2`` = np.packbits of (reference argmax == 1) / (== 2).  Returns the number of differing
+    pixels and asserts it stays within the fixture's count of near-tie pixels (two largest reference logits within 2e-3) -- and is
+    ZERO where the fixture has no near tie.  Every call appends its counts to gpurun_out/mask_mismatch.jsonl (copied to profiles/)."""
+    import json
+    m = np.asarray(mask).astype(np.uint8)
+    r1 = np.unpackbits(g["mask"])[:m.size].reshape(m.shape).astype(bool)
+    r2 = np.unpackbits(g["mask2"])[:m.size].reshape(m.shape).astype(bool)
+    ref = r1.astype(np.uint8) + 2 * r2.astype(np.uint8)
+    ndiff = int(np.count_nonzero(m != ref))
+    budget = int(np.asarray(g[budget_key]).sum())
+    rec = {"case": what, "pixels": int(m.size), "mismatch_pixels": ndiff, "near_tie_pixels_lt_2e-3": budget}
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "mask_mismatch.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    print("mask identity %s: %d of %d pixels differ (near-tie pixels in the fixture: %d)" % (what, ndiff, m.size, budget))
+    assert ndiff <= budget, "%s: argmax mask differs in %d pixels, the fixture has only %d near-tie pixels" % (what, ndiff, budget)
+    return ndiff

@@ -104,16 +104,17 @@ def test_esf_eval_b64_vs_reference(name):
         v = t.cpu().numpy()
         np.testing.assert_allclose(v.reshape((rep, 2) + v.shape[1:]), np.broadcast_to(g[k][None], (rep,) + g[k].shape), atol=TOL)
     np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-3)
+    from common import mask_mismatch
     mask = m.predictions().cpu().numpy().astype(np.uint8).reshape(rep, 2, 240, 320)
-    bad = 0
-    for r in range(rep):
-        bad = max(bad, np.count_nonzero(np.packbits(mask[r] == 1) != g["mask"]) + np.count_nonzero(np.packbits(mask[r] == 2) != g["mask2"]))
-    assert bad <= 2 * int(g["gap_lt_2e3"]), "mask differs in %d packed bytes (near-tie budget %d)" % (bad, int(g["gap_lt_2e3"]))
+    worst = max(range(rep), key=lambda r: int(np.count_nonzero(mask[r] != mask[0])))        # (every tile holds the same two frames)
+    bad = mask_mismatch(mask[0], g, name + " (eval, B=64 plan, first tile)")
+    if worst != 0:
+        bad = max(bad, mask_mismatch(mask[worst], g, name + " (eval, B=64 plan, most deviating tile %d)" % worst))
     kinds = _kinds(m._last_plan)
     assert any(k.startswith("conv_f16x3:") for k in kinds), kinds
     if name == "esf_edge_b2":        # the benchmarked configuration: fused pairs, the convBlock head, one-pass Transition_down
         assert {"conv_f16x3:fused1x1", "conv_f16x3:fused3x3c4", "conv_f16x3:tdpool1x1"} <= kinds and kinds & {"conv_f16x3:rs", "conv_f16x3:rw"}, kinds
-    print("%s at B=64: logits err %.2e, worst mask byte diff %d, kernels %s" % (name, err, bad, sorted(kinds)))
+    print("%s at B=64: logits err %.2e, worst mask pixel diff %d, kernels %s" % (name, err, bad, sorted(kinds)))
 
 
 @pytest.mark.parametrize("name", ["esf_edge_b2", "esf_edge_b2_absent1"])

@@ -82,8 +82,9 @@ def test_evaluate_on_real_video_frames():
         # identical masks, except at pixels whose top-2 logit gap in the reference is below 2e-3 (counted in the fixture)
         r1 = np.unpackbits(g["masks"][2 * k]).reshape(H, W).astype(bool)
         r2 = np.unpackbits(g["masks"][2 * k + 1]).reshape(H, W).astype(bool)
-        ndiff = int(np.count_nonzero((seg[k] == 1) != r1) + np.count_nonzero((seg[k] == 2) != r2))
-        assert ndiff <= 2 * int(g["gap_lt_2e3"][k]), "mask %d differs in %d pixels (near-tie budget %d)" % (k, ndiff, g["gap_lt_2e3"][k])
+        ndiff = int(np.count_nonzero(np.asarray(seg[k]) != (r1.astype(np.int64) + 2 * r2.astype(np.int64))))
+        print("real video frame %d: %d mask pixels differ (near-tie pixels in the fixture: %d)" % (k, ndiff, int(g["gap_lt_2e3"][k])))
+        assert ndiff <= int(g["gap_lt_2e3"][k]), "mask %d differs in %d pixels (near-tie budget %d)" % (k, ndiff, g["gap_lt_2e3"][k])
     # fit stage alone: reference masks + reference initial ellipses -> bit-identical result
     masks = np.stack([np.unpackbits(g["masks"][2 * k]).reshape(H, W).astype(np.int64)
                       + 2 * np.unpackbits(g["masks"][2 * k + 1]).reshape(H, W).astype(np.int64) for k in range(4)])
@@ -125,3 +126,56 @@ def test_evaluate_video_end_to_end(tmp_path):
         frames = list(E.mjpeg_frames(str(tmp_path / name)))
         assert len(frames) == 4 and frames[0].shape == (240, 640)
     assert os.path.exists(tmp_path / "clip_pred2_baseline.npy")
+
+
+_DP_TRAIN_WORKER = r"""
+import os, sys, json, hashlib
+sys.path.insert(0, %(root)r)
+import torch
+import egne_amd
+from egne_amd import parallel, train, _entry
+out = sys.argv[1]
+model = train.main(["--synthetic", "16", "--batchsize", "4", "--epochs", "1", "--setting", "configs/baseline_edge.yaml", "--curObj", "x",
+                    "--expname", "dp2_rank" + os.environ["RANK"], "--pipeline", sys.argv[2]] + sys.argv[3:])
+rank, world = parallel.rank(), parallel.world_size()
+h = hashlib.sha256()
+for n, p in sorted(model.state_dict().items()):
+    if "num_batches_tracked" in n or "running_" in n or "dsIdentify" in n:
+        continue            # BatchNorm statistics are per rank between validations (DataParallel keeps replica 0's), the identity head is outside the optimiser
+    h.update(p.detach().float().cpu().numpy().tobytes())
+ts, _ = parallel.samplers(_entry.SyntheticEyes(16, seed=1234), _entry.SyntheticEyes(4, seed=99), rank, world)
+ts.set_epoch(0)
+json.dump({"rank": rank, "world": world, "sha": h.hexdigest(), "shard": list(ts),
+           "w0": float(model.enc.head.conv1.weight.detach().double().sum())}, open(os.path.join(out, "rank%%d.json" %% rank), "w"))
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("pipeline,extra", [("0", []), ("1", ["--prec", "16"])])
+def test_train_py_two_ranks_one_epoch(tmp_path, pipeline, extra):
+    """train.py --synthetic for one epoch on TWO ranks (torch.distributed, gloo backend with both ranks on this GPU: RCCL refuses two
+    ranks on one device, and the pool's boxes have one): disjoint shards of one per-epoch permutation, one gradient all-reduce per
+    step, identical weights on both ranks afterwards, different from the initial weights (train.py:205,262-287 with nn.DataParallel
+    replaced by one process per GPU).  Second case: the default pipeline and --prec 16 (bf16 activation storage)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_train_worker.py"
+    script.write_text(_DP_TRAIN_WORKER % dict(root=root))
+    port = 29700 + (os.getpid() % 200) + (0 if pipeline == "0" else 1)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", LOCAL_RANK="0", EGNE_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(tmp_path), pipeline] + extra, env=dict(env, RANK=str(r)), cwd=str(tmp_path),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert [x["world"] for x in res] == [2, 2]
+    assert res[0]["sha"] == res[1]["sha"], "the ranks ended the epoch with different weights"
+    assert not set(res[0]["shard"]) & set(res[1]["shard"]) and len(res[0]["shard"]) == len(res[1]["shard"]) == 8
+    from common import esf_module
+    w_init = float(esf_module("baseline_edge").enc.head.conv1.weight.detach().double().sum())
+    assert abs(res[0]["w0"] - w_init) > 1e-6, "the weights did not move"
