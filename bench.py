@@ -338,6 +338,7 @@ class Bench:
         _engine.EVENT_KINDS = None if self.a.layers else {"conv_f16x3", "conv_bf16", "conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad"}
         self.barrier()
         t0 = time.perf_counter()
+        out = None
         for _ in range(steps):
             out = step()
         last = flush()              # ... and drained inside it: exactly K batches take the whole path
@@ -484,7 +485,7 @@ class Bench:
     def leg_infer(self, steps, warmup, fit=False, events=True, pipeline=None):
         B = self.a.batch or 64
         dt, ev, out = self.timed(self.infer_step(B, fit, pipeline), steps, warmup, events)
-        assert self.torch.isfinite(out[3]).all()
+        assert steps == 0 or self.torch.isfinite(out[3]).all()
         return B, dt, ev
 
     def leg_train(self, steps, warmup, events=True, pipeline=None, storage="fp32"):
@@ -530,7 +531,7 @@ class Bench:
         step.flush = flush
         self.ar_events = []
         dt, ev, out = self.timed(step, steps, warmup, events)
-        assert torch.isfinite(out[3]).all()
+        assert steps == 0 or torch.isfinite(out[3]).all()
         ar = [a.elapsed_time(b) for a, b in self.ar_events[-steps:]] if self.ar_events else []
         self.allreduce_ms = round(sum(ar) / len(ar), 4) if ar else 0.0
         self.grad_bytes = int(net._grad_flat.numel() * 4) if getattr(net, "_grad_flat", None) is not None else 0
@@ -571,6 +572,16 @@ def main():
              "exact fp32 elsewhere; training: split-f16 products for the 3x3 forward convolutions, their data and weight gradients (pre-scales "
              "measured on the device every step), exact fp32 MFMA for 1x1 convolutions and everything else")
 
+    if a.steps == 0:
+        # warm-up only (plan building, weight packing, calibration, W untimed steps, nothing else): the run a profiler trace of
+        # `--steps K` is compared with, so that per-step kernel counts and times of the STEADY state come out by subtraction
+        if a.mode == "train":
+            bn.leg_train(0, a.warmup, events=False, pipeline=not a.no_pipeline, storage="bf16" if a.train_storage in ("bf16", "both") else "fp32")
+        else:
+            bn.leg_infer(0, a.warmup, fit=a.fit, events=False, pipeline=not a.no_pipeline)
+        if rank == 0:
+            print(json.dumps({"warmup_only": True, "warmup": a.warmup, "mode": a.mode}), flush=True)
+        return
     if a.mode in ("all", "infer"):
         fit_ = a.fit and a.mode == "infer"
         if a.no_pipeline:
@@ -675,6 +686,14 @@ def main():
             r["region_ms_per_step"] = round(1e3 * dt_k / steps, 3)
             r["measured_in"] = meas
             r.setdefault("traffic_source", "not measured in this run")
+        if rbf and storage == "bf16" and B == 256 and a.config == "baseline_edge" and a.chz == 32:
+            try:        # HBM bytes per launch of the bf16 family from the committed PMC passes of the same command (not measured in this run)
+                with open(os.path.join(ROOT, "profiles", ROUND + "_pmc_traffic_train_b256.json")) as f:
+                    rbf["traffic"] = json.load(f)["families"]["bf16_conv"]["hbm_bytes_per_launch"]
+                rbf["traffic_source"] = ("copied from profiles/%s_pmc_traffic_train_b256.json (rocprofv3 --pmc passes over `bench.py --mode train --train-batch 256 "
+                                         "--train-storage bf16 --no-pipeline`, FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run" % ROUND)
+            except Exception:
+                pass
         cands = sorted([r for r in (rbf, rsp, r32) if r and r["time_share"] > 0], key=lambda r: -r["time_share"])
         rdom, rsec = cands[0], (cands[1] if len(cands) > 1 else None)        # the family with the larger share of the step first
         which = {"baseline_edge": "configs[2]", "baseline_adain_edge": "configs[3] (per-GPU shard: 256 of the global 1024)"}.get(a.config, a.config)
