@@ -96,6 +96,8 @@ SIGNATURES = {
     "egne_norm_act_pool2": (i32, [vp, i64, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_maxpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_upsample2x_nearest": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_upsample2x_nearest_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_nchw_to_nhwc": (i32, [vp, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     "egne_nhwc_to_nchw": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, vp]),
     "egne_bdcn_stage_scores": (i32, [C.POINTER(vp), i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -142,7 +144,7 @@ SIGNATURES = {
 # Entry points with a bf16-storage twin (same arguments, activation pointers are bf16; suffix _bf16): training plans that keep
 # activations and activation gradients as bf16 in HBM (engine.Plan(dtype=torch.bfloat16)).  Descriptor-based convolutions carry
 # the storage type in egne_conv_desc.dtype instead.
-BF16_TWINS = ["egne_norm_stats", "egne_affine", "egne_avgpool2", "egne_norm_act_pool2", "egne_upsample2x", "egne_nchw_to_nhwc",
+BF16_TWINS = ["egne_upsample2x_nearest", "egne_upsample2x_nearest_bwd", "egne_norm_stats", "egne_affine", "egne_avgpool2", "egne_norm_act_pool2", "egne_upsample2x", "egne_nchw_to_nhwc",
               "egne_ellipse_head_act", "egne_selu_inplace", "egne_spatial_mean", "egne_softmax3", "egne_adain", "egne_conf_loss",
               "egne_loss_bwd", "egne_act_bwd_bias", "egne_norm_pool2_bwd", "egne_norm_bwd_store", "egne_norm_bwd",
               "egne_avgpool2_bwd", "egne_upsample2x_bwd", "egne_ellipse_head_act_bwd", "egne_selu_bwd", "egne_softmax3_bwd",

@@ -349,6 +349,24 @@ __global__ void upsample2x_bwd_k(const T* __restrict__ gy, long long gs, int go,
   }
 }
 
+// transpose of the nearest-neighbour x2 up-sampling: gx[y][x] += the four output pixels that copied it
+template <typename T>
+__global__ void upsample2x_nearest_bwd_k(const T* __restrict__ gy, long long gs, int go, T* __restrict__ gx, long long xs, int xo, int B, int H, int W, int Cp) {
+  const int nv = Cp >> 2, Wo = 2 * W, Ho = 2 * H;
+  const long long total = (long long)B * H * W * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv) * 4;
+    long long p = i / nv;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    const T* s = gy + (((long long)b * Ho + 2 * y) * Wo + 2 * x) * gs + go + c;
+    const f32x4 acc = (ld4(s) + ld4(s + gs)) + (ld4(s + (long long)Wo * gs) + ld4(s + (long long)Wo * gs + gs));
+    T* dp = gx + (((long long)b * H + y) * W + x) * xs + xo + c;
+    st4(dp, ld4(dp) + acc);
+  }
+}
+
 template <typename T>
 __global__ void head_act_bwd_k(T* __restrict__ g, const T* __restrict__ y, int B, int ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -896,6 +914,20 @@ extern "C" int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* g
 extern "C" int egne_upsample2x_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W,
                                         int Cp, void* stream) {
   return upsample2x_bwd_impl((const egne_bf16*)gy, gs, go, (egne_bf16*)gx, xs, xo, B, H, W, Cp, stream);
+}
+
+template <typename T>
+static int upsample2x_nearest_bwd_impl(const T* gy, int64_t gs, int go, T* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(gy, gs, go, Cp) && slice_ok(gx, xs, xo, Cp) && B > 0 && H > 0 && W > 0, "upsample2x_nearest_bwd: bad arguments");
+  hipLaunchKernelGGL(upsample2x_nearest_bwd_k<T>, dim3(grid_for((long long)B * H * W * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, gy,
+                     (long long)gs, go, gx, (long long)xs, xo, B, H, W, Cp);
+  return egne::check_launch("egne_upsample2x_nearest_bwd");
+}
+extern "C" int egne_upsample2x_nearest_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream) {
+  return upsample2x_nearest_bwd_impl(gy, gs, go, gx, xs, xo, B, H, W, Cp, stream);
+}
+extern "C" int egne_upsample2x_nearest_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream) {
+  return upsample2x_nearest_bwd_impl((const egne_bf16*)gy, gs, go, (egne_bf16*)gx, xs, xo, B, H, W, Cp, stream);
 }
 
 template <typename T>

@@ -247,6 +247,18 @@ __global__ void upsample2x_k(const T* __restrict__ x, long long xs, int xo, T* _
   st4(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, r);
 }
 
+// F.interpolate(scale_factor=2, mode='nearest') (models/RITnet_v1.py:89): y[oy][ox] = x[oy >> 1][ox >> 1]
+template <typename T>
+__global__ void upsample2x_nearest_k(const T* __restrict__ x, long long xs, int xo, T* __restrict__ y, long long ys, int yo, int B, int H, int W, int Cp) {
+  const int Wo = 2 * W, Ho = 2 * H;
+  const unsigned nv = Cp >> 2;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)Wo * nv) return;
+  const int ox = (int)(t / nv), c = (int)(t - ox * nv) * 4;
+  const int oy = blockIdx.y, b = blockIdx.z;
+  st4(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c, ld4(x + (((long long)b * H + (oy >> 1)) * W + (ox >> 1)) * xs + xo + c));
+}
+
 template <typename T>
 __global__ void nchw_to_nhwc_k(const float* __restrict__ x, int B, int C, int H, int W, T* __restrict__ y,
                                long long ys, int yo, int Cp) {
@@ -471,6 +483,21 @@ extern "C" int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int
 extern "C" int egne_upsample2x_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W,
                                     int Cp, void* stream) {
   return upsample2x_impl((const egne_bf16*)x, xs, xo, (egne_bf16*)y, ys, yo, B, H, W, Cp, stream);
+}
+
+template <typename T>
+static int upsample2x_nearest_impl(const T* x, int64_t xs, int xo, T* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp), "upsample2x_nearest: bad slices");
+  EGNE_REQUIRE(B > 0 && H > 0 && W > 0 && 2 * H <= 65535 && B <= 65535, "upsample2x_nearest: bad shape");
+  hipLaunchKernelGGL(upsample2x_nearest_k<T>, dim3((2 * W * (Cp / 4) + 255) / 256, 2 * H, B), dim3(256), 0, (hipStream_t)stream, x, (long long)xs, xo,
+                     y, (long long)ys, yo, B, H, W, Cp);
+  return egne::check_launch("egne_upsample2x_nearest");
+}
+extern "C" int egne_upsample2x_nearest(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+  return upsample2x_nearest_impl(x, xs, xo, y, ys, yo, B, H, W, Cp, stream);
+}
+extern "C" int egne_upsample2x_nearest_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
+  return upsample2x_nearest_impl((const egne_bf16*)x, xs, xo, (egne_bf16*)y, ys, yo, B, H, W, Cp, stream);
 }
 
 template <typename T>

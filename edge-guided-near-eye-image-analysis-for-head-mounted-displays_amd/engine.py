@@ -1411,6 +1411,16 @@ class Plan:
                        name + ".bwd")
             self.tape.append(emit)
 
+    def upsample2x_nearest(self, src, dst, B, H, W, name="upsample_nn"):
+        """F.interpolate(scale_factor=2, mode='nearest') (models/RITnet_v1.py:89)."""
+        assert src.Cp == dst.Cp
+        self._add(self.L.egne_upsample2x_nearest, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, src.Cp), name, kind="upsample2x")
+        if self.train:
+            def emit(bw, src=src, dst=dst):
+                gs, gd = self.gp(src), self.gp(dst)
+                bw.raw(self.L.egne_upsample2x_nearest_bwd, (gd.ptr, gd.stride, gd.off, gs.ptr, gs.stride, gs.off, B, H, W, src.Cp), name + ".bwd")
+            self.tape.append(emit)
+
     def raw(self, fn, args, name):
         self._add(fn, args, name, kind=getattr(fn, "__name__", None) or "host")
 

@@ -67,6 +67,20 @@ def _cl(conv, layout, pad=(0, 0), act=ACT_NONE, **kw):
 _cl.eval_plan = False
 
 
+def concat_members(pl, nb, h, w, chans):
+    """Pieces for the members of a would-be torch.cat.  fp32 plans: channel slices of ONE buffer (a 32-channel slice is 128
+    contiguous bytes per pixel: a whole cache line).  bf16 plans: a buffer per member -- the memory system fetches 128-byte
+    lines, so a 64-byte slice of a wider pixel row streams at half rate (measured: 2.55 vs 5.04 TB/s, scratch/bf16_stride.py),
+    while a tensor of its own is contiguous from pixel to pixel."""
+    if pl.bf16:
+        return [Piece(pl.buf(nb, h, w, pad8(c)), 0, c) for c in chans]
+    b, out, off = pl.buf(nb, h, w, sum(pad8(c) for c in chans)), [], 0
+    for c in chans:
+        out.append(Piece(b, off, c))
+        off += pad8(c)
+    return out
+
+
 def _lay(pieces):
     return [(p.C, p.Cp) for p in pieces]
 
@@ -187,17 +201,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     res = [(H >> i, W >> i) for i in range(5)]
 
     def slices(nb, h, w, chans):
-        """Pieces for the members of a would-be torch.cat.  fp32 plans: channel slices of ONE buffer (a 32-channel slice is 128
-        contiguous bytes per pixel: a whole cache line).  bf16 plans: a buffer per member -- the memory system fetches 128-byte
-        lines, so a 64-byte slice of a wider pixel row streams at half rate (measured: 2.55 vs 5.04 TB/s, scratch/bf16_stride.py),
-        while a tensor of its own is contiguous from pixel to pixel."""
-        if pl.bf16:
-            return [Piece(pl.buf(nb, h, w, pad8(c)), 0, c) for c in chans]
-        b, out, off = pl.buf(nb, h, w, sum(pad8(c) for c in chans)), [], 0
-        for c in chans:
-            out.append(Piece(b, off, c))
-            off += pad8(c)
-        return out
+        return concat_members(pl, nb, h, w, chans)
 
     def dbuf(i):
         h, w = res[i]
@@ -436,8 +440,17 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
             mod.append(q)
         xb = mod
 
-    # ---- regression module (utils.py:983-1037) ------------------------------------------------------
-    rg = model.elReg
+    regression_head(pl, model.elReg, xb, B, hb, wb, training)
+    loss_head(pl, opb, B, H, W, dev, training)
+    confusion_head(pl, model, fc, B, training, variant == "v2")
+    if training:
+        pl.build_backward()
+    return pl
+
+
+def regression_head(pl, rg, xb, B, hb, wb, training):
+    """regressionModule (utils.py:983-1037) on the bottleneck pieces ``xb`` [B, hb, wb]: sets pl.elOut (+ pl.g_elOut)."""
+    L = pl.L
     l = _cl(rg.c1, _lay(xb), act=ACT_LEAKY)
     h1, w1 = l.out_hw(hb, wb)
     r1 = pl.buf(B, h1, w1, 128)
@@ -474,7 +487,12 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
         pl.tape.append(lambda bw: bw.raw(_PyCall(lambda: pl.gbuf(r6).view(B, 16)[:, :10].copy_(pl.g_elOut)), (),
                                          "elOut.copy.bwd"))
 
-    # ---- loss head -----------------------------------------------------------------------------------
+
+
+def loss_head(pl, opb, B, H, W, dev, training):
+    """get_allLoss (models/RITnet_v2.py:372-432 = models/RITnet_v1.py:322-372) on the logits buffer ``opb`` [B,H,W,8]: the loss
+    kernel's descriptor, ground-truth staging tensors, argmax mask and NCHW logits."""
+    L = pl.L
     ld = _lib.LossDesc()
     pl.t_target = pl.vec(B, H, W, dtype=torch.int64)
     pl.t_spat = pl.vec(B, H, W)
@@ -514,9 +532,13 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
                                      pl.g_elOut.data_ptr()), "loss.bwd")
         pl.tape.append(emit_loss)
 
-    # ---- dataset-confusion head (RITnet_v2.py:343-350; loss.py:139-157) -------------------------------
+
+
+def confusion_head(pl, model, fc, B, training, enabled):
+    """dataset-confusion head (models/RITnet_v2.py:343-350 = RITnet_v1.py:297-307; loss.py:139-157) on pl.latent_p."""
+    L = pl.L
     pl.t_id = pl.vec(B, dtype=torch.int64)
-    if model.disentangle and variant == "v2":
+    if model.disentangle and enabled:
         lins = model.dsIdentify_lin.layersLin
         cur, cc = Piece(pl.latent_p, 0, fc), fc
         for i, lin in enumerate(lins):   # actBool=False, dropout 0: plain linear stack (utils.py:953-981)
@@ -541,6 +563,3 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
                                                 gpd.ptr, gpd.stride), "conf_loss.bwd")
             # tape order: the conf-loss emitter must run BEFORE the linear layers' backward, i.e. be appended last
             pl.tape.append(emit_conf)
-    if training:
-        pl.build_backward()
-    return pl

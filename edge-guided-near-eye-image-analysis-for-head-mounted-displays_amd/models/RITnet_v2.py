@@ -236,14 +236,17 @@ class DenseNet2D(nn.Module):
         st = self.storage_dtype if self.training else torch.float32
         key = (B, H, W, dev, bool(self.training), bool(self.disentangle), bool(self.toggle), st)
         if key not in self._plans:
-            self._plans[key] = build_forward_plan(self, B, H, W, dev, bool(self.training), dtype=st)
+            self._plans[key] = self._build_plan(B, H, W, dev, bool(self.training), st)
         return self._plans[key]
+
+    def _build_plan(self, B, H, W, dev, training, dtype):
+        return build_forward_plan(self, B, H, W, dev, training, dtype=dtype)
 
     def forward(self, x, x_edge, target, pupil_center, elNorm, spatWts, distMap, cond, ID, alpha):
         """models/RITnet_v2.py:261-354.  Returns (op, elPred, latent, loss[1], elOut)."""
         if self.variant == "v2":
             assert (self.setting["input_concat"] + self.setting["add_edge"] < 2), "edge can use only 1 time!"
-        else:
+        elif self.variant == "concat":
             assert self.setting["add_edge"] == 1
         require_cuda(x, "x")
         want_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())

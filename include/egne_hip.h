@@ -371,6 +371,13 @@ typedef struct {
 int64_t egne_loss_workspace_floats(int B, int H, int W);
 int egne_loss_fwd(const egne_loss_desc* d, void* stream);
 
+/* Nearest-neighbour x2 up-sampling of an NHWC slice and its transpose (gx += the four copies): F.interpolate(scale_factor=2,
+ * mode='nearest') of the comparator model models/RITnet_v1.py:89 (H, W = INPUT size).  bf16 twins: *_bf16. */
+int egne_upsample2x_nearest(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);
+int egne_upsample2x_nearest_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
+int egne_upsample2x_nearest_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);
+int egne_upsample2x_nearest_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
+
 /* regressionModule output activations (utils.py:1023-1036): tanh / sigmoid / identity split of the
  * 10 raw outputs, in place over [B,10] (row stride `ld`). */
 int egne_ellipse_head_act(float* x, int B, int ld, void* stream);

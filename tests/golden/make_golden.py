@@ -400,6 +400,47 @@ def gold_evaluate(bd):
          op_sub=np.stack(ops), gap_lt_2e3=np.array(gaps))
 
 
+def gold_ritnet_v1():
+    """The comparator model models/RITnet_v1.py (modelSummary.py:18-26 'ritnet_v1') on the golden batch: eval outputs, training
+    loss, BatchNorm running statistics, per-parameter gradient norms and a few full gradients."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models import RITnet_v1 as R1
+    m = quiet(R1.DenseNet2D)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=0, kind="esf"))
+    b = synth.make_batch(2, seed=1234)
+    args = batch_args(b, torch.zeros_like(b["img"]))
+    m.eval()
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut = quiet(m, *args)
+    srt = op.sort(dim=1, descending=True)[0]
+    arrs = dict(B=2, img_sha=sha(b["img"]), elOut=npy(elOut), elPred=npy(elPred), latent=npy(latent), loss=npy(loss),
+                op=npy(op[:, :, ::4, ::4]), op_sum=npy(op.double().sum((2, 3))), op_absmax=np.array(op.abs().max().item()),
+                mask=np.packbits(npy(op.max(1)[1]).astype(np.uint8) == 1), mask2=np.packbits(npy(op.max(1)[1]).astype(np.uint8) == 2),
+                gap_lt_2e3=np.array(int(((srt[:, 0] - srt[:, 1]) < 2e-3).sum())))
+    m.train()
+    m.zero_grad()
+    op, elPred, latent, loss, elOut = quiet(m, *args)
+    loss.sum().backward()
+    arrs.update(t_loss=npy(loss), t_elOut=npy(elOut), t_latent=npy(latent), t_op_sub=npy(op[:, :, ::4, ::4]),
+                t_bn1_rm=npy(m.enc.down_block1.bn.running_mean), t_bn1_rv=npy(m.enc.down_block1.bn.running_var),
+                t_bn5_rm=npy(m.enc.down_block5.bn.running_mean), t_bn5_rv=npy(m.enc.down_block5.bn.running_var))
+    names, gl2 = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            gl2.append(p.grad.double().norm().item())
+    arrs.update(grad_names=np.array(names), grad_l2=np.array(gl2))
+    for k in ("elReg.l2.weight", "dec.final.weight", "enc.down_block1.conv1.weight", "enc.down_block3.conv31.weight", "dec.up_block4.conv11.bias"):
+        arrs["grad::" + k] = npy(dict(m.named_parameters())[k].grad)
+    save("ritnet_v1_b2", **arrs)
+    import json
+    keys = os.path.join(HERE, "state_keys.json")
+    d = json.load(open(keys))
+    d["ritnet_v1"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(keys, "w") as f:
+        json.dump(d, f, indent=0)
+
+
 def gold_keys():
     """Checkpoint key schema (name -> shape) of every reference module on the path."""
     import json
@@ -417,7 +458,7 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate"]
+    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate", "ritnet_v1"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
@@ -439,3 +480,5 @@ if __name__ == "__main__":
         gold_keys()
     if "evaluate" in what:
         gold_evaluate(bd or ref_bdcn())
+    if "ritnet_v1" in what:
+        gold_ritnet_v1()

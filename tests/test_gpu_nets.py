@@ -457,3 +457,71 @@ def test_backward_only_supports_the_loss(edge_of):
     op = m(*args)[0]
     with pytest.raises(NotImplementedError):
         op.sum().backward()
+
+
+# ---------------------------------------------------------------------------------------------
+# comparator model of the reference's registry: models/RITnet_v1.py ('ritnet_v1', modelSummary.py:18-26)
+# ---------------------------------------------------------------------------------------------
+def _v1_model():
+    from egne_amd import synth
+    from egne_amd.modelSummary import get_model
+    m = get_model("ritnet_v1", None)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=0, kind="esf"))
+    return m.to(DEV)
+
+
+def _v1_args():
+    from common import batch_args
+    from egne_amd import synth
+    b = synth.make_batch(2, seed=1234)
+    return [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, torch.zeros_like(b["img"]))]
+
+
+def test_ritnet_v1_eval_vs_reference():
+    """The comparator on the HIP path (same launch-plan machinery and kernels as ESF-Net + nearest-neighbour up-sampling) against the
+    reference-generated fixture: logits within 1e-3 relative to the largest logit (the untrained comparator's logits reach ~1e3),
+    ellipse head / latent at 1e-3, identical argmax masks."""
+    from common import gold, mask_mismatch
+    g = gold("ritnet_v1_b2")
+    m = _v1_model().eval()
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut = m(*_v1_args())
+    scale = float(g["op_absmax"])
+    err = np.abs(op.cpu()[:, :, ::4, ::4].numpy() - g["op"]).max()
+    assert err < 1e-3 * max(scale, 1.0), "logits off by %.2e (largest logit %.1f)" % (err, scale)
+    np.testing.assert_allclose(elOut.cpu().numpy(), g["elOut"], atol=TOL)
+    np.testing.assert_allclose(elPred.cpu().numpy(), g["elPred"], atol=TOL)
+    np.testing.assert_allclose(latent.cpu().numpy(), g["latent"], rtol=1e-3, atol=TOL)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-3)
+    mask_mismatch(m.predictions().cpu().numpy(), g, "ritnet_v1_b2 (eval, B=2)")
+    kinds = {k for k, _ in m._last_plan.meta}
+    assert any(k.startswith("conv_f16x3:") for k in kinds), kinds
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_ritnet_v1_train_step_vs_reference(storage):
+    """loss.backward() of the comparator against the reference's autograd: loss, BatchNorm running statistics, gradient norms, full
+    gradients (fp32 storage at the ESF-Net tolerances; bf16 storage at those of tests/test_gpu_bf16.py)."""
+    from common import gold
+    g = gold("ritnet_v1_b2")
+    m = _v1_model().to(storage).train()
+    op, elPred, latent, loss, elOut = m(*_v1_args())
+    bf = storage == torch.bfloat16
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g["t_loss"], rtol=1e-2 if bf else 1e-3)
+    np.testing.assert_allclose(m.enc.down_block1.bn.running_mean.cpu().numpy(), g["t_bn1_rm"], rtol=2e-2 if bf else 1e-4, atol=2e-3 if bf else 1e-5)
+    np.testing.assert_allclose(m.enc.down_block5.bn.running_var.cpu().numpy(), g["t_bn5_rv"], rtol=5e-2 if bf else 1e-3, atol=2e-3 if bf else 1e-5)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([params[n].grad.double().norm().item() for n in names])
+    rel = np.abs(got - g["grad_l2"]) / np.maximum(g["grad_l2"], 1e-6 * g["grad_l2"].max())
+    print("ritnet_v1 %s storage: grad-norm rel median %.2e max %.2e (%s)" % ("bf16" if bf else "fp32", np.median(rel), rel.max(), names[int(np.argmax(rel))]))
+    if bf:
+        assert np.median(rel) < 3e-2 and np.sort(rel)[int(0.9 * len(rel))] < 2e-1
+    else:
+        assert rel.max() < 1e-2
+        for k in ("elReg.l2.weight", "dec.final.weight", "enc.down_block1.conv1.weight", "enc.down_block3.conv31.weight", "dec.up_block4.conv11.bias"):
+            r = g["grad::" + k]
+            e = np.abs(params[k].grad.cpu().numpy() - r).max()
+            assert e <= 1.5e-2 * np.abs(r).max() + 1e-7, "%s: max err %.3e (scale %.3e)" % (k, e, np.abs(r).max())

@@ -22,8 +22,11 @@ def test_state_dict_schema_matches_reference():
     cfgd = os.path.join(os.path.dirname(egne_amd.__file__), "configs")
     got = {k: list(v.shape) for k, v in bdcn_module().state_dict().items()}
     assert got == ref["bdcn"]
+    from egne_amd.modelSummary import get_model, model_dict
+    assert {"ritnet_v1", "ritnet_v2", "ritnet_concat"} <= set(model_dict)             # modelSummary.py:18-26 registry
+    assert {k: list(v.shape) for k, v in get_model("ritnet_v1", None).state_dict().items()} == ref["ritnet_v1"]
     for key, want in ref.items():
-        if key == "bdcn":
+        if key in ("bdcn", "ritnet_v1"):
             continue
         parts = key.split(":")
         st = yaml.safe_load(open(os.path.join(cfgd, parts[1] + ".yaml")))

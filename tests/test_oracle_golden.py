@@ -225,3 +225,32 @@ def test_spatial_weights_restatement_properties():
     assert e2[11, :].all() and e2.sum() == 48
     assert (w[2][11] == 21).all() and (w[2][12] == 21).all() and (w[2] == 21).sum() == 96      # dilated one row down
     assert (oprep.spatial_weights(lab[1:2]) == w[1:2]).all()
+
+
+def test_ritnet_v1_comparator_vs_reference():
+    """oracle/ritnet_v1.py (the comparator models/RITnet_v1.py) against the fixture the reference itself produced: eval outputs,
+    training loss, BatchNorm running statistics and parameter gradient norms."""
+    from common import batch_args, gold
+    from egne_amd import synth
+    from egne_amd.models.RITnet_v1 import DenseNet2D
+    from oracle import ritnet_v1 as o
+    g = gold("ritnet_v1_b2")
+    sd0 = synth.seeded_state_dict(DenseNet2D().state_dict(), seed=0, kind="esf")
+    b = synth.make_batch(2, seed=1234)
+    args = batch_args(b, torch.zeros_like(b["img"]))
+    with torch.no_grad():
+        op, elPred, latent, loss, elOut, _ = o.ritnet_v1_forward(sd0, *args)
+    assert np.abs(op[:, :, ::4, ::4].numpy() - g["op"]).max() < 2e-4 * float(g["op_absmax"])
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
+    np.testing.assert_allclose(elOut.numpy(), g["elOut"], atol=2e-5)
+    np.testing.assert_allclose(latent.numpy(), g["latent"], atol=2e-4)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd0.items()}
+    upd = {}
+    out = o.ritnet_v1_forward(sd, *args, training=True, update=upd)
+    out[3].sum().backward()
+    np.testing.assert_allclose(out[3].detach().numpy(), g["t_loss"], rtol=2e-5)
+    np.testing.assert_allclose(upd["enc.down_block1.bn.running_mean"].numpy(), g["t_bn1_rm"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(upd["enc.down_block5.bn.running_var"].numpy(), g["t_bn5_rv"], rtol=1e-4, atol=1e-5)
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([sd[n].grad.double().norm().item() for n in names])
+    assert (np.abs(got - g["grad_l2"]) / np.maximum(g["grad_l2"], 1e-6 * g["grad_l2"].max())).max() < 2e-3
