@@ -232,3 +232,50 @@ extern "C" int egne_spatial_weights(const int64_t* label, int B, int H, int W, f
   hipLaunchKernelGGL(spatial_weights_k, dim3(B), dim3(1024), lds, (hipStream_t)stream, (const long long*)label, H, W, out);
   return egne::check_launch("egne_spatial_weights");
 }
+
+// ---- batched augmentation (data_augment.py:12-130, applied per sample in CurriculumLib.py:114-120) -------------------------
+// The branches of augment() that are plain NumPy: 0 flip left-right (:25-36), 2 gamma through a 256-entry table (:44-49; the
+// table itself is built on the host with the reference's expression, the device only looks it up), 3 exposure (:51-56),
+// 4 additive Gaussian noise (:58-65), >= 7 no change (:121-124).  Arithmetic in double as NumPy does it, clip to [0, 255] and
+// truncate towards zero (ndarray.astype(np.uint8) of a non-negative double).  param[b]: exposure offset (3) or noise standard
+// deviation (4); noise: the standard-normal draws [B,H,W] (only read for choice 4).  One thread per 8 pixels of a row.
+namespace {
+
+__global__ __launch_bounds__(256) void augment_k(const unsigned char* __restrict__ img, const long long* __restrict__ label,
+                                                  const int* __restrict__ choice, const double* __restrict__ param,
+                                                  const unsigned char* __restrict__ lut, const double* __restrict__ noise,
+                                                  unsigned char* __restrict__ oimg, long long* __restrict__ olabel, int H, int W) {
+  const int b = blockIdx.y, ch = choice[b];
+  const long long fb = (long long)b * H * W;
+  const double p = param[b];
+  const int per_row = (W + 7) / 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * per_row; i += gridDim.x * blockDim.x) {
+    const int y = i / per_row, x0 = (i - y * per_row) * 8;
+    const long long r = fb + (long long)y * W;
+    for (int k = 0; k < 8 && x0 + k < W; ++k) {
+      const int x = x0 + k, xs = ch == 0 ? W - 1 - x : x;
+      const unsigned char v = img[r + xs];
+      unsigned char o = v;
+      if (ch == 2) o = lut[b * 256 + v];
+      else if (ch == 3 || ch == 4) {
+        double f = __dadd_rn((double)v, ch == 3 ? p : __dmul_rn(p, noise[r + x]));   // no fma: NumPy rounds the product first
+        f = f < 0.0 ? 0.0 : (f > 255.0 ? 255.0 : f);
+        o = (unsigned char)(int)f;
+      }
+      oimg[r + x] = o;
+      olabel[r + x] = label[r + xs];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int egne_augment(const uint8_t* img, const int64_t* label, const int32_t* choice, const double* param, const uint8_t* lut,
+                            const double* noise, uint8_t* out_img, int64_t* out_label, int B, int H, int W, void* stream) {
+  EGNE_REQUIRE(img && label && choice && param && lut && out_img && out_label && B > 0 && H > 0 && W > 0, "augment: bad arguments");
+  EGNE_REQUIRE((const void*)img != (const void*)out_img && (const void*)label != (const void*)out_label, "augment: in place is not supported (flip)");
+  const int per_row = (W + 7) / 8, blocks = (H * per_row + 255) / 256;
+  hipLaunchKernelGGL(augment_k, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, img, (const long long*)label, choice, param, lut,
+                     noise, out_img, (long long*)out_label, H, W);
+  return egne::check_launch("egne_augment");
+}

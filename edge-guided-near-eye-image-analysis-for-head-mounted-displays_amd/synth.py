@@ -193,3 +193,23 @@ def make_batch(B, H=H_DEF, W=W_DEF, seed=1234, mask_absent_every=8):
         distMap=torch.from_numpy(dist), pupil_center=torch.from_numpy(pc),
         elNorm=torch.from_numpy(eln), cond=torch.from_numpy(cond), ID=torch.from_numpy(ID),
         alpha=0.5)
+
+
+def augment_case(seed=7, H=H_DEF, W=W_DEF):
+    """One raw sample as the reference's Dataset hands it to data_augment.augment (CurriculumLib.py:114): uint8 frame, integer mask
+    with the ORIGINAL labels 0..3, pupil centre and (pupil, iris) ellipse parameters in pixels / radians.  Every third seed marks the
+    pupil as absent (all -1)."""
+    rng = np.random.RandomState(seed)
+    b = make_batch(1, H, W, seed=1000 + seed)
+    im = b["img"][0, 0].numpy()
+    base = np.clip((im - im.min()) / (im.max() - im.min()) * 255.0 + rng.uniform(-20, 20), 0, 255).astype(np.uint8)
+    mask = b["label"][0].numpy().astype(np.int64)
+    mask[mask > 0] += 1                                   # iris 2, pupil 3 as stored; sclera band below
+    mask[(mask == 0) & (rng.rand(H, W) < 0.2)] = 1
+    pupil_c = np.array([W * rng.uniform(0.3, 0.7), H * rng.uniform(0.3, 0.7)])
+    el = np.stack([np.array([pupil_c[0], pupil_c[1], rng.uniform(15, 30), rng.uniform(12, 25), rng.uniform(-1.5, 1.5)]),
+                   np.array([W * rng.uniform(0.3, 0.7), H * rng.uniform(0.3, 0.7), rng.uniform(50, 75), rng.uniform(50, 70), rng.uniform(-1.5, 1.5)])])
+    if seed % 3 == 0:
+        pupil_c[:] = -1
+        el[0, :] = -1
+    return base, mask, pupil_c, el

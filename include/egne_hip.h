@@ -522,6 +522,13 @@ int egne_zscore(const float* x, float* y, int B, int n, void* stream);
  *   [B,H,W] (class indices), out float32 [B,H,W].  PARITY UNPINNED: neither OpenCV nor a fixture of this function exists in the
  *   build container; the kernel is bit-identical to the restatement of OpenCV's published algorithm in oracle/dataprep.py. */
 int egne_spatial_weights(const int64_t* label, int B, int H, int W, float* out, void* stream);
+/* egne_augment: the NumPy branches of data_augment.augment (data_augment.py:12-130; called per sample from CurriculumLib.py:114-120)
+ *   over a batch: choice[b] = 0 flip left-right (image and label), 2 gamma = lut[b][pixel] (256-entry uint8 table per frame, built on
+ *   the host as the reference builds it), 3 exposure pixel + param[b], 4 noise pixel + param[b] * noise[b][y][x] (standard-normal
+ *   draws, double), >= 7 copy; double arithmetic, clip to [0,255], truncation.  The cv2 branches (1 blur, 5 lines, 6 rotate) are not
+ *   implemented: the host wrapper rejects them.  img / out_img uint8 [B,H,W], label / out_label int64 [B,H,W]; not in place. */
+int egne_augment(const uint8_t* img, const int64_t* label, const int32_t* choice, const double* param, const uint8_t* lut,
+                 const double* noise, uint8_t* out_img, int64_t* out_label, int B, int H, int W, void* stream);
 
 /*
  * ---- bf16 activation storage (training plans; BASELINE.json configs[2..4], reference loop train.py:262-287, --prec args.py:17-28) ----

@@ -441,6 +441,36 @@ def gold_ritnet_v1():
         json.dump(d, f, indent=0)
 
 
+def gold_augment():
+    """data_augment.augment (:12-130) for the branches that do not call into OpenCV (0 flip, 3 exposure, 4 noise, 7 none) and the
+    random branch selection itself: the outputs of the reference for seeded np.random states.  Branch 2 goes through cv2.LUT,
+    which the shim does not have: only its table (data_augment.py:47) is recorded."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        import data_augment as DA
+    arrs = {}
+    cases = [(0, 7, 100), (0, 9, 101), (3, 7, 102), (3, 8, 103), (4, 7, 104), (4, 9, 105), (7, 8, 106)]
+    # randomly selected branch (choice=None): np.random seeds whose first draw (data_augment.py:23) lands on a NumPy branch
+    want = {0: 1, 3: 2, 4: 2, 7: 1}
+    for s in range(200):
+        c = int(np.random.RandomState(s).randint(0, 8))
+        if want.get(c, 0) > 0:
+            want[c] -= 1
+            cases.append((-1 - c, 7 + s % 3, s))
+    for n, (choice, seed, npseed) in enumerate(cases):
+        base, mask, pc, el = synth.augment_case(seed)
+        np.random.seed(npseed)
+        ob, om, opc, (op_, oi) = DA.augment(base.copy(), mask.copy(), pc.copy(), el.copy(), choice=choice if choice >= 0 else None)
+        arrs["c%d_img_sha" % n] = np.array(sha(ob))
+        arrs["c%d_img_rows" % n] = ob[::16]
+        arrs["c%d_mask_sha" % n] = np.array(sha(om.astype(np.int64)))
+        arrs["c%d_pc" % n] = np.asarray(opc, np.float64)
+        arrs["c%d_el" % n] = np.stack([op_, oi]).astype(np.float64)
+    arrs["cases"] = np.array(cases)
+    for g in (0.6, 0.8, 1.2, 1.4):
+        arrs["gamma_table_%d" % int(g * 10)] = 255.0 * (np.linspace(0, 1, 256) ** g)
+    save("augment", **arrs)
+
+
 def gold_keys():
     """Checkpoint key schema (name -> shape) of every reference module on the path."""
     import json
@@ -458,7 +488,7 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate", "ritnet_v1"]
+    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate", "ritnet_v1", "augment"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
@@ -482,3 +512,5 @@ if __name__ == "__main__":
         gold_evaluate(bd or ref_bdcn())
     if "ritnet_v1" in what:
         gold_ritnet_v1()
+    if "augment" in what:
+        gold_augment()

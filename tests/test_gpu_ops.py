@@ -496,6 +496,59 @@ def test_dataprep_dist_maps_bit_exact_and_zscore(G):
     print("dist_maps: %.0f frames/s" % (64 * 5 / (e0.elapsed_time(e1) * 1e-3)))
 
 
+def test_augment_batch_vs_reference(G):
+    """Batched device augmentation (dataprep.hip egne_augment, egne_amd.data_augment) against the reference's own outputs
+    (tests/golden/augment.npz: flip / exposure / noise / none, branch given or drawn) bit for bit, one frame per launch as the
+    reference does it and all frames in ONE launch; the gamma branch against the oracle (its table is the reference's, the look-up
+    is unpinned); OpenCV branches are refused."""
+    import hashlib
+    from test_oracle_golden import _augment_cases
+    from egne_amd import data_augment as DA
+    from oracle import data_augment as oaug
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    cases = list(_augment_cases())
+    for n, choice, npseed, (base, mask, pc, el), exp, _ in cases:
+        np.random.seed(npseed)
+        ob, om, opc, (op_, oi) = DA.augment(base, mask, pc, el, choice if choice >= 0 else None)
+        assert ob.dtype == np.uint8 and sha(ob) == exp["img_sha"], "case %d: %d pixels differ in the sampled rows" % (n, (ob[::16] != exp["rows"]).sum())
+        assert sha(om.astype(np.int64)) == exp["mask_sha"], "case %d mask" % n
+        assert np.array_equal(opc, exp["pc"]) and np.array_equal(np.stack([op_, oi]), exp["el"]), "case %d geometry" % n
+    # one launch over a batch with mixed branches (explicit choices, host-drawn noise in the reference's order per frame)
+    ex = [c for c in cases if c[1] >= 0]
+    img = torch.from_numpy(np.stack([c[3][0] for c in ex])).cuda()
+    lab = torch.from_numpy(np.stack([c[3][1] for c in ex])).cuda()
+    pcs = torch.from_numpy(np.stack([c[3][2] for c in ex]))
+    els = torch.from_numpy(np.stack([c[3][3] for c in ex]))
+    np.random.seed(11)
+    oi_, ol_, pc_, el_, ch_ = DA.augment_batch(img, lab, pcs, els, choices=[c[1] for c in ex], host_noise=True)
+    np.random.seed(11)
+    for k, c in enumerate(ex):
+        wb, wm, wpc, (wp, wi) = oaug.augment(*c[3], c[1])
+        assert np.array_equal(oi_[k].cpu().numpy(), wb) and np.array_equal(ol_[k].cpu().numpy(), wm), "batched frame %d" % k
+        assert np.array_equal(pc_[k].numpy(), wpc) and np.array_equal(el_[k].numpy(), np.stack([wp, wi]))
+    # gamma: table of the reference, look-up on the device
+    base, mask, pc, el = cases[0][3]
+    for s in range(4):
+        np.random.seed(40 + s)
+        got = DA.augment(base, mask, pc, el, 2)
+        np.random.seed(40 + s)
+        want = oaug.augment(base, mask, pc, el, 2)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # device-drawn noise: right statistics (mean 0, the drawn standard deviation), untouched label
+    flat = torch.full((4, 240, 320), 128, dtype=torch.uint8).cuda()
+    np.random.seed(3)
+    o, l2, _, _, _ = DA.augment_batch(flat, lab[:1].repeat(4, 1, 1), pcs[:4], els[:4], choices=[4] * 4)
+    np.random.seed(3)
+    stds = [14 * np.random.rand() + 2 for _ in range(4)]
+    d = o.double() - 128.0
+    for k in range(4):
+        assert abs(d[k].mean().item() + 0.5) < 0.2 and abs(d[k].std().item() / stds[k] - 1) < 0.05    # truncation shifts the mean by -0.5
+    assert torch.equal(l2, lab[:1].repeat(4, 1, 1))
+    for c in (1, 5, 6):
+        with pytest.raises(NotImplementedError):
+            DA.augment(base, mask, pc, el, c)
+
+
 def test_deep_trunk_kernel_with_frame_tail(G):
     """conv4-like layer at a batch where the 256x256 launch is cut to whole rounds of workgroups and the remaining frames go to
     the 128x128 kernel (engine.BIG_SPLIT_TAIL): both launches together must equal the convolution of the whole batch

@@ -206,6 +206,33 @@ def test_dataprep_dist_maps_and_zscore():
     np.testing.assert_array_equal(oprep.zscore(g["img"]), g["z"])
 
 
+def _augment_cases():
+    import hashlib
+    from egne_amd import synth
+    g = gold("augment")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for n, (choice, seed, npseed) in enumerate(g["cases"].tolist()):
+        exp = dict(img_sha=str(g["c%d_img_sha" % n]), rows=g["c%d_img_rows" % n], mask_sha=str(g["c%d_mask_sha" % n]),
+                   pc=g["c%d_pc" % n], el=g["c%d_el" % n])
+        yield n, choice, npseed, synth.augment_case(seed), exp, sha
+
+
+def test_augment_numpy_branches_vs_reference():
+    """oracle.data_augment.augment against the outputs of the reference's own function (data_augment.py:12-130): flip, exposure,
+    noise and no-change, with the branch given and with the branch drawn from np.random (which pins the order of the draws), bit
+    for bit; the gamma tables of :47."""
+    from oracle import data_augment as oaug
+    for n, choice, npseed, (base, mask, pc, el), exp, sha in _augment_cases():
+        np.random.seed(npseed)
+        ob, om, opc, (op_, oi) = oaug.augment(base, mask, pc, el, choice if choice >= 0 else None)
+        assert sha(ob) == exp["img_sha"] and np.array_equal(ob[::16], exp["rows"]), "case %d image" % n
+        assert sha(om) == exp["mask_sha"], "case %d mask" % n
+        assert np.array_equal(opc, exp["pc"]) and np.array_equal(np.stack([op_, oi]), exp["el"]), "case %d geometry" % n
+    g = gold("augment")
+    for gm in (0.6, 0.8, 1.2, 1.4):
+        assert np.array_equal(255.0 * (np.linspace(0, 1, 256) ** gm), g["gamma_table_%d" % int(gm * 10)])
+
+
 def test_spatial_weights_restatement_properties():
     """oracle.dataprep.spatial_weights (CurriculumLib.py:128-129; PARITY UNPINNED - no OpenCV and no fixture in the build container):
     what can be checked without the reference - values are 1 or 21, a constant label has no edges, the edge set is one pixel
