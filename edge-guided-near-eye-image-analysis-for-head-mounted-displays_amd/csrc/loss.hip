@@ -241,3 +241,99 @@ extern "C" int egne_loss_fwd(const egne_loss_desc* dp, void* stream) {
   hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(256), 0, st, d, nblk);
   return egne::check_launch("egne_loss_fwd");
 }
+
+// ---- loss of the DeepVOG comparator (models/deepvog_pytorch.py:148-167 get_allLoss), forward only -------------------------------
+// Two output channels; the target is (label == 2).  l_seg = 10 * cross_entropy(softmax(op), target) averaged per frame, then over the
+// frames whose mask is present (cond[:,1] == 0); plus the mean L1 distance of the soft-argmax centre of channel 1 (temperature 4) to
+// the normalised pupil centre.  Same two passes as above: per-block partials, one combining block.
+namespace {
+
+constexpr int DV_NPART = 8;   // (max, se, sex, sey) of channel 1 * 4, [4] sum CE, [5..7] unused
+
+__global__ __launch_bounds__(256) void deepvog_loss_partial_k(const float* __restrict__ logits, long long ps, int ch_off,
+                                                             const long long* __restrict__ target, int H, int W, int nblk,
+                                                             float* __restrict__ partials, float* __restrict__ op_nchw,
+                                                             long long* __restrict__ mask) {
+  const int b = blockIdx.y, blk = blockIdx.x, hw = H * W;
+  const int p0 = blk * PIX_PER_BLOCK, p1 = min(hw, p0 + PIX_PER_BLOCK);
+  Lse a{-INFINITY, 0.f, 0.f, 0.f};
+  float ce = 0.f;
+  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    const long long gp = (long long)b * hw + p;
+    const float* q = logits + gp * ps + ch_off;
+    const float v0 = q[0], v1 = q[1];
+    op_nchw[((long long)b * 2) * hw + p] = v0;
+    op_nchw[((long long)b * 2 + 1) * hw + p] = v1;
+    mask[gp] = v1 > v0 ? 1 : 0;                                   // torch.max returns the first maximum
+    const float m = fmaxf(v0, v1), e0 = expf(v0 - m), e1 = expf(v1 - m), inv = 1.f / (e0 + e1);
+    const float s0 = e0 * inv, s1 = e1 * inv;                     // softmax over the two channels
+    const float sm = fmaxf(s0, s1), lse = sm + logf(expf(s0 - sm) + expf(s1 - sm));
+    ce += lse - (target[gp] == 2 ? s1 : s0);                      // F.cross_entropy applied to the PROBABILITIES (:160)
+    const int y = p / W, x = p - y * W;
+    lse_add(a, 4.f * v1, lin11(x, W), lin11(y, H));
+  }
+  __shared__ Lse sh[256];
+  __shared__ float shc[256];
+  sh[threadIdx.x] = a; shc[threadIdx.x] = ce;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { lse_merge(sh[threadIdx.x], sh[threadIdx.x + s]); shc[threadIdx.x] += shc[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* r = partials + ((long long)b * nblk + blk) * DV_NPART;
+    r[0] = sh[0].m; r[1] = sh[0].s; r[2] = sh[0].sx; r[3] = sh[0].sy; r[4] = shc[0];
+  }
+}
+
+// one block; thread b handles frame b (strided); out_terms[0] = loss, [1] = l_seg, [2] = mean seg2pt term
+__global__ __launch_bounds__(256) void deepvog_loss_final_k(const float* __restrict__ partials, int nblk, int B, int H, int W,
+                                                           const float* __restrict__ pupil_center, const float* __restrict__ cond,
+                                                           float* __restrict__ out_terms, float* __restrict__ pred_c) {
+  __shared__ double sseg[256], sok[256], spt[256];
+  double seg = 0.0, ok = 0.0, pt = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    Lse a{-INFINITY, 0.f, 0.f, 0.f};
+    double ce = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const float* r = partials + ((long long)b * nblk + k) * DV_NPART;
+      Lse t{r[0], r[1], r[2], r[3]};
+      lse_merge(a, t);
+      ce += r[4];
+    }
+    const float cx = a.sx / a.s, cy = a.sy / a.s;
+    pred_c[b * 2] = cx; pred_c[b * 2 + 1] = cy;
+    const float gx = 2.f * (pupil_center[b * 2] / (float)W) - 1.f, gy = 2.f * (pupil_center[b * 2 + 1] / (float)H) - 1.f;   // utils.normPts
+    pt += fabsf(cx - gx) + fabsf(cy - gy);
+    const float w = 1.f - cond[b * 4 + 1];
+    seg += 10.0 * (ce / ((double)H * W)) * w;
+    ok += w;
+  }
+  sseg[threadIdx.x] = seg; sok[threadIdx.x] = ok; spt[threadIdx.x] = pt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sseg[threadIdx.x] += sseg[threadIdx.x + s]; sok[threadIdx.x] += sok[threadIdx.x + s]; spt[threadIdx.x] += spt[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double lseg = sok[0] != 0.0 ? sseg[0] / sok[0] : 0.0, lpt = spt[0] / (2.0 * B);
+    out_terms[0] = (float)(lseg + lpt); out_terms[1] = (float)lseg; out_terms[2] = (float)lpt;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t egne_deepvog_loss_workspace_floats(int B, int H, int W) { return (int64_t)B * loss_nblk(H, W) * DV_NPART; }
+
+extern "C" int egne_deepvog_loss_fwd(const float* logits, int64_t pix_stride, int ch_off, const int64_t* target, const float* pupil_center,
+                                     const float* cond, int B, int H, int W, float* partials, float* out_terms, float* pred_c,
+                                     float* op_nchw, int64_t* mask, void* stream) {
+  EGNE_REQUIRE(logits && target && pupil_center && cond && partials && out_terms && pred_c && op_nchw && mask, "deepvog_loss: null pointer");
+  EGNE_REQUIRE(B > 0 && H > 1 && W > 1 && ch_off + 2 <= pix_stride, "deepvog_loss: bad shape");
+  const int nblk = loss_nblk(H, W);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(deepvog_loss_partial_k, dim3(nblk, B), dim3(256), 0, st, logits, (long long)pix_stride, ch_off, (const long long*)target,
+                     H, W, nblk, partials, op_nchw, (long long*)mask);
+  hipLaunchKernelGGL(deepvog_loss_final_k, dim3(1), dim3(256), 0, st, partials, nblk, B, H, W, pupil_center, cond, out_terms, pred_c);
+  return egne::check_launch("egne_deepvog_loss_fwd");
+}

@@ -7,6 +7,7 @@ modules in the container, this package's modules on the GPU box).  Host-side num
 only; nothing here is on the measured path.
 """
 import math
+import re
 import zlib
 
 import numpy as np
@@ -70,9 +71,10 @@ def seeded_state_dict(template, seed=0, kind="esf", gain=1.0):
         elif len(shape) == 2:  # linear weight [out, in]
             t = torch.randn(shape, generator=g) / math.sqrt(shape[1])
         elif len(shape) == 1:
-            if ".bn." in key and leaf == "weight":
+            bn = ".bn." in key or re.search(r"\.bn\d+\.", key) is not None
+            if bn and leaf == "weight":
                 t = 0.5 + torch.rand(shape, generator=g)
-            elif ".bn." in key and leaf == "bias":
+            elif bn and leaf == "bias":
                 t = 0.1 * torch.randn(shape, generator=g)
             else:  # conv / linear bias
                 t = 0.05 * torch.randn(shape, generator=g)

@@ -371,6 +371,15 @@ typedef struct {
 int64_t egne_loss_workspace_floats(int B, int H, int W);
 int egne_loss_fwd(const egne_loss_desc* d, void* stream);
 
+/* Loss of the DeepVOG comparator (models/deepvog_pytorch.py:148-167 get_allLoss), forward only: 10 * cross_entropy(softmax(op), label == 2)
+ * averaged per frame and over the frames with cond[:,1] == 0, plus the mean L1 distance between the soft-argmax centre of channel 1
+ * (loss.py:16-46, temperature 4) and utils.normPts(pupil_center).  logits: two channels of an NHWC fp32 slice.  Also writes the NCHW logits
+ * [B,2,H,W], the argmax mask [B,H,W] int64 and pred_c [B,2]; out_terms[0] = loss, [1] = segmentation term, [2] = centre term. */
+int64_t egne_deepvog_loss_workspace_floats(int B, int H, int W);
+int egne_deepvog_loss_fwd(const float* logits, int64_t pix_stride, int ch_off, const int64_t* target, const float* pupil_center,
+                          const float* cond, int B, int H, int W, float* partials, float* out_terms, float* pred_c,
+                          float* op_nchw, int64_t* mask, void* stream);
+
 /* Nearest-neighbour x2 up-sampling of an NHWC slice and its transpose (gx += the four copies): F.interpolate(scale_factor=2,
  * mode='nearest') of the comparator model models/RITnet_v1.py:89 (H, W = INPUT size).  bf16 twins: *_bf16. */
 int egne_upsample2x_nearest(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream);

@@ -441,6 +441,36 @@ def gold_ritnet_v1():
         json.dump(d, f, indent=0)
 
 
+def gold_deepvog():
+    """The comparator model models/deepvog_pytorch.py (modelSummary.py:26 'deepvog') in evaluation mode on the golden batch, with
+    non-trivial BatchNorm statistics; one frame has its mask marked absent (cond[:,1] = 1)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models import deepvog_pytorch as DV
+    m = quiet(DV.DeepVOG_pytorch)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=1, kind="esf"))
+    arrs = {}
+    for tag, B, absent in (("b2", 2, ()), ("b3", 3, (1,))):
+        b = synth.make_batch(B, seed=1234)
+        for i in absent:
+            b["cond"][i, 1] = 1.0
+        m.eval()
+        with torch.no_grad():
+            out, elPred, emb, loss, _ = quiet(m, *batch_args(b, torch.zeros_like(b["img"])))
+        srt = out.sort(dim=1, descending=True)[0]
+        arrs.update({tag + "_img_sha": sha(b["img"]), tag + "_loss": npy(loss), tag + "_pred_c": npy(elPred[:, :2]),
+                     tag + "_pred_c2": npy(elPred[:, 5:7]), tag + "_emb": npy(emb), tag + "_op": npy(out[:, :, ::4, ::4]),
+                     tag + "_op_sum": npy(out.double().sum((2, 3))), tag + "_op_absmax": np.array(out.abs().max().item()),
+                     tag + "_mask": np.packbits(npy(out.max(1)[1]).astype(np.uint8) == 1),
+                     tag + "_gap_lt_2e3": np.array(int(((srt[:, 0] - srt[:, 1]) < 2e-3).sum()))})
+    save("deepvog_b2", **arrs)
+    import json
+    keys = os.path.join(HERE, "state_keys.json")
+    d = json.load(open(keys))
+    d["deepvog"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(keys, "w") as f:
+        json.dump(d, f, indent=0)
+
+
 def gold_augment():
     """data_augment.augment (:12-130) for the branches that do not call into OpenCV (0 flip, 3 exposure, 4 noise, 7 none) and the
     random branch selection itself: the outputs of the reference for seeded np.random states.  Branch 2 goes through cv2.LUT,
@@ -488,7 +518,7 @@ def gold_keys():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate", "ritnet_v1", "augment"]
+    what = sys.argv[1:] or ["bdcn", "esf", "adain", "dp", "prep", "loss", "fit", "metrics", "keys", "evaluate", "ritnet_v1", "augment", "deepvog"]
     bd = None
     if "bdcn" in what:
         bd = gold_bdcn()
@@ -514,3 +544,5 @@ if __name__ == "__main__":
         gold_ritnet_v1()
     if "augment" in what:
         gold_augment()
+    if "deepvog" in what:
+        gold_deepvog()

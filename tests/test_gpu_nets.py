@@ -525,3 +525,52 @@ def test_ritnet_v1_train_step_vs_reference(storage):
             r = g["grad::" + k]
             e = np.abs(params[k].grad.cpu().numpy() - r).max()
             assert e <= 1.5e-2 * np.abs(r).max() + 1e-7, "%s: max err %.3e (scale %.3e)" % (k, e, np.abs(r).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# second comparator: models/deepvog_pytorch.py ('deepvog', modelSummary.py:26), evaluation only
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["b2", "b3"])
+def test_deepvog_eval_vs_reference(tag):
+    """DeepVOG on the HIP path (BatchNorm folded into the convolutions, 2x2 / stride-2 convolutions on the generic kernel, nearest
+    up-sampling, its own loss kernel) against the reference-generated fixture: logits within 1e-3 of the largest logit, loss at 1e-3
+    (case b3 has a frame whose mask is marked absent), predicted centre at 1e-3, identical argmax mask; return tuple laid out as
+    models/deepvog_pytorch.py:140-146; training mode refused."""
+    from common import gold
+    from test_oracle_golden import _deepvog_case
+    from egne_amd import synth
+    from egne_amd.modelSummary import get_model
+    g = gold("deepvog_b2")
+    m = get_model("deepvog", None)
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=1, kind="esf"))
+    m = m.to(DEV).eval()
+    b = _deepvog_case(tag)
+    B = b["img"].shape[0]
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in
+            (b["img"], torch.zeros_like(b["img"]), b["label"], b["pupil_center"], b["elNorm"], b["spatWts"], b["distMap"], b["cond"], b["ID"], b["alpha"])]
+    with torch.no_grad():
+        out, elPred, emb, loss, emb2 = m(*args)
+    scale = float(g[tag + "_op_absmax"])
+    err = np.abs(out.cpu()[:, :, ::4, ::4].numpy() - g[tag + "_op"]).max()
+    print("deepvog %s: logits off by %.2e (largest %.1f)" % (tag, err, scale))
+    assert err < 1e-3 * max(scale, 1.0)
+    np.testing.assert_allclose(out.double().sum((2, 3)).cpu().numpy(), g[tag + "_op_sum"], rtol=1e-3, atol=1e-3 * scale * 240 * 320 * 0.01)
+    np.testing.assert_allclose(loss.cpu().numpy(), g[tag + "_loss"], rtol=1e-3)
+    np.testing.assert_allclose(elPred[:, :2].cpu().numpy(), g[tag + "_pred_c"], atol=TOL)
+    assert torch.equal(elPred[:, :2], elPred[:, 5:7]) and elPred.shape == (B, 10)
+    r = torch.cat([elPred[:, 2:5], elPred[:, 7:10]], 1)
+    assert ((r >= 0) & (r < 1)).all()                                      # torch.rand filler (:141-143)
+    assert emb.shape == (B, 5) and (emb == 1).all() and emb2 is emb and loss.shape == (1,)
+    got = m.predictions().cpu().numpy().astype(np.uint8)
+    ref = np.unpackbits(g[tag + "_mask"])[:got.size].reshape(got.shape)
+    ndiff = int((got != ref).sum())
+    print("deepvog %s mask: %d of %d pixels differ (near ties in the fixture: %d)" % (tag, ndiff, got.size, int(g[tag + "_gap_lt_2e3"])))
+    assert ndiff <= int(g[tag + "_gap_lt_2e3"])
+    # a changed parameter / running statistic reaches the folded weights
+    with torch.no_grad():
+        m.down_block2.bn1.running_mean.add_(0.05)
+        out2 = m(*args)[0]
+    assert (out2 - out).abs().max().item() > 1e-4 * scale
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(*args)

@@ -23,10 +23,11 @@ def test_state_dict_schema_matches_reference():
     got = {k: list(v.shape) for k, v in bdcn_module().state_dict().items()}
     assert got == ref["bdcn"]
     from egne_amd.modelSummary import get_model, model_dict
-    assert {"ritnet_v1", "ritnet_v2", "ritnet_concat"} <= set(model_dict)             # modelSummary.py:18-26 registry
+    assert {"ritnet_v1", "ritnet_v2", "ritnet_concat", "deepvog"} <= set(model_dict)  # modelSummary.py:18-26 registry
     assert {k: list(v.shape) for k, v in get_model("ritnet_v1", None).state_dict().items()} == ref["ritnet_v1"]
+    assert {k: list(v.shape) for k, v in get_model("deepvog", None).state_dict().items()} == ref["deepvog"]
     for key, want in ref.items():
-        if key in ("bdcn", "ritnet_v1"):
+        if key in ("bdcn", "ritnet_v1", "deepvog"):
             continue
         parts = key.split(":")
         st = yaml.safe_load(open(os.path.join(cfgd, parts[1] + ".yaml")))

@@ -206,6 +206,36 @@ def test_dataprep_dist_maps_and_zscore():
     np.testing.assert_array_equal(oprep.zscore(g["img"]), g["z"])
 
 
+def _deepvog_case(tag):
+    from egne_amd import synth
+    B, absent = {"b2": (2, ()), "b3": (3, (1,))}[tag]
+    b = synth.make_batch(B, seed=1234)
+    for i in absent:
+        b["cond"][i, 1] = 1.0
+    return b
+
+
+def test_deepvog_comparator_vs_reference():
+    """oracle/deepvog.py (the comparator models/deepvog_pytorch.py, eval mode) against the fixture the reference itself produced:
+    logits, loss (one case with a frame whose mask is marked absent), predicted centre, the constant embedding."""
+    from common import gold
+    from egne_amd import synth
+    from egne_amd.models.deepvog_pytorch import DeepVOG_pytorch
+    from oracle import deepvog as o
+    g = gold("deepvog_b2")
+    sd = synth.seeded_state_dict(DeepVOG_pytorch().state_dict(), seed=1, kind="esf")
+    for tag in ("b2", "b3"):
+        b = _deepvog_case(tag)
+        with torch.no_grad():
+            out, pc, loss, _ = o.deepvog_forward(sd, b["img"], b["label"], b["pupil_center"], b["cond"])
+        assert np.abs(out[:, :, ::4, ::4].numpy() - g[tag + "_op"]).max() < 2e-5 * float(g[tag + "_op_absmax"])
+        np.testing.assert_allclose(loss.numpy(), g[tag + "_loss"], rtol=2e-6)
+        np.testing.assert_allclose(pc.numpy(), g[tag + "_pred_c"], atol=2e-6)
+        np.testing.assert_array_equal(g[tag + "_pred_c"], g[tag + "_pred_c2"])
+        assert (g[tag + "_emb"] == 1).all() and g[tag + "_emb"].shape == (out.shape[0], 5)
+        assert np.array_equal(np.packbits(out.max(1)[1].numpy().astype(np.uint8) == 1), g[tag + "_mask"])
+
+
 def _augment_cases():
     import hashlib
     from egne_amd import synth
