@@ -65,6 +65,8 @@ SIGNATURES = {
     "egne_conv3x3_smallcin_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
     "egne_pack_conv_weight_f16x2": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "egne_conv2d_f16x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
+    "egne_conv2d_f16x3_small_workspace_floats": (i64, [C.POINTER(ConvDesc)]),
+    "egne_conv2d_f16x3_small_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp, i64, vp]),
     "egne_pack_conv_weight_f16frag": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "egne_conv3x3_halo_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_conv1x1_3x3_fused_f16_fwd": (i32, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), vp, vp, f32, f32, vp, vp, f32, f32, vp]),

@@ -52,7 +52,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 template <int WGM, int WGN, int TM, int TN, bool GROUPED>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ whi,
                                                          const _Float16* __restrict__ wlo, float a_scale,
-                                                         float out_scale) {
+                                                         float out_scale, float* __restrict__ ksplit_ws) {
   egne::dyn_scales(p.dyn_scale, a_scale, out_scale);
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int AR = BM / 32;                  // A rows staged per thread (float4 each)
@@ -199,15 +199,20 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
     }
 
   const int nchunk = (sg.Cp + KC - 1) / KC;
-  const int nsteps = T * nchunk * p.ngroups;
-  int g = 0, tap = 0, c0 = 0;
-  load_step(0, 0, 0);
+  const int nsteps_all = T * nchunk * p.ngroups;
+  // split-K launches (gridDim.z > 1, one group): block z accumulates steps [z * n / Z, (z + 1) * n / Z) and leaves its scaled partial
+  // sums in ksplit_ws[z][M][CoutP]; splitk_finish_k adds them up and applies the epilogue
+  const int Z = GROUPED ? 1 : (int)gridDim.z, zi = GROUPED ? 0 : (int)blockIdx.z;
+  const int step0 = (int)((long long)nsteps_all * zi / Z), nsteps = (int)((long long)nsteps_all * (zi + 1) / Z);
+  int g = 0, tap = step0 % T, c0 = (step0 / T) * KC;
+  ky_n = tap / p.kw; kx_n = tap - ky_n * p.kw;
+  load_step(0, tap, c0);
   store_step();
   __syncthreads();
 
   const int arow = (wm * TM * 32 + li) * LDH + lh * 8;
   const int brow = (wn * TN * 32 + li) * LDH + lh * 8;
-  for (int step = 0; step < nsteps; ++step) {
+  for (int step = step0; step < nsteps; ++step) {
     int ng = g, ntap = tap + 1, nc0 = c0;
     if (++kx_n == p.kw) { kx_n = 0; ++ky_n; }
     if (ntap == T) {
@@ -262,6 +267,23 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 
   // ---- epilogue: lane holds channel n of 16 rows (pixels) m = mrow + c_r, c_r = (r&3) + 8*(r>>2) + 4*lh ----
   const long long left = M - m0;                                    // rows of this tile inside the tensor
+  if (!GROUPED && Z > 1) {
+    float* wz = ksplit_ws + ((long long)zi * M + m0) * p.CoutP;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + li;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int mrow = (wm * TM + tm) * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mr = mrow + (r & 3) + 8 * (r >> 2);
+          if (mr < left) wz[(long long)mr * p.CoutP + n] = acc[tm][tn][r] * out_scale;
+        }
+      }
+    }
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * 4));
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
                                                 p.residual ? (unsigned)((left < BM ? left : BM) * p.res_pix_stride * 4) : 0u);
@@ -298,6 +320,31 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   }
 }
 
+// out[m][n] = epilogue(sum_z ws[z][m][n]): bias, activation, post affine, residual -- the tail of a split-K launch.
+// One thread per (row, 4 channels).
+__global__ __launch_bounds__(256) void splitk_finish_k(const egne_conv_desc p, const float* __restrict__ ws, int Z, long long M) {
+  const int nq = p.CoutP / 4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * nq) return;
+  const long long m = i / nq;
+  const int n = (int)(i - m * nq) * 4;
+  if (n >= p.Cout_store) return;
+  f32x4 a = *(const f32x4*)(ws + m * p.CoutP + n);
+  for (int z = 1; z < Z; ++z) a += *(const f32x4*)(ws + ((long long)z * M + m) * p.CoutP + n);
+  const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  float* o = p.out + m * p.out_pix_stride + p.out_ch_off + n;
+  const float* rs = p.residual ? p.residual + m * p.res_pix_stride + p.res_ch_off + n : nullptr;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (n + e >= p.Cout_store) break;
+    float v = a[e] + (p.bias ? p.bias[n + e] : 0.f);
+    v = fmaxf(v, v * slope);
+    if (p.post_scale) v = v * p.post_scale[n + e] + p.post_shift[n + e];
+    if (rs) v += rs[e];
+    o[e] = v;
+  }
+}
+
 // OIHW fp32 -> two f16 arrays [tap][CoutP][Ktot] holding hi / lo of w * wscale (zero padded)
 __global__ void pack_weight_f16x2_k(const float* __restrict__ w, int Cout, int Cin, int T, int CoutP, int Ktot,
                                     float wscale, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
@@ -331,8 +378,41 @@ extern "C" int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Ci
 // the 128x128 tile, otherwise the 256x32 tile; ngroups = 3 runs the fused MSBlock branch, weights packed
 // group after group with ONE common w_scale).  One input slice without fused affine, Cp % 32 == 0, stride 1,
 // zero padding.  a_scale / w_scale: exact power-of-two pre-scales (w_scale must match the pack).
-extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, const void* wlo, float a_scale,
-                                     float w_scale, void* stream) {
+namespace {
+
+// Small problems (few output tiles, a long K loop: the 30x40 and 15x20 levels at one or two frames) leave most of the chip idle
+// and each workgroup latency bound on its own K loop.  They run on smaller tiles (64 x 64, 128 x 32) and with the K range split
+// over gridDim.z workgroups whose partial sums go through a workspace.  Returns Z (1 = no split) and the tile choice.
+struct SmallPlan { int small, Z, wide; long long ws_floats; };   // wide: 128 x 128 tiles instead of 64 x 64
+
+SmallPlan small_plan(const egne_conv_desc& d) {
+  static const int target = [] { const char* e = getenv("EGNE_SMALL_WGS"); return e ? atoi(e) : 640; }();
+  static const int wide_ok = [] { const char* e = getenv("EGNE_SMALL_WIDE"); return e ? atoi(e) : 1; }();
+  static const int minsteps = [] { const char* e = getenv("EGNE_SMALL_MINSTEPS"); return e ? atoi(e) : 6; }();
+  SmallPlan sp{0, 1, 0, 0};
+  if (d.ngroups != 1) return sp;
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  const int nsteps = d.kh * d.kw * ((d.seg[0].Cp + KC - 1) / KC);
+  long long tiles;      // of the standard tile choice
+  if (d.CoutP % 128 == 0) tiles = ((M + 127) / 128) * (d.CoutP / 128);
+  else if (d.CoutP % 64 == 0) tiles = ((M + 255) / 256) * (d.CoutP / 64);
+  else tiles = ((M + 255) / 256) * (d.CoutP / 32);
+  if (tiles >= 192) return sp;
+  sp.small = 1;
+  // wide layers with a deep K loop keep the 128 x 128 tile (half the operand bytes per flop: at 64 x 64 the launch is bound by the L2)
+  sp.wide = wide_ok && d.CoutP % 128 == 0 && nsteps >= 8 * minsteps && tiles * (nsteps / minsteps) >= target;
+  const long long t2 = sp.wide ? tiles : (d.CoutP % 64 == 0 ? ((M + 63) / 64) * (d.CoutP / 64) : ((M + 127) / 128) * (d.CoutP / 32));
+  int Z = (int)((target + t2 - 1) / t2);
+  if (Z > nsteps / minsteps) Z = nsteps / minsteps;
+  if (Z > 16) Z = 16;
+  if (Z < 1) Z = 1;
+  sp.Z = Z;
+  sp.ws_floats = Z > 1 ? (long long)Z * M * d.CoutP : 0;
+  return sp;
+}
+
+int f16x3_impl(const egne_conv_desc* dp, const void* whi, const void* wlo, float a_scale, float w_scale, float* ws, long long ws_floats,
+               bool allow_small, void* stream) {
   EGNE_REQUIRE(dp && whi && wlo, "conv_f16x3: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.nseg == 1 && d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP && d.stride == 1 && d.pad_mode == 0 &&
@@ -357,19 +437,58 @@ extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, 
   const _Float16* h = (const _Float16*)whi;
   const _Float16* l = (const _Float16*)wlo;
   static const int big = [] { const char* e = getenv("EGNE_SPLIT_BIG"); return e ? atoi(e) : 0; }();
-  if (d.CoutP % 128 == 0 && d.ngroups == 1 && big && M >= 256 * 512) {
+  const SmallPlan sp = allow_small ? small_plan(d) : SmallPlan{0, 1, 0, 0};
+  if (sp.small) {
+    EGNE_REQUIRE(sp.Z == 1 || (ws && ws_floats >= sp.ws_floats && ((uintptr_t)ws & 15) == 0), "conv_f16x3: split-K workspace too small (%lld floats, need %lld)",
+                 ws_floats, sp.ws_floats);
+    if (sp.wide) {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)(d.CoutP / 128), (unsigned)sp.Z);
+      hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, ws);
+    } else if (d.CoutP % 64 == 0) {
+      dim3 grid((unsigned)((M + 63) / 64), (unsigned)(d.CoutP / 64), (unsigned)sp.Z);
+      hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, ws);
+    } else {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)(d.CoutP / 32), (unsigned)sp.Z);
+      hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 1, 1, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, ws);
+    }
+    if (sp.Z > 1) {
+      const long long items = M * (d.CoutP / 4);
+      hipLaunchKernelGGL(splitk_finish_k, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, d, ws, sp.Z, M);
+    }
+  } else if (d.CoutP % 128 == 0 && d.ngroups == 1 && big && M >= 256 * 512) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)(d.CoutP / 128));
-    hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
+    hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, (float*)nullptr);
   } else if (d.CoutP % 128 == 0 && d.ngroups == 1) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)(d.CoutP / 128));
-    hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
+    hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, (float*)nullptr);
   } else if (d.CoutP % 64 == 0 && d.ngroups == 1) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)(d.CoutP / 64));
-    hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
+    hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 2, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, (float*)nullptr);
   } else {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)(d.CoutP / 32));
-    if (d.ngroups > 1) hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 1, true>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
-    else hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 1, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os);
+    if (d.ngroups > 1) hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 1, true>), grid, dim3(256), 0, st, d, h, l, a_scale, os, (float*)nullptr);
+    else hipLaunchKernelGGL((conv_f16x3_kernel<4, 1, 2, 1, false>), grid, dim3(256), 0, st, d, h, l, a_scale, os, (float*)nullptr);
   }
   return egne::check_launch("egne_conv2d_f16x3_fwd");
 }
+
+}  // namespace
+
+extern "C" int egne_conv2d_f16x3_fwd(const egne_conv_desc* dp, const void* whi, const void* wlo, float a_scale,
+                                     float w_scale, void* stream) {
+  return f16x3_impl(dp, whi, wlo, a_scale, w_scale, nullptr, 0, false, stream);
+}
+
+// Workspace (floats) the small-problem form of the same convolution needs for this descriptor: > 0 split-K, 0 small tiles without a
+// split, -1 the problem is not small (egne_conv2d_f16x3_small_fwd then runs the standard launch).
+extern "C" int64_t egne_conv2d_f16x3_small_workspace_floats(const egne_conv_desc* dp) {
+  if (!dp) return -1;
+  const SmallPlan sp = small_plan(*dp);
+  return sp.small ? sp.ws_floats : -1;
+}
+
+extern "C" int egne_conv2d_f16x3_small_fwd(const egne_conv_desc* dp, const void* whi, const void* wlo, float a_scale, float w_scale,
+                                           float* ws, int64_t ws_floats, void* stream) {
+  return f16x3_impl(dp, whi, wlo, a_scale, w_scale, ws, ws_floats, true, stream);
+}
+

@@ -70,7 +70,7 @@ __device__ void normalise(const double* el, int Hh, int Ww, double* out) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// One WAVE per (frame, class), four searches per workgroup, no barriers.
+// A PAIR of waves per (frame, class), two searches per workgroup.
 //
 // Why not a workgroup per search (rounds 1-2: 512 threads, the mask scanned word by word): the 128 searches of a 64-frame batch
 // then sit on 128 CUs for 3.2 ms with ~12 KB of LDS each, and while they do, the network's persistent kernels on the other
@@ -85,8 +85,19 @@ __device__ void normalise(const double* el, int Hh, int Ww, double* out) {
 // pixel) or empty are tested pixel by pixel around it; walks that do not settle within a few steps and degenerate ellipses fall
 // back to testing every pixel of the row -- so the result is the reference's bit for bit (tests/golden/fit_cases.npz,
 // evaluate_real_frames.npz).
+//
+// The search itself is a chain of up to 281 dependent evaluations (utils.py:450-486), ~8 us each: its length is the latency of a
+// one- or two-frame call.  Two things shorten the chain without changing a single result.  (1) The two candidates of a coordinate
+// step, now[j] - d and (now[j] - d) + 2d, are known before either is scored: the waves of a pair score one each at the same time
+// and swap the scores through LDS; the step then takes the reference's decisions in the reference's order (the evaluation counter
+// counts what the reference would have evaluated).  (2) The score a sweep ends with is the score of a parameter vector that has
+// usually been scored already -- nothing accepted: the vector the sweep started from; one coordinate accepted: that candidate --
+// so it is looked up by exact (bitwise) comparison of the three parameters and only evaluated on a miss (the reference's
+// subtract / add-twice / subtract sequence can move a rejected coordinate by a rounding, which is then a miss).
+// s_barrier waits on the surviving waves only, so a pair that finishes leaves the other pair of its workgroup running.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int FIT_WAVES = 4;
+constexpr int FIT_WAVES = 4;        // per workgroup: 2 searches x 2 waves
+constexpr int FIT_PAIRS = FIT_WAVES / 2;
 
 struct Ell { float cx, cy, a, b, ct, st; };
 
@@ -116,27 +127,28 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
                                                                 const float* __restrict__ xs, const float* __restrict__ ys,
                                                                 const double* __restrict__ init, double* __restrict__ out,
                                                                 int* __restrict__ evals) {
-  extern __shared__ unsigned fit_lds[];  // xs[W], ys[H], then per wave [H][wpr] packed mask
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ unsigned fit_lds[];  // xs[W], ys[H], swap area [pairs][2 parities][2 waves], then per pair [H][wpr] packed mask
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave >> 1, sub = wave & 1;
   const int wpr = (W + 31) >> 5, nwords = H * wpr;
   float* lxs = (float*)fit_lds;
   float* lys = lxs + W;
-  unsigned* bits = fit_lds + W + H + wave * nwords;
+  volatile unsigned* swap = fit_lds + W + H + pair * 4;
+  unsigned* bits = fit_lds + W + H + FIT_PAIRS * 4 + pair * nwords;
   for (int i = threadIdx.x; i < W; i += blockDim.x) lxs[i] = xs[i];
   for (int i = threadIdx.x; i < H; i += blockDim.x) lys[i] = ys[i];
-  __syncthreads();                        // the only barrier: every wave reaches it before anything can end it
-  const int e = blockIdx.x * FIT_WAVES + wave;
-  if (e >= n) return;                     // (whole waves: no lane of a live wave is switched off)
+  __syncthreads();
+  const int e = blockIdx.x * FIT_PAIRS + pair;
+  if (e >= n) return;                     // (whole pairs: both waves of a search take every barrier below together)
   const int fr = frame_of[e];
   if (fr < 0 || fr >= nframes) {   // a fit that names a frame the mask tensor does not hold: report NaN, read nothing
-    if (lane < 5) out[e * 5 + lane] = __longlong_as_double(0x7ff8000000000000ll);
-    if (lane == 0 && evals) evals[e] = 0;
+    if (sub == 0 && lane < 5) out[e * 5 + lane] = __longlong_as_double(0x7ff8000000000000ll);
+    if (sub == 0 && lane == 0 && evals) evals[e] = 0;
     return;
   }
   const long long* m = mask + (long long)fr * H * W;
   const int k = cls[e];
-  unsigned cnt = 0;            // (wave-uniform: ballots)
-  for (int y = 0; y < H; ++y)
+  unsigned cnt = 0;            // (wave-uniform: ballots); each wave of the pair packs every other row
+  for (int y = sub; y < H; y += 2)
     for (int x0 = 0; x0 < W; x0 += 64) {          // one coalesced 512-byte load per step, the class test of 64 pixels as one ballot
       const int x = x0 + lane;
       const unsigned long long bal = __ballot(x < W && m[(long long)y * W + x] == k);
@@ -144,16 +156,24 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
       if (lane == 0) bits[y * wpr + (x0 >> 5)] = (unsigned)bal;
       if (lane == 1 && (x0 >> 5) + 1 < wpr) bits[y * wpr + (x0 >> 5) + 1] = (unsigned)(bal >> 32);
     }
-  const int nseg = (int)cnt;
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's mask words are in LDS before its lanes read each other's
+  int parity = 0;
+  // both waves leave a word, meet at the barrier and read the pair's two words (double buffered: one barrier per exchange)
+  auto exchange = [&](unsigned mine, unsigned& w0, unsigned& w1) {
+    if (lane == 0) swap[parity * 2 + sub] = mine;
+    __syncthreads();
+    w0 = swap[parity * 2]; w1 = swap[parity * 2 + 1];
+    parity ^= 1;
+  };
+  unsigned c0, c1;
+  exchange(cnt, c0, c1);                  // (the barrier also orders the mask words of both waves before the first evaluation)
+  const int nseg = (int)(c0 + c1);
 
   const double cx = init[e * 5 + 0], cy = init[e * 5 + 1];
   double now[3] = {init[e * 5 + 2], init[e * 5 + 3], init[e * 5 + 4] * 180. / PI_REF}, d[3] = {1.0, 1.0, 1.0};
 
-  // IoU of the packed mask with the ellipse (cx, cy, now[0], now[1], now[2] degrees); every lane computes the same parameters
-  auto evaluate = [&]() -> float {
-    double el[5] = {cx, cy, now[0], now[1], now[2] / 180. * PI_REF};
+  // IoU of the packed mask with the ellipse (cx, cy, q[0], q[1], q[2] degrees); every lane computes the same parameters
+  auto evaluate = [&](const double* q) -> float {
+    double el[5] = {cx, cy, q[0], q[1], q[2] / 180. * PI_REF};
     double nm[5];
     normalise(el, H, W, nm);
     const Ell E = {(float)nm[0], (float)nm[1], (float)nm[2], (float)nm[3], (float)cos(nm[4]), (float)sin(nm[4])};
@@ -229,24 +249,51 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
     return __fdiv_rn(fi, __fsub_rn(__fadd_rn((float)nseg, (float)ne), fi));
   };
 
+  auto same = [](const double* a, const double* b) {
+    return __double_as_longlong(a[0]) == __double_as_longlong(b[0]) && __double_as_longlong(a[1]) == __double_as_longlong(b[1]) &&
+           __double_as_longlong(a[2]) == __double_as_longlong(b[2]);
+  };
   int nev = 1;
-  double rt = (double)evaluate();
+  float base_sc = evaluate(now);               // both waves (no exchange needed): score of `now` at the start of the sweep
+  double base_q[3] = {now[0], now[1], now[2]};
+  double rt = (double)base_sc;
   for (int sweep = 0; sweep < 40; ++sweep) {
     int flag = 0;
+    float acc_sc = 0.f;                          // the last accepted candidate and its score
+    double acc_q[3] = {0., 0., 0.};
+    bool have_acc = false;
     for (int j = 0; j < 3; ++j) {
-      now[j] -= d[j];
-      float sc = evaluate(); ++nev;
-      if ((double)sc > rt) { flag = 1; continue; }          // (rt only changes between sweeps)
-      now[j] += 2. * d[j];
-      sc = evaluate(); ++nev;
-      if ((double)sc > rt) { flag = 1; continue; }
-      now[j] -= d[j]; d[j] *= 0.8;
+      const double lo = now[j] - d[j], hi = lo + 2. * d[j];          // the reference's two candidates, in its arithmetic
+      double q[3] = {now[0], now[1], now[2]};
+      q[j] = sub ? hi : lo;
+      const float mine = evaluate(q);
+      unsigned u0, u1;
+      exchange(__float_as_uint(mine), u0, u1);
+      const float sc_lo = __uint_as_float(u0), sc_hi = __uint_as_float(u1);
+      ++nev;
+      if ((double)sc_lo > rt) {                  // (rt only changes between sweeps)
+        now[j] = lo; flag = 1; have_acc = true; acc_sc = sc_lo;
+        acc_q[0] = now[0]; acc_q[1] = now[1]; acc_q[2] = now[2];
+        continue;
+      }
+      ++nev;
+      if ((double)sc_hi > rt) {
+        now[j] = hi; flag = 1; have_acc = true; acc_sc = sc_hi;
+        acc_q[0] = now[0]; acc_q[1] = now[1]; acc_q[2] = now[2];
+        continue;
+      }
+      now[j] = hi - d[j]; d[j] *= 0.8;
     }
-    const float sc = evaluate(); ++nev;
+    ++nev;
+    float sc;
+    if (same(now, base_q)) sc = base_sc;
+    else if (have_acc && same(now, acc_q)) sc = acc_sc;
+    else sc = evaluate(now);
     if ((double)sc > rt) rt = (double)sc;
+    base_sc = sc; base_q[0] = now[0]; base_q[1] = now[1]; base_q[2] = now[2];
     if (!flag) break;
   }
-  if (lane == 0) {
+  if (sub == 0 && lane == 0) {
     out[e * 5 + 0] = cx; out[e * 5 + 1] = cy; out[e * 5 + 2] = now[0]; out[e * 5 + 3] = now[1];
     out[e * 5 + 4] = now[2] / 180.0 * PI_REF;
     if (evals) evals[e] = nev;
@@ -299,9 +346,9 @@ extern "C" int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t*
                                 void* stream) {
   EGNE_REQUIRE(mask && frame_of && cls && xs && ys && init && out, "ellipse_fit: null pointer");
   EGNE_REQUIRE(n > 0 && nframes > 0 && H > 1 && W > 1, "ellipse_fit: bad shape");
-  const size_t lds = ((size_t)FIT_WAVES * H * ((W + 31) / 32) + W + H) * 4;
+  const size_t lds = ((size_t)FIT_PAIRS * (H * ((W + 31) / 32) + 4) + W + H) * 4;
   EGNE_REQUIRE(lds <= 60 * 1024, "ellipse_fit: %dx%d masks do not fit LDS", H, W);
-  hipLaunchKernelGGL(ellipse_fit_k, dim3((n + FIT_WAVES - 1) / FIT_WAVES), dim3(64 * FIT_WAVES), lds, (hipStream_t)stream, (const long long*)mask,
+  hipLaunchKernelGGL(ellipse_fit_k, dim3((n + FIT_PAIRS - 1) / FIT_PAIRS), dim3(64 * FIT_WAVES), lds, (hipStream_t)stream, (const long long*)mask,
                      nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
   return egne::check_launch("egne_ellipse_fit");
 }

@@ -35,6 +35,7 @@ MS1X1_ENABLED = os.environ.get("EGNE_MS1X1", "1") != "0"
 C4H_MODE = os.environ.get("EGNE_C4H", "wide")     # "wide" | "all" | "off"
 MS1X1_MIN_PIX = int(os.environ.get("EGNE_MS1X1_MIN_PIX", "30000"))
 BIG_ENABLED = os.environ.get("EGNE_BIG", "1") != "0"
+SMALL_ENABLED = os.environ.get("EGNE_SMALL", "1") != "0"      # small-problem form of the flat split-f16 kernel (64-wide tiles, split-K)
 BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
 BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
 BIG_SPLIT_TAIL = os.environ.get("EGNE_BIG_SPLIT_TAIL", "1") != "0"
@@ -747,6 +748,20 @@ class Plan:
             split = False            # narrow fused-affine layers: the fp32 halo kernel beats the flat split kernel
         if smallcin:
             split = shalo = False
+        # small problems (one or two frames at the deep levels): 64-wide tiles + split-K on the flat kernel (conv_f16x3.hip small_plan)
+        small_ws = -1
+        if SMALL_ENABLED and split and not self.train and layer.G == 1 and not (lattice or msdil):
+            dq = _lib.ConvDesc()
+            dq.B, dq.Ho, dq.Wo, dq.kh, dq.kw, dq.ngroups, dq.CoutP = B, Ho, Wo, layer.kh, layer.kw, 1, layer.split_coutp()
+            dq.seg[0].Cp = pieces[0].Cp
+            small_ws = int(self.L.egne_conv2d_f16x3_small_workspace_floats(C.byref(dq)))
+        small = small_ws >= 0
+        if small and stats and STATS_FUSED and shalo and dst.Cp == min(layer.Cout_store, dst.Cp):
+            tall_ = ((H + 31) // 32) * ((W + 7) // 8) < ((W + 31) // 32) * ((H + 7) // 8)
+            if rs or (layer.dils[0] == 1 and not tall_):
+                small = False            # the halo / role-split kernel writes the consumer's InstanceNorm sums from its epilogue: one launch
+        if small:
+            shalo = rs = big = False
         if smallcin or split:
             halo = False
         big_tail = 0     # frames handed to the 128x128 kernel so that the 256x256 launch fills whole rounds of 256 CUs
@@ -920,6 +935,11 @@ class Plan:
             if fuse_stats:
                 self.last_stats = self._stats_finish(ws, d, B, H * W, tx * ty * 4, name)
                 stats = False
+        elif split and small:
+            wsb = self.vec(max(small_ws, 4))
+            self._add(self.L.egne_conv2d_f16x3_small_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
+                                                           layer.w_scale, wsb.data_ptr(), small_ws), name, flops=flops,
+                      kind="conv_f16x3:small", cal=cal3, ws=[(4, layer, "w_scale")])
         elif split:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE,
                                                      layer.w_scale), name, flops=flops, kind="conv_f16x3:flat", cal=cal3, ws=[(4, layer, "w_scale")])

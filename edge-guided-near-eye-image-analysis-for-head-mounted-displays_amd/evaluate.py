@@ -136,6 +136,19 @@ def _seg_and_fit(frames, model):
     return run
 
 
+def graphed_runner(warmup_frames, model, edge_model):
+    """edge -> seg -> fit of a fixed small batch as one hipGraph replay (egne_amd.pipeline.GraphedFrames): the per-eye loop of
+    evaluate.py:235-249 at one or two frames per call.  ``runner(frames)`` returns the same device tensors as the eager path (edge maps
+    [N,H,W], class maps [N,H,W], fitted ellipses [N,2,5]); results are bit-identical to it."""
+    from egne_amd.pipeline import GraphedFrames
+    from egne_amd.utils import calc_edge
+    ns = argparse.Namespace(prec=torch.float32, edge_thres=0)
+
+    def stage(x):
+        return _seg_and_fit(x, model)(calc_edge(ns, x, edge_model, x.device))
+    return GraphedFrames(stage, warmup_frames)
+
+
 def _to_host(res):
     edge, mask, fit = res
     fit = fit.cpu().numpy()

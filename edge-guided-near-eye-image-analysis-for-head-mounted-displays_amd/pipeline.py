@@ -68,3 +68,47 @@ class TwoStagePipeline:
         cur.wait_stream(self.sa)
         cur.wait_stream(self.sb)
         return out
+
+
+class GraphedFrames:
+    """Edge map + segmentation + ellipse fit of a FIXED small batch of frames as ONE hipGraph replay.
+
+    The head-mounted-display case of the reference feeds the two eyes of a video frame one at a time (evaluate.py:235-249): at one
+    or two frames the path is ~120 short dependent launches and the Python launch loop needs ~2.5 ms of host time per call to queue
+    them -- as long as the GPU needs to run them.  A replay costs the host one call (the host thread is free for decoding / drawing
+    frames, evaluate.py:195-308); the GPU time of a call is what it was (measured: 3.52 vs 3.56 ms at one frame, 5.33 vs 5.37 ms
+    at two, scratch/latency2.py -- the launches were queued ahead of the GPU already).  ``stage(frames)`` -- any function of a static input tensor that only queues work on the current stream
+    (egne_amd.evaluate builds edge -> ESF-Net -> argmax -> fit) -- is run a few times eagerly on ``warmup`` (this is also where the
+    split-f16 kernels calibrate their power-of-two activation scales, Plan.run) and then captured; ``__call__`` copies the new
+    frames into the static input and replays.  The returned tensors are the graph's own output buffers: they are overwritten by the
+    next call (clone what must outlive it).
+
+    The captured launches carry the calibrated scales and the packed weights by value / by address: capture again (``capture()``)
+    after the weights change.  The scales have 32x of headroom over the warm-up frames, as in the eager path."""
+
+    def __init__(self, stage, warmup, n_warm=3):
+        self.stage = stage
+        self.x = warmup.clone()
+        self.n_warm = n_warm
+        self.graph = None
+        self.capture()
+
+    def capture(self):
+        dev = self.x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.n_warm):
+                self.stage(self.x)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self.stage(self.x)
+
+    def __call__(self, frames):
+        if frames.shape != self.x.shape:
+            raise ValueError("GraphedFrames: captured for frames of shape %s, got %s" % (tuple(self.x.shape), tuple(frames.shape)))
+        self.x.copy_(frames, non_blocking=True)
+        self.graph.replay()
+        return self.out

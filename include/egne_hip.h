@@ -141,6 +141,14 @@ int egne_pack_conv_weight_f16x2(const float* w_oihw, int Cout, int Cin, int kh, 
                                 float wscale, void* whi, void* wlo, void* stream);
 int egne_conv2d_f16x3_fwd(const egne_conv_desc* d, const void* whi, const void* wlo, float a_scale,
                           float w_scale, void* stream);
+/* The same convolution for SMALL problems (one or two frames at the 30x40 / 15x20 levels: evaluate.py:235-249 feeds one eye per call):
+ * few output tiles and a long K loop would leave most compute units idle, so the launch uses 64 x 64 (or 128 x 32) tiles and splits the K
+ * range over gridDim.z workgroups; their partial sums go through `ws` ([Z][B*Ho*Wo][CoutP] floats) and a second launch applies bias /
+ * activation / post affine / residual.  egne_conv2d_f16x3_small_workspace_floats: floats of workspace this descriptor needs (0: small tiles,
+ * no split), or -1 if the problem is not small -- egne_conv2d_f16x3_small_fwd then runs exactly egne_conv2d_f16x3_fwd.  ngroups = 1 only. */
+int64_t egne_conv2d_f16x3_small_workspace_floats(const egne_conv_desc* d);
+int egne_conv2d_f16x3_small_fwd(const egne_conv_desc* d, const void* whi, const void* wlo, float a_scale, float w_scale,
+                                float* ws, int64_t ws_floats, void* stream);
 
 /* Deep variant of egne_conv2d_f16x3_fwd for the wide trunk layers (vgg16_c.py:70-78): 256 x 256 (or 256 x 128) tile, 8 waves,
  * two LDS stages, one barrier per K step; weights as ready-made LDS images staged by LDS-DMA

@@ -45,8 +45,29 @@ for B in (1, 2):
     rows = sorted(((e0.elapsed_time(e1) * 1e3, name, kind) for kind, fl, e0, e1, name in ev), reverse=True)
     tot = sum(r[0] for r in rows)
     print("   sum of launch durations %.3f ms over %d launches; top: %s" % (tot / 1e3, len(rows), [(n_, round(us)) for us, n_, k in rows[:12]]))
+    if os.environ.get("LAT_DUMP"):
+        for kind, fl, e0, e1, name in ev:
+            print("      %-34s %-22s %7.1f us  %8.3f GF" % (name, kind, e0.elapsed_time(e1) * 1e3, fl / 1e9))
     import collections
     fam = collections.defaultdict(lambda: [0.0, 0])
     for us, n_, k in rows:
         fam[k][0] += us; fam[k][1] += 1
     print("   by kind:", [(k, round(v[0]), v[1]) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]])
+
+# the same call as one hipGraph replay (egne_amd.pipeline.GraphedFrames)
+from egne_amd.evaluate import graphed_runner, _seg_and_fit
+for B in (1, 2):
+    x = synth.make_batch(B, seed=1)["img"].to(dev)
+    run = graphed_runner(x, net, bd)
+    with torch.no_grad():
+        want = _seg_and_fit(x, net)(calc_edge(args, x, bd, dev))
+    got = run(x)
+    torch.cuda.synchronize()
+    print("   captured with branches:", [getattr(p_, "branch_runs", 0) for p_ in bd._plans.values()], flush=True)
+    same = all(torch.equal(a, b) for a, b in zip(want, got))
+    n = 200
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = run(x); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("B=%d graph replay (edge + seg + fit): %.3f ms per call (synchronised), identical to the eager call: %s" % (B, dt * 1e3, same), flush=True)

@@ -574,3 +574,32 @@ def test_deepvog_eval_vs_reference(tag):
     m.train()
     with pytest.raises(NotImplementedError):
         m(*args)
+
+
+def test_graphed_frames_replay_is_bit_identical():
+    """egne_amd.pipeline.GraphedFrames (edge -> ESF-Net -> argmax -> fit of a fixed two-frame batch as one hipGraph replay, the
+    per-eye loop of evaluate.py:235-249): the replay on NEW frames returns exactly what the eager calls return for them."""
+    import argparse
+    from egne_amd import synth
+    from egne_amd.evaluate import _seg_and_fit, graphed_runner
+    from egne_amd.utils import calc_edge
+    import os
+    import yaml
+    import egne_amd
+    from egne_amd import _entry
+    with open(os.path.join(os.path.dirname(egne_amd.__file__), "configs", "baseline_edge.yaml")) as f:
+        bd, net = _entry.seeded_networks(yaml.safe_load(f))
+    bd, net = bd.to(DEV).eval(), net.to(DEV).eval()
+    ns = argparse.Namespace(prec=torch.float32, edge_thres=0)
+    warm = synth.make_batch(2, seed=5)["img"].to(DEV)
+    run = graphed_runner(warm, net, bd)
+    for seed in (6, 7):
+        x = synth.make_batch(2, seed=seed)["img"].to(DEV)
+        got = [t.clone() for t in run(x)]
+        with torch.no_grad():
+            want = _seg_and_fit(x, net)(calc_edge(ns, x, bd, DEV))
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        run(warm[:1])
