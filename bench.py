@@ -313,6 +313,50 @@ class Bench:
             self.torch.distributed.barrier()
         self.torch.cuda.synchronize()
 
+    def leg_latency(self, calls=100):
+        """edge + seg + fit of ONE call of 1 / 2 frames, synchronised after every call (a caller that needs this frame's ellipses
+        before the next frame arrives): eager launch loop and hipGraph replay (egne_amd.pipeline.GraphedFrames); results of both
+        are checked to be identical.  Returns (ms of the faster form at two frames, details)."""
+        torch = self.torch
+        from egne_amd.evaluate import _seg_and_fit, graphed_runner
+        from egne_amd.utils import calc_edge
+        self.net.eval()
+        out = {"what": "wall ms per call of edge map + ESF-Net + argmax mask + both ellipse fits, torch.cuda.synchronize() after every call, frames "
+                       "resident in HBM, median of %d calls; `no_fit`: the same without the fit stage; `graph`: the call as one hipGraph replay" % calls}
+
+        def med(fn):
+            ts = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return round(1e3 * sorted(ts)[len(ts) // 2], 3)
+        for B in (1, 2):
+            x = self.batch(B)["img"]
+
+            def eager(fit=True):
+                with torch.no_grad():
+                    e = calc_edge(self.args, x, self.bd, self.dev)
+                    if fit:
+                        return _seg_and_fit(x, self.net)(e)
+                    z = lambda *s: torch.zeros(s, device=self.dev)          # noqa: E731
+                    lab = torch.zeros((B, H_, W_), dtype=torch.long, device=self.dev)
+                    self.net(x, e, lab, z(B, 2), z(B, 2, 5), z(B, H_, W_), z(B, 3, H_, W_), z(B, 4), torch.zeros(B, dtype=torch.long, device=self.dev), 0)
+                    return self.net.predictions()
+            H_, W_ = x.shape[2:]
+            for _ in range(5):
+                want = eager()
+            torch.cuda.synchronize()
+            run = graphed_runner(x, self.net, self.bd)
+            got = run(x)
+            torch.cuda.synchronize()
+            same = all(torch.equal(p, q) for p, q in zip(want, got))
+            eager(False)
+            out["b%d" % B] = {"eager": med(eager), "graph": med(lambda: run(x)), "no_fit": med(lambda: eager(False)), "graph_equals_eager": bool(same)}
+        self.free_plans()
+        return min(out["b2"]["eager"], out["b2"]["graph"]), out
+
     def free_plans(self):
         self.bd._plans.clear()
         self.net._plans.clear()
@@ -663,6 +707,10 @@ def main():
                              "roofline": {k: r32[k] for k in ("bound", "achieved", "peak", "unit", "frac", "time_share")}}
         _engine.F16X3_ENABLED, _engine.ESF_SPLIT = old
         bn.free_plans()
+
+    if a.mode == "all" and world == 1:
+        # ---- one or two frames per call: the head-mounted-display case (evaluate.py:235-249 feeds one eye at a time) ----
+        res["latency_b2_ms"], res["latency"] = bn.leg_latency()
 
     def train_leg(storage):
         steps = a.train_steps if a.mode == "all" else a.steps

@@ -96,8 +96,11 @@ __device__ void normalise(const double* el, int Hh, int Ww, double* out) {
 // subtract / add-twice / subtract sequence can move a rejected coordinate by a rounding, which is then a miss).
 // s_barrier waits on the surviving waves only, so a pair that finishes leaves the other pair of its workgroup running.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int FIT_WAVES = 4;        // per workgroup: 2 searches x 2 waves
-constexpr int FIT_PAIRS = FIT_WAVES / 2;
+// FIT_PAIRS searches per workgroup, ROWW waves per candidate.  A whole batch: two searches of two waves (64 compute units for its 128
+// searches; eight per workgroup were measured too: the lock step of 16 waves at every barrier stretches the launch from 1.85 to
+// 3.0 ms and the step gains nothing).  Few searches (a one- or two-frame call, where the chain IS the latency): a workgroup of eight
+// waves per search, four per candidate, so that the ~140 rows of an iris ellipse are one pass of 256 lanes instead of three of 64;
+// the partial counts of the waves are integers, so their sum does not depend on the split.
 
 struct Ell { float cx, cy, a, b, ct, st; };
 
@@ -122,33 +125,36 @@ __device__ __forceinline__ unsigned row_pop(const unsigned* rowbits, int x0, int
   return n;
 }
 
-__global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long* __restrict__ mask, int nframes, const int* __restrict__ frame_of,
-                                                                const int* __restrict__ cls, int n, int H, int W,
-                                                                const float* __restrict__ xs, const float* __restrict__ ys,
-                                                                const double* __restrict__ init, double* __restrict__ out,
-                                                                int* __restrict__ evals) {
-  extern __shared__ unsigned fit_lds[];  // xs[W], ys[H], swap area [pairs][2 parities][2 waves], then per pair [H][wpr] packed mask
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave >> 1, sub = wave & 1;
+template <int FIT_PAIRS, int ROWW>
+__global__ __launch_bounds__(128 * FIT_PAIRS * ROWW) void ellipse_fit_k(const long long* __restrict__ mask, int nframes, const int* __restrict__ frame_of,
+                                                                       const int* __restrict__ cls, int n, int H, int W,
+                                                                       const float* __restrict__ xs, const float* __restrict__ ys,
+                                                                       const double* __restrict__ init, double* __restrict__ out,
+                                                                       int* __restrict__ evals) {
+  // NW = 2 * ROWW waves per search: wave w scores candidate sub = w / ROWW over the rows y = y_lo + part * 64 + lane (+ 64 * ROWW ...)
+  constexpr int NW = 2 * ROWW, SWAP = 2 * NW * 2;     // swap area per search: [2 parities][NW waves][ne, ni]
+  extern __shared__ unsigned fit_lds[];  // xs[W], ys[H], swap areas, then per search [H][wpr] packed mask
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave / NW, wv = wave % NW, sub = wv / ROWW, part = wv % ROWW;
   const int wpr = (W + 31) >> 5, nwords = H * wpr;
   float* lxs = (float*)fit_lds;
   float* lys = lxs + W;
-  volatile unsigned* swap = fit_lds + W + H + pair * 4;
-  unsigned* bits = fit_lds + W + H + FIT_PAIRS * 4 + pair * nwords;
+  volatile unsigned* swap = fit_lds + W + H + pair * SWAP;
+  unsigned* bits = fit_lds + W + H + FIT_PAIRS * SWAP + pair * nwords;
   for (int i = threadIdx.x; i < W; i += blockDim.x) lxs[i] = xs[i];
   for (int i = threadIdx.x; i < H; i += blockDim.x) lys[i] = ys[i];
   __syncthreads();
   const int e = blockIdx.x * FIT_PAIRS + pair;
-  if (e >= n) return;                     // (whole pairs: both waves of a search take every barrier below together)
+  if (e >= n) return;                     // (whole searches: all waves of a search take every barrier below together)
   const int fr = frame_of[e];
   if (fr < 0 || fr >= nframes) {   // a fit that names a frame the mask tensor does not hold: report NaN, read nothing
-    if (sub == 0 && lane < 5) out[e * 5 + lane] = __longlong_as_double(0x7ff8000000000000ll);
-    if (sub == 0 && lane == 0 && evals) evals[e] = 0;
+    if (wv == 0 && lane < 5) out[e * 5 + lane] = __longlong_as_double(0x7ff8000000000000ll);
+    if (wv == 0 && lane == 0 && evals) evals[e] = 0;
     return;
   }
   const long long* m = mask + (long long)fr * H * W;
   const int k = cls[e];
-  unsigned cnt = 0;            // (wave-uniform: ballots); each wave of the pair packs every other row
-  for (int y = sub; y < H; y += 2)
+  unsigned cnt = 0;            // (wave-uniform: ballots); the waves of the search pack the rows in turn
+  for (int y = wv; y < H; y += NW)
     for (int x0 = 0; x0 < W; x0 += 64) {          // one coalesced 512-byte load per step, the class test of 64 pixels as one ballot
       const int x = x0 + lane;
       const unsigned long long bal = __ballot(x < W && m[(long long)y * W + x] == k);
@@ -157,22 +163,25 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
       if (lane == 1 && (x0 >> 5) + 1 < wpr) bits[y * wpr + (x0 >> 5) + 1] = (unsigned)(bal >> 32);
     }
   int parity = 0;
-  // both waves leave a word, meet at the barrier and read the pair's two words (double buffered: one barrier per exchange)
-  auto exchange = [&](unsigned mine, unsigned& w0, unsigned& w1) {
-    if (lane == 0) swap[parity * 2 + sub] = mine;
+  // every wave leaves its two words, all meet at the barrier and read the sums per candidate (double buffered: one barrier per exchange)
+  auto exchange = [&](unsigned m0, unsigned m1, unsigned* s0, unsigned* s1) {
+    volatile unsigned* sw = swap + parity * NW * 2;
+    if (lane == 0) { sw[wv * 2] = m0; sw[wv * 2 + 1] = m1; }
     __syncthreads();
-    w0 = swap[parity * 2]; w1 = swap[parity * 2 + 1];
+    s0[0] = s0[1] = s1[0] = s1[1] = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { s0[i / ROWW] += sw[i * 2]; s1[i / ROWW] += sw[i * 2 + 1]; }
     parity ^= 1;
   };
-  unsigned c0, c1;
-  exchange(cnt, c0, c1);                  // (the barrier also orders the mask words of both waves before the first evaluation)
-  const int nseg = (int)(c0 + c1);
+  unsigned ca[2], cb[2];
+  exchange(cnt, 0u, ca, cb);              // (the barrier also orders the mask words of all waves before the first evaluation)
+  const int nseg = (int)(ca[0] + ca[1]);
 
   const double cx = init[e * 5 + 0], cy = init[e * 5 + 1];
   double now[3] = {init[e * 5 + 2], init[e * 5 + 3], init[e * 5 + 4] * 180. / PI_REF}, d[3] = {1.0, 1.0, 1.0};
 
   // IoU of the packed mask with the ellipse (cx, cy, q[0], q[1], q[2] degrees); every lane computes the same parameters
-  auto evaluate = [&](const double* q) -> float {
+  auto evaluate = [&](const double* q, unsigned& ne_out, unsigned& ni_out) {
     double el[5] = {cx, cy, q[0], q[1], q[2] / 180. * PI_REF};
     double nm[5];
     normalise(el, H, W, nm);
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
       // the row quadratic A dx^2 + Bq dx + C <= 0 (approximate arithmetic: it only seeds the exact walk)
       const float ia = 1.f / (E.a * E.a), ib = 1.f / (E.b * E.b);
       const float A = E.ct * E.ct * ia + E.st * E.st * ib, Bc = 2.f * E.st * E.ct * (ia - ib), Cc = E.st * E.st * ia + E.ct * E.ct * ib;
-      for (int y = y_lo + lane; y <= y_hi; y += 64) {
+      for (int y = y_lo + part * 64 + lane; y <= y_hi; y += 64 * ROWW) {
         const float dy = __fsub_rn(lys[y], E.cy);
         const float dyst = __fmul_rn(dy, E.st), dyct = __fmul_rn(dy, E.ct);
         const unsigned* rowbits = bits + y * wpr;
@@ -245,8 +254,18 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
       }
     }
     for (int o = 32; o >= 1; o >>= 1) { ne += __shfl_xor(ne, o); ni += __shfl_xor(ni, o); }
+    ne_out = ne; ni_out = ni;
+  };
+  auto iou = [&](unsigned ne, unsigned ni) -> float {
     const float fi = (float)ni;
     return __fdiv_rn(fi, __fsub_rn(__fadd_rn((float)nseg, (float)ne), fi));
+  };
+  // one round: candidate qa on the waves with sub = 0, qb on the others (each over its share of the rows), both scores to every wave
+  auto score2 = [&](const double* qa, const double* qb, float& sa, float& sb) {
+    unsigned ne, ni, nes[2], nis[2];
+    evaluate(sub ? qb : qa, ne, ni);
+    exchange(ne, ni, nes, nis);
+    sa = iou(nes[0], nis[0]); sb = iou(nes[1], nis[1]);
   };
 
   auto same = [](const double* a, const double* b) {
@@ -254,7 +273,8 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
            __double_as_longlong(a[2]) == __double_as_longlong(b[2]);
   };
   int nev = 1;
-  float base_sc = evaluate(now);               // both waves (no exchange needed): score of `now` at the start of the sweep
+  float base_sc, unused;
+  score2(now, now, base_sc, unused);           // score of `now` at the start of the sweep
   double base_q[3] = {now[0], now[1], now[2]};
   double rt = (double)base_sc;
   for (int sweep = 0; sweep < 40; ++sweep) {
@@ -264,12 +284,10 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
     bool have_acc = false;
     for (int j = 0; j < 3; ++j) {
       const double lo = now[j] - d[j], hi = lo + 2. * d[j];          // the reference's two candidates, in its arithmetic
-      double q[3] = {now[0], now[1], now[2]};
-      q[j] = sub ? hi : lo;
-      const float mine = evaluate(q);
-      unsigned u0, u1;
-      exchange(__float_as_uint(mine), u0, u1);
-      const float sc_lo = __uint_as_float(u0), sc_hi = __uint_as_float(u1);
+      double qa[3] = {now[0], now[1], now[2]}, qb[3] = {now[0], now[1], now[2]};
+      qa[j] = lo; qb[j] = hi;
+      float sc_lo, sc_hi;
+      score2(qa, qb, sc_lo, sc_hi);
       ++nev;
       if ((double)sc_lo > rt) {                  // (rt only changes between sweeps)
         now[j] = lo; flag = 1; have_acc = true; acc_sc = sc_lo;
@@ -288,12 +306,12 @@ __global__ __launch_bounds__(64 * FIT_WAVES) void ellipse_fit_k(const long long*
     float sc;
     if (same(now, base_q)) sc = base_sc;
     else if (have_acc && same(now, acc_q)) sc = acc_sc;
-    else sc = evaluate(now);
+    else score2(now, now, sc, unused);
     if ((double)sc > rt) rt = (double)sc;
     base_sc = sc; base_q[0] = now[0]; base_q[1] = now[1]; base_q[2] = now[2];
     if (!flag) break;
   }
-  if (sub == 0 && lane == 0) {
+  if (wv == 0 && lane == 0) {
     out[e * 5 + 0] = cx; out[e * 5 + 1] = cy; out[e * 5 + 2] = now[0]; out[e * 5 + 3] = now[1];
     out[e * 5 + 4] = now[2] / 180.0 * PI_REF;
     if (evals) evals[e] = nev;
@@ -346,9 +364,16 @@ extern "C" int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t*
                                 void* stream) {
   EGNE_REQUIRE(mask && frame_of && cls && xs && ys && init && out, "ellipse_fit: null pointer");
   EGNE_REQUIRE(n > 0 && nframes > 0 && H > 1 && W > 1, "ellipse_fit: bad shape");
-  const size_t lds = ((size_t)FIT_PAIRS * (H * ((W + 31) / 32) + 4) + W + H) * 4;
-  EGNE_REQUIRE(lds <= 60 * 1024, "ellipse_fit: %dx%d masks do not fit LDS", H, W);
-  hipLaunchKernelGGL(ellipse_fit_k, dim3((n + FIT_PAIRS - 1) / FIT_PAIRS), dim3(64 * FIT_WAVES), lds, (hipStream_t)stream, (const long long*)mask,
-                     nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
+  const size_t per_search = ((size_t)H * ((W + 31) / 32) + 32) * 4, fixed = (size_t)(W + H) * 4;
+  EGNE_REQUIRE(2 * per_search + fixed <= 64 * 1024, "ellipse_fit: %dx%d masks do not fit LDS", H, W);
+  hipStream_t st = (hipStream_t)stream;
+  const long long* mk = (const long long*)mask;
+  if (n >= 16) {           // a batch: two searches of two waves per workgroup
+    const size_t lds = fixed + 2 * ((size_t)H * ((W + 31) / 32) + 8) * 4;
+    hipLaunchKernelGGL((ellipse_fit_k<2, 1>), dim3((unsigned)((n + 1) / 2)), dim3(256), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
+  } else {                 // one or two frames: a workgroup of eight waves per search (the rows of an evaluation in one pass)
+    const size_t lds = fixed + ((size_t)H * ((W + 31) / 32) + 32) * 4;
+    hipLaunchKernelGGL((ellipse_fit_k<1, 4>), dim3((unsigned)n), dim3(512), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
+  }
   return egne::check_launch("egne_ellipse_fit");
 }
