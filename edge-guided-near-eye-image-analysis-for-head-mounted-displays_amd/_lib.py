@@ -83,6 +83,8 @@ SIGNATURES = {
     "egne_spatial_weights": (i32, [vp, i32, i32, i32, vp, vp]),
     "egne_deepvog_loss_workspace_floats": (i64, [i32, i32, i32]),
     "egne_deepvog_loss_fwd": (i32, [vp, i64, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "egne_deepvog_loss_bwd": (i32, [vp, i64, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, i32, vp]),
+    "egne_affine_act": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp, vp, i32, vp]),
     "egne_augment": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "egne_conv3x3_smallcin_f16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, f32, f32, vp]),
     "egne_pack_conv3x3_c4_weight_f16": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),

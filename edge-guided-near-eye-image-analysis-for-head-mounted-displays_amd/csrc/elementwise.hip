@@ -137,6 +137,21 @@ __global__ void affine_k(const T* x, long long pix_stride, int ch_off, T* y, lon
   }
 }
 
+// y = act(x * scale[c] + shift[c]): BatchNorm followed by its activation (models/deepvog_pytorch.py:36-41)
+__global__ void affine_act_k(const float* x, long long pix_stride, int ch_off, float* y, long long ys, int yo, int Cp,
+                             long long npix, const float* __restrict__ scale, const float* __restrict__ shift, float slope) {
+  const int nv = Cp >> 2;
+  const long long total = npix * nv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / nv;
+    const int c = (int)(i - p * nv) * 4;
+    f32x4 v = ld4(x + p * pix_stride + ch_off + c) * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+    st4(y + p * ys + yo + c, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void avgpool2_k(const T* __restrict__ x, long long xs, int xo, T* __restrict__ y, long long ys,
@@ -412,6 +427,15 @@ extern "C" int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int
 extern "C" int egne_affine(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix,
                            const float* scale, const float* shift, void* stream) {
   return affine_impl<float>(x, xs, xo, y, ys, yo, Cp, npix, scale, shift, stream);
+}
+extern "C" int egne_affine_act(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix,
+                               const float* scale, const float* shift, int act, void* stream) {
+  EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(y, ys, yo, Cp) && scale && shift && npix > 0, "affine_act: bad arguments");
+  EGNE_REQUIRE(act == EGNE_ACT_NONE || act == EGNE_ACT_RELU || act == EGNE_ACT_LEAKY, "affine_act: activation %d", act);
+  const float slope = act == EGNE_ACT_RELU ? 0.f : (act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  hipLaunchKernelGGL(affine_act_k, dim3(grid_for(npix * (Cp / 4))), dim3(256), 0, (hipStream_t)stream, x, (long long)xs, xo, y,
+                     (long long)ys, yo, Cp, (long long)npix, scale, shift, slope);
+  return egne::check_launch("egne_affine_act");
 }
 extern "C" int egne_affine_bf16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int Cp, int64_t npix,
                                 const float* scale, const float* shift, void* stream) {

@@ -321,7 +321,64 @@ __global__ __launch_bounds__(256) void deepvog_loss_final_k(const float* __restr
   }
 }
 
+// Backward of the DeepVOG loss w.r.t. the two logits of every pixel (gradient of `gscale` * loss), from the forward's pred_c and per-block
+// partials (the soft-argmax normaliser is rebuilt from them).  g = d l_seg + d l_pt:
+//   l_seg: w_b = 10 * ok_b / (sum ok * H * W);  q = softmax(p) with p = softmax(op);  dp_c = w_b (q_c - [c == t]);  dop_c = p_c (dp_c - sum_k dp_k p_k)
+//   l_pt : pred = sum_i s_i (x_i, y_i), s = softmax_i(4 op_1);  dop_1,i += 4 s_i ((x_i - px) sgn_x + (y_i - py) sgn_y) / (2 B)
+__global__ __launch_bounds__(256) void deepvog_loss_bwd_k(const float* __restrict__ logits, long long ps, int ch_off,
+                                                         const long long* __restrict__ target, const float* __restrict__ pupil_center,
+                                                         const float* __restrict__ cond, const float* __restrict__ partials,
+                                                         const float* __restrict__ pred_c, const float* __restrict__ gscale, int B, int H,
+                                                         int W, int nblk, float* __restrict__ g, long long gs, int go) {
+  const int b = blockIdx.y, hw = H * W;
+  __shared__ float sh[4];
+  if (threadIdx.x == 0) {
+    Lse a{-INFINITY, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nblk; ++k) {
+      const float* r = partials + ((long long)b * nblk + k) * DV_NPART;
+      Lse t{r[0], r[1], r[2], r[3]};
+      lse_merge(a, t);
+    }
+    float ok = 0.f;
+    for (int i = 0; i < B; ++i) ok += 1.f - cond[i * 4 + 1];
+    sh[0] = a.m; sh[1] = a.s;
+    sh[2] = ok != 0.f ? 10.f * (1.f - cond[b * 4 + 1]) / (ok * (float)hw) : 0.f;
+  }
+  __syncthreads();
+  const float m = sh[0], S = sh[1], wseg = sh[2] * gscale[0];
+  const float px = pred_c[b * 2], py = pred_c[b * 2 + 1];
+  const float tx = 2.f * (pupil_center[b * 2] / (float)W) - 1.f, ty = 2.f * (pupil_center[b * 2 + 1] / (float)H) - 1.f;
+  const float sx = (px > tx) - (px < tx), sy = (py > ty) - (py < ty);
+  const float wpt = gscale[0] * 4.f / (2.f * (float)B);
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+    const long long gp = (long long)b * hw + p;
+    const float* q = logits + gp * ps + ch_off;
+    const float v0 = q[0], v1 = q[1];
+    const float mm = fmaxf(v0, v1), e0 = expf(v0 - mm), e1 = expf(v1 - mm), inv = 1.f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const float pm = fmaxf(p0, p1), f0 = expf(p0 - pm), f1 = expf(p1 - pm), fi = 1.f / (f0 + f1);
+    const int t = target[gp] == 2;
+    const float d0 = wseg * (f0 * fi - (t ? 0.f : 1.f)), d1 = wseg * (f1 * fi - (t ? 1.f : 0.f));
+    const float dot = d0 * p0 + d1 * p1;
+    const int y = p / W, x = p - y * W;
+    const float s = expf(4.f * v1 - m) / S;
+    float* o = g + gp * gs + go;
+    o[0] = p0 * (d0 - dot);
+    o[1] = p1 * (d1 - dot) + wpt * s * ((lin11(x, W) - px) * sx + (lin11(y, H) - py) * sy);
+  }
+}
+
 }  // namespace
+
+extern "C" int egne_deepvog_loss_bwd(const float* logits, int64_t pix_stride, int ch_off, const int64_t* target, const float* pupil_center,
+                                     const float* cond, int B, int H, int W, const float* partials, const float* pred_c, const float* gscale,
+                                     float* g_logits, int64_t gs, int go, void* stream) {
+  EGNE_REQUIRE(logits && target && pupil_center && cond && partials && pred_c && gscale && g_logits, "deepvog_loss_bwd: null pointer");
+  EGNE_REQUIRE(B > 0 && H > 1 && W > 1 && ch_off + 2 <= pix_stride && go + 2 <= gs, "deepvog_loss_bwd: bad shape");
+  hipLaunchKernelGGL(deepvog_loss_bwd_k, dim3(64, B), dim3(256), 0, (hipStream_t)stream, logits, (long long)pix_stride, ch_off,
+                     (const long long*)target, pupil_center, cond, partials, pred_c, gscale, B, H, W, loss_nblk(H, W), g_logits, (long long)gs, go);
+  return egne::check_launch("egne_deepvog_loss_bwd");
+}
 
 extern "C" int64_t egne_deepvog_loss_workspace_floats(int B, int H, int W) { return (int64_t)B * loss_nblk(H, W) * DV_NPART; }
 

@@ -454,6 +454,11 @@ class TransposedLayer(ConvLayer):
         elif fwd.stride == 2 and (fwd.kh, fwd.kw) == (4, 4) and fwd.pad == (1, 1):
             assert C_ == Cp_, "phase-packed dgrad: input slice must not be channel padded"
             shape, khw, pad, cout_pad, self.phase = (4 * C_, fwd.Cout, 2, 2), (2, 2), (1, 1), 4 * Cp_, 1
+        elif fwd.stride == 2 and (fwd.kh, fwd.kw) == (2, 2) and fwd.pad == (0, 0):
+            # non-overlapping windows (models/deepvog_pytorch.py:22): input pixel (2m + a, 2n + b) only hears from output (m, n) through
+            # tap (a, b) -- a 1x1 convolution per phase, the four phases as channel blocks: W'[(a,b,ci)][co] = w[co][ci][a][b]
+            assert C_ == Cp_, "phase-packed dgrad: input slice must not be channel padded"
+            shape, khw, pad, cout_pad, self.phase = (4 * C_, fwd.Cout, 1, 1), (1, 1), (0, 0), 4 * Cp_, 2
         else:
             raise NotImplementedError("dgrad of a %dx%d stride-%d convolution" % (fwd.kh, fwd.kw, fwd.stride))
         self.derived = torch.zeros(shape, dtype=torch.float32, device=dev)
@@ -462,7 +467,10 @@ class TransposedLayer(ConvLayer):
 
     def refresh(self):
         w = self.fwd.weights[0].detach()
-        if self.phase:
+        if self.phase == 2:
+            Co, Ci = w.shape[:2]
+            self.derived.copy_(w.permute(2, 3, 1, 0).reshape(4 * Ci, Co, 1, 1))
+        elif self.phase:
             Co, Ci = w.shape[:2]
             v = w.view(Co, Ci, 2, 2, 2, 2).flip(2).flip(4)            # [co][ci][j][a][i][b], j = 1 - t
             self.derived.copy_(v.permute(3, 5, 1, 0, 2, 4).reshape(4 * Ci, Co, 2, 2))
@@ -1337,7 +1345,7 @@ class Plan:
                 continue
             if layer.stride != 1 or layer.pad_mode == 1:
                 # reflect-padded / strided blocks: gradient w.r.t. the padded input, then fold the padding back
-                assert pc.scale is None and layer.pad_mode == 1 and layer.pad[0] == layer.pad[1]
+                assert pc.scale is None and layer.pad[0] == layer.pad[1] and (layer.pad_mode == 1 or (layer.stride, layer.kh, layer.kw, layer.pad[0]) == (2, 2, 2, 0))
                 tl = TransposedLayer(layer, i, self.device)
                 self.pre.append(tl.guard)            # forward plan: refreshed before the backward plan re-packs
                 hp, wp = tl.out_hw(Ho, Wo)
@@ -1350,7 +1358,7 @@ class Plan:
                 tmp = bw.buf(B, hp, wp, tl.Cout_store)
                 bw.conv(tl, [gin], Piece(tmp, 0, tl.Cout, tl.Cout_store), B, Ho, Wo, name=name + ".dgrad_pad")
                 tgt = self.gp(pc)
-                bw.raw(L.egne_reflect_pad_bwd, (tmp.data_ptr(), tmp.shape[-1], 0, tl.phase, pc.Cp, tgt.ptr, tgt.stride, tgt.off,
+                bw.raw(L.egne_reflect_pad_bwd, (tmp.data_ptr(), tmp.shape[-1], 0, 1 if tl.phase else 0, pc.Cp, tgt.ptr, tgt.stride, tgt.off,
                                                 B, H, W, P), name + ".pad_bwd")
                 continue
             bf_dgrad = (self.bf16 and BF16_FAST3X3 and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1

@@ -387,6 +387,15 @@ int64_t egne_deepvog_loss_workspace_floats(int B, int H, int W);
 int egne_deepvog_loss_fwd(const float* logits, int64_t pix_stride, int ch_off, const int64_t* target, const float* pupil_center,
                           const float* cond, int B, int H, int W, float* partials, float* out_terms, float* pred_c,
                           float* op_nchw, int64_t* mask, void* stream);
+/* Its backward (loss.backward() of train.py:286 for this comparator): g_logits[b][y][x][go .. go+2) = gscale[0] * d loss / d logits, from the
+ * forward's `partials` and `pred_c` (the launch stores, it does not accumulate). */
+int egne_deepvog_loss_bwd(const float* logits, int64_t pix_stride, int ch_off, const int64_t* target, const float* pupil_center,
+                          const float* cond, int B, int H, int W, const float* partials, const float* pred_c, const float* gscale /* device */,
+                          float* g_logits, int64_t gs, int go, void* stream);
+/* y = act(x * scale[c] + shift[c]) over an NHWC fp32 slice: BatchNorm (scale / shift from its statistics) followed by its activation,
+ * the order of models/deepvog_pytorch.py:36-41 (conv -> bn -> relu). */
+int egne_affine_act(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int Cp, int64_t npix, const float* scale,
+                    const float* shift, int act, void* stream);
 
 /* Nearest-neighbour x2 up-sampling of an NHWC slice and its transpose (gx += the four copies): F.interpolate(scale_factor=2,
  * mode='nearest') of the comparator model models/RITnet_v1.py:89 (H, W = INPUT size).  bf16 twins: *_bf16. */

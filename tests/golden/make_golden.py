@@ -462,6 +462,25 @@ def gold_deepvog():
                      tag + "_op_sum": npy(out.double().sum((2, 3))), tag + "_op_absmax": np.array(out.abs().max().item()),
                      tag + "_mask": np.packbits(npy(out.max(1)[1]).astype(np.uint8) == 1),
                      tag + "_gap_lt_2e3": np.array(int(((srt[:, 0] - srt[:, 1]) < 2e-3).sum()))})
+    # training mode (batch statistics) on the three-frame case: loss, running statistics of the first and a deep BatchNorm, every
+    # parameter's gradient norm and a few full gradients (up_block5.conv2 / bn2 are built but unused: no gradient)
+    b = synth.make_batch(3, seed=1234)
+    b["cond"][1, 1] = 1.0
+    m.train()
+    m.zero_grad()
+    out, elPred, emb, loss, _ = quiet(m, *batch_args(b, torch.zeros_like(b["img"])))
+    loss.sum().backward()
+    arrs.update(t_loss=npy(loss), t_op_sub=npy(out[:, :, ::4, ::4]), t_op_absmax=np.array(out.abs().max().item()),
+                t_bn1_rm=npy(m.down_block1.bn1.running_mean), t_bn1_rv=npy(m.down_block1.bn1.running_var),
+                t_bnu_rm=npy(m.up_block2.bn2.running_mean), t_bnu_rv=npy(m.up_block2.bn2.running_var))
+    names, gl2 = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            gl2.append(p.grad.double().norm().item())
+    arrs.update(grad_names=np.array(names), grad_l2=np.array(gl2))
+    for k in ("down_block1.conv1.weight", "down_block2.conv2.weight", "up_block1.bn2.bias", "conv1.weight", "down_block4.bn2.weight"):
+        arrs["grad::" + k] = npy(dict(m.named_parameters())[k].grad)
     save("deepvog_b2", **arrs)
     import json
     keys = os.path.join(HERE, "state_keys.json")

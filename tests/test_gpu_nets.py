@@ -571,9 +571,56 @@ def test_deepvog_eval_vs_reference(tag):
         m.down_block2.bn1.running_mean.add_(0.05)
         out2 = m(*args)[0]
     assert (out2 - out).abs().max().item() > 1e-4 * scale
-    m.train()
+
+
+def test_deepvog_train_step_vs_reference():
+    """DeepVOG in training mode (BatchNorm with batch statistics before the ReLU, 2x2 / stride-2 convolutions and their phase-packed data
+    gradient, its own loss backward) against the reference-generated fixture: loss and logits at 1e-3, running statistics, EVERY
+    parameter's gradient norm within 2e-3 of the largest norm (the conv biases in front of a batch-statistics BatchNorm have a zero
+    gradient: round-off on both sides) and five full gradients; the unused up_block5.conv2 / bn2 receive none; a second identical step
+    reproduces the first (replayed plan, zeroed gradient arena)."""
+    from common import gold
+    from test_oracle_golden import _deepvog_case
+    from egne_amd import synth
+    from egne_amd.modelSummary import get_model
+    g = gold("deepvog_b2")
+    m = get_model("deepvog", None)
+    sd0 = synth.seeded_state_dict(m.state_dict(), seed=1, kind="esf")
+    m.load_state_dict(sd0)
+    m = m.to(DEV).train()
+    b = _deepvog_case("b3")
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in
+            (b["img"], torch.zeros_like(b["img"]), b["label"], b["pupil_center"], b["elNorm"], b["spatWts"], b["distMap"], b["cond"], b["ID"], b["alpha"])]
+    grads = []
+    for step in range(2):
+        m.load_state_dict(sd0)                                   # (running statistics back to the start)
+        m.zero_grad(set_to_none=True)
+        out, elPred, emb, loss, _ = m(*args)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+    scale = float(g["t_op_absmax"])
+    assert np.abs(out.detach().cpu()[:, :, ::4, ::4].numpy() - g["t_op_sub"]).max() < 1e-3 * max(scale, 1.0)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g["t_loss"], rtol=1e-3)
+    np.testing.assert_allclose(m.down_block1.bn1.running_mean.cpu().numpy(), g["t_bn1_rm"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(m.down_block1.bn1.running_var.cpu().numpy(), g["t_bn1_rv"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(m.up_block2.bn2.running_mean.cpu().numpy(), g["t_bnu_rm"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(m.up_block2.bn2.running_var.cpu().numpy(), g["t_bnu_rv"], rtol=1e-3, atol=1e-5)
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([grads[1][n].double().norm().item() for n in names])
+    rel = np.abs(got - g["grad_l2"]) / g["grad_l2"].max()
+    worst = int(rel.argmax())
+    print("deepvog gradients: worst norm deviation %.2e of the largest norm (%s)" % (rel[worst], names[worst]))
+    assert rel.max() < 2e-3
+    for k in [k[6:] for k in g.files if k.startswith("grad::")]:
+        ref = g["grad::" + k]
+        assert np.abs(grads[1][k].numpy() - ref).max() < 2e-3 * max(np.abs(ref).max(), 1e-6), k
+    for k in ("up_block5.conv2.weight", "up_block5.bn2.weight"):
+        assert float(grads[1][k].abs().max()) == 0.0            # views of the gradient arena exist for every parameter; these stay zero
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
     with pytest.raises(NotImplementedError):
-        m(*args)
+        m.to(torch.bfloat16)
 
 
 def test_graphed_frames_replay_is_bit_identical():

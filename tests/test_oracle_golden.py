@@ -234,6 +234,20 @@ def test_deepvog_comparator_vs_reference():
         np.testing.assert_array_equal(g[tag + "_pred_c"], g[tag + "_pred_c2"])
         assert (g[tag + "_emb"] == 1).all() and g[tag + "_emb"].shape == (out.shape[0], 5)
         assert np.array_equal(np.packbits(out.max(1)[1].numpy().astype(np.uint8) == 1), g[tag + "_mask"])
+    # training mode: batch statistics, loss, running statistics, gradient norms (conv biases in front of a batch-statistics BatchNorm
+    # have a zero gradient up to round-off: compared on the scale of the largest norm)
+    b = _deepvog_case("b3")
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    upd = {}
+    out, pc, loss, _ = o.deepvog_forward(sdg, b["img"], b["label"], b["pupil_center"], b["cond"], training=True, update=upd)
+    loss.sum().backward()
+    np.testing.assert_allclose(loss.detach().numpy(), g["t_loss"], rtol=2e-6)
+    np.testing.assert_allclose(upd["down_block1.bn1.running_mean"].numpy(), g["t_bn1_rm"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(upd["up_block2.bn2.running_var"].numpy(), g["t_bnu_rv"], rtol=1e-5, atol=1e-6)
+    names = [str(n) for n in g["grad_names"]]
+    got = np.array([sdg[n].grad.double().norm().item() for n in names])
+    assert np.abs(got - g["grad_l2"]).max() < 1e-4 * g["grad_l2"].max()
+    assert sdg["up_block5.conv2.weight"].grad is None and "up_block5.conv2.weight" not in names          # built but unused (:81-82)
 
 
 def _augment_cases():
