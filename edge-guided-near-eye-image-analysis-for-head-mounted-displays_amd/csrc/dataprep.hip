@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void augment_k(const unsigned char* __restrict
       unsigned char o = v;
       if (ch == 2) o = lut[b * 256 + v];
       else if (ch == 3 || ch == 4) {
-        double f = __dadd_rn((double)v, ch == 3 ? p : __dmul_rn(p, noise[r + x]));   // no fma: NumPy rounds the product first
+        double f = __dadd_rn((double)v, ch == 3 ? p : (noise ? __dmul_rn(p, noise[r + x]) : 0.0));   // no fma: NumPy rounds the product first
         f = f < 0.0 ? 0.0 : (f > 255.0 ? 255.0 : f);
         o = (unsigned char)(int)f;
       }

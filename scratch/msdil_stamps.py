@@ -1,9 +1,11 @@
-import os, sys
+"""Where the waves of the one-launch dilated-group kernel spend their cycles (egne_msdil_debug stamps, dbg bit 64): per producer wave the
+cycles in weight loads / gather+convert / weight stores and at barriers, per consumer wave MFMA work vs waiting at barriers."""
+import os, sys, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
-os.environ["EGNE_MSDIL_DBG"] = "16"
 import torch, numpy as np
 import egne_amd
+from egne_amd import _lib
 from egne_amd.engine import ConvLayer, Piece, Plan
 DEV = torch.device('cuda:0')
 B, H, W = 64, 240, 320
@@ -15,12 +17,24 @@ bs = [torch.nn.Parameter(torch.randn(32, generator=g).to(DEV)) for _ in range(3)
 layer = ConvLayer(ws, bs, [(32, 32)], pad=(1, 1), dils=(4, 8, 12), act=1); layer.split = True
 out = pl.buf(B, H, W, 32)
 pl.conv(layer, [Piece(ob, 0, 32)], Piece(out, 0, 32), B, H, W, residual=Piece(ob, 0, 32))
+print(pl.meta[-1][0])
+L = _lib.lib()
+L.egne_msdil_debug.restype = C.c_int
+L.egne_msdil_debug.argtypes = [C.c_int, C.c_void_p]
 for _ in range(3): pl.run()
 torch.cuda.synchronize()
-st = out.view(torch.int64).reshape(-1)[:8 * 9 * 8].cpu().numpy().reshape(8, 9, 8)
-t0 = st[0, 0, 0]
-for w in range(8):
-    if w < 4:
-        print("P%d" % w, " ".join("[%d +%d +%d]" % (st[w, s, 0] - t0, st[w, s, 1] - st[w, s, 0], st[w, s, 2] - st[w, s, 1]) for s in range(9)))
-    else:
-        print("C%d" % w, " ".join("[%d wait %d]" % (st[w, s, 0] - t0, st[w, s, 1] - st[w, s, 0]) for s in range(9)))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); [pl.run() for _ in range(10)]; e1.record(); torch.cuda.synchronize()
+print("launch (both column classes): %.1f us" % (e0.elapsed_time(e1) * 100))
+for dbg, what in ((64, "stamps"), (64 | 2, "stamps, conversion off"), (64 | 1, "stamps, loads off")):
+    assert L.egne_msdil_debug(dbg, None) == 0
+    pl.run(); torch.cuda.synchronize()
+    st = np.zeros(256 * 8 * 4, np.uint64)
+    assert L.egne_msdil_debug(0, st.ctypes.data_as(C.c_void_p)) == 0
+    st = st.reshape(256, 8, 4).astype(np.int64)
+    ntile = st[:, 4:, 2].max()
+    prod = st[:, :4]; cons = st[:, 4:]
+    print("%s: tiles per workgroup %d" % (what, ntile))
+    print("  producers (mean cycles per workgroup): weights+issue %d, gather/convert %d, weight stores %d, barrier wait per tile %d" % (
+        prod[..., 0].mean(), prod[..., 1].mean(), prod[..., 3].mean(), (prod[..., 2] >> 32).mean()))
+    print("  consumers: work %d, wait %d" % (cons[..., 0].mean(), cons[..., 1].mean()))
