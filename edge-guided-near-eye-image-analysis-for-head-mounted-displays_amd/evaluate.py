@@ -30,6 +30,7 @@ def parse_args(argv=None):
     p.add_argument('--path2data', type=str, default='videos')
     p.add_argument('--align_width', type=int, default=1)
     p.add_argument('--method', type=str, default='baseline')
+    p.add_argument('--model', type=str, default='ritnet_v2')                            # evaluate.py:37,362-367: 'ritnet_v2' | 'deepvog'
     p.add_argument('--loadfile', type=str, default='logs/baseline_edge_16.pkl')        # evaluate.py:357
     p.add_argument('--setting', type=str, default='configs/baseline_edge.yaml')        # evaluate.py:359
     p.add_argument('--max_frames', type=int, default=0)
@@ -347,8 +348,15 @@ def main(argv=None):
     args = parse_args(argv)
     device = torch.device('cuda')
     setting = _entry.load_setting(args.setting)
+    if args.model not in ('ritnet_v2', 'deepvog'):
+        sys.exit('evaluate.py: illegal model %r (evaluate.py:362-367 knows ritnet_v2 and deepvog)' % args.model)
     if args.synthetic:
         edge_net, model = _entry.seeded_networks(setting)
+        if args.model == 'deepvog':
+            from egne_amd import synth
+            from egne_amd.modelSummary import get_model
+            model = get_model('deepvog', None)
+            model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=1, kind='esf'))
     else:
         for need in (args.loadfile, 'gen_00000016.pt'):        # the reference dies in torch.load (evaluate.py:360-371)
             if not os.path.exists(need):
@@ -357,7 +365,7 @@ def main(argv=None):
         from egne_amd.modelSummary import get_model
         edge_net = BDCN()
         edge_net.load_state_dict(torch.load('gen_00000016.pt', map_location='cpu')['a'])
-        model = get_model('ritnet_v2', setting)
+        model = get_model(args.model, setting)
         model.load_state_dict(torch.load(args.loadfile, map_location='cpu')['state_dict'], strict=True)
     edge_net, model = edge_net.to(device).eval(), model.to(device).eval()
     if args.synthetic:

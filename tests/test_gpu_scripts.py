@@ -63,6 +63,16 @@ def test_evaluate_py_synthetic():
     assert pup.shape == (2, 5) and iri.shape == (2, 5) and np.isfinite(pup).all() and np.isfinite(iri).all()
 
 
+def test_evaluate_py_model_flag():
+    """--model (evaluate.py:37,362-367): the DeepVOG comparator runs through the same edge -> seg -> fit path (its two-class output has
+    no iris class: the ellipses are whatever the search makes of the seeds, as in the reference); anything else is refused."""
+    from egne_amd import evaluate as E
+    pup, iri = E.main(["--synthetic", "2", "--model", "deepvog"])
+    assert pup.shape == (2, 5) and iri.shape == (2, 5)
+    with pytest.raises(SystemExit):
+        E.main(["--synthetic", "2", "--model", "ritnet_v9"])
+
+
 def test_evaluate_on_real_video_frames():
     """Real frames of the reference's videos/example1.avi (fixture: 4 eye crops) through the evaluate
     path: logits within 1e-3 of the reference, identical masks, and -- given the same (mask, initial
