@@ -327,3 +327,44 @@ def test_first_writer_bookkeeping_of_gradient_slices():
     w1 = pl._new_slot()
     assert w1 == w0 + 4 and pl.ndyn == 2 and pl.dynbuf.dtype == torch.int32
     assert pl._absmax_of[(id(a), 0, 32, 0, 2)][0] == w0
+
+
+def test_augment_draws_consume_the_random_stream_like_the_reference():
+    """egne_amd.data_augment.draw (host side of the batched device augmentation): for every NumPy branch it leaves np.random in the
+    state the reference's augment() leaves it in (restated in oracle/data_augment.py, itself pinned by tests/golden/augment.npz), so a
+    seeded loader selects the same augmentations; the gamma tables are the reference's (data_augment.py:47) after its uint8 cast; the
+    OpenCV branches are refused or skipped on request."""
+    import numpy as np
+    from egne_amd import data_augment as DA, synth
+    from oracle import data_augment as oaug
+    g = np.load(os.path.join(GOLD, "augment.npz"))
+    for gm in (0.6, 0.8, 1.2, 1.4):
+        assert np.array_equal(DA.gamma_table(gm), g["gamma_table_%d" % int(gm * 10)].astype(np.uint8))
+    base, mask, pc, el = synth.augment_case(8)
+    for choice in (0, 2, 3, 4, 7):
+        for seed in (1, 2):
+            np.random.seed(seed)
+            oaug.augment(base, mask, pc, el, choice)
+            want = np.random.get_state()[1].copy(), np.random.get_state()[2]
+            np.random.seed(seed)
+            ch, param, lut, noise = DA.draw(1, base.shape, [choice], host_noise=True)
+            got = np.random.get_state()[1], np.random.get_state()[2]
+            assert np.array_equal(want[0], got[0]) and want[1] == got[1], "branch %d leaves another random state" % choice
+            assert ch[0] == choice and (noise is not None) == (choice == 4)
+    # branch drawn at random: same first draw, same follow-up draws
+    for seed in range(12):
+        first = int(np.random.RandomState(seed).randint(0, 8))
+        np.random.seed(seed)
+        if first in DA.CV2_CHOICES:
+            with pytest.raises(NotImplementedError):
+                DA.draw(1, base.shape)
+            np.random.seed(seed)
+            ch, _, _, _ = DA.draw(1, base.shape, on_cv2="skip")
+            assert ch[0] == 7
+            continue
+        oaug.augment(base, mask, pc, el)
+        want = np.random.get_state()
+        np.random.seed(seed)
+        ch, _, _, _ = DA.draw(1, base.shape, host_noise=True)
+        got = np.random.get_state()
+        assert ch[0] == min(first, 7) and np.array_equal(want[1], got[1]) and want[2] == got[2]
