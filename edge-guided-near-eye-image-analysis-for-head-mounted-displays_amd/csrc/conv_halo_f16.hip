@@ -48,7 +48,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // NW = waves along N: <WM=2, WN, NW=1> gives every wave 2 tile rows x all 32*WN channels; <WM=4, WN=1, NW=2> gives a
 // wave 4 tile rows x 32 of the 64 channels -- same accumulators, but each weight fragment fetched from L1/L2 feeds
 // twice as many MFMAs (PMC: the weight ring of the <2,2,1> shape ran the vector L1 at 80 % of its 64 B/clk).
-template <int WM, int WN, int D, bool LAT, int NW, int PF = 0, bool TP = false>
+template <int WM, int WN, int D, bool LAT, int NW, int PF = 0, bool TP = false, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         float ps = 1.f, pt = 0.f;
         if (p.post_scale && nok) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
         double st_s = 0., st_q = 0.;         // sum / sum of squares of this wave's stored values of channel n (stats_ws)
+        [[maybe_unused]] float pool_keep[16];   // (POOL) stored values of the wave's first row, -inf where nothing was stored
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
@@ -300,8 +301,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
             const double vm = c < cm ? (double)v : 0.;
             st_s += vm; st_q += vm * vm;
+            if constexpr (POOL) {
+              // second output: 2x2 / stride-2 ceil-mode max pooling of the STORED values (vgg16_c.py:70-78 pool behind the convolution).
+              // A wave owns the row pair (y, y + 1), y even, and a lane the pixel pairs (x, x + 1), x even, of its channel: the
+              // four values of a window sit in this lane's registers of the two rows.
+              const float vp = c < cm ? v : -INFINITY;
+              if (tm == 0) pool_keep[r] = vp;
+              else pool_keep[r] = fmaxf(pool_keep[r], vp);
+            }
           }
           acc[tm][tn] = (f32x16)(0.f);
+        }
+        if constexpr (POOL) {
+          if (p.pool_out) {
+            const int y = cur.y0 + wrow * WM, Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+            const __amdgpu_buffer_rsrc_t rpool = make_rsrc(p.pool_out + (long long)cur.b * Hp * Wp * p.pool_pix_stride,
+                                                           (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * 4u);
+            const int xl0 = cur.x0 + 4 * lh;
+            const unsigned q0 = (unsigned)((((y >> 1) * Wp + (xl0 >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + n) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const int c = (r & 3) + 8 * (r >> 2);
+              const float m = fmaxf(pool_keep[r], pool_keep[r + 1]);
+              const bool ok = nok && y < p.H && xl0 + c < p.W;           // the window's first pixel exists (ceil mode clips the rest)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), rpool, (int)(ok ? q0 + (c >> 1) * (int)p.pool_pix_stride * 4 : OOB), 0, 0);
+            }
+          }
         }
         if (!LAT && !TP && NW == 1 && p.stats_ws) {     // one chunk = this wave's rows of this tile (fixed order: deterministic)
           st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
@@ -410,6 +435,21 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
     if (d.dil[0] == 1) return launch_hf<4, 1, 1, false, 2>(d, h, l, a_scale, os, st);
     if (d.dil[0] == 2) return launch_hf<4, 1, 2, false, 2>(d, h, l, a_scale, os, st);
     return launch_hf<4, 1, 1, true, 2>(d, h, l, a_scale, os, st);
+  }
+  if (d.pool_out) {
+    // second output (2x2 / stride-2 ceil-mode max pooling of the stored values): plain walk, dilation 1, a monotonic activation, no post
+    // affine / residual / statistics -- the engine asks for it only then
+    EGNE_REQUIRE(d.dil[0] == 1 && !d.post_scale && !d.residual && !d.stats_ws && ((uintptr_t)d.pool_out & 3) == 0 &&
+                 d.pool_ch_off + d.Cout_store <= d.pool_pix_stride &&
+                 (long long)((d.H + 1) / 2) * ((d.W + 1) / 2) * d.pool_pix_stride * 4 < (1ll << 31), "conv_halo_f16: pooled second output");
+    constexpr size_t lds = (size_t)2 * (8 + 2) * (TW + 2) * LDH * sizeof(_Float16);
+    const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + 7) / 8, ntiles = tiles_x * tiles_y * d.B;
+    const int ny = d.CoutP / (w2 ? 64 : 32);
+    int gx = (256 * 2 + ny - 1) / ny;
+    if (gx > ntiles) gx = ntiles;
+    if (w2) hipLaunchKernelGGL((conv3x3_halo_f16_kernel<2, 2, 1, false, 1, 0, false, true>), dim3(gx, ny), dim3(256), lds, st, d, h, l, a_scale, os, tiles_x, tiles_y, ntiles);
+    else hipLaunchKernelGGL((conv3x3_halo_f16_kernel<2, 1, 1, false, 1, 0, false, true>), dim3(gx, ny), dim3(256), lds, st, d, h, l, a_scale, os, tiles_x, tiles_y, ntiles);
+    return egne::check_launch("egne_conv3x3_halo_f16_fwd");
   }
   static const int pf = [] { const char* e = getenv("EGNE_SHALO_PF"); return e ? atoi(e) : 0; }();
   if (d.dil[0] == 1 && pf == 1) return w2 ? launch_hf<2, 2, 1, false, 1, 1>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false, 1, 1>(d, h, l, a_scale, os, st);

@@ -21,6 +21,7 @@ HALO_F16_MAX_COUTP = int(os.environ.get("EGNE_HALO_F16_MAX_COUTP", "256"))
 LATTICE_ENABLED = os.environ.get("EGNE_LATTICE", "1") != "0"   # dilated MSBlock groups as lattice-halo launches
 LAYER_BYTES = {}          # layer name -> algorithmic bytes of its launch(es) (input slices + stored output), for bench.py --layers
 TDPOOL_FUSED = os.environ.get("EGNE_TDPOOL_FUSED", "1") != "0"     # Transition_down: pooling folded into the 1x1's operand load
+HALO_POOL = os.environ.get("EGNE_HALO_POOL", "1") != "0"       # ... and the halo kernel writes pool2 behind conv2_2
 POOL_FUSED = os.environ.get("EGNE_POOL_FUSED", "1") != "0"     # conv1_2 writes pool1 from its epilogue (conv3x3_rs_f16.hip)
 RW_MIN_W = int(os.environ.get("EGNE_RW_MIN_W", "120"))         # streamed-weights form: narrowest map
 RW_MAX_COUTP = int(os.environ.get("EGNE_RW_MAX_COUTP", "32"))   # ... widest output
@@ -936,6 +937,12 @@ class Plan:
             tx, ty = (W + 31) // 32, (H + 7) // 8
             tall = ((H + 31) // 32) * ((W + 7) // 8) < tx * ty          # the kernel would walk the map transposed
             fuse_stats = stats and STATS_FUSED and layer.dils[0] == 1 and not tall and dst.Cp == int(d.Cout_store)
+            pq = getattr(self, "_pool_req", None)
+            if (pq is not None and POOL_FUSED and HALO_POOL and not lattice and not stats and layer.dils[0] == 1 and layer.post is None
+                    and residual is None and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and pq.Cp >= int(d.Cout_store) and layer.sfrag_coutp() % 64 == 0
+                    and ((H + 1) // 2) * ((W + 1) // 2) * pq.stride < 2 ** 29):
+                d.pool_out, d.pool_pix_stride, d.pool_ch_off = pq.ptr, pq.stride, pq.off      # pool2 of vgg16_c.py:72 from conv2_2's epilogue
+                self.last_pooled = True
             if fuse_stats:
                 ws = self._stats_ws(d, B, tx * ty * 4)
             self._add(self.L.egne_conv3x3_halo_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,

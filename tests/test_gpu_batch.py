@@ -45,7 +45,7 @@ def test_bdcn_big_batch_vs_reference(rep):
     assert "conv_f16x3:big" in kinds, kinds            # the deep trunk kernel is part of this plan
     # ... and so are the role-split 3x3 (conv1_2 with pool1 as its second output), the one-launch dilated groups and the halo kernel
     assert {"conv_f16x3:msdil", "conv_f16x3:halo", "conv_f16x3:first"} <= kinds and kinds & {"conv_f16x3:rs", "conv_f16x3:rw"}, kinds
-    assert sum(n == "vgg.pool" for n in _names(pl)) == 3, "pool1 should come from conv1_2's epilogue"
+    assert sum(n == "vgg.pool" for n in _names(pl)) == 2, "pool1 / pool2 should come from the epilogues of conv1_2 / conv2_2"
     if rep == 20:                                      # B=40: ragged last round -> frame tail on the flat kernel
         assert any(n.endswith(".tail") for n in _names(pl)), "no .tail launch in the B=40 plan"
     print("B=%d: edge err %.2e, kernels %s" % (2 * rep, err, sorted(kinds)))

@@ -923,6 +923,37 @@ def test_conv3x3_role_split_pooled_second_output(G, B, H, W):
         assert (gp - pooled).abs().max().item() / scale < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cout,act", [(2, 120, 160, 128, 1), (2, 61, 83, 128, 2), (1, 40, 96, 64, 1), (1, 9, 33, 192, 1)])
+def test_conv3x3_halo_pooled_second_output(G, B, H, W, Cout, act):
+    """vgg16_c.py:71-72: relu(conv2_2(x)) (128 input channels: the LDS-halo kernel) and its 2x2 / stride 2 / ceil-mode max pooling from ONE
+    launch -- both against a float64 convolution; odd sizes (clipped last window), ragged tiles, LeakyReLU (negative values in the
+    pool), poison around both output slices."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = _rand(G, B, 128, H, W) * 2
+    w, b = _rand(G, Cout, 128, 3, 3) / 34, _rand(G, Cout)
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    truth = F.relu(y) if act == 1 else F.leaky_relu(y)
+    pooled = F.max_pool2d(truth, 2, stride=2, ceil_mode=True)
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(128, 128)], pad=(1, 1), act=act)
+    layer.split = True
+    out, pout = pl.buf(B, H, W, Cout + 8), pl.buf(B, (H + 1) // 2, (W + 1) // 2, Cout + 16)
+    out.fill_(777.0); pout.fill_(777.0)
+    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W, pool=Piece(pout, 8, Cout))
+    assert pl.last_pooled and pl.meta[-1][0] == "conv_f16x3:halo", pl.meta
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        o, q = out.cpu(), pout.cpu()
+        assert (o[..., Cout:] == 777.0).all() and (q[..., :8] == 777.0).all() and (q[..., 8 + Cout:] == 777.0).all()
+        got, gp = o[..., :Cout].permute(0, 3, 1, 2).double(), q[..., 8:8 + Cout].permute(0, 3, 1, 2).double()
+        scale = truth.abs().max().item()
+        assert (got - truth).abs().max().item() / scale < 2e-6
+        assert (gp - pooled).abs().max().item() / scale < 2e-6
+
+
 @pytest.mark.parametrize("Cin,B,H,W,post", [(1, 3, 61, 83, True), (2, 2, 240, 320, True), (3, 2, 33, 64, False)])
 def test_convblock_pair_fused(G, Cin, B, H, W, post):
     """utils.py:1047-1048 convBlock: conv2(leaky(conv1(x))) with conv1 on 1-3 channels, as ONE launch (the first conv's 9 taps
