@@ -1192,8 +1192,7 @@ def test_conv3x3_weight_gradient_split_f16(G, B, Cin, Cout, H, W, norm, mag):
     if norm:
         mean, rstd = x.mean((2, 3)), 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
         xe = F.leaky_relu(F.instance_norm(x.double()))
-    y = F.leaky_relu(F.conv2d(xe, w, b, padding=1))
-    y.backward(gy.double())
+    y_lin = F.conv2d(xe, w, b, padding=1)
     pl = Plan(torch.device(DEV), train=True)
     assert pl.dyn_scales
     (px,) = to_nhwc_buf(pl, [x], B, H, W)
@@ -1218,6 +1217,12 @@ def test_conv3x3_weight_gradient_split_f16(G, B, Cin, Cout, H, W, norm, mag):
         pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV)
         bw.run()
     torch.cuda.synchronize()
+    # the float64 gradient takes the LeakyReLU branch of every pixel from the DEVICE's forward output: a pre-activation within
+    # round-off of zero may land on either side, and with gradients of random sign one such pixel moves the sums by ~1e-3 of their
+    # size (seen with an unlucky draw) -- that is the activation's discontinuity, not the arithmetic under test
+    y_dev = out.cpu()[..., :Cout].permute(0, 3, 1, 2).double()
+    assert ((y_dev > 0) != (y_lin > 0)).double().mean().item() < 1e-4
+    y_lin.backward(gy.double() * torch.where(y_dev > 0, 1.0, 0.01))
     ew = (wd.grad.cpu().double() / 2 - w.grad).abs().max().item() / w.grad.abs().max().item()
     eb = (bd.grad.cpu().double() / 2 - b.grad).abs().max().item() / b.grad.abs().max().item()
     assert ew < 1e-5 and eb < 1e-5, (ew, eb)       # fp32 accumulation over up to 150 000 pixels per weight
