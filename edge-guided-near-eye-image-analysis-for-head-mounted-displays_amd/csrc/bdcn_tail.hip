@@ -66,7 +66,10 @@ __device__ __forceinline__ float convT_at(const float* __restrict__ m, int h, in
   const int yy = y + crop, xx = x + crop;
   float acc = 0.f;
   // in[iy] contributes with tap ky = yy - iy*stride in [0,k)
-  const int iy1 = yy / stride, ix1 = xx / stride;
+  // (stride is 2 / 4 / 8 in bdcn_new.py:91-97: a shift; the general case keeps the division)
+  const bool p2 = (stride & (stride - 1)) == 0;
+  const int sh = 31 - __builtin_clz((unsigned)stride);
+  const int iy1 = p2 ? yy >> sh : yy / stride, ix1 = p2 ? xx >> sh : xx / stride;
 #pragma unroll
   for (int a = 1; a >= 0; --a) {
     const int iy = iy1 - a;
@@ -87,12 +90,12 @@ __device__ __forceinline__ float convT_at(const float* __restrict__ m, int h, in
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// grid (ceil(W / 256), H, B): a thread per pixel, no 64-bit division per element (it cost more than the gathers)
 __global__ __launch_bounds__(256) void bdcn_tail_k(const egne_bdcn_tail_desc d) {
-  const long long HW = (long long)d.H * d.W, total = (long long)d.B * HW;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / HW);
-    const int r = (int)(i - (long long)b * HW);
-    const int y = r / d.W, x = r - y * d.W;
+  const long long HW = (long long)d.H * d.W;
+  const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (x < d.W) {
+    const long long i = (long long)b * HW + (long long)y * d.W + x;
     float sa[5], sb[5];
     sa[0] = d.s[0][i];
     sb[0] = d.s1[0][i];
@@ -173,9 +176,8 @@ extern "C" int egne_bdcn_tail(const egne_bdcn_tail_desc* dp, void* stream) {
     const int oh = (d.h[k] - 1) * d.stride[k] + 2 * d.stride[k], ow = (d.w[k] - 1) * d.stride[k] + 2 * d.stride[k];
     EGNE_REQUIRE(d.crop[k] + d.H <= oh && d.crop[k] + d.W <= ow, "bdcn_tail: stage %d upsampled %dx%d smaller than crop+%dx%d", k, oh, ow, d.H, d.W);
   }
-  long long total = (long long)d.B * d.H * d.W, g = (total + 255) / 256;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(bdcn_tail_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d);
+  EGNE_REQUIRE(d.H <= 65535 && d.B <= 65535, "bdcn_tail: grid limits");
+  hipLaunchKernelGGL(bdcn_tail_k, dim3((unsigned)((d.W + 255) / 256), (unsigned)d.H, (unsigned)d.B), dim3(256), 0, (hipStream_t)stream, d);
   return egne::check_launch("egne_bdcn_tail");
 }
 
