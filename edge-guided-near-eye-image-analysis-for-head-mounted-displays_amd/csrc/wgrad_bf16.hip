@@ -316,16 +316,23 @@ bool wgrad1x1_bf16_supported(const egne_conv_desc& d, long long gzs) {
   }
   const int nco = d.CoutP / 32;
   if (gzs % 8 || d.out_ch_off % 8 || d.Cout_store % 8 || gzs * 256 * 2 >= (1ll << 31)) return false;
-  if (nco + nkc > W1_MAXT || nco * nkc > 64 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
+  // wide layers (the 1x1 convolutions of the decoder's lower levels: up to 15 channel tiles in, 5 out) run as several launches, each
+  // over a group of input tiles with all output tiles: at most 64 block pairs and W1_MAXT staged tiles per launch
+  if (nco > 12 || (long long)d.B * d.Ho * d.Wo < 4096) return false;
+  (void)nkc;
   return true;
 }
 
-static int w1_tiles(const egne_conv_desc& d) {
-  int nt = d.CoutP / 32;
-  for (int s = 0; s < d.nseg; ++s) nt += (d.seg[s].Cp + 31) / 32;
-  return nt;
+// input tiles per launch and the pixel chunk that goes with the staged tile count
+static int w1_group(const egne_conv_desc& d) {
+  const int nco = d.CoutP / 32;
+  int nkc = 0;
+  for (int s = 0; s < d.nseg; ++s) nkc += (d.seg[s].Cp + 31) / 32;
+  int g = 64 / nco;
+  if (g > W1_MAXT - nco) g = W1_MAXT - nco;
+  return g < nkc ? g : nkc;
 }
-static int w1_chunk(const egne_conv_desc& d) { const int nt = w1_tiles(d); return nt <= 4 ? 256 : (nt <= 8 ? 128 : 64); }
+static int w1_chunk(const egne_conv_desc& d) { const int nt = d.CoutP / 32 + w1_group(d); return nt <= 4 ? 256 : (nt <= 8 ? 128 : 64); }
 
 int wgrad1x1_bf16_splits(const egne_conv_desc& d) {
   const long long M = (long long)d.B * d.Ho * d.Wo;
@@ -337,26 +344,37 @@ int wgrad1x1_bf16_splits(const egne_conv_desc& d) {
 
 int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st) {
   if (gzo % 8 || ((uintptr_t)gz & 15)) return fail(EGNE_ERR_ARG, "wgrad1x1_bf16: gz slice must start on a multiple of 8 channels (offset %d)", gzo);
-  const int nco = d.CoutP / 32, nsplit = wgrad1x1_bf16_splits(d);
-  W1Tab tab{};
-  int j = nco, kofs = 0;
+  const int nco = d.CoutP / 32, nsplit = wgrad1x1_bf16_splits(d), group = w1_group(d), ch = w1_chunk(d);
+  // every 32-channel input tile: (slice, first channel, column of the weight gradient)
+  short tseg[64], tc0[64], tk[64];
+  int nkc = 0, kofs = 0;
   for (int s = 0; s < d.nseg; ++s) {
-    for (int c0 = 0; c0 < d.seg[s].Cp; c0 += 32, ++j) { tab.seg[j] = (short)s; tab.c0[j] = (short)c0; tab.kofs[j] = (short)kofs; }
+    for (int c0 = 0; c0 < d.seg[s].Cp; c0 += 32, ++nkc) {
+      if (nkc >= 64) return fail(EGNE_ERR_ARG, "wgrad1x1_bf16: more than 64 input tiles");
+      tseg[nkc] = (short)s; tc0[nkc] = (short)c0; tk[nkc] = (short)kofs;
+    }
     kofs += d.seg[s].Cp;
   }
-  const int nkc = j - nco, ppw = (nco * nkc + 7) / 8, ch = w1_chunk(d);
   const size_t bytes = (size_t)nsplit * d.CoutP * d.Ktot * sizeof(float);
   if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: memset failed");     // channels beyond a slice's blocks
-  const size_t lds = (size_t)(nco + nkc) * ch * 32 * sizeof(egne_bf16);
-  auto go = [&](auto kern) -> int {
-    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
-    if (!raised) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(kern, dim3(nsplit), dim3(512), lds, st, d, gz, gzs, gzo, nsplit, nco, nkc, tab, ws);
-    return check_launch("egne_conv2d_wgrad (1x1, bf16)");
-  };
-  if (ch == 256) return go(wgrad1x1_bf16_kernel<1, 256>);                               // <= 4 tiles: <= 4 pairs
-  if (ch == 128) return ppw <= 1 ? go(wgrad1x1_bf16_kernel<1, 128>) : go(wgrad1x1_bf16_kernel<2, 128>);     // <= 8 tiles: <= 16 pairs
-  return ppw <= 2 ? go(wgrad1x1_bf16_kernel<2, 64>) : ppw <= 4 ? go(wgrad1x1_bf16_kernel<4, 64>) : go(wgrad1x1_bf16_kernel<8, 64>);
+  for (int k0 = 0; k0 < nkc; k0 += group) {        // one launch per group of input tiles (gz is staged again by each)
+    const int nk = nkc - k0 < group ? nkc - k0 : group, ppw = (nco * nk + 7) / 8;
+    W1Tab tab{};
+    for (int i = 0; i < nk; ++i) { tab.seg[nco + i] = tseg[k0 + i]; tab.c0[nco + i] = tc0[k0 + i]; tab.kofs[nco + i] = tk[k0 + i]; }
+    const size_t lds = (size_t)(nco + nk) * ch * 32 * sizeof(egne_bf16);
+    auto go = [&](auto kern) -> int {
+      static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
+      if (!raised) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: cannot raise the dynamic LDS limit");
+      hipLaunchKernelGGL(kern, dim3(nsplit), dim3(512), lds, st, d, gz, gzs, gzo, nsplit, nco, nk, tab, ws);
+      return check_launch("egne_conv2d_wgrad (1x1, bf16)");
+    };
+    int rc;
+    if (ch == 256) rc = go(wgrad1x1_bf16_kernel<1, 256>);                               // <= 4 tiles: <= 4 pairs
+    else if (ch == 128) rc = ppw <= 1 ? go(wgrad1x1_bf16_kernel<1, 128>) : go(wgrad1x1_bf16_kernel<2, 128>);     // <= 8 tiles: <= 16 pairs
+    else rc = ppw <= 2 ? go(wgrad1x1_bf16_kernel<2, 64>) : ppw <= 4 ? go(wgrad1x1_bf16_kernel<4, 64>) : go(wgrad1x1_bf16_kernel<8, 64>);
+    if (rc != 0) return rc;
+  }
+  return 0;
 }
 
 int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st) {

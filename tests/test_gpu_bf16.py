@@ -180,7 +180,8 @@ def test_conv_generic_bf16_storage(G):
 
 
 @pytest.mark.parametrize("kind,Cin,Cout,H,W", [("3x3", 32, 32, 24, 40), ("3x3", 38, 64, 21, 35), ("3x3n", 64, 64, 30, 40),
-                                              ("1x1", 166, 64, 48, 64), ("1x1big", 352, 100, 60, 40)])
+                                              ("1x1", 166, 64, 48, 64), ("1x1big", 352, 100, 60, 40),
+                                              ("1x1wide", 459, 153, 60, 40)])      # 15 input x 5 output tiles: two launches over groups of input tiles
 def test_weight_and_data_gradients_bf16_storage(G, kind, Cin, Cout, H, W):
     """Backward of one convolution of a bf16-storage plan (engine.Plan._bw_conv): activation mask + bias gradient
     (egne_act_bwd_bias_bf16), weight gradient (egne_conv2d_wgrad, dtype 1) and data gradient, against float64 autograd on the
