@@ -522,7 +522,9 @@ int egne_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int kh, 
  * init [n][5] (cx,cy,a,b,theta) pixels, out [n][5] doubles, evals[n] IoU evaluation count (optional).
  * nframes = number of class maps in `mask`; a fit whose frame_of is outside [0, nframes) reads nothing and
  * reports NaN.  Each IoU evaluation scans the ellipse's bounding box only (pixels outside it cannot be inside
- * the ellipse, so the counts -- and therefore the search -- are unchanged).
+ * the ellipse, so the counts -- and therefore the search -- are unchanged).  The two candidates of a coordinate step are scored at the
+ * same time by different waves and a sweep's closing score is looked up when its parameters were scored before; decisions are taken in the
+ * reference's order and evals[] counts the evaluations the reference's sequential search performs (csrc/fit.hip).
  *
  * egne_ellipse_init_from_pred: the seeds of that search straight from the network's regression output on the
  * device (evaluate.py:135-151 does this per frame on the host): elPred [nframes][10] float32 normalised
