@@ -58,6 +58,7 @@ F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of
 STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm statistics from the producing conv's epilogue
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
 FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
+FUSE_C4 = os.environ.get("EGNE_FUSE_C4", "1") != "0"              # convBlock head (3x3 on <= 4 channels + 3x3) as one launch
 CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
 RECAL_EVERY = int(os.environ.get("EGNE_RECAL_EVERY", "1024"))     # inference plans: runs between two calibrations (0: first run only).  The scales
 #   leave 32x of head-room over the calibration batch; a later batch beyond that would overflow f16 silently, so the maxima are re-measured
@@ -1134,7 +1135,7 @@ class Plan:
         # operand of an up block folded through the 1x1; only the fused kernel does this -- callers check pair_fusable first)
         assert up_add is None or (fused and l1.CoutP == 32 and l2.CoutP == 32 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 8), name
         # convBlock (utils.py:1047-1048): a 3x3 on <= 4 input channels in front of the 3x3 -- same kernel, taps folded into K
-        fused_c4 = (FUSE_1X1 and F16X3_ENABLED and not self.train and not self.bf16 and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
+        fused_c4 = (FUSE_1X1 and FUSE_C4 and F16X3_ENABLED and not self.train and not self.bf16 and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
                     and l1.stride == 1 and l1.G == 1 and l1.pad == (1, 1) and l1.pad_mode == 0 and l1.dils[0] == 1 and l1.Cin <= 4
                     and l1.post is None and len(pieces) == 1 and pieces[0].scale is None and pieces[0].Cp >= 4 and l1.CoutP == 32
                     and l2.kh == 3 and l2.kw == 3 and l2.stride == 1 and l2.G == 1 and l2.pad == (1, 1) and l2.dils[0] == 1

@@ -172,7 +172,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     # Inference with one input channel: the image and edge batches sit back to back in ONE [NB][H][W] tensor that the fused
     # convBlock head reads in place (NCHW with C = 1 is NHWC with a pixel pitch of one float) -- no layout kernels, no 8-channel
     # padded staging copy (2 x 315 MB written and read back per step at B = 64).
-    planar_in = (PLANAR_IN and not training and in_c == 1 and _eng.ESF_SPLIT and _eng.FUSE_1X1 and _eng.F16X3_ENABLED
+    planar_in = (PLANAR_IN and not training and in_c == 1 and _eng.ESF_SPLIT and _eng.FUSE_1X1 and _eng.FUSE_C4 and _eng.F16X3_ENABLED
                  and W >= _eng.FUSE_1X1_MIN_W and chz == 32)
     if planar_in:
         pin = pl.vec(NB, 1, H, W)
