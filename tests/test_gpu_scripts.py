@@ -136,6 +136,15 @@ def test_evaluate_video_end_to_end(tmp_path):
         frames = list(E.mjpeg_frames(str(tmp_path / name)))
         assert len(frames) == 4 and frames[0].shape == (240, 640)
     assert os.path.exists(tmp_path / "clip_pred2_baseline.npy")
+    # --low_latency 1: a frame's two eyes per call through the hipGraph replay; the same ellipses up to what the small-batch kernels'
+    # summation order moves (initial ellipses within 1e-3, the search may take another step)
+    args2 = E.parse_args(["--path2data", str(tmp_path), "--low_latency", "1", "--method", "live"])
+    res2 = E.evaluate_ellseg_per_video(str(vid), args2, net, bd, dev)
+    assert set(res2) == set(res)
+    close = sum(np.allclose(res2[k][0], res[k][0], atol=1e-2) and np.allclose(res2[k][1], res[k][1], atol=1e-2) for k in res)
+    assert close >= len(res) - 2, "%d of %d results differ between the batched and the per-frame path" % (len(res) - close, len(res))
+    for k in res:
+        np.testing.assert_allclose(res2[k][0][:2], res[k][0][:2], atol=0.35)
 
 
 _DP_TRAIN_WORKER = r"""
