@@ -17,7 +17,7 @@ c_fp = C.c_void_p  # device pointers travel as integers
 
 class Seg(C.Structure):
     _fields_ = [("ptr", c_fp), ("pix_stride", C.c_int64), ("ch_off", C.c_int32), ("Cp", C.c_int32),
-                ("scale", c_fp), ("shift", c_fp), ("act_in", C.c_int32), ("reserved", C.c_int32)]
+                ("scale", c_fp), ("shift", c_fp), ("act_in", C.c_int32), ("presplit", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -34,7 +34,8 @@ class ConvDesc(C.Structure):
                 ("Cout_store", C.c_int32),
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
                 ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
-                ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p), ("dtype", C.c_int32)]
+                ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p), ("dtype", C.c_int32),
+                ("out_split", C.c_int32), ("out_split_scale", C.c_float)]
 
 
 class BdcnTailDesc(C.Structure):

@@ -197,13 +197,19 @@ class BDCN(nn.Module):
                 l0 = ConvLayer([mb.conv.weight], [mb.conv.bias], [(c_in, pad8(c_in))], pad=(1, 1), act=ACT_RELU)
                 l0.split = True
                 o = Piece(o_buf, 0, 32)
-                pl.conv(l0, [src], o, B, hh, ww, name="ms%s.conv" % b)
                 r = self.rate
                 dil = tuple(r * i if r >= 1 else 1 for i in (1, 2, 3))
                 lg = ConvLayer([mb.conv1.weight, mb.conv2.weight, mb.conv3.weight],
                                [mb.conv1.bias, mb.conv2.bias, mb.conv3.bias], [(32, 32)], pad=(1, 1), dils=dil,
                                act=ACT_RELU)
                 lg.split = True
+                # `o` feeds the three dilated convolutions only (bdcn_new.py:50-54), which stage every element 13.5 times: where the
+                # one-launch kernel runs them, the producer writes o as split hi / lo halves once (engine.SplitScale)
+                if engine.PRESPLIT and pl.msdil_ok(lg, o, hh, ww):
+                    o.presplit = engine.SplitScale()
+                pl.conv(l0, [src], o, B, hh, ww, name="ms%s.conv" % b)
+                if not pl.last_presplit:
+                    o.presplit = None          # (the kernel chosen for this convolution writes plain fp32)
                 if fused_scores is None:
                     fused_scores = SCORES_FUSED and pl.msdil_ok(lg, o, hh, ww)
                     if fused_scores:

@@ -105,6 +105,9 @@ bool wgrad1x1_bf16_supported(const egne_conv_desc& d, long long gzs);   // 1x1 o
 int wgrad1x1_bf16_splits(const egne_conv_desc& d);
 int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long gzs, int gzo, float* ws, hipStream_t st);
 
+int msdil_ps_launch(const egne_conv_desc& d, const void* fhi, const void* flo, float a_scale, float w_scale, const float* score_w,
+                    const float* score_c, float* s0, float* s1, int accumulate, hipStream_t st);   // msblock_dil_ps_f16.hip
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace egne

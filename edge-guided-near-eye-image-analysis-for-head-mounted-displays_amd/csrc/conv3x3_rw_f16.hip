@@ -315,11 +315,32 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           for (int e = 0; e < 4; ++e) v[e] += rv[e];
         }
       }
+      if (p.out_split) {
+        // split-pair storage (egne_conv_desc.out_split): the consumer's hi / lo f16 halves of v * out_split_scale, written here ONCE
+        // instead of being derived by every consumer workgroup that stages the element (the dilated group stages it 13.5 times)
+        h2 h0, h1, l0, l1;
+        egne::split2(v[0], v[1], p.out_split_scale, h0, l0);
+        egne::split2(v[2], v[3], p.out_split_scale, h1, l1);
+        const u32x4 pk = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+        v = __builtin_bit_cast(f32x4, pk);
+      }
       prev[tm][ph][nh] = v;
     };
     auto store_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, prev[tm][ph][nh]), rout, jok[nh] ? tvo[tm][ph] : (int)OOB, nh * 64, 0);
+      if (p.out_split) {
+        // split-pair storage: per pixel and 32-channel block [hi x 32 | lo x 32] halves, the lane's channels {4 kg ..} and {16 + 4 kg ..}
+        // side by side at positions 8 kg .. 8 kg + 7 of either plane (the consumer's weights are packed in that channel order): one
+        // 16-byte store per plane, 64 contiguous bytes per pixel and store instruction as with plain fp32
+        if constexpr (nh == 1) {
+          const u32x4 p0 = __builtin_bit_cast(u32x4, prev[tm][ph][0]), p1 = __builtin_bit_cast(u32x4, prev[tm][ph][1]);
+          const u32x4 hi = {p0[0], p0[1], p1[0], p1[1]}, lo = {p0[2], p0[3], p1[2], p1[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(hi, rout, tvo[tm][ph], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(lo, rout, tvo[tm][ph], 64, 0);
+        }
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, prev[tm][ph][nh]), rout, jok[nh] ? tvo[tm][ph] : (int)OOB, nh * 64, 0);
+      }
     };
     bool have_prev = false;
     lds_barrier();
@@ -468,6 +489,8 @@ extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi
                                 d.pool_ch_off + d.Cout_store <= d.pool_pix_stride &&
                                 (long long)((d.H + 1) / 2) * ((d.W + 1) / 2) * d.pool_pix_stride * 4 < (1ll << 31)), "conv3x3_rw: pooled output");
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv3x3_rw: weights / scales");
+  EGNE_REQUIRE(!d.out_split || (d.out_split_scale > 0.f && d.Cout_store % 32 == 0 && d.out_ch_off % 32 == 0 && !d.pool_out && !d.post_scale && !d.residual),
+               "conv3x3_rw: split-pair output needs whole 32-channel blocks, a positive scale and no pooled / post-affine / residual options");
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
                (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv3x3_rw: frame too large for 32-bit byte offsets");
   const float os = 1.0f / (a_scale * w_scale);

@@ -49,9 +49,12 @@ __device__ __forceinline__ void lds_barrier() {
 // XIN: this launch holds only tiles whose widest strip lies inside the image columns (x0 >= 12, x0 + 32 + 12 <= W): item addresses
 // are then a per-lane constant + a wave-uniform term.  A map is covered by an XIN launch over the interior tile columns and a
 // !XIN launch over the two border columns (cols: 0 = all tile columns, 1 = interior, 2 = the two border columns).
-template <int D0, int D1, int D2, int NPW, bool XIN>       // NPW: producer waves (4 or 8); 4 consumer waves follow them
+// PS: the input (= the residual) is held in SPLIT-PAIR storage (egne_conv_desc.out_split of its producer, written with a_scale):
+// per pixel [hi x 32 | lo x 32] halves, so a producer item is a 16-byte COPY into the operand image (no conversion at all -- the
+// fp32 form splits every element 13.5 times per tile) and the epilogue recovers o = (hi + lo) * inv_a.
+template <int D0, int D1, int D2, int NPW, bool XIN, bool PS>       // NPW: producer waves (4 or 8); 4 consumer waves follow them
 __global__ __launch_bounds__(64 * (NPW + 4))
-void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
+void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale, float inv_a,
                         float out_scale, int tiles_x, int tiles_y, int ntiles, int cols, const float* __restrict__ score_w,
                         const float* __restrict__ score_c, float* __restrict__ s0, float* __restrict__ s1, int accumulate) {
   constexpr int DMAX = D2 > D1 ? (D2 > D0 ? D2 : D0) : (D1 > D0 ? D1 : D0);
@@ -150,12 +153,16 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       stbuf(std::integral_constant<int, BUF>{})[I] = __builtin_amdgcn_raw_buffer_load_b128(r, (on && !(dbg & 1)) ? off : (int)OOB, 0, 0);
     };
     // LDS slot of item I: pixel pg + PPI I, and (pixel >> 2) & 3 = (pg >> 2) & 3 for every I: lane constant + 64 B * PPI * I
-    const int lofs = (ptid >> 3) * 32 + (((piece >> 1) ^ ((ptid >> 5) & 3)) << 3) + ((piece & 1) << 2);
+    const int lofs = PS ? (piece >> 2) * NPXMAX * 32 + (ptid >> 3) * 32 + (((piece & 3) ^ ((ptid >> 5) & 3)) << 3)      // piece = (plane, 16-byte chunk)
+                        : (ptid >> 3) * 32 + (((piece >> 1) ^ ((ptid >> 5) & 3)) << 3) + ((piece & 1) << 2);
     static_assert(PPI % 4 == 0, "the swizzle key of an item must not depend on I");
     auto convert1 = [&](_Float16* buf, auto sc, auto ic) {
       constexpr int S = decltype(sc)::value, I = decltype(ic)::value, BUF = S % NBUF, g = S % 3;
       constexpr int d = dil_of(g), SW = TW + 2 * d;
-      if (TH * SW % PPI == 0 || (ptid >> 3) + PPI * I < TH * SW) {
+      if constexpr (PS) {
+        if (TH * SW % PPI == 0 || (ptid >> 3) + PPI * I < TH * SW)
+          *(u32x4*)&buf[lofs + 32 * PPI * I] = stbuf(std::integral_constant<int, BUF>{})[I];
+      } else if (TH * SW % PPI == 0 || (ptid >> 3) + PPI * I < TH * SW) {
         const f32x4 v = __builtin_bit_cast(f32x4, stbuf(std::integral_constant<int, BUF>{})[I]);
         h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
         egne::split2(v[0], v[1], a_scale, h0, l0);
@@ -298,12 +305,20 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
         const int cm = (nok && y < H) ? cmax : 0;
         const int pix = y * W + xl;
         const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + li) * 4);
-        const unsigned r0 = (unsigned)((pix * (int)p.res_pix_stride + p.res_ch_off + li) * 4);
+        // (split-pair storage keeps channel li at position 8 * ((li >> 2) & 3) + 4 * (li >> 4) + (li & 3) of either plane)
+        const unsigned r0 = PS ? (unsigned)((pix * (int)p.res_pix_stride + p.res_ch_off) * 4 + (8 * ((li >> 2) & 3) + 4 * (li >> 4) + (li & 3)) * 2)
+                               : (unsigned)((pix * (int)p.res_pix_stride + p.res_ch_off + li) * 4);
         float rv[16], sc[32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = (r & 3) + 8 * (r >> 2);
-          rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0));
+          if constexpr (PS) {
+            const unsigned short uh = __builtin_amdgcn_raw_buffer_load_b16(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0);
+            const unsigned short ul = __builtin_amdgcn_raw_buffer_load_b16(rres, (int)(c < cm ? r0 + c * res_step : OOB), 64, 0);
+            rv[r] = ((float)__builtin_bit_cast(_Float16, uh) + (float)__builtin_bit_cast(_Float16, ul)) * inv_a;
+          } else {
+            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(c < cm ? r0 + c * res_step : OOB), 0, 0));
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -384,25 +399,37 @@ extern "C" int egne_msblock_dil_scores_f16_fwd(const egne_conv_desc* dp, const v
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B;
   constexpr size_t lds = ((size_t)2 * 2 * TH * (TW + 24) * 32 + 2 * 12 * 512) * sizeof(_Float16);
-  static bool once = hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  static bool once = hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)msblock_dil_kernel<4, 8, 12, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "msblock_dil: cannot raise the dynamic LDS limit to %zu", lds);
-  const float os = 1.0f / (a_scale * w_scale);
+  const float os = 1.0f / (a_scale * w_scale), inv_a = 1.0f / a_scale;
+  const bool ps = g.presplit != 0;
+  // split-pair input: the residual must be that same slice (bdcn_new.py:54 adds `o` itself), whole 32-channel blocks
+  EGNE_REQUIRE(!ps || (d.residual == g.ptr && d.res_pix_stride == g.pix_stride && d.res_ch_off == g.ch_off && g.ch_off % 32 == 0),
+               "msblock_dil: a split-pair input must also be the residual");
+  static const bool ps_sym = getenv("EGNE_MSDIL_PS_OLD") == nullptr;      // (diagnostics: the producer / consumer kernel with copying producers)
+  if (ps && ps_sym) return egne::msdil_ps_launch(d, fhi, flo, a_scale, w_scale, score_w, score_c, s0, s1, accumulate, (hipStream_t)stream);
+  auto launch = [&](auto xin, int grid, int nt, int cols) {
+    constexpr bool XIN = decltype(xin)::value;
+    if (ps) hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, XIN, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+                               (const _Float16*)flo, a_scale, inv_a, os, tiles_x, tiles_y, nt, cols, score_w, score_c, s0, s1, accumulate);
+    else hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, XIN, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
+                            (const _Float16*)flo, a_scale, inv_a, os, tiles_x, tiles_y, nt, cols, score_w, score_c, s0, s1, accumulate);
+  };
   // interior tile columns (x0 >= 12 and x0 + 44 <= W <=> tile column 1 .. tiles_x - 2 when W >= 32 * (tiles_x - 1) + 12) on the
   // fast-address kernel, the two border columns (or everything on narrow maps) on the checked one
   const bool split = tiles_x > 2 && d.W >= TW * (tiles_x - 1) + 12;
   if (split) {
     const int nt_in = (tiles_x - 2) * tiles_y * d.B, nt_b = 2 * tiles_y * d.B;
-    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, true>), dim3(nt_in < 256 ? nt_in : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
-                       (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, nt_in, 1, score_w, score_c, s0, s1, accumulate);
+    launch(std::true_type{}, nt_in < 256 ? nt_in : 256, nt_in, 1);
     static const bool only_interior = getenv("EGNE_MSDIL_ONLY_INTERIOR") != nullptr;      // diagnostics: stamps of the interior launch
-    if (!only_interior) hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, false>), dim3(nt_b < 256 ? nt_b : 256), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
-                       (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, nt_b, 2, score_w, score_c, s0, s1, accumulate);
+    if (!only_interior) launch(std::false_type{}, nt_b < 256 ? nt_b : 256, nt_b, 2);
   } else {
     int gx = 256;
     if (gx > ntiles) gx = ntiles;
-    hipLaunchKernelGGL((msblock_dil_kernel<4, 8, 12, 4, false>), dim3(gx), dim3(512), lds, (hipStream_t)stream, d, (const _Float16*)fhi,
-                       (const _Float16*)flo, a_scale, os, tiles_x, tiles_y, ntiles, 0, score_w, score_c, s0, s1, accumulate);
+    launch(std::false_type{}, gx, ntiles, 0);
   }
   return egne::check_launch("egne_msblock_dil_f16_fwd");
 }

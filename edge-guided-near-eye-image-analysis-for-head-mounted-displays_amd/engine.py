@@ -87,13 +87,14 @@ def _ptr(t, elem_off=0):
 class Piece:
     """A channel slice [off, off+Cp) of an NHWC fp32 buffer (optionally starting at sample n0)."""
 
-    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd")
+    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd", "presplit")
 
     def __init__(self, buf, off, C_, Cp=None, n0=0):
         self.buf, self.off, self.C, self.Cp, self.n0 = buf, int(off), int(C_), int(Cp or pad8(C_)), int(n0)
         self.scale = self.shift = None
         self.act_in = ACT_NONE
         self.nograd = False
+        self.presplit = None    # a SplitScale: the slice is held in split-pair storage (egne_conv_desc.out_split), see Plan.conv
         assert self.off % 4 == 0 and self.Cp % 8 == 0 and self.off + self.Cp <= buf.shape[-1]
 
     @property
@@ -112,6 +113,24 @@ class Piece:
 
     def samples(self, n0):
         return Piece(self.buf, self.off, self.C, self.Cp, n0)
+
+
+class SplitScale:
+    """Scale of a slice in SPLIT-PAIR storage (include/egne_hip.h, egne_conv_desc.out_split): its producer writes hi = f16(x s),
+    lo = f16(x s - hi) instead of x, its one consumer copies the halves into its operand image.  ``value`` is set when the plan is
+    calibrated, from a bound on the producer's output (max |in| * max_co sum |w| + max |b|): a bound that is loose by 2^k costs
+    k bits of the range in which elements still split into two normal halves (2^-14 of the maximum when it is tight) and nothing
+    of the 22 bits of the large elements."""
+
+    def __init__(self):
+        self.value = F16X3_ASCALE
+
+
+PRESPLIT = os.environ.get("EGNE_PRESPLIT", "1") != "0"    # MSBlock: `o` written in split-pair storage by its producer (resident-weights 3x3)
+# Position p of a 32-channel block in split-pair storage holds channel 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3): the producer's
+# lanes end with channels {4 kg .. 4 kg + 3} and {16 + 4 kg .. 16 + 4 kg + 3} of a pixel (transposed 16x16x32 product) and store them as
+# ONE 16-byte piece per plane; the consumer's weights are packed in the same order (ConvLayer.k_perm).
+SPLIT_PAIR_PERM = torch.tensor([16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3) for p in range(32)])
 
 
 class ConvLayer:
@@ -160,6 +179,7 @@ class ConvLayer:
         self.bp = None
         self._versions = None
         self.post = None  # (scale, shift) tensors [CoutP] for a folded eval-mode BatchNorm
+        self.k_perm = None  # input-channel order of the split-f16 packs (SPLIT_PAIR_PERM when the input is held in split-pair storage)
 
     def _kinv(self, dev):
         k, c0 = [], 0
@@ -170,7 +190,7 @@ class ConvLayer:
 
     def ensure_packed(self, dev):
         vers = tuple(w._version for w in self.weights) + tuple(
-            (b._version if b is not None else -1) for b in (self.biases or []))
+            (b._version if b is not None else -1) for b in (self.biases or [])) + (id(getattr(self, "k_perm", None)),)
         have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
                 and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big)
@@ -286,6 +306,8 @@ class ConvLayer:
             # one power-of-two scale for all groups that puts max|w| in [1024, 2048): hi and lo halves stay f16-normal
             import math
             ws = [w.detach().contiguous() for w in self.weights]
+            if getattr(self, "k_perm", None) is not None:       # the operand image holds the input channels in another order
+                ws = [w[:, self.k_perm.to(w.device)].contiguous() for w in ws]
             age = getattr(self, "_ws_age", 0)
             if not getattr(self, "stale_scale_ok", False) or age % WSCALE_EVERY == 0:
                 mx = max(float(w.abs().max()) for w in ws)          # host sync, at (re)pack time only
@@ -677,7 +699,7 @@ class Plan:
     def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None, pool=None):
         """``pool``: a Piece for the 2x2 / stride-2 ceil-mode max pooling of the result; ``self.last_pooled`` tells the caller
         whether the convolution kernel wrote it (otherwise the caller runs maxpool2)."""
-        self._pool_req, self.last_pooled = pool, False
+        self._pool_req, self.last_pooled, self.last_presplit = pool, False, False
         r = self._conv_impl(layer, pieces, dst, B, H, W, residual, name, stats, scores)
         self._pool_req = None
         LAYER_BYTES[name] = float(self.esz) * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
@@ -736,6 +758,9 @@ class Plan:
                  and H * W * pieces[0].stride < 2 ** 29 and H * W * dst.stride < 2 ** 29)
         if msdil:
             lattice = False
+        assert pieces[0].presplit is None or msdil if not isinstance(pieces[0], PlanarPiece) else True, "%s: only the one-launch dilated group reads split-pair storage" % name
+        if msdil and pieces[0].presplit is not None:
+            layer.k_perm = SPLIT_PAIR_PERM
         if self.dyn_scales:     # kernels that read egne_conv_desc.dyn_scale: role-split / resident-weights / halo / flat
             s1x1 = ms1x1 = big = lattice = msdil = c4h = False
         # narrow-input 3x3 layers on wide maps: producer / consumer waves (conv3x3_rs_f16.hip) instead of the all-in-one halo kernel
@@ -890,11 +915,13 @@ class Plan:
             # 32-channel map is never stored (scores = (weights [2][32], constants [2], s, s1, accumulate))
             cw_, cc_, s0_, s1_, accum = scores
             d.out = None
+            cal3 = self._presplit_in(d, pieces, residual, cal3)
             self._add(self.L.egne_msblock_dil_scores_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
                                                                layer.w_scale, cw_.data_ptr(), cc_.data_ptr(), s0_.data_ptr(),
                                                                s1_.data_ptr(), int(accum)), name, flops=flops,
                       kind="conv_f16x3:msdil", cal=cal3, ws=[(4, layer, "w_scale")])
         elif msdil:
+            cal3 = self._presplit_in(d, pieces, residual, cal3)
             self._add(self.L.egne_msblock_dil_f16_fwd, (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE,
                                                         layer.w_scale), name, flops=flops, kind="conv_f16x3:msdil", cal=cal3, ws=[(4, layer, "w_scale")])
         elif lattice:
@@ -928,6 +955,21 @@ class Plan:
                   and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
             if fuse_stats:
                 ws = self._stats_ws(d, B, nchunk)
+            ps = dst.presplit
+            if (ps is not None and rw and raw and CALIBRATE and not self.dyn_scales and layer.post is None and residual is None
+                    and not self.last_pooled and int(d.Cout_store) % 32 == 0 and dst.off % 32 == 0):
+                # split-pair output: hi / lo halves of out * s, s from a bound on |out| taken when the launch is calibrated
+                d.out_split, d.out_split_scale = 1, ps.value
+                self.last_presplit = True
+
+                def cal_ps(args, vmax, d=d, layer=layer, ps=ps):
+                    with torch.no_grad():
+                        bound = vmax * float(layer.weights[0].detach().abs().sum(dim=(1, 2, 3)).max())
+                        if layer.biases is not None and layer.biases[0] is not None:
+                            bound += float(layer.biases[0].detach().abs().max())
+                    ps.value = d.out_split_scale = _a_scale_for(bound)
+                    return args[:3] + (_a_scale_for(vmax),) + args[4:]
+                cal3 = (cal_ps, list(pieces), B * H * W)
             self._add(self.L.egne_conv3x3_rw_f16_fwd if rw else self.L.egne_conv3x3_rs_f16_fwd,
                       (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE, layer.w_scale), name, flops=flops,
                       kind="conv_f16x3:rw" if rw else "conv_f16x3:rs", cal=cal3, ws=[(4, layer, "w_scale")])
@@ -983,6 +1025,16 @@ class Plan:
             self.keep.append(db)
             self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
         return Ho, Wo
+
+    def _presplit_in(self, d, pieces, residual, cal):
+        """One-launch dilated group whose input was written in split-pair storage: flag the slice and take the launch's pre-scale
+        from the producer's SplitScale when the plan is calibrated (the producer's launch comes first)."""
+        ps = pieces[0].presplit
+        if ps is None:
+            return cal
+        assert residual is not None and residual.buf is pieces[0].buf and residual.off == pieces[0].off, "split-pair input must be the residual too"
+        d.seg[0].presplit = 1
+        return (lambda args, vmax, ps=ps: args[:3] + (ps.value,) + args[4:], [], 0)
 
     def _conv_bf16(self, layer, pieces, dst, B, H, W, residual, name, stats, scores):
         """Convolutions of a plan with bf16 activation storage: the 3x3 "same" convolutions over one slice run on bf16 MFMAs

@@ -48,7 +48,8 @@ typedef struct {
   const float* scale;   /* optional per-(n,c) affine applied while loading: x*scale+shift  */
   const float* shift;   /*   ([B][Cp], used to fuse InstanceNorm / BatchNorm into the consumer) */
   int32_t act_in;       /* egne_act applied after the affine (LeakyReLU of Transition_down) */
-  int32_t reserved;
+  int32_t presplit;     /* 1: the slice is held in SPLIT-PAIR storage (see egne_conv_desc.out_split), written with the scale that is
+                         * passed as this launch's a_scale; honoured by egne_msblock_dil(_scores)_f16_fwd only, 0 everywhere else */
 } egne_seg;
 
 /*
@@ -113,6 +114,17 @@ typedef struct {
    * egne_conv2d_fwd, egne_conv3x3_smallcin_fwd, egne_conv2d_wgrad, egne_conv3x3_bf16_fwd; every other convolution entry
    * point requires 0. */
   int32_t dtype;
+  /* Optional (egne_conv3x3_rw_f16_fwd): SPLIT-PAIR storage of the output.  The split-f16 kernels multiply every fp32 element by a
+   * power of two s and split it into hi = f16(x s), lo = f16(x s - hi) while staging it; a tensor whose ONLY consumer stages each
+   * element many times (bdcn_new.py:50-54: `o` of an MSBlock feeds three dilated 3x3 convolutions, 13.5 stagings per element)
+   * is written in that form once, by its producer: per pixel and 32-channel block 128 bytes = [hi x 32 | lo x 32] halves instead
+   * of 32 floats (same bytes, same strides / offsets in units of 4 bytes; out_ch_off and Cout_store whole blocks); position p of
+   * either plane holds channel 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3) of the block (the order the producer's lanes end
+   * with, so that a lane stores 16 contiguous bytes per plane) and the consumer's weights are packed in that order.  The consumer
+   * (seg.presplit = 1) copies 16-byte pieces straight into its LDS operand image and recovers x = (hi + lo) / s where it needs
+   * the value itself (the 4-way sum of bdcn_new.py:54), exact to 2^-22 |x|. */
+  int32_t out_split;
+  float out_split_scale;      /* s > 0, a power of two */
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);

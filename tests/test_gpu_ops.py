@@ -765,6 +765,64 @@ def test_msblock_dilated_group_one_launch(G, B, H, W, stride_pad):
         assert err < 2e-6, "relative error %.2e" % err
 
 
+@pytest.mark.parametrize("B,H,W,Cin,mag", [(2, 240, 320, 64, 1.0), (3, 120, 160, 128, 1.0), (2, 75, 101, 64, 3e3), (2, 60, 80, 256, 1e-3), (1, 30, 40, 512, 1.0)])
+def test_msblock_with_split_pair_storage(G, B, H, W, Cin, mag):
+    """A whole MSBlock (bdcn_new.py:49-55) the way the edge network's plan runs it: the 3x3 convolution writes `o` in SPLIT-PAIR
+    storage (egne_conv_desc.out_split: hi / lo f16 halves of o * s, s from a bound taken at calibration), the one-launch dilated
+    group copies the halves into its operand image and recovers o itself for the 4-way sum -- against float64, at activation
+    magnitudes from 1e-3 to 3e3, on maps with ragged tiles, and bit-identical on replay.  Where the producer is not the
+    resident-weights kernel the plan must fall back to plain fp32 storage (asserted either way)."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, SplitScale, pad8
+    x = F.relu(_rand(G, B, Cin, H, W)) * 2 * mag
+    w0, b0 = _rand(G, 32, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, 32) * mag
+    ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+    bs = [_rand(G, 32) * mag for _ in range(3)]
+    o = F.relu(F.conv2d(x.double(), w0.double(), b0.double(), padding=1))
+    truth = o.clone()
+    for w, b, d in zip(ws, bs, (4, 8, 12)):
+        truth = truth + F.relu(F.conv2d(o, w.double(), b.double(), padding=d, dilation=d))
+    pl = Plan(torch.device(DEV))
+    (px,) = to_nhwc_buf(pl, [x], B, H, W)
+    l0 = ConvLayer([torch.nn.Parameter(w0.to(DEV))], [torch.nn.Parameter(b0.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=1)
+    lg = ConvLayer([torch.nn.Parameter(w.to(DEV)) for w in ws], [torch.nn.Parameter(b.to(DEV)) for b in bs], [(32, 32)],
+                   pad=(1, 1), dils=(4, 8, 12), act=1)
+    l0.split = lg.split = True
+    obuf, out = pl.buf(B, H, W, 32), pl.buf(B, H, W, 32)
+    po = Piece(obuf, 0, 32)
+    assert pl.msdil_ok(lg, po, H, W)
+    po.presplit = SplitScale()
+    pl.conv(l0, [px], po, B, H, W)
+    split = pl.last_presplit
+    if not split:
+        po.presplit = None
+    pl.conv(lg, [po], Piece(out, 0, 32), B, H, W, residual=po)
+    kinds = [k for k, _ in pl.meta]
+    assert kinds[-1] == "conv_f16x3:msdil" and split == (kinds[0] == "conv_f16x3:rw"), kinds
+    firsts = []
+    for _ in range(2):          # calibrating run, replay
+        pl.run()
+        torch.cuda.synchronize()
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 3e-6, "relative error %.2e (split-pair storage %s)" % (err, split)
+        firsts.append(out.clone())
+    assert torch.equal(firsts[0], firsts[1])
+    if split:
+        s = po.presplit.value
+        omax = o.abs().max().item()
+        assert 1.0 < s * omax < 2048.0, (s, omax)        # the bound holds (nothing overflows f16) and is within 2^10 of the maximum
+        # the stored halves ARE the split of o: hi + lo reproduces o to 2^-21 of the maximum
+        raw = obuf.view(torch.float16).reshape(B, H, W, 2, 32).float().cpu()
+        from egne_amd.engine import SPLIT_PAIR_PERM
+        pos = raw[..., 0, :] + raw[..., 1, :]                  # position p of a plane holds channel SPLIT_PAIR_PERM[p]
+        rec = torch.empty_like(pos)
+        rec[..., SPLIT_PAIR_PERM] = pos
+        rec = rec.permute(0, 3, 1, 2).double() / s
+        assert (rec - o).abs().max().item() < 2.0 ** -20 * omax
+    print("MSBlock %dx%dx%d Cin %d mag %g: err %.2e, split-pair storage %s (%s)" % (B, H, W, Cin, mag, err, split, kinds[0]))
+
+
 @pytest.mark.parametrize("kind,B,H,W,C1,C2", [("halo", 3, 61, 83, 32, 32), ("halo", 2, 120, 160, 64, 96), ("pair", 3, 61, 83, 32, 32),
                                               ("pair", 2, 37, 70, 64, 64), ("halo", 2, 60, 80, 32, 32), ("halo", 2, 64, 96, 32, 64)])
 def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C2):
