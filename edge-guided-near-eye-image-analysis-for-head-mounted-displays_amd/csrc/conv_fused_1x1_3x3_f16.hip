@@ -82,11 +82,15 @@ __device__ __forceinline__ void lds_barrier() {
 // UNI: every slice of the 1x1's input is a channel range of ONE buffer (a dense block's x | x1 | x22: models/RITnet_v2.py:57-62):
 //     one buffer resource per tile instead of one per channel group (whose 64-bit frame pointers, kept across the statically
 //     unrolled item schedule, overflowed the scalar register file: ~350 v_readlane / v_writelane per tile and producer wave).
+// C1V (with C4, one-channel planar input): the first convolution runs on the VECTOR ALU in exact fp32 -- 9 fused multiply-adds per
+//     (halo pixel, channel) on a 12 x 36 input patch staged in LDS, weights as scalar operands (p1.w = float [32][12]: nine taps, the
+//     bias, two zeros per channel) -- instead of gathering nine dwords per halo pixel from memory (96 tiny loads per tile), splitting
+//     them and spending a K = 48 MFMA on nine taps: the producers were 12.4 k cycles per tile against the consumers' 6.3 k.
 // GL: channel groups in the LAST batch when known at compile time (0: decided from G1 at run time, one branch per group).  With
 //     it an item is straight-line code: all its weight fragments are requested from LDS up front and the three MFMAs of group u
 //     are interleaved with the fp32 -> hi / lo split of group u + 1 (sched_group_barrier), instead of a ds_read latency and
 //     three back-to-back MFMAs per group in a wave that issues in order.
-template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false, bool UNI = false, int GL = 0>
+template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false, bool UNI = false, int GL = 0, bool C1V = false>
 __global__ __launch_bounds__(512)
 void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, const GroupTab gt, const _Float16* __restrict__ w1hi,
                           const _Float16* __restrict__ w1lo, int G1, const _Float16* __restrict__ f2hi,
@@ -141,7 +145,98 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   float* const lp = (float*)(lw + (WLDS ? G1 * NCH * 2 * 512 : 0));
   __syncthreads();
 
-  if (wave < 4) {
+  if constexpr (C1V) if (wave < 4) {
+    // =================================================================== producers, one-channel first layer on the vector ALU
+    static_assert(!C1V || (C4 && NCH == 1 && TH == 8 && !UPADD), "C1V: 1 -> 32 channels in front of a 32-channel 3x3, 8-row tiles");
+    constexpr int PW = TW + 4, PH = TH + 4, PN = PW * PH;      // input patch of a tile: 12 x 36 pixels (halo of the halo)
+    float* const lpatch = lp;                                  // two patches
+    const egne_seg sg = p1.seg[0];
+    const float sl = p1.act == EGNE_ACT_RELU ? 0.f : (p1.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+    const int hq = wave >> 1;                                  // wave-uniform: channels 16 hq .. 16 hq + 15 (scalar weight operands)
+    unsigned preg[2];
+    auto patch_issue = [&](const Tile& tl, bool on) {
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(sg.ptr + (long long)tl.b * H * W, (unsigned)H * W * 4u);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 256 * k, py = idx / PW, px = idx - py * PW;
+        const int y = tl.y0 - 2 + py, x = tl.x0 - 2 + px;
+        const bool ok = on && idx < PN && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && !(dbg & 1);
+        preg[k] = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (y * W + x) * 4 : (int)OOB, 0, 0);      // zero padding of the first convolution
+      }
+    };
+    auto patch_store = [&](float* dst) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx < PN) dst[idx] = __builtin_bit_cast(float, preg[k]);
+      }
+    };
+    // the weight table in LDS ([32][12] floats behind the patches): a uniform-address ds_read_b128 is a broadcast, and unlike a load
+    // from memory it neither queues behind the patch prefetch nor costs a vector-memory instruction per weight
+    float* const lwt = lpatch + 2 * PN;
+    for (int e = tid; e < 32 * 12; e += 256) lwt[e] = p1.w[e];
+    auto produce = [&](int i) {           // tile i into image i & 1 from patch i & 1; patch i + 1 stored, patch i + 2 requested
+      const Tile tl = decode(tile_at(i));
+      _Float16* Thi = ldsh + (i & 1) * IMG;
+      _Float16* Tlo = Thi + NPX * LDH;
+      const float* pt = lpatch + (i & 1) * PN;
+      // a lane's three halo pixels (hp = 64 (wave & 1) + lane + 128 r) side by side, so that a channel's weights are read once for them
+      float t[3][9], vs[3];
+      int hpv[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int hp = (wave & 1) * 64 + lane + 128 * r;       // halo pixel of the 10 x 34 intermediate
+        const int hpc = hp < NPX ? hp : 0;
+        const int hy = hpc / HWd, hx = hpc - hy * HWd;
+        const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
+        vs[r] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? a2 : 0.f;    // zero OUTSIDE the image: the 3x3's padding
+        hpv[r] = hp;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t[r][k] = pt[(hy + k / 3) * PW + hx + k % 3];
+      }
+      h8 hi[3][2], lo[3][2];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const f32x4* wc = (const f32x4*)(lwt + (hq * 16 + j) * 12);
+        const f32x4 w0 = wc[0], w1 = wc[1], w2 = wc[2];
+        const float w[10] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float acc = w[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc = __builtin_fmaf(w[k], t[r][k], acc);
+          acc = fmaxf(acc, acc * sl) * vs[r];
+          const _Float16 h = (_Float16)acc;
+          hi[r][j >> 3][j & 7] = h;
+          lo[r][j >> 3][j & 7] = (_Float16)(acc - (float)h);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (hpv[r] < NPX) {
+          const int o = hpv[r] * LDH + hq * 16;
+          *(h8*)&Thi[o] = hi[r][0]; *(h8*)&Thi[o + 8] = hi[r][1];
+          *(h8*)&Tlo[o] = lo[r][0]; *(h8*)&Tlo[o + 8] = lo[r][1];
+        }
+      patch_store(lpatch + ((i + 1) & 1) * PN);
+      const bool on2 = i + 2 < nmine;
+      patch_issue(decode(tile_at(on2 ? i + 2 : i)), on2);
+    };
+    patch_issue(decode(tile_at(0)), nmine > 0);
+    patch_store(lpatch);
+    patch_issue(decode(tile_at(nmine > 1 ? 1 : 0)), nmine > 1);
+    lds_barrier();                          // patch 0 visible to every producer wave
+    if (nmine > 0) produce(0);
+    lds_barrier();
+    stamp(t_wait); t_work = 0; t_wait = 0;
+    for (int i = 0; i < nmine; ++i) {
+      if (i + 1 < nmine) produce(i + 1);
+      stamp(t_work);
+      lds_barrier();
+      stamp(t_wait);
+    }
+  }
+  if (!C1V && wave < 4) {
     // =================================================================== producers: 1x1 on the halo -> LDS image
     // Every producer wave runs a STATIC schedule of N = JOBS * NB items per tile (item = 4 channel groups of one 32-pixel
     // block; wave w owns blocks w, w + 4, ...; a block past the halo is all out-of-range lanes: no traffic, nothing
@@ -412,7 +507,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       lds_barrier();
       stamp(t_wait);
     }
-  } else {
+  }
+  if (wave >= 4) {
     // =================================================================== consumers: 9 taps from the LDS image
     if (dbg & 128) __builtin_amdgcn_s_setprio(1);
     // Wave -> (rows, output tiles): 8-row tiles give every wave two rows and all WN output tiles; with 4-row tiles and
@@ -463,7 +559,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, w_off(s) + tn * 1024, 0);
         ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, w_off(s) + tn * 1024, 0);
       }
-    if constexpr (UPADD) lds_barrier();      // matches the producers' staging barrier
+    if constexpr (UPADD || C1V) lds_barrier();      // matches the producers' staging barrier
     lds_barrier();
     stamp(t_wait); t_work = 0; t_wait = 0;
     for (int i = 0; i < nmine; ++i) {
@@ -533,8 +629,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             const int pix = y * W + xl;
             const int o0 = (pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4;
             const int r0 = (pix * (int)p2.res_pix_stride + p2.res_ch_off + n) * 4;
-            if (st_on) egne::epi_row32_select<true>(edge, full_epi, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
-            else egne::epi_row32_select<false>(edge, full_epi, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
+            if (st_on) egne::epi_row32_select<true>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
+            else egne::epi_row32_select<false>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
           }
           if (st_on) {                 // one chunk = this wave's rows of this tile (fixed order: deterministic)
             st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
@@ -557,19 +653,20 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   }
 }
 
-template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false, bool UNI = false, int GL = 0>
+template <int NCH, int WN, int TH, int NB, bool C4 = false, bool UPADD = false, bool UNI = false, int GL = 0, bool C1V = false>
 int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const GroupTab& gt, const _Float16* w1hi, const _Float16* w1lo,
                  int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
   const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0) +
-                     (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * 32 * NCH * sizeof(float) : 0);
-  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                     (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * 32 * NCH * sizeof(float) : 0) +
+                     (C1V ? ((size_t)2 * (TH + 4) * (TW + 4) + 32 * 12) * sizeof(float) : 0);
+  static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL, C1V>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024) == hipSuccess;
   if (!once || lds > 160 * 1024) return egne::fail(EGNE_ERR_LAUNCH, "conv_fused_1x1_3x3: %zu bytes of LDS", lds);
   int gx = 256;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
+  hipLaunchKernelGGL((fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL, C1V>), dim3(gx), dim3(512), lds, st, d1, d2, gt, w1hi, w1lo, G1, f2hi, f2lo, a1, os1,
                      a2, os2, tiles_x, tiles_y, ntiles);
   return egne::check_launch("egne_conv1x1_3x3_fused_f16_fwd");
 }
@@ -703,6 +800,11 @@ extern "C" int egne_conv3x3c4_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const
   GroupTab gt;
   gt.dn = 0;
   for (int k = 0; k < MAXG; ++k) gt.v[k] = gt.off[k] = 0;
+  // one-channel planar input with the compact fp32 weight table in d1.w ([32][12] floats: nine taps, bias, two zeros): first layer on
+  // the vector ALU in exact fp32 (no weight fragments in LDS: G1 = 0)
+  if (planar && d1.w && ((uintptr_t)d1.w & 15) == 0)
+    return launch_fused<1, 1, 8, 1, true, false, false, 3, true>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 0, (const _Float16*)f2hi,
+                                                                 (const _Float16*)f2lo, a1, 1.0f / (a1 * w1_scale), a2, 1.0f / (a2 * w2_scale), (hipStream_t)stream);
   return launch_fused<1, 1, 8, 1, true, false, false, 3>(d1, d2, gt, (const _Float16*)c4hi, (const _Float16*)c4lo, 3, (const _Float16*)f2hi, (const _Float16*)f2lo,
                                         a1, 1.0f / (a1 * w1_scale), a2, 1.0f / (a2 * w2_scale), (hipStream_t)stream);
 }

@@ -18,8 +18,8 @@ struct EpiLane {          // per lane and 32-channel block, fixed for the launch
 };
 
 // MASK: edge tile (pixels past W, rows past H, channels past Cout_store are dropped: cm = valid pixels from xl, 0 for none);
-// FULL: post affine and residual present (generic path); STATS: accumulate st_s / st_q.
-template <bool MASK, bool FULL, bool STATS>
+// POST: post affine present; RES: residual present (a load per value); STATS: accumulate st_s / st_q.
+template <bool MASK, bool POST, bool RES, bool STATS>
 __device__ __forceinline__ void epi_row32(const epi_f32x16& acc, const __amdgpu_buffer_rsrc_t rout, const __amdgpu_buffer_rsrc_t rres,
                                           int voff, int roff, int out_step, int res_step, int cm, float os, float slope,
                                           const EpiLane& k, double& st_s, double& st_q) {
@@ -30,10 +30,8 @@ __device__ __forceinline__ void epi_row32(const epi_f32x16& acc, const __amdgpu_
     const bool ok = !MASK || c < cm;
     float v = acc[r] * os + k.bias;
     v = fmaxf(v, v * slope);
-    if constexpr (FULL) {
-      v = v * k.post_scale + k.post_shift;
-      v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? roff : OOBO, c * res_step, 0));
-    }
+    if constexpr (POST) v = v * k.post_scale + k.post_shift;
+    if constexpr (RES) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? roff : OOBO, c * res_step, 0));
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ok ? voff : OOBO, c * out_step, 0);
     if constexpr (STATS) {
       const double vm = ok ? (double)v : 0.;
@@ -42,14 +40,18 @@ __device__ __forceinline__ void epi_row32(const epi_f32x16& acc, const __amdgpu_
   }
 }
 
-// runtime (wave-uniform) selection of the specialisation
+// runtime (wave-uniform) selection of the specialisation.  `post` / `res`: post affine / residual present.  The convBlock head of
+// ESF-Net (eval BatchNorm folded into a post affine, no residual; utils.py:1047-1049) is the most expensive launch of that network:
+// its interior tiles take a form of their own -- the generic one issued a residual load per value from an empty resource.
 template <bool STATS>
-__device__ __forceinline__ void epi_row32_select(bool mask, bool full, const epi_f32x16& acc, const __amdgpu_buffer_rsrc_t rout,
+__device__ __forceinline__ void epi_row32_select(bool mask, bool post, bool res, const epi_f32x16& acc, const __amdgpu_buffer_rsrc_t rout,
                                                  const __amdgpu_buffer_rsrc_t rres, int voff, int roff, int out_step, int res_step, int cm,
                                                  float os, float slope, const EpiLane& k, double& st_s, double& st_q) {
-  if (!mask && !full) epi_row32<false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
-  else if (!full) epi_row32<true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
-  else epi_row32<true, true, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
+  if (!mask && !post && !res) epi_row32<false, false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
+  else if (!post && !res) epi_row32<true, false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
+  else if (!mask && !res) epi_row32<false, true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
+  else if (!res) epi_row32<true, true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
+  else epi_row32<true, true, true, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
 }
 
 }  // namespace egne

@@ -59,6 +59,7 @@ STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
 FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
 FUSE_C4 = os.environ.get("EGNE_FUSE_C4", "1") != "0"              # convBlock head (3x3 on <= 4 channels + 3x3) as one launch
+C1V = os.environ.get("EGNE_C1V", "1") != "0"                      # ... with the one-channel first convolution on the vector ALU (exact fp32)
 CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
 RECAL_EVERY = int(os.environ.get("EGNE_RECAL_EVERY", "1024"))     # inference plans: runs between two calibrations (0: first run only).  The scales
 #   leave 32x of head-room over the calibration batch; a later batch beyond that would overflow f16 silently, so the maxima are re-measured
@@ -1299,6 +1300,19 @@ class Plan:
         d2.out, d2.out_pix_stride, d2.out_ch_off = dst.ptr, dst.stride, dst.off
         d2.Cout_store = min(l2.Cout_store, dst.Cp)
         self.keep += [d1, d2]
+        if C1V and isinstance(src, PlanarPiece) and l1.Cin == 1 and l1.Cout <= 32:
+            # one-channel input: the first convolution on the vector ALU in exact fp32 (conv_fused_1x1_3x3_f16.hip, C1V); its weights as
+            # a compact table [32][12] = nine taps, bias, two zeros per channel (scalar operands of the kernel)
+            w12 = self.vec(32, 12)
+
+            def refresh_w12(w12=w12, l1=l1):
+                with torch.no_grad():
+                    w12.zero_()
+                    w12[:l1.Cout, :9].copy_(l1.weights[0].detach().reshape(l1.Cout, 9))
+                    if l1.biases is not None and l1.biases[0] is not None:
+                        w12[:l1.Cout, 9].copy_(l1.biases[0].detach())
+            self.pre.append(VersionGuard([l1.weights[0]] + ([l1.biases[0]] if l1.biases is not None and l1.biases[0] is not None else []), refresh_w12))
+            d1.w = w12.data_ptr()
 
         def rescale(args, vmax, l1=l1):
             with torch.no_grad():
