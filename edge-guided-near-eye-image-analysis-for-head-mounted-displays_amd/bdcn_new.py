@@ -20,9 +20,12 @@ from . import engine
 from .engine import ACT_RELU, ConvLayer, Piece, PlanarPiece, Plan, VersionGuard, maxpool_out, pad8, require_cuda
 
 import os
+import types
 
 PLANAR_IN = os.environ.get("EGNE_PLANAR_IN", "1") != "0"     # conv1_1 reads the NCHW frames in place
 SCORES_FUSED = os.environ.get("EGNE_SCORES_FUSED", "1") != "0"     # stage score heads in the epilogue of the MSBlock kernel
+MS_SIDE_STREAM = os.environ.get("EGNE_MS_SIDE", "1") != "0"        # MSBlocks on the plan's second stream next to the trunk
+MS_SIDE_MIN_B = int(os.environ.get("EGNE_MS_SIDE_MIN_B", "8"))      # ... for batches of at least this many frames
 
 # (name, cin, cout, dilation) / pool markers; vgg16_c.py:11-39
 _VGG = [("conv1_1", 3, 64, 1), ("conv1_2", 64, 64, 1), ("P", 2),
@@ -135,7 +138,114 @@ class BDCN(nn.Module):
             pl.raw(L.egne_nchw_to_nhwc, (x_in.data_ptr(), B, 3, H, W, xb.data_ptr(), 8, 0, 8), "bdcn.in")
             cur = Piece(xb, 0, 3)
         ch, hh, ww = 3, H, W
-        feats = []
+        # MSBlocks + stage scores.  A block only needs its own trunk layer, so it is emitted right behind that layer and -- for batches
+        # that fill the chip -- launched on the plan's SECOND stream (Plan.side_default): the narrow MSBlock launches of stages 3-5
+        # (300 tiles on 512 workgroup slots) and the ragged frame tails of the wide trunk layers (88 of 256 slots) run next to each
+        # other instead of one after the other.  The side stream is joined in front of the tail kernel, which reads every score map.
+        tail = _lib.BdcnTailDesc()
+        tail.B, tail.H, tail.W = B, H, W
+        block_of = {}           # trunk layer name -> (stage index, block index)
+        for si, (st, blocks, cin) in enumerate(_STAGES):
+            for bi, b in enumerate(blocks):
+                block_of["conv" + b] = (si, bi)
+        stages = {}
+        side = MS_SIDE_STREAM and B >= MS_SIDE_MIN_B
+
+        def stage_state(si, h_s, w_s):
+            if si in stages:
+                return stages[si]
+            st, blocks, cin = _STAGES[si]
+            nb = len(blocks)
+            S = types.SimpleNamespace(st=st, blocks=blocks, nb=nb, h=h_s, w=w_s, ms_bufs=[], fused=None)
+            S.o_buf = pl.buf(B, h_s, w_s, 32)
+            S.dn = [getattr(self, "conv%s_down" % b) for b in blocks]
+            S.sa, S.sb = getattr(self, "score_dsn" + st), getattr(self, "score_dsn%s_1" % st)
+            S.s, S.s1 = pl.vec(B, h_s, w_s), pl.vec(B, h_s, w_s)
+            # Score heads fused into the dilated-branch kernel (bdcn_new.py:118-166 is linear after the MSBlock): per block
+            # and head ONE 32-vector  head_w[21] @ down_w[21, 32]; the constant  head_w @ sum_k down_b[k] + head_b  rides with
+            # the stage's first block.  The 32-channel block outputs are then never written.
+            S.cw, S.cc = pl.vec(nb, 2, 32), pl.vec(2)
+
+            def refresh_scores(cw=S.cw, cc=S.cc, dn=S.dn, sa=S.sa, sb=S.sb):
+                with torch.no_grad():
+                    heads = torch.stack([sa.weight.detach().reshape(21), sb.weight.detach().reshape(21)])      # [2, 21]
+                    for k, m in enumerate(dn):
+                        cw[k].copy_(heads @ m.weight.detach().reshape(21, 32))
+                    bsum = torch.stack([m.bias.detach() for m in dn]).sum(0)
+                    cc.copy_(heads @ bsum + torch.cat([sa.bias.detach(), sb.bias.detach()]))
+            S.refresh_scores = refresh_scores
+            stages[si] = S
+            return S
+
+        def emit_block(si, bi, src, c_in, hh, ww):
+            S = stage_state(si, hh, ww)
+            b = S.blocks[bi]
+            pl.side_default = side
+            mb = getattr(self, "msblock" + b)
+            l0 = ConvLayer([mb.conv.weight], [mb.conv.bias], [(c_in, pad8(c_in))], pad=(1, 1), act=ACT_RELU)
+            l0.split = True
+            o = Piece(S.o_buf, 0, 32)
+            r = self.rate
+            dil = tuple(r * i if r >= 1 else 1 for i in (1, 2, 3))
+            lg = ConvLayer([mb.conv1.weight, mb.conv2.weight, mb.conv3.weight],
+                           [mb.conv1.bias, mb.conv2.bias, mb.conv3.bias], [(32, 32)], pad=(1, 1), dils=dil,
+                           act=ACT_RELU)
+            lg.split = True
+            # `o` feeds the three dilated convolutions only (bdcn_new.py:50-54), which stage every element 13.5 times: where the
+            # one-launch kernel runs them, the producer writes o as split hi / lo halves once (engine.SplitScale)
+            if engine.PRESPLIT and pl.msdil_ok(lg, o, hh, ww):
+                o.presplit = engine.SplitScale()
+            pl.conv(l0, [src], o, B, hh, ww, name="ms%s.conv" % b)
+            if not pl.last_presplit:
+                o.presplit = None          # (the kernel chosen for this convolution writes plain fp32)
+            if S.fused is None:
+                S.fused = SCORES_FUSED and pl.msdil_ok(lg, o, hh, ww)
+                if S.fused:
+                    pl.pre.append(VersionGuard([p for m in S.dn + [S.sa, S.sb] for p in (m.weight, m.bias)], S.refresh_scores))
+            if S.fused:
+                pl.conv(lg, [o], Piece(S.o_buf, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b, scores=(S.cw[bi], S.cc, S.s, S.s1, bi > 0))
+            else:
+                msb = pl.buf(B, hh, ww, 32)
+                pl.conv(lg, [o], Piece(msb, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b)
+                S.ms_bufs.append(msb)
+            if bi == S.nb - 1:
+                finish_stage(si, S)
+            pl.side_default = False
+
+        def finish_stage(si, S):
+            st, nb, dn, sa, sb, s, s1 = S.st, S.nb, S.dn, S.sa, S.sb, S.s, S.s1
+            if not S.fused:
+                wd, bd = pl.vec(nb, 21, 32), pl.vec(nb, 21)
+                heads = pl.vec(2, 21)
+                hb = pl.vec(2)
+
+                def refresh(wd=wd, bd=bd, heads=heads, hb=hb, dn=dn, sa=sa, sb=sb):
+                    with torch.no_grad():
+                        for k, m in enumerate(dn):
+                            wd[k].copy_(m.weight.detach().reshape(21, 32))
+                            bd[k].copy_(m.bias.detach())
+                        heads[0].copy_(sa.weight.detach().reshape(21))
+                        heads[1].copy_(sb.weight.detach().reshape(21))
+                        hb[0:1].copy_(sa.bias.detach())
+                        hb[1:2].copy_(sb.bias.detach())
+                pl.pre.append(VersionGuard([p for m in dn + [sa, sb] for p in (m.weight, m.bias)], refresh))
+                arr = (C.c_void_p * nb)(*[t.data_ptr() for t in S.ms_bufs])
+                pl.keep.append(arr)
+                pl.raw(L.egne_bdcn_stage_scores,
+                       (arr, nb, 32, B * S.h * S.w, wd.data_ptr(), bd.data_ptr(), heads.data_ptr(), hb.data_ptr(),
+                        heads.data_ptr() + 4 * 21, hb.data_ptr() + 4, s.data_ptr(), s1.data_ptr()), "bdcn.scores" + st)
+            tail.s[si], tail.s1[si] = s.data_ptr(), s1.data_ptr()
+            tail.h[si], tail.w[si] = S.h, S.w
+            if st in _UPS:
+                key, stride, crop = _UPS[st]
+                upw = pl.vec(2 * stride, 2 * stride)
+                mod = getattr(self, key)
+                pl.pre.append(VersionGuard([mod.weight], lambda upw=upw, mod=mod: upw.copy_(
+                    mod.weight.detach().reshape(upw.shape))))
+                tail.up[si], tail.stride[si], tail.crop[si] = upw.data_ptr(), stride, crop
+            else:
+                tail.stride[si], tail.crop[si] = 1, 0
+
         pooled = None               # a stride-2 pooling already written by the convolution in front of it
         for idx, item in enumerate(_VGG):
             if item[0] == "P":
@@ -163,94 +273,10 @@ class BDCN(nn.Module):
             pl.conv(layer, [cur], dst, B, hh, ww, name="vgg." + name, pool=pq)
             pooled = pq if pl.last_pooled else None
             cur = dst
-            feats.append((dst, cout, hh, ww))
-        # MSBlocks + stage scores
-        tail = _lib.BdcnTailDesc()
-        tail.B, tail.H, tail.W = B, H, W
-        fi = 0
-        for si, (st, blocks, cin) in enumerate(_STAGES):
-            ms_bufs = []
-            h_s, w_s = feats[fi][2], feats[fi][3]
-            o_buf = pl.buf(B, h_s, w_s, 32)
-            nb = len(blocks)
-            dn = [getattr(self, "conv%s_down" % b) for b in blocks]
-            sa, sb = getattr(self, "score_dsn" + st), getattr(self, "score_dsn%s_1" % st)
-            s = pl.vec(B, h_s, w_s)
-            s1 = pl.vec(B, h_s, w_s)
-            # Score heads fused into the dilated-branch kernel (bdcn_new.py:118-166 is linear after the MSBlock): per block
-            # and head ONE 32-vector  head_w[21] @ down_w[21, 32]; the constant  head_w @ sum_k down_b[k] + head_b  rides with
-            # the stage's first block.  The 32-channel block outputs are then never written.
-            cw, cc = pl.vec(nb, 2, 32), pl.vec(2)
-
-            def refresh_scores(cw=cw, cc=cc, dn=dn, sa=sa, sb=sb):
-                with torch.no_grad():
-                    heads = torch.stack([sa.weight.detach().reshape(21), sb.weight.detach().reshape(21)])      # [2, 21]
-                    for k, m in enumerate(dn):
-                        cw[k].copy_(heads @ m.weight.detach().reshape(21, 32))
-                    bsum = torch.stack([m.bias.detach() for m in dn]).sum(0)
-                    cc.copy_(heads @ bsum + torch.cat([sa.bias.detach(), sb.bias.detach()]))
-            fused_scores = None
-            for bi, b in enumerate(blocks):
-                src, c_in, hh, ww = feats[fi]
-                fi += 1
-                mb = getattr(self, "msblock" + b)
-                l0 = ConvLayer([mb.conv.weight], [mb.conv.bias], [(c_in, pad8(c_in))], pad=(1, 1), act=ACT_RELU)
-                l0.split = True
-                o = Piece(o_buf, 0, 32)
-                r = self.rate
-                dil = tuple(r * i if r >= 1 else 1 for i in (1, 2, 3))
-                lg = ConvLayer([mb.conv1.weight, mb.conv2.weight, mb.conv3.weight],
-                               [mb.conv1.bias, mb.conv2.bias, mb.conv3.bias], [(32, 32)], pad=(1, 1), dils=dil,
-                               act=ACT_RELU)
-                lg.split = True
-                # `o` feeds the three dilated convolutions only (bdcn_new.py:50-54), which stage every element 13.5 times: where the
-                # one-launch kernel runs them, the producer writes o as split hi / lo halves once (engine.SplitScale)
-                if engine.PRESPLIT and pl.msdil_ok(lg, o, hh, ww):
-                    o.presplit = engine.SplitScale()
-                pl.conv(l0, [src], o, B, hh, ww, name="ms%s.conv" % b)
-                if not pl.last_presplit:
-                    o.presplit = None          # (the kernel chosen for this convolution writes plain fp32)
-                if fused_scores is None:
-                    fused_scores = SCORES_FUSED and pl.msdil_ok(lg, o, hh, ww)
-                    if fused_scores:
-                        pl.pre.append(VersionGuard([p for m in dn + [sa, sb] for p in (m.weight, m.bias)], refresh_scores))
-                if fused_scores:
-                    pl.conv(lg, [o], Piece(o_buf, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b, scores=(cw[bi], cc, s, s1, bi > 0))
-                else:
-                    msb = pl.buf(B, hh, ww, 32)
-                    pl.conv(lg, [o], Piece(msb, 0, 32), B, hh, ww, residual=o, name="ms%s.dil" % b)
-                    ms_bufs.append(msb)
-            if not fused_scores:
-                wd, bd = pl.vec(nb, 21, 32), pl.vec(nb, 21)
-                heads = pl.vec(2, 21)
-                hb = pl.vec(2)
-
-                def refresh(wd=wd, bd=bd, heads=heads, hb=hb, dn=dn, sa=sa, sb=sb):
-                    with torch.no_grad():
-                        for k, m in enumerate(dn):
-                            wd[k].copy_(m.weight.detach().reshape(21, 32))
-                            bd[k].copy_(m.bias.detach())
-                        heads[0].copy_(sa.weight.detach().reshape(21))
-                        heads[1].copy_(sb.weight.detach().reshape(21))
-                        hb[0:1].copy_(sa.bias.detach())
-                        hb[1:2].copy_(sb.bias.detach())
-                pl.pre.append(VersionGuard([p for m in dn + [sa, sb] for p in (m.weight, m.bias)], refresh))
-                arr = (C.c_void_p * nb)(*[t.data_ptr() for t in ms_bufs])
-                pl.keep.append(arr)
-                pl.raw(L.egne_bdcn_stage_scores,
-                       (arr, nb, 32, B * h_s * w_s, wd.data_ptr(), bd.data_ptr(), heads.data_ptr(), hb.data_ptr(),
-                        heads.data_ptr() + 4 * 21, hb.data_ptr() + 4, s.data_ptr(), s1.data_ptr()), "bdcn.scores" + st)
-            tail.s[si], tail.s1[si] = s.data_ptr(), s1.data_ptr()
-            tail.h[si], tail.w[si] = h_s, w_s
-            if st in _UPS:
-                key, stride, crop = _UPS[st]
-                upw = pl.vec(2 * stride, 2 * stride)
-                mod = getattr(self, key)
-                pl.pre.append(VersionGuard([mod.weight], lambda upw=upw, mod=mod: upw.copy_(
-                    mod.weight.detach().reshape(upw.shape))))
-                tail.up[si], tail.stride[si], tail.crop[si] = upw.data_ptr(), stride, crop
-            else:
-                tail.stride[si], tail.crop[si] = 1, 0
+            si, bi = block_of[name]
+            emit_block(si, bi, dst, cout, hh, ww)
+        pl.serial_timing = True
+        pl.join_before.add(len(pl.calls))       # the tail kernel reads every stage's score maps: the side stream is joined first
         fw, fb = pl.vec(10), pl.vec(1)
         pl.pre.append(VersionGuard([self.fuse.weight, self.fuse.bias], lambda: (
             fw.copy_(self.fuse.weight.detach().reshape(10)), fb.copy_(self.fuse.bias.detach()))))

@@ -549,7 +549,10 @@ class Plan:
         self.dyn_scales = bool(train) and TRAIN_SPLIT and not self.bf16     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
         self._touching, self._touched = False, {}     # build_backward: channel ranges of gradient twins already handed out
-        self.side_calls, self.side_stream = {}, None   # call index -> event: weight-gradient launches overlapped with the data path
+        self.side_calls, self.side_stream = {}, None   # call index -> event: launches on the plan's second stream (weight gradients; the edge network's MSBlocks)
+        self.side_default = False                      # _add: launches emitted while this is set go to the second stream
+        self.join_before = set()                       # call indices in front of which the main stream waits for the second one
+        self.serial_timing = False                     # run(events): one stream when launches are timed (overlapping kernels stretch each other's durations)
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _StorageLib(_lib.lib(), self.bf16)
 
@@ -673,7 +676,7 @@ class Plan:
             self.wscale_refs.append((len(self.calls), ai, layer, attr))
         if cal is not None and CALIBRATE:
             self.cal[len(self.calls)] = cal
-        if side:      # launched on the plan's second stream behind an event of the main one (Plan.run); joined at the end of the run
+        if side or self.side_default:      # launched on the plan's second stream behind an event of the main one (Plan.run); joined at the end of the run
             self.side_calls[len(self.calls)] = None
         self.calls.append((fn, args, name))
         self.meta.append((kind or name.split(".")[0], flops))
@@ -1543,7 +1546,7 @@ class Plan:
         if self.cal and (repacked or not self.calibrated or (RECAL_EVERY and self._runs_since_cal >= RECAL_EVERY)):
             self._runs_since_cal = 0
             return self._run_calibrating(st)
-        if self.side_calls:
+        if self.side_calls and not (events is not None and self.serial_timing):
             return self._run_two_streams(st, events)
         if events is None:
             for fn, args, name in self.calls:
@@ -1589,6 +1592,8 @@ class Plan:
         sp = C.c_void_p(side.cuda_stream)
         for i, ((fn, args, name), (kind, flops)) in enumerate(zip(self.calls, self.meta)):
             on_side = i in self.side_calls
+            if i in self.join_before:
+                main.wait_stream(side)
             if on_side:
                 ev = self.side_calls[i]
                 ev.record(main)
