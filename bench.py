@@ -47,7 +47,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (as egne_amd/__init__.py:
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"; the split kernel issues 3 MFMAs per product
-ROUND = "r03"
+ROUND = "r04"
 FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad")
 
 
@@ -72,6 +72,13 @@ def parse():
     ap.add_argument("--chz", type=int, default=32, help="ESF-Net base width (64 = BASELINE.json configs[4]'s wider model)")
     ap.add_argument("--fit", action="store_true", help="--mode infer: the headline step includes the ellipse-fit stage")
     ap.add_argument("--layers", action="store_true", help="print a per-launch time / TFLOP/s table to stderr")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="build the RCCL process group even with ONE rank (EGNE_FORCE_DIST=1): the training legs then run the gradient all-reduce, "
+                         "the parameter broadcast and the timing all-gather through RCCL and report allreduce_ms_per_step > 0")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0: min(cores, 32), see --cpu-thread-sweep)")
+    ap.add_argument("--cpu-thread-sweep", action="store_true",
+                    help="time the CPU baseline's B=2 edge + seg part at 16 / 32 / 64 / 128 / all logical cores and print the table (one-off: which "
+                         "thread count is the fair baseline)")
     return ap.parse_args()
 
 
@@ -121,7 +128,33 @@ def _timeit(fn, budget_s, warm=2, lo=2, hi=5):
     return ts[len(ts) // 2], ts[0], n, warm
 
 
-def cpu_baseline(setting, bd_sd, net_sd, batches=(2, 8), budget_s=7.0, parity=None):
+def cpu_thread_sweep(setting, bd_sd, net_sd, budget_s=6.0):
+    """One-off: edge + seg of the B = 2 sample (the `cpu_baseline.value` part) at several torch thread counts on this box."""
+    import torch
+    import egne_amd  # noqa: F401
+    from egne_amd import synth
+    from oracle import bdcn as obdcn, esfnet as oesf
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    b = synth.make_batch(2, seed=1234)
+    rows = []
+    for n in [t for t in (8, 16, 32, 64, 128, 256) if t < ncores] + [ncores]:
+        torch.set_num_threads(n)
+        keep = {}
+
+        def f():
+            with torch.no_grad():
+                keep["e"] = obdcn.calc_edge(bd_sd, b["img"])
+                oesf.esf_forward(net_sd, setting, b["img"], keep["e"], b["label"], b["pupil_center"], b["elNorm"], b["spatWts"], b["distMap"],
+                                 b["cond"], b["ID"], b["alpha"])
+        med, mn, k, w = _timeit(f, budget_s, warm=1, lo=2, hi=4)
+        rows.append({"threads": n, "median_s": round(med, 3), "min_s": round(mn, 3), "frames_per_s": round(2 / med, 3), "timed": k})
+        print("cpu thread sweep: %4d threads  %.3f s  %.2f frames/s" % (n, med, 2 / med), file=sys.stderr, flush=True)
+    return {"what": "oracle edge + seg + loss, fp32, eval, B=2, torch CPU at several intra-op thread counts (one-off sweep: which count is the fair baseline)",
+            "affinity_cores": ncores, "os_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(), "rows": rows,
+            "best": max(rows, key=lambda r: r["frames_per_s"])}
+
+
+def cpu_baseline(setting, bd_sd, net_sd, batches=(2, 8), budget_s=7.0, parity=None, threads=0):
     """the oracle (CPU restatement of the reference path, pinned by the reference-generated fixtures) timed on
     this box's host cores, on bounded samples: BDCN forward, ESF-Net forward (+ loss), ESF-Net forward + backward + Adam, and the
     ellipse fit, each on its own; B = 2 (BASELINE.json configs[0]) and B = 8; 2 warm-ups and up to 5 timed iterations per part (as
@@ -135,7 +168,7 @@ def cpu_baseline(setting, bd_sd, net_sd, batches=(2, 8), budget_s=7.0, parity=No
     from oracle import bdcn as obdcn, esfnet as oesf, fit as ofit
     # the box exposes far more logical cores than torch's intra-op pool uses well (over-subscription was pathologically slow)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(min(ncores, 32))
+    torch.set_num_threads(threads if threads > 0 else min(ncores, 32))
     out = {"kind": "port", "unit": "eye-frames/s", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(),
            "affinity_cores": ncores, "cpu_model": _cpu_model(), "torch_threads": torch.get_num_threads(),
            "protocol": "BASELINE.md section 3: 2 warm-ups, 2-5 timed iterations per part (~%.0f s budget each), median and min" % budget_s,
@@ -257,9 +290,14 @@ class Bench:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != a.gpus:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, self.world))
-        if self.world > 1:
+        self.dist = self.world > 1 or a.force_dist           # collectives are issued (more than one rank, or a forced one-rank RCCL group)
+        if self.dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if a.force_dist:
+                os.environ["EGNE_FORCE_DIST"] = "1"
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
         _lib.lib()  # fail loudly if the HIP extension is missing
         torch.cuda.set_device(local)
@@ -309,7 +347,7 @@ class Bench:
                 "near_tie_pixels_lt_2e-3": int(near.sum()), "pixels": int(mask.numel())}
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist:
             self.torch.distributed.barrier()
         self.torch.cuda.synchronize()
 
@@ -391,7 +429,7 @@ class Bench:
         dt = time.perf_counter() - t0
         self.bd._events = self.net._events = None
         self.rank_dts = [dt]
-        if self.world > 1:
+        if self.dist:
             tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
             every = [torch.zeros_like(tt) for _ in range(self.world)]
             torch.distributed.all_gather(every, tt)             # every rank's own clock around its K steps (both barriers inside)
@@ -403,7 +441,8 @@ class Bench:
         """What the multi-GPU scaling run needs to be read without guessing: how many ranks took part, each rank's own rate, and
         the whole-job value per GPU (at --gpus 1 this IS `value`)."""
         rates = [B * steps / t for t in self.rank_dts]
-        return {"ranks_seen": self.world if self.world == 1 else int(self.torch.distributed.get_world_size()),
+        return {"ranks_seen": int(self.torch.distributed.get_world_size()) if self.dist else self.world,
+                "process_group": ("nccl (RCCL), %d rank(s)%s" % (self.world, ", forced" if self.a.force_dist else "")) if self.dist else "none (one process)",
                 "per_rank_frames_per_s_min": round(min(rates), 2), "per_rank_frames_per_s_max": round(max(rates), 2),
                 "value_per_gpu": round(B * steps / max(self.rank_dts), 2)}
 
@@ -429,15 +468,18 @@ class Bench:
 
     def rooflines(self, fam, steps, B, dt):
         conv_t, conv_f, conv_n = [sum(fam.get(k, [0.0, 0.0, 0])[i] for k in FP32_FAM) for i in range(3)]
+        conv_b = sum(fam.get(k, [0.0, 0.0, 0, 0.0])[3] for k in FP32_FAM)
         sub = {k.split(":")[1]: v for k, v in fam.items() if k.startswith("conv_f16x3:")}
         sp_t, sp_f, sp_n = [sum(v[i] for v in sub.values()) for i in range(3)]
+        sp_b = sum(v[3] for v in sub.values())
         achieved = conv_f / conv_t / 1e12 if conv_t > 0 else 0.0
         r_fp32 = {"bound": "mfma", "kernel": "exact-fp32 conv family on v_mfma_f32_32x32x2_f32: conv_igemm_kernel, conv3x3_halo_kernel, "
                   "conv3x3_c4_kernel (+ conv_wgrad_kernel, conv3x3_wgrad_halo_kernel in training)",
                   "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                   "launches_per_step": conv_n // max(steps, 1), "avg_launch_ms": round(1e3 * conv_t / max(conv_n, 1), 4),
-                  "algorithmic_gflop_per_frame": round(conv_f / steps / B / 1e9, 2), "time_share": round(conv_t / dt, 4)}
+                  "algorithmic_gflop_per_frame": round(conv_f / steps / B / 1e9, 2), "time_share": round(conv_t / dt, 4),
+                  "algorithmic_bytes_per_step": int(conv_b / max(steps, 1))}
         sp_ach = sp_f / sp_t / 1e12 if sp_t > 0 else 0.0
         r_split = {"bound": "mfma", "kernel": "split-f16 conv family (fp32 tensors, 3 x v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 per product, fp32 "
                    "accumulate): conv_f16x3_big_kernel, conv3x3_rw_kernel, conv3x3_rs_kernel, fused_1x1_3x3_kernel, msblock_dil_kernel, "
@@ -448,6 +490,7 @@ class Bench:
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": None,
                    "launches_per_step": sp_n // max(steps, 1), "avg_launch_ms": round(1e3 * sp_t / max(sp_n, 1), 4),
                    "algorithmic_gflop_per_frame": round(sp_f / steps / B / 1e9, 2), "time_share": round(sp_t / dt, 4),
+                   "algorithmic_bytes_per_step": int(sp_b / max(steps, 1)),
                    "by_kernel": {k: {"tflops": round(v[1] / v[0] / 1e12, 1) if v[0] > 0 else 0.0, "time_share": round(v[0] / dt, 4),
                                      "launches_per_step": v[2] // max(steps, 1)} for k, v in sorted(sub.items())}}
         bf = {k.split(":")[1]: v for k, v in fam.items() if k.startswith("conv_bf16:")}
@@ -548,7 +591,7 @@ class Bench:
             out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
                       t["ID"], t["alpha"])
             out[3].backward()
-            if self.world > 1:       # one flat RCCL all-reduce of the gradient arena (13.45 MB for baseline_edge), timed with HIP events on the stream it runs on
+            if self.dist:            # one flat RCCL all-reduce of the gradient arena (13.45 MB for baseline_edge), timed with HIP events on the stream it runs on
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 parallel.allreduce_grads(net)
@@ -657,9 +700,14 @@ def main():
                 if B == 64:
                     r_split["traffic"] = tr["split_f16"]["hbm_bytes_per_launch"]
                     r_fp32["traffic"] = tr["fp32_conv"]["hbm_bytes_per_launch"]
-                    for r in (r_split, r_fp32):
+                    for r, key in ((r_split, "split_f16"), (r_fp32, "fp32_conv")):
                         r["traffic_source"] = ("copied from profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes over `bench.py --mode infer --no-pipeline`, "
                                                "FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run" % rnd)
+                        # per STEP, next to the algorithmic bytes of the same launches (every input slice read once, the output written once):
+                        # a ratio well above 1 would mean wasted re-reads
+                        r["traffic_bytes_per_step"] = int(1e9 * (tr[key]["hbm_read_gb_per_step"] + tr[key]["hbm_write_gb_per_step"]))
+                        if r.get("algorithmic_bytes_per_step"):
+                            r["traffic_over_algorithmic"] = round(r["traffic_bytes_per_step"] / r["algorithmic_bytes_per_step"], 3)
                 break
             except Exception:
                 continue
@@ -794,9 +842,27 @@ def main():
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and a.mode != "train":
-            res["cpu_baseline"] = cpu_baseline(bn.setting, bn.bd_sd, bn.net_sd, budget_s=a.cpu_budget, parity=bn.parity_sample)
+            res["cpu_baseline"] = cpu_baseline(bn.setting, bn.bd_sd, bn.net_sd, budget_s=a.cpu_budget, parity=bn.parity_sample, threads=a.cpu_threads)
+            if a.cpu_thread_sweep:
+                res["cpu_thread_sweep"] = cpu_thread_sweep(bn.setting, bn.bd_sd, bn.net_sd)
+        # the other legs' headline numbers as top-level scalars AND inside `config` (a record that keeps only the standard keys still has them)
+        extra = {}
+        if "with_fit" in res:
+            extra.update(with_fit_value=res["with_fit"]["value"], with_fit_ms_per_step=res["with_fit"]["ms_per_step"])
+        if "exact_fp32" in res:
+            extra.update(exact_fp32_value=res["exact_fp32"]["value"])
+        if "train" in res:
+            extra.update(train_value=res["train"]["value"], train_ms_per_step=res["train"]["ms_per_step"],
+                         train_allreduce_ms_per_step=res["train"]["allreduce_ms_per_step"])
+            if "fp32_storage" in res["train"]:
+                extra.update(train_fp32_storage_value=res["train"]["fp32_storage"]["value"])
+        if "latency_b2_ms" in res:
+            extra.update(latency_b2_ms_edge_seg_fit=res["latency_b2_ms"])
+        res.update(extra)
+        if isinstance(res.get("config"), dict):
+            res["config"].update(extra)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if bn.dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -18,12 +18,24 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """EGNE_FORCE_DIST=1: build the process group and run every collective even with ONE rank -- the way to take the RCCL path
+    (all-reduce of the gradient arena on its HIP stream, broadcasts, the device branch of sum_over_ranks) on a one-GPU box."""
+    return os.environ.get("EGNE_FORCE_DIST", "0") not in ("", "0")
+
+
+def active():
+    """True when collectives are to be issued: more than one rank, or a forced one-rank group."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not forced():
         return 0, 1
     if not dist.is_initialized():
+        os.environ.setdefault("RANK", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # nccl = RCCL over xGMI, one rank per GPU.  EGNE_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) --
@@ -43,7 +55,7 @@ def world_size():
 
 def broadcast_state(model, src=0):
     """Same parameters and BatchNorm buffers on every rank before the first step."""
-    if world_size() == 1:
+    if not active():
         return
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
@@ -54,7 +66,7 @@ def broadcast_buffers(model, src=0):
     """BatchNorm running statistics of rank ``src`` on every rank.  nn.DataParallel keeps replica 0's buffers
     and drops the others'; ranks here update their own, so they are re-aligned before each validation pass
     (and therefore before every checkpoint)."""
-    if world_size() == 1:
+    if not active():
         return
     with torch.no_grad():
         for t in model.buffers():
@@ -63,7 +75,7 @@ def broadcast_buffers(model, src=0):
 
 def sum_over_ranks(values, device=None):
     """Element-wise sum of a short list of python floats over all ranks (validation means)."""
-    if world_size() == 1:
+    if not active():
         return list(values)
     t = torch.tensor(list(values), dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -121,7 +133,7 @@ def grad_arena(model):
 def allreduce_grads(model, async_op=False):
     """Average gradients over ranks with one collective on the flat arena (in place)."""
     n = world_size()
-    if n == 1:
+    if not active():
         return None
     flat, is_view = grad_arena(model)
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
@@ -143,7 +155,7 @@ def allreduce_grads(model, async_op=False):
 def mean_loss(loss):
     """Logging only: the DataParallel caller's ``loss.mean()`` over replicas (train.py:285)."""
     n = world_size()
-    if n == 1:
+    if not active():
         return loss
     t = loss.detach().clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

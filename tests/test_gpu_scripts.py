@@ -198,3 +198,94 @@ def test_train_py_two_ranks_one_epoch(tmp_path, pipeline, extra):
     from common import esf_module
     w_init = float(esf_module("baseline_edge").enc.head.conv1.weight.detach().double().sum())
     assert abs(res[0]["w0"] - w_init) > 1e-6, "the weights did not move"
+
+
+_RCCL_WORKER = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch
+import torch.distributed as dist
+import egne_amd
+from egne_amd import parallel, synth
+from common import batch_args, bdcn_module, esf_module
+import types
+from egne_amd.utils import calc_edge
+
+mode = sys.argv[1]                    # "none" | "sync" | "async"
+dev = "cuda:0"
+torch.cuda.set_device(0)
+rank, world = parallel.init()
+out = {"active": parallel.active(), "backend": dist.get_backend() if dist.is_initialized() else None, "world": world}
+b = synth.make_batch(2, seed=1234)
+edge = calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), b["img"].to(dev), bdcn_module().to(dev), dev)
+m = esf_module("baseline_edge").to(dev).train()
+parallel.broadcast_state(m)
+opt = torch.optim.Adam([p for n, p in m.named_parameters() if "dsIdentify" not in n], lr=5e-4)
+args = [a.to(dev) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+ms = []
+for step in range(2):                 # train.py:284-287 with the gradient exchange of egne_amd.parallel in place of nn.DataParallel
+    opt.zero_grad()
+    loss = m(*args)[3]
+    loss.backward()
+    if mode != "none":
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = parallel.allreduce_grads(m, async_op=(mode == "async"))
+        if mode == "async":
+            work, finish = r
+            work.wait()
+            finish()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    opt.step()
+torch.cuda.synchronize()
+out["loss_mean"] = float(parallel.mean_loss(loss.detach()).item())
+out["sum"] = parallel.sum_over_ranks([1.5, 2.5], device=dev)
+h = hashlib.sha256()
+for k, v in sorted(m.state_dict().items()):
+    h.update(v.detach().cpu().contiguous().numpy().tobytes())
+out.update(sha=h.hexdigest(), allreduce_ms=ms, loss=float(loss.item()))
+json.dump(out, open(sys.argv[2], "w"))
+if dist.is_initialized():
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def test_rccl_one_rank_training_matches_the_plain_run(tmp_path):
+    """EGNE_FORCE_DIST=1: an nccl (= RCCL) process group of ONE rank on this box's GPU.  Two Adam steps whose gradient arena goes
+    through parallel.allreduce_grads on the HIP stream (blocking and async_op forms), after the parameter broadcast, must leave exactly
+    the weights of the run without a process group (SUM over one rank, / 1); the all-reduce takes measurable time; the scalar
+    all-reduces (mean_loss, the device branch of sum_over_ranks) return their inputs.  train.py:205,285 with nn.DataParallel replaced
+    by one process per GPU -- the scaling run itself needs an 8-GPU node, the code path does not."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % dict(root=root))
+    res = {}
+    for i, mode in enumerate(("none", "sync", "async")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + (os.getpid() % 90) + i), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.pop("EGNE_DIST_BACKEND", None)
+        if mode != "none":
+            env["EGNE_FORCE_DIST"] = "1"
+        else:
+            env.pop("EGNE_FORCE_DIST", None)
+        outp = tmp_path / ("%s.json" % mode)
+        p = subprocess.run([sys.executable, str(script), mode, str(outp)], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, "%s run failed:\n%s" % (mode, p.stdout.decode()[-3000:])
+        res[mode] = json.load(open(outp))
+    assert not res["none"]["active"] and res["none"]["backend"] is None
+    for mode in ("sync", "async"):
+        r = res[mode]
+        assert r["active"] and r["backend"] == "nccl" and r["world"] == 1
+        assert r["sha"] == res["none"]["sha"], "%s: weights differ from the run without a process group" % mode
+        assert r["loss"] == res["none"]["loss"] and abs(r["loss_mean"] - r["loss"]) < 1e-6 * abs(r["loss"])
+        assert r["sum"] == [1.5, 2.5]
+        assert len(r["allreduce_ms"]) == 2 and all(t > 0 for t in r["allreduce_ms"])
+    print("RCCL, one rank: all-reduce of the gradient arena %.3f ms (blocking), %.3f ms (async_op)"
+          % (res["sync"]["allreduce_ms"][-1], res["async"]["allreduce_ms"][-1]))
