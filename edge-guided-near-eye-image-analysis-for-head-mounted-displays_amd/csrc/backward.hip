@@ -432,12 +432,20 @@ constexpr int WPX = 128;  // pixels per chunk (two barriers per 16 MFMAs of ever
 constexpr int WLD = 33;   // LDS row pitch (floats): lanes read consecutive floats of one pixel row
 constexpr int WNR = WPX / 32;
 
-template <typename TS>
+// BFM (bf16 tensors): the contraction over pixels on v_mfma_f32_32x32x16_bf16 -- both tiles staged as plain [pixel][32] bf16 rows and
+// read back transposed ("eight consecutive pixels of one channel") with ds_read_b64_tr_b16, as wgrad_bf16.hip does: two MFMAs of 32
+// cycles per wave and chunk instead of sixteen of 64.  The generic form serves the reflect-padded 7x7 and the 4x4 / stride-2
+// convolutions of the StyleEncoder (RITnet_v2.py:91-107), where it was 35 % of a configs[3] training step.
+typedef __attribute__((address_space(3))) egne_bf16x4* wg_lds_bf4_ptr;
+template <typename TS, bool BFM = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p, const TS* __restrict__ gz, long long gzs,
                                                          int gzo, int nsplit, float* __restrict__ ws) {
-  __shared__ float As[WPX * WLD];   // gz chunk   [pixel][co]
-  __shared__ float Bs[WPX * WLD];   // x chunk    [pixel][k]
+  static_assert(!BFM || sizeof(TS) == 2, "bf16 MFMA form: bf16 tensors");
+  __shared__ __attribute__((aligned(16))) float As[WPX * WLD];   // gz chunk   [pixel][co]
+  __shared__ __attribute__((aligned(16))) float Bs[WPX * WLD];   // x chunk    [pixel][k]
   __shared__ float red[4][16][64];
+  egne_bf16* const Ah = (egne_bf16*)As;      // BFM: [pixel][32] bf16, 64-byte rows
+  egne_bf16* const Bh = (egne_bf16*)Bs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int T = p.kh * p.kw;
@@ -524,6 +532,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
         for (int e = 0; e < 4; ++e) bv[i][e] = fmaxf(bv[i][e], bv[i][e] * slope_in);
     }
     __syncthreads();
+    if constexpr (BFM) {
+#pragma unroll
+      for (int i = 0; i < WNR; ++i) {
+        *(egne_bf16x4*)&Ah[(lr + 32 * i) * 32 + lc] = __builtin_convertvector(av[i], egne_bf16x4);      // (gz: exact, the values were bf16)
+        *(egne_bf16x4*)&Bh[(lr + 32 * i) * 32 + lc] = __builtin_convertvector(bv[i], egne_bf16x4);
+      }
+      __syncthreads();
+      // wave w contracts pixels 32 w .. 32 w + 31 of the chunk in two 16-pixel steps.  Transposing read: 16-lane group g takes channels
+      // 16 (g & 1) .. + 15 and the pixel octet g >> 1 of the step; lane 4 q + c of the group supplies pixel q, channels 4 c .. 4 c + 3
+      const int g16 = lane >> 4, i16 = lane & 15;
+      const int lbase = (8 * (g16 >> 1) + (i16 >> 2)) * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const egne_bf16* ga = Ah + lbase + (32 * wave + 16 * s) * 32;
+        const egne_bf16* xa = Bh + lbase + (32 * wave + 16 * s) * 32;
+        const egne_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)ga);
+        const egne_bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)(ga + 4 * 32));
+        const egne_bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)xa);
+        const egne_bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)(xa + 4 * 32));
+        const egne_bf16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const egne_bf16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < WNR; ++i)
 #pragma unroll
@@ -534,6 +566,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
     for (int s = 0; s < WPX / 8; ++s) {
       const int px = (wave * (WPX / 8) + s) * 2 + lh;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[px * WLD + li], Bs[px * WLD + li], acc, 0, 0, 0);
+    }
     }
   }
   // cross-wave reduction; lane holds column k = li of rows co = (r&3) + 8*(r>>2) + 4*lh
@@ -1099,7 +1132,13 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
   } else {
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
     dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
-    hipLaunchKernelGGL(conv_wgrad_kernel<TS>, grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+    static const bool bfm = [] { const char* e = getenv("EGNE_IGEMM_BF16_MFMA"); return !e || e[0] != '0'; }();
+    if constexpr (sizeof(TS) == 2) {
+      if (bfm) hipLaunchKernelGGL((conv_wgrad_kernel<TS, true>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+    } else {
+      hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+    }
   }
   for (int g = 0; g < d.ngroups; ++g) {
     EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);

@@ -74,14 +74,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // buffer resource with one multiply-add, padded lanes get 0x80000000 (the buffer unit returns zeros).  Weights,
 // residual and output go through buffer instructions with lane-constant offsets.  Reflect padding (StyleEncoder
 // only) recomputes the mirrored coordinates per step.
-template <int WM, int WN, bool GROUPED, typename TS>
+// BFM (bf16 tensors only): the products on v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_32x32x2_f32 -- the LDS tiles hold bf16 (what the
+// activation tensor is stored as anyway; the fp32 weights are rounded to bf16 while they are staged, as conv3x3_bf16.hip does), two
+// MFMAs of 32 cycles per 32-channel K step and 32x32 block instead of sixteen of 64.  This is what the layers of a bf16-storage
+// training plan run on that no specialised kernel takes: the StyleEncoder of the AdaIN configuration (reflect-padded 7x7, 4x4 /
+// stride 2; RITnet_v2.py:91-107) and the data gradients of those layers, the regression head, multi-slice 1x1 leftovers.
+template <int WM, int WN, bool GROUPED, typename TS, bool BFM = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p) {
+  static_assert(!BFM || (sizeof(TS) == 2 && !GROUPED), "bf16 MFMA form: bf16 tensors, one group");
   constexpr int ES = sizeof(TS);          // bytes per activation element (weights, bias and affine tables are fp32 always)
+  constexpr int LDHB = 40;                // BFM: LDS row pitch in halfs (80 B: conflict-free ds_read_b128 over 32 rows)
   constexpr int BM = 128 * WM, BN = 32 * WN;
   constexpr int AR = BM / 32;  // A rows staged per thread
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDK];
   float* As = lds;
   float* Bs = lds + BM * LDK;
+  egne_bf16* const Ah = (egne_bf16*)lds;                 // BFM: the same storage as bf16 rows of LDHB halfs
+  egne_bf16* const Bh = Ah + BM * LDHB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -213,14 +222,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
         f32x4 v = raw_to_f32(ra[i]) * sc + sh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
-        *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = v;
+        if constexpr (BFM) *(egne_bf16x4*)&Ah[(rbase + 32 * i) * LDHB + col4 * 4] = __builtin_convertvector(v, egne_bf16x4);
+        else *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = v;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < AR; ++i) *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = raw_to_f32(ra[i]);
+      for (int i = 0; i < AR; ++i) {
+        if constexpr (BFM) *(typename Raw4<TS>::type*)&Ah[(rbase + 32 * i) * LDHB + col4 * 4] = ra[i];      // the stored bf16 values as they are
+        else *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = raw_to_f32(ra[i]);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < WN; ++j) *(u32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
+    for (int j = 0; j < WN; ++j) {
+      if constexpr (BFM) *(egne_bf16x4*)&Bh[(rbase + 32 * j) * LDHB + col4 * 4] = __builtin_convertvector(__builtin_bit_cast(f32x4, rb[j]), egne_bf16x4);
+      else *(u32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
+    }
   };
 
   f32x16 acc[WM][WN];
@@ -258,6 +274,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
 
     int rem = p.seg[cur.seg].Cp - cur.c0;
     const int nk8 = rem >= KC ? KC / 8 : (rem >> 3);
+    if constexpr (BFM) {
+      // lane (li, lh) supplies channels 16 s + 8 lh .. + 7 of its row to both operands; columns past the slice were staged as zeros
+      const egne_bf16* arh = &Ah[(wave * 32 * WM + li) * LDHB + lh * 8];
+      const egne_bf16* brh = &Bh[li * LDHB + lh * 8];
+      const int nk16 = rem >= KC ? 2 : ((rem + 15) >> 4);
+      for (int s = 0; s < nk16; ++s) {
+        egne_bf16x8 a[WM], b[WN];
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm) a[tm] = *(const egne_bf16x8*)(arh + tm * 32 * LDHB + s * 16);
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn) b[tn] = *(const egne_bf16x8*)(brh + tn * 32 * LDHB + s * 16);
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    } else
     for (int s = 0; s < nk8; ++s) {
       f32x4 a[WM], b[WN];
 #pragma unroll
@@ -440,7 +473,9 @@ int launch(const egne_conv_desc& d, hipStream_t st) {
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / BN));
   if (d.dtype == 1) {       // bf16 activation tensors (training plans); the fused MSBlock form belongs to the frozen fp32 network
     if (d.ngroups > 1) return egne::fail(EGNE_ERR_ARG, "conv: grouped launches take fp32 tensors only");
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16>), grid, dim3(256), 0, st, d);
+    static const bool bfm = [] { const char* e = getenv("EGNE_IGEMM_BF16_MFMA"); return !e || e[0] != '0'; }();
+    if (bfm) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16, true>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16>), grid, dim3(256), 0, st, d);
   } else if (d.ngroups > 1)
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, true, float>), grid, dim3(256), 0, st, d);
   else
