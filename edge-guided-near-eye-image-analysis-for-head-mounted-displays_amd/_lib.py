@@ -162,6 +162,8 @@ for _n in BF16_TWINS:
 SIGNATURES.update({
     "egne_pack_conv_weight_bf16frag": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "egne_conv3x3_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
+    "egne_conv_narrow_bf16_supported": (i32, [C.POINTER(ConvDesc)]),
+    "egne_conv_narrow_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp]),
     "egne_conv1x1_bf16_pack_elems": (i64, [C.POINTER(ConvDesc)]),
     "egne_pack_conv1x1_bf16": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp]),
     "egne_conv1x1_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),

@@ -437,7 +437,9 @@ constexpr int WNR = WPX / 32;
 // cycles per wave and chunk instead of sixteen of 64.  The generic form serves the reflect-padded 7x7 and the 4x4 / stride-2
 // convolutions of the StyleEncoder (RITnet_v2.py:91-107), where it was 35 % of a configs[3] training step.
 typedef __attribute__((address_space(3))) egne_bf16x4* wg_lds_bf4_ptr;
-template <typename TS, bool BFM = false>
+// FOLD (one slice of 8 padded channels, one group): a column tile holds FOUR taps x 8 channels instead of one tap x 32 channels of
+// which 8 exist -- a quarter of the tiles, each reading gz once for four taps (the 7x7 on three channels: 13 x 2 tiles instead of 49 x 2).
+template <typename TS, bool BFM = false, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p, const TS* __restrict__ gz, long long gzs,
                                                          int gzo, int nsplit, float* __restrict__ ws) {
   static_assert(!BFM || sizeof(TS) == 2, "bf16 MFMA form: bf16 tensors");
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
     }
     c0 = ct * 32;
   }
+  if constexpr (FOLD) { seg = 0; kofs = 0; g = 0; c0 = 0; tap = 4 * (int)blockIdx.z + ((tid & 7) >> 1); }      // (this thread's tap of the group)
   const egne_seg sg = p.seg[seg];
   const int co0 = blockIdx.y * 32;
   const long long M = (long long)p.B * p.Ho * p.Wo;
@@ -479,11 +482,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
 
   // loader: thread -> (pixel rows tid>>3 + 32*i, float4 column = tid&7) of both tiles
   const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const bool aok = co0 + lc < p.Cout_store, bok = c0 + lc < sg.Cp;
+  const int xc = FOLD ? ((tid & 7) & 1) * 4 : c0 + lc;         // first of this thread's four input channels
+  const bool aok = co0 + lc < p.Cout_store, bok = FOLD ? tap < T : c0 + lc < sg.Cp;
   f32x16 acc = (f32x16)(0.f);
-  for (long long mc = m_begin; mc < m_end; mc += WPX) {
-    f32x4 av[WNR], bv[WNR];
-    int bb[WNR];
+  // the loads of chunk c + 1 are requested before the MFMAs of chunk c (they used to be requested and waited for inside one chunk: a
+  // full memory latency per 128 pixels, 937 times per workgroup for the StyleEncoder's first layer)
+  f32x4 av[WNR], bv[WNR];
+  int bb[WNR];
+  // (frame, row, column) of this thread's rows, advanced by 128 pixels per chunk: the 64-bit division per row and chunk this replaces
+  // was most of the kernel's instructions on small-channel layers
+  int cb[WNR], cy[WNR], cx[WNR];
+  {
+#pragma unroll
+    for (int i = 0; i < WNR; ++i) {
+      const long long m = m_begin + lr + 32 * i;
+      cb[i] = (int)(m / hw);
+      const int r = (int)(m - (long long)cb[i] * hw);
+      cy[i] = r / p.Wo; cx[i] = r - cy[i] * p.Wo;
+    }
+  }
+  const int adv_y = WPX / p.Wo, adv_x = WPX - adv_y * p.Wo;
+  auto issue = [&](long long mc) {
 #pragma unroll
     for (int i = 0; i < WNR; ++i) {
       const long long m = mc + lr + 32 * i;
@@ -491,13 +510,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
       const TS* ap = (in && aok) ? gz + m * gzs + gzo + co0 + lc : zero_page<TS>();
       const TS* bp = zero_page<TS>();
       bb[i] = -1;
+      const int b = cb[i], oy = cy[i], ox = cx[i];
+      cx[i] += adv_x; cy[i] += adv_y;                     // the next chunk's coordinates
+      if (cx[i] >= p.Wo) { cx[i] -= p.Wo; ++cy[i]; }
+      while (cy[i] >= p.Ho) { cy[i] -= p.Ho; ++cb[i]; }
       if (simple) {
-        if (in && bok) bp = (const TS*)sg.ptr + m * sg.pix_stride + sg.ch_off + c0 + lc;
-        if (sg.scale && in && bok) bb[i] = (int)(m / hw);
+        if (in && bok) bp = (const TS*)sg.ptr + m * sg.pix_stride + sg.ch_off + xc;
+        if (sg.scale && in && bok) bb[i] = b;
       } else if (in && bok) {
-        const int b = (int)(m / hw);
-        const int r = (int)(m - (long long)b * hw);
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
         int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
         bool ok = true;
         if (p.pad_mode == 1) {
@@ -507,19 +527,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
           ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         }
         if (ok) {
-          bp = (const TS*)sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + c0 + lc;
+          bp = (const TS*)sg.ptr + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + xc;
           bb[i] = b;
         }
       }
       av[i] = ld4(ap);
       bv[i] = ld4(bp);
     }
+  };
+  if (m_begin < m_end) issue(m_begin);
+  for (long long mc = m_begin; mc < m_end; mc += WPX) {
     if (sg.scale) {
 #pragma unroll
       for (int i = 0; i < WNR; ++i) {
         const bool ok = bb[i] >= 0;
-        const f32x4 sc = *(const f32x4*)(ok ? sg.scale + (long long)bb[i] * sg.Cp + c0 + lc : egne_zero_page);
-        const f32x4 sh = *(const f32x4*)(ok ? sg.shift + (long long)bb[i] * sg.Cp + c0 + lc : egne_zero_page);
+        const f32x4 sc = *(const f32x4*)(ok ? sg.scale + (long long)bb[i] * sg.Cp + xc : egne_zero_page);
+        const f32x4 sh = *(const f32x4*)(ok ? sg.shift + (long long)bb[i] * sg.Cp + xc : egne_zero_page);
         f32x4 v = bv[i] * sc + sh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
@@ -539,6 +562,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
         *(egne_bf16x4*)&Bh[(lr + 32 * i) * 32 + lc] = __builtin_convertvector(bv[i], egne_bf16x4);
       }
       __syncthreads();
+      if (mc + WPX < m_end) issue(mc + WPX);
       // wave w contracts pixels 32 w .. 32 w + 31 of the chunk in two 16-pixel steps.  Transposing read: 16-lane group g takes channels
       // 16 (g & 1) .. + 15 and the pixel octet g >> 1 of the step; lane 4 q + c of the group supplies pixel q, channels 4 c .. 4 c + 3
       const int g16 = lane >> 4, i16 = lane & 15;
@@ -561,6 +585,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
 #pragma unroll
       for (int e = 0; e < 4; ++e) { As[(lr + 32 * i) * WLD + lc + e] = av[i][e]; Bs[(lr + 32 * i) * WLD + lc + e] = bv[i][e]; }
     __syncthreads();
+    if (mc + WPX < m_end) issue(mc + WPX);
     // wave w consumes pixel pairs 16w..16w+15 of the chunk: D[co][k] += A[co][px] * B[px][k]
 #pragma unroll
     for (int s = 0; s < WPX / 8; ++s) {
@@ -574,13 +599,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const egne_conv_desc p,
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
   if (wave == 0) {
-    float* dst = ws + (((long long)blockIdx.x * p.ngroups + g) * T + tap) * (long long)p.CoutP * p.Ktot;
+    const int otap = FOLD ? 4 * (int)blockIdx.z + (li >> 3) : tap;       // FOLD: column li = (tap of the group, channel li & 7)
+    float* dst = ws + (((long long)blockIdx.x * p.ngroups + g) * T + otap) * (long long)p.CoutP * p.Ktot;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
       const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int k = c0 + li;
-      if (k < sg.Cp) dst[(long long)co * p.Ktot + kofs + k] = v;
+      const int k = FOLD ? (li & 7) : c0 + li;
+      if (FOLD ? otap < T : k < sg.Cp) dst[(long long)co * p.Ktot + kofs + k] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Generic weight gradient, bf16 tensors, WIDE form: a workgroup owns one (tap, 32-channel input chunk) column for FOUR 32-channel output
+// blocks -- wave w contracts every pixel of a 128-pixel chunk for output block w (eight v_mfma_f32_32x32x16_bf16 per chunk, no
+// cross-wave reduction), so an x tile staged once feeds four times the matrix work of the tile-per-workgroup form above, whose
+// 16 KB of loads and two barriers bought two MFMAs per wave (the 4x4 / stride-2 blocks of the StyleEncoder, RITnet_v2.py:96-103, ran
+// at 73 TFLOP/s).  Operands by ds_read_b64_tr_b16 from plain [pixel][32] bf16 rows; the next chunk's loads fly during the MFMAs.
+// Plain inputs only (no fused affine / activation on load), 16-byte aligned slices.  Partials: ws[split][tap][CoutP][Ktot].
+// FOLD (one slice of 8 padded channels, 64 output channels): a column tile holds four taps x 8 channels (as conv_wgrad_kernel<.., FOLD>);
+// the workgroup takes TWO such tap groups and both output blocks -- wave w = (output block w & 1, tap group w >> 1).
+// ------------------------------------------------------------------------------------------------------------------------
+template <bool FOLD>
+__global__ __launch_bounds__(256) void conv_wgrad_wide_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ gz, long long gzs,
+                                                              int gzo, int nsplit, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) egne_bf16 Gh[4 * WPX * 32];     // [output block][pixel][32 co]
+  __shared__ __attribute__((aligned(16))) egne_bf16 Xh[(FOLD ? 2 : 1) * WPX * 32];         // [tap group][pixel][32 k]
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.kh * p.kw;
+  int ct = blockIdx.z, seg = 0, kofs = 0, tap = 0, c0 = 0;
+  if constexpr (!FOLD) {
+    int per_tap = 0;
+    for (int s = 0; s < p.nseg; ++s) per_tap += (p.seg[s].Cp + 31) / 32;
+    tap = ct / per_tap; ct -= tap * per_tap;
+    for (seg = 0; seg < p.nseg; ++seg) {
+      const int n = (p.seg[seg].Cp + 31) / 32;
+      if (ct < n) break;
+      ct -= n; kofs += p.seg[seg].Cp;
+    }
+    c0 = ct * 32;
+  }
+  const egne_seg sg = p.seg[seg];
+  const egne_bf16* const xin = (const egne_bf16*)sg.ptr;
+  const int cog = FOLD ? 0 : blockIdx.y * 128;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long per = ((M + nsplit - 1) / nsplit + WPX - 1) / WPX * WPX;
+  const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
+  const int hw = p.Ho * p.Wo;
+  // gz loader: rows (tid >> 3) + 32 i, 16-byte pieces (tid & 7) [and (tid & 7) + 8] of the row's 64 [128] output channels
+  const int glr = tid >> 3, gpc = tid & 7;
+  constexpr int GH = FOLD ? 1 : 2;
+  // x loader: rows (tid >> 2) + 64 j, piece tid & 3 of the row's 32 columns: 8 input channels, or (FOLD) all 8 channels of one tap
+  const int xlr = tid >> 2, xpc = tid & 3;
+  constexpr int XG = FOLD ? 2 : 1;
+  int dyv[XG], dxv[XG];
+  bool xokv[XG];
+#pragma unroll
+  for (int q = 0; q < XG; ++q) {
+    const int tp = FOLD ? 4 * (2 * (int)blockIdx.z + q) + xpc : tap;
+    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+    dyv[q] = (ky - p.pad_h) * p.dil[0]; dxv[q] = (kx - p.pad_w) * p.dil[0];
+    xokv[q] = FOLD ? tp < T : c0 + xpc * 8 < sg.Cp;
+  }
+  const int xch = FOLD ? 0 : c0 + xpc * 8;
+  u32x4_ rg[4][GH], rx[2][XG];
+  int cb[2], cy[2], cx[2];         // (frame, row, column) of this thread's two x rows, advanced by 128 pixels per chunk (no division per chunk)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long long m = m_begin + xlr + 64 * j;
+    cb[j] = (int)(m / hw);
+    const int r = (int)(m - (long long)cb[j] * hw);
+    cy[j] = r / p.Wo; cx[j] = r - cy[j] * p.Wo;
+  }
+  const int adv_y = WPX / p.Wo, adv_x = WPX - adv_y * p.Wo;
+  auto issue = [&](long long mc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = mc + glr + 32 * i;
+#pragma unroll
+      for (int h = 0; h < GH; ++h) {
+        const int co = cog + (gpc + 8 * h) * 8;
+        const egne_bf16* ap = (m < m_end && co < p.Cout_store) ? gz + m * gzs + gzo + co : zero_page<egne_bf16>();
+        rg[i][h] = *(const u32x4_*)ap;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long long m = mc + xlr + 64 * j;
+      const int b = cb[j], oy = cy[j], ox = cx[j];
+      cx[j] += adv_x; cy[j] += adv_y;
+      if (cx[j] >= p.Wo) { cx[j] -= p.Wo; ++cy[j]; }
+      while (cy[j] >= p.Ho) { cy[j] -= p.Ho; ++cb[j]; }
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        const egne_bf16* bp = zero_page<egne_bf16>();
+        if (m < m_end && xokv[q]) {
+          int iy = oy * p.stride + dyv[q], ix = ox * p.stride + dxv[q];
+          bool ok = true;
+          if (p.pad_mode == 1) {
+            iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+            ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+          } else {
+            ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          }
+          if (ok) bp = xin + (((long long)b * p.H + iy) * p.W + ix) * sg.pix_stride + sg.ch_off + xch;
+        }
+        rx[j][q] = *(const u32x4_*)bp;
+      }
+    }
+  };
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int lbase = (8 * (g16 >> 1) + (i16 >> 2)) * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);      // transposing read, as conv_wgrad_kernel<BFM>
+  f32x16 acc = (f32x16)(0.f);
+  if (m_begin < m_end) issue(m_begin);
+  for (long long mc = m_begin; mc < m_end; mc += WPX) {
+    __syncthreads();                 // every wave is done with the previous chunk's tiles
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < GH; ++h) {
+        const int pc = gpc + 8 * h;
+        *(u32x4_*)&Gh[((pc >> 2) * WPX + glr + 32 * i) * 32 + (pc & 3) * 8] = rg[i][h];
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < XG; ++q) *(u32x4_*)&Xh[(q * WPX + xlr + 64 * j) * 32 + xpc * 8] = rx[j][q];
+    __syncthreads();
+    if (mc + WPX < m_end) issue(mc + WPX);
+    const egne_bf16* ga = Gh + (FOLD ? (wave & 1) : wave) * WPX * 32 + lbase;
+    const egne_bf16* xa = Xh + (FOLD ? (wave >> 1) : 0) * WPX * 32 + lbase;
+#pragma unroll
+    for (int s = 0; s < WPX / 16; ++s) {
+      const egne_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)(ga + 16 * s * 32));
+      const egne_bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)(ga + (16 * s + 4) * 32));
+      const egne_bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)(xa + 16 * s * 32));
+      const egne_bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds_bf4_ptr)(xa + (16 * s + 4) * 32));
+      const egne_bf16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const egne_bf16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+  // lane holds column k = lane & 31 of rows co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of this wave's output block
+  const int cob = FOLD ? 32 * (wave & 1) : cog + 32 * wave;
+  const int kcol = lane & 31;
+  const int otap = FOLD ? 4 * (2 * (int)blockIdx.z + (wave >> 1)) + (kcol >> 3) : tap;
+  const int k = FOLD ? (kcol & 7) : c0 + kcol;
+  if (cob < p.CoutP && (FOLD ? otap < T : k < sg.Cp)) {
+    float* dst = ws + ((long long)blockIdx.x * T + otap) * (long long)p.CoutP * p.Ktot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      dst[(long long)co * p.Ktot + kofs + k] = acc[r];
     }
   }
 }
@@ -1043,7 +1216,10 @@ extern "C" int egne_conv2d_wgrad_splits(const egne_conv_desc* dp) {
   { int a, b2, ch; if (w1_supported(d, &a, &b2, &ch)) return w1_splits(d, ch); }
   int per_tap = 0;
   for (int s = 0; s < d.nseg; ++s) per_tap += (d.seg[s].Cp + 31) / 32;
-  const long long tiles = (long long)(d.CoutP / 32) * per_tap * d.kh * d.kw * d.ngroups;
+  long long tiles = (long long)(d.CoutP / 32) * per_tap * d.kh * d.kw * d.ngroups;
+  // bf16 tensors, one 8-channel slice and 64 outputs: the wide folded form takes two tap groups x both output blocks per workgroup --
+  // 7 column tiles instead of 98 for a 7x7, so more pixel splits to fill the chip
+  if (d.dtype == 1 && d.ngroups == 1 && d.nseg == 1 && d.seg[0].Cp == 8 && d.CoutP == 64 && d.kh * d.kw >= 4) tiles = 2 * (((d.kh * d.kw + 3) / 4 + 1) / 2);
   const long long M = (long long)d.B * d.Ho * d.Wo;
   long long ns = 4096 / (tiles > 0 ? tiles : 1);
   if (ns < 1) ns = 1;
@@ -1133,8 +1309,26 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
     dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
     static const bool bfm = [] { const char* e = getenv("EGNE_IGEMM_BF16_MFMA"); return !e || e[0] != '0'; }();
+    static const bool fold_on = [] { const char* e = getenv("EGNE_IGEMM_FOLD"); return !e || e[0] != '0'; }();
     if constexpr (sizeof(TS) == 2) {
-      if (bfm) hipLaunchKernelGGL((conv_wgrad_kernel<TS, true>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+      if (bfm && fold_on && d.nseg == 1 && d.seg[0].Cp == 8 && d.Ktot == 8 && d.ngroups == 1 && T >= 4 && d.CoutP == 64 && gzs % 8 == 0 && gzo % 8 == 0 &&
+          ((uintptr_t)gz & 15) == 0 && !d.seg[0].scale && d.seg[0].act_in == EGNE_ACT_NONE && d.seg[0].ch_off % 8 == 0 && d.seg[0].pix_stride % 8 == 0) {
+        dim3 gridf(nsplit, 1, ((T + 3) / 4 + 1) / 2);         // two tap groups and both output blocks per workgroup
+        hipLaunchKernelGGL(conv_wgrad_wide_kernel<true>, gridf, dim3(256), 0, st, d, (const egne_bf16*)gz, (long long)gzs, gzo, nsplit, (float*)ws);
+      } else if (bfm && fold_on && d.nseg == 1 && d.seg[0].Cp == 8 && d.Ktot == 8 && d.ngroups == 1 && T >= 4) {
+        dim3 gridf(nsplit, d.CoutP / 32, (T + 3) / 4);
+        hipLaunchKernelGGL((conv_wgrad_kernel<TS, true, true>), gridf, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
+      } else if (bfm && d.ngroups == 1 && d.CoutP >= 128 && gzs % 8 == 0 && gzo % 8 == 0 && ((uintptr_t)gz & 15) == 0 && [&] {
+                   for (int s2 = 0; s2 < d.nseg; ++s2) {
+                     const egne_seg& q = d.seg[s2];
+                     if (q.scale || q.act_in != EGNE_ACT_NONE || q.ch_off % 8 || q.pix_stride % 8 || q.Cp % 8) return false;
+                   }
+                   return true;
+                 }()) {
+        // wide form: four output blocks per workgroup (the strided / reflect-padded convolutions of the StyleEncoder and their kin)
+        dim3 gridw(nsplit, (d.CoutP + 127) / 128, per_tap * T);
+        hipLaunchKernelGGL(conv_wgrad_wide_kernel<false>, gridw, dim3(256), 0, st, d, (const egne_bf16*)gz, (long long)gzs, gzo, nsplit, (float*)ws);
+      } else if (bfm) hipLaunchKernelGGL((conv_wgrad_kernel<TS, true>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
       else hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);
     } else {
       hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), grid, dim3(256), 0, st, d, gz, (long long)gzs, gzo, nsplit, (float*)ws);

@@ -79,9 +79,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // MFMAs of 32 cycles per 32-channel K step and 32x32 block instead of sixteen of 64.  This is what the layers of a bf16-storage
 // training plan run on that no specialised kernel takes: the StyleEncoder of the AdaIN configuration (reflect-padded 7x7, 4x4 /
 // stride 2; RITnet_v2.py:91-107) and the data gradients of those layers, the regression head, multi-slice 1x1 leftovers.
-template <int WM, int WN, bool GROUPED, typename TS, bool BFM = false>
+// FOLD (one slice of 8 padded channels, one group): four TAPS share a 32-channel K step -- column group col4 >> 1 of the staged row is
+// tap 4 s + (col4 >> 1), its half col4 & 1 the channels 0-3 / 4-7 -- so that a k x k convolution on <= 8 input channels takes
+// ceil(k k / 4) staging rounds instead of k k rounds that are three quarters zeros (the StyleEncoder's reflect-padded 7x7 on the
+// three softmax channels, RITnet_v2.py:95: 13 rounds instead of 49).
+template <int WM, int WN, bool GROUPED, typename TS, bool BFM = false, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p) {
   static_assert(!BFM || (sizeof(TS) == 2 && !GROUPED), "bf16 MFMA form: bf16 tensors, one group");
+  static_assert(!FOLD || !GROUPED, "folded taps: one group");
   constexpr int ES = sizeof(TS);          // bytes per activation element (weights, bias and affine tables are fp32 always)
   constexpr int LDHB = 40;                // BFM: LDS row pitch in halfs (80 B: conflict-free ds_read_b128 over 32 rows)
   constexpr int BM = 128 * WM, BN = 32 * WN;
@@ -156,9 +161,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   // affine / activation, zeroes the padding and writes LDS.
   unsigned okmask = 0;       // bit i: row i of the staged step is inside the image
   int st_seg = 0, st_c = 0;  // slice / first channel of the staged step (for the deferred affine)
+  int fold_step = 0;         // FOLD: the step being loaded (= tap group)
   auto load_step = [&](const KState& s) {
     const egne_seg sg = p.seg[s.seg];
     const int dil = p.dil[s.g];
+    if constexpr (FOLD) {
+      const int tap = 4 * fold_step + (col4 >> 1), c = (col4 & 1) * 4;
+      const bool tok = tap < T;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+      okmask = 0;
+      st_seg = 0; st_c = c;
+      const long long left = ((long long)p.B - b0) * frame_px * sg.pix_stride * ES;
+      const __amdgpu_buffer_rsrc_t rin = make_rsrc((const TS*)sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+                                                   (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+      const int ps4 = (int)sg.pix_stride * ES, coff = (sg.ch_off + c) * ES;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int iy = (pyx[i] >> 16) + dy, ix = (pyx[i] & 0xffff) + dx;
+        bool ok = tok && pb[i] >= 0;
+        if (p.pad_mode == 1) {
+          iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        }
+        const int q = (pb[i] - b0) * frame_px + iy * p.W + ix;
+        ra[i] = load_raw4<TS>(rin, ok ? q * ps4 + coff : (int)OOB, 0);
+        okmask |= (ok ? 1u : 0u) << i;
+      }
+      // weights [tap][CoutP][8]: row n of the B tile holds (tap, channel half) at column group col4
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, tok ? ((tap * p.CoutP + n0 + rbase + 32 * j) * 8 + c) * 4 : (int)OOB, 0, 0);
+      return;
+    }
     const int ky = s.tap / p.kw, kx = s.tap - ky * p.kw;
     const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
     const int c = s.c0 + col4 * 4;
@@ -253,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
   // total number of K steps
   int steps_per_group = 0;
   for (int s = 0; s < p.nseg; ++s) steps_per_group += ((p.seg[s].Cp + KC - 1) / KC) * T;
-  const int nsteps = steps_per_group * p.ngroups;
+  const int nsteps = FOLD ? (T + 3) / 4 : steps_per_group * p.ngroups;
 
   KState cur = {0, 0, 0, 0, 0};
   load_step(cur);
@@ -269,10 +306,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p)
     const bool more = step + 1 < nsteps;
     if (more) {
       if (GROUPED && nxt.g != cur.g) make_masks(nxt.g);
+      fold_step = step + 1;
       load_step(nxt);
     }
 
-    int rem = p.seg[cur.seg].Cp - cur.c0;
+    int rem = FOLD ? KC : p.seg[cur.seg].Cp - cur.c0;
     const int nk8 = rem >= KC ? KC / 8 : (rem >> 3);
     if constexpr (BFM) {
       // lane (li, lh) supplies channels 16 s + 8 lh .. + 7 of its row to both operands; columns past the slice were staged as zeros
@@ -474,7 +512,11 @@ int launch(const egne_conv_desc& d, hipStream_t st) {
   if (d.dtype == 1) {       // bf16 activation tensors (training plans); the fused MSBlock form belongs to the frozen fp32 network
     if (d.ngroups > 1) return egne::fail(EGNE_ERR_ARG, "conv: grouped launches take fp32 tensors only");
     static const bool bfm = [] { const char* e = getenv("EGNE_IGEMM_BF16_MFMA"); return !e || e[0] != '0'; }();
-    if (bfm) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16, true>), grid, dim3(256), 0, st, d);
+    static const bool fold_on = [] { const char* e = getenv("EGNE_IGEMM_FOLD"); return !e || e[0] != '0'; }();
+    // one slice of 8 padded channels and at least four taps: four taps per K step
+    const bool fold = fold_on && d.nseg == 1 && d.seg[0].Cp == 8 && !d.seg[0].scale && d.kh * d.kw >= 4 && d.Ktot == 8;
+    if (bfm && fold) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16, true, true>), grid, dim3(256), 0, st, d);
+    else if (bfm) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16, true>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16>), grid, dim3(256), 0, st, d);
   } else if (d.ngroups > 1)
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, true, float>), grid, dim3(256), 0, st, d);

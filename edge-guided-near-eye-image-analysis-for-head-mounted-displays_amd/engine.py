@@ -70,6 +70,7 @@ HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 
 HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
+BF16_NARROW = os.environ.get("EGNE_BF16_NARROW", "1") != "0"       # bf16-storage plans: k x k convolutions onto <= 8 channels on the LDS-halo kernel (conv_narrow_bf16.hip)
 BF16_FAST3X3 = os.environ.get("EGNE_BF16_FAST3X3", "1") != "0"     # bf16-storage plans: 3x3 convolutions and their data gradients on bf16 MFMAs (0: exact-fp32 implicit GEMM)
 
 
@@ -1116,6 +1117,9 @@ class Plan:
             self._add(self.L.egne_conv3x3_bf16_fwd, (C.byref(d), layer.bfrag.data_ptr()), name, flops=flops, kind="conv_bf16:3x3")
         elif fast1:
             self._add(self.L.egne_conv1x1_bf16_fwd, (C.byref(d), layer.b1frag.data_ptr()), name, flops=flops, kind="conv_bf16:1x1")
+        elif BF16_NARROW and int(self.L.egne_conv_narrow_bf16_supported(C.byref(d))):
+            # k x k onto <= 8 channels (the data gradient of the StyleEncoder's 7x7): LDS-halo kernel instead of 98 implicit-GEMM steps
+            self._add(self.L.egne_conv_narrow_bf16_fwd, (C.byref(d),), name, flops=flops, kind="conv_bf16:narrow")
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
         if stats:

@@ -635,6 +635,16 @@ int egne_pack_conv_weight_bf16frag(const float* w_oihw, int Cout, int Cin, int k
 int egne_conv3x3_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
 /*
+ * k x k (k = 3, 5, 7) / stride 1 / zero-padded convolution with a NARROW output (Cout_store <= 8) over ONE bf16 slice of 32 or 64
+ * channels, LDS-resident halo, v_mfma_f32_16x16x32_bf16 (egne_conv_desc.dtype must be 1; d.w = the fp32 flat pack
+ * [tap][CoutP][Ktot] of egne_pack_conv_weight, rounded to bf16 inside).  Replaces egne_conv2d_fwd for the data gradient of the
+ * StyleEncoder's reflect-padded 7x7 (models/RITnet_v2.py:95 under train.py:285-286: 64 channels back to the 3 softmax channels
+ * over 49 taps), which the implicit GEMM ran at 22 TFLOP/s.  egne_conv_narrow_bf16_supported tells whether a descriptor qualifies.
+ */
+int egne_conv_narrow_bf16_supported(const egne_conv_desc* d);
+int egne_conv_narrow_bf16_fwd(const egne_conv_desc* d, void* stream);
+
+/*
  * 1x1 convolution over up to EGNE_MAXSEG RAW bf16 slices on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, bf16 output): conv21 / conv31
  * of the dense blocks, Transition_down behind its pooling, conv11 / conv21 of the up blocks (models/RITnet_v2.py:38-41,59-61,85-86)
  * and their merged data gradients in training plans with bf16 storage (dtype 1).  Streaming: a lane's operand of a 16-channel
