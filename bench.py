@@ -584,7 +584,7 @@ class Bench:
         net.to(torch.bfloat16 if storage == "bf16" else torch.float32)       # storage of the training plan's activations (models/RITnet_v2.py: DenseNet2D.to)
         net.train()
         parallel.broadcast_state(net)
-        opt = torch.optim.Adam([p for n, p in net.named_parameters() if "dsIdentify" not in n], lr=5e-4)
+        opt = torch.optim.Adam([p for n, p in net.named_parameters() if "dsIdentify" not in n], lr=5e-4, fused=True)     # (as egne_amd/train.py)
 
         def rest(edge):   # train.py:284-287: forward, loss.backward(), (DP) gradient all-reduce, Adam
             opt.zero_grad()          # (train.py:284; PyTorch's default drops the gradient views, the model re-attaches its flat arena with one fill)

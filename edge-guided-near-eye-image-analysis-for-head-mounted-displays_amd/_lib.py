@@ -161,6 +161,7 @@ for _n in BF16_TWINS:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 SIGNATURES.update({
     "egne_pack_conv_weight_bf16frag": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "egne_pack_conv_weight_bf16frag_dgrad": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "egne_conv3x3_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
     "egne_conv_narrow_bf16_supported": (i32, [C.POINTER(ConvDesc)]),
     "egne_conv_narrow_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp]),

@@ -394,7 +394,36 @@ __global__ void pack_weight_bf16frag_k(const float* __restrict__ w, int Cout, in
   }
 }
 
+// the same fragments for the DATA GRADIENT w.r.t. input channels [c0, c0 + cn) of the forward convolution w [Co][Ci][kh][kw]: the
+// ordinary convolution over gz with W'[ci][co][j][i] = w[co][c0 + ci][kh-1-j][kw-1-i], read straight out of the forward weight
+// (the host used to build W' with two flips and a strided copy per layer and step)
+__global__ void pack_weight_bf16frag_dgrad_k(const float* __restrict__ w, int Co, int Ci, int c0, int cn, int T, int CoutP, int Ktot,
+                                             egne_bf16* __restrict__ out) {
+  const long long total = (long long)T * CoutP * Ktot;
+  const int NT = CoutP >> 5;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), nn = (int)((i >> 3) & 31), h = (int)((i >> 8) & 1);
+    long long q = i >> 9;
+    const int nt = (int)(q % NT); q /= NT;
+    const int k16 = (int)(q % (Ktot >> 4));
+    const int t = (int)(q / (Ktot >> 4));
+    const int n = nt * 32 + nn, k = k16 * 16 + h * 8 + j;          // n: input channel of the forward layer, k: its output channel
+    out[i] = (egne_bf16)((n < cn && k < Co) ? w[((long long)k * Ci + c0 + n) * T + (T - 1 - t)] : 0.f);
+  }
+}
+
 }  // namespace
+
+extern "C" int egne_pack_conv_weight_bf16frag_dgrad(const float* w_oihw, int Cout, int Cin, int kh, int kw, int c0, int cn, int CoutP, int Ktot,
+                                                    void* wfrag, void* stream) {
+  EGNE_REQUIRE(w_oihw && wfrag && Cout > 0 && Cin > 0 && c0 >= 0 && cn > 0 && c0 + cn <= Cin && CoutP >= cn && CoutP % 32 == 0 && Ktot >= Cout &&
+               Ktot % 32 == 0, "pack_bf16frag_dgrad: bad sizes Cout %d Cin %d c0 %d cn %d CoutP %d Ktot %d", Cout, Cin, c0, cn, CoutP, Ktot);
+  long long total = (long long)kh * kw * CoutP * Ktot, g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pack_weight_bf16frag_dgrad_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, c0, cn, kh * kw,
+                     CoutP, Ktot, (egne_bf16*)wfrag);
+  return egne::check_launch("egne_pack_conv_weight_bf16frag_dgrad");
+}
 
 extern "C" int egne_pack_conv_weight_bf16frag(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot, void* wfrag,
                                               void* stream) {

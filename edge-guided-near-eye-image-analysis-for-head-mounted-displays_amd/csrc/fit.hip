@@ -125,7 +125,11 @@ __device__ __forceinline__ unsigned row_pop(const unsigned* rowbits, int x0, int
   return n;
 }
 
-template <int FIT_PAIRS, int ROWW>
+// LOCAL: the waves of a search meet through LDS flags of their own instead of the workgroup barrier, so that MANY searches can share a
+// workgroup without running in lock step (eight searches per workgroup: 16 of the chip's 256 compute units host the batch's 128
+// searches instead of 64 -- a compute unit that hosts a search wave cannot take a workgroup of the network's persistent kernels,
+// whose two 256-register waves per SIMD need the whole register file, and that workgroup's share of the tiles then waits).
+template <int FIT_PAIRS, int ROWW, bool LOCAL = false>
 __global__ __launch_bounds__(128 * FIT_PAIRS * ROWW) void ellipse_fit_k(const long long* __restrict__ mask, int nframes, const int* __restrict__ frame_of,
                                                                        const int* __restrict__ cls, int n, int H, int W,
                                                                        const float* __restrict__ xs, const float* __restrict__ ys,
@@ -139,10 +143,13 @@ __global__ __launch_bounds__(128 * FIT_PAIRS * ROWW) void ellipse_fit_k(const lo
   float* lxs = (float*)fit_lds;
   float* lys = lxs + W;
   volatile unsigned* swap = fit_lds + W + H + pair * SWAP;
-  unsigned* bits = fit_lds + W + H + FIT_PAIRS * SWAP + pair * nwords;
+  volatile unsigned* flags = fit_lds + W + H + FIT_PAIRS * SWAP + pair * NW;       // LOCAL: exchange count of every wave of the search
+  unsigned* bits = fit_lds + W + H + FIT_PAIRS * (SWAP + NW) + pair * nwords;
   for (int i = threadIdx.x; i < W; i += blockDim.x) lxs[i] = xs[i];
   for (int i = threadIdx.x; i < H; i += blockDim.x) lys[i] = ys[i];
+  if (threadIdx.x < FIT_PAIRS * NW) fit_lds[W + H + FIT_PAIRS * SWAP + threadIdx.x] = 0u;
   __syncthreads();
+  unsigned seq = 0;
   const int e = blockIdx.x * FIT_PAIRS + pair;
   if (e >= n) return;                     // (whole searches: all waves of a search take every barrier below together)
   const int fr = frame_of[e];
@@ -167,7 +174,17 @@ __global__ __launch_bounds__(128 * FIT_PAIRS * ROWW) void ellipse_fit_k(const lo
   auto exchange = [&](unsigned m0, unsigned m1, unsigned* s0, unsigned* s1) {
     volatile unsigned* sw = swap + parity * NW * 2;
     if (lane == 0) { sw[wv * 2] = m0; sw[wv * 2 + 1] = m1; }
-    __syncthreads();
+    if constexpr (LOCAL) {
+      // release: this wave's words (and, the first time, its rows of the packed mask) before its count; then wait for the counts of
+      // all waves of THIS search.  The areas are double buffered and a wave can run at most one exchange ahead of its partners.
+      ++seq;
+      __threadfence_block();
+      if (lane == 0) flags[wv] = seq;
+      if (lane < NW) { while (flags[lane] < seq) __builtin_amdgcn_s_sleep(2); }
+      __threadfence_block();
+    } else {
+      __syncthreads();
+    }
     s0[0] = s0[1] = s1[0] = s1[1] = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { s0[i / ROWW] += sw[i * 2]; s1[i / ROWW] += sw[i * 2 + 1]; }
@@ -368,11 +385,21 @@ extern "C" int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t*
   EGNE_REQUIRE(2 * per_search + fixed <= 64 * 1024, "ellipse_fit: %dx%d masks do not fit LDS", H, W);
   hipStream_t st = (hipStream_t)stream;
   const long long* mk = (const long long*)mask;
-  if (n >= 16) {           // a batch: two searches of two waves per workgroup
-    const size_t lds = fixed + 2 * ((size_t)H * ((W + 31) / 32) + 8) * 4;
+  static const int dense = [] { const char* e = getenv("EGNE_FIT_DENSE"); return e ? atoi(e) : 4; }();      // searches per workgroup of a large batch (2: round 3's form; 4 measured best: 32.3 vs 32.5 ms per step with the fit stage, 8 spills at 128 registers)
+  if (n >= 64 && dense == 8 && 8 * per_search + fixed <= 150 * 1024) {
+    // a large batch: EIGHT searches of two waves per workgroup, pair-local synchronisation (see LOCAL above)
+    const size_t lds = fixed + 8 * ((size_t)H * ((W + 31) / 32) + 8 + 2) * 4;
+    static bool once = hipFuncSetAttribute((const void*)ellipse_fit_k<8, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+    if (!once) return egne::fail(EGNE_ERR_LAUNCH, "ellipse_fit: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL((ellipse_fit_k<8, 1, true>), dim3((unsigned)((n + 7) / 8)), dim3(1024), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
+  } else if (n >= 64 && dense == 4) {
+    const size_t lds = fixed + 4 * ((size_t)H * ((W + 31) / 32) + 8 + 2) * 4;
+    hipLaunchKernelGGL((ellipse_fit_k<4, 1, true>), dim3((unsigned)((n + 3) / 4)), dim3(512), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
+  } else if (n >= 16) {           // a batch: two searches of two waves per workgroup
+    const size_t lds = fixed + 2 * ((size_t)H * ((W + 31) / 32) + 8 + 2) * 4;
     hipLaunchKernelGGL((ellipse_fit_k<2, 1>), dim3((unsigned)((n + 1) / 2)), dim3(256), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
   } else {                 // one or two frames: a workgroup of eight waves per search (the rows of an evaluation in one pass)
-    const size_t lds = fixed + ((size_t)H * ((W + 31) / 32) + 32) * 4;
+    const size_t lds = fixed + ((size_t)H * ((W + 31) / 32) + 32 + 8) * 4;
     hipLaunchKernelGGL((ellipse_fit_k<1, 4>), dim3((unsigned)n), dim3(512), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
   }
   return egne::check_launch("egne_ellipse_fit");

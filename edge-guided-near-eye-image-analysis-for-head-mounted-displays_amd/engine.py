@@ -70,6 +70,7 @@ HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 
 HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
+BF16_DGRAD_PACK = os.environ.get("EGNE_BF16_DGRAD_PACK", "1") != "0"   # bf16-storage plans: data-gradient fragments packed straight from the forward weight
 BF16_NARROW = os.environ.get("EGNE_BF16_NARROW", "1") != "0"       # bf16-storage plans: k x k convolutions onto <= 8 channels on the LDS-halo kernel (conv_narrow_bf16.hip)
 BF16_FAST3X3 = os.environ.get("EGNE_BF16_FAST3X3", "1") != "0"     # bf16-storage plans: 3x3 convolutions and their data gradients on bf16 MFMAs (0: exact-fp32 implicit GEMM)
 
@@ -523,6 +524,45 @@ class SplitDgradLayer(ConvLayer):
     def refresh(self):
         w = self.fwd.weights[0].detach()
         self.derived.copy_(w[:, self.c0:self.c0 + self.cn].flip(2).flip(3).transpose(0, 1))     # (copy_ bumps the version: re-packed)
+
+
+class BfDgradLayer(ConvLayer):
+    """Data gradient of a stride-1 zero-padded k x k convolution w.r.t. input slice ``idx`` for bf16-storage plans: the ordinary
+    convolution over gz that conv3x3_bf16.hip runs, its bf16 fragments packed STRAIGHT from the forward weight
+    (egne_pack_conv_weight_bf16frag_dgrad: flip and transpose are index arithmetic of the pack kernel) -- one launch per layer and
+    step where SplitDgradLayer cost two flips, a strided copy and the pack."""
+
+    def __init__(self, fwd, idx):
+        assert fwd.stride == 1 and fwd.pad_mode == 0 and fwd.G == 1
+        C_, Cp_ = fwd.in_layout[idx]
+        self.fwd, self.c0, self.cn = fwd, sum(c for c, _ in fwd.in_layout[:idx]), C_
+        w = fwd.weights[0]
+        self.weights, self.biases = [w], None
+        self.in_layout = [(fwd.Cout, fwd.Cout_store)]
+        self.Cout, self.Cin = C_, fwd.Cout
+        self.kh, self.kw = fwd.kh, fwd.kw
+        self.stride, self.pad_mode, self.act, self.dils = 1, 0, ACT_NONE, fwd.dils
+        self.pad = (fwd.kh - 1 - fwd.pad[0], fwd.kw - 1 - fwd.pad[1])
+        self.Ktot, self.CoutP, self.Cout_store, self.G = fwd.Cout_store, pad32(C_), Cp_, 1
+        self.bp = self.bfrag = self.post = None
+        self.need_bfrag = self.need_flat = False
+        self.split = self.split1 = False
+        self._versions = None
+
+    def ensure_packed(self, dev):
+        w = self.weights[0]
+        vers = (w._version, w.data_ptr())
+        if self.bfrag is not None and vers == self._versions:
+            return False
+        assert self.need_bfrag, "BfDgradLayer serves the bf16 3x3 kernel only"
+        kts = pad32(self.Ktot)
+        if self.bfrag is None:
+            self.bfrag = torch.empty(self.kh * self.kw * self.CoutP * kts, dtype=torch.bfloat16, device=dev)
+        wd = w.detach().contiguous()
+        _lib.check(_lib.lib().egne_pack_conv_weight_bf16frag_dgrad(wd.data_ptr(), self.fwd.Cout, self.fwd.Cin, self.kh, self.kw, self.c0, self.cn,
+                                                                   self.CoutP, kts, self.bfrag.data_ptr(), _lib.stream_ptr()), "pack_bf16frag_dgrad")
+        self._versions = vers
+        return True
 
 
 class Plan:
@@ -1051,7 +1091,7 @@ class Plan:
         one = len(pieces) == 1 and layer.stride == 1 and layer.pad_mode == 0 and layer.dils[0] == 1 and layer.kh == 3 and layer.kw == 3 \
             and layer.pad == (1, 1)
         smallcin = (one and SMALLCIN_ENABLED and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None
-                    and not isinstance(layer, (DgradLayer, SplitDgradLayer)) and layer.post is None)
+                    and not isinstance(layer, (DgradLayer, SplitDgradLayer, BfDgradLayer)) and layer.post is None)
         fast3 = (one and not smallcin and BF16_FAST3X3 and pieces[0].Cp % 8 == 0 and pieces[0].off % 8 == 0 and pieces[0].stride % 8 == 0
                  and layer.CoutP <= 256 and min(layer.Cout_store, dst.Cp) % 4 == 0 and min(layer.Cout_store, dst.Cp) >= 8
                  and H * W * max(pieces[0].stride, dst.stride) < 2 ** 30
@@ -1449,8 +1489,10 @@ class Plan:
                 dl.stale_scale_ok = True
                 self.pre.append(dl.guard)
                 bw._dyn_hint = gz_max
+            elif bf_dgrad and BF16_DGRAD_PACK and pad32(pc.C) <= 256 and gy.stride % 8 == 0 and H * W * max(gy.stride, pc.stride) < 2 ** 30:
+                dl = BfDgradLayer(layer, i)     # an ordinary 3x3 over gz with flipped / transposed weights, packed straight from the forward weight
             elif bf_dgrad:
-                dl = SplitDgradLayer(layer, i, self.device)     # an ordinary 3x3 over gz with flipped / transposed weights: the bf16 kernel serves it
+                dl = SplitDgradLayer(layer, i, self.device)     # (the same through a derived tensor: two flips and a strided copy per step)
                 self.pre.append(dl.guard)
             else:
                 dl = DgradLayer(layer, i)

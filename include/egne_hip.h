@@ -632,6 +632,10 @@ int egne_conf_loss_bwd_bf16(const void* pred, int ld, const int64_t* gt, int B, 
  */
 int egne_pack_conv_weight_bf16frag(const float* w_oihw, int Cout, int Cin, int kh, int kw, int CoutP, int Ktot, void* wfrag,
                                    void* stream);
+/* ... and the fragments of its DATA GRADIENT w.r.t. input channels [c0, c0 + cn) of the forward weight w_oihw [Cout][Cin][kh][kw]: an
+ * ordinary convolution over gz with W'[ci][co][j][i] = w[co][c0 + ci][kh-1-j][kw-1-i] (CoutP >= cn rows, Ktot >= Cout columns). */
+int egne_pack_conv_weight_bf16frag_dgrad(const float* w_oihw, int Cout, int Cin, int kh, int kw, int c0, int cn, int CoutP, int Ktot,
+                                         void* wfrag, void* stream);
 int egne_conv3x3_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
 /*
