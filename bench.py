@@ -137,7 +137,9 @@ def cpu_thread_sweep(setting, bd_sd, net_sd, budget_s=6.0):
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     b = synth.make_batch(2, seed=1234)
     rows = []
-    for n in [t for t in (8, 16, 32, 64, 128, 256) if t < ncores] + [ncores]:
+    # (more threads than the box's CPU share only over-subscribe it: measured 6.1 frames/s at 8, 6.0 at 16, 4.0 at 32, 1.7 at 64, 0.8 at 128 threads and
+    #  no result in seven minutes at 256 on a 16-core share of an EPYC 9575F -- the sweep stops at 64)
+    for n in [t for t in (4, 8, 16, 32, 64) if t <= ncores]:
         torch.set_num_threads(n)
         keep = {}
 
@@ -166,9 +168,10 @@ def cpu_baseline(setting, bd_sd, net_sd, batches=(2, 8), budget_s=7.0, parity=No
     import egne_amd  # noqa: F401
     from egne_amd import synth
     from oracle import bdcn as obdcn, esfnet as oesf, fit as ofit
-    # the box exposes far more logical cores than torch's intra-op pool uses well (over-subscription was pathologically slow)
+    # the box exposes 256 logical cores but a one-GPU lease has a 16-core share: the thread sweep (profiles/r04_cpu_thread_sweep.json:
+    # 6.1 frames/s at 8 threads, 6.0 at 16, 4.0 at 32, 1.7 at 64, 0.8 at 128) puts the fair baseline at <= 16 threads
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(threads if threads > 0 else min(ncores, 32))
+    torch.set_num_threads(threads if threads > 0 else min(ncores, 16))
     out = {"kind": "port", "unit": "eye-frames/s", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(),
            "affinity_cores": ncores, "cpu_model": _cpu_model(), "torch_threads": torch.get_num_threads(),
            "protocol": "BASELINE.md section 3: 2 warm-ups, 2-5 timed iterations per part (~%.0f s budget each), median and min" % budget_s,
