@@ -243,6 +243,54 @@ def test_weight_and_data_gradients_bf16_storage(G, kind, Cin, Cout, H, W):
         assert ex < EPS, "data gradient: relative error %.2e" % ex
 
 
+@pytest.mark.parametrize("case,Cin,Cout,k,stride,P,H,W", [("7x7 on 3 channels (folded taps)", 3, 64, 7, 1, 3, 45, 70), ("4x4 stride 2", 64, 128, 4, 2, 1, 48, 64),
+                                                          ("4x4 stride 2, wide", 128, 256, 4, 2, 1, 30, 40)])
+def test_style_encoder_layers_bf16_storage(G, case, Cin, Cout, k, stride, P, H, W):
+    """The reflect-padded blocks of the StyleEncoder (RITnet_v2.py:91-107, utils.py:1051-1149) as a bf16-storage training plan runs
+    them, forward and backward, against float64 autograd on the bf16-representable tensors: the generic implicit GEMM on bf16 MFMAs
+    (four taps per K step for the 8-channel slice), the weight gradient in its wide forms (four output blocks -- or two tap groups
+    x both blocks -- per workgroup), the data gradient w.r.t. the PADDED input (engine.TransposedLayer; for the 7x7 the LDS-halo
+    kernel conv_narrow_bf16.hip) folded back by egne_reflect_pad_bwd."""
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    B = 2
+    x = _q(torch.rand(B, Cin, H, W, generator=G))                       # (softmax-like: non-negative)
+    w, b = _rand(G, Cout, Cin, k, k) / (k * Cin ** 0.5), _rand(G, Cout) * 0.1
+    pl = _plan()
+    pl.train = True
+    pieces = _pieces(pl, [x], B, H, W)
+    wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    wp.grad, bp.grad = torch.zeros_like(wp), torch.zeros_like(bp)
+    layer = ConvLayer([wp], [bp], [(p.C, p.Cp) for p in pieces], stride=stride, pad=(P, P), act=1, pad_mode=1)
+    Ho, Wo = layer.out_hw(H, W)
+    gy = _q(_rand(G, B, Cout, Ho, Wo) * 1e-3)
+    out = pl.buf(B, Ho, Wo, pad8(Cout))
+    pl.conv(layer, pieces, Piece(out, 0, Cout), B, H, W, name="enc")
+    bw = pl.build_backward()
+    pl.run()
+    pl.zero_grads()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    kinds = [m[0] for m in bw.meta]
+    xd = x.double().requires_grad_(True)
+    wd, bd = _q(w).double().requires_grad_(True), b.double().requires_grad_(True)
+    z = F.conv2d(F.pad(xd, (P, P, P, P), mode="reflect"), wd, bd, stride=stride)
+    ystored = out.float().cpu()[..., :Cout].permute(0, 3, 1, 2).double()
+    _check(ystored, F.relu(z.detach()), case + ": forward")
+    gzq = _q((gy.double() * (ystored > 0)).float()).double()           # ReLU mask from the STORED output, gz rounded to bf16 as the kernels read it
+    z.backward(gzq)
+    e = (wp.grad.double().cpu() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+    eb = (bp.grad.double().cpu() - gzq.sum((0, 2, 3))).abs().max().item() / gzq.sum((0, 2, 3)).abs().max().item()
+    gx = pl.gbuf(pieces[0].buf).float().cpu()[..., :Cin].permute(0, 3, 1, 2).double()
+    ex = (gx - xd.grad).abs().max().item() / xd.grad.abs().max().item()
+    print("%s: weight gradient %.2e, bias gradient %.2e, data gradient %.2e (relative to the largest element); backward kernels %s"
+          % (case, e, eb, ex, sorted(set(kinds))))
+    assert e < 3e-3 and eb < 1e-4 and ex < 2 * EPS
+    assert "conv_bf16:wgrad" in kinds
+    if k == 7:
+        assert "conv_bf16:narrow" in kinds, kinds
+
+
 def test_elementwise_twins_match_the_fp32_kernels(G):
     """Every bf16 twin reads / writes bf16 and computes as its fp32 original: run both on the same bf16-representable data and
     compare (the twin's result may differ by one bf16 rounding of the OUTPUT; statistics and parameter gradients are fp32 on
