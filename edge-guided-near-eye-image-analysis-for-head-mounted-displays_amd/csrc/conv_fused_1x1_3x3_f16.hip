@@ -97,7 +97,11 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
                           const _Float16* __restrict__ f2lo, float a1, float os1, float a2, float os2, int tiles_x, int tiles_y,
                           int ntiles) {
   constexpr int GB = NCH == 1 ? 4 : 2;              // 16-channel groups per producer item (8 / 4 KB of loads per wave)
-  constexpr bool WLDS = NCH == 1;                   // the 1x1's weights in LDS (they fit beside two 32-channel images only)
+  constexpr bool WLDS = NCH == 1;                   // the 1x1's weights in LDS (all of them fit beside two 32-channel images only)
+  constexpr int LG = WLDS ? MAXG : 7;               // 64-channel intermediate: the first LG channel groups' fragments are LDS resident (28 KB is what
+                                                    // two 64-channel images leave), the rest comes from L2 per item.  Each producer wave pulling every
+                                                    // fragment from L2 for every 32-pixel block was 256-384 KB per tile and CU on top of the consumers'
+                                                    // 288 KB and the activations: the launch ran at the CU's L2 port (~30 B/clk), not at the MFMA pipe
   constexpr int HHd = TH + 2, NPX = HHd * HWd, NMT = (NPX + 31) / 32;
   constexpr int IMG = 2 * NCH * NPX * LDH;          // halfs per image: [hi | lo][NCH][NPX][LDH]
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
@@ -136,13 +140,14 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
   // the 1x1's weight fragments live in LDS for the whole launch ([group][tile][hi | lo][lane][8]): read through the LDS
   // queue they never wait behind the producers' prefetched activations (vmcnt retires in order)
   _Float16* lw = (_Float16*)(lbias + 32 * NCH);
-  for (int it = tid; it < (WLDS ? G1 * NCH * 2 * 64 : 0); it += 512) {        // 16-byte items
+  const int GLDS = G1 < LG ? G1 : LG;
+  for (int it = tid; it < GLDS * NCH * 2 * 64; it += 512) {        // 16-byte items
     const int l = it & 63, hl = (it >> 6) & 1, q = it >> 7;      // q = group * NCH + tile
     *(u32x4*)&lw[(long long)it * 8] = *(const u32x4*)((hl ? w1lo : w1hi) + ((long long)q * 64 + l) * 8);
   }
   // UPADD: two tiles of the low-resolution addend, [6 rows][18 columns][32 * NCH] floats each
   constexpr int PROWS = TH / 2 + 2, PCOLS = TW / 2 + 2, PTILE = PROWS * PCOLS * 32 * NCH;
-  float* const lp = (float*)(lw + (WLDS ? G1 * NCH * 2 * 512 : 0));
+  float* const lp = (float*)(lw + GLDS * NCH * 2 * 512);
   __syncthreads();
 
   if constexpr (C1V) if (wave < 4) {
@@ -257,6 +262,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int gg = bi * GB + u;
+        if (gg < LG) continue;                       // LDS resident
         const int wo = gg < G1 ? (gg * NCH * 64 + lane) * 16 : (int)OOB;
 #pragma unroll
         for (int tn = 0; tn < NCH; ++tn) {
@@ -348,15 +354,20 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
       if constexpr (!WLDS) load_w(std::integral_constant<int, (K + 1) % N>{});
       if constexpr (K + DIST < N) issue(tl, true, std::integral_constant<int, K + DIST>{});
       else issue(nx, nx_on, std::integral_constant<int, K + DIST - N>{});
-      if constexpr (GL > 0 && WLDS) {
+      if constexpr (GL > 0) {
         constexpr int NG = bi == NB - 1 ? GL : GB;
+        constexpr int NLDS = (bi * GB + NG <= LG) ? NG : (bi * GB >= LG ? 0 : LG - bi * GB);     // groups of this item read from LDS
         h8 bh[NG][NCH], bl[NG][NCH];
 #pragma unroll
         for (int u = 0; u < NG; ++u)
 #pragma unroll
           for (int tn = 0; tn < NCH; ++tn) {
-            const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
-            bh[u][tn] = *(const h8*)wp; bl[u][tn] = *(const h8*)(wp + 512);
+            if (bi * GB + u < LG) {
+              const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
+              bh[u][tn] = *(const h8*)wp; bl[u][tn] = *(const h8*)(wp + 512);
+            } else if constexpr (!WLDS) {
+              bh[u][tn] = __builtin_bit_cast(h8, wq[K & 1][u][tn][0]); bl[u][tn] = __builtin_bit_cast(h8, wq[K & 1][u][tn][1]);
+            }
           }
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
@@ -369,13 +380,13 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[u][tn], ah, acc[tn], 0, 0, 0);
           }
         }
-        // desired issue order: split of group 0, then each MFMA followed by a third of the next group's split
-        __builtin_amdgcn_sched_group_barrier(0x100, NG * NCH * 2, 0);     // the LDS reads
+        // desired issue order: split of group 0, then each MFMA followed by a share of the next group's split
+        if constexpr (NLDS > 0) __builtin_amdgcn_sched_group_barrier(0x100, NLDS * NCH * 2, 0);     // the LDS reads
         __builtin_amdgcn_sched_group_barrier(0x002, 30, 0);
 #pragma unroll
         for (int m = 0; m < NG * NCH * 3; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, NCH == 1 ? 10 : 5, 0);
         }
       } else {
 #pragma unroll
@@ -385,11 +396,11 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
           split8(xa[BUF][u], xb[BUF][u], a1, ah, al);
 #pragma unroll
           for (int tn = 0; tn < NCH; ++tn) {
-            h8 bh, bl;
-            if constexpr (WLDS) {
+            h8 bh = {}, bl = {};
+            if (bi * GB + u < LG) {
               const _Float16* wp = lw + (((bi * GB + u) * NCH + tn) * 128 + lane) * 8;
               bh = *(const h8*)wp; bl = *(const h8*)(wp + 512);
-            } else {
+            } else if constexpr (!WLDS) {
               bh = __builtin_bit_cast(h8, wq[K & 1][u][tn][0]); bl = __builtin_bit_cast(h8, wq[K & 1][u][tn][1]);
             }
             acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[tn], 0, 0, 0);
@@ -658,7 +669,7 @@ int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const Group
                  int G1, const _Float16* f2hi, const _Float16* f2lo, float a1, float os1, float a2, float os2, hipStream_t st) {
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
-  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : 0) +
+  const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : (size_t)(G1 < 7 ? G1 : 7) * 4096) +
                      (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * 32 * NCH * sizeof(float) : 0) +
                      (C1V ? ((size_t)2 * (TH + 4) * (TW + 4) + 32 * 12) * sizeof(float) : 0);
   static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL, C1V>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -766,6 +777,8 @@ extern "C" int egne_conv1x1_3x3_fused_f16_fwd(const egne_conv_desc* dp1, const e
   (nb2 == 2 ? launch_fused<2, WN_, 4, 2, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
             : nb2 == 4 ? launch_fused<2, WN_, 4, 4, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st) \
                        : launch_fused<2, WN_, 4, 6, false, false, U_>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st))
+  if (uni && d2.CoutP == 64 && G == 7) return launch_fused<2, 2, 4, 4, false, false, true, 1>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);    // ESF-Net block 1:
+  if (uni && d2.CoutP == 64 && G == 11) return launch_fused<2, 2, 4, 6, false, false, true, 1>(d1, d2, gt, a, b, G, c, e, a1, os1, a2, os2, st);   // straight-line items
   if (uni && d2.CoutP == 64) return EGNE_FUSED2(2, true);     // dense block with 64-channel intermediates (one buffer)
   return d2.CoutP == 32 ? EGNE_FUSED2(1, false) : EGNE_FUSED2(2, false);
 #undef EGNE_FUSED2

@@ -8,9 +8,9 @@ import egne_amd
 from egne_amd import engine, _lib
 from egne_amd.engine import ConvLayer, Piece, Plan, pad8
 DEV = torch.device('cuda:0')
-B, H, W = 64, 240, 320
+B, H, W = [int(v) for v in os.environ.get('BHW', '64,240,320').split(',')]
 chans = [int(c) for c in (sys.argv[1].split(',') if len(sys.argv) > 1 else "32,32,32".split(','))]
-C1 = C2 = 32
+C1 = C2 = int(os.environ.get('C12', '32'))
 pl = Plan(DEV)
 pieces = []
 uni = os.environ.get("UNI", "1") == "1"
