@@ -154,21 +154,22 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial(T* __restrict__ g, l
   }
 }
 
-// 256 threads = 32 channels x 8 interleaved chunk ranges, summed through LDS in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void reduce_chunks_k(const double* __restrict__ ws, int stride, int n, int nchunk, float* __restrict__ out,
-                                                       int accumulate) {
-  __shared__ double part[8][32];
+// 1024 threads = 32 channels x 32 interleaved chunk ranges, summed through LDS in a fixed order (deterministic).  (8 ranges were 128
+// dependent loads per thread for the 1024 chunks of a full-resolution tensor: 27 us per call, 54 calls per training step.)
+__global__ __launch_bounds__(1024) void reduce_chunks_k(const double* __restrict__ ws, int stride, int n, int nchunk, float* __restrict__ out,
+                                                        int accumulate) {
+  __shared__ double part[32][32];
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + c;
   double s = 0;
   if (i < n)
-    for (int k = q; k < nchunk; k += 8) s += ws[(long long)k * stride + i];
+    for (int k = q; k < nchunk; k += 32) s += ws[(long long)k * stride + i];
   part[q][c] = s;
   __syncthreads();
   if (q == 0 && i < n) {
     double t = 0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += part[r][c];
+    for (int r = 0; r < 32; ++r) t += part[r][c];
     out[i] = accumulate ? out[i] + (float)t : (float)t;
   }
 }
@@ -240,18 +241,27 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const T* __restrict__ x,
   }
 }
 
-__global__ void norm_bwd_final(const double* __restrict__ ws, int Cp, int Bn, int nchunk, float* __restrict__ sums,
-                               float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Bn * Cp) return;
-  const int n = i / Cp, c = i - n * Cp;
+// one block per (32 channels, n), 32 partial-sum streams per channel, fixed combination order (see norm_stats_final)
+__global__ __launch_bounds__(1024) void norm_bwd_final(const double* __restrict__ ws, int Cp, int Bn, int nchunk, float* __restrict__ sums,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int n = blockIdx.y, cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, kg = threadIdx.x >> 5;
   double a = 0, b = 0;
-  for (int k = 0; k < nchunk; ++k) {
-    const double* w = ws + (((long long)n * nchunk + k) * Cp + c) * 2;
-    a += w[0]; b += w[1];
+  if (c < Cp) {
+    const double* w = ws + ((long long)n * nchunk * Cp + c) * 2;
+    for (int k = kg; k < nchunk; k += 32) {
+      const double2 v = *(const double2*)(w + (long long)k * Cp * 2);
+      a += v.x; b += v.y;
+    }
   }
-  sums[2 * i] = (float)a; sums[2 * i + 1] = (float)b;
-  if (dgamma && c < C) { dgamma[c] += (float)b; dbeta[c] += (float)a; }   // Bn == 1 for BatchNorm
+  __shared__ double sh[32][32][2];
+  sh[kg][cl][0] = a; sh[kg][cl][1] = b;
+  __syncthreads();
+  if (kg == 0 && c < Cp) {
+    for (int g = 1; g < 32; ++g) { a += sh[g][cl][0]; b += sh[g][cl][1]; }
+    const int i = n * Cp + c;
+    sums[2 * i] = (float)a; sums[2 * i + 1] = (float)b;
+    if (dgamma && c < C) { dgamma[c] += (float)b; dbeta[c] += (float)a; }   // Bn == 1 for BatchNorm
+  }
 }
 
 template <typename T>
@@ -995,7 +1005,7 @@ static int act_bwd_bias_impl(T* g, int64_t gs, int go, const T* y, int64_t ys, i
   hipLaunchKernelGGL(act_bwd_bias_partial<T>, dim3(nchunk, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, y,
                      (long long)ys, yo, act, Cp, (long long)npix, nchunk, (double*)ws, (unsigned*)absmax_bits);
   if (dbias)
-    hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 31) / 32), dim3(256), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
+    hipLaunchKernelGGL(reduce_chunks_k, dim3((Cp + 31) / 32), dim3(1024), 0, st, (const double*)ws, Cp, C < Cp ? C : Cp,
                        nchunk, dbias, accumulate);
   return egne::check_launch("egne_act_bwd_bias");
 }
@@ -1026,7 +1036,7 @@ static int norm_bwd_impl(const T* x, int64_t xs, int xo, const float* scale, con
                          int C, void* ws, void* stream, int poolW, int accumulate) {
   EGNE_REQUIRE(slice_ok(x, xs, xo, Cp) && slice_ok(gy, gs, go, Cp) && slice_ok(gx, gxs, gxo, Cp), "norm_bwd: bad slices");
   EGNE_REQUIRE(vec_ok<T>(xs, xo, Cp) && vec_ok<T>(gs, go, Cp) && vec_ok<T>(gxs, gxo, Cp), "norm_bwd: slices must be 16-byte vectors (8 bf16 channels)");
-  EGNE_REQUIRE(scale && shift && sums && ws && B > 0 && HW > 0, "norm_bwd: null pointer");
+  EGNE_REQUIRE(scale && shift && sums && ws && ((uintptr_t)ws & 15) == 0 && B > 0 && HW > 0, "norm_bwd: null pointer (ws must be 16-byte aligned)");
   EGNE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || !per_sample), "norm_bwd: dgamma/dbeta only for batch statistics");
   const int Bn = per_sample ? B : 1;
   const long long npix = per_sample ? HW : (long long)B * HW;
@@ -1034,7 +1044,7 @@ static int norm_bwd_impl(const T* x, int64_t xs, int xo, const float* scale, con
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(norm_bwd_partial<T>, dim3(nchunk, (Cp + 31) / 32, Bn), dim3(256), 0, st, x, (long long)xs, xo, scale, shift,
                      gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws, poolW);
-  hipLaunchKernelGGL(norm_bwd_final, dim3((Bn * Cp + 255) / 256), dim3(256), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
+  hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, Bn), dim3(1024), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
                      dgamma, dbeta, C);
   hipLaunchKernelGGL(norm_bwd_apply<T>, dim3(grid_for((long long)Bn * npix * (Cp / egne_vt<T>::N))), dim3(256), 0, st, x, (long long)xs, xo,
                      scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,

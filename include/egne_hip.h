@@ -283,7 +283,7 @@ int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int Cp, int64_t 
  * ([B][Cp]).  F.instance_norm at models/RITnet_v2.py:40,57 (eps 1e-5, biased variance).  With
  * per_sample=0 the statistics run over (B,H,W): training-mode BatchNorm2d of utils.py:1049 and
  * the result is [1][Cp]; mean/var (biased) are also written when the pointers are non-NULL.
- * Two deterministic stages with fp64 partial sums in `ws` (egne_norm_stats_workspace_bytes). */
+ * Two deterministic stages with fp64 partial sums in `ws` (egne_norm_stats_workspace_bytes; 16-byte aligned, as for egne_norm_bwd). */
 int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int per_sample);
 int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int B, int HW,
                     int per_sample, float eps, float* scale, float* shift,
