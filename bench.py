@@ -524,7 +524,6 @@ class Bench:
         # 2B workgroups leaves most of the chip idle); the host takes delivery of batch i-1's ellipses before it queues batch i+1.
         host = [torch.empty((B, 2, 5), dtype=torch.float64).pin_memory() for _ in range(2)] if fit else None
         # (EGNE_FIT_PRIO=1: the network's two streams at high priority, the fit stream at normal priority -- measured)
-        side = torch.cuda.Stream(device=dev) if fit else None
         state = {"n": 0, "done": [None, None]}
 
         # Two-stage pipeline across batches (unless --no-pipeline): the frozen edge network of batch i runs on stream A while
@@ -534,6 +533,8 @@ class Bench:
         from egne_amd.pipeline import TwoStagePipeline
         use_pipe = (not self.a.no_pipeline) if pipeline is None else pipeline
         pipe = TwoStagePipeline(args, bd, dev) if use_pipe else None
+        from egne_amd.pipeline import WindowedFit
+        wfit = WindowedFit(dev, windowed=use_pipe) if fit else None
 
         def esf(edge):
             out = net(t["img"], edge, t["label"], t["pupil_center"], t["elNorm"], t["spatWts"], t["distMap"], t["cond"],
@@ -541,18 +542,11 @@ class Bench:
             if fit:
                 k = state["n"] & 1
                 mask, elp = net.predictions(), out[1]
-                ready_f = torch.cuda.Event()
-                ready_f.record()
                 if state["done"][k] is not None:
                     state["done"][k].synchronize()          # the ellipses of two batches ago have landed in host[k]
-                side.wait_event(ready_f)
-                with torch.cuda.stream(side):
-                    mask.record_stream(side)
-                    elp.record_stream(side)
-                    host[k].copy_(fit_ellipses_from_pred(mask, elp), non_blocking=True)
-                    done = torch.cuda.Event()
-                    done.record(side)
-                state["done"][k] = done
+                # (egne_amd.pipeline.WindowedFit: the searches are released where the NEXT batch's ESF-Net reaches its low-resolution
+                #  levels, next to launches that hand one workgroup to each free CU -- not next to persistent ones)
+                state["done"][k] = wfit.submit(mask, elp, then=lambda res, k=k: host[k].copy_(res, non_blocking=True))
                 state["n"] += 1
             return out
 
@@ -568,6 +562,9 @@ class Bench:
                 return None
             with torch.no_grad():
                 r = pipe.flush()
+            for d in state["done"]:          # every search of the timed region is finished inside it
+                if d is not None:
+                    d.synchronize()
             return r[0] if r is not None else None
         step.flush = flush
         return step

@@ -41,6 +41,8 @@ BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
 BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
 BIG_SPLIT_TAIL = os.environ.get("EGNE_BIG_SPLIT_TAIL", "1") != "0"
 BIG_CUS = 256
+WINDOW_NAME = os.environ.get("EGNE_FIT_WINDOW", "enc.b3.conv1")      # launch in front of which pending WINDOW_HOOKS are released ("none": never)
+WINDOW_HOOKS = []     # callables waiting for a plan's launch window (Plan.window_at): run on the host where the plan queues that launch
 EVENT_KINDS = None   # bench.py: restrict the per-launch HIP events of Plan.run(events) to these kernel families
 S1X1_MIN_PIX = int(os.environ.get("EGNE_S1X1_MIN_PIX", "100000"))
 HALO_F16_ENABLED = os.environ.get("EGNE_HALO_F16", "1") != "0"
@@ -593,6 +595,7 @@ class Plan:
         self.side_calls, self.side_stream = {}, None   # call index -> event: launches on the plan's second stream (weight gradients; the edge network's MSBlocks)
         self.side_default = False                      # _add: launches emitted while this is set go to the second stream
         self.join_before = set()                       # call indices in front of which the main stream waits for the second one
+        self.window_at = None                          # call index at which pending WINDOW_HOOKS are released (None: never)
         self.serial_timing = False                     # run(events): one stream when launches are timed (overlapping kernels stretch each other's durations)
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _StorageLib(_lib.lib(), self.bf16)
@@ -719,6 +722,8 @@ class Plan:
             self.cal[len(self.calls)] = cal
         if side or self.side_default:      # launched on the plan's second stream behind an event of the main one (Plan.run); joined at the end of the run
             self.side_calls[len(self.calls)] = None
+        if name == WINDOW_NAME and self.window_at is None and not self.train:
+            self.window_at = len(self.calls)       # WINDOW_HOOKS are released in front of this launch (_open_window)
         self.calls.append((fn, args, name))
         self.meta.append((kind or name.split(".")[0], flops))
 
@@ -1595,12 +1600,16 @@ class Plan:
         if self.side_calls and not (events is not None and self.serial_timing):
             return self._run_two_streams(st, events)
         if events is None:
-            for fn, args, name in self.calls:
+            for i, (fn, args, name) in enumerate(self.calls):
+                if i == self.window_at and WINDOW_HOOKS:
+                    self._open_window()
                 rc = fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, name)
             return
-        for (fn, args, name), (kind, flops) in zip(self.calls, self.meta):
+        for i, ((fn, args, name), (kind, flops)) in enumerate(zip(self.calls, self.meta)):
+            if i == self.window_at and WINDOW_HOOKS:
+                self._open_window()
             if EVENT_KINDS is not None and kind.split(":")[0] not in EVENT_KINDS:      # untimed launch (each event pair costs ~2 us of GPU time)
                 rc = fn(*args, st)
                 if rc != 0:
@@ -1613,6 +1622,20 @@ class Plan:
             if rc != 0:
                 _lib.check(rc, name)
             events.append((kind, flops, e0, e1, name))
+
+    def _open_window(self):
+        """Launch index ``window_at`` is where work that should run NEXT TO this plan's following launches is released (the ellipse
+        searches of an earlier batch next to the edge network's deep trunk layers, whose workgroups are handed out one per free CU:
+        a CU held by a search costs them 1/256 of their rate, while a launch of 256 persistent workgroups with a static share of
+        the tiles each waits for its last workgroup to find a CU).  Every pending hook gets an event recorded here on the current
+        stream; it makes its own stream wait for it and queues its work."""
+        if torch.cuda.is_current_stream_capturing():      # (a hipGraph capture of this plan: the hooks belong to the eager loop around it)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        hooks, WINDOW_HOOKS[:] = list(WINDOW_HOOKS), []
+        for h in hooks:
+            h(ev)
 
     def _refresh_wscales(self):
         """A repack may have chosen another power-of-two weight scale (ensure_packed re-measures max |w|): the launches carry the
@@ -1638,6 +1661,8 @@ class Plan:
         sp = C.c_void_p(side.cuda_stream)
         for i, ((fn, args, name), (kind, flops)) in enumerate(zip(self.calls, self.meta)):
             on_side = i in self.side_calls
+            if i == self.window_at and WINDOW_HOOKS:
+                self._open_window()
             if i in self.join_before:
                 main.wait_stream(side)
             if on_side:

@@ -119,9 +119,11 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
     return _to_host(_seg_and_fit(frames, model)(edge))
 
 
-def _seg_and_fit(frames, model):
+def _seg_and_fit(frames, model, wfit=None):
     """Second stage of a batch (evaluate.py:117-166): ESF-Net on the frames and their edge maps, argmax mask, both ellipses
-    fitted on the device.  Returns a callable of the edge maps (egne_amd.pipeline.TwoStagePipeline runs it on its second stream)."""
+    fitted on the device.  Returns a callable of the edge maps (egne_amd.pipeline.TwoStagePipeline runs it on its second stream).
+    ``wfit`` (egne_amd.pipeline.WindowedFit): the searches go to its stream and are released in the next batch's launch window; the
+    third result is then a handle (``_to_host`` waits for it)."""
     dev = frames.device
     N, _, H, W = frames.shape
 
@@ -133,6 +135,8 @@ def _seg_and_fit(frames, model):
             z = lambda *s: torch.zeros(s, device=dev)              # noqa: E731
             out = model(frames, edge, labels.long(), z(N, 2), z(N, 2, 5), z(N, H, W), z(N, 3, H, W), z(N, 4),
                         torch.zeros(N, dtype=torch.long, device=dev), 0)
+            if wfit is not None:
+                return edge[:, 0].clone(), model.predictions().clone(), wfit.submit(model.predictions(), out[1])
             fit = fit_ellipses_from_pred(model.predictions(), out[1])     # [N,2,5] on the device: (iris, pupil)
             return edge[:, 0].clone(), model.predictions().clone(), fit
     return run
@@ -153,6 +157,9 @@ def graphed_runner(warmup_frames, model, edge_model):
 
 def _to_host(res):
     edge, mask, fit = res
+    if not torch.is_tensor(fit):       # WindowedFit.Handle: the searches may still be waiting for their window
+        fit.synchronize()
+        fit = fit.result
     fit = fit.cpu().numpy()
     return edge.cpu().numpy(), mask.cpu().numpy(), fit[:, 1], fit[:, 0]
 
@@ -266,7 +273,7 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
     edge -> seg -> fitted ellipses -> back to the source geometry; writes <name>_result_<method>.avi (overlay: class colours,
     both ellipses, frame number) and <name>_edge_<method>.avi (255 - 255*edge), both Motion-JPEG, and the ellipse dictionary
     <name>_pred2_<method>.npy {frame: (iris, pupil)} -- eyes are batched 32 at a time instead of one by one."""
-    from egne_amd.pipeline import TwoStagePipeline
+    from egne_amd.pipeline import TwoStagePipeline, WindowedFit
     stem = os.path.splitext(path_vid)[0]
     out, pending = {}, []
     vid_out = edge_out = None
@@ -274,6 +281,10 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
     # i-1 meanwhile: results come back one batch late
     pipe = TwoStagePipeline(argparse.Namespace(prec=torch.float32, edge_thres=0), edge_model, torch.device(device))
     queued = []                                  # frames of the batches whose results are still on the device
+    # the ellipse searches of batch i are released where ESF-Net of batch i+1 reaches its low-resolution levels (WindowedFit): a
+    # batch is drawn once the NEXT batch's second stage has been queued, i.e. two batches behind the decoder
+    wfit = WindowedFit(torch.device(device))
+    ready = []
 
     live = bool(getattr(args, 'low_latency', 0))    # head-mounted-display use: a frame's ellipses before the next frame arrives
     runner = [None]
@@ -297,14 +308,18 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
             return
         queued.append(list(pending))
         pending.clear()
-        r = pipe.submit(x, _seg_and_fit(x, model))
+        r = pipe.submit(x, _seg_and_fit(x, model, wfit))
         if r is not None:
-            draw(queued.pop(0), r)
+            ready.append((queued.pop(0), r))
+        while len(ready) > 1:
+            draw(*ready.pop(0))
 
     def drain():
         r = pipe.flush()
         if r is not None and queued:
-            draw(queued.pop(0), r)
+            ready.append((queued.pop(0), r))
+        while ready:
+            draw(*ready.pop(0))
 
     def draw(frames_of_batch, r):
         nonlocal vid_out, edge_out

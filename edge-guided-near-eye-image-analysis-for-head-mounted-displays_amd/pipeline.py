@@ -70,6 +70,74 @@ class TwoStagePipeline:
         return out
 
 
+class WindowedFit:
+    """The ellipse searches of a batch (utils.fit_ellipses_from_pred, evaluate.py:135-166) on a stream of their own, RELEASED where a
+    later launch plan reaches its window (engine.WINDOW_NAME, default the 30x40 level of ESF-Net's encoder).
+
+    A batch of searches is 2B sequential chains on a few dozen CUs for ~1.9 ms.  Queued right behind the network that produced the
+    class maps it runs next to whatever the two network streams launch then -- mostly PERSISTENT kernels: 256 workgroups with a
+    static 1/256 share of the tiles each, one per CU; the workgroup whose CU a search holds waits for another one to finish and the
+    launch takes up to twice as long.  ESF-Net's low-resolution levels (and the edge network's deep trunk) are ordinary grids that
+    hand a workgroup to whichever CU is free: next to them a search costs its share of the CUs and nothing more.  Measured on
+    MI355X, B = 64, edge + seg + fit pipelined (scratch/ab_fit.sh): 1998-2001 frames/s released at once, 2009-2021 in a window.
+
+    ``submit(mask, elPred, then=None)`` is called on the stream that produced the two tensors; it returns a handle: ``result`` (device
+    tensor [F,2,5], valid once the handle is done), ``synchronize()`` (host waits; queues the searches at once if their window has not
+    opened yet -- the last batches of a run), ``wait(stream)``.  ``then(result)`` runs on the search stream right behind the searches
+    (e.g. the copy to pinned host memory)."""
+
+    class Handle:
+        def __init__(self):
+            self.result, self.done, self._launch = None, None, None
+
+        def _ensure(self):
+            if self.done is None:
+                from . import engine
+                if self._launch in engine.WINDOW_HOOKS:
+                    engine.WINDOW_HOOKS.remove(self._launch)
+                self._launch(None)
+
+        def synchronize(self):
+            self._ensure()
+            self.done.synchronize()
+
+        def wait(self, stream=None):
+            self._ensure()
+            (stream or torch.cuda.current_stream()).wait_event(self.done)
+
+    def __init__(self, device, windowed=True):
+        from . import engine
+        self.side = torch.cuda.Stream(device=device)
+        self.windowed = bool(windowed) and engine.WINDOW_NAME != "none"
+
+    def submit(self, mask, elPred, then=None):
+        from . import engine
+        from .utils import fit_ellipses_from_pred
+        ready = torch.cuda.Event()
+        ready.record()
+        h = WindowedFit.Handle()
+        side = self.side
+
+        def launch(window):
+            side.wait_event(ready)
+            if window is not None:
+                side.wait_event(window)
+            with torch.cuda.stream(side), torch.no_grad():
+                mask.record_stream(side)
+                elPred.record_stream(side)
+                h.result = fit_ellipses_from_pred(mask, elPred)
+                if then is not None:
+                    then(h.result)
+                h.done = torch.cuda.Event()
+                h.done.record(side)
+        h._launch = launch
+        if self.windowed:
+            engine.WINDOW_HOOKS.append(launch)
+        else:
+            launch(None)
+        return h
+
+
 class GraphedFrames:
     """Edge map + segmentation + ellipse fit of a FIXED small batch of frames as ONE hipGraph replay.
 

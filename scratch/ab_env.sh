@@ -1,17 +1,6 @@
 #!/bin/bash
-# A/B of engine environment knobs on the B=64 inference step (pipelined, no fit / with fit)
-run() { echo "== $*"; env "$@" python - <<'PY'
-import sys, types
-sys.path.insert(0, ".")
-import bench
-a = types.SimpleNamespace(gpus=1, batch=64, train_batch=256, config="baseline_edge", chz=32, no_pipeline=False, layers=False, fit=False)
-bn = bench.Bench(a)
-for fit in (False, True):
-    B, dt, _ = bn.leg_infer(20, 5, fit=fit, events=False)
-    print("fit=%s pipelined: %.3f ms/step" % (fit, 1e3 * dt / 20))
-PY
-}
-run A=1
-run EGNE_RW_MIN_W=60 EGNE_RW_MAX_COUTP=128
-run EGNE_RW_MIN_W=60 EGNE_RW_MAX_COUTP=64
-run EGNE_FIT_PRIO=1
+# usage: bash scratch/ab_env.sh "<ENV=val ...>" "<ENV=val ...>" ...   one bench.py --mode infer run per setting ("" = defaults), value / ms printed
+for s in "$@"; do
+  env $s python3 bench.py --mode infer --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/ab_one.json
+  python3 -c "import json,sys; d=json.loads(open('gpurun_out/ab_one.json').read()); print('%-60s value %8.2f  %7.3f ms' % (sys.argv[1] or '(defaults)', d['value'], d['ms_per_step']))" "$s"
+done

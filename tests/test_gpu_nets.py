@@ -449,6 +449,44 @@ def test_pipelined_inference_is_bit_identical(bdcn):
             assert torch.equal(a, c)
 
 
+def test_windowed_fit_matches_the_direct_call_and_waits_for_its_window(bdcn):
+    """egne_amd.pipeline.WindowedFit: the ellipse searches of a batch on a stream of their own, released where a later ESF-Net
+    forward reaches its window launch (engine.WINDOW_NAME) -- same bits as utils.fit_ellipses_from_pred called directly; a handle
+    whose window never opens queues its searches when it is asked for the result."""
+    from common import batch_args, esf_module
+    from egne_amd import engine, synth
+    from egne_amd.pipeline import WindowedFit
+    from egne_amd.utils import calc_edge, fit_ellipses_from_pred
+    ns = types.SimpleNamespace(prec=torch.float32, edge_thres=0)
+    m = esf_module("baseline_edge").to(DEV).eval()
+    b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth.make_batch(3, seed=77).items()}
+    with torch.no_grad():
+        edge = calc_edge(ns, b["img"], bdcn, DEV)
+        out = m(*batch_args(b, edge))
+        mask, elp = m.predictions(), out[1].clone()
+        want = fit_ellipses_from_pred(mask, elp)
+    torch.cuda.synchronize()
+    assert engine.WINDOW_NAME == "enc.b3.conv1" and m._last_plan.window_at is not None and not engine.WINDOW_HOOKS
+    wf = WindowedFit(DEV)
+    seen = []
+    h = wf.submit(mask, elp, then=lambda r: seen.append(r.clone()))
+    assert h.done is None and len(engine.WINDOW_HOOKS) == 1              # waiting for a window
+    with torch.no_grad():
+        m(*batch_args(b, edge))                                           # the next forward opens it
+    assert h.done is not None and not engine.WINDOW_HOOKS
+    h.synchronize()
+    assert torch.equal(h.result, want) and torch.equal(seen[0], want)
+    h2 = wf.submit(mask, elp)                                             # no later forward: asked for, it queues itself
+    assert h2.done is None
+    h2.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(h2.result, want) and not engine.WINDOW_HOOKS
+    h3 = WindowedFit(DEV, windowed=False).submit(mask, elp)               # released at once
+    assert h3.done is not None
+    h3.synchronize()
+    assert torch.equal(h3.result, want)
+
+
 def test_backward_only_supports_the_loss(edge_of):
     from common import batch_args, esf_module
     b, edge = edge_of(B=2, seed=1234)
