@@ -210,14 +210,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
     const int wchunk = nt0 * 1024 + (c0 >> 4) * stride_k16;
     // register ring: slot = (tap % RT) * 2 + ks holds the fragments of (tap, ks); refilled RT taps ahead
     constexpr int RT = (WN == 1 && NW == 1) ? 2 : 1;
+    // a last chunk with <= 16 real channels (38 -> 64, 76 -> 96, 100 -> 100: ESF-Net's growth 1.2 leaves such tails): its second
+    // 16-channel k-step multiplies zeros by zeros -- skipped, fragments and MFMAs alike (wave-uniform)
+    const bool half = Cp - c0 <= 16;
     u32x4 qh[2 * RT][WN], ql[2 * RT][WN];
 #pragma unroll
     for (int s = 0; s < 2 * RT; ++s)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
         const int o = wchunk + wtap(s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
-        qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
-        ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
+        const int wl = (half && (s & 1)) ? (int)OOB : wlane;
+        qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wl, o, 0);
+        ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wl, o, 0);
       }
     constexpr int TAP_UNROLL = NW == 2 ? 1 : 9;   // the NW = 2 shape only fits 2 waves per SIMD with the tap loop rolled
 #pragma unroll TAP_UNROLL
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
       if (PF == 2 && tap == 4) prefetch();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 1 && half) continue;
         const int slot = (tap % RT) * 2 + ks;
         h8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll

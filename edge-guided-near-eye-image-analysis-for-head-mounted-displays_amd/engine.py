@@ -29,6 +29,7 @@ RW_MAX_CP = int(os.environ.get("EGNE_RW_MAX_CP", "512"))        # ... and widest
 RW_ENABLED = os.environ.get("EGNE_RW", "1") != "0"             # resident-weights form of the role-split 3x3 (no consumer loads)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
+TAIL16_HALO = os.environ.get("EGNE_TAIL16_HALO", "1") != "0"      # 33..48-channel slices: halo kernel (skips the zero half k-step) instead of role-split
 MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
 S1X1_ENABLED = os.environ.get("EGNE_S1X1", "1") != "0"
@@ -826,6 +827,10 @@ class Plan:
                    and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
         rs = rw_wide or (rs and 8 <= pieces[0].Cp <= 64 and layer.sfrag_coutp() in (32, 64, 128)
                          and not (pieces[0].Cp <= 32 and layer.sfrag_coutp() == 128))
+        # a slice whose last 32-channel chunk holds <= 16 channels (38 -> 64 of ESF-Net's second down block): the halo kernel skips the
+        # zero half of that chunk's k-steps (3 of 4 for 40 channels), the role-split kernels' 16x16x32 MFMAs cannot
+        if rs and not rw_wide and TAIL16_HALO and 32 < pieces[0].Cp <= 64 and 0 < pieces[0].Cp % 32 <= 16:
+            rs = False
         shalo = shalo or rs
         if lattice or msdil:
             shalo = True
