@@ -165,6 +165,9 @@ SIGNATURES.update({
     "egne_conv3x3_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
     "egne_conv_narrow_bf16_supported": (i32, [C.POINTER(ConvDesc)]),
     "egne_conv_narrow_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp]),
+    "egne_pack_conv3x3_narrow_weight": (i32, [vp, i32, i32, vp, vp]),
+    "egne_conv3x3_narrow_supported": (i32, [C.POINTER(ConvDesc)]),
+    "egne_conv3x3_narrow_fwd": (i32, [C.POINTER(ConvDesc), vp]),
     "egne_conv1x1_bf16_pack_elems": (i64, [C.POINTER(ConvDesc)]),
     "egne_pack_conv1x1_bf16": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp]),
     "egne_conv1x1_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),

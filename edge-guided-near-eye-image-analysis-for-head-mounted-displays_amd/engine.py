@@ -29,6 +29,7 @@ RW_MAX_CP = int(os.environ.get("EGNE_RW_MAX_CP", "512"))        # ... and widest
 RW_ENABLED = os.environ.get("EGNE_RW", "1") != "0"             # resident-weights form of the role-split 3x3 (no consumer loads)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
+NARROW_F32 = os.environ.get("EGNE_NARROW_F32", "1") != "0"          # <= 4 output channels: exact-fp32 vector-ALU kernel (conv_narrow_f32.hip)
 TAIL16_HALO = os.environ.get("EGNE_TAIL16_HALO", "1") != "0"      # 33..48-channel slices: halo kernel (skips the zero half k-step) instead of role-split
 MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
 LATTICE_MIN_W = int(os.environ.get("EGNE_LATTICE_MIN_W", "20"))
@@ -766,6 +767,48 @@ class Plan:
         if self.bf16:
             return self._conv_bf16(layer, pieces, dst, B, H, W, residual, name, stats, scores)
         Ho, Wo = layer.out_hw(H, W)
+        # <= 4 output channels over a narrow raw slice (ESF-Net's logits layer, 32 -> 3 at full resolution): exact fp32 on the vector
+        # ALU, weights as scalar operands (conv_narrow_f32.hip) -- the matrix kernels compute a 32-wide output block for it
+        if (NARROW_F32 and not self.train and not self.dyn_scales and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
+                and layer.pad == (1, 1) and layer.pad_mode == 0 and layer.dils[0] == 1 and layer.Cout <= 4 and len(pieces) == 1
+                and not isinstance(pieces[0], PlanarPiece) and pieces[0].scale is None and pieces[0].presplit is None
+                and 32 <= pieces[0].Cp <= 64 and residual is None and not stats and scores is None
+                and getattr(self, "_pool_req", None) is None and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
+                and H * W * pieces[0].stride < 2 ** 29):
+            layer.need_flat = True
+            if layer not in self.layers:
+                self.layers.append(layer)
+            layer.ensure_packed(self.device)
+            d = _lib.ConvDesc()
+            d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
+            d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.pad_mode, d.ngroups = 3, 3, 1, 1, 1, 0, 1
+            for g in range(_lib.MAXGROUP):
+                d.dil[g] = 1
+            d.nseg = 1
+            p0 = pieces[0]
+            sg = d.seg[0]
+            sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp, sg.act_in = p0.ptr, p0.stride, p0.off, p0.Cp, p0.act_in
+            cp32 = (p0.Cp + 31) // 32 * 32
+            wn = self.vec(9 * cp32 * 4)          # [tap][channel][4 outputs]: re-packed when the weight changes
+
+            def repack(layer=layer, wn=wn):
+                w = layer.weights[0].detach().to(torch.float32).contiguous()
+                _lib.check(self.L.egne_pack_conv3x3_narrow_weight(w.data_ptr(), layer.Cout, layer.Cin, wn.data_ptr(), _lib.stream_ptr()), "pack_conv3x3_narrow")
+            self.pre.append(VersionGuard([layer.weights[0]], repack))
+            d.Ktot, d.CoutP, d.w = cp32, 4, wn.data_ptr()
+            d.bias = layer.bp.data_ptr() if layer.biases is not None else None
+            d.act = layer.act
+            if layer.post is not None:
+                d.post_scale, d.post_shift = layer.post[0].data_ptr(), layer.post[1].data_ptr()
+            d.out, d.out_pix_stride, d.out_ch_off = dst.ptr, dst.stride, dst.off
+            # four outputs cost the kernel no more instructions than three (two packed multiply-adds per operand) and leave as ONE 16-byte
+            # store per pixel: the pack's rows, the bias and the post affine beyond Cout are zero, so the slice's padding channel gets 0
+            vec4 = dst.Cp >= 4 and dst.off % 4 == 0 and dst.stride % 4 == 0 and layer.CoutP >= 4
+            d.Cout_store = 4 if vec4 else layer.Cout
+            assert int(self.L.egne_conv3x3_narrow_supported(C.byref(d))) == 1 and p0.act_in == ACT_NONE, name
+            self.keep.append(d)
+            self._add(self.L.egne_conv3x3_narrow_fwd, (C.byref(d),), name, flops=2.0 * B * H * W * layer.Cout * layer.Cin * 9, kind="conv3x3_narrow")
+            return Ho, Wo
         halo = (HALO_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and layer.G == 1
                 and layer.pad == (1, 1) and layer.pad_mode == 0 and len(pieces) == 1 and layer.dils[0] <= 2
                 and W >= HALO_MIN_W and layer.CoutP <= HALO_MAX_COUTP and H * W * pieces[0].stride < 2 ** 31)

@@ -649,6 +649,19 @@ int egne_conv_narrow_bf16_supported(const egne_conv_desc* d);
 int egne_conv_narrow_bf16_fwd(const egne_conv_desc* d, void* stream);
 
 /*
+ * 3x3 / stride 1 / pad 1 convolution with a NARROW output (Cout_store <= 4) over ONE raw fp32 slice of 4..64 channels, EXACT fp32 on
+ * the vector ALU (one rounding per fused multiply-add, accumulation tap-major then channel; bias, optional ReLU / LeakyReLU, post affine): the
+ * logits layer of ESF-Net (models/RITnet_v2.py:249 `final` / utils.py:1047 convBlock conv2: 32 -> 3 classes at 240x320), which the
+ * matrix kernels ran as a 32-wide output block.  d.w = [9 taps][CP][4 outputs] fp32 from egne_pack_conv3x3_narrow_weight (CP = the
+ * slice's channels rounded up to 32; 64-byte aligned; read through the scalar cache; d.Ktot / d.CoutP are ignored).  Post affine
+ * allowed; no residual / statistics / fused input affine; egne_conv3x3_narrow_supported tells whether a descriptor qualifies.
+ * Replaces egne_conv3x3_rw_f16_fwd for that layer in inference plans (egne_conv2d_fwd semantics).
+ */
+int egne_pack_conv3x3_narrow_weight(const float* w_oihw, int Cout, int Cin, float* out, void* stream);
+int egne_conv3x3_narrow_supported(const egne_conv_desc* d);
+int egne_conv3x3_narrow_fwd(const egne_conv_desc* d, void* stream);
+
+/*
  * 1x1 convolution over up to EGNE_MAXSEG RAW bf16 slices on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, bf16 output): conv21 / conv31
  * of the dense blocks, Transition_down behind its pooling, conv11 / conv21 of the up blocks (models/RITnet_v2.py:38-41,59-61,85-86)
  * and their merged data gradients in training plans with bf16 storage (dtype 1).  Streaming: a lane's operand of a 16-channel

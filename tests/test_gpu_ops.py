@@ -786,6 +786,56 @@ def test_msblock_dilated_group_one_launch(G, B, H, W, stride_pad):
         assert err < 2e-6, "relative error %.2e" % err
 
 
+@pytest.mark.parametrize("Cin,Cout,B,H,W,act", [
+    (32, 3, 2, 61, 83, 0),        # ESF-Net's logits layer class (models/RITnet_v2.py:249): ragged tiles in x and y
+    (32, 3, 1, 240, 320, 0),
+    (64, 4, 2, 24, 40, 2),        # two 32-channel chunks, four outputs, LeakyReLU
+    (40, 1, 3, 17, 33, 1),        # a padded chunk (40 of 64 channels), one output, ReLU
+    (62, 2, 1, 9, 70, 0),
+])
+def test_conv3x3_narrow_output_is_exact_fp32(G, Cin, Cout, B, H, W, act):
+    """conv_narrow_f32.hip (egne_conv3x3_narrow_fwd): a 3x3 / pad 1 convolution with <= 4 output channels on the vector ALU in exact
+    fp32 -- against float64 at the rounding level of a sequential fp32 sum, the engine routes such a layer of an
+    inference plan to it, and nothing outside the destination slice is touched."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    x = _rand(G, B, Cin, H, W) * 3
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    truth = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if act == 1:
+        truth = F.relu(truth)
+    elif act == 2:
+        truth = F.leaky_relu(truth, 0.01)
+    pl = Plan(torch.device(DEV))
+    (piece,) = to_nhwc_buf(pl, [x], B, H, W)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(piece.C, piece.Cp)], pad=(1, 1), act=act)
+    layer.split = True
+    if act == 2:          # eval BatchNorm behind the activation (utils.py:1049)
+        a_, b_ = _rand(G, Cout).abs() + 0.5, _rand(G, Cout)
+        truth = truth * a_.double()[None, :, None, None] + b_.double()[None, :, None, None]
+        pa, pb = torch.zeros(layer.CoutP, device=DEV), torch.zeros(layer.CoutP, device=DEV)
+        pa[:Cout], pb[:Cout] = a_.to(DEV), b_.to(DEV)
+        layer.post = (pa, pb)
+    out = pl.buf(B, H, W, 16)
+    out.fill_(777.0)
+    pl.conv(layer, [piece], Piece(out, 4, Cout), B, H, W, name="narrow")
+    assert [m[0] for m in pl.meta] == ["conv3x3_narrow"] and pl.calls[0][0] is pl.L.egne_conv3x3_narrow_fwd
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        o = out.cpu()
+        assert (o[..., :4] == 777.0).all() and (o[..., 8:] == 777.0).all(), "stores outside the output slice"
+        assert (o[..., 4 + Cout:8] == 0.0).all()        # one 16-byte store per pixel: the slice's padding channels get zeros
+        got = o[..., 4:4 + Cout].permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 1.5e-6, "relative error %.2e" % err       # 288-576 sequential fp32 multiply-adds per output
+    # a training plan keeps the matrix path (its backward plan indexes the split packs)
+    pl2 = Plan(torch.device(DEV), train=True)
+    (p2,) = to_nhwc_buf(pl2, [x], B, H, W)
+    pl2.conv(layer, [p2], Piece(pl2.buf(B, H, W, 8), 0, Cout), B, H, W, name="narrow")
+    assert pl2.meta[0][0] != "conv3x3_narrow"
+
+
 @pytest.mark.parametrize("B,H,W,Cin,mag", [(2, 240, 320, 64, 1.0), (3, 120, 160, 128, 1.0), (2, 75, 101, 64, 3e3), (2, 60, 80, 256, 1e-3), (1, 30, 40, 512, 1.0)])
 def test_msblock_with_split_pair_storage(G, B, H, W, Cin, mag):
     """A whole MSBlock (bdcn_new.py:49-55) the way the edge network's plan runs it: the 3x3 convolution writes `o` in SPLIT-PAIR
