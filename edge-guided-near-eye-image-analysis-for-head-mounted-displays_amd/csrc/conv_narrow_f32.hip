@@ -42,7 +42,7 @@ void conv3x3_narrow_f32_kernel(const egne_conv_desc p, int tiles_x, int tiles_y,
   const unsigned frame_in = (unsigned)p.H * p.W * (unsigned)sg.pix_stride * 4u;
   constexpr int NO = 4;
   cfloat* const w = (cfloat*)(unsigned long long)p.w;
-  const bool vec_out = p.Cout_store == 4 && (p.out_ch_off & 3) == 0 && (p.out_pix_stride & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+  const bool vec_out = (p.Cout_store & 3) == 0 && (p.out_ch_off & 3) == 0 && (p.out_pix_stride & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
   const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   float bias[NO], ps[NO], pt[NO];          // v = act(acc + bias) * post_scale + post_shift (eval BatchNorm behind the activation, utils.py:1049)
 #pragma unroll
@@ -144,11 +144,13 @@ void conv3x3_narrow_f32_kernel(const egne_conv_desc p, int tiles_x, int tiles_y,
         const float v = acc[o] + bias[o];
         r[o] = fmaxf(v, v * slope) * ps[o] + pt[o];
       }
-      if (vec_out) { *(f32x4*)op = f32x4{r[0], r[1], r[2], r[3]}; }
-      else {
+      if (vec_out) {                           // stored channels past the fourth are the slice's padding: zeros
+        *(f32x4*)op = f32x4{r[0], r[1], r[2], r[3]};
+        if (p.Cout_store == 8) *(f32x4*)(op + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
 #pragma unroll
-        for (int o = 0; o < NO; ++o)
-          if (o < p.Cout_store) op[o] = r[o];
+        for (int o = 0; o < 8; ++o)
+          if (o < p.Cout_store) op[o] = o < NO ? r[o < NO ? o : 0] : 0.f;
       }
     }
     if (!more) break;
@@ -164,7 +166,7 @@ bool supported(const egne_conv_desc& d) {
   if (!g.ptr || g.scale || g.shift || g.act_in != EGNE_ACT_NONE || g.presplit || g.Cp % 4 || g.Cp > 64 || g.Cp < 4 || g.ch_off % 4 || g.pix_stride % 4 ||
       ((uintptr_t)g.ptr & 15) || g.ch_off + g.Cp > g.pix_stride)
     return false;
-  if (!d.w || ((uintptr_t)d.w & 63) || !d.out || d.Cout_store < 1 || d.Cout_store > 4 || d.out_ch_off + d.Cout_store > d.out_pix_stride)
+  if (!d.w || ((uintptr_t)d.w & 63) || !d.out || d.Cout_store < 1 || d.Cout_store > 8 || d.out_ch_off + d.Cout_store > d.out_pix_stride)
     return false;
   if (d.residual || (d.post_scale && !d.post_shift) || d.stats_ws || d.pool_out || d.dyn_scale || d.absmax_out || d.out_split) return false;
   if (d.act != EGNE_ACT_NONE && d.act != EGNE_ACT_RELU && d.act != EGNE_ACT_LEAKY) return false;
@@ -194,9 +196,9 @@ extern "C" int egne_pack_conv3x3_narrow_weight(const float* w_oihw, int Cout, in
 extern "C" int egne_conv3x3_narrow_supported(const egne_conv_desc* d) { return d && supported(*d) ? 1 : 0; }
 
 // d.w: [9][32 or 64][4] fp32 (egne_pack_conv3x3_narrow_weight), 64-byte aligned; one raw fp32 slice of 4..64 channels, 1..4 stored
-// output channels (d.Ktot / d.CoutP are not read)
+// output channels, 5..8 when the slice's padding channels are to be written as zeros (d.Ktot / d.CoutP are not read)
 extern "C" int egne_conv3x3_narrow_fwd(const egne_conv_desc* dp, void* stream) {
-  EGNE_REQUIRE(dp && supported(*dp), "conv3x3_narrow: descriptor not supported (3x3 / pad 1, one raw fp32 slice of <= 64 channels, <= 4 outputs)");
+  EGNE_REQUIRE(dp && supported(*dp), "conv3x3_narrow: descriptor not supported (3x3 / pad 1, one raw fp32 slice of <= 64 channels, <= 4 outputs + padding)");
   const egne_conv_desc& d = *dp;
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH, ntiles = tiles_x * tiles_y * d.B;
   const int nch = (d.seg[0].Cp + 31) / 32;

@@ -801,10 +801,10 @@ class Plan:
             if layer.post is not None:
                 d.post_scale, d.post_shift = layer.post[0].data_ptr(), layer.post[1].data_ptr()
             d.out, d.out_pix_stride, d.out_ch_off = dst.ptr, dst.stride, dst.off
-            # four outputs cost the kernel no more instructions than three (two packed multiply-adds per operand) and leave as ONE 16-byte
-            # store per pixel: the pack's rows, the bias and the post affine beyond Cout are zero, so the slice's padding channel gets 0
-            vec4 = dst.Cp >= 4 and dst.off % 4 == 0 and dst.stride % 4 == 0 and layer.CoutP >= 4
-            d.Cout_store = 4 if vec4 else layer.Cout
+            # the kernel computes four outputs (two packed multiply-adds per operand: no more instructions than three) and stores the
+            # slice's padding channels as zeros, like every other convolution of the library (the pack's rows, the bias and the post
+            # affine beyond Cout are zero)
+            d.Cout_store = min(layer.Cout_store, dst.Cp)
             assert int(self.L.egne_conv3x3_narrow_supported(C.byref(d))) == 1 and p0.act_in == ACT_NONE, name
             self.keep.append(d)
             self._add(self.L.egne_conv3x3_narrow_fwd, (C.byref(d),), name, flops=2.0 * B * H * W * layer.Cout * layer.Cin * 9, kind="conv3x3_narrow")

@@ -649,7 +649,8 @@ int egne_conv_narrow_bf16_supported(const egne_conv_desc* d);
 int egne_conv_narrow_bf16_fwd(const egne_conv_desc* d, void* stream);
 
 /*
- * 3x3 / stride 1 / pad 1 convolution with a NARROW output (Cout_store <= 4) over ONE raw fp32 slice of 4..64 channels, EXACT fp32 on
+ * 3x3 / stride 1 / pad 1 convolution with a NARROW output (<= 4 channels; Cout_store <= 8, stored channels past the fourth are
+ * written as zeros: the padding of an 8-channel slice) over ONE raw fp32 slice of 4..64 channels, EXACT fp32 on
  * the vector ALU (one rounding per fused multiply-add, accumulation tap-major then channel; bias, optional ReLU / LeakyReLU, post affine): the
  * logits layer of ESF-Net (models/RITnet_v2.py:249 `final` / utils.py:1047 convBlock conv2: 32 -> 3 classes at 240x320), which the
  * matrix kernels ran as a 32-wide output block.  d.w = [9 taps][CP][4 outputs] fp32 from egne_pack_conv3x3_narrow_weight (CP = the

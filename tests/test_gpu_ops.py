@@ -824,8 +824,8 @@ def test_conv3x3_narrow_output_is_exact_fp32(G, Cin, Cout, B, H, W, act):
         pl.run()
         torch.cuda.synchronize()
         o = out.cpu()
-        assert (o[..., :4] == 777.0).all() and (o[..., 8:] == 777.0).all(), "stores outside the output slice"
-        assert (o[..., 4 + Cout:8] == 0.0).all()        # one 16-byte store per pixel: the slice's padding channels get zeros
+        assert (o[..., :4] == 777.0).all(), "stores outside the output slice"
+        assert (o[..., 4 + Cout:12] == 0.0).all() and (o[..., 12:] == 777.0).all()       # the slice's padding channels are written as zeros
         got = o[..., 4:4 + Cout].permute(0, 3, 1, 2).double()
         err = (got - truth).abs().max().item() / truth.abs().max().item()
         assert err < 1.5e-6, "relative error %.2e" % err       # 288-576 sequential fp32 multiply-adds per output
@@ -977,8 +977,20 @@ def test_conv3x3_role_split(G, B, Cin, Cout, H, W, mode):
         (pr,) = to_nhwc_buf(pl, [r], B, H, W)
         residual = pr
         truth = truth + r.double()
-    pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W, residual=residual, stats=(mode == "norm"))
+    from egne_amd import engine
+    # (a 33..48-channel slice takes the halo kernel by default -- it skips the zero half of the last chunk's k-steps, engine.TAIL16_HALO;
+    #  here the role-split kernels are what is tested, the halo route is asserted below)
+    tail16, engine.TAIL16_HALO = engine.TAIL16_HALO, False
+    try:
+        pl.conv(layer, [px], Piece(out, 0, Cout), B, H, W, residual=residual, stats=(mode == "norm"))
+    finally:
+        engine.TAIL16_HALO = tail16
     assert any(m[0] in ("conv_f16x3:rs", "conv_f16x3:rw") for m in pl.meta)     # role-split: register-ring or resident-weights form
+    if 32 < pad8(Cin) <= 48 and tail16:
+        pl2 = Plan(torch.device(DEV))
+        (p2,) = to_nhwc_buf(pl2, [x], B, H, W)
+        pl2.conv(layer, [p2], Piece(pl2.buf(B, H, W, pad8(Cout)), 0, Cout), B, H, W)
+        assert [m[0] for m in pl2.meta] == ["conv_f16x3:halo"]
     for _ in range(2):
         pl.run()
         torch.cuda.synchronize()
