@@ -59,12 +59,13 @@ __global__ __launch_bounds__(256) void stage_scores_k(const float* m0, const flo
   }
 }
 
-// ConvTranspose2d(1,1,k=2*stride,stride) of a [h,w] map sampled at cropped output pixel (y,x).
-__device__ __forceinline__ float convT_at(const float* __restrict__ m, int h, int w, const float* __restrict__ kw_,
-                                          int stride, int crop, int y, int x) {
+// ConvTranspose2d(1,1,k=2*stride,stride) of the two score maps of a stage ([h,w] each, same taps) sampled at cropped output pixel
+// (y,x): the <= 2 x 2 contributing inputs and their taps are found once for both maps; kw_ = the k x k table (in LDS).
+__device__ __forceinline__ void convT2_at(const float* __restrict__ ma, const float* __restrict__ mb, int h, int w,
+                                          const float* kw_, int stride, int crop, int y, int x, float& ra, float& rb) {
   const int k = 2 * stride;
   const int yy = y + crop, xx = x + crop;
-  float acc = 0.f;
+  float acc_a = 0.f, acc_b = 0.f;
   // in[iy] contributes with tap ky = yy - iy*stride in [0,k)
   // (stride is 2 / 4 / 8 in bdcn_new.py:91-97: a shift; the general case keeps the division)
   const bool p2 = (stride & (stride - 1)) == 0;
@@ -82,19 +83,31 @@ __device__ __forceinline__ float convT_at(const float* __restrict__ m, int h, in
       if (ix < 0 || ix >= w) continue;
       const int kx = xx - ix * stride;
       if (kx >= k) continue;
-      acc += m[iy * w + ix] * kw_[ky * k + kx];
+      const float t = kw_[ky * k + kx];
+      acc_a += ma[iy * w + ix] * t;
+      acc_b += mb[iy * w + ix] * t;
     }
   }
-  return acc;
+  ra = acc_a; rb = acc_b;
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-// grid (ceil(W / 256), H, B): a thread per pixel, no 64-bit division per element (it cost more than the gathers)
+// grid (ceil(W / 64), ceil(H / 4), B): a thread per pixel of a 64 x 4 block (320-wide frames fill every lane; 256 x 1 blocks left
+// 37 % of them idle), the four upsampler tables (k x k, k = 2 stride <= 32) staged in LDS once per block, both score maps of a
+// stage interpolated with one set of indices.  No 64-bit division per element.
+constexpr int UPMAX = 32 * 32;
 __global__ __launch_bounds__(256) void bdcn_tail_k(const egne_bdcn_tail_desc d) {
+  __shared__ float lup[4][UPMAX];
+#pragma unroll
+  for (int k = 1; k < 5; ++k) {
+    const int kk = 4 * d.stride[k] * d.stride[k];
+    for (int i = threadIdx.x; i < kk; i += 256) lup[k - 1][i] = d.up[k][i];
+  }
+  __syncthreads();
   const long long HW = (long long)d.H * d.W;
-  const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-  if (x < d.W) {
+  const int b = blockIdx.z, y = blockIdx.y * 4 + (threadIdx.x >> 6), x = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (x < d.W && y < d.H) {
     const long long i = (long long)b * HW + (long long)y * d.W + x;
     float sa[5], sb[5];
     sa[0] = d.s[0][i];
@@ -102,8 +115,7 @@ __global__ __launch_bounds__(256) void bdcn_tail_k(const egne_bdcn_tail_desc d) 
 #pragma unroll
     for (int k = 1; k < 5; ++k) {
       const long long off = (long long)b * d.h[k] * d.w[k];
-      sa[k] = convT_at(d.s[k] + off, d.h[k], d.w[k], d.up[k], d.stride[k], d.crop[k], y, x);
-      sb[k] = convT_at(d.s1[k] + off, d.h[k], d.w[k], d.up[k], d.stride[k], d.crop[k], y, x);
+      convT2_at(d.s[k] + off, d.s1[k] + off, d.h[k], d.w[k], lup[k - 1], d.stride[k], d.crop[k], y, x, sa[k], sb[k]);
     }
     // cascades, same association as bdcn_new.py:167-176
     float p[10];
@@ -171,13 +183,13 @@ extern "C" int egne_bdcn_tail(const egne_bdcn_tail_desc* dp, void* stream) {
   for (int k = 0; k < 5; ++k) {
     EGNE_REQUIRE(d.s[k] && d.s1[k], "bdcn_tail: null score map %d", k);
     if (k == 0) continue;
-    EGNE_REQUIRE(d.up[k] && d.stride[k] >= 1 && d.crop[k] >= 0, "bdcn_tail: stage %d upsampler", k);
+    EGNE_REQUIRE(d.up[k] && d.stride[k] >= 1 && d.stride[k] <= 16 && d.crop[k] >= 0, "bdcn_tail: stage %d upsampler (stride 1..16)", k);
     // the cropped window must lie inside the transposed-conv output (bdcn_new.py:7-12 crop assert)
     const int oh = (d.h[k] - 1) * d.stride[k] + 2 * d.stride[k], ow = (d.w[k] - 1) * d.stride[k] + 2 * d.stride[k];
     EGNE_REQUIRE(d.crop[k] + d.H <= oh && d.crop[k] + d.W <= ow, "bdcn_tail: stage %d upsampled %dx%d smaller than crop+%dx%d", k, oh, ow, d.H, d.W);
   }
-  EGNE_REQUIRE(d.H <= 65535 && d.B <= 65535, "bdcn_tail: grid limits");
-  hipLaunchKernelGGL(bdcn_tail_k, dim3((unsigned)((d.W + 255) / 256), (unsigned)d.H, (unsigned)d.B), dim3(256), 0, (hipStream_t)stream, d);
+  EGNE_REQUIRE(d.H <= 4 * 65535 && d.B <= 65535, "bdcn_tail: grid limits");
+  hipLaunchKernelGGL(bdcn_tail_k, dim3((unsigned)((d.W + 63) / 64), (unsigned)((d.H + 3) / 4), (unsigned)d.B), dim3(256), 0, (hipStream_t)stream, d);
   return egne::check_launch("egne_bdcn_tail");
 }
 
