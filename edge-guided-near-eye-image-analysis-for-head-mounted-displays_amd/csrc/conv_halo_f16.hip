@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             }
           }
         }
-        if (!LAT && !TP && NW == 1 && p.stats_ws) {     // one chunk = this wave's rows of this tile (fixed order: deterministic)
+        if (!LAT && NW == 1 && p.stats_ws) {     // one chunk = this wave's rows of this tile (fixed order: deterministic; TP: tiles of the transposed walk)
           st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
           if (lh == 0 && n < p.Cout_store) {
             const int tile_in_frame = (cur.y0 / TH) * tiles_x + cur.x0 / TW;
@@ -393,7 +393,7 @@ int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo,
   const int S = LAT ? d.dil[0] : 1;
   auto ntile = [&](int vh, int vw) { return ((((vw + S - 1) / S) + TW - 1) / TW) * ((((vh + S - 1) / S) + TH - 1) / TH); };
   static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
-  if (D == 1 && NW == 1 && PF == 0 && tall_ok && !d.stats_ws && ntile(d.W, d.H) < ntile(d.H, d.W))
+  if (D == 1 && NW == 1 && PF == 0 && tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W))
     return launch_hf_tp<WM, WN, (D == 1 && NW == 1 && PF == 0 ? D : 1), LAT, (D == 1 && NW == 1 && PF == 0 ? NW : 1), 0, true>(d, fhi, flo, a_scale, os, st);
   return launch_hf_tp<WM, WN, D, LAT, NW, PF, false>(d, fhi, flo, a_scale, os, st);
 }
@@ -425,8 +425,14 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
   EGNE_REQUIRE(d.CoutP % 32 == 0 && d.Cout_store <= d.CoutP && d.out && d.out_ch_off + d.Cout_store <= d.out_pix_stride,
                "conv_halo_f16: CoutP %d", d.CoutP);
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv_halo_f16: weights / scales");
-  EGNE_REQUIRE(!d.stats_ws || (d.dil[0] == 1 && ((uintptr_t)d.stats_ws & 15) == 0 && d.stats_nchunk == ((d.W + 31) / 32) * ((d.H + 7) / 8) * 4),
-               "conv_halo_f16: stats_ws needs dilation 1 and stats_nchunk = tiles * 4");
+  {
+    // tiles of the walk the launcher will choose (transposed when that takes fewer 8 x 32 tiles: launch_hf), four chunks per tile
+    const int t_n = ((d.W + 31) / 32) * ((d.H + 7) / 8), t_t = ((d.H + 31) / 32) * ((d.W + 7) / 8);
+    static const bool tall_on = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
+    const int tiles = (tall_on && t_t < t_n) ? t_t : t_n;
+    EGNE_REQUIRE(!d.stats_ws || (d.dil[0] == 1 && ((uintptr_t)d.stats_ws & 15) == 0 && d.stats_nchunk == tiles * 4),
+                 "conv_halo_f16: stats_ws needs dilation 1 and stats_nchunk = tiles * 4 (%d tiles per frame)", tiles);
+  }
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
                (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv_halo_f16: frame too large for 32-bit byte offsets");
   const float os = 1.0f / (a_scale * w_scale);

@@ -70,6 +70,7 @@ RECAL_EVERY = int(os.environ.get("EGNE_RECAL_EVERY", "1024"))     # inference pl
 #   on a schedule (one short sync per split launch, ~0.1 % of the runs in between)
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
+HALO_TALL = os.environ.get("EGNE_SHALO_TALL", "1") != "0"           # conv_halo_f16.hip walks a map transposed when that takes fewer 8 x 32 tiles
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 maps: 253 -> 194 us for 120 -> 128 channels against the flat kernel)
 HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
@@ -1077,7 +1078,9 @@ class Plan:
         elif shalo:
             tx, ty = (W + 31) // 32, (H + 7) // 8
             tall = ((H + 31) // 32) * ((W + 7) // 8) < tx * ty          # the kernel would walk the map transposed
-            fuse_stats = stats and STATS_FUSED and layer.dils[0] == 1 and not tall and dst.Cp == int(d.Cout_store)
+            fuse_stats = stats and STATS_FUSED and layer.dils[0] == 1 and dst.Cp == int(d.Cout_store)
+            if tall and HALO_TALL:                 # the launcher's choice: the tiles (= statistics chunks) of the transposed walk
+                tx, ty = (H + 31) // 32, (W + 7) // 8
             pq = getattr(self, "_pool_req", None)
             if (pq is not None and POOL_FUSED and HALO_POOL and not lattice and not stats and layer.dils[0] == 1 and layer.post is None
                     and residual is None and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and pq.Cp >= int(d.Cout_store) and layer.sfrag_coutp() % 64 == 0
