@@ -48,7 +48,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"; the split kernel issues 3 MFMAs per product
 ROUND = "r04"
-FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad")
+FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad", "conv3x3_narrow")     # exact-fp32 kernels (the last one on the vector ALU)
 
 
 def parse():
@@ -420,7 +420,7 @@ class Bench:
         self.bd._events = self.net._events = (ev if events and not os.environ.get("EGNE_BENCH_NO_EVENTS") else None)
         # HIP events around every conv launch (the roofline families); all ~600 launches of a step only with --layers:
         # an event pair costs ~2 us of GPU time, 2.5 % of the step when every launch carries one
-        _engine.EVENT_KINDS = None if self.a.layers else {"conv_f16x3", "conv_bf16", "conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad"}
+        _engine.EVENT_KINDS = None if self.a.layers else {"conv_f16x3", "conv_bf16", "conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad", "conv3x3_narrow"}
         self.barrier()
         t0 = time.perf_counter()
         out = None

@@ -45,7 +45,7 @@ import csv, glob, json, re, sys, collections
 out = sys.argv[1]
 SPLIT = ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel",
          "fused_1x1_3x3_kernel", "msblock_dil_kernel", "msdil_ps_kernel", "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel", "conv3x3_rw_kernel", "conv1x1_pool_f16x3_kernel", "conv3x3_wgrad_halo_f16_kernel")
-FP32 = ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel", "conv1x1_wgrad_allpairs_kernel")
+FP32 = ("conv3x3_narrow_f32_kernel", "conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel", "conv1x1_wgrad_allpairs_kernel")
 BF16 = ("conv3x3_bf16_kernel", "conv1x1_bf16_kernel", "wgrad3x3_bf16_kernel", "wgrad1x1_bf16_kernel", "conv_wgrad_wide_kernel", "conv_narrow_bf16_kernel")
 def fam(k):
     if any(s in k for s in BF16): return "bf16_conv"
