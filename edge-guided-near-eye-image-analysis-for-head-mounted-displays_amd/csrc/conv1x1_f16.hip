@@ -45,7 +45,11 @@ __device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, float s, h8
 }
 
 // fhi / flo: [G][CoutP/32][64 lanes][8 halfs]; G = sum over slices of ceil(Cp/16)
-template <int TN>
+// UP: p.residual names a HALF-resolution tensor [B][p.Ho][p.Wo] whose bilinear x2 up-sampling (F.interpolate, scale 2, align_corners
+//     False) is added to the result: conv11(cat(up(x), skip)) = up(W_up x) + W_skip skip (models/RITnet_v2.py:84-86; the 1x1 and the
+//     interpolation are linear and the interpolation weights sum to one) -- the up-sampled operand of an up block is never
+//     materialised, the 1x1 reads the skip slices only (conv_fused_1x1_3x3_f16.hip does the same for the 32-channel block).
+template <int TN, bool UP = false>
 __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                             const _Float16* __restrict__ flo, float a_scale, float out_scale,
                                                             int G, long long M, int nblocks) {
@@ -114,6 +118,29 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
       g += n16;
     }
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+    // UP: the lane's pixel (b, y, x) and its four low-resolution taps -- ATen's area_pixel_compute_source_index(scale 0.5,
+    // align_corners false): s = max(0.5 (d + 0.5) - 0.5, 0)
+    [[maybe_unused]] int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+    [[maybe_unused]] float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rres = ro;
+    [[maybe_unused]] bool pix_ok = false;
+    if constexpr (UP) {
+      const int ph = p.Ho, pw = p.Wo, hw = p.H * p.W;
+      const long long m = m0 + li;
+      pix_ok = m < M;
+      const int b = pix_ok ? (int)(m / hw) : 0;
+      const int r = pix_ok ? (int)(m - (long long)b * hw) : 0;
+      const int y = r / p.W, x = r - y * p.W;
+      float sy = 0.5f * (y + 0.5f) - 0.5f, sx = 0.5f * (x + 0.5f) - 0.5f;
+      sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+      const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < ph - 1 ? 1 : 0), x1 = x0 + (x0 < pw - 1 ? 1 : 0);
+      const float ly = sy - y0, lx = sx - x0;
+      w00 = (1.f - ly) * (1.f - lx); w01 = (1.f - ly) * lx; w10 = ly * (1.f - lx); w11 = ly * lx;
+      const int rs = (int)p.res_pix_stride, base = b * ph * pw;
+      o00 = ((base + y0 * pw + x0) * rs + p.res_ch_off) * 4; o01 = ((base + y0 * pw + x1) * rs + p.res_ch_off) * 4;
+      o10 = ((base + y1 * pw + x0) * rs + p.res_ch_off) * 4; o11 = ((base + y1 * pw + x1) * rs + p.res_ch_off) * 4;
+      rres = make_rsrc(p.residual, (unsigned)((long long)p.B * ph * pw * rs * 4));
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -124,6 +151,14 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
         for (int e = 0; e < 4; ++e) {
           const float t = acc[tn][4 * j + e] * out_scale + bias[tn][j][e];
           v[e] = fmaxf(t, t * slope);
+        }
+        if constexpr (UP) {
+          const bool on = pix_ok && n < p.Cout_store;
+          const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o00 + n * 4 : (int)OOB, 0, 0));
+          const f32x4 b_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o01 + n * 4 : (int)OOB, 0, 0));
+          const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o10 + n * 4 : (int)OOB, 0, 0));
+          const f32x4 d_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o11 + n * 4 : (int)OOB, 0, 0));
+          v += w00 * a + w01 * b_ + w10 * c + w11 * d_;
         }
         const int off = n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, off, 0, 0);
@@ -276,12 +311,19 @@ extern "C" int egne_pack_conv1x1_weight_f16(const float* w_oihw, int Cout, int C
 
 // 1x1 / stride 1 / no padding over up to EGNE_MAXSEG raw slices (no fused affine), CoutP 32 or a multiple of 64, no
 // residual, no post affine.  Weights in the order of egne_pack_conv1x1_weight_f16 (G = sum of ceil(Cp/16)).
+// With d.residual set AND d.Ho * 2 == d.H, d.Wo * 2 == d.W (otherwise Ho / Wo equal H / W): the residual is a HALF-resolution
+// tensor [B][Ho][Wo] whose bilinear x2 up-sampling is added to the (activation-free) result, see conv1x1_f16x3_kernel<TN, UP>.
 extern "C" int egne_conv1x1_f16x3_fwd(const egne_conv_desc* dp, const void* fhi, const void* flo, float a_scale, float w_scale,
                                       void* stream) {
   EGNE_REQUIRE(dp && fhi && flo, "conv1x1_f16: null pointer");
   const egne_conv_desc& d = *dp;
-  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.Ho == d.H && d.Wo == d.W &&
-               d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && !d.residual && !d.post_scale, "conv1x1_f16: unsupported descriptor");
+  const bool up = d.residual && d.Ho * 2 == d.H && d.Wo * 2 == d.W;
+  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && (up || (d.Ho == d.H && d.Wo == d.W)) &&
+               d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && (up || !d.residual) && !d.post_scale, "conv1x1_f16: unsupported descriptor");
+  EGNE_REQUIRE(!up || (d.act == EGNE_ACT_NONE && ((uintptr_t)d.residual & 15) == 0 && d.res_pix_stride % 4 == 0 && d.res_ch_off % 4 == 0 &&
+                       d.res_ch_off + d.Cout_store <= d.res_pix_stride && (long long)d.B * d.Ho * d.Wo * d.res_pix_stride * 4 < (1ll << 31) &&
+                       (long long)d.B * d.H * d.W < (1ll << 31)),
+               "conv1x1_f16: up-sampled addend (no activation, 16-byte aligned channel vectors, < 2 GB)");
   EGNE_REQUIRE(d.CoutP % 32 == 0 && (d.CoutP == 32 || d.CoutP % 64 == 0) && d.Cout_store <= d.CoutP && d.Cout_store % 4 == 0 && d.out &&
                ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off % 4 == 0 &&
                d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv1x1_f16: output");
@@ -313,7 +355,19 @@ extern "C" int egne_conv1x1_f16x3_fwd(const egne_conv_desc* dp, const void* fhi,
   if (gx > cap) gx = cap;
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
-  if (TN == 1)
+  if (up) {
+    static bool once_up = [] {
+      return hipFuncSetAttribute((const void*)conv1x1_f16x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+             hipFuncSetAttribute((const void*)conv1x1_f16x3_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    }();
+    if (!once_up) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_f16: cannot raise the dynamic LDS limit");
+    if (TN == 1)
+      hipLaunchKernelGGL((conv1x1_f16x3_kernel<1, true>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+                         a_scale, os, G, M, (int)nb);
+    else
+      hipLaunchKernelGGL((conv1x1_f16x3_kernel<2, true>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+                         a_scale, os, G, M, (int)nb);
+  } else if (TN == 1)
     hipLaunchKernelGGL((conv1x1_f16x3_kernel<1>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
                        a_scale, os, G, M, (int)nb);
   else

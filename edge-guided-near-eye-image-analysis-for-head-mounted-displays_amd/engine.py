@@ -749,12 +749,22 @@ class Plan:
                 and layer.pad == (1, 1) and layer.dils == (4, 8, 12) and layer.CoutP == 32 and piece.Cp == 32 and piece.scale is None
                 and layer.act == ACT_RELU and layer.post is None and H * W * piece.stride < 2 ** 29)
 
-    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None, pool=None):
+    def stream1x1_ok(self, layer, pieces, B, H, W):
+        """True if ``conv`` runs this 1x1 over raw slices on the streaming split-f16 kernel (weights in LDS, operands straight from
+        HBM: conv1x1_f16.hip) -- the kernel that can add an up-sampled half-resolution tensor in its epilogue (``up_add``)."""
+        return (F16X3_ENABLED and S1X1_ENABLED and not self.bf16 and not self.dyn_scales and layer.split1 and layer.kh == 1 and layer.kw == 1
+                and layer.stride == 1 and layer.G == 1 and layer.pad == (0, 0) and layer.post is None
+                and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
+                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 80 * 1024
+                and B * H * W >= S1X1_MIN_PIX)
+
+    def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None, pool=None, up_add=None):
         """``pool``: a Piece for the 2x2 / stride-2 ceil-mode max pooling of the result; ``self.last_pooled`` tells the caller
-        whether the convolution kernel wrote it (otherwise the caller runs maxpool2)."""
-        self._pool_req, self.last_pooled, self.last_presplit = pool, False, False
+        whether the convolution kernel wrote it (otherwise the caller runs maxpool2).  ``up_add`` = (P, ph, pw): a half-resolution
+        tensor whose bilinear x2 up-sampling is added to the result of a streaming 1x1 (callers check ``stream1x1_ok`` first)."""
+        self._pool_req, self.last_pooled, self.last_presplit, self._up_add = pool, False, False, up_add
         r = self._conv_impl(layer, pieces, dst, B, H, W, residual, name, stats, scores)
-        self._pool_req = None
+        self._pool_req = self._up_add = None
         LAYER_BYTES[name] = float(self.esz) * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
         return r
 
@@ -833,11 +843,7 @@ class Plan:
                    and layer.CoutP in (32, 64) and residual is not None and pieces[0].scale is None
                    and min(W // d_ for d_ in layer.dils) >= LATTICE_MIN_W and H * W * pieces[0].stride < 2 ** 31)
         # 1x1 over raw slices: streaming split-f16 kernel (weights in LDS, operands straight from HBM)
-        s1x1 = (F16X3_ENABLED and S1X1_ENABLED and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
-                and layer.G == 1 and layer.pad == (0, 0) and residual is None and layer.post is None
-                and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
-                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 80 * 1024
-                and B * H * W >= S1X1_MIN_PIX)
+        s1x1 = residual is None and self.stream1x1_ok(layer, pieces, B, H, W)
         # 1x1 over raw slices that the streaming kernel cannot take (K or Cout too large): LDS-staged split-f16 GEMM
         ms1x1 = (F16X3_ENABLED and MS1X1_ENABLED and not s1x1 and layer.split1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1
                  and layer.G == 1 and layer.pad == (0, 0) and residual is None and layer.post is None
@@ -1007,6 +1013,11 @@ class Plan:
             self._add(self.L.egne_conv1x1_ms_f16x3_fwd, (C.byref(d), layer.m1hi.data_ptr(), layer.m1lo.data_ptr(), F16X3_ASCALE,
                                                          layer.w_scale_m1), name, flops=flops, kind="conv_f16x3:gemm1x1", cal=cal3, ws=[(4, layer, "w_scale_m1")])
         elif s1x1:
+            if getattr(self, "_up_add", None) is not None:
+                P, ph, pw = self._up_add
+                assert (2 * ph, 2 * pw) == (H, W) and layer.act == ACT_NONE and P.Cp >= int(d.Cout_store) and tuple(P.buf.shape[:3]) == (B, ph, pw), name
+                d.Ho, d.Wo = ph, pw
+                d.residual, d.res_pix_stride, d.res_ch_off = P.ptr, P.stride, P.off
             self._add(self.L.egne_conv1x1_f16x3_fwd, (C.byref(d), layer.s1hi.data_ptr(), layer.s1lo.data_ptr(), F16X3_ASCALE,
                                                       layer.w_scale1), name, flops=flops, kind="conv_f16x3:stream1x1", cal=cal3, ws=[(4, layer, "w_scale1")])
         elif msdil and scores is not None:

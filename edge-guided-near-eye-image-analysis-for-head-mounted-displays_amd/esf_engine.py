@@ -23,9 +23,11 @@ from .engine import ACT_LEAKY, ACT_NONE, ConvLayer, Piece, PlanarPiece, Plan, Ve
 
 
 import os
+import types
 
 PLANAR_IN = os.environ.get("EGNE_PLANAR_IN", "1") != "0"   # one-channel inputs read in place by the fused head (no NHWC staging)
 FOLD_UP = os.environ.get("EGNE_FOLD_UP", "1") != "0"     # up blocks: 1x1 of the up-sampled operand at half resolution
+FOLD_UP_STREAM = os.environ.get("EGNE_FOLD_UP_STREAM", "1") != "0"     # ... also where the pair is not fused (streaming 1x1 with the addend in its epilogue)
 
 
 def enc_sizes(chz, growth=1.2, blks=4):
@@ -333,7 +335,37 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
             l.split1 = l12.split1 or l12.split
         fold_up = (FOLD_UP and not training and oc == 32 and sum((p.Cp + 15) // 16 for p in skip + [x1]) <= 8
                    and pl.pair_fusable(l11s, skip, l12, x1, h, w) and pl.pair_fusable(l21s, skip + [x1], l22, Piece(y, 0, oc), h, w))
-        if fold_up:
+        # wider blocks whose pair is not fused (62 channels at 120x160: more channel groups than the fused kernel stages): the same
+        # identity on the STREAMING 1x1 kernel, which adds the up-sampled W_up x in its epilogue -- no up-sampled tensor, and both 1x1s
+        # read the skip slices only (K = 104 / 168 instead of 204 / 268 channels)
+        ocp = pad8(oc)
+        # (only where the 1x1 over cat(up(x), skip) would run on the streaming kernel as well: against the LDS-staged GEMM of the wider
+        #  blocks the per-pixel gathers of the addend cost more than the halved K saves -- up block 3: 947 -> 1010 us)
+        full = [types.SimpleNamespace(C=p.C, Cp=pad8(p.C), scale=None) for p in prev] + skip
+        l11f, l21f = _cl(ub.conv11, _lay(full)), _cl(ub.conv21, _lay(full + [x1]))
+        fold_up_s = (FOLD_UP and FOLD_UP_STREAM and not training and not fold_up and variant != "concat"
+                     and pl.stream1x1_ok(l11s, skip, B, h, w) and pl.stream1x1_ok(l21s, skip + [x1], B, h, w)
+                     and pl.stream1x1_ok(l11f, full, B, h, w) and pl.stream1x1_ok(l21f, full + [x1], B, h, w))
+        if fold_up_s:
+            wp = torch.zeros(2 * ocp, Cl, 1, 1, device=dev)
+
+            def refresh_wps(wp=wp, ub=ub, Cl=Cl, oc=oc, ocp=ocp):
+                wp.zero_()
+                wp[:oc].copy_(ub.conv11.weight.detach()[:, :Cl])
+                wp[ocp:ocp + oc].copy_(ub.conv21.weight.detach()[:, :Cl])
+            pl.pre.append(VersionGuard([ub.conv11.weight, ub.conv21.weight], refresh_wps))
+            refresh_wps()
+            lpw = ConvLayer([wp], None, _lay(prev))
+            lpw.split1 = l11s.split1
+            Pb = pl.buf(B, ph, pw, 2 * ocp)
+            pl.conv(lpw, prev, Piece(Pb, 0, 2 * ocp), B, ph, pw, name=nm + ".up_w")
+            P1, P2 = Piece(Pb, 0, oc, ocp), Piece(Pb, ocp, oc, ocp)
+            t1, t2 = Piece(pl.buf(B, h, w, ocp), 0, oc), Piece(pl.buf(B, h, w, ocp), 0, oc)
+            pl.conv(l11s, skip, t1, B, h, w, name=nm + ".conv1.a", up_add=(P1, ph, pw))
+            pl.conv(l12, [t1], x1, B, h, w, name=nm + ".conv1.b")
+            pl.conv(l21s, skip + [x1], t2, B, h, w, name=nm + ".conv2.a", up_add=(P2, ph, pw))
+            pl.conv(l22, [t2], Piece(y, 0, oc), B, h, w, name=nm + ".conv2.b")
+        elif fold_up:
             wp = torch.zeros(2 * oc, Cl, 1, 1, device=dev)
 
             def refresh_wp(wp=wp, ub=ub, Cl=Cl, oc=oc):

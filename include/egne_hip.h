@@ -219,7 +219,12 @@ int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* d, const void* fhi, const void
  * straight from HBM, weight fragments stay in LDS.  Same descriptor as egne_conv2d_fwd (`w` unused; no fused affine,
  * residual or post affine; CoutP 32 or a multiple of 64).  Weights: hi / lo f16 fragments [G][CoutP/32][lane][8] where
  * G = sum over slices of ceil(Cp/16) and kmap[g*16 + h*8 + j] (device int32) names the logical input channel in K
- * slot (half h, j) of group g (-1 = padding); the kernel's slot order is channel 16g + (j<4 ? 4h+j : 8+4h+j-4). */
+ * slot (half h, j) of group g (-1 = padding); the kernel's slot order is channel 16g + (j<4 ? 4h+j : 8+4h+j-4).
+ * Up-sampled addend: with d->residual set and Ho * 2 == H, Wo * 2 == W (instead of Ho == H, Wo == W) the residual is a
+ * HALF-resolution tensor [B][Ho][Wo] (res_pix_stride / res_ch_off, 16-byte aligned channel vectors) whose bilinear x2
+ * up-sampling (F.interpolate, scale 2, align_corners False) is added to the activation-free result:
+ * conv11(cat(up(x), skip)) = up(W_up x) + W_skip skip of an up block (models/RITnet_v2.py:84-86) without the up-sampled
+ * tensor. */
 int egne_pack_conv1x1_weight_f16(const float* w_oihw, int Cout, int Cin, const int32_t* kmap, int G, int CoutP,
                                  float wscale, void* fhi, void* flo, void* stream);
 int egne_conv1x1_f16x3_fwd(const egne_conv_desc* d, const void* fhi, const void* flo, float a_scale,

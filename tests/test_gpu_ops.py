@@ -786,6 +786,45 @@ def test_msblock_dilated_group_one_launch(G, B, H, W, stride_pad):
         assert err < 2e-6, "relative error %.2e" % err
 
 
+@pytest.mark.parametrize("chans,Cout,B,H,W", [((64, 38), 62, 2, 24, 40), ((32,), 32, 3, 10, 18), ((96, 76), 100, 1, 30, 44)])
+def test_conv1x1_stream_with_upsampled_addend(G, chans, Cout, B, H, W):
+    """conv1x1_f16.hip in its `up_add` mode (engine.Plan.conv(..., up_add=)): W_skip skip + b + bilinear-x2(P) with P at half resolution --
+    conv11(cat(up(x), skip)) of an up block (models/RITnet_v2.py:84-86) without the up-sampled tensor -- against float64 with
+    F.interpolate(scale_factor=2, mode="bilinear", align_corners=False); frames that end inside a 32-pixel block included."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, pad8
+    xs = [_rand(G, B, c, H, W) * 2 for c in chans]
+    P = _rand(G, B, Cout, H // 2, W // 2) * 3
+    w, b = _rand(G, Cout, sum(chans), 1, 1) / sum(chans) ** 0.5, _rand(G, Cout)
+    truth = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double()) + F.interpolate(P.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    pl = Plan(torch.device(DEV))
+    pieces = to_nhwc_buf(pl, xs, B, H, W)
+    ocp = pad8(Cout)
+    Pb = pl.buf(B, H // 2, W // 2, 2 * ocp)
+    Pb.fill_(55.0)
+    Pb[..., ocp:ocp + Cout] = P.permute(0, 2, 3, 1).to(DEV)           # second half of a two-addend buffer, as the decoder lays it out
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(p.C, p.Cp) for p in pieces])
+    layer.split1 = True
+    from egne_amd import engine
+    old = engine.S1X1_MIN_PIX
+    engine.S1X1_MIN_PIX = 0
+    try:
+        out = pl.buf(B, H, W, ocp + 8)
+        out.fill_(777.0)
+        pl.conv(layer, pieces, Piece(out, 8, Cout), B, H, W, name="a", up_add=(Piece(Pb, ocp, Cout, ocp), H // 2, W // 2))
+    finally:
+        engine.S1X1_MIN_PIX = old
+    assert [m[0] for m in pl.meta] == ["conv_f16x3:stream1x1"]
+    for _ in range(2):
+        pl.run()
+        torch.cuda.synchronize()
+        o = out.cpu()
+        assert (o[..., :8] == 777.0).all(), "stores outside the output slice"
+        got = o[..., 8:8 + Cout].permute(0, 3, 1, 2).double()
+        err = (got - truth).abs().max().item() / truth.abs().max().item()
+        assert err < 3e-6, "relative error %.2e" % err
+
+
 @pytest.mark.parametrize("Cin,Cout,B,H,W,act", [
     (32, 3, 2, 61, 83, 0),        # ESF-Net's logits layer class (models/RITnet_v2.py:249): ragged tiles in x and y
     (32, 3, 1, 240, 320, 0),
