@@ -64,6 +64,11 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
     *(u32x4*)&wl[(long long)it * 8] = *(const u32x4*)src;
   }
   __syncthreads();
+  // UP: this wave's patch of the half-resolution addend behind the weights: [UPC columns][32 TN channels], the two tapped rows
+  // already blended (every pixel of a block shares them and their weight); pixel pitch 32 TN + 8 floats (the 16 (column,
+  // channel-quad) pairs of a 16-lane read group fall on 16 different 16-byte slots)
+  constexpr int UPC = 18, UPP = 32 * TN + 8;
+  [[maybe_unused]] float* const patch = (float*)(wl + (long long)G * TN * 2 * 64 * 8) + wave * (UPC * UPP);
 
   const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   // transposed product: lane holds output channels n = 32*nt + 8*j + 4*kq + e (r = 4*j + e) of pixel li
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
     [[maybe_unused]] int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
     [[maybe_unused]] float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rres = ro;
-    [[maybe_unused]] bool pix_ok = false;
+    [[maybe_unused]] bool pix_ok = false, staged = false;
     if constexpr (UP) {
       const int ph = p.Ho, pw = p.Wo, hw = p.H * p.W;
       const long long m = m0 + li;
@@ -137,9 +142,37 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
       const float ly = sy - y0, lx = sx - x0;
       w00 = (1.f - ly) * (1.f - lx); w01 = (1.f - ly) * lx; w10 = ly * (1.f - lx); w11 = ly * lx;
       const int rs = (int)p.res_pix_stride, base = b * ph * pw;
-      o00 = ((base + y0 * pw + x0) * rs + p.res_ch_off) * 4; o01 = ((base + y0 * pw + x1) * rs + p.res_ch_off) * 4;
-      o10 = ((base + y1 * pw + x0) * rs + p.res_ch_off) * 4; o11 = ((base + y1 * pw + x1) * rs + p.res_ch_off) * 4;
       rres = make_rsrc(p.residual, (unsigned)((long long)p.B * ph * pw * rs * 4));
+      // a block that lies inside ONE image row (wave-uniform): its pixels tap the same two low-resolution rows (blended while they are
+      // staged) and <= 18 columns -- whole-pixel loads (lanes side by side, 128 TN bytes per pixel) into LDS instead of 4 x 4 TN
+      // gathers of 16 bytes per lane, every one of which touches 32 different cache lines
+      const int r0 = (int)(m0 % hw), xb0 = r0 % p.W;
+      staged = rows == 32 && xb0 + 32 <= p.W;
+      if (staged) {
+        const int bb = (int)(m0 / hw), yb = r0 / p.W;
+        float syb = 0.5f * (yb + 0.5f) - 0.5f; syb = syb < 0.f ? 0.f : syb;
+        const int yb0 = (int)syb, yb1 = yb0 + (yb0 < ph - 1 ? 1 : 0);
+        const float lyb = syb - yb0;
+        float sxb = 0.5f * (xb0 + 0.5f) - 0.5f; sxb = sxb < 0.f ? 0.f : sxb;
+        const int cb = (int)sxb;                                  // first column tapped by the block
+        constexpr int VPP = 8 * TN;                              // 16-byte vectors per pixel
+        for (int it = lane; it < UPC * VPP; it += 64) {
+          const int cc = it / VPP, c4 = it - cc * VPP;
+          const int gx = cb + cc < pw ? cb + cc : pw - 1;
+          const int n = nt0 * 32 + c4 * 4;
+          const int o0 = n < p.Cout_store ? (((bb * ph + yb0) * pw + gx) * rs + p.res_ch_off + n) * 4 : (int)OOB;
+          const int o1 = n < p.Cout_store ? (((bb * ph + yb1) * pw + gx) * rs + p.res_ch_off + n) * 4 : (int)OOB;
+          const f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, o0, 0, 0));
+          const f32x4 rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, o1, 0, 0));
+          *(f32x4*)&patch[cc * UPP + c4 * 4] = (1.f - lyb) * ra + lyb * rb;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // one wave: its own LDS writes are visible to its own reads
+        o00 = ((x0 - cb) * UPP) * 4; o01 = ((x1 - cb) * UPP) * 4;
+        w00 = 1.f - lx; w01 = lx;
+      } else {
+        o00 = ((base + y0 * pw + x0) * rs + p.res_ch_off) * 4; o01 = ((base + y0 * pw + x1) * rs + p.res_ch_off) * 4;
+        o10 = ((base + y1 * pw + x0) * rs + p.res_ch_off) * 4; o11 = ((base + y1 * pw + x1) * rs + p.res_ch_off) * 4;
+      }
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -153,12 +186,17 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
           v[e] = fmaxf(t, t * slope);
         }
         if constexpr (UP) {
+          if (staged) {
+            const char* pb = (const char*)patch + (tn * 32 + 8 * j + 4 * kq) * 4;
+            v += w00 * *(const f32x4*)(pb + o00) + w01 * *(const f32x4*)(pb + o01);
+          } else {
           const bool on = pix_ok && n < p.Cout_store;
           const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o00 + n * 4 : (int)OOB, 0, 0));
           const f32x4 b_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o01 + n * 4 : (int)OOB, 0, 0));
           const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o10 + n * 4 : (int)OOB, 0, 0));
           const f32x4 d_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, on ? o11 + n * 4 : (int)OOB, 0, 0));
           v += w00 * a + w01 * b_ + w10 * c + w11 * d_;
+          }
         }
         const int off = n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, off, 0, 0);
@@ -356,16 +394,18 @@ extern "C" int egne_conv1x1_f16x3_fwd(const egne_conv_desc* dp, const void* fhi,
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   if (up) {
+    const size_t lds_up = lds + (size_t)4 * 18 * (32 * TN + 8) * sizeof(float);       // + a patch of the addend per wave
+    EGNE_REQUIRE(lds_up <= 80 * 1024, "conv1x1_f16: K = %d groups of 16 leaves no room for the addend patches", G);
     static bool once_up = [] {
       return hipFuncSetAttribute((const void*)conv1x1_f16x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
              hipFuncSetAttribute((const void*)conv1x1_f16x3_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     }();
     if (!once_up) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_f16: cannot raise the dynamic LDS limit");
     if (TN == 1)
-      hipLaunchKernelGGL((conv1x1_f16x3_kernel<1, true>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+      hipLaunchKernelGGL((conv1x1_f16x3_kernel<1, true>), dim3((unsigned)gx, ny), dim3(256), lds_up, st, d, (const _Float16*)fhi, (const _Float16*)flo,
                          a_scale, os, G, M, (int)nb);
     else
-      hipLaunchKernelGGL((conv1x1_f16x3_kernel<2, true>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+      hipLaunchKernelGGL((conv1x1_f16x3_kernel<2, true>), dim3((unsigned)gx, ny), dim3(256), lds_up, st, d, (const _Float16*)fhi, (const _Float16*)flo,
                          a_scale, os, G, M, (int)nb);
   } else if (TN == 1)
     hipLaunchKernelGGL((conv1x1_f16x3_kernel<1>), dim3((unsigned)gx, ny), dim3(256), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
