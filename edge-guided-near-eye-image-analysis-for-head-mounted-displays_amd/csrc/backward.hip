@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const T* __restrict__ x,
         const long long q = p + ROWS * u;
         const bool ok = q < p1;
         xv4[u] = ok ? ldv(x + (nb + q) * xs + xo + c) : fv_fill<N>(0.f);
-        if (poolW) {
-          const int py = (int)(q / poolW), px = (int)(q - (long long)py * poolW);
+        if (poolW) {       // (q < H W < 2^31: 32-bit division -- the 64-bit one was most of this kernel's instructions)
+          const unsigned uq = (unsigned)q, py = uq / (unsigned)poolW, px = uq - py * (unsigned)poolW;
           g4[u] = ok ? ldv(gy + ((nb >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c) : fv_fill<N>(0.f);
 #pragma unroll
           for (int e = 0; e < N; ++e) g4[u].v[e] *= 0.25f;
@@ -271,21 +271,23 @@ __global__ void norm_bwd_apply(const T* __restrict__ x, long long xs, int xo, co
                                long long npix_per_n, int Bn, int per_sample, const float* __restrict__ sums,
                                T* __restrict__ gx, long long gxs, int gxo, int poolW, int accumulate) {
   constexpr int N = egne_vt<T>::N;
-  const int nv = Cp / N;
-  const long long total = (long long)Bn * npix_per_n * nv;
+  // grid.y = sample (1 for batch statistics): inside a sample every index fits 32 bits (checked by the entry point) -- the flat
+  // 64-bit index cost three 64-bit divisions per vector, most of the instructions of the pooled variant
+  const unsigned nv = (unsigned)(Cp / N);
+  const unsigned total = (unsigned)npix_per_n * nv;
   const float invN = 1.f / (float)npix_per_n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % nv) * N;
-    const long long pp = i / nv;               // global pixel index over (n, p)
-    const int n = per_sample ? (int)(pp / npix_per_n) : 0;
+  const int n = blockIdx.y;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / nv;
+    const int c = (int)(i - p * nv) * N;
+    const long long pp = (long long)n * npix_per_n + p;               // global pixel index over (n, p)
     const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c);
     const egne_fv<N> sh = ldf<N>(shift + (long long)n * Cp + c);
     const egne_fv<N> xv = ldv(x + pp * xs + xo + c);
     egne_fv<N> g;
     float gsc = 1.f;
     if (poolW) {      // per_sample mode, even H and W (checked by the entry point)
-      const long long p = pp - (long long)n * npix_per_n;
-      const int py = (int)(p / poolW), px = (int)(p - (long long)py * poolW);
+      const unsigned py = p / (unsigned)poolW, px = p - py * (unsigned)poolW;
       g = ldv(gy + (((long long)n * npix_per_n >> 2) + (long long)(py >> 1) * (poolW >> 1) + (px >> 1)) * gs + go + c);
       gsc = 0.25f;
     } else {
@@ -1046,7 +1048,9 @@ static int norm_bwd_impl(const T* x, int64_t xs, int xo, const float* scale, con
                      gy, (long long)gs, go, act_in, Cp, npix, nchunk, per_sample, (double*)ws, poolW);
   hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, Bn), dim3(1024), 0, st, (const double*)ws, Cp, Bn, nchunk, sums,
                      dgamma, dbeta, C);
-  hipLaunchKernelGGL(norm_bwd_apply<T>, dim3(grid_for((long long)Bn * npix * (Cp / egne_vt<T>::N))), dim3(256), 0, st, x, (long long)xs, xo,
+  EGNE_REQUIRE(npix * (Cp / egne_vt<T>::N) < (1ll << 32) && Bn <= 65535, "norm_bwd: more than 2^32 vectors per statistics group");
+  const long long gxa = grid_for((long long)Bn * npix * (Cp / egne_vt<T>::N));
+  hipLaunchKernelGGL(norm_bwd_apply<T>, dim3((unsigned)((gxa + Bn - 1) / Bn), Bn), dim3(256), 0, st, x, (long long)xs, xo,
                      scale, shift, gamma, gy, (long long)gs, go, act_in, Cp, npix, Bn, per_sample, sums, gx, (long long)gxs,
                      gxo, poolW, accumulate);
   return egne::check_launch("egne_norm_bwd");
