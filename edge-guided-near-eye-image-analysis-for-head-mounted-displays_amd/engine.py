@@ -749,13 +749,14 @@ class Plan:
                 and layer.pad == (1, 1) and layer.dils == (4, 8, 12) and layer.CoutP == 32 and piece.Cp == 32 and piece.scale is None
                 and layer.act == ACT_RELU and layer.post is None and H * W * piece.stride < 2 ** 29)
 
-    def stream1x1_ok(self, layer, pieces, B, H, W):
+    def stream1x1_ok(self, layer, pieces, B, H, W, up_add=False):
         """True if ``conv`` runs this 1x1 over raw slices on the streaming split-f16 kernel (weights in LDS, operands straight from
         HBM: conv1x1_f16.hip) -- the kernel that can add an up-sampled half-resolution tensor in its epilogue (``up_add``)."""
         return (F16X3_ENABLED and S1X1_ENABLED and not self.bf16 and not self.dyn_scales and layer.split1 and layer.kh == 1 and layer.kw == 1
                 and layer.stride == 1 and layer.G == 1 and layer.pad == (0, 0) and layer.post is None
                 and all(pc.scale is None for pc in pieces) and (layer.CoutP == 32 or layer.CoutP % 64 == 0)
-                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048 <= 80 * 1024
+                and sum((pc.Cp + 15) // 16 for pc in pieces) * (1 if layer.CoutP == 32 else 2) * 2048
+                + (4 * 18 * (32 * (1 if layer.CoutP == 32 else 2) + 8) * 4 if up_add else 0) <= 80 * 1024       # (+ the addend patch of each wave)
                 and B * H * W >= S1X1_MIN_PIX)
 
     def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None, pool=None, up_add=None):

@@ -344,7 +344,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
         full = [types.SimpleNamespace(C=p.C, Cp=pad8(p.C), scale=None) for p in prev] + skip
         l11f, l21f = _cl(ub.conv11, _lay(full)), _cl(ub.conv21, _lay(full + [x1]))
         fold_up_s = (FOLD_UP and FOLD_UP_STREAM and not training and not fold_up and variant != "concat"
-                     and pl.stream1x1_ok(l11s, skip, B, h, w) and pl.stream1x1_ok(l21s, skip + [x1], B, h, w)
+                     and pl.stream1x1_ok(l11s, skip, B, h, w, up_add=True) and pl.stream1x1_ok(l21s, skip + [x1], B, h, w, up_add=True)
                      and pl.stream1x1_ok(l11f, full, B, h, w) and pl.stream1x1_ok(l21f, full + [x1], B, h, w))
         if fold_up_s:
             wp = torch.zeros(2 * ocp, Cl, 1, 1, device=dev)
