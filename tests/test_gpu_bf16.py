@@ -293,6 +293,51 @@ def test_style_encoder_layers_bf16_storage(G, case, Cin, Cout, k, stride, P, H, 
         assert "conv_bf16:narrow" in kinds, kinds
 
 
+@pytest.mark.parametrize("case,chans,Cout,k,stride,P,H,W", [("3x3 over two slices", (64, 32), 32, 3, 1, 1, 48, 64), ("3x3 over two slices, small map", (64, 32), 32, 3, 1, 1, 24, 32),
+                                                          ("2x2 stride 2", (32,), 64, 2, 2, 0, 96, 128), ("2x2 stride 2, small map", (64,), 128, 2, 2, 0, 24, 32),
+                                                          ("3x3 over two wide slices", (256, 128), 256, 3, 1, 1, 30, 40)])
+def test_generic_conv_layers_of_the_comparator_bf16_storage(G, case, chans, Cout, k, stride, P, H, W):
+    """The convolution shapes of models/deepvog_pytorch.py as a bf16-storage training plan would run them -- zero-padded 3x3 over the
+    concatenation of two slices (torch.cat((x, skip)), :66) and the 2x2 / stride-2 down-sampling convolution -- forward and backward
+    on the generic implicit GEMM / weight gradient (bf16 MFMA on maps of >= 1024 pixels, exact fp32 below) against float64 autograd
+    on the bf16-representable tensors."""
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    B = 2
+    xs = [_q(_rand(G, B, c, H, W)) for c in chans]
+    Cin = sum(chans)
+    w, b = _rand(G, Cout, Cin, k, k) / (k * Cin ** 0.5), _rand(G, Cout) * 0.1
+    pl = _plan()
+    pl.train = True
+    pieces = _pieces(pl, xs, B, H, W)
+    wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    wp.grad, bp.grad = torch.zeros_like(wp), torch.zeros_like(bp)
+    layer = ConvLayer([wp], [bp], [(p.C, p.Cp) for p in pieces], stride=stride, pad=(P, P), act=0)
+    Ho, Wo = layer.out_hw(H, W)
+    gy = _q(_rand(G, B, Cout, Ho, Wo) * 1e-3)
+    out = pl.buf(B, Ho, Wo, pad8(Cout))
+    pl.conv(layer, pieces, Piece(out, 0, Cout), B, H, W, name="c")
+    bw = pl.build_backward()
+    pl.run()
+    pl.zero_grads()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    xd = [x.double().requires_grad_(True) for x in xs]
+    wd, bd = (_q(w) if Ho * Wo >= 1024 else w).double().requires_grad_(True), b.double().requires_grad_(True)
+    z = F.conv2d(torch.cat(xd, 1), wd, bd, stride=stride, padding=P)
+    _check(out.float().cpu()[..., :Cout].permute(0, 3, 1, 2).double(), z.detach(), case + ": forward")
+    z.backward(gy.double())
+    e = (wp.grad.double().cpu() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+    eb = (bp.grad.double().cpu() - gy.double().sum((0, 2, 3))).abs().max().item() / gy.double().sum((0, 2, 3)).abs().max().item()
+    exs = []
+    for pc, x_ in zip(pieces, xd):
+        gx = pl.gbuf(pc.buf).float().cpu()[..., pc.off:pc.off + pc.C].permute(0, 3, 1, 2).double()
+        exs.append((gx - x_.grad).abs().max().item() / x_.grad.abs().max().item())
+    print("%s: weight gradient %.2e, bias gradient %.2e, data gradients %s; kinds %s / %s" % (case, e, eb, ["%.2e" % v for v in exs],
+          [m[0] for m in pl.meta], sorted({m[0] for m in bw.meta})))
+    assert e < 3e-3 and eb < 1e-4 and max(exs) < 2 * EPS
+
+
 def test_elementwise_twins_match_the_fp32_kernels(G):
     """Every bf16 twin reads / writes bf16 and computes as its fp32 original: run both on the same bf16-representable data and
     compare (the twin's result may differ by one bf16 rounding of the OUTPUT; statistics and parameter gradients are fp32 on
