@@ -1031,6 +1031,166 @@ extern "C" int egne_act_bwd_bias_bf16(void* g, int64_t gs, int go, const void* y
   return act_bwd_bias_impl((egne_bf16*)g, gs, go, (const egne_bf16*)y, ys, yo, act, Cp, npix, dbias, C, accumulate, ws, (uint32_t*)nullptr, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bias gradient of the 1x1 in front of a 3x3 (the dense blocks' activation-free 'a' layer): db_a = sum_q g_tmp[q] with g_tmp the 3x3's
+// data gradient.  That sum is linear in gz_b (the 3x3's masked output gradient):
+//     sum_q g_tmp[q][c] = sum_{co,tap} W_b[co][c][tap] * S_tap[co],    S_tap[co] = sum of gz_b[.][co] over the pixels p with p + tap
+// inside the image = the per-channel total T (which act_bwd_bias of the 3x3 has just left in its chunk workspace) minus one border
+// row, one border column, plus their corner.  Two small launches replace a pass over the full-resolution g_tmp.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pair_border_k(const T* __restrict__ g, long long gs, int go, int Cs, int H, int W,
+                                                     double* __restrict__ part) {       // part[b][8][Cs]
+  // blockIdx.y = 0: first / last row (+ the four corners), 1: first / last column.  One 16-byte vector per lane and pixel.
+  constexpr int N = egne_vt<T>::N;
+  __shared__ float red[2 * 256 * N];
+  const int cv = Cs / N, np = 256 / cv, v = threadIdx.x % cv, pt = threadIdx.x / cv, cols = blockIdx.y;
+  const T* fb = g + (long long)blockIdx.x * H * W * gs + go;
+  const long long step = cols ? (long long)W * gs : gs, last = cols ? (long long)(W - 1) * gs : (long long)(H - 1) * W * gs;
+  const int n = cols ? H : W;
+  egne_fv<N> a = fv_fill<N>(0.f), b = fv_fill<N>(0.f);
+  if (pt < np) {
+#pragma unroll 2
+    for (int i = pt; i < n; i += np) {
+      const egne_fv<N> u = ldv(fb + i * step + v * N), w = ldv(fb + i * step + last + v * N);
+#pragma unroll
+      for (int k = 0; k < N; ++k) { a.v[k] += u.v[k]; b.v[k] += w.v[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      red[(pt * 2) * Cs + v * N + k] = a.v[k];
+      red[(pt * 2 + 1) * Cs + v * N + k] = b.v[k];
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < Cs) {
+    const int co = threadIdx.x;
+    double s0 = 0, s1 = 0;
+    for (int q = 0; q < np; ++q) { s0 += red[(q * 2) * Cs + co]; s1 += red[(q * 2 + 1) * Cs + co]; }
+    double* o = part + (long long)blockIdx.x * 8 * Cs + co;
+    o[(2 * cols) * Cs] = s0;
+    o[(2 * cols + 1) * Cs] = s1;
+    if (!cols) {
+      o[4 * Cs] = ld1(fb + co);
+      o[5 * Cs] = ld1(fb + (long long)(W - 1) * gs + co);
+      o[6 * Cs] = ld1(fb + (long long)(H - 1) * W * gs + co);
+      o[7 * Cs] = ld1(fb + ((long long)H * W - 1) * gs + co);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void pair_bias_final_k(const double* __restrict__ ws, int nchunk, const double* __restrict__ part,
+                                                          int B, int Cs, int Cout, int Ca, const float* __restrict__ w,
+                                                          float* __restrict__ db_b, float* __restrict__ db_a) {
+  __shared__ double red[32][32];
+  __shared__ double Tl[256], E[8 * 256], S[9 * 256];
+  const int tid = threadIdx.x, c = tid & 31, q = tid >> 5;
+  for (int c0 = 0; c0 < Cs; c0 += 32) {                 // T = the 3x3's per-channel total, reduced as reduce_chunks_k does
+    double s = 0;
+    if (c0 + c < Cs) {
+      const double* wc = ws + c0 + c;
+      int k = q;
+      for (; k + 224 < nchunk; k += 256) {              // eight independent loads in flight (the workspace is L2 / HBM latency bound)
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = wc[(long long)(k + 32 * j) * Cs];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += t[j];
+      }
+      for (; k < nchunk; k += 32) s += wc[(long long)k * Cs];
+    }
+    red[q][c] = s;
+    __syncthreads();
+    if (q == 0 && c0 + c < Cs) {
+      double t = 0;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) t += red[r][c];
+      Tl[c0 + c] = t;
+    }
+    __syncthreads();
+  }
+  const int Ne = 8 * Cs, nr = Ne >= 1024 ? 1 : 1024 / Ne;     // border sums over the frames: nr interleaved frame ranges per element
+  if (nr == 1) {
+    for (int e = tid; e < Ne; e += 1024) {
+      double s = 0;
+#pragma unroll 4
+      for (int b = 0; b < B; ++b) s += part[(long long)b * Ne + e];
+      E[e] = s;
+    }
+  } else {
+    const int r = tid / Ne, e = tid - r * Ne;
+    if (r < nr) {
+      double s = 0;
+#pragma unroll 4
+      for (int b = r; b < B; b += nr) s += part[(long long)b * Ne + e];
+      S[r * Ne + e] = s;                                      // (S is free until the taps are formed below)
+    }
+    __syncthreads();
+    if (tid < Ne) {
+      double s = 0;
+      for (int k = 0; k < nr; ++k) s += S[k * Ne + tid];
+      E[tid] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * Cout; i += 1024) {
+    const int tap = i / Cout, co = i - tap * Cout, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    double s = Tl[co];
+    if (dy) s -= E[(dy > 0 ? 1 : 0) * Cs + co];
+    if (dx) s -= E[(dx > 0 ? 3 : 2) * Cs + co];
+    if (dy && dx) s += E[(4 + (dy > 0 ? 2 : 0) + (dx > 0 ? 1 : 0)) * Cs + co];
+    S[tap * 256 + co] = s;
+  }
+  __syncthreads();
+  if (db_b)
+    for (int co = tid; co < Cout; co += 1024) db_b[co] += (float)Tl[co];
+  // db_a[ca] = sum_{co,tap} w[co][ca][tap] * S[tap][co]: Ca lanes x (1024 / Ca) interleaved co ranges, summed in a fixed order
+  double* acc = E;                                      // E is dead now (S holds what the products need); 1024 doubles fit its 2048
+  const int np = 1024 / Ca, ca = tid % Ca, pt = tid / Ca;
+  if (pt < np) {
+    double s = 0;
+    for (int co = pt; co < Cout; co += np) {
+      const float* wr = w + ((long long)co * Ca + ca) * 9;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) s += (double)wr[tap] * S[tap * 256 + co];
+    }
+    acc[pt * Ca + ca] = s;
+  }
+  __syncthreads();
+  if (pt == 0) {
+    double s = 0;
+    for (int r = 0; r < np; ++r) s += acc[r * Ca + ca];
+    db_a[ca] += (float)s;
+  }
+}
+
+extern "C" int64_t egne_pair_bias_bwd_workspace_bytes(int B, int Cp) { return (int64_t)B * 8 * Cp * sizeof(double); }
+
+template <typename T>
+static int pair_bias_impl(const T* g, int64_t gs, int go, int Cp, int B, int H, int W, const void* act_ws, const float* w, int Cout,
+                          int Ca, float* db_b, float* db_a, void* ws, void* stream) {
+  EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && B > 0 && H > 0 && W > 0, "pair_bias_bwd: bad gradient slice");
+  EGNE_REQUIRE(Cp <= 256 && Cout > 0 && Cout <= Cp && Ca > 0 && Ca <= 256, "pair_bias_bwd: at most 256 channels on either side of the 3x3");
+  EGNE_REQUIRE(act_ws && w && db_a && ws && ((uintptr_t)ws & 7) == 0, "pair_bias_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = chunks_for((long long)B * H * W, Cp, 1);
+  EGNE_REQUIRE(vec_ok<T>(gs, go, Cp), "pair_bias_bwd: the slice must be 16-byte vectors (8 bf16 channels)");
+  hipLaunchKernelGGL(pair_border_k<T>, dim3(B, 2), dim3(256), 0, st, g, (long long)gs, go, Cp, H, W, (double*)ws);
+  hipLaunchKernelGGL(pair_bias_final_k, dim3(1), dim3(1024), 0, st, (const double*)act_ws, nchunk, (const double*)ws, B, Cp, Cout, Ca,
+                     w, db_b, db_a);
+  return egne::check_launch("egne_pair_bias_bwd");
+}
+// g: the 3x3's masked output gradient AFTER egne_act_bwd_bias(..., dbias = NULL, ws = act_ws) (same npix = B*H*W, same Cp);
+// w: the 3x3's fp32 OIHW weights [Cout][Ca][3][3]; db_b (may be NULL) += T, db_a += the 1x1's bias gradient.
+extern "C" int egne_pair_bias_bwd(const float* g, int64_t gs, int go, int Cp, int B, int H, int W, const void* act_ws, const float* w,
+                                  int Cout, int Ca, float* db_b, float* db_a, void* ws, void* stream) {
+  return pair_bias_impl(g, gs, go, Cp, B, H, W, act_ws, w, Cout, Ca, db_b, db_a, ws, stream);
+}
+extern "C" int egne_pair_bias_bwd_bf16(const void* g, int64_t gs, int go, int Cp, int B, int H, int W, const void* act_ws, const float* w,
+                                       int Cout, int Ca, float* db_b, float* db_a, void* ws, void* stream) {
+  return pair_bias_impl((const egne_bf16*)g, gs, go, Cp, B, H, W, act_ws, w, Cout, Ca, db_b, db_a, ws, stream);
+}
+
 extern "C" int64_t egne_norm_bwd_workspace_bytes(int B, int HW, int Cp, int per_sample) {
   const int Bn = per_sample ? B : 1;
   const long long npix = per_sample ? HW : (long long)B * HW;

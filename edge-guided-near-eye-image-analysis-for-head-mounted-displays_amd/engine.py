@@ -53,6 +53,10 @@ ESF_SPLIT = os.environ.get("EGNE_ESF_SPLIT", "1") != "0"      # split-f16 kernel
 #   3x3 forward convolutions, data and weight gradients under TRAIN_SPLIT (pre-scales from device-side maxima)
 ZERO_SKIP = os.environ.get("EGNE_ZERO_SKIP", "1") != "0"           # no zero pass for gradient buffers whose accesses are all covered by full-batch stores
 FIRST_WRITER = os.environ.get("EGNE_FIRST_WRITER", "1") != "0"     # data gradients: the first writer of a gradient slice stores instead of accumulating
+# bias gradient of the dense blocks' activation-free 1x1 'a' layers from the border sums of the following 3x3's output gradient
+# (egne_pair_bias_bwd) instead of a pass over the 3x3's full-resolution data gradient
+PAIR_BIAS = os.environ.get("EGNE_PAIR_BIAS", "1") != "0"
+PAIR_BIAS_SIDE = os.environ.get("EGNE_PAIR_BIAS_SIDE", "1") != "0"    # its two small launches on the plan's second stream
 MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
 WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
 WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "0") != "0"   # weight gradients on a second stream (measured: no gain, 433.6 vs 434.0 frames/s at B=64 -- either kernel fills the LDS of every CU, so they do not co-reside)
@@ -594,6 +598,7 @@ class Plan:
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT and not self.bf16     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
+        self._pair_links = {}                         # 1x1 -> 3x3 pairs whose bias gradients share one reduction (_bw_conv)
         self._touching, self._touched = False, {}     # build_backward: channel ranges of gradient twins already handed out
         self.side_calls, self.side_stream = {}, None   # call index -> event: launches on the plan's second stream (weight gradients; the edge network's MSBlocks)
         self.side_default = False                      # _add: launches emitted while this is set go to the second stream
@@ -1316,6 +1321,11 @@ class Plan:
         if not fused:
             if tmp is None:
                 tmp = Piece(self.buf(B, H, W, pad8(l1.Cout)), 0, l1.Cout)
+            if (PAIR_BIAS and self.train and l1.act == ACT_NONE and l1.biases is not None and l2.biases is not None and l1.G == 1
+                    and l2.G == 1 and l2.kh == 3 and l2.kw == 3 and l2.pad == (1, 1) and l2.dils[0] == 1 and l2.stride == 1
+                    and l2.pad_mode == 0 and l1.Cout <= 256 and pad8(l2.Cout) <= 256 and l2.Cin == l1.Cout):
+                self._pair_links[id(l1)] = l2         # _bw_conv: the 'a' bias gradient comes from b's output gradient
+                self._pair_links[id(l2)] = l1
             self.conv(l1, pieces, tmp, B, H, W, name=name + ".a")
             return self.conv(l2, [tmp], dst, B, H, W, residual=residual, name=name + ".b", stats=stats)
         for p, (c, cp) in zip(pieces, l1.in_layout):
@@ -1479,14 +1489,25 @@ class Plan:
             else:
                 split_wgrad = False
         gz_max = bw._new_slot() if (split_dgrad or split_wgrad) else None     # max |gz| for the split-f16 gradients, from this pass
-        if self.bf16:
+        peer = self._pair_links.get(id(layer))
+        lead = peer is not None and layer.kh == 3            # the pair's 3x3: its chunk sums feed both bias gradients
+        dbias = bias.grad.data_ptr() if bias is not None and not lead else None
+        if peer is not None and not lead:
+            pass                                             # the pair's 1x1: no activation to mask, bias gradient already taken (below)
+        elif self.bf16:
             bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
-                                         bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr()),
-                   name + ".act_bwd")
+                                         dbias, layer.Cout, 1, ws.data_ptr()), name + ".act_bwd")
         else:
             bw.raw(L.egne_act_bwd_bias_absmax, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
-                                                bias.grad.data_ptr() if bias is not None else None, layer.Cout, 1, ws.data_ptr(), gz_max),
-                   name + ".act_bwd")
+                                                dbias, layer.Cout, 1, ws.data_ptr(), gz_max), name + ".act_bwd")
+        if lead:
+            # both bias gradients of the 1x1 -> 3x3 pair from this layer's chunk sums (still in L2) and border sums
+            wsp = bw.vec((int(L.egne_pair_bias_bwd_workspace_bytes(B, Cs)) + 7) // 8, dtype=torch.float64)
+            w3 = layer.weights[0]
+            assert w3.is_contiguous() and tuple(w3.shape) == (layer.Cout, peer.Cout, 3, 3) and (Ho, Wo) == (H, W)
+            bw._add(L.egne_pair_bias_bwd, (gy.ptr, gy.stride, gy.off, Cs, B, Ho, Wo, ws.data_ptr(), w3.data_ptr(), layer.Cout, peer.Cout,
+                                           bias.grad.data_ptr(), peer.biases[0].grad.data_ptr(), wsp.data_ptr()), name + ".pair_bias",
+                    kind="egne_pair_bias_bwd", side=PAIR_BIAS_SIDE)
         w = layer.weights[0]
         assert layer.G == 1 and w.grad is not None and w.grad.is_contiguous()
         gw = (C.c_void_p * 1)(w.grad.data_ptr())

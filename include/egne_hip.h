@@ -468,6 +468,15 @@ int egne_act_bwd_bias_absmax(float* g, int64_t gs, int go, const float* y, int64
                              int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits, void* stream);
 int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
                       int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream);
+/* Bias gradient of an activation-free 1x1 that feeds a 3x3 (stride 1, zero pad 1) -- the 'a' layer of the reference's dense-block
+ * pairs (RITnet_v2.py:145-156 conv1x1 -> conv3x3) -- without a pass over the 3x3's data gradient g_tmp: sum_q g_tmp[q][ca] =
+ * sum_{co,tap} w[co][ca][tap] * S_tap[co], S_tap = the 3x3's per-channel gradient total minus the border row / column the tap
+ * cannot reach.  g: the 3x3's masked output gradient after egne_act_bwd_bias(..., dbias = NULL, ws = act_ws) over the same
+ * B*H*W pixels and Cp channels (its chunk sums are read from act_ws); w: fp32 OIHW [Cout][Ca][3][3]; db_b (may be NULL) += the
+ * 3x3's bias gradient, db_a += the 1x1's.  ws: egne_pair_bias_bwd_workspace_bytes(B, Cp) bytes, 8-byte aligned.  Cp, Ca <= 256. */
+int64_t egne_pair_bias_bwd_workspace_bytes(int B, int Cp);
+int egne_pair_bias_bwd(const float* g, int64_t gs, int go, int Cp, int B, int H, int W, const void* act_ws, const float* w,
+                       int Cout, int Ca, float* db_b, float* db_a, void* ws, void* stream);
 
 /* Backward of the normalisation that the forward fused into a conv's load (InstanceNorm, per_sample=1)
  * or of training-mode BatchNorm (per_sample=0, gamma/dgamma/dbeta given): xh = x*scale+shift,
@@ -602,6 +611,8 @@ int egne_conf_loss_bf16(const void* pred, int ld, const int64_t* gt, int B, int 
 int egne_loss_bwd_bf16(const egne_loss_desc* d, const float* gscale, void* g_logits, int64_t gs, int go, float* g_elOut, void* stream);
 int egne_act_bwd_bias_bf16(void* g, int64_t gs, int go, const void* y, int64_t ys, int yo, int act, int Cp, int64_t npix,
                            float* dbias, int C, int accumulate, void* ws, void* stream);
+int egne_pair_bias_bwd_bf16(const void* g, int64_t gs, int go, int Cp, int B, int H, int W, const void* act_ws, const float* w,
+                            int Cout, int Ca, float* db_b, float* db_a, void* ws, void* stream);
 int egne_norm_bwd_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, const float* gamma,
                        const void* gy, int64_t gs, int go, int act_in, int Cp, int B, int HW, int per_sample, void* gx,
                        int64_t gxs, int gxo, float* sums, float* dgamma, float* dbeta, int C, void* ws, void* stream);

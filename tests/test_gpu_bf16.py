@@ -417,6 +417,43 @@ def test_elementwise_twins_match_the_fp32_kernels(G):
     assert Plan(torch.device(DEV), dtype=BF).L.egne_norm_stats._name_ if hasattr(L.egne_norm_stats, "_name_") else True
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cout,Ca,slice_", [(3, 24, 40, 32, 32, False), (2, 15, 20, 40, 24, True), (2, 1, 9, 8, 8, False),
+                                                  (1, 7, 1, 16, 40, False), (5, 60, 80, 64, 64, False)])
+def test_pair_bias_gradient_from_border_sums(B, H, W, Cout, Ca, slice_):
+    """egne_pair_bias_bwd: the bias gradient of a 1x1 that feeds a 3x3 -- the sum over pixels of the 3x3's data gradient -- from the
+    3x3's chunk sums and border sums, against the explicit sum over conv_transpose2d (float64), for both storages; the 3x3's own
+    bias gradient comes out of the same call."""
+    from egne_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(B * 100 + H)
+    Cs = (Cout + 7) // 8 * 8
+    Ct = Cs + 16 if slice_ else Cs
+    off = 8 if slice_ else 0
+    st = _lib.stream_ptr()
+    w = torch.randn(Cout, Ca, 3, 3, device=DEV) * 0.2
+    for dt in (torch.float32, BF):
+        full = torch.randn(B, H, W, Ct, device=DEV).to(dt)
+        full[..., off + Cout:off + Cs] = 0                      # padding channels hold zeros in a plan
+        gz = full[..., off:off + Cout].double().permute(0, 3, 1, 2)
+        want_a = torch.nn.functional.conv_transpose2d(gz, w.double(), padding=1).sum(dim=(0, 2, 3))
+        want_b = gz.sum(dim=(0, 2, 3))
+        ws = torch.zeros(int(L.egne_act_bwd_bias_workspace_bytes(B * H * W, Cs)) // 8 + 1, dtype=torch.float64, device=DEV)
+        wsp = torch.zeros(int(L.egne_pair_bias_bwd_workspace_bytes(B, Cs)) // 8 + 1, dtype=torch.float64, device=DEV)
+        act = L.egne_act_bwd_bias if dt == torch.float32 else L.egne_act_bwd_bias_bf16
+        pair = L.egne_pair_bias_bwd if dt == torch.float32 else L.egne_pair_bias_bwd_bf16
+        da, db = torch.full((Ca,), 2.0, device=DEV), torch.full((Cout,), -1.0, device=DEV)       # both accumulate
+        before = full.clone()
+        _lib.check(act(full.data_ptr(), Ct, off, None, 0, 0, 0, Cs, B * H * W, None, Cout, 1, ws.data_ptr(), st))
+        _lib.check(pair(full.data_ptr(), Ct, off, Cs, B, H, W, ws.data_ptr(), w.data_ptr(), Cout, Ca, db.data_ptr(), da.data_ptr(),
+                        wsp.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(full, before)
+        sa, sb = want_a.abs().max().item() + 1e-6, want_b.abs().max().item() + 1e-6
+        assert (da.double() - 2.0 - want_a).abs().max().item() <= 2e-6 * sa + 1e-5, (dt, B, H, W)
+        assert (db.double() + 1.0 - want_b).abs().max().item() <= 2e-6 * sb + 1e-5, (dt, B, H, W)
+
+
 NET_CASES = ["esf_edge_b2", "esf_baseline_b2", "esf_concat_b2", "esf_edge_b2_absent1", "esf_adain_edge_b2", "esf_adain_b2_train",
              "esf_adain_edge_detach_b2"]
 
