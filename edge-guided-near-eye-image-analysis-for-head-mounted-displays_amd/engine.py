@@ -56,6 +56,7 @@ FIRST_WRITER = os.environ.get("EGNE_FIRST_WRITER", "1") != "0"     # data gradie
 # bias gradient of the dense blocks' activation-free 1x1 'a' layers from the border sums of the following 3x3's output gradient
 # (egne_pair_bias_bwd) instead of a pass over the 3x3's full-resolution data gradient
 PAIR_BIAS = os.environ.get("EGNE_PAIR_BIAS", "1") != "0"
+ZERO_AHEAD = os.environ.get("EGNE_ZERO_AHEAD", "1") != "0"            # gradient twins zeroed behind the previous backward, on their own stream
 PAIR_BIAS_SIDE = os.environ.get("EGNE_PAIR_BIAS_SIDE", "1") != "0"    # its two small launches on the plan's second stream
 MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
 WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
@@ -598,6 +599,7 @@ class Plan:
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT and not self.bf16     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
+        self._zstream, self._zevent, self._zero_pending = None, None, False      # zero_grads_ahead
         self._pair_links = {}                         # 1x1 -> 3x3 pairs whose bias gradients share one reduction (_bw_conv)
         self._touching, self._touched = False, {}     # build_backward: channel ranges of gradient twins already handed out
         self.side_calls, self.side_stream = {}, None   # call index -> event: launches on the plan's second stream (weight gradients; the edge network's MSBlocks)
@@ -684,6 +686,28 @@ class Plan:
         ts = [t for bid, t in self.gtwins.items() if bid not in free]
         if ts:
             torch._foreach_zero_(ts)
+
+    def zero_grads_ahead(self):
+        """Zero the gradient twins for the NEXT backward pass on a stream of their own, behind everything queued so far: nothing
+        reads a twin between two backward passes, so the 0.7 ms of fills overlap the optimiser step and the next forward (the
+        frozen edge network is MFMA bound) instead of opening the next backward."""
+        if not ZERO_AHEAD:
+            return
+        if self._zstream is None:
+            self._zstream, self._zevent = torch.cuda.Stream(device=self.device), torch.cuda.Event()
+        self._zstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._zstream):
+            self.zero_grads()
+        self._zevent.record(self._zstream)
+        self._zero_pending = True
+
+    def zero_grads_join(self):
+        """Before a backward pass: wait for the fills queued by zero_grads_ahead, or zero now if there were none."""
+        if self._zero_pending:
+            torch.cuda.current_stream().wait_event(self._zevent)
+            self._zero_pending = False
+        else:
+            self.zero_grads()
 
     # ---- launches ----------------------------------------------------------------------------
     DYN_SLOTS = 512

@@ -123,9 +123,10 @@ class _ESFFunction(torch.autograd.Function):
             return None, None, None
         model, pl = ctx.model, ctx.pl
         model._ensure_grad_arena()
-        pl.zero_grads()
+        pl.zero_grads_join()
         pl.gscale.copy_(g_loss.reshape(1))
         pl.bw.run(model._events)
+        pl.zero_grads_ahead()
         return None, None, None
 
 
