@@ -60,7 +60,9 @@ ZERO_AHEAD = os.environ.get("EGNE_ZERO_AHEAD", "1") != "0"            # gradient
 PAIR_BIAS_SIDE = os.environ.get("EGNE_PAIR_BIAS_SIDE", "1") != "0"    # its two small launches on the plan's second stream
 MERGE_DGRAD = os.environ.get("EGNE_MERGE_DGRAD", "1") != "0"       # one data-gradient launch for adjacent raw slices of a 1x1
 WGRAD_SPLIT = os.environ.get("EGNE_WGRAD_SPLIT", "1") != "0"       # training plans: 3x3 weight gradients on split-f16 products (wgrad_halo.hip)
-WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "0") != "0"   # weight gradients on a second stream (measured: no gain, 433.6 vs 434.0 frames/s at B=64 -- either kernel fills the LDS of every CU, so they do not co-reside)
+# weight gradients on the plan's second stream (only the optimiser reads them): bf16 storage 66.5 -> 64.7-65.4 ms per B=64 step, fp32
+# storage 111.5 -> 107.4; round 2 had measured no gain (433.6 vs 434.0 frames/s: the kernels next to them then filled every CU's LDS)
+WGRAD_SIDE_STREAM = os.environ.get("EGNE_WGRAD_SIDE", "1") != "0"
 WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans: steps between re-measuring max |w| of a split-f16 pack (one host sync each)
 TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "1") != "0"     # training plans: split-f16 (22-bit products) 3x3 forward convolutions and data gradients, pre-scales taken on the device
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
