@@ -122,6 +122,7 @@ SIGNATURES = {
     "egne_act_bwd_bias_workspace_bytes": (i64, [i64, i32]),
     "egne_act_bwd_bias": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp]),
     "egne_act_bwd_bias_absmax": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp, vp]),
+    "egne_zero_many": (i32, [vp, i32, i64, vp]),
     "egne_pair_bias_bwd_workspace_bytes": (i64, [i32, i32]),
     "egne_pair_bias_bwd": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
     "egne_norm_bwd_workspace_bytes": (i64, [i32, i32, i32, i32]),

@@ -383,6 +383,32 @@ extern "C" int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int C
   return egne::check_launch("egne_absmax");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Zero a list of device buffers in ONE launch (the gradient twins of a backward plan: torch._foreach_zero_ took 75 launches).
+// table[i] = {address, bytes, first block}: 16-byte aligned, bytes a multiple of 16; a block clears up to 64 KB of one buffer.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_many_k(const unsigned long long* __restrict__ table, int nseg) {
+  int lo = 0, hi = nseg - 1;                          // last segment whose first block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[3 * mid + 2] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  egne_f32x4* base = (egne_f32x4*)table[3 * lo];
+  const unsigned long long nvec = table[3 * lo + 1] >> 4, v0 = (blockIdx.x - table[3 * lo + 2]) * 4096ull;
+  const egne_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned long long v = v0 + i * 256 + threadIdx.x;
+    if (v < nvec) base[v] = z;
+  }
+}
+
+extern "C" int egne_zero_many(const void* table, int nseg, int64_t nblocks, void* stream) {
+  EGNE_REQUIRE(table && nseg > 0 && nblocks > 0 && nblocks < (1ll << 31), "zero_many: bad arguments");
+  hipLaunchKernelGGL(zero_many_k, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)table, nseg);
+  return egne::check_launch("egne_zero_many");
+}
+
 extern "C" int64_t egne_norm_stats_workspace_bytes(int B, int HW, int Cp, int per_sample) {
   const int Bn = per_sample ? B : 1;
   const long long npix = per_sample ? HW : (long long)B * HW;

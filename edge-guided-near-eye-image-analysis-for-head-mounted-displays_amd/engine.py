@@ -602,6 +602,7 @@ class Plan:
         self.dyn_scales = bool(train) and TRAIN_SPLIT and not self.bf16     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
         self.dynbuf, self.ndyn = None, 0
         self._zstream, self._zevent, self._zero_pending = None, None, False      # zero_grads_ahead
+        self._ztable = None                           # zero_grads: (twin addresses, device table, blocks)
         self._pair_links = {}                         # 1x1 -> 3x3 pairs whose bias gradients share one reduction (_bw_conv)
         self._touching, self._touched = False, {}     # build_backward: channel ranges of gradient twins already handed out
         self.side_calls, self.side_stream = {}, None   # call index -> event: launches on the plan's second stream (weight gradients; the edge network's MSBlocks)
@@ -686,8 +687,19 @@ class Plan:
     def zero_grads(self):
         free = getattr(self, "_zero_free", ())
         ts = [t for bid, t in self.gtwins.items() if bid not in free]
-        if ts:
-            torch._foreach_zero_(ts)
+        if not ts:
+            return
+        key = tuple(t.data_ptr() for t in ts)
+        if self._ztable is None or self._ztable[0] != key:       # one launch for all of them (egne_zero_many)
+            rows, blk = [], 0
+            for t in ts:
+                nb = t.numel() * t.element_size()
+                assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nb % 16 == 0
+                rows.append((t.data_ptr(), nb, blk))
+                blk += (nb + 65535) // 65536
+            self._ztable = (key, torch.tensor(rows, dtype=torch.int64).to(self.device), blk)
+        _, tab, blk = self._ztable
+        _lib.check(self.L.egne_zero_many(tab.data_ptr(), len(ts), blk, _lib.stream_ptr()))
 
     def zero_grads_ahead(self):
         """Zero the gradient twins for the NEXT backward pass on a stream of their own, behind everything queued so far: nothing

@@ -468,6 +468,10 @@ int egne_act_bwd_bias_absmax(float* g, int64_t gs, int go, const float* y, int64
                              int64_t npix, float* dbias, int C, int accumulate, void* ws, uint32_t* absmax_bits, void* stream);
 int egne_act_bwd_bias(float* g, int64_t gs, int go, const float* y, int64_t ys, int yo, int act, int Cp,
                       int64_t npix, float* dbias, int C, int accumulate, void* ws, void* stream);
+/* Zero a list of device buffers in one launch (a backward plan's gradient twins before each pass; the reference's autograd
+ * allocates fresh gradients instead).  table: device array of nseg x {uint64 address, uint64 bytes, uint64 first_block}, addresses
+ * 16-byte aligned, bytes a multiple of 16, first_block = the running sum of ceil(bytes / 65536); nblocks = that sum over all. */
+int egne_zero_many(const void* table, int nseg, int64_t nblocks, void* stream);
 /* Bias gradient of an activation-free 1x1 that feeds a 3x3 (stride 1, zero pad 1) -- the 'a' layer of the reference's dense-block
  * pairs (RITnet_v2.py:145-156 conv1x1 -> conv3x3) -- without a pass over the 3x3's data gradient g_tmp: sum_q g_tmp[q][ca] =
  * sum_{co,tap} w[co][ca][tap] * S_tap[co], S_tap = the 3x3's per-channel gradient total minus the border row / column the tap

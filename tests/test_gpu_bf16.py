@@ -454,6 +454,28 @@ def test_pair_bias_gradient_from_border_sums(B, H, W, Cout, Ca, slice_):
         assert (db.double() + 1.0 - want_b).abs().max().item() <= 2e-6 * sb + 1e-5, (dt, B, H, W)
 
 
+@pytest.mark.gpu
+def test_zero_many_clears_exactly_the_listed_buffers():
+    """egne_zero_many: every listed buffer (sizes below, at and above a block's 64 KB, bf16 and fp32) is cleared in one launch and
+    the bytes around them are not touched."""
+    from egne_amd import _lib
+    L = _lib.lib()
+    sizes = [16, 4096, 65536, 65536 + 16, 3 * 65536 - 32, 1 << 20, 48]
+    arena = torch.full((sum(sizes) + 64 * (len(sizes) + 1),), 0x5A, dtype=torch.uint8, device=DEV)
+    rows, off, blk = [], 64, 0
+    for nb in sizes:
+        rows.append((arena.data_ptr() + off, nb, blk))
+        blk += (nb + 65535) // 65536
+        off += nb + 64
+    tab = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    _lib.check(L.egne_zero_many(tab.data_ptr(), len(rows), blk, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    want = torch.full_like(arena, 0x5A)
+    for a, nb, _ in rows:
+        want[a - arena.data_ptr():a - arena.data_ptr() + nb] = 0
+    assert torch.equal(arena, want)
+
+
 NET_CASES = ["esf_edge_b2", "esf_baseline_b2", "esf_concat_b2", "esf_edge_b2_absent1", "esf_adain_edge_b2", "esf_adain_b2_train",
              "esf_adain_edge_detach_b2"]
 
