@@ -1795,6 +1795,7 @@ class Plan:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side if on_side else main)
+            assert not (on_side and getattr(fn, "python", False)), "%s: python calls queue torch work on the main stream" % name
             rc = fn(*args, sp if on_side else st)
             if timed:
                 e1.record(side if on_side else main)

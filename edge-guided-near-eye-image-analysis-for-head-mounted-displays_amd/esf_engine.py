@@ -27,6 +27,9 @@ import types
 
 PLANAR_IN = os.environ.get("EGNE_PLANAR_IN", "1") != "0"   # one-channel inputs read in place by the fused head (no NHWC staging)
 FOLD_UP = os.environ.get("EGNE_FOLD_UP", "1") != "0"     # up blocks: 1x1 of the up-sampled operand at half resolution
+# inference plans: the ellipse regression head (eight latency-bound launches on the 15x20 bottleneck) on the plan's second stream
+# next to the decoder, joined in front of the loss head
+ELREG_SIDE = os.environ.get("EGNE_ELREG_SIDE", "1") != "0"
 FOLD_UP_STREAM = os.environ.get("EGNE_FOLD_UP_STREAM", "1") != "0"     # ... also where the pair is not fused (streaming 1x1 with the addend in its epilogue)
 
 
@@ -141,7 +144,8 @@ def _train_bn(pl, bn, pre, dst, n0, B, HW, name):
 
 
 class _PyCall:
-    """Adapter so that a python callable can sit in a plan's launch list."""
+    """Adapter so that a python callable can sit in a plan's launch list (main stream only: it queues torch work on the current one)."""
+    python = True
 
     def __init__(self, fn):
         self.fn = fn
@@ -304,6 +308,12 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
 
     # ---- decoder on B samples ---------------------------------------------------------------------
     xb = [Piece(bott, 0, fc)] + ([Piece(bott, 0, fc, n0=B)] if add_edge else [])
+    # (not at one or two frames: there the fork and join cost what the head's launches take -- 3.29 -> 3.38 ms per two-frame call)
+    early_head = ELREG_SIDE and B >= 8 and not training and not (variant == "v2" and st["add_seg"] == 1)
+    if early_head:       # (with AdaIN the head reads the bottleneck modulated by the decoder's own output: it stays behind it)
+        pl.side_default = True
+        regression_head(pl, model.elReg, xb, B, hb, wb, training)
+        pl.side_default = False
     prev, ph, pw = xb, hb, wb
     dec = model.dec
     ups = [dec.up_block4, dec.up_block3, dec.up_block2, dec.up_block1]
@@ -472,7 +482,11 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
             mod.append(q)
         xb = mod
 
-    regression_head(pl, model.elReg, xb, B, hb, wb, training)
+    if early_head:
+        pl.join_before.add(len(pl.calls))
+        pl.raw(pl._elout_copy, (), "elOut.copy")
+    else:
+        regression_head(pl, model.elReg, xb, B, hb, wb, training)
     loss_head(pl, opb, B, H, W, dev, training)
     confusion_head(pl, model, fc, B, training, variant == "v2")
     if training:
@@ -511,7 +525,13 @@ def regression_head(pl, rg, xb, B, hb, wb, training):
     pl.conv(l, [Piece(r5, 0, 256)], Piece(r6, 0, 10, 16), B, 1, 1, name="elReg.l2")
     pl.raw(L.egne_ellipse_head_act, (r6.data_ptr(), B, 16), "elReg.act")
     pl.elOut = pl.vec(B, 10)
-    pl.raw(_PyCall(lambda: pl.elOut.copy_(r6.view(B, 16)[:, :10])), (), "elOut.copy")
+    copy_out = _PyCall(lambda: pl.elOut.copy_(r6.view(B, 16)[:, :10]))
+    if pl.side_default:
+        # on the second stream (inference plans): the torch copy is queued by the caller on the main stream, behind the join -- a
+        # python call issued under another torch stream inside a hipGraph capture gave wrong replays (GraphedFrames)
+        pl._elout_copy = copy_out
+    else:
+        pl.raw(copy_out, (), "elOut.copy")
     if training:
         pl.g_elOut = pl.vec(B, 10)
         pl.tape.append(lambda bw: bw.raw(L.egne_ellipse_head_act_bwd, (pl.gbuf(r6).data_ptr(), r6.data_ptr(), B, 16),

@@ -661,6 +661,38 @@ def test_deepvog_train_step_vs_reference():
         m.to(torch.bfloat16)
 
 
+def test_regression_head_next_to_the_decoder_is_bit_identical():
+    """Inference plans of 8+ frames run the ellipse regression head on the plan's second stream next to the decoder
+    (esf_engine.ELREG_SIDE, joined in front of the loss head): every output equals the one-stream plan's, run after run."""
+    import os
+    import yaml
+    import egne_amd
+    from egne_amd import _entry, esf_engine, synth
+    with open(os.path.join(os.path.dirname(egne_amd.__file__), "configs", "baseline_edge.yaml")) as f:
+        bd, net = _entry.seeded_networks(yaml.safe_load(f))
+    bd, net = bd.to(DEV).eval(), net.to(DEV).eval()
+    b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth.make_batch(8, seed=11).items()}
+    outs = {}
+    old = esf_engine.ELREG_SIDE
+    try:
+        for side in (True, False):
+            esf_engine.ELREG_SIDE = side
+            net._plans.clear()
+            with torch.no_grad():
+                edge = bd.forward_fuse(torch.cat((b["img"],) * 3, 1).float())
+                for _ in range(3):
+                    o = net(b["img"], edge, b["label"], b["pupil_center"], b["elNorm"], b["spatWts"], b["distMap"], b["cond"], b["ID"], 0.5)
+            torch.cuda.synchronize()
+            pl = net._last_plan
+            assert bool(pl.side_calls) == side and (len(pl.join_before) == 1) == side
+            outs[side] = [t.clone() for t in o]
+    finally:
+        esf_engine.ELREG_SIDE = old
+        net._plans.clear()
+    for a, c in zip(outs[True], outs[False]):
+        assert torch.equal(a, c)
+
+
 def test_graphed_frames_replay_is_bit_identical():
     """egne_amd.pipeline.GraphedFrames (edge -> ESF-Net -> argmax -> fit of a fixed two-frame batch as one hipGraph replay, the
     per-eye loop of evaluate.py:235-249): the replay on NEW frames returns exactly what the eager calls return for them."""
