@@ -311,6 +311,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     # (not at one or two frames: there the fork and join cost what the head's launches take -- 3.29 -> 3.38 ms per two-frame call)
     early_head = ELREG_SIDE and B >= 8 and not training and not (variant == "v2" and st["add_seg"] == 1)
     if early_head:       # (with AdaIN the head reads the bottleneck modulated by the decoder's own output: it stays behind it)
+        pl.serial_timing = True          # run(events): per-launch timing on one stream (overlapping kernels stretch each other)
         pl.side_default = True
         regression_head(pl, model.elReg, xb, B, hb, wb, training)
         pl.side_default = False
