@@ -660,6 +660,7 @@ class Plan:
         bw = Plan(self.device, dtype=self.dtype)
         bw.fwd = self
         bw.dyn_scales = self.dyn_scales
+        bw.serial_timing = True           # run(events): per-launch timing on one stream (the side-stream launches would stretch their neighbours)
         self._touching, self._touched = True, {}
         for emit in reversed(self.tape):
             emit(bw)
