@@ -901,8 +901,10 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_allpairs_kernel(const egne_
 // sum the split partials and add into the OIHW gradient of group g
 // sum the split partials and add into the OIHW gradient of group g: a block = 32 elements x 8 interleaved split ranges,
 // combined through LDS in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ ws, int nsplit, int G, int g, int T, int Cout, int Cin,
-                                                      const int* __restrict__ kinv, int CoutP, int Ktot, float* __restrict__ gw) {
+// clean: the partial sums are cleared as they are read -- the forms whose kernels do not write every partial (1x1 over slices, the
+// generic implicit GEMM) need a zero-filled workspace, and clearing here replaces a fill in front of every such launch
+__global__ __launch_bounds__(256) void wgrad_reduce_k(float* __restrict__ ws, int nsplit, int G, int g, int T, int Cout, int Cin,
+                                                      const int* __restrict__ kinv, int CoutP, int Ktot, float* __restrict__ gw, int clean) {
   __shared__ float part[8][32];
   const long long total = (long long)T * CoutP * Ktot;
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
@@ -910,7 +912,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
     const long long i = base + c;
     float s = 0.f;
     if (i < total)
-      for (int sp = q; sp < nsplit; sp += 8) s += ws[((long long)sp * G + g) * total + i];
+      for (int sp = q; sp < nsplit; sp += 8) {
+        float* e = ws + ((long long)sp * G + g) * total + i;
+        s += *e;
+        if (clean) *e = 0.f;
+      }
     __syncthreads();
     part[q][c] = s;
     __syncthreads();
@@ -1435,8 +1441,8 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
   EGNE_REQUIRE(ktot == d.Ktot && d.CoutP % 32 == 0 && Cout <= d.CoutP && Cin <= d.Ktot, "wgrad: inconsistent sizes");
   const int T = d.kh * d.kw, nsplit = egne_conv2d_wgrad_splits(dp);
   hipStream_t st = (hipStream_t)stream;
-  const size_t bytes = (size_t)nsplit * d.ngroups * T * d.CoutP * d.Ktot * sizeof(float);
   bool fast3x3 = false;
+  int clean = 0;
   if constexpr (BF) {
     if (egne::wgrad3x3_bf16_supported(d, d.out_pix_stride)) {         // 3x3 "same" convolutions over one slice: bf16 MFMA (wgrad_bf16.hip)
       // the gradient buffer mirrors the output buffer (same pixel stride): the split count above assumed it
@@ -1449,6 +1455,7 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
       const int rc = egne::wgrad1x1_bf16_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);
       if (rc != EGNE_OK) return rc;
       fast3x3 = true;
+      clean = 1;
     }
   }
   if (fast3x3) {
@@ -1464,7 +1471,7 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
                : egne::wgrad_halo_launch(d, gz, (long long)gzs, gzo, (float*)ws, st);   // writes every partial it owns
     if (rc != EGNE_OK) return rc;
   } else if (int nco = 0, nkc = 0, ch = 0; w1_supported(d, &nco, &nkc, &ch)) {
-    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
+    clean = 1;          // (ws arrives zero-filled: the caller's first fill, then the reduction of the previous call)
     W1Tab tab{};
     int j = nco, kofs = 0;
     for (int s = 0; s < d.nseg; ++s) {
@@ -1487,7 +1494,7 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
               : go(conv1x1_wgrad_allpairs_kernel<8, 32, TS>);
     if (rc != EGNE_OK) return rc;
   } else {
-    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "wgrad: memset failed");
+    clean = 1;
     dim3 grid(nsplit, d.CoutP / 32, per_tap * T * d.ngroups);
     static const bool bfm = [] { const char* e = getenv("EGNE_IGEMM_BF16_MFMA"); return !e || e[0] != '0'; }();
     static const bool fold_on = [] { const char* e = getenv("EGNE_IGEMM_FOLD"); return !e || e[0] != '0'; }();
@@ -1518,8 +1525,8 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
   for (int g = 0; g < d.ngroups; ++g) {
     EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
     const long long total = (long long)T * d.CoutP * d.Ktot;
-    hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(total * 8)), dim3(256), 0, st, (const float*)ws, nsplit, d.ngroups, g, T, Cout,
-                       Cin, kinv, d.CoutP, d.Ktot, gw[g]);
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(total * 8)), dim3(256), 0, st, (float*)ws, nsplit, d.ngroups, g, T, Cout,
+                       Cin, kinv, d.CoutP, d.Ktot, gw[g], clean);
   }
   return egne::check_launch("egne_conv2d_wgrad");
 }

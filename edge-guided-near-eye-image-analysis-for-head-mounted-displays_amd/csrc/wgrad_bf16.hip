@@ -355,8 +355,7 @@ int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long
     }
     kofs += d.seg[s].Cp;
   }
-  const size_t bytes = (size_t)nsplit * d.CoutP * d.Ktot * sizeof(float);
-  if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: memset failed");     // channels beyond a slice's blocks
+  // (ws arrives zero-filled -- channels beyond a slice's blocks are not written -- and the reduction clears what it reads)
   for (int k0 = 0; k0 < nkc; k0 += group) {        // one launch per group of input tiles (gz is staged again by each)
     const int nk = nkc - k0 < group ? nkc - k0 : group, ppw = (nco * nk + 7) / 8;
     W1Tab tab{};

@@ -529,7 +529,11 @@ int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int 
 
 /* Weight gradient of the convolution described by `d` (same descriptor as the forward call):
  * gw[g][co][ci][kh][kw] += sum_pixels gz[pixel][co] * input[pixel + tap][ci], gz = gradient w.r.t. the
- * pre-activation output.  gw is a HOST array of ngroups device pointers (OIHW, torch layout). */
+ * pre-activation output.  gw is a HOST array of ngroups device pointers (OIHW, torch layout).
+ * ws: egne_conv2d_wgrad_workspace_bytes(d) bytes of split partial sums, ZERO-FILLED by the caller before its first use and kept for
+ * calls with the same descriptor shape: the forms that do not write every partial (1x1 over slices, the generic implicit GEMM)
+ * rely on the zeros, and their reduction clears what it reads, so the workspace is zero-filled again when the call returns (round 4:
+ * this replaced a fill in front of every such launch). */
 int egne_conv2d_wgrad_splits(const egne_conv_desc* d);
 int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* d);
 int egne_conv2d_wgrad(const egne_conv_desc* d, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,

@@ -241,6 +241,16 @@ def test_weight_and_data_gradients_bf16_storage(G, kind, Cin, Cout, H, W):
         gx = torch.cat([pl.gbuf(p.buf).float().cpu()[..., p.off:p.off + p.C] for p in pieces], -1).permute(0, 3, 1, 2).double()
         ex = (gx - xin2.grad).abs().max().item() / xin2.grad.abs().max().item()
         assert ex < EPS, "data gradient: relative error %.2e" % ex
+    # a second pass over the same plan gives the same bits: the split partial sums of the weight gradient live in a workspace that
+    # the 1x1 form needs zero-filled and that its reduction clears again (egne_conv2d_wgrad)
+    first = wp.grad.clone()
+    wp.grad.zero_()
+    bp.grad.zero_()
+    pl.zero_grads()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    assert torch.equal(wp.grad, first)
 
 
 @pytest.mark.parametrize("case,Cin,Cout,k,stride,P,H,W", [("7x7 on 3 channels (folded taps)", 3, 64, 7, 1, 3, 45, 70), ("4x4 stride 2", 64, 128, 4, 2, 1, 48, 64),
