@@ -710,9 +710,15 @@ class Plan:
             return
         if self._zstream is None:
             self._zstream, self._zevent = torch.cuda.Stream(device=self.device), torch.cuda.Event()
+            # no join follows these fills until the next backward: tell the allocator, so that a plan dropped in between cannot have
+            # a twin's memory handed to a new tensor while its fill is still queued
+            for t in self.gtwins.values():
+                t.record_stream(self._zstream)
         self._zstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._zstream):
             self.zero_grads()
+        if self._ztable is not None:
+            self._ztable[1].record_stream(self._zstream)
         self._zevent.record(self._zstream)
         self._zero_pending = True
 
