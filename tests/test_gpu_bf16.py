@@ -737,6 +737,46 @@ def test_bf16_training_of_the_64_channel_model_at_256_per_gpu(edge_exact):
     _free_hbm()
 
 
+@pytest.mark.parametrize("storage", [torch.bfloat16, torch.float32])
+def test_second_stream_of_the_backward_plan_changes_no_bit(storage):
+    """Weight gradients and the pair bias sums on the backward plan's second stream, gradient twins cleared behind the previous
+    backward pass on a stream of their own (engine.WGRAD_SIDE_STREAM / PAIR_BIAS_SIDE / ZERO_AHEAD): five Adam steps over changing
+    batches end in the same weights, bit for bit, as the same steps with every launch on one stream."""
+    import types
+    from common import batch_args, bdcn_module, esf_module
+    from egne_amd import engine, synth
+    from egne_amd.utils import calc_edge
+    ns = types.SimpleNamespace(prec=torch.float32, edge_thres=0)
+    bd = bdcn_module().to(DEV)
+    data = synth.make_batch(12, seed=77)
+    with torch.no_grad():
+        e = calc_edge(ns, data["img"].to(DEV), bd, DEV)
+    del bd
+
+    def run(flag):
+        old = engine.WGRAD_SIDE_STREAM, engine.PAIR_BIAS_SIDE, engine.ZERO_AHEAD
+        engine.WGRAD_SIDE_STREAM = engine.PAIR_BIAS_SIDE = engine.ZERO_AHEAD = flag
+        try:
+            m = esf_module("baseline_edge", seed=3).to(DEV).to(storage).train()
+            opt = torch.optim.Adam([p for n, p in m.named_parameters() if "dsIdentify" not in n], lr=5e-4)
+            for k in range(5):
+                idx = torch.arange(4) + 4 * (k % 3)
+                bb = {n: (v[idx] if torch.is_tensor(v) else v) for n, v in data.items()}
+                args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(bb, e[idx.to(e.device)])]
+                opt.zero_grad()
+                m(*args)[3].backward()
+                opt.step()
+            torch.cuda.synchronize()
+            pl = m._last_plan
+            assert bool(pl.bw.side_calls) == flag
+            return [p.detach().clone() for p in m.parameters()]
+        finally:
+            engine.WGRAD_SIDE_STREAM, engine.PAIR_BIAS_SIDE, engine.ZERO_AHEAD = old
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_bf16_storage_over_a_training_horizon():
     """200 Adam steps (train.py:262-287: lr 5e-4, alpha ramp) over 64 DISTINCT synthetic frames in batches of 8, from the same
     seeded weights and in the same batch order, once with fp32 and once with bf16 activation storage: the smoothed loss curves and the
