@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="build the RCCL process group even with ONE rank (EGNE_FORCE_DIST=1): the training legs then run the gradient all-reduce, "
                          "the parameter broadcast and the timing all-gather through RCCL and report allreduce_ms_per_step > 0")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0: min(cores, 32), see --cpu-thread-sweep)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0: min(affinity cores, 16), see --cpu-thread-sweep)")
     ap.add_argument("--cpu-thread-sweep", action="store_true",
                     help="time the CPU baseline's B=2 edge + seg part at 16 / 32 / 64 / 128 / all logical cores and print the table (one-off: which "
                          "thread count is the fair baseline)")
@@ -584,6 +584,7 @@ class Bench:
         net.to(torch.bfloat16 if storage == "bf16" else torch.float32)       # storage of the training plan's activations (models/RITnet_v2.py: DenseNet2D.to)
         net.train()
         parallel.broadcast_state(net)
+        parallel.overlap_grads(net)      # (as egne_amd/train.py: two-bucket all-reduce, the first bucket issued inside the backward pass)
         opt = torch.optim.Adam([p for n, p in net.named_parameters() if "dsIdentify" not in n], lr=5e-4, fused=True)     # (as egne_amd/train.py)
 
         def rest(edge):   # train.py:284-287: forward, loss.backward(), (DP) gradient all-reduce, Adam

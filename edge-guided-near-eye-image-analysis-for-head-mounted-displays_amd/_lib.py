@@ -52,7 +52,8 @@ class LossDesc(C.Structure):
                 ("pupil_center", c_fp), ("elNorm", c_fp), ("elOut", c_fp), ("alpha", C.c_float),
                 ("grid_x", c_fp), ("grid_y", c_fp),
                 ("partials", c_fp), ("out_terms", c_fp), ("pred_c", c_fp), ("elPred", c_fp),
-                ("mask", c_fp), ("op_nchw", c_fp), ("coef", c_fp), ("dtype", C.c_int32)]
+                ("mask", c_fp), ("op_nchw", c_fp), ("coef", c_fp), ("dtype", C.c_int32),
+                ("g_op_nchw", c_fp), ("g_pred_c", c_fp), ("g_elOut_up", c_fp)]
 
 
 # name -> (restype, argtypes); every symbol include/egne_hip.h declares

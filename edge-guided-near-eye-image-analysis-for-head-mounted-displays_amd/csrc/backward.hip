@@ -43,6 +43,11 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
   const float ki = (nmask > 0.f) ? gscale * 0.5f * mp / (2.f * nmask) * (-4.f) : 0.f;
   const float fHW = (float)HW;
   const long long base = (long long)b * HW;
+  // upstream gradient w.r.t. the soft-argmax centres (temperature 4 / -4 folded in); the iris centre is a function of the logits only
+  // when some sample has a mask (RITnet_v2.py:392-404)
+  const bool iris_up = d.g_pred_c && nmask > 0.f;
+  const float upx = d.g_pred_c ? 4.f * d.g_pred_c[b * 4 + 2] : 0.f, upy = d.g_pred_c ? 4.f * d.g_pred_c[b * 4 + 3] : 0.f;
+  const float uix = iris_up ? -4.f * d.g_pred_c[b * 4 + 0] : 0.f, uiy = iris_up ? -4.f * d.g_pred_c[b * 4 + 1] : 0.f;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
     const T* lp = (const T*)d.logits + (base + p) * d.pix_stride + d.ch_off;
     const float l0 = ld1(lp), l1 = ld1(lp + 1), l2 = ld1(lp + 2);
@@ -69,10 +74,18 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
     const int y = p / d.W, x = p - y * d.W;
     const float gx = d.grid_x[x], gy = d.grid_y[y];
     const float wp = expf(4.f * l2 - pm) / ps;
+    // d c / d l_j = T p_j (x_j - c) for c = sum_j p_j x_j, p = softmax(T l): the loss term's own upstream (sign / count) plus what the
+    // caller back-propagates through pred_c (elPred's centre entries)
     g2 += kp * wp * (spx * (gx - cpx) + spy * (gy - cpy));
-    if (ki != 0.f) {
+    if (d.g_pred_c) g2 += wp * (upx * (gx - cpx) + upy * (gy - cpy));
+    if (ki != 0.f || iris_up) {
       const float wi = expf(-4.f * l0 - im) / is;
-      g0 += ki * wi * (six * (gx - cix) + siy * (gy - ciy));
+      if (ki != 0.f) g0 += ki * wi * (six * (gx - cix) + siy * (gy - ciy));
+      if (iris_up) g0 += wi * (uix * (gx - cix) + uiy * (gy - ciy));
+    }
+    if (d.g_op_nchw) {
+      const float* q = d.g_op_nchw + (long long)b * 3 * HW + p;
+      g0 += q[0]; g1 += q[HW]; g2 += q[2 * (long long)HW];
     }
     T* o = g_logits + (base + p) * gs + go;
     st1(o, g0); st1(o + 1, g1); st1(o + 2, g2);
@@ -86,6 +99,7 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const egne_loss_desc d, const 
     } else if (j == 5 || j == 6) {
       g = 10.f * gscale * sgn(d.elOut[b * 10 + j] - cf[16 + (j - 5)]) / (2.f * nabs);
     }
+    if (d.g_elOut_up) g += d.g_elOut_up[b * 10 + j];
     g_elOut[b * 10 + j] = g;
   }
 }
@@ -1439,6 +1453,9 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
     ktot += g.Cp; per_tap += (g.Cp + 31) / 32;
   }
   EGNE_REQUIRE(ktot == d.Ktot && d.CoutP % 32 == 0 && Cout <= d.CoutP && Cin <= d.Ktot, "wgrad: inconsistent sizes");
+  // (every argument is checked BEFORE the first launch: the forms below that rely on a zero-filled workspace leave it dirty between
+  //  their partial-sum kernel and the reduction, so no validation may return in between)
+  for (int g = 0; g < d.ngroups; ++g) EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
   const int T = d.kh * d.kw, nsplit = egne_conv2d_wgrad_splits(dp);
   hipStream_t st = (hipStream_t)stream;
   bool fast3x3 = false;
@@ -1523,12 +1540,15 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
     }
   }
   for (int g = 0; g < d.ngroups; ++g) {
-    EGNE_REQUIRE(gw[g], "wgrad: null gradient tensor %d", g);
     const long long total = (long long)T * d.CoutP * d.Ktot;
     hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(total * 8)), dim3(256), 0, st, (float*)ws, nsplit, d.ngroups, g, T, Cout,
                        Cin, kinv, d.CoutP, d.Ktot, gw[g], clean);
   }
-  return egne::check_launch("egne_conv2d_wgrad");
+  const int rc = egne::check_launch("egne_conv2d_wgrad");
+  // a launch of this call failed: the zero-filled-workspace contract of the `clean` forms cannot be trusted any more -- restore it
+  // here, so that the next (good) call does not add this call's stray partial sums to its gradients
+  if (rc != EGNE_OK && clean) (void)hipMemsetAsync(ws, 0, (size_t)egne_conv2d_wgrad_workspace_bytes(dp), st);
+  return rc;
 }
 
 extern "C" int egne_conv2d_wgrad(const egne_conv_desc* dp, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,

@@ -392,7 +392,8 @@ extern "C" int egne_ellipse_fit(const int64_t* mask, int nframes, const int32_t*
     static bool once = hipFuncSetAttribute((const void*)ellipse_fit_k<8, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     if (!once) return egne::fail(EGNE_ERR_LAUNCH, "ellipse_fit: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((ellipse_fit_k<8, 1, true>), dim3((unsigned)((n + 7) / 8)), dim3(1024), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
-  } else if (n >= 64 && dense == 4) {
+  } else if (n >= 64 && dense == 4 && fixed + 4 * ((size_t)H * ((W + 31) / 32) + 8 + 2) * 4 <= 64 * 1024) {
+    // (masks where two searches fit the default 64 KB of dynamic LDS but four do not -- 320x480, 384x512 -- take the two-search form below)
     const size_t lds = fixed + 4 * ((size_t)H * ((W + 31) / 32) + 8 + 2) * 4;
     hipLaunchKernelGGL((ellipse_fit_k<4, 1, true>), dim3((unsigned)((n + 3) / 4)), dim3(512), lds, st, mk, nframes, frame_of, cls, n, H, W, xs, ys, init, out, evals);
   } else if (n >= 16) {           // a batch: two searches of two waves per workgroup

@@ -610,6 +610,7 @@ class Plan:
         self.join_before = set()                       # call indices in front of which the main stream waits for the second one
         self.window_at = None                          # call index at which pending WINDOW_HOOKS are released (None: never)
         self.serial_timing = False                     # run(events): one stream when launches are timed (overlapping kernels stretch each other's durations)
+        self.tail_at, self.tail_hook = None, None      # backward plans: call index where every non-encoder parameter gradient is final, and what to call there (parallel.GradOverlap.tail_ready)
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _StorageLib(_lib.lib(), self.bf16)
 
@@ -1537,6 +1538,12 @@ class Plan:
         peer = self._pair_links.get(id(layer))
         lead = peer is not None and layer.kh == 3            # the pair's 3x3: its chunk sums feed both bias gradients
         dbias = bias.grad.data_ptr() if bias is not None and not lead else None
+        # a bias gradient is accumulated either by the main stream's reductions or by egne_pair_bias_bwd on the second stream, never by
+        # both: the two read-modify-writes are ordered only by the end-of-run join (two layers wrapping ONE Parameter would race)
+        if bias is not None:
+            how = "side" if (peer is not None and PAIR_BIAS_SIDE) else "main"
+            seen = bw.__dict__.setdefault("_bias_writers", {})
+            assert seen.setdefault(id(bias), how) == how, "%s: its bias Parameter is also written from the other stream of the backward plan" % name
         if peer is not None and not lead:
             pass                                             # the pair's 1x1: no activation to mask, bias gradient already taken (below)
         elif self.bf16:
@@ -1732,6 +1739,8 @@ class Plan:
             for i, (fn, args, name) in enumerate(self.calls):
                 if i == self.window_at and WINDOW_HOOKS:
                     self._open_window()
+                if i == self.tail_at and self.tail_hook is not None:
+                    self.tail_hook()
                 rc = fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, name)
@@ -1739,6 +1748,8 @@ class Plan:
         for i, ((fn, args, name), (kind, flops)) in enumerate(zip(self.calls, self.meta)):
             if i == self.window_at and WINDOW_HOOKS:
                 self._open_window()
+            if i == self.tail_at and self.tail_hook is not None:
+                self.tail_hook()
             if EVENT_KINDS is not None and kind.split(":")[0] not in EVENT_KINDS:      # untimed launch (each event pair costs ~2 us of GPU time)
                 rc = fn(*args, st)
                 if rc != 0:
@@ -1762,7 +1773,11 @@ class Plan:
             return
         ev = torch.cuda.Event()
         ev.record()
-        hooks, WINDOW_HOOKS[:] = list(WINDOW_HOOKS), []
+        # (only the hooks registered for THIS plan's device: a plan of another GPU of the process must not launch them)
+        mine = torch.device(self.device).index
+        mine = torch.cuda.current_device() if mine is None else mine
+        hooks = [h for h in WINDOW_HOOKS if getattr(h, "device_index", mine) == mine]
+        WINDOW_HOOKS[:] = [h for h in WINDOW_HOOKS if getattr(h, "device_index", mine) != mine]
         for h in hooks:
             h(ev)
 
@@ -1794,6 +1809,15 @@ class Plan:
                 self._open_window()
             if i in self.join_before:
                 main.wait_stream(side)
+            if i == self.tail_at and self.tail_hook is not None:
+                # every launch that writes a non-encoder parameter gradient is queued (main stream up to here, second stream up to
+                # here): the early bucket of the gradient all-reduce is issued behind both, on the second stream -- RCCL's own stream
+                # waits for it, the main stream goes on with the encoder's backward
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self.tail_hook()
             if on_side:
                 ev = self.side_calls[i]
                 ev.record(main)

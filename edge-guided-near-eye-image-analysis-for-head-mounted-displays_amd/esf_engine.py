@@ -143,6 +143,18 @@ def _train_bn(pl, bn, pre, dst, n0, B, HW, name):
         pl.tape.append(emit)
 
 
+def latent_upstream(pl, bw, gl, B, fcp, fc):
+    """In front of the latent's spatial-mean backward: a caller's gradient w.r.t. the RETURNED latent (models/RITnet_v2.py:282,354;
+    ``_ESFFunction.backward`` leaves it in ``pl._g_latent_up``) joins what the dataset-confusion head left in the twin ``gl``.
+    Nothing happens on the loss-only path."""
+    pl._g_latent_up = None
+
+    def add_upstream():
+        if pl._g_latent_up is not None:
+            gl.view(B, fcp)[:, :fc].add_(pl._g_latent_up.to(gl.dtype))
+    bw.raw(_PyCall(add_upstream), (), "latent.upstream")
+
+
 class _PyCall:
     """Adapter so that a python callable can sit in a plan's launch list (main stream only: it queues torch work on the current one)."""
     python = True
@@ -303,6 +315,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     if training:
         def emit_latent(bw):
             gl, gb = pl.gbuf(pl.latent_p), pl.gbuf(bott)
+            latent_upstream(pl, bw, gl, B, fcp, fc)
             bw.raw(L.egne_spatial_mean_bwd, (gl.data_ptr(), fcp, gb.data_ptr(), gb.shape[-1], 0, fcp, B, hb * wb), "latent.bwd")
         pl.tape.append(emit_latent)
 
@@ -491,7 +504,11 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     loss_head(pl, opb, B, H, W, dev, training)
     confusion_head(pl, model, fc, B, training, variant == "v2")
     if training:
-        pl.build_backward()
+        bw = pl.build_backward()
+        # where the backward pass reaches the encoder: every gradient of the decoder, the AdaIN modules, the regression and the
+        # dataset-identity heads is final (parallel.GradOverlap issues their share of the all-reduce from here)
+        enc_calls = [i for i, (_, _, n) in enumerate(bw.calls) if n.startswith("enc.")]
+        bw.tail_at = enc_calls[0] if enc_calls else None
     return pl
 
 

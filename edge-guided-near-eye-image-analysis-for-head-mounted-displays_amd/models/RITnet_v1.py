@@ -147,6 +147,7 @@ def build_plan(model, B, H, W, dev, training, dtype=torch.float32):
     if training:
         def emit_latent(bw):
             gl, gb = pl.gbuf(pl.latent_p), pl.gp(x5)
+            E.latent_upstream(pl, bw, gl, B, pad8(fc), fc)
             bw.raw(L.egne_spatial_mean_bwd, (gl.data_ptr(), pad8(fc), gb.ptr, gb.stride, gb.off, pad8(fc), B, hb * wb), "latent.bwd")
         pl.tape.append(emit_latent)
     E.regression_head(pl, model.elReg, [x5], B, hb, wb, training)

@@ -116,16 +116,51 @@ class _ESFFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_op, g_elPred, g_latent, g_loss, g_elOut):
-        if any(g is not None for g in (g_op, g_elPred, g_latent, g_elOut)):
-            raise NotImplementedError("the HIP path back-propagates the returned loss only (train.py:285-286 calls "
-                                      "loss.backward()); gradients w.r.t. op / elPred / latent / elOut are not built")
-        if g_loss is None:
-            return None, None, None
+        """``loss.backward()`` alone (train.py:285-286) is the fast path.  A caller that adds its own terms on ``op`` / ``elPred`` /
+        ``latent`` / ``elOut`` (all four carry grad in the reference, models/RITnet_v2.py:334-354) hands their gradients in here: the
+        loss head's backward kernel adds them to its own (egne_loss_desc.g_op_nchw / g_pred_c / g_elOut_up), the latent's joins the
+        bottleneck gradient in front of its spatial-mean backward.  No synchronisation either way."""
         model, pl = ctx.model, ctx.pl
+        if g_loss is None and all(g is None for g in (g_op, g_elPred, g_latent, g_elOut)):
+            return None, None, None
         model._ensure_grad_arena()
         pl.zero_grads_join()
-        pl.gscale.copy_(g_loss.reshape(1))
-        pl.bw.run(model._events)
+        if g_loss is None:
+            pl.gscale.zero_()
+        else:
+            pl.gscale.copy_(g_loss.reshape(1))
+        ld, keep = pl.loss_desc, []
+        B = pl.elOut.shape[0]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
+        if g_op is not None:
+            keep.append(f32(g_op))
+            ld.g_op_nchw = keep[-1].data_ptr()
+        if g_elPred is not None or g_elOut is not None:
+            up = torch.zeros(B, 10, device=pl.elOut.device)
+            if g_elOut is not None:
+                up += f32(g_elOut)
+            if g_elPred is not None:
+                ge = f32(g_elPred)
+                up[:, 2:5] += ge[:, 2:5]
+                up[:, 7:10] += ge[:, 7:10]
+                # no mask in the batch: the iris centre of elPred is a copy of elOut[:, 5:7] (RITnet_v2.py:404), else the soft-argmax
+                # of the logits; out_terms[5] = number of samples with a mask, read on the device
+                has_mask = (pl.terms[5] > 0).to(torch.float32)
+                up[:, 5:7] += (1.0 - has_mask) * ge[:, 0:2]
+                keep.append(torch.cat((ge[:, 0:2], ge[:, 5:7]), 1).contiguous())
+                ld.g_pred_c = keep[-1].data_ptr()
+            keep.append(up)
+            ld.g_elOut_up = up.data_ptr()
+        pl._g_latent_up = f32(g_latent) if g_latent is not None else None
+        gc = getattr(model, "grad_comm", None)        # parallel.overlap_grads: the early bucket of the gradient all-reduce
+        pl.bw.tail_hook = gc.tail_ready if gc is not None else None
+        try:
+            pl.bw.run(model._events)
+        finally:
+            ld.g_op_nchw = ld.g_pred_c = ld.g_elOut_up = None
+            pl._g_latent_up = None
+            pl.bw.tail_hook = None
+        pl._upstream_keep = keep          # alive until the next backward (the launches are asynchronous)
         pl.zero_grads_ahead()
         return None, None, None
 

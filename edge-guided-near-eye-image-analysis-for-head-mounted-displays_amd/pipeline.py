@@ -109,6 +109,24 @@ class WindowedFit:
         from . import engine
         self.side = torch.cuda.Stream(device=device)
         self.windowed = bool(windowed) and engine.WINDOW_NAME != "none"
+        self.device_index = self.side.device.index
+        self._mine = []                 # hooks of this object still waiting for a window
+
+    def close(self):
+        """Drop the searches whose window never opened (an exception in the caller's loop): their hooks would otherwise keep the
+        class maps alive and be launched by an unrelated plan later.  Handles already handed out still work (``synchronize`` queues
+        the searches itself)."""
+        from . import engine
+        for h in self._mine:
+            if h in engine.WINDOW_HOOKS:
+                engine.WINDOW_HOOKS.remove(h)
+        self._mine = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def submit(self, mask, elPred, then=None):
         from . import engine
@@ -131,7 +149,9 @@ class WindowedFit:
                 h.done = torch.cuda.Event()
                 h.done.record(side)
         h._launch = launch
+        launch.device_index = self.device_index        # engine.Plan._open_window releases it only from a plan of the same GPU
         if self.windowed:
+            self._mine = [q for q in self._mine if q in engine.WINDOW_HOOKS] + [launch]
             engine.WINDOW_HOOKS.append(launch)
         else:
             launch(None)

@@ -105,6 +105,7 @@ def main(argv=None):
     model.selfCorr = bool(args.selfCorr)
     edge_net, model = edge_net.to(device).eval(), model.to(device).to(args.prec).train()
     parallel.broadcast_state(model)
+    parallel.overlap_grads(model)       # DP: the decoder-side half of the gradient all-reduce goes out from inside the backward pass (EGNE_OVERLAP_ALLREDUCE=0: one collective after it)
     params = [p for n, p in model.named_parameters() if 'dsIdentify' not in n]     # train.py:146-148
     # train.py:148 (Adam, default betas / eps); on the GPU torch's fused multi-tensor form: a handful of launches per step instead of ~75
     optimizer = torch.optim.Adam(params, lr=args.lr, fused=bool(params) and all(p.is_cuda for p in params))

@@ -392,6 +392,12 @@ typedef struct {
   float* op_nchw;              /* optional */
   float* coef;                 /* optional [B][32]: per-sample state kept for egne_loss_bwd */
   int32_t dtype;               /* storage of `logits`: 0 fp32, 1 bf16 (pix_stride / ch_off in elements); everything else stays fp32 */
+  /* egne_loss_bwd only, all optional (round 5): gradients a caller back-propagates through the OUTPUTS next to the loss
+   * (models/RITnet_v2.py:334-354 returns op, elPred, elOut with grad): added to what the loss terms themselves give. */
+  const float* g_op_nchw;      /* [B,3,H,W] upstream gradient w.r.t. the logits */
+  const float* g_pred_c;       /* [B,2,2] upstream gradient w.r.t. pred_c (iris, pupil soft-argmax centres; the iris row is ignored when
+                                  no sample of the batch has a mask: pred_c's iris row is then a copy of elOut[:,5:7], RITnet_v2.py:404) */
+  const float* g_elOut_up;     /* [B,10] upstream gradient w.r.t. elOut */
 } egne_loss_desc;
 int64_t egne_loss_workspace_floats(int B, int H, int W);
 int egne_loss_fwd(const egne_loss_desc* d, void* stream);
@@ -533,7 +539,8 @@ int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int 
  * ws: egne_conv2d_wgrad_workspace_bytes(d) bytes of split partial sums, ZERO-FILLED by the caller before its first use and kept for
  * calls with the same descriptor shape: the forms that do not write every partial (1x1 over slices, the generic implicit GEMM)
  * rely on the zeros, and their reduction clears what it reads, so the workspace is zero-filled again when the call returns (round 4:
- * this replaced a fill in front of every such launch). */
+ * this replaced a fill in front of every such launch).  Every argument is validated before the first launch (a rejected call queues
+ * nothing and leaves ws as it was); a call whose launches fail clears ws itself before it returns the error (round 5). */
 int egne_conv2d_wgrad_splits(const egne_conv_desc* d);
 int64_t egne_conv2d_wgrad_workspace_bytes(const egne_conv_desc* d);
 int egne_conv2d_wgrad(const egne_conv_desc* d, const float* gz, int64_t gzs, int gzo, int Cout, int Cin,

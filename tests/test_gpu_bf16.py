@@ -251,6 +251,21 @@ def test_weight_and_data_gradients_bf16_storage(G, kind, Cin, Cout, H, W):
     bw.run()
     torch.cuda.synchronize()
     assert torch.equal(wp.grad, first)
+    # a REJECTED call in between (null gradient tensor: every argument is validated before the first launch) queues nothing and
+    # leaves the workspace zero-filled: the next good pass gives the same bits again
+    import ctypes as C
+    from egne_amd import _lib
+    fn, args, _ = [c for c in bw.calls if c[2].endswith(".wgrad")][0]
+    gwi = [i for i, a in enumerate(args) if isinstance(a, C.Array)][0]
+    bad = args[:gwi] + ((C.c_void_p * 1)(None),) + args[gwi + 1:]
+    assert fn(*bad, _lib.stream_ptr()) != 0
+    wp.grad.zero_()
+    bp.grad.zero_()
+    pl.zero_grads()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    assert torch.equal(wp.grad, first)
 
 
 @pytest.mark.parametrize("case,Cin,Cout,k,stride,P,H,W", [("7x7 on 3 channels (folded taps)", 3, 64, 7, 1, 3, 45, 70), ("4x4 stride 2", 64, 128, 4, 2, 1, 48, 64),

@@ -228,6 +228,66 @@ def test_esf_width_generalisation_vs_oracle(edge_of, chz, cfg):
     assert worst < 1e-2, "gradient norms differ by %.2e" % worst
 
 
+@pytest.mark.parametrize("case", ["mask", "nomask", "disent", "outputs_only"])
+def test_gradients_through_the_outputs_vs_oracle(edge_of, case):
+    """SURVEY.md section 8(b) "Autograd": op, elPred, latent and elOut carry grad in the reference (models/RITnet_v2.py:334-354), so
+    a caller may add its own terms on them next to the returned loss.  The HIP path hands their gradients to the loss head's
+    backward kernel (egne_loss_desc.g_op_nchw / g_pred_c / g_elOut_up) and to the latent's twin: parameter gradients against the
+    oracle's autograd for the same composite objective, with masks present (elPred's iris centre is a soft-argmax of the logits),
+    with no mask in the batch (it is a copy of elOut[:, 5:7]), with the dataset-confusion head writing the latent's twin first, and
+    with the outputs' terms ALONE (no gradient of the returned loss at all)."""
+    from common import batch_args, esf_module, setting
+    from oracle import esfnet as oesf
+    cfg = "baseline_edge"
+    kw = dict(B=2, seed=99, mask_absent_every=1) if case == "nomask" else dict(B=2, seed=77)
+    b, edge = edge_of(**kw)
+    dis = case == "disent"
+    m = esf_module(cfg, seed=5, disentangle=dis)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def objective(op, elPred, latent, loss, elOut):
+        extra = (0.1 * op.square().mean() + 3.0 * (elPred * torch.linspace(-1, 1, 10, device=op.device)).sum(1).abs().mean()
+                 + 0.5 * latent.square().mean() + 2.0 * elOut.tanh().sum(1).mean())
+        return extra if case == "outputs_only" else loss.sum() + extra
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    ref = oesf.esf_forward(sdg, setting(cfg), *batch_args(b, edge.cpu()), training=True, disentangle=dis)
+    lref = objective(*ref[:5])
+    lref.backward()
+    m = m.to(DEV).train()
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    out = m(*args)
+    lhip = objective(*out)
+    np.testing.assert_allclose(lhip.item(), lref.item(), rtol=1e-3)
+    lhip.backward()
+    torch.cuda.synchronize()
+
+    def compare(sdr, what):
+        scale = max(v.grad.norm().item() for v in sdr.values() if v.grad is not None)
+        worst, n, num, den = 0.0, 0, 0.0, 0.0
+        for name, p in m.named_parameters():
+            if sdr[name].grad is None:
+                continue
+            r, g = sdr[name].grad.double(), p.grad.double().cpu()
+            num, den = num + (r - g).square().sum().item(), den + r.square().sum().item()
+            if r.norm().item() < 1e-4 * scale:
+                continue
+            n += 1
+            worst = max(worst, (r - g).norm().item() / r.norm().item())
+        whole = (num / den) ** 0.5
+        print("%s, %s: %d tensors, worst per-tensor relative L2 %.2e, whole gradient %.2e" % (case, what, n, worst, whole))
+        assert n > 50 and worst < 3e-2 and whole < 1e-2, "%s: gradients differ from the oracle's autograd (per tensor %.2e, whole %.2e)" % (what, worst, whole)
+    compare(sdg, "loss + terms on the outputs")
+    # the fast path is untouched by what the composite call left behind: a plain loss.backward() right after gives the loss-only gradients
+    for p in m.parameters():
+        p.grad.zero_()
+    m.load_state_dict(sd)             # (training-mode BatchNorm moved the running statistics; the oracle starts from sd again)
+    m(*args)[3].sum().backward()
+    sd2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    oesf.esf_forward(sd2, setting(cfg), *batch_args(b, edge.cpu()), training=True, disentangle=dis)[3].sum().backward()
+    torch.cuda.synchronize()
+    compare(sd2, "loss alone, afterwards")
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 96, 128), (2, 160, 224), (1, 330, 250)])
 def test_bdcn_other_resolutions_vs_oracle(B, H, W):
     """The kernel selection (halo / lattice / transposed tiles / deep trunk tiles) keys on the map size and 240x320 is what

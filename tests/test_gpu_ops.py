@@ -279,6 +279,32 @@ def test_fit_large_batch_form_is_bit_exact_too(G):
     np.testing.assert_array_equal(ev, ev_small[order])
 
 
+def test_fit_large_masks_in_a_large_batch(G):
+    """384x512 class maps: two searches fit the default 64 KB of dynamic LDS, four do not, so a batch of n >= 64 searches must fall
+    back from the four-per-workgroup form to the two-per-workgroup one (fit.hip, egne_ellipse_fit) instead of failing the launch.
+    Four rendered ellipses, each sixteen times in a shuffled batch, against the oracle's search (utils.py:450-486 restated)."""
+    from gpu_util import DEV
+    from egne_amd.utils import fit_ellipses
+    from oracle import fit as ofit
+    H, W = 384, 512
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    cases = [(250.0, 190.0, 90.0, 60.0, 0.3), (200.0, 150.0, 40.0, 55.0, -0.5), (300.0, 220.0, 120.0, 80.0, 1.0), (256.0, 192.0, 30.0, 30.0, 0.0)]
+    masks, inits, want = [], [], []
+    for cx, cy, a, b, t in cases:
+        X = (xx - cx) * np.cos(t) + (yy - cy) * np.sin(t)
+        Y = -(xx - cx) * np.sin(t) + (yy - cy) * np.cos(t)
+        m = ((X / a) ** 2 + (Y / b) ** 2 <= 1.0)
+        init = np.array([cx, cy, a * 0.9 + 2.0, b * 1.1 - 1.5, t + 0.07])
+        masks.append(m.astype(np.int64))
+        inits.append(init)
+        want.append(ofit.fit_ellipse(m, list(init)))
+    order = np.random.RandomState(5).permutation(np.tile(np.arange(4), 16))
+    assert len(order) >= 64
+    out = fit_ellipses(torch.from_numpy(np.stack(masks)).to(DEV), order.tolist(), [1] * len(order), np.stack(inits)[order])
+    bad = [int(i) for i, c in enumerate(order) if not np.array_equal(out[i], want[c])]
+    assert not bad, "fit of 384x512 masks differs from the oracle at positions %s" % bad[:8]
+
+
 def test_errors_are_reported(G):
     """Host-side validation returns an error code + message instead of launching."""
     import ctypes as C

@@ -212,7 +212,7 @@ from common import batch_args, bdcn_module, esf_module
 import types
 from egne_amd.utils import calc_edge
 
-mode = sys.argv[1]                    # "none" | "sync" | "async"
+mode = sys.argv[1]                    # "none" | "sync" | "async" | "overlap" (two buckets, the first issued inside the backward pass)
 dev = "cuda:0"
 torch.cuda.set_device(0)
 rank, world = parallel.init()
@@ -223,6 +223,14 @@ m = esf_module("baseline_edge").to(dev).train()
 parallel.broadcast_state(m)
 opt = torch.optim.Adam([p for n, p in m.named_parameters() if "dsIdentify" not in n], lr=5e-4)
 args = [a.to(dev) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+if mode == "overlap":
+    parallel.overlap_grads(m)
+    issued = []
+    orig = m.grad_comm.tail_ready
+    def spy():
+        orig()
+        issued.append(bool(m.grad_comm.pending))
+    m.grad_comm.tail_ready = spy
 ms = []
 for step in range(2):                 # train.py:284-287 with the gradient exchange of egne_amd.parallel in place of nn.DataParallel
     opt.zero_grad()
@@ -247,6 +255,8 @@ h = hashlib.sha256()
 for k, v in sorted(m.state_dict().items()):
     h.update(v.detach().cpu().contiguous().numpy().tobytes())
 out.update(sha=h.hexdigest(), allreduce_ms=ms, loss=float(loss.item()))
+if mode == "overlap":
+    out["issued_inside_backward"] = issued
 json.dump(out, open(sys.argv[2], "w"))
 if dist.is_initialized():
     dist.barrier()
@@ -266,7 +276,7 @@ def test_rccl_one_rank_training_matches_the_plain_run(tmp_path):
     script = tmp_path / "rccl_worker.py"
     script.write_text(_RCCL_WORKER % dict(root=root))
     res = {}
-    for i, mode in enumerate(("none", "sync", "async")):
+    for i, mode in enumerate(("none", "sync", "async", "overlap")):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + (os.getpid() % 90) + i), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.pop("EGNE_DIST_BACKEND", None)
@@ -280,7 +290,9 @@ def test_rccl_one_rank_training_matches_the_plain_run(tmp_path):
         assert p.returncode == 0, "%s run failed:\n%s" % (mode, p.stdout.decode()[-3000:])
         res[mode] = json.load(open(outp))
     assert not res["none"]["active"] and res["none"]["backend"] is None
-    for mode in ("sync", "async"):
+    # the two-bucket form: the tail of the arena went out from inside both backward passes (parallel.GradOverlap, engine.Plan.tail_hook)
+    assert res["overlap"]["issued_inside_backward"] == [True, True], res["overlap"]
+    for mode in ("sync", "async", "overlap"):
         r = res[mode]
         assert r["active"] and r["backend"] == "nccl" and r["world"] == 1
         assert r["sha"] == res["none"]["sha"], "%s: weights differ from the run without a process group" % mode

@@ -222,6 +222,72 @@ def test_data_parallel_collectives_gloo_world2(tmp_path):
         assert p.returncode == 0 and "ok" in o, "rank %d failed:\n%s" % (r, o[-3000:])
 
 
+_DP4_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import torch, torch.distributed as dist
+from common import esf_module
+from egne_amd import parallel
+rank, world = parallel.init('gloo')
+assert world == 4
+m = esf_module('baseline_adain_edge', seed=rank)
+parallel.broadcast_state(m)
+flat = m._ensure_grad_arena()
+gens = [torch.randn(flat.numel(), generator=torch.Generator().manual_seed(300 + r)) for r in range(4)]
+want = (gens[0] + gens[1] + gens[2] + gens[3]) / 4
+# one bucket
+flat.copy_(gens[rank]); parallel.allreduce_grads(m)
+assert torch.allclose(flat, want, atol=1e-6)
+# two buckets: the tail (everything behind the encoder's block) goes out first, as the backward plan's hook does
+parallel.overlap_grads(m)
+gc = m.grad_comm
+s = gc.split()
+names = [n for n, _ in m.named_parameters()]
+nenc = sum(p.numel() for n, p in m.named_parameters() if n.startswith('enc.'))
+assert s == nenc and 0 < s < flat.numel() and names[0].startswith('enc.'), (s, nenc)
+flat.copy_(gens[rank])
+gc.tail_ready()
+assert gc.pending
+# (the encoder's gradients are still being written while the tail is in flight)
+flat[:s].add_(1.0); flat[:s].sub_(1.0)
+parallel.allreduce_grads(m)
+assert not gc.pending and torch.allclose(flat, want, atol=1e-6)
+# a backward pass that never reached the hook (a foreign model, a plan without encoder launches): the one-bucket path
+flat.copy_(gens[rank]); parallel.allreduce_grads(m)
+assert torch.allclose(flat, want, atol=1e-6)
+# shards, samplers and scalar sums at four ranks
+lo, hi = parallel.shard(1024)
+assert (lo, hi) == (rank * 256, rank * 256 + 256)
+assert parallel.sum_over_ranks([float(rank), 1.0]) == [6.0, 4.0]
+from egne_amd import _entry
+ts, vs = parallel.samplers(_entry.SyntheticEyes(10, seed=1), _entry.SyntheticEyes(11, seed=1), rank, world)
+idx = torch.tensor(list(ts)); allidx = [torch.zeros_like(idx) for _ in range(4)]
+dist.all_gather(allidx, idx)
+assert len(idx) == 2 and len(set(sum((a.tolist() for a in allidx), []))) == 8
+assert list(vs) == list(range(rank, 11, 4))
+opt = torch.optim.SGD(m.parameters(), lr=0.1); opt.step()
+chk = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().reshape(1)
+every = [torch.zeros_like(chk) for _ in range(4)]
+dist.all_gather(every, chk)
+assert all(torch.equal(every[0], e) for e in every)
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok')
+"""
+
+
+def test_data_parallel_collectives_gloo_world4(tmp_path):
+    """Four ranks over gloo (BASELINE.json configs[3]: DP over 4 GPUs): the flat all-reduce, its two-bucket form whose tail bucket is
+    issued first (parallel.GradOverlap: what the backward plan does when it reaches the encoder), shards, samplers."""
+    script = tmp_path / "dp4_worker.py"
+    script.write_text(_DP4_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="4", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(4)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "ok" in o, "rank %d failed:\n%s" % (r, o[-3000:])
+
+
 def test_ellipse_transform_matches_reference():
     from egne_amd import ellipse
     g = gold("ellipse_transform")
