@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
                 ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
                 ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p), ("dtype", C.c_int32),
-                ("out_split", C.c_int32), ("out_split_scale", C.c_float)]
+                ("out_split", C.c_int32), ("out_split_scale", C.c_float), ("ovf_flag", C.c_void_p)]
 
 
 class BdcnTailDesc(C.Structure):

@@ -306,6 +306,7 @@ class BDCN(nn.Module):
     def forward(self, x):
         """bdcn_new.py:116-191: returns [p1_1..p5_1, p1_2..p5_2, fuse], each [B,1,H,W]."""
         pl = self._plan(x, only_fuse=False)
+        self._last_plan = pl
         pl.x_in.copy_(x.to(torch.float32))
         pl.run()
         return [pl.outs[k].clone() for k in range(11)]
@@ -313,6 +314,14 @@ class BDCN(nn.Module):
     def forward_fuse(self, x, edge_thres=0):
         """Only the fused edge map (what utils.calc_edge consumes, utils.py:648)."""
         pl = self._plan(x, only_fuse=True, edge_thres=edge_thres)
+        self._last_plan = pl
         pl.x_in.copy_(x.to(torch.float32))
         pl.run(self._events)
         return pl.outs[10].clone()
+
+    def overflowed(self):
+        """True if the LAST call produced non-finite values inside a split-f16 convolution: a frame whose activations exceed 32x those
+        of the batch the pre-scales were calibrated on left the f16 range (engine.Plan.overflowed) -- the edge maps of that call
+        are invalid.  Synchronises; the plan is re-calibrated by the next call, so the answer to True is to call again."""
+        pl = getattr(self, "_last_plan", None)
+        return pl is not None and pl.overflowed()

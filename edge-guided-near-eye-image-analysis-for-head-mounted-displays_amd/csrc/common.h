@@ -69,6 +69,18 @@ template <int N> __device__ __forceinline__ egne_fv<N> fv_fill(float x) {
 // the all-zero page typed for either storage (invalid lanes load from it unconditionally)
 template <typename T> __device__ __forceinline__ const T* zero_page() { return (const T*)egne_zero_page; }
 
+// ---- f16 overflow of the split operands (round 5) ---------------------------------------------------------------------
+// The split-f16 kernels scale an fp32 operand by a power of two calibrated on an earlier batch (engine.Plan: 32x of head-room)
+// before they round it to f16.  A later batch whose raw activations exceed that head-room turns operands into +-inf, and every
+// accumulator such an operand reaches becomes +-inf or NaN (inf * w, inf * 0, inf - inf): a NON-FINITE accumulator in an epilogue
+// is the one reliable trace of it (activations and pools downstream can swallow it again).  Epilogues OR a per-lane test of what
+// they store (v_cmp_class_f32: sNaN | qNaN | -inf | +inf, one vector instruction per value) and set the sticky device word
+// egne_conv_desc.ovf_flag, which engine.Plan reads back behind every run (Plan.check_overflow: recalibrate and run again).
+__device__ __forceinline__ bool egne_nonfinite(float v) { return __builtin_amdgcn_classf(v, 0x207); }
+__device__ __forceinline__ void egne_ovf_commit(bool bad, unsigned* flag) {
+  if (flag && bad) atomicOr(flag, 1u);
+}
+
 namespace egne {
 
 char* err_buf();  // thread-local 512-byte buffer (defined in api.hip)

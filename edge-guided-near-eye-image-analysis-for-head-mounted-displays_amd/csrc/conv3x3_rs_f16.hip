@@ -287,6 +287,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
 #pragma unroll
     for (int a = 0; a < WMW * WNW * NMH; ++a) { (&pvo[0][0][0])[a] = (int)OOB; (&pvr[0][0][0])[a] = (int)OOB; }
     int pchunk = -1;                                     // no previous tile yet: nothing to write
+    bool ovf_bad = false;                                // a non-finite value was stored (egne_conv_desc.ovf_flag)
     double st_s[WNW][NMH], st_q[WNW][NMH];
     int n4[WNW][NMH];
     bool nokv[WNW][NMH];
@@ -318,6 +319,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         v = v * pss[tn][nh] + pts[tn][nh];
         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr, c * res_step, 0));
       }
+      ovf_bad |= egne_nonfinite(v);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, c * out_step, 0);
       if (st_on) {
         if constexpr (first) { st_s[tn][nh] = 0.; st_q[tn][nh] = 0.; }
@@ -376,7 +378,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) prev[tm][0][tn][0][4 * j + e] = v[e];
+      for (int e = 0; e < 4; ++e) { prev[tm][0][tn][0][4 * j + e] = v[e]; ovf_bad |= egne_nonfinite(v[e]); }
     };
     auto tpo_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, j = Gi % 4, tm = (Gi / 4) % WMW, tn = Gi / (4 * WMW);
@@ -563,6 +565,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       if constexpr (TPO) [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (tpo_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
       else [&]<int... Vs>(std::integer_sequence<int, Vs...>) { (epi_value(std::integral_constant<int, Vs>{}), ...); }(std::make_integer_sequence<int, NV>{});
     }
+    egne_ovf_commit(ovf_bad, p.ovf_flag);
     if constexpr (DBG & 32) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       if (lane == 0 && p.stats_ws) {

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
   const long long left = M - m0;
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * 4));
   constexpr int NJ = M16 ? 1 : 4;
+  bool bad = false;
 #pragma unroll
   for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
@@ -249,12 +250,14 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
         for (int e = 0; e < 4; ++e) {
           const float t = acc[tm][tn][4 * j + e] * out_scale + bv[e];
           v[e] = fmaxf(t, t * slope);
+          bad |= egne_nonfinite(v[e]);
         }
         const int row = wm * 128 + tm * MB + lr;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
                                                nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
       }
     }
+  egne_ovf_commit(bad, p.ovf_flag);
 }
 
 // OIHW fp32 -> LDS images [ntile][step = chunk*T + tap][BN rows][128 B]: row j = output channel ntile*BN + j, granule g =

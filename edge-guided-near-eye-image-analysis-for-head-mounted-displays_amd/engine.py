@@ -73,8 +73,10 @@ FUSE_C4 = os.environ.get("EGNE_FUSE_C4", "1") != "0"              # convBlock he
 C1V = os.environ.get("EGNE_C1V", "1") != "0"                      # ... with the one-channel first convolution on the vector ALU (exact fp32)
 CALIBRATE = os.environ.get("EGNE_CALIBRATE", "1") != "0"          # per-layer pre-scale of RAW inputs from their measured max (Plan.run)
 RECAL_EVERY = int(os.environ.get("EGNE_RECAL_EVERY", "1024"))     # inference plans: runs between two calibrations (0: first run only).  The scales
-#   leave 32x of head-room over the calibration batch; a later batch beyond that would overflow f16 silently, so the maxima are re-measured
-#   on a schedule (one short sync per split launch, ~0.1 % of the runs in between)
+#   leave 32x of head-room over the calibration batch and are re-measured on a schedule (one short sync per split launch, ~0.1 % of the
+#   runs in between).  A batch beyond the head-room turns f16 operands into inf: every split-f16 epilogue tests what it stores and sets
+#   the plan's sticky overflow word (round 5, OVF_CHECK); Plan.overflowed() / check_overflow() read it, the next run refuses to go on
+OVF_CHECK = os.environ.get("EGNE_OVF_CHECK", "1") != "0"          # inference plans: split-f16 epilogues report non-finite results (egne_conv_desc.ovf_flag, Plan.overflowed)
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
 HALO_TALL = os.environ.get("EGNE_SHALO_TALL", "1") != "0"           # conv_halo_f16.hip walks a map transposed when that takes fewer 8 x 32 tiles
@@ -610,6 +612,10 @@ class Plan:
         self.join_before = set()                       # call indices in front of which the main stream waits for the second one
         self.window_at = None                          # call index at which pending WINDOW_HOOKS are released (None: never)
         self.serial_timing = False                     # run(events): one stream when launches are timed (overlapping kernels stretch each other's durations)
+        # f16 overflow of calibrated pre-scales (inference plans): device word set by the split-f16 epilogues, pinned host mirror copied
+        # behind every run, the event that says the copy has landed
+        self.ovf = self.ovf_host = self.ovf_event = None
+        self.overflow_events = 0
         self.tail_at, self.tail_hook = None, None      # backward plans: call index where every non-encoder parameter gradient is final, and what to call there (parallel.GradOverlap.tail_ready)
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _StorageLib(_lib.lib(), self.bf16)
@@ -731,6 +737,68 @@ class Plan:
         else:
             self.zero_grads()
 
+    # ---- f16 overflow of the calibrated pre-scales ---------------------------------------------------------
+    def ovf_ptr(self):
+        """Device address of the plan's sticky overflow word for a split-f16 launch descriptor (egne_conv_desc.ovf_flag), or None:
+        only plans whose pre-scales are CALIBRATED need it (training plans take theirs on the device, bf16 plans have none)."""
+        if not OVF_CHECK or self.train or self.bf16 or self.dyn_scales or getattr(self, "fwd", None) is not None:
+            return None
+        if self.ovf is None:
+            self.ovf = self.vec(1, dtype=torch.int32)
+            self.ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.ovf_event = torch.cuda.Event()
+        return self.ovf.data_ptr()
+
+    def _ovf_publish(self):
+        """Behind the launches of a run: the word goes to pinned host memory (4 bytes, no synchronisation)."""
+        if self.ovf is None:
+            return
+        self.ovf_host.copy_(self.ovf, non_blocking=True)
+        if torch.cuda.is_current_stream_capturing():
+            self._ovf_graphed = True          # the copy is a node of the hipGraph: it lands with every replay, no event to wait on
+        else:
+            self.ovf_event.record()
+            self._ovf_recorded = True
+
+    def _ovf_reset(self):
+        self.ovf.zero_()
+        self.ovf_host.zero_()
+        self.calibrated = False          # the next run measures the maxima of ITS batch and takes its scales from them
+        self.overflow_events += 1
+
+    def overflowed(self, wait=True):
+        """True if a run since the last call produced non-finite values in a split-f16 epilogue: an activation left the f16 range of
+        its calibrated pre-scale (a batch beyond 32x the calibration maxima) -- or the inputs were not finite.  The outputs of
+        that run are INVALID.  Clears the word and marks the plan for re-calibration, so the caller's answer is simply to run
+        the batch again.  ``wait``: block until the last run's word has reached the host (callers ask where they synchronise
+        anyway: test.py / evaluate.py when they read the masks); without it only a completed run is judged."""
+        if self.ovf is None:
+            return False
+        if getattr(self, "_ovf_graphed", False):
+            if not wait:
+                return False
+            torch.cuda.synchronize(self.device)      # replays of a captured plan: whatever ran last has published its word
+        elif not getattr(self, "_ovf_recorded", False):
+            return False
+        elif wait:
+            self.ovf_event.synchronize()
+        elif not self.ovf_event.query():
+            return False
+        if int(self.ovf_host[0]) == 0:
+            return False
+        self._ovf_reset()
+        return True
+
+    def check_overflow(self):
+        """``overflowed()`` answered in place: re-calibrate on the batch that is still in the plan's input buffers and run it again.
+        Returns True if that happened (the caller re-reads the outputs); raises if the second run is not finite either."""
+        if not self.overflowed():
+            return False
+        self.run()
+        if self.overflowed():
+            raise RuntimeError("non-finite values in a split-f16 convolution after re-calibration: the inputs themselves are not finite")
+        return True
+
     # ---- launches ----------------------------------------------------------------------------
     DYN_SLOTS = 512
 
@@ -843,6 +911,7 @@ class Plan:
                 self.layers.append(layer)
             layer.ensure_packed(self.device)
             d = _lib.ConvDesc()
+            d.ovf_flag = self.ovf_ptr()
             d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
             d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.pad_mode, d.ngroups = 3, 3, 1, 1, 1, 0, 1
             for g in range(_lib.MAXGROUP):
@@ -1001,6 +1070,7 @@ class Plan:
             self.layers.append(layer)
         layer.ensure_packed(self.device)
         d = _lib.ConvDesc()
+        d.ovf_flag = self.ovf_ptr()
         d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
         d.kh, d.kw, d.stride = layer.kh, layer.kw, layer.stride
         d.pad_h, d.pad_w, d.pad_mode = layer.pad[0], layer.pad[1], layer.pad_mode
@@ -1318,6 +1388,7 @@ class Plan:
             self.layers.append(layer)
         layer.ensure_packed(self.device)
         d = _lib.ConvDesc()
+        d.ovf_flag = self.ovf_ptr()
         d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
         d.kh = d.kw = d.stride = d.ngroups = 1
         d.nseg = len(pieces)
@@ -1384,6 +1455,7 @@ class Plan:
                 self.layers.append(l)
             l.ensure_packed(self.device)
         d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        d2.ovf_flag = self.ovf_ptr()
         for d, l in ((d1, l1), (d2, l2)):
             d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
             d.kh, d.kw, d.stride = l.kh, l.kw, 1
@@ -1450,6 +1522,7 @@ class Plan:
             l.ensure_packed(self.device)
         assert l1.c4_coutp == 32
         d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        d2.ovf_flag = self.ovf_ptr()
         for d, l in ((d1, l1), (d2, l2)):
             d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
             d.kh, d.kw, d.stride = 3, 3, 1
@@ -1729,12 +1802,21 @@ class Plan:
         if repacked:
             self._refresh_wscales()
         st = _lib.stream_ptr()
+        if self.ovf is not None and self.overflowed(wait=False):
+            raise RuntimeError("an earlier run of this launch plan overflowed the f16 range of its calibrated pre-scales (a batch whose "
+                               "activations exceed 32x the calibration batch's): the outputs of that run are invalid.  The plan has "
+                               "been marked for re-calibration -- run that batch again; callers that check Plan.overflowed() / the "
+                               "model's overflowed() where they synchronise never get here")
         self._runs_since_cal = getattr(self, "_runs_since_cal", 0) + 1
         if self.cal and (repacked or not self.calibrated or (RECAL_EVERY and self._runs_since_cal >= RECAL_EVERY)):
             self._runs_since_cal = 0
-            return self._run_calibrating(st)
+            r = self._run_calibrating(st)
+            self._ovf_publish()
+            return r
         if self.side_calls and not (events is not None and self.serial_timing):
-            return self._run_two_streams(st, events)
+            r = self._run_two_streams(st, events)
+            self._ovf_publish()
+            return r
         if events is None:
             for i, (fn, args, name) in enumerate(self.calls):
                 if i == self.window_at and WINDOW_HOOKS:
@@ -1744,6 +1826,7 @@ class Plan:
                 rc = fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, name)
+            self._ovf_publish()
             return
         for i, ((fn, args, name), (kind, flops)) in enumerate(zip(self.calls, self.meta)):
             if i == self.window_at and WINDOW_HOOKS:
@@ -1762,6 +1845,7 @@ class Plan:
             if rc != 0:
                 _lib.check(rc, name)
             events.append((kind, flops, e0, e1, name))
+        self._ovf_publish()
 
     def _open_window(self):
         """Launch index ``window_at`` is where work that should run NEXT TO this plan's following launches is released (the ellipse

@@ -114,9 +114,19 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
     from egne_amd.utils import calc_edge
     assert frames.dim() == 4, 'Frame must be [N,1,H,W]'
     ns = argparse.Namespace(prec=torch.float32, edge_thres=0)
-    with torch.no_grad():
-        edge = calc_edge(ns, frames, edge_model, frames.device)
-    return _to_host(_seg_and_fit(frames, model)(edge))
+    for attempt in (0, 1):
+        with torch.no_grad():
+            edge = calc_edge(ns, frames, edge_model, frames.device)
+        res = _to_host(_seg_and_fit(frames, model)(edge))
+        # a frame beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): both plans re-calibrate on their
+        # next call, so the frames simply run again
+        if not (_overflowed(model) | _overflowed(edge_model)):
+            return res
+    raise RuntimeError("non-finite activations after re-calibration: the input frames themselves are not finite")
+
+
+def _overflowed(net):
+    return bool(net.overflowed()) if hasattr(net, "overflowed") else False
 
 
 def _seg_and_fit(frames, model, wfit=None):
@@ -286,6 +296,7 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
     wfit = WindowedFit(torch.device(device))
     ready = []
 
+    redo = [False]
     live = bool(getattr(args, 'low_latency', 0))    # head-mounted-display use: a frame's ellipses before the next frame arrives
     runner = [None]
 
@@ -300,6 +311,12 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
             if runner[0] is None or tuple(runner[0].x.shape) != tuple(x.shape):
                 runner[0] = graphed_runner(x, model, edge_model)
             res = [t.clone() for t in runner[0](x)]
+            if _overflowed(model) | _overflowed(edge_model):
+                # beyond the head-room of the scales baked into the captured launches: capture again (its eager warm-up runs re-calibrate)
+                runner[0] = graphed_runner(x, model, edge_model)
+                res = [t.clone() for t in runner[0](x)]
+                if _overflowed(model) | _overflowed(edge_model):
+                    raise RuntimeError("non-finite activations after re-calibration: the input frames themselves are not finite")
             done = torch.cuda.Event()
             done.record()
             frames_now = list(pending)
@@ -326,6 +343,12 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
         res, done = r
         done.synchronize()
         edge, seg, pup, iri = _to_host(res)
+        if redo[0] or _overflowed(model) | _overflowed(edge_model):
+            # invalid results (engine.Plan.overflowed): this batch again, back to back, on the re-calibrated plans -- and the batch
+            # queued behind it too, whose edge maps were computed with the old scales
+            redo[0] = not redo[0]
+            x = torch.stack([e[0] for _, _, fe in frames_of_batch for e in fe]).to(device)
+            edge, seg, pup, iri = evaluate_ellseg_on_image(x, model, edge_model)
         k = 0
         for j, frame_bgr, fe in frames_of_batch:
             overlay, edge_frame = frame_bgr.copy(), frame_bgr.copy()

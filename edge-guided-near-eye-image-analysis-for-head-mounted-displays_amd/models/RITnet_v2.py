@@ -321,6 +321,14 @@ class DenseNet2D(nn.Module):
         loss = pl.terms[0:1].clone()
         return pl.op.clone(), pl.elPred.clone(), pl.latent.to(torch.float32, copy=True), loss, pl.elOut.clone()
 
+    def overflowed(self):
+        """True if the LAST inference call produced non-finite values inside a split-f16 convolution (engine.Plan.overflowed: a batch
+        whose activations exceed 32x those of the batch the f16 pre-scales were calibrated on): its outputs are invalid.
+        Synchronises; the plan re-calibrates on the next call, so the answer to True is to run the batch again.  Training plans take
+        their scales on the device (or have none: bf16 storage) and never report."""
+        last = getattr(self, "_last_plan", None)
+        return last is not None and last.overflowed()
+
     def loss_flags(self):
         """Device scalar: the number of samples of the last forward whose ground-truth mask lacks TWO classes.  The reference's
         wCE dies there (``rmIdx.item()`` on a two-element tensor, loss.py:132); a kernel cannot raise, so the loss head counts

@@ -125,6 +125,10 @@ typedef struct {
    * the value itself (the 4-way sum of bdcn_new.py:54), exact to 2^-22 |x|. */
   int32_t out_split;
   float out_split_scale;      /* s > 0, a power of two */
+  /* Optional (every split-f16 entry point): sticky overflow word.  The kernel sets bit 0 when a value it stores is not finite --
+   * the trace of an operand that left the f16 range under the launch's calibrated pre-scale (or of non-finite input).  The
+   * caller clears it, reads it behind the launches it covers and answers by re-calibrating (engine.Plan.check_overflow). */
+  uint32_t* ovf_flag;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
