@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--train-storage", choices=("fp32", "bf16", "both"), default="both",
                     help="activation / activation-gradient storage of the training leg: bf16 (what BASELINE.json configs[2..4] name; "
                          "fp32 accumulation, fp32 master weights), fp32 (the parity anchor), or both legs (default)")
+    ap.add_argument("--edge-products", choices=("auto", "1", "3"), default="auto",
+                    help="training legs: products per multiply of the frozen edge network (egne_conv_desc.f16_products).  auto = what train.py does: "
+                         "1 (plain f16 operands, fp32 accumulate) next to a bf16-storage plan, which rounds the edge map to bf16 on entry; 3 (the "
+                         "22-bit split) next to an fp32-storage plan.  The bf16 leg also reports its rate with 3 (`edge_split3_value`)")
     ap.add_argument("--mode", choices=("all", "infer", "train", "prep"), default="all",
                     help="all: every leg in one JSON line (default); infer / train: that leg only; "
                          "prep: device-side batch preparation (distance maps + z-score, SURVEY.md 8f N1)")
@@ -575,8 +579,12 @@ class Bench:
         assert steps == 0 or self.torch.isfinite(out[3]).all()
         return B, dt, ev
 
-    def leg_train(self, steps, warmup, events=True, pipeline=None, storage="fp32"):
+    def leg_train(self, steps, warmup, events=True, pipeline=None, storage="fp32", edge_products=None):
         torch = self.torch
+        if edge_products is None:
+            edge_products = {"auto": 1 if storage == "bf16" else 3, "1": 1, "3": 3}[self.a.edge_products]
+        self.bd.f16_products = 1 if edge_products == 1 else 0        # (egne_amd/train.py: --prec 16 sets it on its edge network)
+        self.edge_products = edge_products
         from egne_amd import parallel
         from egne_amd.utils import calc_edge
         B = self.a.train_batch
@@ -625,6 +633,7 @@ class Bench:
         self.grad_bytes = int(net._grad_flat.numel() * 4) if getattr(net, "_grad_flat", None) is not None else 0
         net.eval()
         net.to(torch.float32)
+        self.bd.f16_products = 0
         return B, dt, ev
 
 
@@ -801,7 +810,9 @@ def main():
                     "Adam, batch=%d/GPU, bf16 STORAGE of activations and activation gradients in HBM, fp32 accumulation, fp32 master weights / "
                     "gradient arena / optimiser (3x3 and raw-slice 1x1 convolutions, their data and weight gradients on bf16 MFMAs with weights "
                     "rounded to bf16; everything else fp32 arithmetic on bf16 tensors)" % (which, a.config, a.chz, B))
-            dty = "bf16 storage, f32 accumulate, f32 master weights (frozen edge network: f32 tensors, split-f16 products)"
+            dty = ("bf16 storage, f32 accumulate, f32 master weights (frozen edge network: f32 tensors, %s)"
+                   % ("plain f16 operands / f32 accumulate in the deep trunk layers -- its output is rounded to bf16 on entry; `edge_split3_value`: "
+                      "the same step with the 22-bit split products" if bn.edge_products == 1 else "split-f16 products"))
         else:
             what = ("BASELINE.json %s shape with FP32 storage (the parity anchor): %s.yaml (chz=%d) train step = frozen BDCN forward + ESF-Net "
                     "forward + backward + gradient all-reduce + Adam, batch=%d/GPU, fp32 storage and accumulation (3x3 forward convs, data and "
@@ -819,6 +830,13 @@ def main():
               "roofline": {k: rdom[k] for k in keys if k in rdom}}
         if rsec is not None:
             tr["roofline_secondary"] = {k: rsec[k] for k in keys if k in rsec}
+        tr["edge_products"] = bn.edge_products
+        if storage == "bf16" and bn.edge_products == 1 and a.edge_products == "auto":
+            # the same step with the frozen edge network on the 22-bit split products (what the fp32-storage leg and every inference leg use)
+            s3 = max(2, steps // 2)
+            B3, dt3, _ = bn.leg_train(s3, 1, events=False, storage=storage, edge_products=3)
+            tr["edge_split3_value"] = round(B3 * s3 * world / dt3, 2)
+            tr["edge_split3_ms_per_step"] = round(1e3 * dt3 / s3, 3)
         bn.free_plans()
         return tr, rdom, rsec
 
@@ -838,6 +856,9 @@ def main():
                 res["roofline_secondary"] = rsec
             if "fp32_storage" in tr:
                 res["fp32_storage"] = tr["fp32_storage"]
+            for k in ("edge_products", "edge_split3_value", "edge_split3_ms_per_step"):
+                if k in tr:
+                    res[k] = tr[k]
         else:
             res["train"] = tr
 
@@ -855,6 +876,8 @@ def main():
         if "train" in res:
             extra.update(train_value=res["train"]["value"], train_ms_per_step=res["train"]["ms_per_step"],
                          train_allreduce_ms_per_step=res["train"]["allreduce_ms_per_step"])
+            if "edge_split3_value" in res["train"]:
+                extra.update(train_edge_split3_value=res["train"]["edge_split3_value"])
             if "fp32_storage" in res["train"]:
                 extra.update(train_fp32_storage_value=res["train"]["fp32_storage"]["value"])
         if "latency_b2_ms" in res:

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libegne_hip.so")
+# (EGNE_LIB: another build of the same sources, for A/B timing of a kernel change inside one gpurun call -- never a different backend)
+LIB_PATH = os.environ.get("EGNE_LIB") or os.path.join(_HERE, "csrc", "libegne_hip.so")
 
 MAXSEG, MAXGROUP = 8, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -35,7 +36,7 @@ class ConvDesc(C.Structure):
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
                 ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
                 ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p), ("dtype", C.c_int32),
-                ("out_split", C.c_int32), ("out_split_scale", C.c_float), ("ovf_flag", C.c_void_p)]
+                ("out_split", C.c_int32), ("out_split_scale", C.c_float), ("ovf_flag", C.c_void_p), ("f16_products", C.c_int32)]
 
 
 class BdcnTailDesc(C.Structure):

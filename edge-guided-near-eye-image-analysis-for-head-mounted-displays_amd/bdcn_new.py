@@ -106,6 +106,7 @@ class BDCN(nn.Module):
         self.fuse = nn.Conv2d(10, 1, 1, stride=1)
         self._initialize_weights()
         self._plans = {}
+        self.f16_products = 0
         self._events = None  # bench.py: list collecting per-launch HIP events
         self.edge_thres = 0  # set by utils.calc_edge to fuse the >=0.1 -> 1 threshold into the tail
 
@@ -128,6 +129,10 @@ class BDCN(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _build(self, B, H, W, dev, only_fuse, edge_thres):
         pl = Plan(dev)
+        # BDCN.f16_products = 1: plain f16 operands (one MFMA per product instead of the split's three) in the kernels that know
+        # egne_conv_desc.f16_products -- the frozen edge network next to a training plan with bf16 activation storage, which rounds
+        # the edge map to bf16 on entry (train.py / bench.py set it for --prec 16 only; inference and fp32 storage keep the split)
+        pl.f16_products = getattr(self, "_plan_products", 0)
         L = pl.L
         f = self.features
         x_in = pl.vec(B, 3, H, W)
@@ -298,8 +303,10 @@ class BDCN(nn.Module):
         B, Cc, H, W = x.shape
         if Cc != 3:
             raise ValueError("BDCN expects a 3-channel input, got %d" % Cc)
-        key = (B, H, W, x.device, bool(only_fuse), int(edge_thres))
+        prod = 1 if int(getattr(self, "f16_products", 0)) == 1 else 0
+        key = (B, H, W, x.device, bool(only_fuse), int(edge_thres), prod)
         if key not in self._plans:
+            self._plan_products = prod
             self._plans[key] = self._build(B, H, W, x.device, only_fuse, edge_thres)
         return self._plans[key]
 

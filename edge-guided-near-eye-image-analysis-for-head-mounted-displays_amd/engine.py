@@ -616,6 +616,7 @@ class Plan:
         # behind every run, the event that says the copy has landed
         self.ovf = self.ovf_host = self.ovf_event = None
         self.overflow_events = 0
+        self.f16_products = 0                          # egne_conv_desc.f16_products of the plan's split-f16 launches (1: plain f16 operands; BDCN.f16_products)
         self.tail_at, self.tail_hook = None, None      # backward plans: call index where every non-encoder parameter gradient is final, and what to call there (parallel.GradOverlap.tail_ready)
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
         self.L = _StorageLib(_lib.lib(), self.bf16)
@@ -911,7 +912,7 @@ class Plan:
                 self.layers.append(layer)
             layer.ensure_packed(self.device)
             d = _lib.ConvDesc()
-            d.ovf_flag = self.ovf_ptr()
+            d.ovf_flag, d.f16_products = self.ovf_ptr(), self.f16_products
             d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
             d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.pad_mode, d.ngroups = 3, 3, 1, 1, 1, 0, 1
             for g in range(_lib.MAXGROUP):
@@ -1070,7 +1071,7 @@ class Plan:
             self.layers.append(layer)
         layer.ensure_packed(self.device)
         d = _lib.ConvDesc()
-        d.ovf_flag = self.ovf_ptr()
+        d.ovf_flag, d.f16_products = self.ovf_ptr(), self.f16_products
         d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
         d.kh, d.kw, d.stride = layer.kh, layer.kw, layer.stride
         d.pad_h, d.pad_w, d.pad_mode = layer.pad[0], layer.pad[1], layer.pad_mode
@@ -1388,7 +1389,7 @@ class Plan:
             self.layers.append(layer)
         layer.ensure_packed(self.device)
         d = _lib.ConvDesc()
-        d.ovf_flag = self.ovf_ptr()
+        d.ovf_flag, d.f16_products = self.ovf_ptr(), self.f16_products
         d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
         d.kh = d.kw = d.stride = d.ngroups = 1
         d.nseg = len(pieces)
@@ -1455,7 +1456,7 @@ class Plan:
                 self.layers.append(l)
             l.ensure_packed(self.device)
         d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
-        d2.ovf_flag = self.ovf_ptr()
+        d2.ovf_flag, d2.f16_products = self.ovf_ptr(), self.f16_products
         for d, l in ((d1, l1), (d2, l2)):
             d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
             d.kh, d.kw, d.stride = l.kh, l.kw, 1
@@ -1522,7 +1523,7 @@ class Plan:
             l.ensure_packed(self.device)
         assert l1.c4_coutp == 32
         d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
-        d2.ovf_flag = self.ovf_ptr()
+        d2.ovf_flag, d2.f16_products = self.ovf_ptr(), self.f16_products
         for d, l in ((d1, l1), (d2, l2)):
             d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
             d.kh, d.kw, d.stride = 3, 3, 1

@@ -247,6 +247,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
         pl.conv(l1, [xin_p], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
         pre = pl.buf(NB, H, W, pad8(chz))
         pl.conv(l, [Piece(t0, 0, chz)], Piece(pre, 0, chz), NB, H, W, name="enc.head.conv2")
+        pl.dbg["head_pre"] = pre
         _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn")
         if add_edge:
             _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], B, B, H * W, "enc.head.bn.edge")

@@ -140,6 +140,11 @@ class DeepVOG_pytorch(nn.Module):
         emb = torch.ones(B, 5, device=x.device)
         return out, elPred, emb, loss, emb
 
+    def overflowed(self):
+        """As DenseNet2D.overflowed (engine.Plan.overflowed): the last inference call left the f16 range of its calibrated pre-scales."""
+        last = getattr(self, "_last_plan", None)
+        return last is not None and last.overflowed()
+
     def predictions(self):
         """Argmax mask [B,H,W] int64 of the last forward (utils.get_predictions on the two-channel output): 1 = pupil."""
         last = getattr(self, "_last_plan", None)

@@ -46,14 +46,20 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
     ranks feed the same numbers to the LR scheduler / early stopping."""
     model.eval()
     lsum = nsamp = isum = icnt = 0.0
+    train_products, edge_model.f16_products = getattr(edge_model, "f16_products", 0), 0      # validation: the 22-bit split products, as test.py
     for bt, batch in enumerate(loader):
         if args.test_normal and bt > 20:
             break
         img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
-        with torch.no_grad():
-            edge = calc_edge(args, img.to(device), edge_model, device)
-            out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
-                        dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
+        for attempt in (0, 1):
+            with torch.no_grad():
+                edge = calc_edge(args, img.to(device), edge_model, device)
+                out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
+                            dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
+            # a batch beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): both plans re-calibrate on their
+            # next call, so the batch runs once more
+            if not (bool(model.overflowed()) | bool(edge_model.overflowed())):
+                break
         # batches are weighted by their sample count: under torchrun the shards (and their last batches) differ in size
         n = float(img.shape[0])
         model.raise_on_loss_flags(model.loss_flags())       # two absent classes: loss.py:132 raises in the reference
@@ -64,6 +70,7 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
             isum += float(iou) * n
             icnt += n
     model.train()
+    edge_model.f16_products = train_products
     if nsamp == 0:
         raise RuntimeError("rank %d validated no batch (validation set too small for %d ranks?)" % (parallel.rank(), parallel.world_size()))
     sums = parallel.sum_over_ranks([lsum, nsamp, isum, icnt], device)
@@ -104,6 +111,11 @@ def main(argv=None):
         startEp = netDict['epoch'] + 1 if 'epoch' in netDict else 0
     model.selfCorr = bool(args.selfCorr)
     edge_net, model = edge_net.to(device).eval(), model.to(device).to(args.prec).train()
+    if args.prec in (torch.float16, torch.bfloat16) and os.environ.get("EGNE_EDGE_PRODUCTS", "1") == "1" and hasattr(edge_net, "f16_products"):
+        # --prec 16: the model rounds the edge map to bf16 (8-bit significand) on entry, so the frozen edge network in front of it runs
+        # on plain f16 operands (11 bits, fp32 accumulation: one MFMA per product instead of three; egne_conv_desc.f16_products).
+        # EGNE_EDGE_PRODUCTS=3 keeps the 22-bit split; validation / test.py / evaluate.py always use it
+        edge_net.f16_products = 1
     parallel.broadcast_state(model)
     parallel.overlap_grads(model)       # DP: the decoder-side half of the gradient all-reduce goes out from inside the backward pass (EGNE_OVERLAP_ALLREDUCE=0: one collective after it)
     params = [p for n, p in model.named_parameters() if 'dsIdentify' not in n]     # train.py:146-148

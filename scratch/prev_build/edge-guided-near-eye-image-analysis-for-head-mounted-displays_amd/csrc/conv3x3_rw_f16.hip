@@ -294,7 +294,6 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     // The values are finished (scale, bias, activation [, post affine, residual]) IN PLACE at hand-over; the deferred part is the bare
     // store.  Computing them next to the store would reuse the store's data registers group after group, and overwriting the source
     // of a store in flight costs a wait for its completion (vmcnt): eight write round trips per tile.
-    bool ovf_bad = false;                                // a non-finite value was stored (egne_conv_desc.ovf_flag)
     auto finish_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
       f32x4 v;
@@ -316,7 +315,6 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           for (int e = 0; e < 4; ++e) v[e] += rv[e];
         }
       }
-      if constexpr (nh == 0) ovf_bad |= egne_nonfinite(v[0]);      // lane = pixel: one channel per pixel (common.h)
       if (p.out_split) {
         // split-pair storage (egne_conv_desc.out_split): the consumer's hi / lo f16 halves of v * out_split_scale, written here ONCE
         // instead of being derived by every consumer workgroup that stages the element (the dilated group stages it 13.5 times)
@@ -446,7 +444,6 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     }
     if (have_prev)
       [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
-    egne_ovf_commit(ovf_bad, p.ovf_flag);
   }
   if ((dbg & 64) && lane == 0) {
     unsigned long long* o = g_wstamps + ((long long)blockIdx.x * 8 + wave) * 4;

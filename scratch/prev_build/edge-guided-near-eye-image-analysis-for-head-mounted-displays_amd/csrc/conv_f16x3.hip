@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
           for (int r = 0; r < 16; ++r) {
             const float v = acc[tm][tn][r] * out_scale + bv;
             res[tm][tn][r] += fmaxf(v, v * slope_out);
-          }     // (a non-finite term keeps the sum non-finite: the final store below tests it)
+          }
           acc[tm][tn] = (f32x16)(0.f);
         }
       }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int mr = mrow + (r & 3) + 8 * (r >> 2);
-          if (mr < left) wz[(long long)mr * p.CoutP + n] = acc[tm][tn][r] * out_scale;      // (splitk_finish_k tests the sum)
+          if (mr < left) wz[(long long)mr * p.CoutP + n] = acc[tm][tn][r] * out_scale;
         }
       }
     }
@@ -288,7 +288,6 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
                                                 p.residual ? (unsigned)((left < BM ? left : BM) * p.res_pix_stride * 4) : 0u);
   const int ostep = (int)p.out_pix_stride * 4, rstep = (int)p.res_pix_stride * 4;
-  bool bad = false;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + (wn * TN + tn) * 32 + li;
@@ -315,12 +314,10 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
         if (GROUPED) v = res[tm][tn][r];
         else { v = acc[tm][tn][r] * out_scale + bv; v = fmaxf(v, v * slope_out); }
         v = v * ps + pt + rv[r];
-        if (tn == 0) bad |= egne_nonfinite(v);         // (every output channel of a contaminated pixel is contaminated: one block per wave)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
       }
     }
   }
-  egne_ovf_commit(bad, p.ovf_flag);
 }
 
 // out[m][n] = epilogue(sum_z ws[z][m][n]): bias, activation, post affine, residual -- the tail of a split-K launch.
@@ -345,7 +342,6 @@ __global__ __launch_bounds__(256) void splitk_finish_k(const egne_conv_desc p, c
     if (p.post_scale) v = v * p.post_scale[n + e] + p.post_shift[n + e];
     if (rs) v += rs[e];
     o[e] = v;
-    egne_ovf_commit(egne_nonfinite(v), p.ovf_flag);
   }
 }
 

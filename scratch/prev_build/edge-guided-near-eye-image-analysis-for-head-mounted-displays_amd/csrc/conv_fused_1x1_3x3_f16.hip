@@ -628,7 +628,6 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         const int xl = tl.x0 + 4 * lh;
         const int cmax = xl < W ? W - xl : 0;      // c_r < cmax  <=>  x < W
         const bool edge = tl.x0 + TW > W || tl.y0 + TH > H || (nt0 + WNW) * 32 > p2.Cout_store;     // wave-uniform
-        bool bad = false;
 #pragma unroll
         for (int tn = 0; tn < WNW; ++tn) {
           const int n = (nt0 + tn) * 32 + li;
@@ -641,8 +640,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             const int pix = y * W + xl;
             const int o0 = (pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4;
             const int r0 = (pix * (int)p2.res_pix_stride + p2.res_ch_off + n) * 4;
-            if (st_on) egne::epi_row32_select<true>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q, bad, egne_ovf_row(y, H));
-            else egne::epi_row32_select<false>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q, bad, egne_ovf_row(y, H));
+            if (st_on) egne::epi_row32_select<true>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
+            else egne::epi_row32_select<false>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
           }
           if (st_on) {                 // one chunk = this wave's rows of this tile (fixed order: deterministic)
             st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
@@ -653,7 +652,6 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             }
           }
         }
-        egne_ovf_commit(bad, p2.ovf_flag);
       }
       stamp(t_work);
       lds_barrier();      // image i&1 may be overwritten, image (i+1)&1 is complete

@@ -272,7 +272,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           make_rsrc(p.residual ? p.residual + (long long)cur.b * p.H * p.W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
       const int xl = cur.px + S * (cur.x0 + 4 * lh);
       const int cmax = xl < vW ? (vW - xl + S - 1) / S : 0;      // c_r < cmax  <=>  x < W
-      bool bad = false;       // a non-finite value stored by this tile (egne_conv_desc.ovf_flag)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
         const int n = (nt0 + tn) * 32 + li;
@@ -286,7 +285,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
           const int cm = (nok && y < vH) ? cmax : 0;
-          const bool chk = LAT || D != 1 || egne_ovf_row(y, vH);       // (wave-uniform; common.h: which rows the overflow test needs)
           const int pix = y * rstep + xl * cstep;
           const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
           float rv[16];
@@ -305,7 +303,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             const int c = (r & 3) + 8 * (r >> 2);
             float v = acc[tm][tn][r] * out_scale + bv;
             v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
-            if (chk) bad |= egne_nonfinite(v);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
             const double vm = c < cm ? (double)v : 0.;
             st_s += vm; st_q += vm * vm;
@@ -345,7 +342,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           }
         }
       }
-      egne_ovf_commit(bad, p.ovf_flag);
     }
     t = tnext;
     if (t >= ntiles) break;

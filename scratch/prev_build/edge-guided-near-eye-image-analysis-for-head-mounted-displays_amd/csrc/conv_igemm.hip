@@ -1,0 +1,615 @@
+// Implicit-GEMM convolution for gfx950: fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32.
+//
+// GEMM view:  M = B*Ho*Wo output pixels (flat, so odd sizes such as 29x39 or 15x20 waste nothing),
+//             N = Cout, K = taps * sum(channels of the input slices).
+// A (pixels x K) is gathered on the fly from up to EGNE_MAXSEG NHWC channel slices -- this is how
+// torch.cat disappears -- with zero / reflect padding and an optional per-(n,c) affine + LeakyReLU
+// fused into the load (InstanceNorm / Transition_down).  B (Cout x K) is the pre-packed weight
+// [group][tap][CoutP][Ktot], K contiguous, so both operands are "row x contiguous-k" LDS tiles read
+// with ds_read_b128: lane (i = lane&31, h = lane>>5) fetches k = 8*s + 4*h .. +3 of row i and feeds
+// four 32x32x2 MFMAs (the k pairing (j, 4+j) is the same for A and B, and the K order is free).
+// LDS rows are padded to 36 floats: ds_read_b128 lane groups then hit 16 distinct 16-B slots.
+//
+// Staging is global -> registers -> LDS with the loads of step s+1 issued before the MFMAs of
+// step s (one LDS buffer, two barriers per step, 2 workgroups per CU hide each other's barriers).
+// `ngroups`=3 runs the three dilated 3x3 convs of a BDCN MSBlock back to back on one accumulator
+// set and sums relu(conv_g) in registers; the block's first conv output is added as `residual`.
+#include "common.h"
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32;        // K (channels) per step
+constexpr int LDK = KC + 4;   // LDS row pitch in floats (144 B)
+
+struct KState {
+  int g, seg, c0, tap, kofs;  // group, slice, first channel of the step, tap, K offset of the slice
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == EGNE_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EGNE_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned OOB = 0x80000000u;
+
+// Four consecutive channels of an activation tensor through a buffer resource: 16 bytes of fp32 or 8 bytes of bf16
+// (egne_conv_desc.dtype); `off` is a BYTE offset.  Raw<TS> is what stays in registers until the values are needed.
+template <typename TS> struct Raw4 { typedef u32x4 type; };
+template <> struct Raw4<egne_bf16> { typedef u32x2 type; };
+template <typename TS> __device__ __forceinline__ typename Raw4<TS>::type load_raw4(__amdgpu_buffer_rsrc_t r, int off, int soff) {
+  if constexpr (sizeof(TS) == 4) return __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0);
+  else return __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
+}
+__device__ __forceinline__ f32x4 raw_to_f32(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ f32x4 raw_to_f32(u32x2 v) {
+  const u32x4 w = {v[0] << 16, v[0] & 0xffff0000u, v[1] << 16, v[1] & 0xffff0000u};
+  return __builtin_bit_cast(f32x4, w);
+}
+template <typename TS> __device__ __forceinline__ float load_el(__amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (sizeof(TS) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  else return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
+}
+template <typename TS> __device__ __forceinline__ void store_el(float v, __amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (sizeof(TS) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (egne_bf16)v), r, off, 0, 0);
+}
+template <typename TS> __device__ __forceinline__ void store_4(f32x4 v, __amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (sizeof(TS) == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, egne_bf16x4)), r, off, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// Addressing: a staged row keeps ONE pixel index relative to the first frame of the tile (slice independent) and a
+// bit mask of the taps that fall inside the image; a K step turns it into a 32-bit byte offset of the slice's
+// buffer resource with one multiply-add, padded lanes get 0x80000000 (the buffer unit returns zeros).  Weights,
+// residual and output go through buffer instructions with lane-constant offsets.  Reflect padding (StyleEncoder
+// only) recomputes the mirrored coordinates per step.
+// BFM (bf16 tensors only): the products on v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_32x32x2_f32 -- the LDS tiles hold bf16 (what the
+// activation tensor is stored as anyway; the fp32 weights are rounded to bf16 while they are staged, as conv3x3_bf16.hip does), two
+// MFMAs of 32 cycles per 32-channel K step and 32x32 block instead of sixteen of 64.  This is what the layers of a bf16-storage
+// training plan run on that no specialised kernel takes: the StyleEncoder of the AdaIN configuration (reflect-padded 7x7, 4x4 /
+// stride 2; RITnet_v2.py:91-107) and the data gradients of those layers, the regression head, multi-slice 1x1 leftovers.
+// FOLD (one slice of 8 padded channels, one group): four TAPS share a 32-channel K step -- column group col4 >> 1 of the staged row is
+// tap 4 s + (col4 >> 1), its half col4 & 1 the channels 0-3 / 4-7 -- so that a k x k convolution on <= 8 input channels takes
+// ceil(k k / 4) staging rounds instead of k k rounds that are three quarters zeros (the StyleEncoder's reflect-padded 7x7 on the
+// three softmax channels, RITnet_v2.py:95: 13 rounds instead of 49).
+template <int WM, int WN, bool GROUPED, typename TS, bool BFM = false, bool FOLD = false>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const egne_conv_desc p) {
+  static_assert(!BFM || (sizeof(TS) == 2 && !GROUPED), "bf16 MFMA form: bf16 tensors, one group");
+  static_assert(!FOLD || !GROUPED, "folded taps: one group");
+  constexpr int ES = sizeof(TS);          // bytes per activation element (weights, bias and affine tables are fp32 always)
+  constexpr int LDHB = 40;                // BFM: LDS row pitch in halfs (80 B: conflict-free ds_read_b128 over 32 rows)
+  constexpr int BM = 128 * WM, BN = 32 * WN;
+  constexpr int AR = BM / 32;  // A rows staged per thread
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDK];
+  float* As = lds;
+  float* Bs = lds + BM * LDK;
+  egne_bf16* const Ah = (egne_bf16*)lds;                 // BFM: the same storage as bf16 rows of LDHB halfs
+  egne_bf16* const Bh = Ah + BM * LDHB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int T = p.kh * p.kw;
+  const int hw = p.Ho * p.Wo, frame_px = p.H * p.W;
+  const int b0 = (int)(m0 / hw);
+
+  // ---- loader coordinates: thread (rbase, col4) stages rows rbase+32*i, floats col4*4..+3 ----
+  const int col4 = tid & 7, rbase = tid >> 3;
+  int pb[AR], pyx[AR], pix[AR];     // frame (or -1), input centre (y<<16 | x), pixel index relative to frame b0
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const long long m = m0 + rbase + 32 * i;
+    const int b = (int)(m / hw);
+    const int r = (int)(m - (long long)b * hw);
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    pb[i] = m < M ? b : -1;
+    pyx[i] = ((oy * p.stride) << 16) | (ox * p.stride);
+    pix[i] = (b - b0) * frame_px + oy * p.stride * p.W + ox * p.stride;
+  }
+  unsigned tapmask[AR];
+  auto make_masks = [&](int g) {
+    const int dil = p.dil[g];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      unsigned mk = 0;
+      for (int ky = 0; ky < p.kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx) {
+          const int iy = (pyx[i] >> 16) + (ky - p.pad_h) * dil, ix = (pyx[i] & 0xffff) + (kx - p.pad_w) * dil;
+          if (pb[i] >= 0 && (p.pad_mode == 1 || (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W))) mk |= 1u << (ky * p.kw + kx);
+        }
+      tapmask[i] = mk;
+    }
+  };
+  make_masks(0);
+
+  const unsigned wbytes = (unsigned)p.ngroups * T * p.CoutP * p.Ktot * 4u;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, wbytes);
+  int boff[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) boff[j] = ((n0 + rbase + 32 * j) * p.Ktot + col4 * 4) * 4;
+
+  typename Raw4<TS>::type ra[AR];
+  u32x4 rb[WN];
+
+  auto advance = [&](KState& s) {
+    if (++s.tap < T) return;
+    s.tap = 0;
+    s.c0 += KC;
+    if (s.c0 < p.seg[s.seg].Cp) return;
+    s.c0 = 0;
+    s.kofs += p.seg[s.seg].Cp;
+    if (++s.seg < p.nseg) return;
+    s.seg = 0; s.kofs = 0;
+    ++s.g;
+  };
+
+  // Staging is split in two so that NOTHING consumes a loaded register before the MFMAs of the current
+  // step have been issued: load_step only issues unconditional buffer loads, store_step applies the fused
+  // affine / activation, zeroes the padding and writes LDS.
+  unsigned okmask = 0;       // bit i: row i of the staged step is inside the image
+  int st_seg = 0, st_c = 0;  // slice / first channel of the staged step (for the deferred affine)
+  int fold_step = 0;         // FOLD: the step being loaded (= tap group)
+  auto load_step = [&](const KState& s) {
+    const egne_seg sg = p.seg[s.seg];
+    const int dil = p.dil[s.g];
+    if constexpr (FOLD) {
+      const int tap = 4 * fold_step + (col4 >> 1), c = (col4 & 1) * 4;
+      const bool tok = tap < T;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+      okmask = 0;
+      st_seg = 0; st_c = c;
+      const long long left = ((long long)p.B - b0) * frame_px * sg.pix_stride * ES;
+      const __amdgpu_buffer_rsrc_t rin = make_rsrc((const TS*)sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+                                                   (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+      const int ps4 = (int)sg.pix_stride * ES, coff = (sg.ch_off + c) * ES;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int iy = (pyx[i] >> 16) + dy, ix = (pyx[i] & 0xffff) + dx;
+        bool ok = tok && pb[i] >= 0;
+        if (p.pad_mode == 1) {
+          iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        }
+        const int q = (pb[i] - b0) * frame_px + iy * p.W + ix;
+        ra[i] = load_raw4<TS>(rin, ok ? q * ps4 + coff : (int)OOB, 0);
+        okmask |= (ok ? 1u : 0u) << i;
+      }
+      // weights [tap][CoutP][8]: row n of the B tile holds (tap, channel half) at column group col4
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, tok ? ((tap * p.CoutP + n0 + rbase + 32 * j) * 8 + c) * 4 : (int)OOB, 0, 0);
+      return;
+    }
+    const int ky = s.tap / p.kw, kx = s.tap - ky * p.kw;
+    const int dy = (ky - p.pad_h) * dil, dx = (kx - p.pad_w) * dil;
+    const int c = s.c0 + col4 * 4;
+    const bool cok = c < sg.Cp;
+    okmask = 0;
+    st_seg = s.seg; st_c = c;
+    const long long left = ((long long)p.B - b0) * frame_px * sg.pix_stride * ES;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const TS*)sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+                                                 (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+    const int ps4 = (int)sg.pix_stride * ES;
+    const int coff = (sg.ch_off + c) * ES;
+    if (p.pad_mode == 1) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int iy = (pyx[i] >> 16) + dy, ix = (pyx[i] & 0xffff) + dx;
+        iy = iy < 0 ? -iy : (iy >= p.H ? 2 * p.H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= p.W ? 2 * p.W - 2 - ix : ix);
+        const bool ok = cok && pb[i] >= 0;
+        const int q = (pb[i] - b0) * frame_px + iy * p.W + ix;
+        ra[i] = load_raw4<TS>(rin, ok ? q * ps4 + coff : (int)OOB, 0);
+        okmask |= (ok ? 1u : 0u) << i;
+      }
+    } else {
+      const int tapd = dy * p.W + dx;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = cok && ((tapmask[i] >> s.tap) & 1u);
+        ra[i] = load_raw4<TS>(rin, ok ? (pix[i] + tapd) * ps4 + coff : (int)OOB, 0);
+        okmask |= (ok ? 1u : 0u) << i;
+      }
+    }
+    const int wstep = (((s.g * T + s.tap) * p.CoutP) * p.Ktot + s.kofs + s.c0) * 4;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? boff[j] : (int)OOB, wstep, 0);
+  };
+
+  auto store_step = [&]() {
+    const egne_seg sg = p.seg[st_seg];
+    if (sg.scale) {
+      // per-(n,c) affine of the fused InstanceNorm / BatchNorm (+ activation); padding stays exactly zero.
+      // A tile almost always lies inside one frame: then one scale/shift pair serves all staged rows.
+      const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+      const bool cok2 = st_c < sg.Cp;
+      const bool same = pb[0] == pb[AR - 1] && pb[0] >= 0 && cok2;
+      f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sh0 = {0.f, 0.f, 0.f, 0.f};
+      if (same) {
+        sc0 = *(const f32x4*)(sg.scale + (long long)pb[0] * sg.Cp + st_c);
+        sh0 = *(const f32x4*)(sg.shift + (long long)pb[0] * sg.Cp + st_c);
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = (okmask >> i) & 1u;
+        f32x4 sc = sc0, sh = sh0;
+        if (!same) {
+          const float* sp = ok ? sg.scale + (long long)pb[i] * sg.Cp + st_c : egne_zero_page;
+          const float* hp = ok ? sg.shift + (long long)pb[i] * sg.Cp + st_c : egne_zero_page;
+          sc = *(const f32x4*)sp; sh = *(const f32x4*)hp;
+        } else if (!ok) {
+          sc = (f32x4)(0.f); sh = (f32x4)(0.f);
+        }
+        f32x4 v = raw_to_f32(ra[i]) * sc + sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope_in);
+        if constexpr (BFM) *(egne_bf16x4*)&Ah[(rbase + 32 * i) * LDHB + col4 * 4] = __builtin_convertvector(v, egne_bf16x4);
+        else *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        if constexpr (BFM) *(typename Raw4<TS>::type*)&Ah[(rbase + 32 * i) * LDHB + col4 * 4] = ra[i];      // the stored bf16 values as they are
+        else *(f32x4*)&As[(rbase + 32 * i) * LDK + col4 * 4] = raw_to_f32(ra[i]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      if constexpr (BFM) *(egne_bf16x4*)&Bh[(rbase + 32 * j) * LDHB + col4 * 4] = __builtin_convertvector(__builtin_bit_cast(f32x4, rb[j]), egne_bf16x4);
+      else *(u32x4*)&Bs[(rbase + 32 * j) * LDK + col4 * 4] = rb[j];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+  f32x16 res[GROUPED ? WM : 1][GROUPED ? WN : 1];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      acc[a][b] = (f32x16)(0.f);
+      if (GROUPED) res[a][b] = (f32x16)(0.f);
+    }
+  const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+
+  // total number of K steps
+  int steps_per_group = 0;
+  for (int s = 0; s < p.nseg; ++s) steps_per_group += ((p.seg[s].Cp + KC - 1) / KC) * T;
+  const int nsteps = FOLD ? (T + 3) / 4 : steps_per_group * p.ngroups;
+
+  KState cur = {0, 0, 0, 0, 0};
+  load_step(cur);
+  store_step();
+  __syncthreads();
+
+  const float* arow = &As[(wave * 32 * WM + li) * LDK + lh * 4];
+  const float* brow = &Bs[li * LDK + lh * 4];
+
+  for (int step = 0; step < nsteps; ++step) {
+    KState nxt = cur;
+    advance(nxt);
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      if (GROUPED && nxt.g != cur.g) make_masks(nxt.g);
+      fold_step = step + 1;
+      load_step(nxt);
+    }
+
+    int rem = FOLD ? KC : p.seg[cur.seg].Cp - cur.c0;
+    const int nk8 = rem >= KC ? KC / 8 : (rem >> 3);
+    if constexpr (BFM) {
+      // lane (li, lh) supplies channels 16 s + 8 lh .. + 7 of its row to both operands; columns past the slice were staged as zeros
+      const egne_bf16* arh = &Ah[(wave * 32 * WM + li) * LDHB + lh * 8];
+      const egne_bf16* brh = &Bh[li * LDHB + lh * 8];
+      const int nk16 = rem >= KC ? 2 : ((rem + 15) >> 4);
+      for (int s = 0; s < nk16; ++s) {
+        egne_bf16x8 a[WM], b[WN];
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm) a[tm] = *(const egne_bf16x8*)(arh + tm * 32 * LDHB + s * 16);
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn) b[tn] = *(const egne_bf16x8*)(brh + tn * 32 * LDHB + s * 16);
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    } else
+    for (int s = 0; s < nk8; ++s) {
+      f32x4 a[WM], b[WN];
+#pragma unroll
+      for (int tm = 0; tm < WM; ++tm) a[tm] = *(const f32x4*)(arow + tm * 32 * LDK + s * 8);
+#pragma unroll
+      for (int tn = 0; tn < WN; ++tn) b[tn] = *(const f32x4*)(brow + tn * 32 * LDK + s * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < WN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+
+    if (GROUPED && (!more || nxt.g != cur.g)) {
+      // end of a dilation group: res += act(acc + bias_g)
+#pragma unroll
+      for (int tn = 0; tn < WN; ++tn) {
+        const int n = n0 + tn * 32 + li;
+        const float bv = p.bias ? p.bias[cur.g * p.CoutP + n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < WM; ++tm) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[tm][tn][r] + bv;
+            res[tm][tn][r] += fmaxf(v, v * slope_out);
+          }
+          acc[tm][tn] = (f32x16)(0.f);
+        }
+      }
+    }
+
+    __syncthreads();
+    if (more) store_step();
+    __syncthreads();
+    cur = nxt;
+  }
+
+  // ---- epilogue: lane holds column n of 16 rows: row = (r&3) + 8*(r>>2) + 4*lh ----
+  const long long left = M - m0;
+  const long long rows = left < BM ? left : BM;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc((TS*)p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * ES));
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? (const TS*)p.residual + m0 * p.res_pix_stride : nullptr,
+                                                p.residual ? (unsigned)(rows * p.res_pix_stride * ES) : 0u);
+  const int ostep = (int)p.out_pix_stride * ES, rstep = (int)p.res_pix_stride * ES;
+  unsigned mb = 0;           // max bit pattern of |stored value| (egne_conv_desc.absmax_out)
+#pragma unroll
+  for (int tn = 0; tn < WN; ++tn) {
+    const int n = n0 + tn * 32 + li;
+    const bool nok = n < p.Cout_store;
+    float bv = 0.f, ps = 1.f, pt = 0.f;
+    if (!GROUPED && p.bias) bv = p.bias[n];
+    if (p.post_scale) { ps = p.post_scale[n]; pt = p.post_shift[n]; }
+#pragma unroll
+    for (int tm = 0; tm < WM; ++tm) {
+      const int mrow = wave * 32 * WM + tm * 32 + 4 * lh;
+      const unsigned o0 = nok ? (unsigned)(mrow * ostep + (p.out_ch_off + n) * ES) : OOB;   // rows past M: range check
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      if (p.residual) {
+        const unsigned r0 = nok ? (unsigned)(mrow * rstep + (p.res_ch_off + n) * ES) : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = load_el<TS>(rres, (int)(r0 + ((r & 3) + 8 * (r >> 2)) * rstep));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v;
+        if (GROUPED) v = res[tm][tn][r];
+        else { v = acc[tm][tn][r] + bv; v = fmaxf(v, v * slope_out); }
+        v = v * ps + pt + rv[r];
+        store_el<TS>(v, rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep));
+        const unsigned b = (nok && mrow + (r & 3) + 8 * (r >> 2) < rows) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u;
+        mb = b > mb ? b : mb;
+      }
+    }
+  }
+  if (p.absmax_out) {
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned t = (unsigned)__shfl_xor((int)mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0 && mb > __hip_atomic_load(p.absmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.absmax_out, mb);   // (same-address atomics serialise: most waves find a larger value already there)
+  }
+}
+
+// First layers (Cin <= 4: grey frame / 3 replicated channels).  With 8..32 useful K per tap the tap-by-tap
+// implicit GEMM spends its time in 9 staging rounds; here the 9 taps are folded INTO K: one pixel row of the
+// A tile is [tap0 c0..c3 | tap1 c0..c3 | ... | tap8 c0..c3 | 0 0 0 0] (K = 40), staged once, one barrier, 20
+// fp32 MFMAs per 32x32 tile.  The layer is then a pure store stream (128-256 B per pixel).
+constexpr int C4K = 40, C4LD = 44;
+template <int WN, typename TS>
+__global__ __launch_bounds__(256) void conv3x3_c4_kernel(const egne_conv_desc p, const float* __restrict__ w40) {
+  constexpr int ES = sizeof(TS);
+  __shared__ __attribute__((aligned(16))) float As[256 * C4LD];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * WN * C4LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long M = (long long)p.B * p.H * p.W;
+  const long long m0 = (long long)blockIdx.x * 256;
+  const egne_seg sg = p.seg[0];
+  {
+    const long long m = m0 + tid;
+    const int hw = p.H * p.W;
+    const int b0 = (int)(m0 / hw);
+    const int b = (int)(m / hw);
+    const int r = (int)(m - (long long)b * hw);
+    const int y = r / p.W, x = r - y * p.W;
+    const long long left = ((long long)p.B - b0) * hw * sg.pix_stride * ES;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const TS*)sg.ptr + (long long)b0 * hw * sg.pix_stride, (unsigned)(left < 0x7fffffffll ? left : 0x7fffffffll));
+    const int base = (((b - b0) * hw + r) * (int)sg.pix_stride + sg.ch_off) * ES;
+    typename Raw4<TS>::type v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = m < M && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+      v[t] = load_raw4<TS>(rin, ok ? base + (dy * p.W + dx) * (int)sg.pix_stride * ES : (int)OOB, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *(f32x4*)&As[tid * C4LD + t * 4] = raw_to_f32(v[t]);
+    *(f32x4*)&As[tid * C4LD + 36] = (f32x4)(0.f);
+    for (int i = tid; i < 32 * WN * 10; i += 256) {
+      const int n = i / 10, q = i - n * 10;
+      *(f32x4*)&Bs[n * C4LD + q * 4] = *(const f32x4*)(w40 + (long long)n * C4K + q * 4);
+    }
+  }
+  __syncthreads();
+  // transposed product (weights as the A operand): lane = pixel li, channels n = 8*j + 4*lh + e -> 16-byte stores
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) acc[a][n] = (f32x16)(0.f);
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    f32x4 a[2], bq[WN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const f32x4*)&As[(wave * 64 + tm * 32 + li) * C4LD + s * 8 + lh * 4];
+#pragma unroll
+    for (int tn = 0; tn < WN; ++tn) bq[tn] = *(const f32x4*)&Bs[(tn * 32 + li) * C4LD + s * 8 + lh * 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[tn][j], a[tm][j], acc[tm][tn], 0, 0, 0);
+  }
+  const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  const long long left = M - m0;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc((TS*)p.out + m0 * p.out_pix_stride, (unsigned)((left < 256 ? left : 256) * p.out_pix_stride * ES));
+#pragma unroll
+  for (int tn = 0; tn < WN; ++tn)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = tn * 32 + 8 * j + 4 * lh;
+      const bool nok = n < p.Cout_store;
+      const f32x4 bv = (p.bias && nok) ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
+      f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+      if (p.post_scale && nok) { ps = *(const f32x4*)(p.post_scale + n); pt = *(const f32x4*)(p.post_shift + n); }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[tm][tn][4 * j + e] + bv[e];
+          v[e] = fmaxf(t, t * slope) * ps[e] + pt[e];
+        }
+        const int row = wave * 64 + tm * 32 + li;
+        store_4<TS>(v, rout, nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * ES : (int)OOB);
+      }
+    }
+}
+
+template <int WM, int WN>
+int launch(const egne_conv_desc& d, hipStream_t st) {
+  constexpr int BM = 128 * WM, BN = 32 * WN;
+  const long long M = (long long)d.B * d.Ho * d.Wo;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / BN));
+  if (d.dtype == 1) {       // bf16 activation tensors (training plans); the fused MSBlock form belongs to the frozen fp32 network
+    if (d.ngroups > 1) return egne::fail(EGNE_ERR_ARG, "conv: grouped launches take fp32 tensors only");
+    static const bool bfm = [] { const char* e = getenv("EGNE_IGEMM_BF16_MFMA"); return !e || e[0] != '0'; }();
+    static const bool fold_on = [] { const char* e = getenv("EGNE_IGEMM_FOLD"); return !e || e[0] != '0'; }();
+    // one slice of 8 padded channels and at least four taps: four taps per K step
+    const bool fold = fold_on && d.nseg == 1 && d.seg[0].Cp == 8 && !d.seg[0].scale && d.kh * d.kw >= 4 && d.Ktot == 8;
+    // bf16 MFMA (weights rounded to bf16 while staged) only on maps of >= 1024 pixels: the layers it was built for (the StyleEncoder's
+    // 7x7 / 4x4-s2 blocks from 240x320 down to 30x40).  The regression module and the bottleneck's 1x1s (15x20 maps, a few
+    // MFLOP) keep exact-fp32 products: with their weights rounded the gradient-norm error of bf16 storage over 32 distinct
+    // frames went from 2.1e-2 (median) / 1.3e-1 (p90) to 3.2e-2 / 3.0e-1 (tests/test_gpu_distinct.py)
+    const bool wide_map = (long long)d.Ho * d.Wo >= 1024;
+    if (bfm && wide_map && fold) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16, true, true>), grid, dim3(256), 0, st, d);
+    else if (bfm && wide_map) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16, true>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, egne_bf16>), grid, dim3(256), 0, st, d);
+  } else if (d.ngroups > 1)
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, true, float>), grid, dim3(256), 0, st, d);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, false, float>), grid, dim3(256), 0, st, d);
+  return egne::check_launch("egne_conv2d_fwd");
+}
+
+}  // namespace
+
+// 3x3 / stride 1 / pad 1 / one slice / logical Cin <= 4 / Cout_store <= 64 (vgg16_c.py conv1_1, convBlock head conv1).
+// w40: [CoutP][40] fp32, column tap*4 + c (zero padded) -- packed by the host at load time.
+extern "C" int egne_conv3x3_smallcin_fwd(const egne_conv_desc* dp, const float* w40, void* stream) {
+  EGNE_REQUIRE(dp != nullptr && w40 != nullptr, "conv_smallcin: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_h == 1 && d.pad_w == 1 && d.pad_mode == 0 && d.ngroups == 1 &&
+               d.dil[0] == 1 && d.nseg == 1 && d.Ho == d.H && d.Wo == d.W, "conv_smallcin: geometry not supported");
+  EGNE_REQUIRE(d.seg[0].Cp >= 4 && d.seg[0].scale == nullptr, "conv_smallcin: fused affine not supported");
+  EGNE_REQUIRE(d.Cout_store <= 64 && d.out && d.residual == nullptr, "conv_smallcin: Cout");
+  EGNE_REQUIRE(((uintptr_t)d.seg[0].ptr & 15) == 0 && d.seg[0].ch_off % 4 == 0 && d.seg[0].pix_stride % 4 == 0 && ((uintptr_t)w40 & 15) == 0,
+               "conv_smallcin: alignment");
+  EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride && d.Cout_store % 4 == 0 && d.out_ch_off % 4 == 0 && d.out_pix_stride % 4 == 0 &&
+               ((uintptr_t)d.out & 15) == 0 && d.out_pix_stride * 1024 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0),
+               "conv_smallcin: output slice / alignment");
+  EGNE_REQUIRE(2ll * d.H * d.W * d.seg[0].pix_stride * 4 < (1ll << 31), "conv_smallcin: frame too large for 32-bit byte offsets");
+  EGNE_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv_smallcin: dtype %d", d.dtype);
+  const long long M = (long long)d.B * d.H * d.W;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((M + 255) / 256));
+  if (d.dtype == 1) {
+    if (d.Cout_store <= 32) hipLaunchKernelGGL((conv3x3_c4_kernel<1, egne_bf16>), grid, dim3(256), 0, st, d, w40);
+    else hipLaunchKernelGGL((conv3x3_c4_kernel<2, egne_bf16>), grid, dim3(256), 0, st, d, w40);
+  } else if (d.Cout_store <= 32) hipLaunchKernelGGL((conv3x3_c4_kernel<1, float>), grid, dim3(256), 0, st, d, w40);
+  else hipLaunchKernelGGL((conv3x3_c4_kernel<2, float>), grid, dim3(256), 0, st, d, w40);
+  return egne::check_launch("egne_conv3x3_smallcin_fwd");
+}
+
+extern "C" int egne_conv2d_fwd(const egne_conv_desc* dp, void* stream) {
+  EGNE_REQUIRE(dp != nullptr, "conv: null descriptor");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0, "conv: bad shape %dx%dx%d -> %dx%d", d.B, d.H, d.W, d.Ho, d.Wo);
+  EGNE_REQUIRE(d.kh > 0 && d.kw > 0 && d.stride > 0, "conv: bad kernel %dx%d stride %d", d.kh, d.kw, d.stride);
+  EGNE_REQUIRE(d.ngroups >= 1 && d.ngroups <= EGNE_MAXGROUP, "conv: ngroups %d", d.ngroups);
+  EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG, "conv: nseg %d", d.nseg);
+  EGNE_REQUIRE(d.pad_mode == 0 || d.pad_mode == 1, "conv: pad_mode %d", d.pad_mode);
+  EGNE_REQUIRE(d.dtype == 0 || d.dtype == 1, "conv: dtype %d", d.dtype);
+  EGNE_REQUIRE(d.dtype == 0 || !d.absmax_out, "conv: absmax_out is for fp32 tensors");
+  int ktot = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr != nullptr, "conv: seg %d null", s);
+    EGNE_REQUIRE(g.Cp > 0 && g.Cp % 8 == 0, "conv: seg %d Cp=%d not a multiple of 8", s, g.Cp);
+    EGNE_REQUIRE(g.ch_off % 4 == 0 && g.pix_stride % 4 == 0, "conv: seg %d offset/stride not 16-B aligned", s);
+    EGNE_REQUIRE(g.ch_off + g.Cp <= g.pix_stride, "conv: seg %d exceeds pixel stride", s);
+    EGNE_REQUIRE(((uintptr_t)g.ptr & 15) == 0, "conv: seg %d pointer not 16-B aligned", s);
+    EGNE_REQUIRE((g.scale == nullptr) == (g.shift == nullptr), "conv: seg %d scale/shift mismatch", s);
+    ktot += g.Cp;
+  }
+  EGNE_REQUIRE(ktot == d.Ktot, "conv: Ktot %d != sum of slices %d", d.Ktot, ktot);
+  EGNE_REQUIRE(d.CoutP > 0 && d.CoutP % 32 == 0, "conv: CoutP %d", d.CoutP);
+  EGNE_REQUIRE(d.Cout_store > 0 && d.Cout_store <= d.CoutP, "conv: Cout_store %d", d.Cout_store);
+  EGNE_REQUIRE(d.w != nullptr && d.out != nullptr, "conv: null weight/output");
+  EGNE_REQUIRE(((uintptr_t)d.w & 15) == 0, "conv: weight pointer not 16-B aligned");
+  EGNE_REQUIRE(d.out_ch_off + d.Cout_store <= d.out_pix_stride, "conv: output slice exceeds pixel stride");
+  EGNE_REQUIRE((d.post_scale == nullptr) == (d.post_shift == nullptr), "conv: post affine mismatch");
+  for (int g = 0; g < d.ngroups; ++g) EGNE_REQUIRE(d.dil[g] >= 1, "conv: dilation");
+  if (d.pad_mode == 1)
+    EGNE_REQUIRE(d.pad_h < d.H && d.pad_w < d.W, "conv: reflect pad larger than input");
+  // output size must match the convolution arithmetic for every group (pad scales with dilation)
+  for (int g = 0; g < d.ngroups; ++g) {
+    int ho = (d.H + 2 * d.pad_h * d.dil[g] - d.dil[g] * (d.kh - 1) - 1) / d.stride + 1;
+    int wo = (d.W + 2 * d.pad_w * d.dil[g] - d.dil[g] * (d.kw - 1) - 1) / d.stride + 1;
+    EGNE_REQUIRE(ho == d.Ho && wo == d.Wo, "conv: output %dx%d inconsistent with geometry (%dx%d)", d.Ho, d.Wo, ho, wo);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice: the widest N tile that does not add padding beyond the 32-multiple
+  const int c = d.CoutP;
+  static const int big = [] { const char* e = getenv("EGNE_FLAT_BIG"); return e ? atoi(e) : 0; }();
+  // 1x1 convolutions (HBM-bound, two or three K steps per tile): the 128-pixel tile doubles the workgroups in flight per CU
+  static const int small1 = [] { const char* e = getenv("EGNE_IGEMM_SMALL1X1"); return e ? atoi(e) : 1; }();
+  if (small1 && d.kh == 1 && d.kw == 1 && d.ngroups == 1 && c % 128 != 0) return c % 64 == 0 ? launch<1, 2>(d, st) : launch<1, 1>(d, st);
+  // small maps (regression module, bottleneck): narrower N tiles until the launch has a workgroup for every CU
+  {
+    const long long mt = ((long long)d.B * d.Ho * d.Wo + 127) / 128;
+    if (small1 && d.ngroups == 1 && c % 128 == 0 && mt * (c / 128) < 256) return mt * (c / 64) >= 256 ? launch<1, 2>(d, st) : launch<1, 1>(d, st);
+  }
+  if (c % 128 == 0 && big) return launch<2, 4>(d, st);
+  if (c % 128 == 0) return launch<1, 4>(d, st);
+  if (c % 64 == 0) return launch<2, 2>(d, st);
+  return launch<2, 1>(d, st);
+}

@@ -1,0 +1,281 @@
+// Device-side batch preparation: the signed, normalised distance maps of the three classes
+// (CurriculumLib.py:131-136 -> helperfunctions.one_hot2dist :356-371, exact Euclidean distance transform) and the
+// per-image z-score (CurriculumLib.py:139).  The reference computes both on the host per sample in the DataLoader; at
+// >1000 frames/s that is the bottleneck of a real training loop (the EDT alone is ~2 ms per frame and class on a core).
+//
+// one_hot2dist(posmask):  res = edt(~pos) * ~pos - (edt(pos) - 1) * pos,  / sqrt((H-1)^2 + (W-1)^2),  0 if the class is absent,
+// where edt(m)[p] = distance from p to the nearest pixel with m == 0 (scipy.ndimage.distance_transform_edt; exact: integer
+// squared distances, sqrt in double).  Separable and exact here too: (1) per column the vertical distance to the nearest
+// pixel inside / outside the class, (2) per row  d2(y,x) = min over x' of (x-x')^2 + g(y,x')^2  from an LDS copy of the row.
+// Integer arithmetic up to the final double sqrt / divide, so the float32 result is bit-identical to the reference's.
+// Quirk kept: for a class that fills the whole frame scipy measures to a virtual background pixel at (-1, 0).
+#include "common.h"
+
+namespace {
+
+constexpr unsigned short NONE = 0xffff;   // no such pixel in the column
+
+// grid (ceil(W/256), ncls, B): one thread per column; g[b][c][0][y][x] = rows to the nearest pixel OUTSIDE class c,
+// g[b][c][1][y][x] = rows to the nearest pixel INSIDE class c; flags[b][c] bit0 = class present, bit1 = some pixel outside it
+__global__ void edt_columns_k(const long long* __restrict__ label, int H, int W, int ncls, unsigned short* __restrict__ g,
+                              int* __restrict__ flags) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const long long* lab = label + (long long)b * H * W + x;
+  unsigned short* gout = g + (((long long)b * ncls + c) * 2) * H * W + x;      // nearest outside
+  unsigned short* gin = gout + (long long)H * W;                              // nearest inside
+  int last_in = -1, last_out = -1, seen = 0;
+  for (int y = 0; y < H; ++y) {
+    const bool in = lab[(long long)y * W] == c;
+    if (in) last_in = y; else last_out = y;
+    seen |= in ? 1 : 2;
+    gout[(long long)y * W] = last_out < 0 ? NONE : (unsigned short)(y - last_out);
+    gin[(long long)y * W] = last_in < 0 ? NONE : (unsigned short)(y - last_in);
+  }
+  last_in = -1; last_out = -1;
+  for (int y = H - 1; y >= 0; --y) {
+    const bool in = lab[(long long)y * W] == c;
+    if (in) last_in = y; else last_out = y;
+    const unsigned short a = last_out < 0 ? NONE : (unsigned short)(last_out - y);
+    const unsigned short e = last_in < 0 ? NONE : (unsigned short)(last_in - y);
+    if (a < gout[(long long)y * W]) gout[(long long)y * W] = a;
+    if (e < gin[(long long)y * W]) gin[(long long)y * W] = e;
+  }
+  if (seen) atomicOr(&flags[b * ncls + c], seen);
+}
+
+// grid (H, ncls, B), one workgroup per image row; dynamic LDS: 2*W u16 + W bytes
+__global__ void edt_rows_k(const long long* __restrict__ label, int H, int W, int ncls, const unsigned short* __restrict__ g,
+                           const int* __restrict__ flags, double mx, float* __restrict__ out) {
+  extern __shared__ unsigned short row[];           // [0,W): nearest outside, [W,2W): nearest inside
+  unsigned char* in_row = (unsigned char*)(row + 2 * W);
+  const int y = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const unsigned short* gout = g + ((((long long)b * ncls + c) * 2) * H + y) * W;
+  const unsigned short* gin = gout + (long long)H * W;
+  const long long* lab = label + ((long long)b * H + y) * W;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    row[x] = gout[x];
+    row[W + x] = gin[x];
+    in_row[x] = lab[x] == c;
+  }
+  __syncthreads();
+  const int fl = flags[b * ncls + c];
+  float* o = out + (((long long)b * ncls + c) * H + y) * W;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    double res = 0.0;
+    if (fl & 1) {                                   // class present in this frame
+      const bool in = in_row[x];
+      if (in && !(fl & 2)) {
+        res = -(sqrt((double)((y + 1) * (y + 1) + x * x)) - 1.0);           // scipy: no background anywhere
+      } else {
+        const unsigned short* gv = in ? row : row + W;                      // inside: distance to the outside, and vice versa
+        int best = 0x7fffffff;
+        for (int xp = 0; xp < W; ++xp) {
+          const int v = gv[xp];
+          if (v != NONE) {
+            const int dx = x - xp, d2 = dx * dx + v * v;
+            best = d2 < best ? d2 : best;
+          }
+        }
+        const double dist = sqrt((double)best);
+        res = in ? -(dist - 1.0) : dist;
+      }
+    }
+    o[x] = (float)(res / mx);
+  }
+}
+
+// one workgroup per image: mean, then population std around it, both in double (numpy: (img - img.mean()) / img.std())
+__global__ __launch_bounds__(256) void zscore_k(const float* __restrict__ x, float* __restrict__ y, int n) {
+  __shared__ double sh[256];
+  const float* xi = x + (long long)blockIdx.x * n;
+  float* yi = y + (long long)blockIdx.x * n;
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += xi[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  const double mean = sh[0] / n;
+  __syncthreads();
+  double q = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double d = xi[i] - mean; q += d * d; }
+  sh[threadIdx.x] = q;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  const double sd = sqrt(sh[0] / n);
+  for (int i = threadIdx.x; i < n; i += 256) yi[i] = (float)((xi[i] - mean) / sd);
+}
+
+}  // namespace
+
+extern "C" int64_t egne_dist_maps_workspace_bytes(int B, int H, int W, int ncls) {
+  return (int64_t)B * ncls * 2 * H * W * sizeof(unsigned short) + (int64_t)B * ncls * sizeof(int) + 16;
+}
+
+extern "C" int egne_dist_maps(const int64_t* label, int B, int H, int W, int ncls, float* out, void* ws, void* stream) {
+  EGNE_REQUIRE(label && out && ws && B > 0 && B <= 65535 && H > 1 && W > 1 && H < 32768 && W < 32768 && H <= 65535 && ncls > 0 && ncls <= 16,
+               "dist_maps: bad arguments (B %d H %d W %d classes %d)", B, H, W, ncls);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* g = (unsigned short*)ws;
+  int* flags = (int*)((char*)ws + ((size_t)B * ncls * 2 * H * W * sizeof(unsigned short) + 15) / 16 * 16);
+  if (hipMemsetAsync(flags, 0, (size_t)B * ncls * sizeof(int), st) != hipSuccess) return egne::fail(EGNE_ERR_LAUNCH, "dist_maps: memset failed");
+  hipLaunchKernelGGL(edt_columns_k, dim3((W + 255) / 256, ncls, B), dim3(256), 0, st, (const long long*)label, H, W, ncls, g, flags);
+  const double mx = sqrt((double)(H - 1) * (H - 1) + (double)(W - 1) * (W - 1));
+  const size_t lds = (size_t)2 * W * sizeof(unsigned short) + W;
+  EGNE_REQUIRE(lds <= 64 * 1024, "dist_maps: row too wide for LDS");
+  hipLaunchKernelGGL(edt_rows_k, dim3(H, ncls, B), dim3(256), lds, st, (const long long*)label, H, W, ncls, g, flags, mx, out);
+  return egne::check_launch("egne_dist_maps");
+}
+
+extern "C" int egne_zscore(const float* x, float* y, int B, int n, void* stream) {
+  EGNE_REQUIRE(x && y && B > 0 && n > 1, "zscore: bad arguments");
+  hipLaunchKernelGGL(zscore_k, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return egne::check_launch("egne_zscore");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Spatial weights of a sample (CurriculumLib.py:128-129): 1 + 20 * dilate(Canny(label, 0, 1) / 255, (3, 3)).
+// PARITY UNPINNED (no OpenCV in the build container, no fixture in the reference): the kernel implements the restatement in
+// oracle/dataprep.py (OpenCV's published Canny: 3x3 Sobel with replicated borders, L1 magnitude, fixed-point sector test,
+// non-maximum suppression, hysteresis with thresholds 0 / 1; cv2.dilate with the tuple (3, 3) = a two-row, one-column element)
+// and is tested bit for bit against THAT.  One workgroup per frame; magnitude and state maps (one byte per pixel each) in LDS;
+// hysteresis = monotone growth of the edge set through the surviving pixels until a pass changes nothing.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int lab_at(const long long* __restrict__ l, int H, int W, int y, int x) {
+  y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+  x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+  return (int)(unsigned char)l[(long long)y * W + x];
+}
+
+__device__ __forceinline__ void sobel_at(const long long* __restrict__ l, int H, int W, int y, int x, int& dx, int& dy) {
+  const int a = lab_at(l, H, W, y - 1, x - 1), b = lab_at(l, H, W, y - 1, x), c = lab_at(l, H, W, y - 1, x + 1);
+  const int d = lab_at(l, H, W, y, x - 1), f = lab_at(l, H, W, y, x + 1);
+  const int g = lab_at(l, H, W, y + 1, x - 1), h = lab_at(l, H, W, y + 1, x), i = lab_at(l, H, W, y + 1, x + 1);
+  dx = (c - a) + 2 * (f - d) + (i - g);
+  dy = (g - a) + 2 * (h - b) + (i - c);
+}
+
+__global__ __launch_bounds__(1024) void spatial_weights_k(const long long* __restrict__ label, int H, int W, float* __restrict__ out) {
+  extern __shared__ unsigned char sw_lds[];
+  const int HW = H * W;
+  unsigned char* mag = sw_lds;            // |dx| + |dy| (<= 16 for class labels; saturated at 255)
+  unsigned char* st = sw_lds + HW;        // 0 nothing, 1 survivor of the suppression (m > low), 2 edge
+  __shared__ int changed;
+  const long long* l = label + (long long)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    int dx, dy;
+    sobel_at(l, H, W, y, x, dx, dy);
+    const int m = abs(dx) + abs(dy);
+    mag[i] = (unsigned char)(m > 255 ? 255 : m);
+  }
+  __syncthreads();
+  auto M = [&](int y, int x) -> int { return (y < 0 || y >= H || x < 0 || x >= W) ? 0 : (int)mag[y * W + x]; };
+  constexpr int TG22 = 13573;             // round(tan(22.5 deg) * 2^15)
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    const int m = mag[i];
+    unsigned char s = 0;
+    if (m > 0) {
+      int dx, dy;
+      sobel_at(l, H, W, y, x, dx, dy);
+      const long long ax = abs(dx), ay = (long long)abs(dy) << 15;
+      const long long tg22x = ax * TG22, tg67x = tg22x + (ax << 16);
+      bool keep;
+      if (ay < tg22x) keep = m > M(y, x - 1) && m >= M(y, x + 1);
+      else if (ay > tg67x) keep = m > M(y - 1, x) && m >= M(y + 1, x);
+      else {
+        const int sg = ((dx ^ dy) < 0) ? -1 : 1;
+        keep = m > M(y - 1, x - sg) && m > M(y + 1, x + sg);
+      }
+      if (keep) s = m > 1 ? 2 : 1;
+    }
+    st[i] = s;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < HW; ++pass) {
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      if (st[i] != 1) continue;
+      const int y = i / W, x = i - y * W;
+      bool e = false;
+      for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox) {
+          const int yy = y + oy, xx = x + ox;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W && st[yy * W + xx] == 2) e = true;
+        }
+      if (e) { st[i] = 2; changed = 1; }
+    }
+    __syncthreads();
+    const int c = changed;
+    __syncthreads();
+    if (!c) break;
+  }
+  float* o = out + (long long)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const bool e = st[i] == 2 || (i >= W && st[i - W] == 2);     // two-row structuring element anchored at its lower row
+    o[i] = e ? 21.f : 1.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int egne_spatial_weights(const int64_t* label, int B, int H, int W, float* out, void* stream) {
+  EGNE_REQUIRE(label && out && B > 0 && H > 1 && W > 1, "spatial_weights: bad arguments");
+  const size_t lds = (size_t)2 * H * W;
+  EGNE_REQUIRE(lds <= 156 * 1024, "spatial_weights: a %dx%d map does not fit the LDS (2 bytes per pixel, 156 KB)", H, W);
+  static bool once = hipFuncSetAttribute((const void*)spatial_weights_k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+  if (!once) return egne::fail(EGNE_ERR_LAUNCH, "spatial_weights: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(spatial_weights_k, dim3(B), dim3(1024), lds, (hipStream_t)stream, (const long long*)label, H, W, out);
+  return egne::check_launch("egne_spatial_weights");
+}
+
+// ---- batched augmentation (data_augment.py:12-130, applied per sample in CurriculumLib.py:114-120) -------------------------
+// The branches of augment() that are plain NumPy: 0 flip left-right (:25-36), 2 gamma through a 256-entry table (:44-49; the
+// table itself is built on the host with the reference's expression, the device only looks it up), 3 exposure (:51-56),
+// 4 additive Gaussian noise (:58-65), >= 7 no change (:121-124).  Arithmetic in double as NumPy does it, clip to [0, 255] and
+// truncate towards zero (ndarray.astype(np.uint8) of a non-negative double).  param[b]: exposure offset (3) or noise standard
+// deviation (4); noise: the standard-normal draws [B,H,W] (only read for choice 4).  One thread per 8 pixels of a row.
+namespace {
+
+__global__ __launch_bounds__(256) void augment_k(const unsigned char* __restrict__ img, const long long* __restrict__ label,
+                                                  const int* __restrict__ choice, const double* __restrict__ param,
+                                                  const unsigned char* __restrict__ lut, const double* __restrict__ noise,
+                                                  unsigned char* __restrict__ oimg, long long* __restrict__ olabel, int H, int W) {
+  const int b = blockIdx.y, ch = choice[b];
+  const long long fb = (long long)b * H * W;
+  const double p = param[b];
+  const int per_row = (W + 7) / 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * per_row; i += gridDim.x * blockDim.x) {
+    const int y = i / per_row, x0 = (i - y * per_row) * 8;
+    const long long r = fb + (long long)y * W;
+    for (int k = 0; k < 8 && x0 + k < W; ++k) {
+      const int x = x0 + k, xs = ch == 0 ? W - 1 - x : x;
+      const unsigned char v = img[r + xs];
+      unsigned char o = v;
+      if (ch == 2) o = lut[b * 256 + v];
+      else if (ch == 3 || ch == 4) {
+        double f = __dadd_rn((double)v, ch == 3 ? p : (noise ? __dmul_rn(p, noise[r + x]) : 0.0));   // no fma: NumPy rounds the product first
+        f = f < 0.0 ? 0.0 : (f > 255.0 ? 255.0 : f);
+        o = (unsigned char)(int)f;
+      }
+      oimg[r + x] = o;
+      olabel[r + x] = label[r + xs];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int egne_augment(const uint8_t* img, const int64_t* label, const int32_t* choice, const double* param, const uint8_t* lut,
+                            const double* noise, uint8_t* out_img, int64_t* out_label, int B, int H, int W, void* stream) {
+  EGNE_REQUIRE(img && label && choice && param && lut && out_img && out_label && B > 0 && H > 0 && W > 0, "augment: bad arguments");
+  EGNE_REQUIRE((const void*)img != (const void*)out_img && (const void*)label != (const void*)out_label, "augment: in place is not supported (flip)");
+  const int per_row = (W + 7) / 8, blocks = (H * per_row + 255) / 256;
+  hipLaunchKernelGGL(augment_k, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, img, (const long long*)label, choice, param, lut,
+                     noise, out_img, (long long*)out_label, H, W);
+  return egne::check_launch("egne_augment");
+}

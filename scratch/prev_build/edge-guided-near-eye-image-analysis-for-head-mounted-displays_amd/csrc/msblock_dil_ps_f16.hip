@@ -233,7 +233,6 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
   const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 4u;
   float* sdst = nullptr;
   float sprev = 0.f;
-  bool ovf_bad = false;
   auto score_prefetch = [&](const Tile& tl) {      // lane (l15, kg) finishes head kg >> 1 of pixel block kg & 1
     const int h = kg >> 1, y = tl.y0 + wave, x = tl.x0 + (kg & 1) * 16 + l15;
     sdst = (score_w && y < H && x < W) ? (h ? s1 : s0) + ((long long)tl.b * H + y) * W + x : nullptr;
@@ -269,9 +268,6 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
                  fmaxf(acc[2][ph][nh][e] * out_scale + bq[2][nh][e], 0.f) + o;        // o + o1 + o2 + o3 (bdcn_new.py:54)
           sc[0][ph] += v[e] * cwq[0][nh][e];
           sc[1][ph] += v[e] * cwq[1][nh][e];
-          // (fmaxf(x, 0) swallows NaN and -inf: the overflow test takes the accumulators themselves; lane = pixel: one channel per
-          //  pixel, common.h)
-          if (nh == 0 && e == 0) ovf_bad |= egne_nonfinite(acc[0][ph][nh][e] + acc[1][ph][nh][e] + acc[2][ph][nh][e] + o);
         }
         if (p.out) {
           const int n = nh * 16 + 4 * kg;
@@ -344,7 +340,6 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
       }()), ...);
     }(std::make_integer_sequence<int, NS>{});
   }
-  egne_ovf_commit(ovf_bad, p.ovf_flag);
   if ((dbg & 64) && lane == 0) {
     unsigned long long* o = g_pstamps + ((long long)blockIdx.x * 8 + wave) * 4;
     o[0] = t_work; o[1] = t_wait; o[2] = nmine; o[3] = 0;

@@ -125,16 +125,6 @@ typedef struct {
    * the value itself (the 4-way sum of bdcn_new.py:54), exact to 2^-22 |x|. */
   int32_t out_split;
   float out_split_scale;      /* s > 0, a power of two */
-  /* Optional (every split-f16 entry point): sticky overflow word.  The kernel sets bit 0 when a value it stores is not finite --
-   * the trace of an operand that left the f16 range under the launch's calibrated pre-scale (or of non-finite input).  The
-   * caller clears it, reads it behind the launches it covers and answers by re-calibrating (engine.Plan.check_overflow). */
-  uint32_t* ovf_flag;
-  /* Optional (egne_conv2d_f16x3_big_fwd, egne_msblock_dil(_scores)_f16_fwd on split-pair input, egne_conv3x3_rw_f16_fwd): products per
-   * multiply of the split-f16 arithmetic.  0 / 3: a b ~= hi hi + hi lo + lo hi (22-bit significand, the inference plans and every
-   * fp32-storage plan).  1: hi hi only -- plain f16 operands (11-bit significand), fp32 accumulation: the frozen edge network next
-   * to a training plan with BF16 activation storage (BASELINE.json configs[2..4]), whose input the edge map is rounded to bf16
-   * (8-bit significand) anyway.  Entry points that do not know the field compute all three products. */
-  int32_t f16_products;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);

@@ -51,6 +51,33 @@ def test_bdcn_big_batch_vs_reference(rep):
     print("B=%d: edge err %.2e, kernels %s" % (2 * rep, err, sorted(kinds)))
 
 
+def test_bdcn_plain_f16_operands_next_to_a_bf16_training_plan():
+    """``BDCN.f16_products = 1`` (train.py --prec 16, bench.py's bf16 training leg): the kernels that know egne_conv_desc.f16_products
+    multiply plain f16 operands (11-bit significand, fp32 accumulation) instead of the split's hi / lo pairs.  The edge map feeds a
+    network that rounds it to bf16 on entry, so the bound is bf16's resolution on (0, 1): half an ulp = 2^-9 below 1 -- measured
+    far inside it -- against the reference-generated fixture, whose edge values span 0.12 .. 0.99.  The plan is a separate one (the key
+    carries the product count): the split plan of the same module, used by validation and the inference entry points, still meets
+    1e-3 afterwards."""
+    from common import bdcn_module, gold
+    from egne_amd import synth
+    g = gold("bdcn_b2_240x320")
+    bd = bdcn_module().to(DEV)
+    b = synth.make_batch(2, seed=1234)
+    x = torch.cat((b["img"],) * 3, 1).to(DEV).repeat(32, 1, 1, 1)
+    bd.f16_products = 1
+    got1 = bd.forward_fuse(x).cpu().numpy().reshape(32, 2, 1, 240, 320)
+    pl1 = bd._last_plan
+    assert pl1.f16_products == 1 and "conv_f16x3:big" in _kinds(pl1)
+    bd.f16_products = 0
+    got3 = bd.forward_fuse(x).cpu().numpy().reshape(32, 2, 1, 240, 320)
+    assert bd._last_plan is not pl1 and bd._last_plan.f16_products == 0
+    e1, e3 = np.abs(got1 - g["fuse"][None]).max(), np.abs(got3 - g["fuse"][None]).max()
+    spread = float(g["fuse"].max() - g["fuse"].min())
+    print("edge map, B=64: plain f16 operands %.2e, split products %.2e from the reference (edge values span %.3f)" % (e1, e3, spread))
+    assert e3 < TOL and e1 < 2.0 ** -9, "plain-f16 edge map off by %.2e" % e1
+    assert np.abs(got1 - got3).max() > 0, "the single-product plan ran the split kernels"
+
+
 def test_bdcn_side_outputs_big_batch():
     """All 11 maps at B=64 (the 10 side outputs only at the fixture's 8x8 sub-grid)."""
     from common import bdcn_module, gold

@@ -167,29 +167,17 @@ def test_a_batch_beyond_the_calibrated_f16_range_is_never_silent(frames64):
     calibrated on the FIRST batch (32x of head-room, engine.Plan); a later batch beyond that turns f16 operands into inf.  Every
     split-f16 epilogue now tests what it stores and sets the plan's sticky overflow word (egne_conv_desc.ovf_flag):
 
-    * both B=64 plans are calibrated on the 64 normal frames, then fed the same batch with four frames amplified 200x (raw
-      activations 200x the calibration maxima -- beyond the 32-64x of head-room; a z-scored frame cannot do that, a caller's bug can);
-    * ``overflowed()`` (what test.py / evaluate.py ask where they synchronise) reports it, the plan re-calibrates on the next call,
-      and THAT call's edge maps / logits are within 1e-3 of the oracle for all 64 frames, the amplified ones included;
-    * a caller that never asks gets an exception from the next run instead of going on with invalid results;
-    * the normal batch still meets 1e-3 on the scales taken from the amplified one."""
-    from common import batch_args, esf_module, setting
+    * both B=64 plans are calibrated on the 64 frames ATTENUATED 200x, then fed the frames themselves: raw activations 200x the
+      calibration maxima, beyond the 32-64x of head-room (frames64 holds the oracle's results for exactly these frames);
+    * ``overflowed()`` (what test.py / evaluate.py / train.py's validation ask where they synchronise) reports it, the plan
+      re-calibrates on the next call, and THAT call's edge maps / logits are within 1e-3 of the oracle for all 64 frames, masks
+      identical away from logit ties;
+    * a caller that never asks gets an exception from the next run instead of going on with invalid results."""
+    from common import batch_args, esf_module
     from egne_amd.utils import calc_edge
-    from oracle import bdcn as obdcn, esfnet as oesf
     f = frames64
     b = dict(f["batch"])
-    amp = [3, 17, 40, 63]
-    img2 = b["img"].clone()
-    img2[amp] *= 200.0
-    b2 = dict(b, img=img2)
-    # oracle for the four amplified frames (eval mode: every frame is independent of its neighbours)
-    sub = {k: (v[amp] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 64 else v) for k, v in b2.items()}
-    with torch.no_grad():
-        e_amp = obdcn.calc_edge({k: v for k, v in f["bdcn"].state_dict().items()}, sub["img"])
-        r_amp = oesf.esf_forward(f["esf_sd"], setting("baseline_edge"), *batch_args(sub, e_amp))
-    edge_ref, op_ref = f["edge"].clone(), f["op"].clone()
-    edge_ref[amp], op_ref[amp] = e_amp.cpu(), r_amp[0]
-
+    dim = dict(b, img=b["img"] * 0.005)
     bd = f["bdcn"].to(DEV)
     m = esf_module("baseline_edge", seed=11).to(DEV).eval()
     m.load_state_dict(f["esf_sd"])
@@ -199,41 +187,38 @@ def test_a_batch_beyond_the_calibrated_f16_range_is_never_silent(frames64):
             e = calc_edge(NS, batch["img"].to(DEV), bd, DEV) if edge is None else edge
             return e, m(*_dev(batch_args(batch, e)))[0]
 
-    e0, op0 = run(b)                        # calibrates both plans on the normal frames
+    for net in (bd, m):                     # (the module-scoped edge network may carry a calibrated plan from the tests above)
+        if getattr(net, "_last_plan", None) is not None:
+            net._last_plan.calibrated = False
+    e_dim, _ = run(dim)                     # calibrates both plans on the attenuated frames
     assert not bd.overflowed() and not m.overflowed()
-    assert (e0.cpu() - f["edge"]).abs().max().item() < TOL and (op0.cpu() - f["op"]).abs().max().item() < TOL
-    # the amplified batch on the stale scales: the edge network reports, and its next call is right
-    e1 = calc_edge(NS, b2["img"].to(DEV), bd, DEV)
+    # the frames themselves on the stale scales: the edge network reports, and its next call is right
+    e1 = calc_edge(NS, b["img"].to(DEV), bd, DEV)
     assert bd.overflowed(), "200x the calibration maxima went through the edge network unnoticed"
-    e2 = calc_edge(NS, b2["img"].to(DEV), bd, DEV)
+    e2 = calc_edge(NS, b["img"].to(DEV), bd, DEV)
     assert not bd.overflowed()
-    per = (e2.cpu() - edge_ref).abs().flatten(1).max(1)[0]
-    assert per.max().item() < TOL, "frame %d: edge map off by %.2e after re-calibration" % (int(per.argmax()), per.max())
-    _, op1 = run(b2, e2)
-    assert m.overflowed(), "the amplified frames went through ESF-Net's head unnoticed"
-    _, op2 = run(b2, e2)
+    per_e = (e2.cpu() - f["edge"]).abs().flatten(1).max(1)[0]
+    assert per_e.max().item() < TOL, "frame %d: edge map off by %.2e after re-calibration" % (int(per_e.argmax()), per_e.max())
+    run(b, e2)
+    assert m.overflowed(), "200x the calibration maxima went through ESF-Net's head unnoticed"
+    _, op2 = run(b, e2)
     assert not m.overflowed()
-    per = (op2.cpu() - op_ref).abs().flatten(1).max(1)[0]
+    per = (op2.cpu() - f["op"]).abs().flatten(1).max(1)[0]
     assert per.max().item() < TOL, "frame %d: logits off by %.2e after re-calibration" % (int(per.argmax()), per.max())
-    top2 = op_ref.topk(2, dim=1)[0]
+    top2 = f["op"].topk(2, dim=1)[0]
     near = (top2[:, 0] - top2[:, 1]) < 2e-3
-    assert not ((m.predictions().cpu() != op_ref.max(1)[1]) & ~near).any()
-    bad1 = int((~torch.isfinite(e1)).sum()) + int(((e1.cpu() - edge_ref).abs() > TOL).sum())
-    print("amplified batch on stale scales: %d edge-map values non-finite or off by more than 1e-3 (reported); after re-calibration "
-          "worst frame %.2e (edge), %.2e (logits)" % (bad1, (e2.cpu() - edge_ref).abs().max(), per.max()))
-    # the normal batch on the scales of the amplified one (its elements sit 200x lower in the split's range)
-    e3, op3 = run(b)
-    assert not bd.overflowed() and not m.overflowed()
-    assert (e3.cpu() - f["edge"]).abs().max().item() < TOL and (op3.cpu() - f["op"]).abs().max().item() < TOL
-    # a caller that never asks: force fresh calibration on the normal batch, overflow again, and go on without looking
-    for net in (bd, m):
-        net._last_plan.calibrated = False
-    run(b)
-    calc_edge(NS, b2["img"].to(DEV), bd, DEV)
+    assert not ((m.predictions().cpu() != f["op"].max(1)[1]) & ~near).any()
+    bad1 = int((~torch.isfinite(e1)).sum()) + int(((e1.cpu() - f["edge"]).abs() > TOL).sum())
+    print("frames at 200x the calibration batch, stale scales: %d of %d edge-map values non-finite or off by more than 1e-3 (reported); "
+          "after re-calibration worst frame %.2e (edge), %.2e (logits)" % (bad1, e1.numel(), per_e.max(), per.max()))
+    # a caller that never asks: calibrate on the attenuated frames again, overflow, and go on without looking
+    bd._last_plan.calibrated = False
+    calc_edge(NS, dim["img"].to(DEV), bd, DEV)
+    calc_edge(NS, b["img"].to(DEV), bd, DEV)
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="overflowed the f16 range"):
         calc_edge(NS, b["img"].to(DEV), bd, DEV)
-    e4, _ = run(b)                          # (the refused call marked the plan: this one re-calibrates and is right)
+    e4 = calc_edge(NS, b["img"].to(DEV), bd, DEV)       # (the refused call marked the plan: this one re-calibrates and is right)
     assert (e4.cpu() - f["edge"]).abs().max().item() < TOL and not bd.overflowed()
 
 
