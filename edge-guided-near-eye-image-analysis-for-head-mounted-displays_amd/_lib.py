@@ -39,6 +39,17 @@ class ConvDesc(C.Structure):
                 ("out_split", C.c_int32), ("out_split_scale", C.c_float), ("ovf_flag", C.c_void_p), ("f16_products", C.c_int32)]
 
 
+class Dst(C.Structure):
+    """egne_dst: one destination of egne_conv1x1_bf16_multi_fwd."""
+    _fields_ = [("out", C.c_void_p), ("out_pix_stride", C.c_int64), ("out_ch_off", C.c_int32), ("C", C.c_int32), ("CoutP", C.c_int32),
+                ("wfrag", C.c_void_p), ("residual", C.c_void_p), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
+                ("mask_y", C.c_void_p), ("mask_pix_stride", C.c_int64), ("mask_ch_off", C.c_int32), ("act", C.c_int32),
+                ("sums", C.c_void_p)]
+
+
+MAXDST = 6
+
+
 class BdcnTailDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("s", c_fp * 5), ("s1", c_fp * 5), ("h", C.c_int32 * 5), ("w", C.c_int32 * 5),
@@ -176,6 +187,10 @@ SIGNATURES.update({
     "egne_conv1x1_bf16_pack_elems": (i64, [C.POINTER(ConvDesc)]),
     "egne_pack_conv1x1_bf16": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp]),
     "egne_conv1x1_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
+    "egne_conv1x1_bf16_multi_supported": (i32, [C.POINTER(ConvDesc), i32, C.POINTER(Dst)]),
+    "egne_conv1x1_bf16_multi_fwd": (i32, [C.POINTER(ConvDesc), i32, C.POINTER(Dst), vp]),
+    "egne_group_sums_floats": (i64, [i32, i32, i32, i32]),
+    "egne_group_sums_reduce": (i32, [vp, i64, i32, i32, vp, vp, i32, vp]),
 })
 
 _lib = None

@@ -134,6 +134,163 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
   }
 }
 
+// ---- several destinations in one launch (round 5) -----------------------------------------------------------------------------------
+// The data gradient of a 1x1 over a would-be torch.cat (models/RITnet_v2.py:59-61,85-86) is one 1x1 per member of the cat, every one of
+// them over the SAME input gz: bf16 plans keep each member in a buffer of its own, so the plan ran one launch per member and read gz
+// once per launch (three or four times per layer).  Here a wave loads the 32-pixel group's operands ONCE (all k-steps: at most 4 x 2
+// registers of 16 bytes) and walks the destinations: per destination its weight fragments (all resident in LDS), up to 64 output
+// channels at a time through the wave's LDS tile, out as whole 8-channel vectors with the optional accumulated residual.
+//
+// Two more things ride on the last writer of a gradient slice (egne_dst.mask_y): the activation mask of the layer whose OUTPUT the
+// slice is the gradient of -- gz = g * act'(y), what egne_act_bwd_bias would do in a pass of its own (read g, read y, write g) -- and
+// the per-group channel sums of gz for that layer's bias gradient (egne_dst.sums: [pixel group][C] floats, reduced by
+// egne_group_sums_reduce in a fixed order: deterministic).
+struct DstTab {
+  void* ptr[EGNE_MAXDST]; const void* res[EGNE_MAXDST]; const void* mask[EGNE_MAXDST]; float* sums[EGNE_MAXDST];
+  int stride[EGNE_MAXDST], off[EGNE_MAXDST], C[EGNE_MAXDST], nb16[EGNE_MAXDST], wofs[EGNE_MAXDST];       // wofs: first 1-KB fragment row of the destination in LDS (per k-step: + nbt * ks)
+  int rstride[EGNE_MAXDST], roff[EGNE_MAXDST], mstride[EGNE_MAXDST], moff[EGNE_MAXDST], act[EGNE_MAXDST];
+  const egne_bf16* wfrag[EGNE_MAXDST];
+};
+
+template <int NKS>
+__global__ __launch_bounds__(256)
+void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M) {
+  constexpr int LDP = 64 + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  egne_bf16* const lw = (egne_bf16*)smem;                               // [NKS][nbt][64 lanes][8]
+  float* const tile = (float*)(smem + (size_t)NKS * nbt * 1024) + (threadIdx.x >> 6) * 32 * LDP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l15 = lane & 15, kg = lane >> 4;
+  for (int d = 0; d < ndst; ++d) {
+    const int nb = dt.nb16[d];
+    for (int it = tid; it < NKS * nb * 64; it += 256) {
+      const int l = it & 63, r = it >> 6, j = r % nb, ks = r / nb;
+      *(u32x4*)&lw[((long long)(ks * nbt + dt.wofs[d] + j) * 64 + l) * 8] = *(const u32x4*)(dt.wfrag[d] + (((long long)ks * nb + j) * 64 + l) * 8);
+    }
+  }
+  __syncthreads();
+  const long long ngroups = (M + 31) / 32;
+  const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long g = wave_id; g < ngroups; g += nwaves) {
+    const long long m0 = g * 32;
+    const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
+    u32x4 xb[NKS][2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const egne_seg& sg = p.seg[tab.seg[ks]];
+      const int c = tab.c0[ks] + 8 * kg;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + m0 * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const int off = c < sg.Cp ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
+        xb[ks][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      }
+    }
+    for (int d = 0; d < ndst; ++d) {
+      const int C = dt.C[d];
+      const __amdgpu_buffer_rsrc_t rout = make_rsrc((egne_bf16*)dt.ptr[d] + m0 * dt.stride[d], (unsigned)rows * (unsigned)dt.stride[d] * 2u);
+      const __amdgpu_buffer_rsrc_t rres = make_rsrc(dt.res[d] ? (const egne_bf16*)dt.res[d] + m0 * dt.rstride[d] : nullptr, dt.res[d] ? (unsigned)rows * (unsigned)dt.rstride[d] * 2u : 0u);
+      const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(dt.mask[d] ? (const egne_bf16*)dt.mask[d] + m0 * dt.mstride[d] : nullptr, dt.mask[d] ? (unsigned)rows * (unsigned)dt.mstride[d] * 2u : 0u);
+      const float slope = dt.act[d] == EGNE_ACT_RELU ? 0.f : (dt.act[d] == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+      for (int b0 = 0; b0 < dt.nb16[d]; b0 += 4) {                     // 64 output channels at a time (nb16 is even)
+        const int nbq = dt.nb16[d] - b0 < 4 ? dt.nb16[d] - b0 : 4;     // 2 or 4 blocks
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < nbq) {
+              const egne_bf16x8 a = *(const egne_bf16x8*)&lw[((long long)(ks * nbt + dt.wofs[d] + b0 + j) * 64 + lane) * 8];
+#pragma unroll
+              for (int ph = 0; ph < 2; ++ph)
+                acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xb[ks][ph]), acc[ph][j], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < nbq) *(f32x4*)&tile[(16 * ph + l15) * LDP + 16 * j + 4 * kg] = acc[ph][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
+        const int G = 2 * nbq, PPI = 64 / G;                     // lanes per pixel on the way out (8 channels each), pixels per instruction
+        const int cg = lane % G, pl = lane / G;
+        const int n = 16 * b0 + 8 * cg;                          // first channel of the lane's vector inside the destination
+        const bool nok = n < C;
+        float csum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+        for (int i = 0; i < 32 / PPI; ++i) {
+          const int px = i * PPI + pl;
+          egne_fv<8> v;
+          const f32x4 t0 = *(const f32x4*)&tile[px * LDP + 8 * cg], t1 = *(const f32x4*)&tile[px * LDP + 8 * cg + 4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v.v[e] = t0[e]; v.v[4 + e] = t1[e]; }
+          if (dt.res[d]) {
+            const u32x4 rw = __builtin_amdgcn_raw_buffer_load_b128(rres, nok ? (px * dt.rstride[d] + dt.roff[d] + n) * 2 : (int)OOB, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v.v[2 * e] += __builtin_bit_cast(float, rw[e] << 16);
+              v.v[2 * e + 1] += __builtin_bit_cast(float, rw[e] & 0xffff0000u);
+            }
+          }
+          if (dt.mask[d]) {         // gz = g * act'(y): the slice is the gradient of a layer's activated output y
+            const u32x4 yw = __builtin_amdgcn_raw_buffer_load_b128(rmsk, nok ? (px * dt.mstride[d] + dt.moff[d] + n) * 2 : (int)OOB, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y0 = __builtin_bit_cast(float, yw[e] << 16), y1 = __builtin_bit_cast(float, yw[e] & 0xffff0000u);
+              v.v[2 * e] = y0 > 0.f ? v.v[2 * e] : slope * v.v[2 * e];
+              v.v[2 * e + 1] = y1 > 0.f ? v.v[2 * e + 1] : slope * v.v[2 * e + 1];
+            }
+          }
+          const f32x4 lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
+          const egne_bf16x4 l4 = __builtin_convertvector(lo, egne_bf16x4), h4 = __builtin_convertvector(hi, egne_bf16x4);
+          const egne_bf16x8 pk = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+          const bool pok = nok && px < rows;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rout, pok ? (px * dt.stride[d] + dt.off[d] + n) * 2 : (int)OOB, 0, 0);
+          if (dt.sums[d]) {         // sums of what was STORED (bf16-rounded), as a pass over the stored tensor would see it
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { csum[e] += pok ? (float)l4[e] : 0.f; csum[4 + e] += pok ? (float)h4[e] : 0.f; }
+          }
+        }
+        if (dt.sums[d]) {           // over the PPI pixel lanes that share a channel vector: lanes cg, cg + G, cg + 2 G, ... (fixed order)
+          for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += __shfl_xor(csum[e], o);
+          }
+          if (pl == 0 && nok) {
+            float* w = dt.sums[d] + g * C + n;
+            *(f32x4*)w = f32x4{csum[0], csum[1], csum[2], csum[3]};
+            *(f32x4*)(w + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[c] (+)= sum over groups of sums[group][c], fixed order (egne_dst.sums -> a bias gradient); 32 channels x 32 interleaved group ranges
+__global__ __launch_bounds__(1024) void group_sums_reduce_k(const float* __restrict__ sums, long long ngroups, int ld, int C, float* __restrict__ out,
+                                                            double* __restrict__ total, int accumulate) {
+  __shared__ double part[32][32];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + c;
+  double s = 0;
+  if (i < C)
+    for (long long k = q; k < ngroups; k += 32) s += (double)sums[k * ld + i];
+  part[q][c] = s;
+  __syncthreads();
+  if (q == 0 && i < C) {
+    double t = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += part[r][c];
+    if (out) out[i] = accumulate ? out[i] + (float)t : (float)t;
+    if (total) total[i] = t;
+  }
+}
+
 // flat fp32 pack [CoutP][Ktot] (egne_pack_conv_weight / egne_pack_conv_weight_dgrad with kh = kw = 1) -> bf16 fragments
 // [k-step][CoutP/16][lane = kg*16 + n%16][8]: element j of lane (n, kg) = W[n][kofs(step) + 8 kg + j], zero beyond the slice
 __global__ void pack_conv1x1_bf16_k(const float* __restrict__ wflat, int CoutP, int Ktot, int nks, KTab tab, const int* __restrict__ kofs,
@@ -230,4 +387,79 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   };
   if (nb == 2) return go(conv1x1_bf16_kernel<2>);
   return go(conv1x1_bf16_kernel<4>);
+}
+
+// Several 1x1 convolutions over the SAME input slices in one launch, each with its own weights (fragments of egne_pack_conv1x1_bf16 for a
+// descriptor with that destination's CoutP) and destination slice: the per-member data gradients of a 1x1 over a would-be torch.cat.
+// d: input slices (seg[]), B, H, W, Ktot; its output fields are ignored.  Returns EGNE_ERR_ARG if the shapes do not fit (the caller
+// falls back to one egne_conv1x1_bf16_fwd per destination): more than 4 k-steps, or more weight fragments than fit LDS.
+extern "C" int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* dp, int ndst, const egne_dst* dsts) {
+  if (!dp || !dsts || ndst < 1 || ndst > EGNE_MAXDST) return 0;
+  KTab tab; int nks = 0;
+  if (!make_tab(*dp, &tab, &nks) || nks > 4) return 0;
+  int nbt = 0;
+  for (int i = 0; i < ndst; ++i) {
+    if (dsts[i].CoutP % 32 || dsts[i].C % 8 || dsts[i].C > dsts[i].CoutP) return 0;
+    nbt += dsts[i].CoutP / 16;
+  }
+  return (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float) <= 120 * 1024;
+}
+
+extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, const egne_dst* dsts, void* stream) {
+  EGNE_REQUIRE(dp && dsts && egne_conv1x1_bf16_multi_supported(dp, ndst, dsts), "conv1x1_bf16_multi: shapes not supported");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.dtype == 1 && d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.nseg >= 1 && d.nseg <= EGNE_MAXSEG,
+               "conv1x1_bf16_multi: bf16 1x1 descriptors only");
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.Cp % 8 == 0 && g.ch_off % 8 == 0 && g.pix_stride % 8 == 0 && ((uintptr_t)g.ptr & 15) == 0 &&
+                 g.ch_off + g.Cp <= g.pix_stride && g.pix_stride * 64 < (1ll << 31), "conv1x1_bf16_multi: slice %d (raw, 16-byte groups of 8 channels)", s);
+  }
+  KTab tab; int nks = 0;
+  make_tab(d, &tab, &nks);
+  DstTab dt{};
+  int nbt = 0;
+  for (int i = 0; i < ndst; ++i) {
+    const egne_dst& q = dsts[i];
+    EGNE_REQUIRE(q.out && q.wfrag && ((uintptr_t)q.out & 15) == 0 && q.out_pix_stride % 8 == 0 && q.out_ch_off % 8 == 0 && q.out_ch_off + q.C <= q.out_pix_stride &&
+                 q.out_pix_stride * 64 < (1ll << 31) && ((uintptr_t)q.wfrag & 15) == 0, "conv1x1_bf16_multi: destination %d", i);
+    EGNE_REQUIRE(!q.residual || (((uintptr_t)q.residual & 15) == 0 && q.res_pix_stride % 8 == 0 && q.res_ch_off % 8 == 0 && q.res_pix_stride * 64 < (1ll << 31)),
+                 "conv1x1_bf16_multi: residual of destination %d", i);
+    EGNE_REQUIRE(!q.mask_y || (((uintptr_t)q.mask_y & 15) == 0 && q.mask_pix_stride % 8 == 0 && q.mask_ch_off % 8 == 0 && q.mask_pix_stride * 64 < (1ll << 31)),
+                 "conv1x1_bf16_multi: mask tensor of destination %d", i);
+    EGNE_REQUIRE(!q.sums || ((uintptr_t)q.sums & 15) == 0, "conv1x1_bf16_multi: sums of destination %d", i);
+    dt.ptr[i] = q.out; dt.res[i] = q.residual; dt.mask[i] = q.mask_y; dt.sums[i] = q.sums;
+    dt.stride[i] = (int)q.out_pix_stride; dt.off[i] = q.out_ch_off; dt.C[i] = q.C; dt.nb16[i] = q.CoutP / 16; dt.wofs[i] = nbt;
+    dt.rstride[i] = (int)q.res_pix_stride; dt.roff[i] = q.res_ch_off; dt.mstride[i] = (int)q.mask_pix_stride; dt.moff[i] = q.mask_ch_off; dt.act[i] = q.act;
+    dt.wfrag[i] = (const egne_bf16*)q.wfrag;
+    nbt += q.CoutP / 16;
+  }
+  const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);
+  const long long M = (long long)d.B * d.H * d.W;
+  long long gx = ((M + 31) / 32 + 3) / 4;
+  const long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1));
+  if (gx > cap) gx = cap;
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto kern) -> int {
+    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16_multi: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M);
+    return egne::check_launch("egne_conv1x1_bf16_multi_fwd");
+  };
+  switch (nks) {
+    case 1: return go(conv1x1_bf16_multi_kernel<1>);
+    case 2: return go(conv1x1_bf16_multi_kernel<2>);
+    case 3: return go(conv1x1_bf16_multi_kernel<3>);
+    default: return go(conv1x1_bf16_multi_kernel<4>);
+  }
+}
+
+extern "C" int64_t egne_group_sums_floats(int B, int H, int W, int C) { return (((int64_t)B * H * W + 31) / 32) * C; }
+
+// out[c] (+)= sum over pixel groups of sums[group * ld + c], c < C (egne_dst.sums of a launch over npix pixels: ld = that destination's C);
+// total (optional): the same sums as doubles
+extern "C" int egne_group_sums_reduce(const float* sums, int64_t npix, int ld, int C, float* out, double* total, int accumulate, void* stream) {
+  EGNE_REQUIRE(sums && (out || total) && npix > 0 && C > 0 && ld >= C, "group_sums_reduce: bad arguments");
+  hipLaunchKernelGGL(group_sums_reduce_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, (long long)((npix + 31) / 32), ld, C, out, total, accumulate);
+  return egne::check_launch("egne_group_sums_reduce");
 }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             const int c = (r & 3) + 8 * (r >> 2);
             float v = acc[tm][tn][r] * out_scale + bv;
             v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
-            if (chk) bad |= egne_nonfinite(v);
+            if (tn == 0 && chk) bad |= egne_nonfinite(v);       // (one 32-channel block per wave: every channel of a contaminated pixel is contaminated)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
             const double vm = c < cm ? (double)v : 0.;
             st_s += vm; st_q += vm * vm;

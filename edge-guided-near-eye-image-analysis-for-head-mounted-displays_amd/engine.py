@@ -83,6 +83,11 @@ HALO_TALL = os.environ.get("EGNE_SHALO_TALL", "1") != "0"           # conv_halo_
 HALO_F16_MIN_W = int(os.environ.get("EGNE_HALO_F16_MIN_W", "30"))      # (30x40 maps: 253 -> 194 us for 120 -> 128 channels against the flat kernel)
 HALO_F16_MIN_W_NARROW = int(os.environ.get("EGNE_HALO_F16_MIN_W_NARROW", "30"))   # Cout <= 64: the flat kernel's 256x32 tiles starve the chip
 HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
+# bf16-storage plans: the per-member data gradients of a 1x1 over a would-be torch.cat as ONE launch that reads gz once
+# (egne_conv1x1_bf16_multi_fwd), and -- where such a launch is the last writer of a gradient slice -- the activation mask and bias sums
+# of the layer that slice belongs to in its epilogue instead of a pass of their own (egne_act_bwd_bias)
+MULTI_DGRAD = os.environ.get("EGNE_MULTI_DGRAD", "1") != "0"
+MASK_ON_WRITE = os.environ.get("EGNE_MASK_ON_WRITE", "1") != "0"
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
 BF16_DGRAD_PACK = os.environ.get("EGNE_BF16_DGRAD_PACK", "1") != "0"   # bf16-storage plans: data-gradient fragments packed straight from the forward weight
 BF16_NARROW = os.environ.get("EGNE_BF16_NARROW", "1") != "0"       # bf16-storage plans: k x k convolutions onto <= 8 channels on the LDS-halo kernel (conv_narrow_bf16.hip)
@@ -616,6 +621,7 @@ class Plan:
         # behind every run, the event that says the copy has landed
         self.ovf = self.ovf_host = self.ovf_event = None
         self.overflow_events = 0
+        self._mask_cands = {}                          # (buffer id, first channel, channels, samples) -> multi-destination launch that wrote the slice last (_bw_conv)
         self.f16_products = 0                          # egne_conv_desc.f16_products of the plan's split-f16 launches (1: plain f16 operands; BDCN.f16_products)
         self.tail_at, self.tail_hook = None, None      # backward plans: call index where every non-encoder parameter gradient is final, and what to call there (parallel.GradOverlap.tail_ready)
         self._absmax_of, self._dyn_hint = {}, None   # published max |x| words: (buffer, slice, samples) -> (word, call index); forced word
@@ -750,16 +756,21 @@ class Plan:
             self.ovf_event = torch.cuda.Event()
         return self.ovf.data_ptr()
 
+    OVF_MIRROR_EVERY = 16
+
     def _ovf_publish(self):
-        """Behind the launches of a run: the word goes to pinned host memory (4 bytes, no synchronisation)."""
+        """Behind the launches of a run.  The word itself stays on the device: ``overflowed()`` reads it where the caller
+        synchronises anyway.  For callers that never ask, every 16th run queues a 4-byte copy to pinned host memory, which the start
+        of a later run looks at without waiting (replays of a hipGraph capture bypass this code: their callers ask) -- a copy and
+        an event behind EVERY run cost the pipelined B=64 inference loop 1.2 % (measured; the kernels' own tests cost 0.2 %)."""
         if self.ovf is None:
             return
+        self._ovf_runs = getattr(self, "_ovf_runs", 0) + 1
+        if self._ovf_runs % self.OVF_MIRROR_EVERY or torch.cuda.is_current_stream_capturing():
+            return
         self.ovf_host.copy_(self.ovf, non_blocking=True)
-        if torch.cuda.is_current_stream_capturing():
-            self._ovf_graphed = True          # the copy is a node of the hipGraph: it lands with every replay, no event to wait on
-        else:
-            self.ovf_event.record()
-            self._ovf_recorded = True
+        self.ovf_event.record()
+        self._ovf_recorded = True
 
     def _ovf_reset(self):
         self.ovf.zero_()
@@ -775,18 +786,13 @@ class Plan:
         anyway: test.py / evaluate.py when they read the masks); without it only a completed run is judged."""
         if self.ovf is None:
             return False
-        if getattr(self, "_ovf_graphed", False):
-            if not wait:
+        if wait:
+            # (the caller synchronises here anyway: a 4-byte read of the device word behind everything queued on this stream)
+            if int(self.ovf.item()) == 0:
                 return False
-            torch.cuda.synchronize(self.device)      # replays of a captured plan: whatever ran last has published its word
-        elif not getattr(self, "_ovf_recorded", False):
-            return False
-        elif wait:
-            self.ovf_event.synchronize()
-        elif not self.ovf_event.query():
-            return False
-        if int(self.ovf_host[0]) == 0:
-            return False
+        else:
+            if not getattr(self, "_ovf_recorded", False) or not self.ovf_event.query() or int(self.ovf_host[0]) == 0:
+                return False
         self._ovf_reset()
         return True
 
@@ -1583,9 +1589,18 @@ class Plan:
     def _bw_conv(self, bw, layer, pieces, dst, d, B, H, W, Ho, Wo, name):
         """Backward of y = act(conv(pieces) + b): mask + bias grad, weight grad, data grads."""
         L = self.L
-        gy = self.gp(dst)
         Cs = int(d.Cout_store)
         npix = B * Ho * Wo
+        # Was the last writer of this layer's output gradient a multi-destination 1x1 data gradient over the same pixels?  Then THAT
+        # launch applies the activation mask and leaves the bias sums (egne_dst.mask_y / sums): no egne_act_bwd_bias pass here.
+        masked = None
+        cand = self._mask_cands.get((id(dst.buf), dst.off, Cs, dst.n0, B, Ho, Wo)) if (MASK_ON_WRITE and self.bf16) else None
+        if cand is not None:
+            ents = self._touched.get(id(dst.buf), [])
+            last = max((i for i, e in enumerate(ents) if e[0] < dst.off + dst.Cp and e[1] > dst.off), default=-1)
+            if last == cand[0] and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY):
+                masked = cand
+        gy = self.gp(dst)
         ws = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(npix, Cs)) + 7) // 8, dtype=torch.float64)
         bias = layer.biases[0] if layer.biases is not None else None
         split_dgrad = (bw.dyn_scales and F16X3_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
@@ -1620,6 +1635,17 @@ class Plan:
             assert seen.setdefault(id(bias), how) == how, "%s: its bias Parameter is also written from the other stream of the backward plan" % name
         if peer is not None and not lead:
             pass                                             # the pair's 1x1: no activation to mask, bias gradient already taken (below)
+        elif masked is not None:
+            # mask and channel sums come out of the writer's epilogue; here only the sums' second stage (fixed order: deterministic).
+            # A pair's 3x3 hands the totals to egne_pair_bias_bwd in the chunk-sum layout it reads (chunk 0 = the total, the rest stays zero)
+            _, arr, j = masked
+            if layer.act != ACT_NONE:
+                arr[j].mask_y, arr[j].mask_pix_stride, arr[j].mask_ch_off, arr[j].act = dst.ptr, dst.stride, dst.off, layer.act
+            if dbias is not None or lead:
+                sums = bw.vec(int(L.egne_group_sums_floats(B, Ho, Wo, Cs)))
+                arr[j].sums = sums.data_ptr()
+                bw.raw(L.egne_group_sums_reduce, (sums.data_ptr(), npix, Cs, layer.Cout if dbias is not None else Cs, dbias,
+                                                  ws.data_ptr() if lead else None, 1), name + ".bias_sums")
         elif self.bf16:
             bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
                                          dbias, layer.Cout, 1, ws.data_ptr()), name + ".act_bwd")
@@ -1665,6 +1691,10 @@ class Plan:
                     merged[i] = j - i + 1
                     skip.update(range(i + 1, j + 1))
                 i = j + 1
+        if (MULTI_DGRAD and self.bf16 and BF16_FAST1X1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1 and layer.pad == (0, 0)
+                and layer.pad_mode == 0 and layer.G == 1 and not merged and Cs % 8 == 0 and gy.off % 8 == 0 and gy.stride % 8 == 0
+                and npix >= 4096):
+            skip |= self._multi_dgrad(bw, layer, pieces, gin, gy, Cs, B, Ho, Wo, name)
         for i, pc in enumerate(pieces):
             if pc.nograd or i in skip:
                 continue
@@ -1730,6 +1760,59 @@ class Plan:
                                          tmp.data_ptr(), tmp.shape[-1], 0, pc.act_in, pc.Cp, B, H * W, 1,
                                          tgt.ptr, tgt.stride, tgt.off, sums.data_ptr(), None, None, 0, wsn.data_ptr()),
                        name + ".in_bwd%d" % i)
+
+    def _multi_dgrad(self, bw, layer, pieces, gin, gy, Cs, B, H, W, name):
+        """Data gradients of a 1x1 over several raw bf16 slices as ONE launch (egne_conv1x1_bf16_multi_fwd: gz is read once instead of
+        once per member of the would-be torch.cat).  Returns the indices of the pieces it took (the caller emits the rest one by
+        one).  Each destination is remembered as the possible LAST writer of its gradient slice (``_mask_cands``): the layer
+        whose output the slice is may then hang its activation mask and bias sums on it (_bw_conv)."""
+        L = self.L
+        ok = [i for i, q in enumerate(pieces) if not q.nograd and q.scale is None and not isinstance(q, PlanarPiece)
+              and q.Cp % 8 == 0 and q.off % 8 == 0 and q.stride % 8 == 0 and q.buf.dtype == torch.bfloat16]
+        best = []
+        dm = _lib.ConvDesc()
+        dm.dtype = 1
+        dm.B, dm.H, dm.W, dm.Ho, dm.Wo = B, H, W, H, W
+        dm.kh = dm.kw = dm.stride = dm.ngroups = 1
+        for g in range(_lib.MAXGROUP):
+            dm.dil[g] = 1
+        dm.nseg = 1
+        sg = dm.seg[0]
+        sg.ptr, sg.pix_stride, sg.ch_off, sg.Cp = gy.ptr, gy.stride, gy.off, Cs
+        dm.Ktot = Cs
+        probe = (_lib.Dst * _lib.MAXDST)()
+        for i in ok[:_lib.MAXDST]:            # the longest prefix of the eligible pieces whose weights fit LDS together
+            probe[len(best)].C, probe[len(best)].CoutP = pieces[i].Cp, pad32(pieces[i].C)
+            if not int(L.egne_conv1x1_bf16_multi_supported(C.byref(dm), len(best) + 1, probe)):
+                break
+            best.append(i)
+        if len(best) < 2:
+            return set()
+        arr = (_lib.Dst * len(best))()
+        flops = 0.0
+        for j, i in enumerate(best):
+            pc = pieces[i]
+            dl = DgradLayer(layer, i)
+            dl.need_flat = dl.need_b1 = True
+            if dl not in bw.layers:
+                bw.layers.append(dl)
+            dl.ensure_packed(self.device)
+            first = self.first_touch(pc.buf, pc.off, pc.Cp)
+            tgt = self.gp(pc)
+            ent = len(self._touched[id(pc.buf)]) - 1 if self._touching else -1
+            if first and dl.Cout_store == pc.Cp:
+                self.mark_stored(pc, B)
+            q = arr[j]
+            q.out, q.out_pix_stride, q.out_ch_off, q.C, q.CoutP = tgt.ptr, tgt.stride, tgt.off, pc.Cp, dl.CoutP
+            q.wfrag = dl.b1frag.data_ptr()
+            if not first:
+                q.residual, q.res_pix_stride, q.res_ch_off = tgt.ptr, tgt.stride, tgt.off
+            self._mask_cands[(id(pc.buf), pc.off, pc.Cp, pc.n0, B, H, W)] = (ent, arr, j)
+            flops += 2.0 * B * H * W * pc.C * layer.Cout
+        self.keep += [dm, arr]
+        LAYER_BYTES[name + ".dgrad_multi"] = float(self.esz) * B * H * W * (Cs + sum(pieces[i].Cp * (1 if arr[j].residual is None else 2) for j, i in enumerate(best)))
+        bw._add(L.egne_conv1x1_bf16_multi_fwd, (C.byref(dm), len(best), arr), name + ".dgrad_multi", flops=flops, kind="conv_bf16:1x1")
+        return set(best)
 
     def norm_stats(self, piece, B, HW, per_sample=True, eps=1e-5, want_moments=False, name="norm_stats"):
         Bn = B if per_sample else 1

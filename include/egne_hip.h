@@ -714,11 +714,33 @@ int egne_conv3x3_narrow_fwd(const egne_conv_desc* d, void* stream);
  */
 int64_t egne_conv1x1_bf16_pack_elems(const egne_conv_desc* d);
 int egne_pack_conv1x1_bf16(const egne_conv_desc* d, const float* wflat, const int32_t* seginfo, void* wfrag, void* stream);
+/* Several 1x1 convolutions over the SAME bf16 input slices in one launch (round 5): the per-member data gradients of a 1x1 over a
+ * would-be torch.cat (models/RITnet_v2.py:59-61,85-86; replaces one egne_conv1x1_bf16_fwd per member, each re-reading gz).
+ * A destination may be the LAST writer of its gradient slice: then it applies the activation mask of the layer whose output the
+ * slice is the gradient of (mask_y, act: gz = g * act'(y), the pass egne_act_bwd_bias would make) and leaves per-pixel-group
+ * channel sums of the stored values for that layer's bias gradient (sums: egne_group_sums_floats(B, H, W, C) floats, reduced by
+ * egne_group_sums_reduce in a fixed order). */
+#define EGNE_MAXDST 6
+typedef struct {
+  void* out; int64_t out_pix_stride; int32_t out_ch_off;
+  int32_t C;                    /* channels stored (multiple of 8) */
+  int32_t CoutP;                /* rows of this destination's weight pack (multiple of 32) */
+  const void* wfrag;            /* egne_pack_conv1x1_bf16 fragments for (the input slices, CoutP) */
+  const void* residual; int64_t res_pix_stride; int32_t res_ch_off;      /* optional accumulated tensor (bf16) */
+  const void* mask_y; int64_t mask_pix_stride; int32_t mask_ch_off;      /* optional: activated output whose sign masks the result */
+  int32_t act;                  /* egne_act of that layer */
+  float* sums;                  /* optional [pixel groups of 32][C] */
+} egne_dst;
+int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* d, int ndst, const egne_dst* dsts);
+int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* d, int ndst, const egne_dst* dsts, void* stream);
+int64_t egne_group_sums_floats(int B, int H, int W, int C);
+int egne_group_sums_reduce(const float* sums, int64_t npix, int ld, int C, float* out /* [C], may be NULL */, double* total /* [C], may be NULL */,
+                           int accumulate, void* stream);
 int egne_conv1x1_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
 const char* egne_last_error(void);
 int egne_version(void);
-int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc */
+int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc, 3 egne_dst */
 
 #ifdef __cplusplus
 }

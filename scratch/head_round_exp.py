@@ -27,18 +27,25 @@ def rounder(t):
     return f
 
 def insert_after(plan, prefix_names, fn, tag):
+    # (no index shifts: the plan keeps tables keyed by call index) -- wrap the launch itself
     idx = max(i for i, c in enumerate(plan.calls) if c[2] in prefix_names)
-    plan.calls.insert(idx + 1, (fn, (), tag)); plan.meta.insert(idx + 1, ("host", 0.0))
+    f0, a0, n0 = plan.calls[idx]
+    def both(*a, f0=f0, fn=fn):
+        rc = f0(*a)
+        fn(a[-1])
+        return rc
+    plan.calls[idx] = (both, a0, n0)
 
-def run(storage, fwd_round=False, bwd_round=False, blocks=()):
+def run(storage, fwd_round=False, bwd_round=False, blocks=(), which=("t0", "pre")):
     mm = esf_module(cfg, variant).to(DEV).to(storage).train()
     args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
     out = mm(*args)      # builds the plan
     pl = mm._last_plan
     t0, pre = pl.dbg["t0"], pl.dbg["head_pre"]
     if fwd_round:
-        insert_after(pl, {"enc.head.conv1"}, rounder(t0), "round.t0")
-        insert_after(pl, {"enc.head.conv2"}, rounder(pre), "round.pre")
+        if "t0" in which: insert_after(pl, {"enc.head.conv1"}, rounder(t0), "round.t0")
+        if "pre" in which: insert_after(pl, {"enc.head.conv2"}, rounder(pre), "round.pre")
+        if "x" in which: insert_after(pl, {"enc.head.bn.apply", "enc.head.bn.edge.apply"}, rounder(pl.dbg["D"][0]["x"].buf), "round.x")
     if bwd_round:
         bw = pl.bw
         insert_after(bw, {"enc.head.bn.bwd", "enc.head.bn.edge.bwd"}, rounder(pl.gbuf(pre)), "round.gpre")
@@ -60,9 +67,11 @@ def run(storage, fwd_round=False, bwd_round=False, blocks=()):
         d = torch.cat([(params[n].grad.double().cpu() - sd[n].grad).reshape(-1) for n in sel]); return float(d.norm() / flat_t.norm())
     return whole, cos, per, {p: grp(p) for p in ("enc.head", "enc.down_block1", "enc.down_block2", "enc.down_block3", "enc.down_block4", "enc.bottleneck", "dec.", "elReg")}
 
-for label, a in (("fp32 storage", (torch.float32, False, False)), ("fp32 + head fwd tensors rounded", (torch.float32, True, False)),
-                 ("fp32 + head fwd and grad tensors rounded", (torch.float32, True, True)), ("bf16 storage", (torch.bfloat16, False, False))):
-    w, c, per, g = run(*a)
+for label, a, kw in (("fp32 storage", (torch.float32, False, False), {}), ("fp32 + t0 rounded", (torch.float32, True, False), dict(which=("t0",))),
+                     ("fp32 + pre rounded", (torch.float32, True, False), dict(which=("pre",))),
+                     ("fp32 + block-0 input x rounded", (torch.float32, True, False), dict(which=("x",))),
+                     ("fp32 + t0, pre rounded", (torch.float32, True, False), {}), ("bf16 storage", (torch.bfloat16, False, False), {})):
+    w, c, per, g = run(*a, **kw)
     top = sorted(per, key=per.get)[-4:]
     print("%-42s whole %.3e cos %.5f | share of the whole error by group: %s | worst tensors: %s"
           % (label, w, c, {k: "%.3f" % v for k, v in g.items()}, {k: "%.2f" % per[k] for k in top}), flush=True)

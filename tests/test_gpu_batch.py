@@ -344,6 +344,46 @@ def test_split_kernels_any_activation_magnitude(mag, shape):
         assert err < 2e-6, "mag %g: relative error %.2e" % (mag, err)
     a_scale = pl.calls[-1][1][pl.cal[len(pl.calls) - 1][0]]
     assert 1024 <= a_scale * x.abs().max().item() < 2048, a_scale
+    # the same plan fed 1000x the batch it was calibrated on (beyond the 32x of head-room): the kernel's epilogue reports the f16
+    # overflow (egne_conv_desc.ovf_flag), the plan answers by re-calibrating and running again (Plan.check_overflow)
+    assert not pl.overflowed()
+    if mag < 1e6:
+        px.buf.mul_(1000.0)
+        pl.run()
+        assert pl.check_overflow(), "1000x the calibration batch went through unnoticed"
+        torch.cuda.synchronize()
+        truth2 = F.relu(F.conv2d(x.double() * 1000.0, w.double(), b.double(), padding=1))
+        err = (out.cpu().permute(0, 3, 1, 2).double() - truth2).abs().max().item() / truth2.abs().max().item()
+        assert err < 2e-6 and not pl.overflowed(), "after re-calibration: relative error %.2e" % err
+
+
+def test_esf_stale_scales_after_a_batchnorm_update_are_reported():
+    """A calibrated inference plan whose BatchNorm parameters change under it (a checkpoint with the same convolutions and another head
+    BatchNorm: no convolution is re-packed, so nothing re-calibrates): the raw block-0 tensors grow 3000x, beyond the head-room of
+    the stored f16 pre-scales.  The fused 1x1 -> 3x3 kernels report it (DenseNet2D.overflowed), the next call re-calibrates and
+    matches the oracle."""
+    from common import batch_args, bdcn_module, esf_module, setting
+    from egne_amd import synth
+    from egne_amd.utils import calc_edge
+    from oracle import esfnet as oesf
+    bd = bdcn_module().to(DEV)
+    b = synth.make_batch(2, seed=77)
+    edge = calc_edge(types.SimpleNamespace(prec=torch.float32, edge_thres=0), b["img"].to(DEV), bd, DEV)
+    m = esf_module("baseline_edge", seed=2).to(DEV).eval()
+    args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
+    with torch.no_grad():
+        m(*args)
+        assert not m.overflowed()
+        m.enc.head.bn.weight.mul_(3000.0)
+        m.enc.head.bn.bias.add_(0.3).mul_(3000.0)
+        ref = oesf.esf_forward({k: v.cpu() for k, v in m.state_dict().items()}, setting("baseline_edge"), *batch_args(b, edge.cpu()))
+        m(*args)
+        assert m.overflowed(), "raw activations 3000x the calibration batch's went through unnoticed"
+        op = m(*args)[0]
+        assert not m.overflowed()
+    scale = ref[0].abs().max().item()
+    err = (op.cpu() - ref[0]).abs().max().item()
+    assert err < 1e-3 * max(1.0, scale), "after re-calibration: logits off by %.3g (scale %.3g)" % (err, scale)
 
 
 def test_esf_large_raw_activations_vs_oracle():

@@ -187,9 +187,8 @@ def test_a_batch_beyond_the_calibrated_f16_range_is_never_silent(frames64):
             e = calc_edge(NS, batch["img"].to(DEV), bd, DEV) if edge is None else edge
             return e, m(*_dev(batch_args(batch, e)))[0]
 
-    for net in (bd, m):                     # (the module-scoped edge network may carry a calibrated plan from the tests above)
-        if getattr(net, "_last_plan", None) is not None:
-            net._last_plan.calibrated = False
+    for pl in bd._plans.values():           # (the module-scoped edge network carries plans calibrated by the tests above)
+        pl.calibrated = False
     e_dim, _ = run(dim)                     # calibrates both plans on the attenuated frames
     assert not bd.overflowed() and not m.overflowed()
     # the frames themselves on the stale scales: the edge network reports, and its next call is right
@@ -199,8 +198,13 @@ def test_a_batch_beyond_the_calibrated_f16_range_is_never_silent(frames64):
     assert not bd.overflowed()
     per_e = (e2.cpu() - f["edge"]).abs().flatten(1).max(1)[0]
     assert per_e.max().item() < TOL, "frame %d: edge map off by %.2e after re-calibration" % (int(per_e.argmax()), per_e.max())
-    run(b, e2)
-    assert m.overflowed(), "200x the calibration maxima went through ESF-Net's head unnoticed"
+    # ESF-Net on the stale scales: either it reports, or its results are right
+    _, op_a = run(b, e2)
+    if not m.overflowed():
+        per = (op_a.cpu() - f["op"]).abs().flatten(1).max(1)[0]
+        assert per.max().item() < TOL, "no overflow reported at 200x, yet frame %d is off by %.2e" % (int(per.argmax()), per.max())
+    # (ESF-Net's raw tensors do not follow the input's scale: the head's bias and BatchNorm put a floor under the calibration
+    #  maxima -- tests/test_gpu_batch.py::test_esf_stale_scales_after_a_batchnorm_update_are_reported overflows its plan)
     _, op2 = run(b, e2)
     assert not m.overflowed()
     per = (op2.cpu() - f["op"]).abs().flatten(1).max(1)[0]
@@ -214,10 +218,10 @@ def test_a_batch_beyond_the_calibrated_f16_range_is_never_silent(frames64):
     # a caller that never asks: calibrate on the attenuated frames again, overflow, and go on without looking
     bd._last_plan.calibrated = False
     calc_edge(NS, dim["img"].to(DEV), bd, DEV)
-    calc_edge(NS, b["img"].to(DEV), bd, DEV)
-    torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="overflowed the f16 range"):
-        calc_edge(NS, b["img"].to(DEV), bd, DEV)
+        for _ in range(2 * bd._last_plan.OVF_MIRROR_EVERY + 2):       # (the host mirror of the word is refreshed every 16th run)
+            calc_edge(NS, b["img"].to(DEV), bd, DEV)
+            torch.cuda.synchronize()
     e4 = calc_edge(NS, b["img"].to(DEV), bd, DEV)       # (the refused call marked the plan: this one re-calibrates and is right)
     assert (e4.cpu() - f["edge"]).abs().max().item() < TOL and not bd.overflowed()
 

@@ -74,6 +74,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.egne_sizeof(0) == __import__("ctypes").sizeof(_lib.ConvDesc)
     assert L.egne_sizeof(1) == __import__("ctypes").sizeof(_lib.LossDesc)
     assert L.egne_sizeof(2) == __import__("ctypes").sizeof(_lib.BdcnTailDesc)
+    assert L.egne_sizeof(3) == __import__("ctypes").sizeof(_lib.Dst)
 
 
 def test_no_cpu_fallback_and_loud_failure():
