@@ -189,7 +189,7 @@ SIGNATURES.update({
     "egne_conv1x1_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
     "egne_conv1x1_bf16_multi_supported": (i32, [C.POINTER(ConvDesc), i32, C.POINTER(Dst)]),
     "egne_conv1x1_bf16_multi_fwd": (i32, [C.POINTER(ConvDesc), i32, C.POINTER(Dst), vp]),
-    "egne_group_sums_floats": (i64, [i32, i32, i32, i32]),
+    "egne_conv1x1_bf16_multi_waves": (i64, [C.POINTER(ConvDesc), i32, C.POINTER(Dst)]),
     "egne_group_sums_reduce": (i32, [vp, i64, i32, i32, vp, vp, i32, vp]),
 })
 

@@ -142,9 +142,11 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 // channels at a time through the wave's LDS tile, out as whole 8-channel vectors with the optional accumulated residual.
 //
 // Two more things ride on the last writer of a gradient slice (egne_dst.mask_y): the activation mask of the layer whose OUTPUT the
-// slice is the gradient of -- gz = g * act'(y), what egne_act_bwd_bias would do in a pass of its own (read g, read y, write g) -- and
-// the per-group channel sums of gz for that layer's bias gradient (egne_dst.sums: [pixel group][C] floats, reduced by
-// egne_group_sums_reduce in a fixed order: deterministic).
+// slice is the gradient of -- gz = g * act'(y), what egne_act_bwd_bias would do in a pass of its own (read g, read y, write g) -- and,
+// for ONE destination of the launch (at most 128 channels), the channel sums of gz for that layer's bias gradient: every wave keeps
+// them in registers (fp64) over all the pixel groups it walks and writes one row of egne_dst.sums [wave][C] at the end; the
+// assignment of groups to waves is fixed by the grid, so egne_group_sums_reduce adds the rows in a fixed order (deterministic).
+// (A row per GROUP, reduced by one block, took longer than the pass it replaced: 1.2 M rows per B=256 layer.)
 struct DstTab {
   void* ptr[EGNE_MAXDST]; const void* res[EGNE_MAXDST]; const void* mask[EGNE_MAXDST]; float* sums[EGNE_MAXDST];
   int stride[EGNE_MAXDST], off[EGNE_MAXDST], C[EGNE_MAXDST], nb16[EGNE_MAXDST], wofs[EGNE_MAXDST];       // wofs: first 1-KB fragment row of the destination in LDS (per k-step: + nbt * ks)
@@ -154,7 +156,7 @@ struct DstTab {
 
 template <int NKS>
 __global__ __launch_bounds__(256)
-void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M) {
+void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M, int sum_dst) {
   constexpr int LDP = 64 + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   egne_bf16* const lw = (egne_bf16*)smem;                               // [NKS][nbt][64 lanes][8]
@@ -171,6 +173,9 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
   __syncthreads();
   const long long ngroups = (M + 31) / 32;
   const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+  double wsum[2][8];                  // destination sum_dst: this wave's sums of the lane's 8 channels, first / second 64-channel chunk
+#pragma unroll
+  for (int a = 0; a < 16; ++a) (&wsum[0][0])[a] = 0.;
   for (long long g = wave_id; g < ngroups; g += nwaves) {
     const long long m0 = g * 32;
     const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
@@ -219,6 +224,7 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
         const int cg = lane % G, pl = lane / G;
         const int n = 16 * b0 + 8 * cg;                          // first channel of the lane's vector inside the destination
         const bool nok = n < C;
+        const bool summing = d == sum_dst;
         float csum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] = 0.f;
@@ -250,28 +256,47 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
           const egne_bf16x8 pk = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
           const bool pok = nok && px < rows;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rout, pok ? (px * dt.stride[d] + dt.off[d] + n) * 2 : (int)OOB, 0, 0);
-          if (dt.sums[d]) {         // sums of what was STORED (bf16-rounded), as a pass over the stored tensor would see it
+          if (summing) {            // sums of what was STORED (bf16-rounded), as a pass over the stored tensor would see it
 #pragma unroll
             for (int e = 0; e < 4; ++e) { csum[e] += pok ? (float)l4[e] : 0.f; csum[4 + e] += pok ? (float)h4[e] : 0.f; }
           }
         }
-        if (dt.sums[d]) {           // over the PPI pixel lanes that share a channel vector: lanes cg, cg + G, cg + 2 G, ... (fixed order)
-          for (int o = G; o < 64; o <<= 1) {
+        if (summing) {              // (the group's <= 16 values per lane and channel in fp32, the running sums in fp64)
+          if (b0 == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += __shfl_xor(csum[e], o);
+            for (int e = 0; e < 8; ++e) wsum[0][e] += (double)csum[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wsum[1][e] += (double)csum[e];
           }
-          if (pl == 0 && nok) {
-            float* w = dt.sums[d] + g * C + n;
-            *(f32x4*)w = f32x4{csum[0], csum[1], csum[2], csum[3]};
-            *(f32x4*)(w + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
-          }
+        }
+      }
+    }
+  }
+  if (sum_dst >= 0) {
+    // over the pixel lanes that share a channel vector (lanes cg, cg + G, cg + 2 G, ...: fixed order), then one row [C] per wave
+    const int C = dt.C[sum_dst], nb16 = dt.nb16[sum_dst];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int b0 = 4 * ch;
+      if (b0 < nb16) {
+        const int nbq = nb16 - b0 < 4 ? nb16 - b0 : 4, G = 2 * nbq;
+        for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wsum[ch][e] += __shfl_xor(wsum[ch][e], o);
+        }
+        const int n = 16 * b0 + 8 * (lane % G);
+        if (lane < G && n < C) {
+          float* w = dt.sums[sum_dst] + wave_id * C + n;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (float)wsum[ch][e];
         }
       }
     }
   }
 }
 
-// out[c] (+)= sum over groups of sums[group][c], fixed order (egne_dst.sums -> a bias gradient); 32 channels x 32 interleaved group ranges
+// out[c] (+)= sum over rows of sums[row][c], fixed order (egne_dst.sums -> a bias gradient); 32 channels x 32 interleaved row ranges
 __global__ __launch_bounds__(1024) void group_sums_reduce_k(const float* __restrict__ sums, long long ngroups, int ld, int C, float* __restrict__ out,
                                                             double* __restrict__ total, int accumulate) {
   __shared__ double part[32][32];
@@ -405,6 +430,24 @@ extern "C" int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* dp, int n
   return (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float) <= 120 * 1024;
 }
 
+static long long multi_grid(const egne_conv_desc& d, int nks, int nbt) {
+  const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);
+  const long long M = (long long)d.B * d.H * d.W;
+  long long gx = ((M + 31) / 32 + 3) / 4;
+  const long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1));
+  return gx > cap ? cap : gx;
+}
+
+// rows of egne_dst.sums this launch writes (one per wave): what the caller allocates (x C floats) and hands to egne_group_sums_reduce
+extern "C" int64_t egne_conv1x1_bf16_multi_waves(const egne_conv_desc* dp, int ndst, const egne_dst* dsts) {
+  if (!egne_conv1x1_bf16_multi_supported(dp, ndst, dsts)) return -1;
+  KTab tab; int nks = 0;
+  make_tab(*dp, &tab, &nks);
+  int nbt = 0;
+  for (int i = 0; i < ndst; ++i) nbt += dsts[i].CoutP / 16;
+  return multi_grid(*dp, nks, nbt) * 4;
+}
+
 extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, const egne_dst* dsts, void* stream) {
   EGNE_REQUIRE(dp && dsts && egne_conv1x1_bf16_multi_supported(dp, ndst, dsts), "conv1x1_bf16_multi: shapes not supported");
   const egne_conv_desc& d = *dp;
@@ -418,9 +461,13 @@ extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, c
   KTab tab; int nks = 0;
   make_tab(d, &tab, &nks);
   DstTab dt{};
-  int nbt = 0;
+  int nbt = 0, sum_dst = -1;
   for (int i = 0; i < ndst; ++i) {
     const egne_dst& q = dsts[i];
+    if (q.sums) {
+      EGNE_REQUIRE(sum_dst < 0 && q.CoutP <= 128, "conv1x1_bf16_multi: channel sums for ONE destination of at most 128 channels per launch");
+      sum_dst = i;
+    }
     EGNE_REQUIRE(q.out && q.wfrag && ((uintptr_t)q.out & 15) == 0 && q.out_pix_stride % 8 == 0 && q.out_ch_off % 8 == 0 && q.out_ch_off + q.C <= q.out_pix_stride &&
                  q.out_pix_stride * 64 < (1ll << 31) && ((uintptr_t)q.wfrag & 15) == 0, "conv1x1_bf16_multi: destination %d", i);
     EGNE_REQUIRE(!q.residual || (((uintptr_t)q.residual & 15) == 0 && q.res_pix_stride % 8 == 0 && q.res_ch_off % 8 == 0 && q.res_pix_stride * 64 < (1ll << 31)),
@@ -436,14 +483,12 @@ extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, c
   }
   const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);
   const long long M = (long long)d.B * d.H * d.W;
-  long long gx = ((M + 31) / 32 + 3) / 4;
-  const long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1));
-  if (gx > cap) gx = cap;
+  const long long gx = multi_grid(d, nks, nbt);
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto kern) -> int {
     static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
     if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16_multi: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M, sum_dst);
     return egne::check_launch("egne_conv1x1_bf16_multi_fwd");
   };
   switch (nks) {
@@ -454,12 +499,10 @@ extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, c
   }
 }
 
-extern "C" int64_t egne_group_sums_floats(int B, int H, int W, int C) { return (((int64_t)B * H * W + 31) / 32) * C; }
-
-// out[c] (+)= sum over pixel groups of sums[group * ld + c], c < C (egne_dst.sums of a launch over npix pixels: ld = that destination's C);
-// total (optional): the same sums as doubles
-extern "C" int egne_group_sums_reduce(const float* sums, int64_t npix, int ld, int C, float* out, double* total, int accumulate, void* stream) {
-  EGNE_REQUIRE(sums && (out || total) && npix > 0 && C > 0 && ld >= C, "group_sums_reduce: bad arguments");
-  hipLaunchKernelGGL(group_sums_reduce_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, (long long)((npix + 31) / 32), ld, C, out, total, accumulate);
+// out[c] (+)= sum over rows of sums[row * ld + c], c < C (egne_dst.sums of a launch: nrows = egne_conv1x1_bf16_multi_waves, ld = that
+// destination's C); total (optional): the same sums as doubles
+extern "C" int egne_group_sums_reduce(const float* sums, int64_t nrows, int ld, int C, float* out, double* total, int accumulate, void* stream) {
+  EGNE_REQUIRE(sums && (out || total) && nrows > 0 && C > 0 && ld >= C, "group_sums_reduce: bad arguments");
+  hipLaunchKernelGGL(group_sums_reduce_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, (long long)nrows, ld, C, out, total, accumulate);
   return egne::check_launch("egne_group_sums_reduce");
 }

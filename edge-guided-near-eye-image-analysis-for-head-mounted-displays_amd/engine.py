@@ -1598,7 +1598,9 @@ class Plan:
         if cand is not None:
             ents = self._touched.get(id(dst.buf), [])
             last = max((i for i, e in enumerate(ents) if e[0] < dst.off + dst.Cp and e[1] > dst.off), default=-1)
-            if last == cand[0] and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY):
+            needs_sums = (layer.biases is not None and layer.biases[0] is not None) or id(layer) in self._pair_links
+            taken = any(q.sums for q in cand[1])              # a launch sums for ONE destination (<= 128 channels)
+            if last == cand[0] and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and (not needs_sums or (not taken and pad32(Cs) <= 128)):
                 masked = cand
         gy = self.gp(dst)
         ws = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(npix, Cs)) + 7) // 8, dtype=torch.float64)
@@ -1638,13 +1640,14 @@ class Plan:
         elif masked is not None:
             # mask and channel sums come out of the writer's epilogue; here only the sums' second stage (fixed order: deterministic).
             # A pair's 3x3 hands the totals to egne_pair_bias_bwd in the chunk-sum layout it reads (chunk 0 = the total, the rest stays zero)
-            _, arr, j = masked
+            _, arr, j, dm = masked
             if layer.act != ACT_NONE:
                 arr[j].mask_y, arr[j].mask_pix_stride, arr[j].mask_ch_off, arr[j].act = dst.ptr, dst.stride, dst.off, layer.act
             if dbias is not None or lead:
-                sums = bw.vec(int(L.egne_group_sums_floats(B, Ho, Wo, Cs)))
+                nrows = int(L.egne_conv1x1_bf16_multi_waves(C.byref(dm), len(arr), arr))
+                sums = bw.vec(nrows * Cs)
                 arr[j].sums = sums.data_ptr()
-                bw.raw(L.egne_group_sums_reduce, (sums.data_ptr(), npix, Cs, layer.Cout if dbias is not None else Cs, dbias,
+                bw.raw(L.egne_group_sums_reduce, (sums.data_ptr(), nrows, Cs, layer.Cout if dbias is not None else Cs, dbias,
                                                   ws.data_ptr() if lead else None, 1), name + ".bias_sums")
         elif self.bf16:
             bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
@@ -1807,7 +1810,7 @@ class Plan:
             q.wfrag = dl.b1frag.data_ptr()
             if not first:
                 q.residual, q.res_pix_stride, q.res_ch_off = tgt.ptr, tgt.stride, tgt.off
-            self._mask_cands[(id(pc.buf), pc.off, pc.Cp, pc.n0, B, H, W)] = (ent, arr, j)
+            self._mask_cands[(id(pc.buf), pc.off, pc.Cp, pc.n0, B, H, W)] = (ent, arr, j, dm)
             flops += 2.0 * B * H * W * pc.C * layer.Cout
         self.keep += [dm, arr]
         LAYER_BYTES[name + ".dgrad_multi"] = float(self.esz) * B * H * W * (Cs + sum(pieces[i].Cp * (1 if arr[j].residual is None else 2) for j, i in enumerate(best)))

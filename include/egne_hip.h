@@ -717,9 +717,9 @@ int egne_pack_conv1x1_bf16(const egne_conv_desc* d, const float* wflat, const in
 /* Several 1x1 convolutions over the SAME bf16 input slices in one launch (round 5): the per-member data gradients of a 1x1 over a
  * would-be torch.cat (models/RITnet_v2.py:59-61,85-86; replaces one egne_conv1x1_bf16_fwd per member, each re-reading gz).
  * A destination may be the LAST writer of its gradient slice: then it applies the activation mask of the layer whose output the
- * slice is the gradient of (mask_y, act: gz = g * act'(y), the pass egne_act_bwd_bias would make) and leaves per-pixel-group
- * channel sums of the stored values for that layer's bias gradient (sums: egne_group_sums_floats(B, H, W, C) floats, reduced by
- * egne_group_sums_reduce in a fixed order). */
+ * slice is the gradient of (mask_y, act: gz = g * act'(y), the pass egne_act_bwd_bias would make); ONE destination per launch (at most
+ * 128 channels) may also leave the channel sums of its stored values for that layer's bias gradient (sums: one row [C] per wave,
+ * egne_conv1x1_bf16_multi_waves rows, added by egne_group_sums_reduce in a fixed order). */
 #define EGNE_MAXDST 6
 typedef struct {
   void* out; int64_t out_pix_stride; int32_t out_ch_off;
@@ -729,12 +729,12 @@ typedef struct {
   const void* residual; int64_t res_pix_stride; int32_t res_ch_off;      /* optional accumulated tensor (bf16) */
   const void* mask_y; int64_t mask_pix_stride; int32_t mask_ch_off;      /* optional: activated output whose sign masks the result */
   int32_t act;                  /* egne_act of that layer */
-  float* sums;                  /* optional [pixel groups of 32][C] */
+  float* sums;                  /* optional [egne_conv1x1_bf16_multi_waves][C] */
 } egne_dst;
 int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* d, int ndst, const egne_dst* dsts);
 int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* d, int ndst, const egne_dst* dsts, void* stream);
-int64_t egne_group_sums_floats(int B, int H, int W, int C);
-int egne_group_sums_reduce(const float* sums, int64_t npix, int ld, int C, float* out /* [C], may be NULL */, double* total /* [C], may be NULL */,
+int64_t egne_conv1x1_bf16_multi_waves(const egne_conv_desc* d, int ndst, const egne_dst* dsts);   /* rows of egne_dst.sums the launch writes */
+int egne_group_sums_reduce(const float* sums, int64_t nrows, int ld, int C, float* out /* [C], may be NULL */, double* total /* [C], may be NULL */,
                            int accumulate, void* stream);
 int egne_conv1x1_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
