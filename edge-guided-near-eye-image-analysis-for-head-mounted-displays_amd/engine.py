@@ -86,6 +86,7 @@ HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
 # bf16-storage plans: the per-member data gradients of a 1x1 over a would-be torch.cat as ONE launch that reads gz once
 # (egne_conv1x1_bf16_multi_fwd), and -- where such a launch is the last writer of a gradient slice -- the activation mask and bias sums
 # of the layer that slice belongs to in its epilogue instead of a pass of their own (egne_act_bwd_bias)
+NORM_FUSE = os.environ.get("EGNE_NORM_FUSE", "1") != "0"         # ... and the InstanceNorm backward of a block's input / output inside that masking pass (egne_act_norm_bwd)
 MULTI_DGRAD = os.environ.get("EGNE_MULTI_DGRAD", "1") != "0"
 MASK_ON_WRITE = os.environ.get("EGNE_MASK_ON_WRITE", "1") != "0"
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
@@ -109,7 +110,7 @@ def _ptr(t, elem_off=0):
 class Piece:
     """A channel slice [off, off+Cp) of an NHWC fp32 buffer (optionally starting at sample n0)."""
 
-    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd", "presplit")
+    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd", "presplit", "norm_fuse")
 
     def __init__(self, buf, off, C_, Cp=None, n0=0):
         self.buf, self.off, self.C, self.Cp, self.n0 = buf, int(off), int(C_), int(Cp or pad8(C_)), int(n0)
@@ -117,6 +118,9 @@ class Piece:
         self.act_in = ACT_NONE
         self.nograd = False
         self.presplit = None    # a SplitScale: the slice is held in split-pair storage (egne_conv_desc.out_split), see Plan.conv
+        # training plans: the InstanceNorm backward of this tensor's normalised readers joins its gradient where its PRODUCING convolution
+        # masks it (egne_act_norm_bwd; set by the plan builder on tensors whose producer is a convolution of the plan, Plan._pending)
+        self.norm_fuse = False
         assert self.off % 4 == 0 and self.Cp % 8 == 0 and self.off + self.Cp <= buf.shape[-1]
 
     @property
@@ -130,7 +134,7 @@ class Piece:
 
     def with_norm(self, scale, shift, act_in=ACT_NONE):
         p = Piece(self.buf, self.off, self.C, self.Cp, self.n0)
-        p.scale, p.shift, p.act_in, p.nograd = scale, shift, act_in, self.nograd
+        p.scale, p.shift, p.act_in, p.nograd, p.norm_fuse = scale, shift, act_in, self.nograd, self.norm_fuse
         return p
 
     def samples(self, n0):
@@ -621,6 +625,7 @@ class Plan:
         # behind every run, the event that says the copy has landed
         self.ovf = self.ovf_host = self.ovf_event = None
         self.overflow_events = 0
+        self._pending = {}                             # (buffer id, first channel, first sample) -> normalisation-backward addends waiting for the tensor's producer (_bw_conv)
         self._mask_cands = {}                          # (buffer id, first channel, channels, samples) -> multi-destination launch that wrote the slice last (_bw_conv)
         self.f16_products = 0                          # egne_conv_desc.f16_products of the plan's split-f16 launches (1: plain f16 operands; BDCN.f16_products)
         self.tail_at, self.tail_hook = None, None      # backward plans: call index where every non-encoder parameter gradient is final, and what to call there (parallel.GradOverlap.tail_ready)
@@ -669,6 +674,23 @@ class Plan:
         zeroed before the backward pass, so the first writer may STORE instead of accumulate (no read of the slice)."""
         return FIRST_WRITER and self._touching and all(b <= off or a >= off + Cp for a, b, _ in self._touched.get(id(buf), ()))
 
+    def norm_fusable(self, piece):
+        """True if the InstanceNorm backward of ``piece``'s normalised readers is deferred to its producer's masking pass."""
+        return NORM_FUSE and self.bf16 and self.train and bool(getattr(piece, "norm_fuse", False))
+
+    def defer_norm_bwd(self, piece, scale, shift, B, H, W, a1=None, gq=None, act_q=ACT_NONE):
+        """Register an upstream gradient of IN(piece) (``a1``: full resolution; ``gq``: of the 2x2-pooled act_q(IN(piece))) for the fused
+        backward that ``piece``'s producing convolution emits (_bw_conv): every reader of one normalised tensor shares its
+        (scale, shift), and the normalisation's backward is linear in the upstream gradient."""
+        ent = self._pending.setdefault((id(piece.buf), piece.off, piece.n0), dict(scale=scale, shift=shift, B=B, H=H, W=W, a1=None, gq=None, act_q=ACT_NONE))
+        assert ent["scale"] is scale and ent["shift"] is shift and (ent["B"], ent["H"], ent["W"]) == (B, H, W), "readers of one normalised tensor share its statistics"
+        if a1 is not None:
+            assert ent["a1"] is None
+            ent["a1"] = a1
+        if gq is not None:
+            assert ent["gq"] is None
+            ent["gq"], ent["act_q"] = gq, act_q
+
     def build_backward(self):
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
         bw = Plan(self.device, dtype=self.dtype)
@@ -679,6 +701,7 @@ class Plan:
         for emit in reversed(self.tape):
             emit(bw)
         self._touching = False
+        assert not self._pending, "deferred normalisation gradients without a producer to take them: %s" % list(self._pending)
         # gradient twins that need no zero pass: every access is a full-batch store or touches only channels stored earlier
         self._zero_free = set()
         if ZERO_SKIP:
@@ -1594,7 +1617,8 @@ class Plan:
         # Was the last writer of this layer's output gradient a multi-destination 1x1 data gradient over the same pixels?  Then THAT
         # launch applies the activation mask and leaves the bias sums (egne_dst.mask_y / sums): no egne_act_bwd_bias pass here.
         masked = None
-        cand = self._mask_cands.get((id(dst.buf), dst.off, Cs, dst.n0, B, Ho, Wo)) if (MASK_ON_WRITE and self.bf16) else None
+        pend = self._pending.pop((id(dst.buf), dst.off, dst.n0), None) if self._pending else None
+        cand = self._mask_cands.get((id(dst.buf), dst.off, Cs, dst.n0, B, Ho, Wo)) if (MASK_ON_WRITE and self.bf16 and pend is None) else None
         if cand is not None:
             ents = self._touched.get(id(dst.buf), [])
             last = max((i for i, e in enumerate(ents) if e[0] < dst.off + dst.Cp and e[1] > dst.off), default=-1)
@@ -1635,7 +1659,18 @@ class Plan:
             how = "side" if (peer is not None and PAIR_BIAS_SIDE) else "main"
             seen = bw.__dict__.setdefault("_bias_writers", {})
             assert seen.setdefault(id(bias), how) == how, "%s: its bias Parameter is also written from the other stream of the backward plan" % name
-        if peer is not None and not lead:
+        if pend is not None:
+            # the InstanceNorm backward of this layer's output (its normalised readers left their upstream gradients in _pending) inside
+            # the masking pass: gz = act'(y) (g + IN-backward(a1 + act_q' up(gq) / 4)), bias sums as egne_act_bwd_bias leaves them
+            assert masked is None and not (peer is not None and not lead) and (pend["B"], pend["H"], pend["W"]) == (B, Ho, Wo), name
+            sums = bw.vec(B * Cs * 2)
+            wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, Ho * Wo, Cs, 1)) + 7) // 8, dtype=torch.float64)
+            a1, gq = pend["a1"], pend["gq"]
+            bw.raw(L.egne_act_norm_bwd, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, pend["scale"].data_ptr(), pend["shift"].data_ptr(),
+                                         a1.ptr if a1 is not None else None, a1.stride if a1 is not None else 0, a1.off if a1 is not None else 0,
+                                         gq.ptr if gq is not None else None, gq.stride if gq is not None else 0, gq.off if gq is not None else 0,
+                                         pend["act_q"], Cs, B, Ho, Wo, sums.data_ptr(), wsn.data_ptr(), dbias, layer.Cout, ws.data_ptr()), name + ".act_norm_bwd")
+        elif peer is not None and not lead:
             pass                                             # the pair's 1x1: no activation to mask, bias gradient already taken (below)
         elif masked is not None:
             # mask and channel sums come out of the writer's epilogue; here only the sums' second stage (fixed order: deterministic).
@@ -1752,6 +1787,12 @@ class Plan:
                 # the first writer of a gradient slice stores, later ones accumulate (the twin is zero before the backward pass)
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d" % i)
                 bw._dyn_hint = None
+            elif self.norm_fusable(pc) and pc.act_in == ACT_NONE and pc.scale.shape[0] == B:
+                # the data gradient w.r.t. IN(x) waits for x's producer (egne_act_norm_bwd): no normalisation-backward pass here
+                tmp = bw.buf(B, H, W, pc.Cp)
+                bw.conv(dl, [gin], Piece(tmp, 0, pc.C, pc.Cp), B, Ho, Wo, name=name + ".dgrad%d" % i)
+                bw._dyn_hint = None
+                self.defer_norm_bwd(pc, pc.scale, pc.shift, B, H, W, a1=Piece(tmp, 0, pc.C, pc.Cp))
             else:
                 tmp = bw.buf(B, H, W, pc.Cp)
                 bw.conv(dl, [gin], Piece(tmp, 0, pc.C, pc.Cp), B, Ho, Wo, name=name + ".dgrad%d" % i)

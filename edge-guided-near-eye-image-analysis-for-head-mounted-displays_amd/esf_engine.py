@@ -226,6 +226,15 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
         o, x, x1, x22 = slices(NB, h, w, [inters[i], ins[i], inters[i], inters[i]])
         return dict(out=o, x=x, x1=x1, x22=x22)
     D = [dbuf(i) for i in range(5)]
+    if training:
+        # blocks 0-3: `out` is produced by conv32 and read normalised by the pooled Transition_down only; the input x of blocks 1-3 is
+        # produced by the previous Transition_down's 1x1 and read normalised by conv1 and the pooled Transition_down: their InstanceNorm
+        # backward rides on the producer's masking pass (engine.Plan.defer_norm_bwd).  Block 0's x comes out of the head's BatchNorm and
+        # the bottleneck's Transition_down does not pool: the separate passes stay there.
+        for i in range(4):
+            D[i]["out"].norm_fuse = TD_POOL_FIRST_TRAIN and res[i][0] % 2 == 0 and res[i][1] % 2 == 0
+            if i >= 1:
+                D[i]["x"].norm_fuse = D[i]["out"].norm_fuse
 
     t0 = pl.buf(NB, H, W, pad8(chz))
     l1 = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
@@ -288,6 +297,9 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
                                                dstp.ptr, dstp.stride, dstp.off, NB, h, w, src.Cp), nm + ".TDpool")
                 if training:
                     def emit_pool(bw, src=src, dstp=dstp, a_=a_, b_=b_, h=h, w=w, nm=nm):
+                        if pl.norm_fusable(src):          # the producer of `src` takes it (egne_act_norm_bwd in its masking pass)
+                            pl.defer_norm_bwd(src, a_, b_, NB, h, w, gq=pl.gp(dstp), act_q=ACT_LEAKY)
+                            return
                         gq = pl.gp(dstp)
                         first = pl.first_touch(src.buf, src.off, src.Cp)       # the first writer of a gradient slice stores
                         gs_ = pl.gp(src)

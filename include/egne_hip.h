@@ -543,6 +543,22 @@ int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo
 int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag,
                        const float* gscale /* device, 1 float */, float* gpred, int gld, void* stream);
 
+/* Fused backward of a tensor x that was InstanceNorm-ed once (scale / shift per sample, egne_norm_stats) for up to two consumers
+ * (round 5; models/RITnet_v2.py:57: conv1 behind IN(x); :40-44: Transition_down behind avg_pool2d(leaky(IN(.)))): the
+ * normalisation's backward is linear in its upstream gradient G = a1 + act_q'(xh) up(gq) / 4 (a1: full-resolution addend, gq: the
+ * gradient of the 2x2-pooled tensor; either may be NULL), and its result joins the gradient of x where the layer that PRODUCED x
+ * masks it: g <- act'(x) (g + rstd (G - mean G - xh mean(G xh))) in place, with that layer's bias sums (dbias += ..., and the chunk
+ * sums in ws_bias as egne_act_bwd_bias leaves them for egne_pair_bias_bwd).  Replaces egne_norm_bwd + egne_norm_pool2_bwd +
+ * egne_act_bwd_bias: five passes over full-resolution tensors less.  B samples of H x W pixels (even for a pooled addend).
+ * sums: [B][Cp][2] floats (scratch); ws_norm: egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1); ws_bias:
+ * egne_act_bwd_bias_workspace_bytes(B*H*W, Cp). */
+int egne_act_norm_bwd(float* g, int64_t gs, int go, const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                      const float* a1, int64_t a1s, int a1o, const float* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                      float* sums, void* ws_norm, float* dbias /* may be NULL */, int C, void* ws_bias, void* stream);
+int egne_act_norm_bwd_bf16(void* g, int64_t gs, int go, const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                           const void* a1, int64_t a1s, int a1o, const void* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                           float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream);
+
 /* Weight gradient of the convolution described by `d` (same descriptor as the forward call):
  * gw[g][co][ci][kh][kw] += sum_pixels gz[pixel][co] * input[pixel + tap][ci], gz = gradient w.r.t. the
  * pre-activation output.  gw is a HOST array of ngroups device pointers (OIHW, torch layout).
