@@ -547,14 +547,18 @@ def test_windowed_fit_matches_the_direct_call_and_waits_for_its_window(bdcn):
     assert torch.equal(h3.result, want)
 
 
-def test_backward_only_supports_the_loss(edge_of):
+def test_backward_through_an_output_alone(edge_of):
+    """Round 4 refused gradients of anything but the returned loss; since round 5 the outputs carry them
+    (test_gradients_through_the_outputs_vs_oracle has the numbers): a backward pass through ``op`` alone runs and fills the arena."""
     from common import batch_args, esf_module
     b, edge = edge_of(B=2, seed=1234)
     m = esf_module("baseline_edge").to(DEV).train()
     args = [a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)]
     op = m(*args)[0]
-    with pytest.raises(NotImplementedError):
-        op.sum().backward()
+    op.sum().backward()
+    torch.cuda.synchronize()
+    g = m.dec.final.conv2.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
 
 
 # ---------------------------------------------------------------------------------------------
