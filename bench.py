@@ -47,7 +47,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (as egne_amd/__init__.py:
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"; the split kernel issues 3 MFMAs per product
-ROUND = "r04"
+ROUND = "r05"
 FP32_FAM = ("conv_igemm", "conv3x3_halo", "conv3x3_smallcin", "conv_wgrad", "conv3x3_narrow")     # exact-fp32 kernels (the last one on the vector ALU)
 
 
@@ -703,7 +703,7 @@ def main():
         # latest round that has them (profiles/rNN_pmc_traffic.json, same command, B = 64) and labelled as such
         for r in (r_split, r_fp32):
             r["traffic_source"] = "not measured in this run"
-        for rnd in (ROUND, "r02"):
+        for rnd in (ROUND, "r04", "r02"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
                     tr = json.load(f)["families"]

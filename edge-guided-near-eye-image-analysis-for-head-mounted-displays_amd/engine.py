@@ -691,6 +691,25 @@ class Plan:
             assert ent["gq"] is None
             ent["gq"], ent["act_q"] = gq, act_q
 
+    def flush_deferred_norm(self, bw, piece, name):
+        """A producer of ``piece`` that is not a convolution of the plan (the head's BatchNorm in front of block 0): the deferred
+        InstanceNorm backward of its normalised readers as a pass of its own, still ONE statistics + ONE apply pass for both readers
+        (egne_act_norm_bwd without mask and bias sums) -- called by that producer's backward emitter before it reads the gradient."""
+        pend = self._pending.pop((id(piece.buf), piece.off, piece.n0), None)
+        if pend is None:
+            return
+        L = self.L
+        B, H, W = pend["B"], pend["H"], pend["W"]
+        g = self.gp(Piece(piece.buf, piece.off, piece.C, piece.Cp, piece.n0))
+        sums = bw.vec(B * piece.Cp * 2)
+        wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, H * W, piece.Cp, 1)) + 7) // 8, dtype=torch.float64)
+        wsb = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(B * H * W, piece.Cp)) + 7) // 8, dtype=torch.float64)
+        a1, gq = pend["a1"], pend["gq"]
+        bw.raw(L.egne_act_norm_bwd, (g.ptr, g.stride, g.off, piece.ptr, piece.stride, piece.off, ACT_NONE, pend["scale"].data_ptr(), pend["shift"].data_ptr(),
+                                     a1.ptr if a1 is not None else None, a1.stride if a1 is not None else 0, a1.off if a1 is not None else 0,
+                                     gq.ptr if gq is not None else None, gq.stride if gq is not None else 0, gq.off if gq is not None else 0,
+                                     pend["act_q"], piece.Cp, B, H, W, sums.data_ptr(), wsn.data_ptr(), None, 0, wsb.data_ptr()), name + ".norm_bwd_fused")
+
     def build_backward(self):
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
         bw = Plan(self.device, dtype=self.dtype)

@@ -133,6 +133,7 @@ def _train_bn(pl, bn, pre, dst, n0, B, HW, name):
     if pl.train:
         def emit(bw):
             L = pl.L
+            pl.flush_deferred_norm(bw, Piece(dst.buf, dst.off, dst.C, dst.Cp, 0), name)      # (block 0's input: its readers' InstanceNorm backward first)
             gq, gpre = pl.gp(q), pl.gp(p)
             sums = bw.vec(pre.Cp * 2)
             ws = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, HW, pre.Cp, 0)) + 7) // 8, dtype=torch.float64)
@@ -229,12 +230,11 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     if training:
         # blocks 0-3: `out` is produced by conv32 and read normalised by the pooled Transition_down only; the input x of blocks 1-3 is
         # produced by the previous Transition_down's 1x1 and read normalised by conv1 and the pooled Transition_down: their InstanceNorm
-        # backward rides on the producer's masking pass (engine.Plan.defer_norm_bwd).  Block 0's x comes out of the head's BatchNorm and
-        # the bottleneck's Transition_down does not pool: the separate passes stay there.
+        # backward rides on the producer's masking pass (engine.Plan.defer_norm_bwd).  Block 0's x comes out of the head's BatchNorm: its
+        # deferred backward is one fused pass in front of the BatchNorm's; the bottleneck's Transition_down does not pool: separate passes.
         for i in range(4):
             D[i]["out"].norm_fuse = TD_POOL_FIRST_TRAIN and res[i][0] % 2 == 0 and res[i][1] % 2 == 0
-            if i >= 1:
-                D[i]["x"].norm_fuse = D[i]["out"].norm_fuse
+            D[i]["x"].norm_fuse = D[i]["out"].norm_fuse       # (block 0: flushed by the head BatchNorm's backward, Plan.flush_deferred_norm)
 
     t0 = pl.buf(NB, H, W, pad8(chz))
     l1 = _cl(enc.head.conv1, [(in_c, 8)], pad=(1, 1), act=ACT_LEAKY)
