@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   unsigned okmask = 0;
   int st_c = 0;
   int ky_n = 0, kx_n = 0;   // tap coordinates of the step being loaded (no per-step division)
+  // egne_conv_desc.f16_products == 1 (wave-uniform): plain f16 operands -- no lo halves loaded, derived, stored or multiplied (the frame
+  // tails of the deep trunk layers of the edge network next to a bf16-storage training plan)
+  const bool np1 = p.f16_products == 1;
   auto load_step = [&](int g, int tap, int c0) {
     const int dil = p.dil[g];
     const int tapoff = (((ky_n - p.pad_h) * p.W + (kx_n - p.pad_w)) * dil * (int)sg.pix_stride + c0) * 4;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(rwh, boff[j], wstep, 0);
-      rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(rwl, boff[j], wstep, 0);
+      if (!np1) rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(rwl, boff[j], wstep, 0);
     }
   };
   const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
       const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
       const int o = (rbase + 32 * i) * LDH + col4 * 4;
       *(h4*)&Ahi[o] = hi;
-      *(h4*)&Alo[o] = lo;
+      if (!np1) *(h4*)&Alo[o] = lo;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
       if (BN * 4 % 256 == 0 || (item >> 2) < BN) {
         const int o = (item >> 2) * LDH + (item & 3) * 8;
         *(u32x4*)&Bhi[o] = rbh[j];
-        *(u32x4*)&Blo[o] = rbl[j];
+        if (!np1) *(u32x4*)&Blo[o] = rbl[j];
       }
     }
   };
@@ -227,19 +230,21 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         ah[t] = *(const h8*)&Ahi[arow + t * 32 * LDH + ks * 16];
-        al[t] = *(const h8*)&Alo[arow + t * 32 * LDH + ks * 16];
+        if (!np1) al[t] = *(const h8*)&Alo[arow + t * 32 * LDH + ks * 16];
       }
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         bh[t] = *(const h8*)&Bhi[brow + t * 32 * LDH + ks * 16];
-        bl[t] = *(const h8*)&Blo[brow + t * 32 * LDH + ks * 16];
+        if (!np1) bl[t] = *(const h8*)&Blo[brow + t * 32 * LDH + ks * 16];
       }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          if (!np1) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          }
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
         }
     }
