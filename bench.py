@@ -114,7 +114,23 @@ def _cpu_model():
     return platform.processor() or platform.machine()
 
 
-def _timeit(fn, budget_s, warm=2, lo=2, hi=5):
+def _sources_sha16():
+    """Fingerprint of what decides kernel times and HBM traffic: the HIP sources, the C-ABI header and the plan builders.  The PMC
+    traffic files under profiles/ carry the fingerprint of the tree they were measured on; the bench line says whether it still
+    matches (`roofline.traffic_sources_match`): a copied traffic figure from an older build is labelled as such."""
+    import glob
+    import hashlib
+    pkg = os.path.join(ROOT, "edge-guided-near-eye-image-analysis-for-head-mounted-displays_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "egne_hip.h")] + [os.path.join(pkg, f) for f in ("engine.py", "esf_engine.py", "bdcn_new.py")])
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _timeit(fn, budget_s, warm=2, lo=5, hi=5):
     """``warm`` untimed calls, then between ``lo`` and ``hi`` timed ones -- as many as fit ``budget_s`` judging by the last warm-up.
     Returns (median, min, timed calls, warm-ups) in seconds."""
     last = None
@@ -178,7 +194,7 @@ def cpu_baseline(setting, bd_sd, net_sd, batches=(2, 8), budget_s=7.0, parity=No
     torch.set_num_threads(threads if threads > 0 else min(ncores, 16))
     out = {"kind": "port", "unit": "eye-frames/s", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(),
            "affinity_cores": ncores, "cpu_model": _cpu_model(), "torch_threads": torch.get_num_threads(),
-           "protocol": "BASELINE.md section 3: 2 warm-ups, 2-5 timed iterations per part (~%.0f s budget each), median and min" % budget_s,
+           "protocol": "BASELINE.md section 3: 2 warm-ups (1 for the training part), 5 timed iterations per part, median and min",
            "parts": {}}
     t_all = time.perf_counter()
     for B in batches:
@@ -706,7 +722,10 @@ def main():
         for rnd in (ROUND, "r04", "r02"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
-                    tr = json.load(f)["families"]
+                    trj = json.load(f)
+                    tr = trj["families"]
+                for r in (r_split, r_fp32):
+                    r["traffic_sources_match"] = trj.get("sources_sha16") == _sources_sha16()
                 if B == 64:
                     r_split["traffic"] = tr["split_f16"]["hbm_bytes_per_launch"]
                     r_fp32["traffic"] = tr["fp32_conv"]["hbm_bytes_per_launch"]
@@ -795,7 +814,10 @@ def main():
         if rbf and storage == "bf16" and B == 256 and a.config == "baseline_edge" and a.chz == 32:
             try:        # HBM bytes per launch of the bf16 family from the committed PMC passes of the same command (not measured in this run)
                 with open(os.path.join(ROOT, "profiles", ROUND + "_pmc_traffic_train_b256.json")) as f:
-                    rbf["traffic"] = json.load(f)["families"]["bf16_conv"]["hbm_bytes_per_launch"]
+                    trj = json.load(f)
+                    rbf["traffic"] = trj["families"]["bf16_conv"]["hbm_bytes_per_launch"]
+                    rbf["traffic_sources_match"] = trj.get("sources_sha16") == _sources_sha16()
+                    rbf["step_hbm_gb"] = round(sum(v["hbm_read_gb_per_step"] + v["hbm_write_gb_per_step"] for v in trj["families"].values()), 1)
                 rbf["traffic_source"] = ("copied from profiles/%s_pmc_traffic_train_b256.json (rocprofv3 --pmc passes over `bench.py --mode train --train-batch 256 "
                                          "--train-storage bf16 --no-pipeline`, FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run" % ROUND)
             except Exception:
@@ -818,7 +840,7 @@ def main():
                     "forward + backward + gradient all-reduce + Adam, batch=%d/GPU, fp32 storage and accumulation (3x3 forward convs, data and "
                     "weight gradients on split-f16 products, 1x1 exact fp32; EGNE_TRAIN_SPLIT=0 for all-fp32)" % (which, a.config, a.chz, B))
             dty = "f32 storage; 3x3 products split into f16 hi/lo pairs (22-bit significand), f32 accumulate; 1x1 exact f32 MFMA"
-        keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches_per_step", "avg_launch_ms",
+        keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_sources_match", "step_hbm_gb", "launches_per_step", "avg_launch_ms",
                 "algorithmic_gflop_per_frame", "time_share", "region_ms_per_step", "measured_in", "by_kernel", "algorithmic_gb_per_frame", "tflops")
         tr = {"value": round(B * steps * world / dt, 2), "unit": "eye-frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
               "warmup": warm, "frames_per_gpu_per_step": B, "dtype": dty, "storage": storage,
