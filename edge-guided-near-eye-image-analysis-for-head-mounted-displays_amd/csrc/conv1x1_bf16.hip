@@ -156,7 +156,7 @@ struct DstTab {
 
 template <int NKS>
 __global__ __launch_bounds__(256)
-void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M, int sum_dst) {
+void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M, int sum_dst, int nks) {
   constexpr int LDP = 64 + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   egne_bf16* const lw = (egne_bf16*)smem;                               // [NKS][nbt][64 lanes][8]
@@ -165,7 +165,7 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
   const int l15 = lane & 15, kg = lane >> 4;
   for (int d = 0; d < ndst; ++d) {
     const int nb = dt.nb16[d];
-    for (int it = tid; it < NKS * nb * 64; it += 256) {
+    for (int it = tid; it < nks * nb * 64; it += 256) {
       const int l = it & 63, r = it >> 6, j = r % nb, ks = r / nb;
       *(u32x4*)&lw[((long long)(ks * nbt + dt.wofs[d] + j) * 64 + l) * 8] = *(const u32x4*)(dt.wfrag[d] + (((long long)ks * nb + j) * 64 + l) * 8);
     }
@@ -182,8 +182,9 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
     u32x4 xb[NKS][2];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      const egne_seg& sg = p.seg[tab.seg[ks]];
-      const int c = tab.c0[ks] + 8 * kg;
+      const bool on = ks < nks;                                   // (NKS = 6 / 8 also serve 5 / 7 k-steps)
+      const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
+      const int c = on ? tab.c0[ks] + 8 * kg : 1 << 20;
       const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + m0 * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
@@ -204,6 +205,7 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
         for (int a = 0; a < 8; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
+          if (ks >= nks) break;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (j < nbq) {
@@ -417,11 +419,11 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
 // Several 1x1 convolutions over the SAME input slices in one launch, each with its own weights (fragments of egne_pack_conv1x1_bf16 for a
 // descriptor with that destination's CoutP) and destination slice: the per-member data gradients of a 1x1 over a would-be torch.cat.
 // d: input slices (seg[]), B, H, W, Ktot; its output fields are ignored.  Returns EGNE_ERR_ARG if the shapes do not fit (the caller
-// falls back to one egne_conv1x1_bf16_fwd per destination): more than 4 k-steps, or more weight fragments than fit LDS.
+// falls back to one egne_conv1x1_bf16_fwd per destination): more than 8 k-steps, or more weight fragments than fit LDS.
 extern "C" int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* dp, int ndst, const egne_dst* dsts) {
   if (!dp || !dsts || ndst < 1 || ndst > EGNE_MAXDST) return 0;
   KTab tab; int nks = 0;
-  if (!make_tab(*dp, &tab, &nks) || nks > 4) return 0;
+  if (!make_tab(*dp, &tab, &nks) || nks > 8) return 0;
   int nbt = 0;
   for (int i = 0; i < ndst; ++i) {
     if (dsts[i].CoutP % 32 || dsts[i].C % 8 || dsts[i].C > dsts[i].CoutP) return 0;
@@ -488,14 +490,16 @@ extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, c
   auto go = [&](auto kern) -> int {
     static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
     if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16_multi: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M, sum_dst);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M, sum_dst, nks);
     return egne::check_launch("egne_conv1x1_bf16_multi_fwd");
   };
   switch (nks) {
     case 1: return go(conv1x1_bf16_multi_kernel<1>);
     case 2: return go(conv1x1_bf16_multi_kernel<2>);
     case 3: return go(conv1x1_bf16_multi_kernel<3>);
-    default: return go(conv1x1_bf16_multi_kernel<4>);
+    case 4: return go(conv1x1_bf16_multi_kernel<4>);
+    case 5: case 6: return go(conv1x1_bf16_multi_kernel<6>);
+    default: return go(conv1x1_bf16_multi_kernel<8>);
   }
 }
 
