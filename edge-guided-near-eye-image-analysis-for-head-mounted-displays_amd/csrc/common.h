@@ -81,7 +81,13 @@ template <typename T> __device__ __forceinline__ const T* zero_page() { return (
 // zero included).  So a kernel whose lanes hold pixels tests ONE channel per pixel, and a kernel whose lanes hold channels and
 // whose registers walk the pixels of an image row tests the rows y % 3 == 1 and the last row of a 3x3 / dilation-1 convolution
 // (any three consecutive rows, clipped to the image, contain one of them) -- egne_ovf_row.
+#ifdef EGNE_NO_OVF_CHECK      // (A/B builds only: what the tests cost, scratch/ab_ovf.sh)
+__device__ __forceinline__ bool egne_nonfinite(float) { return false; }
+__device__ __forceinline__ bool egne_nonfinite64(double) { return false; }
+#else
 __device__ __forceinline__ bool egne_nonfinite(float v) { return __builtin_amdgcn_classf(v, 0x207); }
+__device__ __forceinline__ bool egne_nonfinite64(double v) { return !__builtin_isfinite(v); }
+#endif
 __device__ __forceinline__ bool egne_ovf_row(int y, int H) { return y % 3 == 1 || y == H - 1; }
 __device__ __forceinline__ void egne_ovf_commit(bool bad, unsigned* flag) {
   if (flag && bad) atomicOr(flag, 1u);

@@ -288,7 +288,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           make_rsrc(p.residual ? p.residual + (long long)cur.b * p.H * p.W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
       const int xl = cur.px + S * (cur.x0 + 4 * lh);
       const int cmax = xl < vW ? (vW - xl + S - 1) / S : 0;      // c_r < cmax  <=>  x < W
-      bool bad = false;       // a non-finite value stored by this tile (egne_conv_desc.ovf_flag)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
         const int n = (nt0 + tn) * 32 + li;
@@ -302,7 +301,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
           const int cm = (nok && y < vH) ? cmax : 0;
-          const bool chk = LAT || D != 1 || egne_ovf_row(y, vH);       // (wave-uniform; common.h: which rows the overflow test needs)
           const int pix = y * rstep + xl * cstep;
           const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
           float rv[16];
@@ -321,7 +319,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             const int c = (r & 3) + 8 * (r >> 2);
             float v = acc[tm][tn][r] * out_scale + bv;
             v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
-            if (tn == 0 && chk) bad |= egne_nonfinite(v);       // (one 32-channel block per wave: every channel of a contaminated pixel is contaminated)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
             const double vm = c < cm ? (double)v : 0.;
             st_s += vm; st_q += vm * vm;
@@ -352,6 +349,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             }
           }
         }
+        // (egne_conv_desc.ovf_flag is NOT tested here: this kernel sits at its register limit -- any form of the test, per value, per
+        //  selected row or once per tile on the fp64 sum of squares, added 50+ spill instructions and 4-6 % to its launches.  A value
+        //  it stores non-finite is caught one launch later: every tensor this kernel writes in the two networks is read raw by a
+        //  kernel that does test -- the trunk / MSBlock / dense-block convolution behind it -- or enters InstanceNorm statistics,
+        //  which turn the whole tensor NaN for those; engine.Plan.overflowed reads the word after the run either way.)
         if (!LAT && NW == 1 && p.stats_ws) {     // one chunk = this wave's rows of this tile (fixed order: deterministic; TP: tiles of the transposed walk)
           st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
           if (lh == 0 && n < p.Cout_store) {
@@ -361,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           }
         }
       }
-      egne_ovf_commit(bad, p.ovf_flag);
     }
     t = tnext;
     if (t >= ntiles) break;

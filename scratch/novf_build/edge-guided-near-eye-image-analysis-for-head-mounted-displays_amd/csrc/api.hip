@@ -15,6 +15,7 @@ extern "C" int egne_sizeof(int which) {
     case 0: return (int)sizeof(egne_conv_desc);
     case 1: return (int)sizeof(egne_loss_desc);
     case 2: return (int)sizeof(egne_bdcn_tail_desc);
+    case 3: return (int)sizeof(egne_dst);
     default: return -1;
   }
 }

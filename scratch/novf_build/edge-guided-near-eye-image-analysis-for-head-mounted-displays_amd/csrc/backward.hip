@@ -255,6 +255,156 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const T* __restrict__ x,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused form (round 5).  A down block's input x (and its output `out`) is normalised ONCE (scale / shift per sample) and consumed by two
+// readers: conv1 behind IN(x) (models/RITnet_v2.py:57) and Transition_down behind avg_pool(leaky(IN(.))) (:40-44).  The InstanceNorm
+// backward is linear in its upstream gradient, so both go through ONE backward with
+//   G = a1 + leaky'(xh) * up(gq) / 4        (a1: conv1's data gradient, full resolution; gq: the pooled cell's gradient)
+//   gx = rstd * (G - mean(G) - xh * mean(G xh)),
+// and gx is not accumulated into the gradient tensor by a pass of its own: it is added where the tensor's producing layer masks its
+// output gradient anyway (egne_act_norm_bwd: gz = act'(y) * (g + gx), y = x, + that layer's bias sums) -- the pass egne_act_bwd_bias
+// makes.  Before: two statistics passes + two apply passes (each a read-modify-write of the gradient) + the masking pass.
+template <typename T>
+struct NormAddends {
+  const T* a1; long long a1s; int a1o;       // full-resolution addend (may be null)
+  const T* gq; long long gqs; int gqo;       // pooled addend (may be null): [n][H/2][W/2], poolW = W of the full-resolution map
+  int poolW, act_q;                          // activation between the normalisation and the pooling (LeakyReLU of Transition_down)
+};
+
+template <typename T, int N>
+__device__ __forceinline__ egne_fv<N> norm_addend_G(const NormAddends<T>& A, const egne_fv<N>& xh, long long nb, unsigned q, int c, bool ok) {
+  egne_fv<N> G = fv_fill<N>(0.f);
+  if (A.a1 && ok) G = ldv(A.a1 + (nb + q) * A.a1s + A.a1o + c);
+  if (A.gq && ok) {
+    const unsigned py = q / (unsigned)A.poolW, px = q - py * (unsigned)A.poolW;
+    const egne_fv<N> g = ldv(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float ge = 0.25f * g.v[e];
+      if (A.act_q == EGNE_ACT_LEAKY) ge = xh.v[e] > 0.f ? ge : 0.01f * ge;
+      else if (A.act_q == EGNE_ACT_RELU) ge = xh.v[e] > 0.f ? ge : 0.f;
+      G.v[e] += ge;
+    }
+  }
+  return G;
+}
+
+// sums of G and G xh per (n, chunk, c): the layout of norm_bwd_partial (finished by norm_bwd_final)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_fuse_partial(const T* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, NormAddends<T> A, int Cp, long long npix_per_n,
+                                                         int nchunk, double* __restrict__ ws) {
+  constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
+  const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
+  const int v = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int c = cg * 32 + v * N;
+  const long long per = (npix_per_n + nchunk - 1) / nchunk;
+  const long long p0 = (long long)chunk * per, p1 = p0 + per < npix_per_n ? p0 + per : npix_per_n;
+  double s1[N], s2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { s1[e] = 0; s2[e] = 0; }
+  if (c < Cp) {
+    const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
+    const long long nb = (long long)n * npix_per_n;
+    for (long long p = p0 + row; p < p1; p += 2 * ROWS) {        // two rows per trip: their loads are issued together
+      egne_fv<N> xh[2], G[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long long q = p + ROWS * u;
+        const bool ok = q < p1;
+        const egne_fv<N> xv = ok ? ldv(x + (nb + q) * xs + xo + c) : fv_fill<N>(0.f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) xh[u].v[e] = xv.v[e] * sc.v[e] + sh.v[e];
+        G[u] = norm_addend_G<T, N>(A, xh[u], nb, (unsigned)q, c, ok);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < N; ++e) { s1[e] += G[u].v[e]; s2[e] += (double)G[u].v[e] * xh[u].v[e]; }
+    }
+  }
+  __shared__ double sh_[ROWS][32][2];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { sh_[row][v * N + e][0] = s1[e]; sh_[row][v * N + e][1] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc_ = threadIdx.x >> 1, w_ = threadIdx.x & 1;
+    double a = 0;
+    for (int r = 0; r < ROWS; ++r) a += sh_[r][cc_][w_];
+    const int cc = cg * 32 + cc_;
+    if (cc < Cp) ws[(((long long)n * nchunk + chunk) * Cp + cc) * 2 + w_] = a;
+  }
+}
+
+// gz = act'(y) * (g + rstd * (G - m1 - xh m2)) in place + bias partial sums in the layout of act_bwd_bias_partial (chunks over the
+// flattened (n, pixel) index); y = x: the tensor the gradient belongs to is the one that was normalised
+template <typename T>
+__global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, long long gs, int go, const T* __restrict__ y, long long ys, int yo,
+                                                            int act, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ sums, NormAddends<T> A, int Cp, unsigned HW,
+                                                            long long npix, int nchunk, double* __restrict__ ws) {
+  constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
+  const int chunk = blockIdx.x, cg = blockIdx.y;
+  const int v = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int c = cg * 32 + v * N;
+  const long long per = (npix + nchunk - 1) / nchunk;
+  const long long p0 = (long long)chunk * per, p1 = p0 + per < npix ? p0 + per : npix;
+  const float invN = 1.f / (float)HW;
+  double s[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s[e] = 0;
+  if (c < Cp) {
+    for (long long p = p0 + row; p < p1; p += 2 * ROWS) {
+      egne_fv<N> t[2], yy[2], G[2], sc[2], m1[2], m2[2];
+      bool okk[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long long q = p + ROWS * u;
+        const bool ok = okk[u] = q < p1;
+        const unsigned n = ok ? (unsigned)((unsigned long long)q / HW) : 0u;        // (npix < 2^32: checked by the entry point)
+        const unsigned qq = (unsigned)(q - (long long)n * HW);
+        t[u] = ok ? ldv(g + q * gs + go + c) : fv_fill<N>(0.f);
+        yy[u] = ok ? ldv(y + q * ys + yo + c) : fv_fill<N>(0.f);
+        sc[u] = ldf<N>(scale + (long long)n * Cp + c);
+        const egne_fv<N> shv = ldf<N>(shift + (long long)n * Cp + c);
+        egne_fv<N> xh;
+#pragma unroll
+        for (int e = 0; e < N; ++e) xh.v[e] = yy[u].v[e] * sc[u].v[e] + shv.v[e];
+        G[u] = norm_addend_G<T, N>(A, xh, (long long)n * HW, qq, c, ok);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float a = sums[2 * ((long long)n * Cp + c + e)] * invN, b = sums[2 * ((long long)n * Cp + c + e) + 1] * invN;
+          G[u].v[e] = sc[u].v[e] * (G[u].v[e] - a - xh.v[e] * b);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long long q = p + ROWS * u;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          float r = t[u].v[e] + G[u].v[e];
+          if (act == EGNE_ACT_LEAKY) r = yy[u].v[e] > 0.f ? r : 0.01f * r;
+          else if (act == EGNE_ACT_RELU) r = yy[u].v[e] > 0.f ? r : 0.f;
+          t[u].v[e] = okk[u] ? r : 0.f;
+        }
+        if (okk[u]) stv(g + q * gs + go + c, t[u]);
+#pragma unroll
+        for (int e = 0; e < N; ++e) s[e] += t[u].v[e];
+      }
+    }
+  }
+  __shared__ double sh[ROWS][32];
+#pragma unroll
+  for (int e = 0; e < N; ++e) sh[row][v * N + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double a = 0;
+    for (int r = 0; r < ROWS; ++r) a += sh[r][threadIdx.x];
+    const int cc = cg * 32 + threadIdx.x;
+    if (cc < Cp) ws[(long long)chunk * Cp + cc] = a;
+  }
+}
+
 // one block per (32 channels, n), 32 partial-sum streams per channel, fixed combination order (see norm_stats_final)
 __global__ __launch_bounds__(1024) void norm_bwd_final(const double* __restrict__ ws, int Cp, int Bn, int nchunk, float* __restrict__ sums,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
@@ -1288,6 +1438,44 @@ extern "C" int egne_norm_pool2_bwd_bf16(const void* x, int64_t xs, int xo, const
   EGNE_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "norm_pool2_bwd: even map sizes only (got %dx%d)", H, W);
   return norm_bwd_impl((const egne_bf16*)x, xs, xo, scale, shift, (const float*)nullptr, (const egne_bf16*)gzp, gs, go, act_in, Cp, B,
                        H * W, 1, (egne_bf16*)gx, gxs, gxo, sums, (float*)nullptr, (float*)nullptr, 0, ws, stream, W, accumulate);
+}
+
+// Fused backward of a tensor that was InstanceNorm-ed once for up to two consumers (see norm_fuse_partial): statistics of
+// G = a1 + act_q'(xh) up(gq) / 4, then gz = act'(x) (g + rstd (G - mean G - xh mean(G xh))) in place over g, + the bias sums of the
+// layer whose output x is (dbias += sums, or the chunk sums in ws_bias for egne_pair_bias_bwd).  B samples of H x W pixels.
+// ws_norm: egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1); sums: [B][Cp][2] floats; ws_bias: egne_act_bwd_bias_workspace_bytes(B*H*W, Cp).
+template <typename T>
+static int act_norm_bwd_impl(T* g, int64_t gs, int go, const T* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                             const T* a1, int64_t a1s, int a1o, const T* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                             float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
+  EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && slice_ok(x, xs, xo, Cp) && scale && shift && sums && ws_norm && ws_bias && (a1 || gq), "act_norm_bwd: bad arguments");
+  EGNE_REQUIRE(vec_ok<T>(gs, go, Cp) && vec_ok<T>(xs, xo, Cp) && (!a1 || vec_ok<T>(a1s, a1o, Cp)) && (!gq || vec_ok<T>(gqs, gqo, Cp)),
+               "act_norm_bwd: slices must be 16-byte vectors (8 bf16 channels)");
+  EGNE_REQUIRE(B > 0 && H > 0 && W > 0 && (!gq || (H % 2 == 0 && W % 2 == 0)) && (long long)B * H * W < (1ll << 32) && B <= 65535 &&
+               ((uintptr_t)ws_norm & 15) == 0, "act_norm_bwd: shape (even maps for a pooled addend)");
+  const long long HW = (long long)H * W, npix = (long long)B * HW;
+  NormAddends<T> A{a1, (long long)a1s, a1o, gq, (long long)gqs, gqo, W, act_q};
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = chunks_for(HW, Cp, B);
+  hipLaunchKernelGGL(norm_fuse_partial<T>, dim3(nchunk, (Cp + 31) / 32, B), dim3(256), 0, st, x, (long long)xs, xo, scale, shift, A, Cp, HW, nchunk, (double*)ws_norm);
+  hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, B), dim3(1024), 0, st, (const double*)ws_norm, Cp, B, nchunk, sums,
+                     (float*)nullptr, (float*)nullptr, 0);
+  const int nchb = chunks_for(npix, Cp, 1);
+  hipLaunchKernelGGL(act_norm_bwd_partial<T>, dim3(nchb, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, x, (long long)xs, xo, act, scale, shift,
+                     (const float*)sums, A, Cp, (unsigned)HW, npix, nchb, (double*)ws_bias);
+  if (dbias) hipLaunchKernelGGL(reduce_chunks_k, dim3((C + 31) / 32), dim3(1024), 0, st, (const double*)ws_bias, Cp, C, nchb, dbias, 1);
+  return egne::check_launch("egne_act_norm_bwd");
+}
+extern "C" int egne_act_norm_bwd(float* g, int64_t gs, int go, const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                                 const float* a1, int64_t a1s, int a1o, const float* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                                 float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
+  return act_norm_bwd_impl(g, gs, go, x, xs, xo, act, scale, shift, a1, a1s, a1o, gq, gqs, gqo, act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream);
+}
+extern "C" int egne_act_norm_bwd_bf16(void* g, int64_t gs, int go, const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                                      const void* a1, int64_t a1s, int a1o, const void* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                                      float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
+  return act_norm_bwd_impl((egne_bf16*)g, gs, go, (const egne_bf16*)x, xs, xo, act, scale, shift, (const egne_bf16*)a1, a1s, a1o, (const egne_bf16*)gq, gqs, gqo,
+                           act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream);
 }
 
 template <typename T>

@@ -69,6 +69,28 @@ template <int N> __device__ __forceinline__ egne_fv<N> fv_fill(float x) {
 // the all-zero page typed for either storage (invalid lanes load from it unconditionally)
 template <typename T> __device__ __forceinline__ const T* zero_page() { return (const T*)egne_zero_page; }
 
+// ---- f16 overflow of the split operands (round 5) ---------------------------------------------------------------------
+// The split-f16 kernels scale an fp32 operand by a power of two calibrated on an earlier batch (engine.Plan: 32x of head-room)
+// before they round it to f16.  A later batch whose raw activations exceed that head-room turns operands into +-inf, and every
+// accumulator such an operand reaches becomes +-inf or NaN (inf * w, inf * 0, inf - inf): a NON-FINITE accumulator in an epilogue
+// is the one reliable trace of it (activations and pools downstream can swallow it again).  Epilogues OR a per-lane test of what
+// they store (v_cmp_class_f32: sNaN | qNaN | -inf | +inf, one vector instruction per value) and set the sticky device word
+// egne_conv_desc.ovf_flag, which engine.Plan reads back behind every run (Plan.check_overflow: recalibrate and run again).
+// What has to be tested (measured: testing every stored value cost 1.7 % of the B=64 inference step): an f16 operand that became
+// inf contaminates EVERY output channel of EVERY output pixel whose receptive field holds it (inf * w is inf or NaN for any w,
+// zero included).  So a kernel whose lanes hold pixels tests ONE channel per pixel, and a kernel whose lanes hold channels and
+// whose registers walk the pixels of an image row tests the rows y % 3 == 1 and the last row of a 3x3 / dilation-1 convolution
+// (any three consecutive rows, clipped to the image, contain one of them) -- egne_ovf_row.
+#ifdef EGNE_NO_OVF_CHECK      // (A/B builds only: what the tests cost, scratch/ab_ovf.sh)
+__device__ __forceinline__ bool egne_nonfinite(float) { return false; }
+#else
+__device__ __forceinline__ bool egne_nonfinite(float v) { return __builtin_amdgcn_classf(v, 0x207); }
+#endif
+__device__ __forceinline__ bool egne_ovf_row(int y, int H) { return y % 3 == 1 || y == H - 1; }
+__device__ __forceinline__ void egne_ovf_commit(bool bad, unsigned* flag) {
+  if (flag && bad) atomicOr(flag, 1u);
+}
+
 namespace egne {
 
 char* err_buf();  // thread-local 512-byte buffer (defined in api.hip)

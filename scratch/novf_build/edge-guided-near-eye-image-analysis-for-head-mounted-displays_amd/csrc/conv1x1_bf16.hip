@@ -1,0 +1,512 @@
+// 1x1 convolution over up to EGNE_MAXSEG raw bf16 slices on v_mfma_f32_16x16x32_bf16 (fp32 accumulate, bf16 output): the concat-free
+// 1x1 convolutions of ESF-Net (models/RITnet_v2.py:59-61 conv21 / conv31, :38-41 Transition_down behind its pooling, :85-86
+// conv11 / conv21 of the up blocks) and their merged data gradients in training plans with bf16 activation storage.
+//
+// Streaming form: the tensor IS the MFMA operand.  With the product transposed (weights as the A operand) a lane's B operand of a
+// 32-channel k-step is "8 consecutive channels of one pixel" = ONE 16-byte global load, the four k-groups of a pixel are four
+// neighbouring lanes -- 64 contiguous bytes per pixel and instruction, which is all a 32-channel slice has --, so activations never
+// touch LDS or the vector ALU on the way in; the weights of the workgroup's output channels stay in LDS for the whole launch.
+// What the first version got wrong (measured: 1.8 TB/s on the merged data gradients, behind the exact-fp32 implicit GEMM): it stored
+// each lane's 4 result channels as they come out of the MFMA -- 16 contiguous bytes per pixel and instruction, and the same for the
+// accumulated residual.  The memory pipeline works per cache line touched, not per byte: here a wave's 32 x CW result tile goes
+// through LDS once (fp32) and leaves as 16-byte vectors of 8 channels with the lanes of a pixel side by side: whole 128-byte lines
+// per pixel for 64 output channels, residual read the same way.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned OOB = 0x80000000u;
+constexpr int KC = 4;              // k-steps (of 32 channels) requested together: 2 x 4 loads of 16 bytes per lane in flight
+constexpr int MAXKS = 48;          // k-steps of a launch (table in the kernel arguments)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// per k-step: slice index and first channel of the step inside the slice
+struct KTab { unsigned char seg[MAXKS]; unsigned short c0[MAXKS]; };
+
+// NB16: 16-channel output blocks of this workgroup (CW = 16 NB16 channels; blockIdx.y selects the group)
+template <int NB16>
+__global__ __launch_bounds__(256)
+void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ wfrag, int nks, int nb16_total, KTab tab, long long M) {
+  static_assert(NB16 == 2 || NB16 == 4, "the pixel-major store pattern needs 8 CW to divide 64 lanes");
+  constexpr int CW = 16 * NB16, LDP = CW + 4;                           // result tile row pitch (floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  egne_bf16* const lw = (egne_bf16*)smem;                               // [nks][NB16][64 lanes][8]
+  float* const tile = (float*)(smem + (size_t)nks * NB16 * 1024) + (threadIdx.x >> 6) * 32 * LDP;     // this wave's [32 px][LDP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int b0 = blockIdx.y * NB16;
+  for (int it = tid; it < nks * NB16 * 64; it += 256) {                 // 16-byte items
+    const int l = it & 63, r = it >> 6, j = r % NB16, ks = r / NB16;
+    const bool ok = b0 + j < nb16_total;
+    const u32x4 v = ok ? *(const u32x4*)(wfrag + (((long long)ks * nb16_total + b0 + j) * 64 + l) * 8) : u32x4{0u, 0u, 0u, 0u};
+    *(u32x4*)&lw[(long long)it * 8] = v;
+  }
+  __syncthreads();
+  const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  egne_bf16* const outp = (egne_bf16*)p.out;
+  const egne_bf16* const resp = (const egne_bf16*)p.residual;
+  const int cw0 = 16 * b0;                                               // first output channel of this workgroup
+  constexpr int G = CW / 8;                                              // lanes per pixel on the way out (8 channels each)
+  constexpr int PPI = 64 / G;                                            // pixels per store instruction
+  const long long ngroups = (M + 31) / 32;
+  const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long g = wave_id; g < ngroups; g += nwaves) {
+    const long long m0 = g * 32;
+    const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
+    f32x4 acc[2][NB16];
+#pragma unroll
+    for (int a = 0; a < 2 * NB16; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
+    for (int k0 = 0; k0 < nks; k0 += KC) {
+      u32x4 xb[KC][2];
+#pragma unroll
+      for (int u = 0; u < KC; ++u) {
+        const int ks = k0 + u;
+        const bool on = ks < nks;
+        const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
+        const int c = (on ? tab.c0[ks] : 0) + 8 * kg;
+        const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + m0 * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {      // rows past M fall outside the resource and read zeros
+          const int off = (on && c < sg.Cp) ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
+          xb[u][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KC; ++u) {
+        if (k0 + u < nks) {
+#pragma unroll
+          for (int j = 0; j < NB16; ++j) {
+            const egne_bf16x8 a = *(const egne_bf16x8*)&lw[(((k0 + u) * NB16 + j) * 64 + lane) * 8];
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+              acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xb[u][ph]), acc[ph][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lane holds pixel 16 ph + l15, channels 16 j + 4 kg + r: through the wave's LDS tile into pixel-major 8-channel vectors
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int j = 0; j < NB16; ++j) {
+        const int n = cw0 + 16 * j + 4 * kg;
+        const f32x4 bv = (p.bias && n < p.Cout_store) ? *(const f32x4*)(p.bias + n) : (f32x4)(0.f);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[ph][j][e] + bv[e];
+          v[e] = fmaxf(t, t * slope);
+        }
+        *(f32x4*)&tile[(16 * ph + l15) * LDP + 16 * j + 4 * kg] = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(outp + m0 * p.out_pix_stride, (unsigned)rows * (unsigned)p.out_pix_stride * 2u);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(resp ? resp + m0 * p.res_pix_stride : nullptr, resp ? (unsigned)rows * (unsigned)p.res_pix_stride * 2u : 0u);
+#pragma unroll
+    for (int i = 0; i < 32 / PPI; ++i) {
+      const int px = i * PPI + lane / G, cg = lane % G;
+      const int n = cw0 + 8 * cg;
+      const bool nok = n < p.Cout_store;                     // Cout_store is a multiple of 8
+      egne_fv<8> v;
+      const f32x4 t0 = *(const f32x4*)&tile[px * LDP + 8 * cg], t1 = *(const f32x4*)&tile[px * LDP + 8 * cg + 4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v.v[e] = t0[e]; v.v[4 + e] = t1[e]; }
+      if (resp) {
+        const u32x4 rw = __builtin_amdgcn_raw_buffer_load_b128(rres, nok ? (px * (int)p.res_pix_stride + p.res_ch_off + n) * 2 : (int)OOB, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v.v[2 * e] += __builtin_bit_cast(float, rw[e] << 16);
+          v.v[2 * e + 1] += __builtin_bit_cast(float, rw[e] & 0xffff0000u);
+        }
+      }
+      const f32x4 lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
+      const egne_bf16x4 l4 = __builtin_convertvector(lo, egne_bf16x4), h4 = __builtin_convertvector(hi, egne_bf16x4);
+      const egne_bf16x8 pk = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rout,
+                                             nok ? (px * (int)p.out_pix_stride + p.out_ch_off + n) * 2 : (int)OOB, 0, 0);
+    }
+  }
+}
+
+// ---- several destinations in one launch (round 5) -----------------------------------------------------------------------------------
+// The data gradient of a 1x1 over a would-be torch.cat (models/RITnet_v2.py:59-61,85-86) is one 1x1 per member of the cat, every one of
+// them over the SAME input gz: bf16 plans keep each member in a buffer of its own, so the plan ran one launch per member and read gz
+// once per launch (three or four times per layer).  Here a wave loads the 32-pixel group's operands ONCE (all k-steps: at most 4 x 2
+// registers of 16 bytes) and walks the destinations: per destination its weight fragments (all resident in LDS), up to 64 output
+// channels at a time through the wave's LDS tile, out as whole 8-channel vectors with the optional accumulated residual.
+//
+// Two more things ride on the last writer of a gradient slice (egne_dst.mask_y): the activation mask of the layer whose OUTPUT the
+// slice is the gradient of -- gz = g * act'(y), what egne_act_bwd_bias would do in a pass of its own (read g, read y, write g) -- and,
+// for ONE destination of the launch (at most 128 channels), the channel sums of gz for that layer's bias gradient: every wave keeps
+// them in registers (fp64) over all the pixel groups it walks and writes one row of egne_dst.sums [wave][C] at the end; the
+// assignment of groups to waves is fixed by the grid, so egne_group_sums_reduce adds the rows in a fixed order (deterministic).
+// (A row per GROUP, reduced by one block, took longer than the pass it replaced: 1.2 M rows per B=256 layer.)
+struct DstTab {
+  void* ptr[EGNE_MAXDST]; const void* res[EGNE_MAXDST]; const void* mask[EGNE_MAXDST]; float* sums[EGNE_MAXDST];
+  int stride[EGNE_MAXDST], off[EGNE_MAXDST], C[EGNE_MAXDST], nb16[EGNE_MAXDST], wofs[EGNE_MAXDST];       // wofs: first 1-KB fragment row of the destination in LDS (per k-step: + nbt * ks)
+  int rstride[EGNE_MAXDST], roff[EGNE_MAXDST], mstride[EGNE_MAXDST], moff[EGNE_MAXDST], act[EGNE_MAXDST];
+  const egne_bf16* wfrag[EGNE_MAXDST];
+};
+
+template <int NKS>
+__global__ __launch_bounds__(256)
+void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M, int sum_dst, int nks) {
+  constexpr int LDP = 64 + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  egne_bf16* const lw = (egne_bf16*)smem;                               // [NKS][nbt][64 lanes][8]
+  float* const tile = (float*)(smem + (size_t)NKS * nbt * 1024) + (threadIdx.x >> 6) * 32 * LDP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l15 = lane & 15, kg = lane >> 4;
+  for (int d = 0; d < ndst; ++d) {
+    const int nb = dt.nb16[d];
+    for (int it = tid; it < nks * nb * 64; it += 256) {
+      const int l = it & 63, r = it >> 6, j = r % nb, ks = r / nb;
+      *(u32x4*)&lw[((long long)(ks * nbt + dt.wofs[d] + j) * 64 + l) * 8] = *(const u32x4*)(dt.wfrag[d] + (((long long)ks * nb + j) * 64 + l) * 8);
+    }
+  }
+  __syncthreads();
+  const long long ngroups = (M + 31) / 32;
+  const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+  double wsum[2][8];                  // destination sum_dst: this wave's sums of the lane's 8 channels, first / second 64-channel chunk
+#pragma unroll
+  for (int a = 0; a < 16; ++a) (&wsum[0][0])[a] = 0.;
+  for (long long g = wave_id; g < ngroups; g += nwaves) {
+    const long long m0 = g * 32;
+    const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
+    u32x4 xb[NKS][2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bool on = ks < nks;                                   // (NKS = 6 / 8 also serve 5 / 7 k-steps)
+      const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
+      const int c = on ? tab.c0[ks] + 8 * kg : 1 << 20;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + m0 * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const int off = c < sg.Cp ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
+        xb[ks][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      }
+    }
+    for (int d = 0; d < ndst; ++d) {
+      const int C = dt.C[d];
+      const __amdgpu_buffer_rsrc_t rout = make_rsrc((egne_bf16*)dt.ptr[d] + m0 * dt.stride[d], (unsigned)rows * (unsigned)dt.stride[d] * 2u);
+      const __amdgpu_buffer_rsrc_t rres = make_rsrc(dt.res[d] ? (const egne_bf16*)dt.res[d] + m0 * dt.rstride[d] : nullptr, dt.res[d] ? (unsigned)rows * (unsigned)dt.rstride[d] * 2u : 0u);
+      const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(dt.mask[d] ? (const egne_bf16*)dt.mask[d] + m0 * dt.mstride[d] : nullptr, dt.mask[d] ? (unsigned)rows * (unsigned)dt.mstride[d] * 2u : 0u);
+      const float slope = dt.act[d] == EGNE_ACT_RELU ? 0.f : (dt.act[d] == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+      for (int b0 = 0; b0 < dt.nb16[d]; b0 += 4) {                     // 64 output channels at a time (nb16 is even)
+        const int nbq = dt.nb16[d] - b0 < 4 ? dt.nb16[d] - b0 : 4;     // 2 or 4 blocks
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks >= nks) break;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < nbq) {
+              const egne_bf16x8 a = *(const egne_bf16x8*)&lw[((long long)(ks * nbt + dt.wofs[d] + b0 + j) * 64 + lane) * 8];
+#pragma unroll
+              for (int ph = 0; ph < 2; ++ph)
+                acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xb[ks][ph]), acc[ph][j], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < nbq) *(f32x4*)&tile[(16 * ph + l15) * LDP + 16 * j + 4 * kg] = acc[ph][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
+        const int G = 2 * nbq, PPI = 64 / G;                     // lanes per pixel on the way out (8 channels each), pixels per instruction
+        const int cg = lane % G, pl = lane / G;
+        const int n = 16 * b0 + 8 * cg;                          // first channel of the lane's vector inside the destination
+        const bool nok = n < C;
+        const bool summing = d == sum_dst;
+        float csum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+        for (int i = 0; i < 32 / PPI; ++i) {
+          const int px = i * PPI + pl;
+          egne_fv<8> v;
+          const f32x4 t0 = *(const f32x4*)&tile[px * LDP + 8 * cg], t1 = *(const f32x4*)&tile[px * LDP + 8 * cg + 4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v.v[e] = t0[e]; v.v[4 + e] = t1[e]; }
+          if (dt.res[d]) {
+            const u32x4 rw = __builtin_amdgcn_raw_buffer_load_b128(rres, nok ? (px * dt.rstride[d] + dt.roff[d] + n) * 2 : (int)OOB, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v.v[2 * e] += __builtin_bit_cast(float, rw[e] << 16);
+              v.v[2 * e + 1] += __builtin_bit_cast(float, rw[e] & 0xffff0000u);
+            }
+          }
+          if (dt.mask[d]) {         // gz = g * act'(y): the slice is the gradient of a layer's activated output y
+            const u32x4 yw = __builtin_amdgcn_raw_buffer_load_b128(rmsk, nok ? (px * dt.mstride[d] + dt.moff[d] + n) * 2 : (int)OOB, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y0 = __builtin_bit_cast(float, yw[e] << 16), y1 = __builtin_bit_cast(float, yw[e] & 0xffff0000u);
+              v.v[2 * e] = y0 > 0.f ? v.v[2 * e] : slope * v.v[2 * e];
+              v.v[2 * e + 1] = y1 > 0.f ? v.v[2 * e + 1] : slope * v.v[2 * e + 1];
+            }
+          }
+          const f32x4 lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
+          const egne_bf16x4 l4 = __builtin_convertvector(lo, egne_bf16x4), h4 = __builtin_convertvector(hi, egne_bf16x4);
+          const egne_bf16x8 pk = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+          const bool pok = nok && px < rows;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rout, pok ? (px * dt.stride[d] + dt.off[d] + n) * 2 : (int)OOB, 0, 0);
+          if (summing) {            // sums of what was STORED (bf16-rounded), as a pass over the stored tensor would see it
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { csum[e] += pok ? (float)l4[e] : 0.f; csum[4 + e] += pok ? (float)h4[e] : 0.f; }
+          }
+        }
+        if (summing) {              // (the group's <= 16 values per lane and channel in fp32, the running sums in fp64)
+          if (b0 == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wsum[0][e] += (double)csum[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wsum[1][e] += (double)csum[e];
+          }
+        }
+      }
+    }
+  }
+  if (sum_dst >= 0) {
+    // over the pixel lanes that share a channel vector (lanes cg, cg + G, cg + 2 G, ...: fixed order), then one row [C] per wave
+    const int C = dt.C[sum_dst], nb16 = dt.nb16[sum_dst];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int b0 = 4 * ch;
+      if (b0 < nb16) {
+        const int nbq = nb16 - b0 < 4 ? nb16 - b0 : 4, G = 2 * nbq;
+        for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wsum[ch][e] += __shfl_xor(wsum[ch][e], o);
+        }
+        const int n = 16 * b0 + 8 * (lane % G);
+        if (lane < G && n < C) {
+          float* w = dt.sums[sum_dst] + wave_id * C + n;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (float)wsum[ch][e];
+        }
+      }
+    }
+  }
+}
+
+// out[c] (+)= sum over rows of sums[row][c], fixed order (egne_dst.sums -> a bias gradient); 32 channels x 32 interleaved row ranges
+__global__ __launch_bounds__(1024) void group_sums_reduce_k(const float* __restrict__ sums, long long ngroups, int ld, int C, float* __restrict__ out,
+                                                            double* __restrict__ total, int accumulate) {
+  __shared__ double part[32][32];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + c;
+  double s = 0;
+  if (i < C)
+    for (long long k = q; k < ngroups; k += 32) s += (double)sums[k * ld + i];
+  part[q][c] = s;
+  __syncthreads();
+  if (q == 0 && i < C) {
+    double t = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += part[r][c];
+    if (out) out[i] = accumulate ? out[i] + (float)t : (float)t;
+    if (total) total[i] = t;
+  }
+}
+
+// flat fp32 pack [CoutP][Ktot] (egne_pack_conv_weight / egne_pack_conv_weight_dgrad with kh = kw = 1) -> bf16 fragments
+// [k-step][CoutP/16][lane = kg*16 + n%16][8]: element j of lane (n, kg) = W[n][kofs(step) + 8 kg + j], zero beyond the slice
+__global__ void pack_conv1x1_bf16_k(const float* __restrict__ wflat, int CoutP, int Ktot, int nks, KTab tab, const int* __restrict__ kofs,
+                                    const int* __restrict__ segcp, egne_bf16* __restrict__ out) {
+  const long long total = (long long)nks * CoutP * 32;
+  const int nb16 = CoutP >> 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+    long long q = i >> 9;
+    const int cb = (int)(q % nb16), ks = (int)(q / nb16);
+    const int n = cb * 16 + (l & 15), c = tab.c0[ks] + 8 * (l >> 4) + j;
+    const int s = tab.seg[ks];
+    out[i] = (egne_bf16)(c < segcp[s] ? wflat[(long long)n * Ktot + kofs[s] + c] : 0.f);
+  }
+}
+
+bool make_tab(const egne_conv_desc& d, KTab* tab, int* nks_) {
+  int nks = 0;
+  for (int s = 0; s < d.nseg; ++s)
+    for (int c0 = 0; c0 < d.seg[s].Cp; c0 += 32) {
+      if (nks >= MAXKS) return false;
+      tab->seg[nks] = (unsigned char)s; tab->c0[nks] = (unsigned short)c0; ++nks;
+    }
+  *nks_ = nks;
+  return true;
+}
+
+// 16-channel output blocks per workgroup and the LDS bytes that takes: all of them up to 64 channels, else pieces of 64 or 32
+// (2 or 4: the pixel-major store pattern needs 8 CW to divide 64 lanes; CoutP is a multiple of 32, so nb16 is even)
+int blocks_per_wg(int nb16) { return nb16 <= 4 ? nb16 : (nb16 % 4 == 0 ? 4 : 2); }
+size_t lds_bytes(int nks, int nb) { return (size_t)nks * nb * 1024 + (size_t)4 * 32 * (16 * nb + 4) * sizeof(float); }
+
+}  // namespace
+
+// number of bf16 elements of the fragment pack of a descriptor (k-steps x CoutP x 32), or -1 if the launch is not supported
+extern "C" int64_t egne_conv1x1_bf16_pack_elems(const egne_conv_desc* dp) {
+  if (!dp) return -1;
+  KTab tab; int nks = 0;
+  if (!make_tab(*dp, &tab, &nks)) return -1;
+  if (lds_bytes(nks, blocks_per_wg(dp->CoutP / 16)) > 120 * 1024) return -1;
+  return (int64_t)nks * dp->CoutP * 32;
+}
+
+// wflat: device pointer to the fp32 pack [CoutP][Ktot] of the same descriptor; seginfo: device int32 [2 * nseg] = the K offset of
+// every slice, then the padded channel count of every slice
+extern "C" int egne_pack_conv1x1_bf16(const egne_conv_desc* dp, const float* wflat, const int32_t* seginfo, void* wfrag, void* stream) {
+  EGNE_REQUIRE(dp && wflat && seginfo && wfrag, "pack_conv1x1_bf16: null pointer");
+  const egne_conv_desc& d = *dp;
+  KTab tab; int nks = 0;
+  EGNE_REQUIRE(d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && d.CoutP % 32 == 0 && make_tab(d, &tab, &nks), "pack_conv1x1_bf16: too many k-steps");
+  long long total = (long long)nks * d.CoutP * 32, g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pack_conv1x1_bf16_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, wflat, d.CoutP, d.Ktot, nks, tab, seginfo,
+                     seginfo + d.nseg, (egne_bf16*)wfrag);
+  return egne::check_launch("egne_pack_conv1x1_bf16");
+}
+
+extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag, void* stream) {
+  EGNE_REQUIRE(dp && wfrag, "conv1x1_bf16: null pointer");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.dtype == 1, "conv1x1_bf16: the descriptor must say bf16 tensors (dtype 1)");
+  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.Ho == d.H && d.Wo == d.W &&
+               d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && !d.post_scale && !d.stats_ws && !d.pool_out && !d.dyn_scale && !d.absmax_out,
+               "conv1x1_bf16: geometry / options not supported");
+  int ktot = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.Cp % 8 == 0 && g.ch_off % 8 == 0 && g.pix_stride % 8 == 0 && ((uintptr_t)g.ptr & 15) == 0 &&
+                 g.ch_off + g.Cp <= g.pix_stride && g.pix_stride * 64 < (1ll << 31), "conv1x1_bf16: slice %d (raw, 16-byte groups of 8 channels)", s);
+    ktot += g.Cp;
+  }
+  EGNE_REQUIRE(ktot == d.Ktot && d.CoutP % 32 == 0 && d.Cout_store % 8 == 0 && d.Cout_store <= d.CoutP && d.out && ((uintptr_t)d.out & 15) == 0 &&
+               d.out_pix_stride % 8 == 0 && d.out_ch_off % 8 == 0 && d.out_ch_off + d.Cout_store <= d.out_pix_stride &&
+               d.out_pix_stride * 64 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0), "conv1x1_bf16: output (16-byte groups of 8 channels)");
+  EGNE_REQUIRE(!d.residual || (((uintptr_t)d.residual & 15) == 0 && d.res_pix_stride % 8 == 0 && d.res_ch_off % 8 == 0 && d.res_pix_stride * 64 < (1ll << 31)),
+               "conv1x1_bf16: residual alignment");
+  KTab tab; int nks = 0;
+  EGNE_REQUIRE(make_tab(d, &tab, &nks), "conv1x1_bf16: more than %d k-steps", MAXKS);
+  const int nb16 = d.CoutP / 16, nb = blocks_per_wg(nb16);
+  const size_t lds = lds_bytes(nks, nb);
+  EGNE_REQUIRE(lds <= 120 * 1024, "conv1x1_bf16: %zu bytes of LDS per workgroup exceed the budget", lds);
+  const long long M = (long long)d.B * d.H * d.W;
+  const int gy = (nb16 + nb - 1) / nb;
+  long long gx = ((M + 31) / 32 + 3) / 4;
+  long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1)) / gy;     // workgroups: as many as stay resident
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto kern) -> int {
+    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, d, (const egne_bf16*)wfrag, nks, nb16, tab, M);
+    return egne::check_launch("egne_conv1x1_bf16_fwd");
+  };
+  if (nb == 2) return go(conv1x1_bf16_kernel<2>);
+  return go(conv1x1_bf16_kernel<4>);
+}
+
+// Several 1x1 convolutions over the SAME input slices in one launch, each with its own weights (fragments of egne_pack_conv1x1_bf16 for a
+// descriptor with that destination's CoutP) and destination slice: the per-member data gradients of a 1x1 over a would-be torch.cat.
+// d: input slices (seg[]), B, H, W, Ktot; its output fields are ignored.  Returns EGNE_ERR_ARG if the shapes do not fit (the caller
+// falls back to one egne_conv1x1_bf16_fwd per destination): more than 8 k-steps, or more weight fragments than fit LDS.
+extern "C" int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* dp, int ndst, const egne_dst* dsts) {
+  if (!dp || !dsts || ndst < 1 || ndst > EGNE_MAXDST) return 0;
+  KTab tab; int nks = 0;
+  if (!make_tab(*dp, &tab, &nks) || nks > 8) return 0;
+  int nbt = 0;
+  for (int i = 0; i < ndst; ++i) {
+    if (dsts[i].CoutP % 32 || dsts[i].C % 8 || dsts[i].C > dsts[i].CoutP) return 0;
+    nbt += dsts[i].CoutP / 16;
+  }
+  return (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float) <= 120 * 1024;
+}
+
+static long long multi_grid(const egne_conv_desc& d, int nks, int nbt) {
+  const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);
+  const long long M = (long long)d.B * d.H * d.W;
+  long long gx = ((M + 31) / 32 + 3) / 4;
+  const long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1));
+  return gx > cap ? cap : gx;
+}
+
+// rows of egne_dst.sums this launch writes (one per wave): what the caller allocates (x C floats) and hands to egne_group_sums_reduce
+extern "C" int64_t egne_conv1x1_bf16_multi_waves(const egne_conv_desc* dp, int ndst, const egne_dst* dsts) {
+  if (!egne_conv1x1_bf16_multi_supported(dp, ndst, dsts)) return -1;
+  KTab tab; int nks = 0;
+  make_tab(*dp, &tab, &nks);
+  int nbt = 0;
+  for (int i = 0; i < ndst; ++i) nbt += dsts[i].CoutP / 16;
+  return multi_grid(*dp, nks, nbt) * 4;
+}
+
+extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, const egne_dst* dsts, void* stream) {
+  EGNE_REQUIRE(dp && dsts && egne_conv1x1_bf16_multi_supported(dp, ndst, dsts), "conv1x1_bf16_multi: shapes not supported");
+  const egne_conv_desc& d = *dp;
+  EGNE_REQUIRE(d.dtype == 1 && d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.nseg >= 1 && d.nseg <= EGNE_MAXSEG,
+               "conv1x1_bf16_multi: bf16 1x1 descriptors only");
+  for (int s = 0; s < d.nseg; ++s) {
+    const egne_seg& g = d.seg[s];
+    EGNE_REQUIRE(g.ptr && !g.scale && !g.shift && g.Cp % 8 == 0 && g.ch_off % 8 == 0 && g.pix_stride % 8 == 0 && ((uintptr_t)g.ptr & 15) == 0 &&
+                 g.ch_off + g.Cp <= g.pix_stride && g.pix_stride * 64 < (1ll << 31), "conv1x1_bf16_multi: slice %d (raw, 16-byte groups of 8 channels)", s);
+  }
+  KTab tab; int nks = 0;
+  make_tab(d, &tab, &nks);
+  DstTab dt{};
+  int nbt = 0, sum_dst = -1;
+  for (int i = 0; i < ndst; ++i) {
+    const egne_dst& q = dsts[i];
+    if (q.sums) {
+      EGNE_REQUIRE(sum_dst < 0 && q.CoutP <= 128, "conv1x1_bf16_multi: channel sums for ONE destination of at most 128 channels per launch");
+      sum_dst = i;
+    }
+    EGNE_REQUIRE(q.out && q.wfrag && ((uintptr_t)q.out & 15) == 0 && q.out_pix_stride % 8 == 0 && q.out_ch_off % 8 == 0 && q.out_ch_off + q.C <= q.out_pix_stride &&
+                 q.out_pix_stride * 64 < (1ll << 31) && ((uintptr_t)q.wfrag & 15) == 0, "conv1x1_bf16_multi: destination %d", i);
+    EGNE_REQUIRE(!q.residual || (((uintptr_t)q.residual & 15) == 0 && q.res_pix_stride % 8 == 0 && q.res_ch_off % 8 == 0 && q.res_pix_stride * 64 < (1ll << 31)),
+                 "conv1x1_bf16_multi: residual of destination %d", i);
+    EGNE_REQUIRE(!q.mask_y || (((uintptr_t)q.mask_y & 15) == 0 && q.mask_pix_stride % 8 == 0 && q.mask_ch_off % 8 == 0 && q.mask_pix_stride * 64 < (1ll << 31)),
+                 "conv1x1_bf16_multi: mask tensor of destination %d", i);
+    EGNE_REQUIRE(!q.sums || ((uintptr_t)q.sums & 15) == 0, "conv1x1_bf16_multi: sums of destination %d", i);
+    dt.ptr[i] = q.out; dt.res[i] = q.residual; dt.mask[i] = q.mask_y; dt.sums[i] = q.sums;
+    dt.stride[i] = (int)q.out_pix_stride; dt.off[i] = q.out_ch_off; dt.C[i] = q.C; dt.nb16[i] = q.CoutP / 16; dt.wofs[i] = nbt;
+    dt.rstride[i] = (int)q.res_pix_stride; dt.roff[i] = q.res_ch_off; dt.mstride[i] = (int)q.mask_pix_stride; dt.moff[i] = q.mask_ch_off; dt.act[i] = q.act;
+    dt.wfrag[i] = (const egne_bf16*)q.wfrag;
+    nbt += q.CoutP / 16;
+  }
+  const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);
+  const long long M = (long long)d.B * d.H * d.W;
+  const long long gx = multi_grid(d, nks, nbt);
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto kern) -> int {
+    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16_multi: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M, sum_dst, nks);
+    return egne::check_launch("egne_conv1x1_bf16_multi_fwd");
+  };
+  switch (nks) {
+    case 1: return go(conv1x1_bf16_multi_kernel<1>);
+    case 2: return go(conv1x1_bf16_multi_kernel<2>);
+    case 3: return go(conv1x1_bf16_multi_kernel<3>);
+    case 4: return go(conv1x1_bf16_multi_kernel<4>);
+    case 5: case 6: return go(conv1x1_bf16_multi_kernel<6>);
+    default: return go(conv1x1_bf16_multi_kernel<8>);
+  }
+}
+
+// out[c] (+)= sum over rows of sums[row * ld + c], c < C (egne_dst.sums of a launch: nrows = egne_conv1x1_bf16_multi_waves, ld = that
+// destination's C); total (optional): the same sums as doubles
+extern "C" int egne_group_sums_reduce(const float* sums, int64_t nrows, int ld, int C, float* out, double* total, int accumulate, void* stream) {
+  EGNE_REQUIRE(sums && (out || total) && nrows > 0 && C > 0 && ld >= C, "group_sums_reduce: bad arguments");
+  hipLaunchKernelGGL(group_sums_reduce_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, (long long)nrows, ld, C, out, total, accumulate);
+  return egne::check_launch("egne_group_sums_reduce");
+}

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
       g += n16;
     }
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+    bool bad = false;          // a non-finite result of this block (egne_conv_desc.ovf_flag)
     // UP: the lane's pixel (b, y, x) and its four low-resolution taps -- ATen's area_pixel_compute_source_index(scale 0.5,
     // align_corners false): s = max(0.5 (d + 0.5) - 0.5, 0)
     [[maybe_unused]] int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
           const float t = acc[tn][4 * j + e] * out_scale + bias[tn][j][e];
           v[e] = fmaxf(t, t * slope);
         }
+        if (tn == 0 && j == 0) bad |= egne_nonfinite(v[0]);       // lane = pixel: one channel per pixel (common.h)
         if constexpr (UP) {
           if (staged) {
             const char* pb = (const char*)patch + (tn * 32 + 8 * j + 4 * kq) * 4;
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_kernel(const egne_conv_desc
         const int off = n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, off, 0, 0);
       }
+    egne_ovf_commit(bad, p.ovf_flag);
   }
 }
 
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(256) void conv1x1_pool_f16x3_kernel(const egne_conv
       g += n16;
     }
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+    bool bad = false;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -309,9 +313,11 @@ __global__ __launch_bounds__(256) void conv1x1_pool_f16x3_kernel(const egne_conv
           const float t = acc[tn][4 * j + e] * out_scale + bias[tn][j][e];
           v[e] = fmaxf(t, t * slope);
         }
+        if (tn == 0 && j == 0) bad |= egne_nonfinite(v[0]);       // lane = pixel: one channel per pixel (common.h)
         const int off = n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, off, 0, 0);
       }
+    egne_ovf_commit(bad, p.ovf_flag);
   }
 }
 

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void conv1x1_ms_f16x3_kernel(const egne_conv_d
   const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
   const int ostep = (int)p.out_pix_stride * 4;
+  bool bad = false;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + (wn * TN + tn) * 32 + li;
@@ -161,11 +162,13 @@ __global__ __launch_bounds__(256) void conv1x1_ms_f16x3_kernel(const egne_conv_d
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[tm][tn][r] * out_scale + bv;
+        if (tn == 0) bad |= egne_nonfinite(v);         // (every output channel of a contaminated pixel is contaminated: one block per wave)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v, v * slope)), rout,
                                               (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
       }
     }
   }
+  egne_ovf_commit(bad, p.ovf_flag);
 }
 
 // OIHW (kh = kw = 1) fp32 -> two f16 arrays [CoutP][Ktot]: hi / lo of w[n][kmap[k]] * wscale (kmap[k] = -1: padding column)

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(const egne_conv_des
     const long long m0 = (long long)blk * 32;
     const long long rows = M - m0 < 32 ? M - m0 : 32;
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+    bool bad = false;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -130,9 +131,11 @@ __global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(const egne_conv_des
           const float t = acc[tn][4 * j + e] * out_scale + bias[tn][j][e];
           v[e] = fmaxf(t, t * slope) * ps[tn][j][e] + pt[tn][j][e];
         }
+        if (tn == 0 && j == 0) bad |= egne_nonfinite(v[0]);       // lane = pixel: one channel per pixel (common.h)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
                                                n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
       }
+    egne_ovf_commit(bad, p.ovf_flag);
   }
 }
 

@@ -279,14 +279,16 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     for (int a = 0; a < WMW * NMH * WNW * NMH; ++a) (&prev[0][0][0][0])[a] = (acc_t)(0.f);
     __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 0u), rres = make_rsrc(nullptr, 0u);
     int pbase[WMW], pcm[WMW];                            // previous tile: first pixel of the lane per row, valid pixels from it
+    bool pchk[WMW];                                      // ... and whether the row is one the overflow test looks at (egne_ovf_row)
 #pragma unroll
-    for (int tm = 0; tm < WMW; ++tm) { pbase[tm] = 0; pcm[tm] = 0; }
+    for (int tm = 0; tm < WMW; ++tm) { pbase[tm] = 0; pcm[tm] = 0; pchk[tm] = false; }
     int pvo[WMW][WNW][NMH], pvr[WMW][WNW][NMH];            // previous tile: byte offsets of (row, channel) in the output / residual
     bool pedge = true;                                   // ... and whether it needs per-value range checks (nothing stored before the first tile)
     const bool full_epi = p.post_scale != nullptr || p.residual != nullptr;
 #pragma unroll
     for (int a = 0; a < WMW * WNW * NMH; ++a) { (&pvo[0][0][0])[a] = (int)OOB; (&pvr[0][0][0])[a] = (int)OOB; }
     int pchunk = -1;                                     // no previous tile yet: nothing to write
+    bool ovf_bad = false;                                // a non-finite value was stored (egne_conv_desc.ovf_flag)
     double st_s[WNW][NMH], st_q[WNW][NMH];
     int n4[WNW][NMH];
     bool nokv[WNW][NMH];
@@ -318,6 +320,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         v = v * pss[tn][nh] + pts[tn][nh];
         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr, c * res_step, 0));
       }
+      if (pchk[tm]) ovf_bad |= egne_nonfinite(v);          // lane = channel: the rows egne_ovf_row names (wave-uniform)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, c * out_step, 0);
       if (st_on) {
         if constexpr (first) { st_s[tn][nh] = 0.; st_q[tn][nh] = 0.; }
@@ -377,6 +380,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) prev[tm][0][tn][0][4 * j + e] = v[e];
+      if constexpr (tn == 0 && j == 0) ovf_bad |= egne_nonfinite(v[0]);      // lane = pixel: one channel per pixel (common.h)
     };
     auto tpo_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, j = Gi % 4, tm = (Gi / 4) % WMW, tn = Gi / (4 * WMW);
@@ -529,6 +533,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           const int y = tl.y0 + row0 + tm;
           pbase[tm] = y * W + xl;
           pcm[tm] = (y < H && xl < W) ? W - xl : 0;
+          pchk[tm] = egne_ovf_row(y, H);
 #pragma unroll
           for (int tn = 0; tn < WNW; ++tn)
 #pragma unroll
@@ -563,6 +568,7 @@ void conv3x3_rs_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       if constexpr (TPO) [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (tpo_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
       else [&]<int... Vs>(std::integer_sequence<int, Vs...>) { (epi_value(std::integral_constant<int, Vs>{}), ...); }(std::make_integer_sequence<int, NV>{});
     }
+    egne_ovf_commit(ovf_bad, p.ovf_flag);
     if constexpr (DBG & 32) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       if (lane == 0 && p.stats_ws) {

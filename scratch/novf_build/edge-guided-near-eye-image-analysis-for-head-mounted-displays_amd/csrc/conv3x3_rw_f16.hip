@@ -55,7 +55,9 @@ __device__ __forceinline__ void lds_barrier() {
 // a job's chunk (36 KB) STREAMED into one of two LDS weight buffers by the producers one job ahead -- the wider layers
 // (conv2_2, the MSBlock convs of stages 2-5, the dense blocks at 60x80) on the same consumer loop.
 // ncb = output blocks of 32 channels; tiles_x / tiles_y / ntiles as usual.
-template <int KCH>
+// NP: products per multiply (egne_conv_desc.f16_products): 3 = hi hi + hi lo + lo hi, 1 = hi hi only (plain f16 operands: the lo
+// halves are neither derived, stored nor read; the frozen edge network next to a bf16-storage training plan)
+template <int KCH, int NP = 3>
 __global__ __launch_bounds__(512)
 void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
                        float out_scale, int tiles_x, int tiles_y, int ntiles, int ncb, int nrun) {
@@ -176,13 +178,25 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           }
           if (!((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) v = (f32x4)(0.f);
         }
+        const int o = lofs + 32 * 32 * I;
+        if constexpr (NP == 1) {
+          float t0, t1, t2, t3;                   // (one-lane-value multiplies, as split_f16.h: no packed f32 next to the MFMAs)
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t0) : "s"(a_scale), "v"(v[0]));
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t1) : "s"(a_scale), "v"(v[1]));
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t2) : "s"(a_scale), "v"(v[2]));
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t3) : "s"(a_scale), "v"(v[3]));
+          const egne::sp_f32x2 u0 = {t0, t1}, u1 = {t2, t3};
+          const h2 h0 = __builtin_convertvector(u0, h2), h1 = __builtin_convertvector(u1, h2);
+          const h4 hi = {h0[0], h0[1], h1[0], h1[1]};
+          *(h4*)&img[o] = hi;
+        } else {
         h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
         egne::split2(v[0], v[1], a_scale, h0, l0);
         egne::split2(v[2], v[3], a_scale, h1, l1);
         const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
-        const int o = lofs + 32 * 32 * I;
         *(h4*)&img[o] = hi;
         *(h4*)&img[NPX * 32 + o] = lo;
+        }
       }
     };
     // STREAM: the 2304 16-byte pieces of a chunk's weights (LDS order [tap][ks][hl][lane]), nine per producer lane, requested one
@@ -294,6 +308,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     // The values are finished (scale, bias, activation [, post affine, residual]) IN PLACE at hand-over; the deferred part is the bare
     // store.  Computing them next to the store would reuse the store's data registers group after group, and overwriting the source
     // of a store in flight costs a wait for its completion (vmcnt): eight write round trips per tile.
+    bool ovf_bad = false;                                // a non-finite value was stored (egne_conv_desc.ovf_flag)
     auto finish_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
       f32x4 v;
@@ -315,6 +330,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           for (int e = 0; e < 4; ++e) v[e] += rv[e];
         }
       }
+      if constexpr (nh == 0) ovf_bad |= egne_nonfinite(v[0]);      // lane = pixel: one channel per pixel (common.h)
       if (p.out_split) {
         // split-pair storage (egne_conv_desc.out_split): the consumer's hi / lo f16 halves of v * out_split_scale, written here ONCE
         // instead of being derived by every consumer workgroup that stages the element (the dilated group stages it 13.5 times)
@@ -363,14 +379,14 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh) {
             wh[Bq][nh] = *(const h8*)&wb[T * 2048 + nh * 128];
-            wo[Bq][nh] = *(const h8*)&wb[T * 2048 + 512 + nh * 128];
+            if constexpr (NP == 3) wo[Bq][nh] = *(const h8*)&wb[T * 2048 + 512 + nh * 128];
           }
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
               ah[Bq][tm][ph] = *(const h8*)&Thi[aofs[T][tm][ph]];
-              al[Bq][tm][ph] = *(const h8*)&Tlo[aofs[T][tm][ph]];
+              if constexpr (NP == 3) al[Bq][tm][ph] = *(const h8*)&Tlo[aofs[T][tm][ph]];
             }
         };
         fetch(std::integral_constant<int, 0>{});
@@ -388,8 +404,10 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                   f32x4& c = acc[tm][ph][nh];
-                  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[Bq][nh], al[Bq][tm][ph], c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[Bq][nh], ah[Bq][tm][ph], c, 0, 0, 0);
+                  if constexpr (NP == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[Bq][nh], al[Bq][tm][ph], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[Bq][nh], ah[Bq][tm][ph], c, 0, 0, 0);
+                  }
                   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[Bq][nh], ah[Bq][tm][ph], c, 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
@@ -444,6 +462,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     }
     if (have_prev)
       [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
+    egne_ovf_commit(ovf_bad, p.ovf_flag);
   }
   if ((dbg & 64) && lane == 0) {
     unsigned long long* o = g_wstamps + ((long long)blockIdx.x * 8 + wave) * 4;
@@ -451,16 +470,16 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
   }
 }
 
-template <int KCH>
+template <int KCH, int NP = 3>
 int launch_rw(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32, nrun = (d.Cout_store + 31) / 32;
   constexpr size_t lds = ((size_t)2 * IMGH + (size_t)(KCH == 0 ? 2 : KCH) * WCH) * sizeof(_Float16);
   static_assert(lds <= 163840, "LDS budget");
-  static bool once = hipFuncSetAttribute((const void*)conv3x3_rw_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  static bool once = hipFuncSetAttribute((const void*)conv3x3_rw_kernel<KCH, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_rw: cannot raise the dynamic LDS limit to %zu", lds);
   // 256 workgroups = 8 XCDs x 32; the ncb blocks of a worker sit on one XCD: 32 / ncb workers per XCD
-  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb, nrun);
+  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH, NP>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb, nrun);
   return egne::check_launch("egne_conv3x3_rw_f16_fwd");
 }
 
@@ -496,6 +515,11 @@ extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *h = (const _Float16*)fhi, *l = (const _Float16*)flo;
+  if (d.f16_products == 1) {       // plain f16 operands (egne_conv_desc.f16_products; a split-pair OUTPUT is still written as both halves)
+    if (d.Ktot == 32) return launch_rw<1, 1>(d, h, l, a_scale, os, st);
+    if (d.Ktot == 64) return launch_rw<2, 1>(d, h, l, a_scale, os, st);
+    return launch_rw<0, 1>(d, h, l, a_scale, os, st);
+  }
   if (d.Ktot == 32) return launch_rw<1>(d, h, l, a_scale, os, st);
   if (d.Ktot == 64) return launch_rw<2>(d, h, l, a_scale, os, st);
   return launch_rw<0>(d, h, l, a_scale, os, st);

@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   unsigned okmask = 0;
   int st_c = 0;
   int ky_n = 0, kx_n = 0;   // tap coordinates of the step being loaded (no per-step division)
+  // egne_conv_desc.f16_products == 1 (wave-uniform): plain f16 operands -- no lo halves loaded, derived, stored or multiplied (the frame
+  // tails of the deep trunk layers of the edge network next to a bf16-storage training plan)
+  const bool np1 = p.f16_products == 1;
   auto load_step = [&](int g, int tap, int c0) {
     const int dil = p.dil[g];
     const int tapoff = (((ky_n - p.pad_h) * p.W + (kx_n - p.pad_w)) * dil * (int)sg.pix_stride + c0) * 4;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(rwh, boff[j], wstep, 0);
-      rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(rwl, boff[j], wstep, 0);
+      if (!np1) rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(rwl, boff[j], wstep, 0);
     }
   };
   const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
       const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
       const int o = (rbase + 32 * i) * LDH + col4 * 4;
       *(h4*)&Ahi[o] = hi;
-      *(h4*)&Alo[o] = lo;
+      if (!np1) *(h4*)&Alo[o] = lo;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
       if (BN * 4 % 256 == 0 || (item >> 2) < BN) {
         const int o = (item >> 2) * LDH + (item & 3) * 8;
         *(u32x4*)&Bhi[o] = rbh[j];
-        *(u32x4*)&Blo[o] = rbl[j];
+        if (!np1) *(u32x4*)&Blo[o] = rbl[j];
       }
     }
   };
@@ -227,19 +230,21 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         ah[t] = *(const h8*)&Ahi[arow + t * 32 * LDH + ks * 16];
-        al[t] = *(const h8*)&Alo[arow + t * 32 * LDH + ks * 16];
+        if (!np1) al[t] = *(const h8*)&Alo[arow + t * 32 * LDH + ks * 16];
       }
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         bh[t] = *(const h8*)&Bhi[brow + t * 32 * LDH + ks * 16];
-        bl[t] = *(const h8*)&Blo[brow + t * 32 * LDH + ks * 16];
+        if (!np1) bl[t] = *(const h8*)&Blo[brow + t * 32 * LDH + ks * 16];
       }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          if (!np1) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          }
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
         }
     }
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
           for (int r = 0; r < 16; ++r) {
             const float v = acc[tm][tn][r] * out_scale + bv;
             res[tm][tn][r] += fmaxf(v, v * slope_out);
-          }
+          }     // (a non-finite term keeps the sum non-finite: the final store below tests it)
           acc[tm][tn] = (f32x16)(0.f);
         }
       }
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int mr = mrow + (r & 3) + 8 * (r >> 2);
-          if (mr < left) wz[(long long)mr * p.CoutP + n] = acc[tm][tn][r] * out_scale;
+          if (mr < left) wz[(long long)mr * p.CoutP + n] = acc[tm][tn][r] * out_scale;      // (splitk_finish_k tests the sum)
         }
       }
     }
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + m0 * p.res_pix_stride : nullptr,
                                                 p.residual ? (unsigned)((left < BM ? left : BM) * p.res_pix_stride * 4) : 0u);
   const int ostep = (int)p.out_pix_stride * 4, rstep = (int)p.res_pix_stride * 4;
+  bool bad = false;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + (wn * TN + tn) * 32 + li;
@@ -314,10 +320,12 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const egne_conv_desc p,
         if (GROUPED) v = res[tm][tn][r];
         else { v = acc[tm][tn][r] * out_scale + bv; v = fmaxf(v, v * slope_out); }
         v = v * ps + pt + rv[r];
+        if (tn == 0) bad |= egne_nonfinite(v);         // (every output channel of a contaminated pixel is contaminated: one block per wave)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(o0 + ((r & 3) + 8 * (r >> 2)) * ostep), 0, 0);
       }
     }
   }
+  egne_ovf_commit(bad, p.ovf_flag);
 }
 
 // out[m][n] = epilogue(sum_z ws[z][m][n]): bias, activation, post affine, residual -- the tail of a split-K launch.
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(256) void splitk_finish_k(const egne_conv_desc p, c
     if (p.post_scale) v = v * p.post_scale[n + e] + p.post_shift[n + e];
     if (rs) v += rs[e];
     o[e] = v;
+    egne_ovf_commit(egne_nonfinite(v), p.ovf_flag);
   }
 }
 

@@ -40,7 +40,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 
 // NB = 32-channel blocks per wave along N (2 -> BN = 256 with 4 waves along N, 1 -> BN = 128)
-template <int NB, bool M16>
+// NP = products per multiply: 3 (hi hi + hi lo + lo hi) or 1 (hi hi: plain f16 operands; egne_conv_desc.f16_products) -- the lo halves
+// are then neither derived, stored nor read (the weight image keeps its layout: the lo chunks of a row are simply not touched)
+template <int NB, bool M16, int NP = 3>
 __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_desc p, const char* __restrict__ wimg, float a_scale,
                                                              float out_scale) {
   constexpr int BN = 128 * NB;
@@ -120,6 +122,13 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 v = __builtin_bit_cast(f32x4, ra[i]);
+      if constexpr (NP == 1) {
+        const f32x2 t0 = {v[0] * a_scale, v[1] * a_scale}, t1 = {v[2] * a_scale, v[3] * a_scale};
+        const h2 h0 = __builtin_convertvector(t0, h2), h1 = __builtin_convertvector(t1, h2);
+        const h4 hi = {h0[0], h0[1], h1[0], h1[1]};
+        *(h4*)(base + ldst_hi[i]) = hi;
+        continue;
+      }
       h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
       egne::split2(v[0], v[1], a_scale, h0, l0);
       egne::split2(v[2], v[3], a_scale, h1, l1);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
 #pragma unroll
       for (int t = 0; t < NTN; ++t) {
         bh[t] = *(const h8*)(base + boffs[t] + ch);
-        bl[t] = *(const h8*)(base + boffs[t] + cl);
+        if constexpr (NP == 3) bl[t] = *(const h8*)(base + boffs[t] + cl);
       }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -181,15 +190,17 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           ah[t] = *(const h8*)(base + aoffs[half * 4 + t] + ch);
-          al[t] = *(const h8*)(base + aoffs[half * 4 + t] + cl);
+          if constexpr (NP == 3) al[t] = *(const h8*)(base + aoffs[half * 4 + t] + cl);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int tn = 0; tn < NTN; ++tn) {
             acc_t& c = acc[half * 4 + t][tn];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], al[t], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[tn], ah[t], c, 0, 0, 0);
+            if constexpr (NP == 3) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], al[t], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[tn], ah[t], c, 0, 0, 0);
+            }
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], ah[t], c, 0, 0, 0);
           }
       }
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
   const long long left = M - m0;
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * 4));
   constexpr int NJ = M16 ? 1 : 4;
+  bool bad = false;
 #pragma unroll
   for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
@@ -250,11 +262,13 @@ __global__ __launch_bounds__(512) void conv_f16x3_big_kernel(const egne_conv_des
           const float t = acc[tm][tn][4 * j + e] * out_scale + bv[e];
           v[e] = fmaxf(t, t * slope);
         }
+        if (tn == 0 && j == 0) bad |= egne_nonfinite(v[0]);       // lane = pixel: one channel per pixel (common.h)
         const int row = wm * 128 + tm * MB + lr;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
                                                nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
       }
     }
+  egne_ovf_commit(bad, p.ovf_flag);
 }
 
 // OIHW fp32 -> LDS images [ntile][step = chunk*T + tap][BN rows][128 B]: row j = output channel ntile*BN + j, granule g =
@@ -319,6 +333,16 @@ extern "C" int egne_conv2d_f16x3_big_fwd(const egne_conv_desc* dp, const void* w
   }();
   static const bool m16 = !(getenv("EGNE_BIG_M16") && atoi(getenv("EGNE_BIG_M16")) == 0);     // MFMA shape (header)
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv_f16x3_big: cannot raise the dynamic LDS limit");
+  if (d.f16_products == 1) {       // plain f16 operands (the edge network next to a bf16-storage training plan): 16x16x32 shape only
+    static bool once1 = hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)conv_f16x3_big_kernel<1, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    if (!once1) return egne::fail(EGNE_ERR_LAUNCH, "conv_f16x3_big: cannot raise the dynamic LDS limit");
+    if (d.CoutP % 256 == 0)
+      hipLaunchKernelGGL((conv_f16x3_big_kernel<2, true, 1>), dim3((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 256)), dim3(512), 2 * (BM + 256) * ROWB, st, d, (const char*)wimg, a_scale, os);
+    else
+      hipLaunchKernelGGL((conv_f16x3_big_kernel<1, true, 1>), dim3((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 128)), dim3(512), 2 * (BM + 128) * ROWB, st, d, (const char*)wimg, a_scale, os);
+    return egne::check_launch("egne_conv2d_f16x3_big_fwd");
+  }
   if (d.CoutP % 256 == 0) {
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 256));
     if (m16) hipLaunchKernelGGL((conv_f16x3_big_kernel<2, true>), grid, dim3(512), 2 * (BM + 256) * ROWB, st, d, (const char*)wimg, a_scale, os);

@@ -145,8 +145,12 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     const int l = it & 63, hl = (it >> 6) & 1, q = it >> 7;      // q = group * NCH + tile
     *(u32x4*)&lw[(long long)it * 8] = *(const u32x4*)((hl ? w1lo : w1hi) + ((long long)q * 64 + l) * 8);
   }
-  // UPADD: two tiles of the low-resolution addend, [6 rows][18 columns][32 * NCH] floats each
-  constexpr int PROWS = TH / 2 + 2, PCOLS = TW / 2 + 2, PTILE = PROWS * PCOLS * 32 * NCH;
+  // UPADD: two tiles of the low-resolution addend, [6 rows][18 columns][32 * NCH + 4] floats each.  The pixel pitch is 144 (272) bytes,
+  // not 128 (256): the 32 lanes of a half wave read 16-byte vectors of 16-17 DIFFERENT patch pixels at the same channel offset, and
+  // with a power-of-two pitch all of them start in the same four banks (measured: 45-47 % of the LDS cycles of these launches were
+  // bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_ACTIVE); 36 k mod 64 walks all sixteen 4-bank slots
+  constexpr int PP = 32 * NCH + 4;
+  constexpr int PROWS = TH / 2 + 2, PCOLS = TW / 2 + 2, PTILE = PROWS * PCOLS * PP;
   float* const lp = (float*)(lw + GLDS * NCH * 2 * 512);
   __syncthreads();
 
@@ -428,8 +432,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < ph - 1 ? 1 : 0), x1 = x0 + (x0 < pw - 1 ? 1 : 0);
             const float ly = sy - y0, lx = sx - x0;
             const int ry = tl.y0 / 2 - 1, rx = tl.x0 / 2 - 1;
-            o00 = ((y0 - ry) * PCOLS + x0 - rx) * 32 * NCH; o01 = ((y0 - ry) * PCOLS + x1 - rx) * 32 * NCH;
-            o10 = ((y1 - ry) * PCOLS + x0 - rx) * 32 * NCH; o11 = ((y1 - ry) * PCOLS + x1 - rx) * 32 * NCH;
+            o00 = ((y0 - ry) * PCOLS + x0 - rx) * PP; o01 = ((y0 - ry) * PCOLS + x1 - rx) * PP;
+            o10 = ((y1 - ry) * PCOLS + x0 - rx) * PP; o11 = ((y1 - ry) * PCOLS + x1 - rx) * PP;
             w00 = (1.f - ly) * (1.f - lx) * vs; w01 = (1.f - ly) * lx * vs; w10 = ly * (1.f - lx) * vs; w11 = ly * lx * vs;
             if (!valid) o00 = o01 = o10 = o11 = 0;
           }
@@ -480,8 +484,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
     auto store_p = [&](float* dstp) {
 #pragma unroll
       for (int i = 0; i < NPI; ++i) {
-        const int it = tid + 256 * i;
-        if (it < PROWS * PCOLS * 8 * NCH) *(u32x4*)&dstp[it * 4] = pst[i];
+        const int it = tid + 256 * i, px = it / (8 * NCH), pc = it - px * (8 * NCH);
+        if (it < PROWS * PCOLS * 8 * NCH) *(u32x4*)&dstp[px * PP + pc * 4] = pst[i];
       }
     };
     auto produce = [&](int i) {           // tile i of this workgroup into image i & 1; prefetches the head of tile i + 1
@@ -628,6 +632,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
         const int xl = tl.x0 + 4 * lh;
         const int cmax = xl < W ? W - xl : 0;      // c_r < cmax  <=>  x < W
         const bool edge = tl.x0 + TW > W || tl.y0 + TH > H || (nt0 + WNW) * 32 > p2.Cout_store;     // wave-uniform
+        bool bad = false;
 #pragma unroll
         for (int tn = 0; tn < WNW; ++tn) {
           const int n = (nt0 + tn) * 32 + li;
@@ -640,8 +645,8 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             const int pix = y * W + xl;
             const int o0 = (pix * (int)p2.out_pix_stride + p2.out_ch_off + n) * 4;
             const int r0 = (pix * (int)p2.res_pix_stride + p2.res_ch_off + n) * 4;
-            if (st_on) egne::epi_row32_select<true>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
-            else egne::epi_row32_select<false>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q);
+            if (st_on) egne::epi_row32_select<true>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q, bad, egne_ovf_row(y, H));
+            else egne::epi_row32_select<false>(edge, p2.post_scale != nullptr, p2.residual != nullptr, acc[tm][tn], rout, rres, o0, r0, out_step, res_step, cm, os2, slope_out, ek[tn], st_s, st_q, bad, egne_ovf_row(y, H));
           }
           if (st_on) {                 // one chunk = this wave's rows of this tile (fixed order: deterministic)
             st_s += __shfl_xor(st_s, 32); st_q += __shfl_xor(st_q, 32);
@@ -652,6 +657,7 @@ void fused_1x1_3x3_kernel(const egne_conv_desc p1, const egne_conv_desc p2, cons
             }
           }
         }
+        egne_ovf_commit(bad, p2.ovf_flag);
       }
       stamp(t_work);
       lds_barrier();      // image i&1 may be overwritten, image (i+1)&1 is complete
@@ -670,7 +676,7 @@ int launch_fused(const egne_conv_desc& d1, const egne_conv_desc& d2, const Group
   const int tiles_x = (d2.W + TW - 1) / TW, tiles_y = (d2.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d2.B;
   const size_t lds = (size_t)2 * 2 * NCH * (TH + 2) * HWd * LDH * sizeof(_Float16) + 32 * NCH * sizeof(float) + (NCH == 1 ? (size_t)G1 * 2048 : (size_t)(G1 < 7 ? G1 : 7) * 4096) +
-                     (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * 32 * NCH * sizeof(float) : 0) +
+                     (UPADD ? (size_t)2 * (TH / 2 + 2) * (TW / 2 + 2) * (32 * NCH + 4) * sizeof(float) : 0) +
                      (C1V ? ((size_t)2 * (TH + 4) * (TW + 4) + 32 * 12) * sizeof(float) : 0);
   static bool once = hipFuncSetAttribute((const void*)fused_1x1_3x3_kernel<NCH, WN, TH, NB, C4, UPADD, UNI, GL, C1V>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024) == hipSuccess;

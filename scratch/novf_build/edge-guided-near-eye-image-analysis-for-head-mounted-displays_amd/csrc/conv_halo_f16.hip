@@ -48,7 +48,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // NW = waves along N: <WM=2, WN, NW=1> gives every wave 2 tile rows x all 32*WN channels; <WM=4, WN=1, NW=2> gives a
 // wave 4 tile rows x 32 of the 64 channels -- same accumulators, but each weight fragment fetched from L1/L2 feeds
 // twice as many MFMAs (PMC: the weight ring of the <2,2,1> shape ran the vector L1 at 80 % of its 64 B/clk).
-template <int WM, int WN, int D, bool LAT, int NW, int PF = 0, bool TP = false, bool POOL = false>
+// NP: products per multiply (egne_conv_desc.f16_products): 3 = hi hi + hi lo + lo hi; 1 = hi hi only (plain f16 operands: no lo halves
+// derived, stored, fetched or multiplied -- half the weight fragments each wave pulls from L2)
+template <int WM, int WN, int D, bool LAT, int NW, int PF = 0, bool TP = false, bool POOL = false, int NP = 3>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                                                                const _Float16* __restrict__ flo, float a_scale,
                                                                float out_scale, int tiles_x, int tiles_y, int ntiles) {
@@ -154,11 +156,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
       if (i < NI - 1 || tid + 256 * i < nitems) {
         const f32x4 v = __builtin_bit_cast(f32x4, st[i]);
         // x*a_scale = hi + lo, two elements per (packed) instruction
+        const int o = lofs0 + i * 32 * LDH;
+        if constexpr (NP == 1) {
+          float t0, t1, t2, t3;
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t0) : "s"(a_scale), "v"(v[0]));
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t1) : "s"(a_scale), "v"(v[1]));
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t2) : "s"(a_scale), "v"(v[2]));
+          asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t3) : "s"(a_scale), "v"(v[3]));
+          const egne::sp_f32x2 u0 = {t0, t1}, u1 = {t2, t3};
+          const h2 h0 = __builtin_convertvector(u0, h2), h1 = __builtin_convertvector(u1, h2);
+          const h4 hi = {h0[0], h0[1], h1[0], h1[1]};
+          *(h4*)&Ahi[o] = hi;
+          continue;
+        }
         h2 h0, h1, l0, l1;                        // x * a_scale = hi + lo, plain (unpacked) VALU: split_f16.h
         egne::split2(v[0], v[1], a_scale, h0, l0);
         egne::split2(v[2], v[3], a_scale, h1, l1);
         const h4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
-        const int o = lofs0 + i * 32 * LDH;
         *(h4*)&Ahi[o] = hi;
         *(h4*)&Alo[o] = lo;
       }
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         const int o = wchunk + wtap(s >> 1) * stride_tap + (s & 1) * stride_k16 + tn * 1024;
         const int wl = (half && (s & 1)) ? (int)OOB : wlane;
         qh[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wl, o, 0);
-        ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wl, o, 0);
+        if constexpr (NP == 3) ql[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wl, o, 0);
       }
     constexpr int TAP_UNROLL = NW == 2 ? 1 : 9;   // the NW = 2 shape only fits 2 waves per SIMD with the tap loop rolled
 #pragma unroll TAP_UNROLL
@@ -238,27 +252,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm) {
           ah[tm] = *(const h8*)&Ahi[aoff + tm * HWd * LDH + ks * 16];
-          al[tm] = *(const h8*)&Alo[aoff + tm * HWd * LDH + ks * 16];
+          if constexpr (NP == 3) al[tm] = *(const h8*)&Alo[aoff + tm * HWd * LDH + ks * 16];
         }
 #pragma unroll
         for (int tn = 0; tn < WN; ++tn) {
           bh[tn] = __builtin_bit_cast(h8, qh[slot][tn]);
-          bl[tn] = __builtin_bit_cast(h8, ql[slot][tn]);
+          if constexpr (NP == 3) bl[tn] = __builtin_bit_cast(h8, ql[slot][tn]);
         }
         if (tap + RT < 9) {
 #pragma unroll
           for (int tn = 0; tn < WN; ++tn) {
             const int o = wchunk + wtap(tap + RT) * stride_tap + ks * stride_k16 + tn * 1024;
             qh[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwh, wlane, o, 0);
-            ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
+            if constexpr (NP == 3) ql[slot][tn] = __builtin_amdgcn_raw_buffer_load_b128(rwl, wlane, o, 0);
           }
         }
 #pragma unroll
         for (int tm = 0; tm < WM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < WN; ++tn) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            if constexpr (NP == 3) {
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            }
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
           }
       }
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           make_rsrc(p.residual ? p.residual + (long long)cur.b * p.H * p.W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
       const int xl = cur.px + S * (cur.x0 + 4 * lh);
       const int cmax = xl < vW ? (vW - xl + S - 1) / S : 0;      // c_r < cmax  <=>  x < W
+      bool bad = false;       // a non-finite value stored by this tile (egne_conv_desc.ovf_flag)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn) {
         const int n = (nt0 + tn) * 32 + li;
@@ -285,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
         for (int tm = 0; tm < WM; ++tm) {
           const int y = cur.py + S * (cur.y0 + wrow * WM + tm);
           const int cm = (nok && y < vH) ? cmax : 0;
+          const bool chk = LAT || D != 1 || egne_ovf_row(y, vH);       // (wave-uniform; common.h: which rows the overflow test needs)
           const int pix = y * rstep + xl * cstep;
           const unsigned o0 = (unsigned)((pix * (int)p.out_pix_stride + p.out_ch_off + n) * 4);
           float rv[16];
@@ -303,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
             const int c = (r & 3) + 8 * (r >> 2);
             float v = acc[tm][tn][r] * out_scale + bv;
             v = fmaxf(v, v * slope_out) * ps + pt + rv[r];
+            if (tn == 0 && chk) bad |= egne_nonfinite(v);       // (one 32-channel block per wave: every channel of a contaminated pixel is contaminated)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
             const double vm = c < cm ? (double)v : 0.;
             st_s += vm; st_q += vm * vm;
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16_kernel(const egne_con
           }
         }
       }
+      egne_ovf_commit(bad, p.ovf_flag);
     }
     t = tnext;
     if (t >= ntiles) break;
@@ -369,7 +389,7 @@ __global__ void pack_weight_f16frag_k(const float* __restrict__ w, int Cout, int
   }
 }
 
-template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0, bool TP = false>
+template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0, bool TP = false, int NP = 3>
 int launch_hf_tp(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   constexpr int TH = (4 / NW) * WM;
   const int S = LAT ? d.dil[0] : 1;
@@ -380,22 +400,22 @@ int launch_hf_tp(const egne_conv_desc& d, const _Float16* fhi, const _Float16* f
   const int ntiles = tiles_x * tiles_y * d.B * S * S, ny = d.CoutP / (32 * WN * NW);
   int gx = (256 * 2 + ny - 1) / ny;
   if (gx > ntiles) gx = ntiles;
-  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW, PF, TP>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
+  hipLaunchKernelGGL((conv3x3_halo_f16_kernel<WM, WN, D, LAT, NW, PF, TP, false, NP>), dim3(gx, ny), dim3(256), lds, st, d, fhi, flo, a_scale, os, tiles_x,
                      tiles_y, ntiles);
   return egne::check_launch("egne_conv3x3_halo_f16_fwd");
 }
 
 // Walk the image transposed when 8 x 32 tiles fit it better that way (dilation 8 on 240x320: 30 x 40 lattice points per
 // phase = 8 wide tiles at 59 % fill or 5 tall tiles at 94 %; plain 60x80 and 30x40 maps likewise).  D = 1 shapes only.
-template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0>
+template <int WM, int WN, int D, bool LAT, int NW = 1, int PF = 0, int NP = 3>
 int launch_hf(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   constexpr int TH = (4 / NW) * WM;
   const int S = LAT ? d.dil[0] : 1;
   auto ntile = [&](int vh, int vw) { return ((((vw + S - 1) / S) + TW - 1) / TW) * ((((vh + S - 1) / S) + TH - 1) / TH); };
   static const bool tall_ok = [] { const char* e = getenv("EGNE_SHALO_TALL"); return !e || e[0] != '0'; }();
   if (D == 1 && NW == 1 && PF == 0 && tall_ok && ntile(d.W, d.H) < ntile(d.H, d.W))
-    return launch_hf_tp<WM, WN, (D == 1 && NW == 1 && PF == 0 ? D : 1), LAT, (D == 1 && NW == 1 && PF == 0 ? NW : 1), 0, true>(d, fhi, flo, a_scale, os, st);
-  return launch_hf_tp<WM, WN, D, LAT, NW, PF, false>(d, fhi, flo, a_scale, os, st);
+    return launch_hf_tp<WM, WN, (D == 1 && NW == 1 && PF == 0 ? D : 1), LAT, (D == 1 && NW == 1 && PF == 0 ? NW : 1), 0, true, NP>(d, fhi, flo, a_scale, os, st);
+  return launch_hf_tp<WM, WN, D, LAT, NW, PF, false, NP>(d, fhi, flo, a_scale, os, st);
 }
 
 }  // namespace
@@ -458,13 +478,16 @@ extern "C" int egne_conv3x3_halo_f16_fwd(const egne_conv_desc* dp, const void* f
     const int ny = d.CoutP / (w2 ? 64 : 32);
     int gx = (256 * 2 + ny - 1) / ny;
     if (gx > ntiles) gx = ntiles;
-    if (w2) hipLaunchKernelGGL((conv3x3_halo_f16_kernel<2, 2, 1, false, 1, 0, false, true>), dim3(gx, ny), dim3(256), lds, st, d, h, l, a_scale, os, tiles_x, tiles_y, ntiles);
+    if (w2 && d.f16_products == 1) hipLaunchKernelGGL((conv3x3_halo_f16_kernel<2, 2, 1, false, 1, 0, false, true, 1>), dim3(gx, ny), dim3(256), lds, st, d, h, l, a_scale, os, tiles_x, tiles_y, ntiles);
+    else if (w2) hipLaunchKernelGGL((conv3x3_halo_f16_kernel<2, 2, 1, false, 1, 0, false, true>), dim3(gx, ny), dim3(256), lds, st, d, h, l, a_scale, os, tiles_x, tiles_y, ntiles);
     else hipLaunchKernelGGL((conv3x3_halo_f16_kernel<2, 1, 1, false, 1, 0, false, true>), dim3(gx, ny), dim3(256), lds, st, d, h, l, a_scale, os, tiles_x, tiles_y, ntiles);
     return egne::check_launch("egne_conv3x3_halo_f16_fwd");
   }
   static const int pf = [] { const char* e = getenv("EGNE_SHALO_PF"); return e ? atoi(e) : 0; }();
   if (d.dil[0] == 1 && pf == 1) return w2 ? launch_hf<2, 2, 1, false, 1, 1>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false, 1, 1>(d, h, l, a_scale, os, st);
   if (d.dil[0] == 1 && pf == 2) return w2 ? launch_hf<2, 2, 1, false, 1, 2>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false, 1, 2>(d, h, l, a_scale, os, st);
+  // plain f16 operands (egne_conv_desc.f16_products = 1): the dilation-1 shapes of the edge network (MSBlock convolutions of stages 3-5, conv2_2)
+  if (d.dil[0] == 1 && d.f16_products == 1) return w2 ? launch_hf<2, 2, 1, false, 1, 0, 1>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false, 1, 0, 1>(d, h, l, a_scale, os, st);
   if (d.dil[0] == 1) return w2 ? launch_hf<2, 2, 1, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 1, false>(d, h, l, a_scale, os, st);
   if (d.dil[0] == 2) return w2 ? launch_hf<2, 2, 2, false>(d, h, l, a_scale, os, st) : launch_hf<2, 1, 2, false>(d, h, l, a_scale, os, st);
   // larger dilations: lattice mode (the dilation-S conv as S*S ordinary convs on sub-lattices)

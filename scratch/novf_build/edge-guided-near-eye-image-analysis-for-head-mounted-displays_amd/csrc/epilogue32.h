@@ -19,10 +19,10 @@ struct EpiLane {          // per lane and 32-channel block, fixed for the launch
 
 // MASK: edge tile (pixels past W, rows past H, channels past Cout_store are dropped: cm = valid pixels from xl, 0 for none);
 // POST: post affine present; RES: residual present (a load per value); STATS: accumulate st_s / st_q.
-template <bool MASK, bool POST, bool RES, bool STATS>
+template <bool MASK, bool POST, bool RES, bool STATS, bool CHECK = true>
 __device__ __forceinline__ void epi_row32(const epi_f32x16& acc, const __amdgpu_buffer_rsrc_t rout, const __amdgpu_buffer_rsrc_t rres,
                                           int voff, int roff, int out_step, int res_step, int cm, float os, float slope,
-                                          const EpiLane& k, double& st_s, double& st_q) {
+                                          const EpiLane& k, double& st_s, double& st_q, bool& bad) {
   constexpr int OOBO = (int)0x80000000u;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -32,6 +32,7 @@ __device__ __forceinline__ void epi_row32(const epi_f32x16& acc, const __amdgpu_
     v = fmaxf(v, v * slope);
     if constexpr (POST) v = v * k.post_scale + k.post_shift;
     if constexpr (RES) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? roff : OOBO, c * res_step, 0));
+    if constexpr (CHECK) bad |= egne_nonfinite(v);          // (egne_conv_desc.ovf_flag: an f16 operand left its range upstream of this value)
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ok ? voff : OOBO, c * out_step, 0);
     if constexpr (STATS) {
       const double vm = ok ? (double)v : 0.;
@@ -46,12 +47,15 @@ __device__ __forceinline__ void epi_row32(const epi_f32x16& acc, const __amdgpu_
 template <bool STATS>
 __device__ __forceinline__ void epi_row32_select(bool mask, bool post, bool res, const epi_f32x16& acc, const __amdgpu_buffer_rsrc_t rout,
                                                  const __amdgpu_buffer_rsrc_t rres, int voff, int roff, int out_step, int res_step, int cm,
-                                                 float os, float slope, const EpiLane& k, double& st_s, double& st_q) {
-  if (!mask && !post && !res) epi_row32<false, false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
-  else if (!post && !res) epi_row32<true, false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
-  else if (!mask && !res) epi_row32<false, true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
-  else if (!res) epi_row32<true, true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
-  else epi_row32<true, true, true, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q);
+                                                 float os, float slope, const EpiLane& k, double& st_s, double& st_q, bool& bad, bool chk) {
+  // `chk` (wave-uniform): this image row is one the overflow test looks at (egne_ovf_row); the common interior forms skip it otherwise
+  if (!chk && !mask && !post && !res) { epi_row32<false, false, false, STATS, false>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad); return; }
+  if (!chk && !mask && !res) { epi_row32<false, true, false, STATS, false>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad); return; }
+  if (!mask && !post && !res) epi_row32<false, false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad);
+  else if (!post && !res) epi_row32<true, false, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad);
+  else if (!mask && !res) epi_row32<false, true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad);
+  else if (!res) epi_row32<true, true, false, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad);
+  else epi_row32<true, true, true, STATS>(acc, rout, rres, voff, roff, out_step, res_step, cm, os, slope, k, st_s, st_q, bad);
 }
 
 }  // namespace egne

@@ -295,6 +295,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
       const int xl = tl.x0 + 4 * lh;
       const int cmax = xl < W ? W - xl : 0;
       const bool nok = li < p.Cout_store;
+      bool bad = false;
       const float b0 = p.bias ? p.bias[li] : 0.f, b1 = p.bias ? p.bias[p.CoutP + li] : 0.f, b2 = p.bias ? p.bias[2 * p.CoutP + li] : 0.f;
       // optional: this block's share of the stage's two score maps (bdcn_new.py:118-166: 1x1 "down" conv 32 -> 21, summed over
       // the stage's blocks, then the two 21 -> 1 heads -- all linear, so per block and head ONE 32-vector, score_w[2][32])
@@ -325,6 +326,8 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
           const int c = (r & 3) + 8 * (r >> 2);
           const float v = fmaxf(acc[0][tm][r] * out_scale + b0, 0.f) + fmaxf(acc[1][tm][r] * out_scale + b1, 0.f) +
                           fmaxf(acc[2][tm][r] * out_scale + b2, 0.f) + rv[r];      // o + o1 + o2 + o3 (bdcn_new.py:54)
+          // (fmaxf(x, 0) swallows NaN and -inf: the overflow test looks at the accumulators themselves, egne_conv_desc.ovf_flag)
+          bad |= egne_nonfinite(acc[0][tm][r] + acc[1][tm][r] + acc[2][tm][r]) | egne_nonfinite(rv[r]);
           if (p.out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)(c < cm ? o0 + c * out_step : OOB), 0, 0);
           sc[r] = v * cw0; sc[16 + r] = v * cw1;
         }
@@ -365,6 +368,7 @@ void msblock_dil_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi
           }
         }
       }
+      egne_ovf_commit(bad, p.ovf_flag);
     }
     stamp(t_work);
     lds_barrier();

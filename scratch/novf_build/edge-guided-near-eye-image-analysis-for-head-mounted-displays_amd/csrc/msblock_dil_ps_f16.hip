@@ -56,7 +56,9 @@ constexpr int ni_of(int g) { return TH * (TW + 2 * dil_of(g)) * 8 / 512; }     /
 // XIN: this launch holds only tiles whose widest strip lies inside the image columns (x0 >= 12, x0 + 32 + 12 <= W): item addresses are
 // then a per-lane constant + a wave-uniform term (rows outside the image fall outside the per-frame buffer resource and read zeros).
 // cols: 0 = all tile columns, 1 = interior, 2 = the two border columns (as msblock_dil_f16.hip).
-template <bool XIN>
+// NP: products per multiply (egne_conv_desc.f16_products): 3 = hi hi + hi lo + lo hi; 1 = hi hi only -- the lo plane of the input is
+// then not even copied (its pieces read zeros through the out-of-range offset), which halves what the copy side pulls from L2
+template <bool XIN, int NP = 3>
 __global__ __launch_bounds__(512)
 void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float inv_a, float out_scale,
                      int tiles_x, int tiles_y, int ntiles, int cols, const float* __restrict__ score_w, const float* __restrict__ score_c,
@@ -157,7 +159,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
         off = ((y * W + x) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4;
         off = ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? off : (int)OOB;
       }
-      stbuf(std::integral_constant<int, g>{})[I] = __builtin_amdgcn_raw_buffer_load_b128(r, (on && !(dbg & 1)) ? off : (int)OOB, 0, 0);
+      stbuf(std::integral_constant<int, g>{})[I] = __builtin_amdgcn_raw_buffer_load_b128(r, (on && !(dbg & 1) && (NP == 3 || piece < 4)) ? off : (int)OOB, 0, 0);
     }
   };
   auto write_strip = [&](int q, auto sc) {          // strip S (global count q) out of its registers into strip / weight buffer q & 1
@@ -188,7 +190,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
         wh[nh] = *(const h8*)&wb[KX * 2048 + nh * 128];
-        wo[nh] = *(const h8*)&wb[KX * 2048 + 512 + nh * 128];
+        if constexpr (NP == 3) wo[nh] = *(const h8*)&wb[KX * 2048 + 512 + nh * 128];
       }
     };
     auto fetch = [&](auto kc) {
@@ -198,7 +200,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
         const int qq = wave * SW + ph * 16 + l15 + KX * d;
         const int o = qq * 32 + ((kg ^ ((qq >> 1) & 3)) << 3);
         ah[Bq][ph] = *(const h8*)&Shi[o];
-        al[Bq][ph] = *(const h8*)&Slo[o];
+        if constexpr (NP == 3 || (S == 3 && KX == 1)) al[Bq][ph] = *(const h8*)&Slo[o];       // (NP == 1: zeros, read once for the residual o)
       }
     };
     fetch(std::integral_constant<int, 0>{});
@@ -210,6 +212,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
         if constexpr (S == 3 && kx == 1) { resh[0] = ah[1][0]; resh[1] = ah[1][1]; resl[0] = al[1][0]; resl[1] = al[1][1]; }
         __builtin_amdgcn_sched_barrier(0);
         // three products per accumulator, the four accumulators interleaved: no MFMA reads the result of the one before it
+        if constexpr (NP == 3) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -218,6 +221,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh) acc[g][ph][nh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[nh], ah[Bq][ph], acc[g][ph][nh], 0, 0, 0);
+        }
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -233,6 +237,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
   const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 4u;
   float* sdst = nullptr;
   float sprev = 0.f;
+  bool ovf_bad = false;
   auto score_prefetch = [&](const Tile& tl) {      // lane (l15, kg) finishes head kg >> 1 of pixel block kg & 1
     const int h = kg >> 1, y = tl.y0 + wave, x = tl.x0 + (kg & 1) * 16 + l15;
     sdst = (score_w && y < H && x < W) ? (h ? s1 : s0) + ((long long)tl.b * H + y) * W + x : nullptr;
@@ -268,6 +273,9 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
                  fmaxf(acc[2][ph][nh][e] * out_scale + bq[2][nh][e], 0.f) + o;        // o + o1 + o2 + o3 (bdcn_new.py:54)
           sc[0][ph] += v[e] * cwq[0][nh][e];
           sc[1][ph] += v[e] * cwq[1][nh][e];
+          // (fmaxf(x, 0) swallows NaN and -inf: the overflow test takes the accumulators themselves; lane = pixel: one channel per
+          //  pixel, common.h)
+          if (nh == 0 && e == 0) ovf_bad |= egne_nonfinite(acc[0][ph][nh][e] + acc[1][ph][nh][e] + acc[2][ph][nh][e] + o);
         }
         if (p.out) {
           const int n = nh * 16 + 4 * kg;
@@ -340,6 +348,7 @@ void msdil_ps_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, c
       }()), ...);
     }(std::make_integer_sequence<int, NS>{});
   }
+  egne_ovf_commit(ovf_bad, p.ovf_flag);
   if ((dbg & 64) && lane == 0) {
     unsigned long long* o = g_pstamps + ((long long)blockIdx.x * 8 + wave) * 4;
     o[0] = t_work; o[1] = t_wait; o[2] = nmine; o[3] = 0;
@@ -357,22 +366,29 @@ int msdil_ps_launch(const egne_conv_desc& d, const void* fhi, const void* flo, f
   const int ntiles = tiles_x * tiles_y * d.B;
   constexpr size_t lds = ((size_t)2 * BUFH + 2 * WBUFH) * sizeof(_Float16) + 162 * sizeof(float) + 18 * 64 * sizeof(int) + WBUFH * sizeof(_Float16);
   static_assert(lds <= 163840, "LDS budget");
-  static bool once = hipFuncSetAttribute((const void*)msdil_ps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)msdil_ps_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  if (!once) return egne::fail(EGNE_ERR_LAUNCH, "msblock_dil (split-pair input): cannot raise the dynamic LDS limit to %zu", lds);
   const float os = 1.0f / (a_scale * w_scale), inv_a = 1.0f / a_scale;
   const bool split = tiles_x > 2 && d.W >= TW * (tiles_x - 1) + 12;
-  if (split) {
-    const int nt_in = (tiles_x - 2) * tiles_y * d.B, nt_b = 2 * tiles_y * d.B;
-    hipLaunchKernelGGL((msdil_ps_kernel<true>), dim3(nt_in < 256 ? nt_in : 256), dim3(512), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
-                       inv_a, os, tiles_x, tiles_y, nt_in, 1, score_w, score_c, s0, s1, accumulate);
-    static const bool only_interior = getenv("EGNE_MSDIL_ONLY_INTERIOR") != nullptr;      // diagnostics: stamps of the interior launch
-    if (!only_interior) hipLaunchKernelGGL((msdil_ps_kernel<false>), dim3(nt_b < 256 ? nt_b : 256), dim3(512), lds, st, d, (const _Float16*)fhi,
-                                           (const _Float16*)flo, inv_a, os, tiles_x, tiles_y, nt_b, 2, score_w, score_c, s0, s1, accumulate);
-  } else {
-    hipLaunchKernelGGL((msdil_ps_kernel<false>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
-                       inv_a, os, tiles_x, tiles_y, ntiles, 0, score_w, score_c, s0, s1, accumulate);
-  }
+  auto go = [&](auto npc) -> int {
+    constexpr int NP = decltype(npc)::value;
+    static bool once = hipFuncSetAttribute((const void*)msdil_ps_kernel<false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                       hipFuncSetAttribute((const void*)msdil_ps_kernel<true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!once) return egne::fail(EGNE_ERR_LAUNCH, "msblock_dil (split-pair input): cannot raise the dynamic LDS limit to %zu", lds);
+    if (split) {
+      const int nt_in = (tiles_x - 2) * tiles_y * d.B, nt_b = 2 * tiles_y * d.B;
+      hipLaunchKernelGGL((msdil_ps_kernel<true, NP>), dim3(nt_in < 256 ? nt_in : 256), dim3(512), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+                         inv_a, os, tiles_x, tiles_y, nt_in, 1, score_w, score_c, s0, s1, accumulate);
+      static const bool only_interior = getenv("EGNE_MSDIL_ONLY_INTERIOR") != nullptr;      // diagnostics: stamps of the interior launch
+      if (!only_interior) hipLaunchKernelGGL((msdil_ps_kernel<false, NP>), dim3(nt_b < 256 ? nt_b : 256), dim3(512), lds, st, d, (const _Float16*)fhi,
+                                             (const _Float16*)flo, inv_a, os, tiles_x, tiles_y, nt_b, 2, score_w, score_c, s0, s1, accumulate);
+    } else {
+      hipLaunchKernelGGL((msdil_ps_kernel<false, NP>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, st, d, (const _Float16*)fhi, (const _Float16*)flo,
+                         inv_a, os, tiles_x, tiles_y, ntiles, 0, score_w, score_c, s0, s1, accumulate);
+    }
+    return EGNE_OK;
+  };
+  // egne_conv_desc.f16_products == 1: plain f16 operands (the edge network next to a bf16-storage training plan)
+  const int rc = d.f16_products == 1 ? go(std::integral_constant<int, 1>{}) : go(std::integral_constant<int, 3>{});
+  if (rc != EGNE_OK) return rc;
   return egne::check_launch("egne_msblock_dil_f16_fwd (split-pair input)");
 }
 }  // namespace egne

@@ -125,6 +125,16 @@ typedef struct {
    * the value itself (the 4-way sum of bdcn_new.py:54), exact to 2^-22 |x|. */
   int32_t out_split;
   float out_split_scale;      /* s > 0, a power of two */
+  /* Optional (every split-f16 entry point): sticky overflow word.  The kernel sets bit 0 when a value it stores is not finite --
+   * the trace of an operand that left the f16 range under the launch's calibrated pre-scale (or of non-finite input).  The
+   * caller clears it, reads it behind the launches it covers and answers by re-calibrating (engine.Plan.check_overflow). */
+  uint32_t* ovf_flag;
+  /* Optional (egne_conv2d_f16x3_big_fwd, egne_msblock_dil(_scores)_f16_fwd on split-pair input, egne_conv3x3_rw_f16_fwd): products per
+   * multiply of the split-f16 arithmetic.  0 / 3: a b ~= hi hi + hi lo + lo hi (22-bit significand, the inference plans and every
+   * fp32-storage plan).  1: hi hi only -- plain f16 operands (11-bit significand), fp32 accumulation: the frozen edge network next
+   * to a training plan with BF16 activation storage (BASELINE.json configs[2..4]), whose input the edge map is rounded to bf16
+   * (8-bit significand) anyway.  Entry points that do not know the field compute all three products. */
+  int32_t f16_products;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
@@ -533,6 +543,22 @@ int egne_spatial_mean_bwd(const float* g, int gld, float* gx, int64_t xs, int xo
 int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int C, int flag,
                        const float* gscale /* device, 1 float */, float* gpred, int gld, void* stream);
 
+/* Fused backward of a tensor x that was InstanceNorm-ed once (scale / shift per sample, egne_norm_stats) for up to two consumers
+ * (round 5; models/RITnet_v2.py:57: conv1 behind IN(x); :40-44: Transition_down behind avg_pool2d(leaky(IN(.)))): the
+ * normalisation's backward is linear in its upstream gradient G = a1 + act_q'(xh) up(gq) / 4 (a1: full-resolution addend, gq: the
+ * gradient of the 2x2-pooled tensor; either may be NULL), and its result joins the gradient of x where the layer that PRODUCED x
+ * masks it: g <- act'(x) (g + rstd (G - mean G - xh mean(G xh))) in place, with that layer's bias sums (dbias += ..., and the chunk
+ * sums in ws_bias as egne_act_bwd_bias leaves them for egne_pair_bias_bwd).  Replaces egne_norm_bwd + egne_norm_pool2_bwd +
+ * egne_act_bwd_bias: five passes over full-resolution tensors less.  B samples of H x W pixels (even for a pooled addend).
+ * sums: [B][Cp][2] floats (scratch); ws_norm: egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1); ws_bias:
+ * egne_act_bwd_bias_workspace_bytes(B*H*W, Cp). */
+int egne_act_norm_bwd(float* g, int64_t gs, int go, const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                      const float* a1, int64_t a1s, int a1o, const float* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                      float* sums, void* ws_norm, float* dbias /* may be NULL */, int C, void* ws_bias, void* stream);
+int egne_act_norm_bwd_bf16(void* g, int64_t gs, int go, const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
+                           const void* a1, int64_t a1s, int a1o, const void* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
+                           float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream);
+
 /* Weight gradient of the convolution described by `d` (same descriptor as the forward call):
  * gw[g][co][ci][kh][kw] += sum_pixels gz[pixel][co] * input[pixel + tap][ci], gz = gradient w.r.t. the
  * pre-activation output.  gw is a HOST array of ngroups device pointers (OIHW, torch layout).
@@ -704,11 +730,33 @@ int egne_conv3x3_narrow_fwd(const egne_conv_desc* d, void* stream);
  */
 int64_t egne_conv1x1_bf16_pack_elems(const egne_conv_desc* d);
 int egne_pack_conv1x1_bf16(const egne_conv_desc* d, const float* wflat, const int32_t* seginfo, void* wfrag, void* stream);
+/* Several 1x1 convolutions over the SAME bf16 input slices in one launch (round 5): the per-member data gradients of a 1x1 over a
+ * would-be torch.cat (models/RITnet_v2.py:59-61,85-86; replaces one egne_conv1x1_bf16_fwd per member, each re-reading gz).
+ * A destination may be the LAST writer of its gradient slice: then it applies the activation mask of the layer whose output the
+ * slice is the gradient of (mask_y, act: gz = g * act'(y), the pass egne_act_bwd_bias would make); ONE destination per launch (at most
+ * 128 channels) may also leave the channel sums of its stored values for that layer's bias gradient (sums: one row [C] per wave,
+ * egne_conv1x1_bf16_multi_waves rows, added by egne_group_sums_reduce in a fixed order). */
+#define EGNE_MAXDST 6
+typedef struct {
+  void* out; int64_t out_pix_stride; int32_t out_ch_off;
+  int32_t C;                    /* channels stored (multiple of 8) */
+  int32_t CoutP;                /* rows of this destination's weight pack (multiple of 32) */
+  const void* wfrag;            /* egne_pack_conv1x1_bf16 fragments for (the input slices, CoutP) */
+  const void* residual; int64_t res_pix_stride; int32_t res_ch_off;      /* optional accumulated tensor (bf16) */
+  const void* mask_y; int64_t mask_pix_stride; int32_t mask_ch_off;      /* optional: activated output whose sign masks the result */
+  int32_t act;                  /* egne_act of that layer */
+  float* sums;                  /* optional [egne_conv1x1_bf16_multi_waves][C] */
+} egne_dst;
+int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* d, int ndst, const egne_dst* dsts);
+int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* d, int ndst, const egne_dst* dsts, void* stream);
+int64_t egne_conv1x1_bf16_multi_waves(const egne_conv_desc* d, int ndst, const egne_dst* dsts);   /* rows of egne_dst.sums the launch writes */
+int egne_group_sums_reduce(const float* sums, int64_t nrows, int ld, int C, float* out /* [C], may be NULL */, double* total /* [C], may be NULL */,
+                           int accumulate, void* stream);
 int egne_conv1x1_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
 const char* egne_last_error(void);
 int egne_version(void);
-int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc */
+int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc, 3 egne_dst */
 
 #ifdef __cplusplus
 }
