@@ -306,21 +306,33 @@ __global__ __launch_bounds__(256) void norm_fuse_partial(const T* __restrict__ x
   if (c < Cp) {
     const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
     const long long nb = (long long)n * npix_per_n;
-    for (long long p = p0 + row; p < p1; p += 2 * ROWS) {        // two rows per trip: their loads are issued together
-      egne_fv<N> xh[2], G[2];
+    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {        // four rows per trip: all their loads are issued before the first use
+      egne_fv<N> xv[4], a1v[4], gqv[4];
+      bool okk[4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const long long q = p + ROWS * u;
-        const bool ok = q < p1;
-        const egne_fv<N> xv = ok ? ldv(x + (nb + q) * xs + xo + c) : fv_fill<N>(0.f);
-#pragma unroll
-        for (int e = 0; e < N; ++e) xh[u].v[e] = xv.v[e] * sc.v[e] + sh.v[e];
-        G[u] = norm_addend_G<T, N>(A, xh[u], nb, (unsigned)q, c, ok);
+        const bool ok = okk[u] = q < p1;
+        xv[u] = ok ? ldv(x + (nb + q) * xs + xo + c) : fv_fill<N>(0.f);
+        a1v[u] = (A.a1 && ok) ? ldv(A.a1 + (nb + q) * A.a1s + A.a1o + c) : fv_fill<N>(0.f);
+        if (A.gq && ok) {
+          const unsigned uq = (unsigned)q, py = uq / (unsigned)A.poolW, px = uq - py * (unsigned)A.poolW;
+          gqv[u] = ldv(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
+        } else {
+          gqv[u] = fv_fill<N>(0.f);
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < N; ++e) { s1[e] += G[u].v[e]; s2[e] += (double)G[u].v[e] * xh[u].v[e]; }
+        for (int e = 0; e < N; ++e) {
+          const float xh = xv[u].v[e] * sc.v[e] + sh.v[e];
+          float ge = 0.25f * gqv[u].v[e];
+          if (A.act_q == EGNE_ACT_LEAKY) ge = xh > 0.f ? ge : 0.01f * ge;
+          else if (A.act_q == EGNE_ACT_RELU) ge = xh > 0.f ? ge : 0.f;
+          const float G = okk[u] ? a1v[u].v[e] + ge : 0.f;
+          s1[e] += G; s2[e] += (double)G * xh;
+        }
     }
   }
   __shared__ double sh_[ROWS][32][2];
@@ -336,58 +348,63 @@ __global__ __launch_bounds__(256) void norm_fuse_partial(const T* __restrict__ x
   }
 }
 
-// gz = act'(y) * (g + rstd * (G - m1 - xh m2)) in place + bias partial sums in the layout of act_bwd_bias_partial (chunks over the
-// flattened (n, pixel) index); y = x: the tensor the gradient belongs to is the one that was normalised
+// gz = act'(y) * (g + rstd * (G - m1 - xh m2)) in place + bias partial sums: one row [Cp] of ws per (sample, chunk) -- every row of ws
+// is summed by the second stages (reduce_chunks_k, egne_pair_bias_bwd), so any partition of the pixels will do; y = x: the tensor
+// the gradient belongs to is the one that was normalised.  Grid (chunks per sample, channel groups, samples): the per-(n, c)
+// coefficients are loaded once per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, long long gs, int go, const T* __restrict__ y, long long ys, int yo,
                                                             int act, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            const float* __restrict__ sums, NormAddends<T> A, int Cp, unsigned HW,
-                                                            long long npix, int nchunk, double* __restrict__ ws) {
+                                                            const float* __restrict__ sums, NormAddends<T> A, int Cp, long long HW,
+                                                            int nps, double* __restrict__ ws) {
   constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
-  const int chunk = blockIdx.x, cg = blockIdx.y;
+  const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
   const int v = threadIdx.x % CV, row = threadIdx.x / CV;
   const int c = cg * 32 + v * N;
-  const long long per = (npix + nchunk - 1) / nchunk;
-  const long long p0 = (long long)chunk * per, p1 = p0 + per < npix ? p0 + per : npix;
+  const long long per = (HW + nps - 1) / nps;
+  const long long p0 = (long long)chunk * per, p1 = p0 + per < HW ? p0 + per : HW;
   const float invN = 1.f / (float)HW;
   double s[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) s[e] = 0;
   if (c < Cp) {
-    for (long long p = p0 + row; p < p1; p += 2 * ROWS) {
-      egne_fv<N> t[2], yy[2], G[2], sc[2], m1[2], m2[2];
-      bool okk[2];
+    const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
+    float m1[N], m2[N];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+    for (int e = 0; e < N; ++e) { m1[e] = sums[2 * ((long long)n * Cp + c + e)] * invN; m2[e] = sums[2 * ((long long)n * Cp + c + e) + 1] * invN; }
+    const long long nb = (long long)n * HW;
+    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {
+      egne_fv<N> t[4], yy[4], a1v[4], gqv[4];
+      bool okk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
         const long long q = p + ROWS * u;
         const bool ok = okk[u] = q < p1;
-        const unsigned n = ok ? (unsigned)((unsigned long long)q / HW) : 0u;        // (npix < 2^32: checked by the entry point)
-        const unsigned qq = (unsigned)(q - (long long)n * HW);
-        t[u] = ok ? ldv(g + q * gs + go + c) : fv_fill<N>(0.f);
-        yy[u] = ok ? ldv(y + q * ys + yo + c) : fv_fill<N>(0.f);
-        sc[u] = ldf<N>(scale + (long long)n * Cp + c);
-        const egne_fv<N> shv = ldf<N>(shift + (long long)n * Cp + c);
-        egne_fv<N> xh;
-#pragma unroll
-        for (int e = 0; e < N; ++e) xh.v[e] = yy[u].v[e] * sc[u].v[e] + shv.v[e];
-        G[u] = norm_addend_G<T, N>(A, xh, (long long)n * HW, qq, c, ok);
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const float a = sums[2 * ((long long)n * Cp + c + e)] * invN, b = sums[2 * ((long long)n * Cp + c + e) + 1] * invN;
-          G[u].v[e] = sc[u].v[e] * (G[u].v[e] - a - xh.v[e] * b);
+        t[u] = ok ? ldv(g + (nb + q) * gs + go + c) : fv_fill<N>(0.f);
+        yy[u] = ok ? ldv(y + (nb + q) * ys + yo + c) : fv_fill<N>(0.f);
+        a1v[u] = (A.a1 && ok) ? ldv(A.a1 + (nb + q) * A.a1s + A.a1o + c) : fv_fill<N>(0.f);
+        if (A.gq && ok) {
+          const unsigned uq = (unsigned)q, py = uq / (unsigned)A.poolW, px = uq - py * (unsigned)A.poolW;
+          gqv[u] = ldv(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
+        } else {
+          gqv[u] = fv_fill<N>(0.f);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const long long q = p + ROWS * u;
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-          float r = t[u].v[e] + G[u].v[e];
+          const float xh = yy[u].v[e] * sc.v[e] + sh.v[e];
+          float ge = 0.25f * gqv[u].v[e];
+          if (A.act_q == EGNE_ACT_LEAKY) ge = xh > 0.f ? ge : 0.01f * ge;
+          else if (A.act_q == EGNE_ACT_RELU) ge = xh > 0.f ? ge : 0.f;
+          float r = t[u].v[e] + sc.v[e] * (a1v[u].v[e] + ge - m1[e] - xh * m2[e]);
           if (act == EGNE_ACT_LEAKY) r = yy[u].v[e] > 0.f ? r : 0.01f * r;
           else if (act == EGNE_ACT_RELU) r = yy[u].v[e] > 0.f ? r : 0.f;
           t[u].v[e] = okk[u] ? r : 0.f;
         }
-        if (okk[u]) stv(g + q * gs + go + c, t[u]);
+        if (okk[u]) stv(g + (nb + q) * gs + go + c, t[u]);
 #pragma unroll
         for (int e = 0; e < N; ++e) s[e] += t[u].v[e];
       }
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, l
     double a = 0;
     for (int r = 0; r < ROWS; ++r) a += sh[r][threadIdx.x];
     const int cc = cg * 32 + threadIdx.x;
-    if (cc < Cp) ws[(long long)chunk * Cp + cc] = a;
+    if (cc < Cp) ws[((long long)n * nps + chunk) * Cp + cc] = a;
   }
 }
 
@@ -1460,9 +1477,13 @@ static int act_norm_bwd_impl(T* g, int64_t gs, int go, const T* x, int64_t xs, i
   hipLaunchKernelGGL(norm_fuse_partial<T>, dim3(nchunk, (Cp + 31) / 32, B), dim3(256), 0, st, x, (long long)xs, xo, scale, shift, A, Cp, HW, nchunk, (double*)ws_norm);
   hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, B), dim3(1024), 0, st, (const double*)ws_norm, Cp, B, nchunk, sums,
                      (float*)nullptr, (float*)nullptr, 0);
+  // ws_bias holds chunks_for(B H W) rows (egne_act_bwd_bias_workspace_bytes: what egne_pair_bias_bwd / the reduction below sum over): nps
+  // chunks per sample fill the first B * nps of them, the rest stay zero (the caller's zero-filled allocation is never written there)
   const int nchb = chunks_for(npix, Cp, 1);
-  hipLaunchKernelGGL(act_norm_bwd_partial<T>, dim3(nchb, (Cp + 31) / 32), dim3(256), 0, st, g, (long long)gs, go, x, (long long)xs, xo, act, scale, shift,
-                     (const float*)sums, A, Cp, (unsigned)HW, npix, nchb, (double*)ws_bias);
+  EGNE_REQUIRE(B <= nchb, "act_norm_bwd: %d samples for %d partial-sum rows", B, nchb);
+  const int nps = nchb / B;
+  hipLaunchKernelGGL(act_norm_bwd_partial<T>, dim3(nps, (Cp + 31) / 32, B), dim3(256), 0, st, g, (long long)gs, go, x, (long long)xs, xo, act, scale, shift,
+                     (const float*)sums, A, Cp, HW, nps, (double*)ws_bias);
   if (dbias) hipLaunchKernelGGL(reduce_chunks_k, dim3((C + 31) / 32), dim3(1024), 0, st, (const double*)ws_bias, Cp, C, nchb, dbias, 1);
   return egne::check_launch("egne_act_norm_bwd");
 }

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 if [ "$only" = all ] || [ "$only" = bench ]; then
 python3 $R/bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo bench done
 python3 $R/bench.py --mode train --steps 4 --warmup 2 --train-batch 256 --train-storage bf16 --force-dist 2>/dev/null | grep "^{" > $out/bench_train_b256_bf16_rccl1.json
+python3 $R/bench.py --mode train --steps 4 --warmup 2 --train-batch 256 --train-storage bf16 --force-dist --no-pipeline 2>/dev/null | grep "^{" > $out/bench_train_b256_bf16_rccl1_nopipe.json
 python3 $R/bench.py --mode train --steps 4 --warmup 2 --train-batch 256 --config baseline_adain_edge --train-storage bf16 > $out/bench_train_adain_bf16.json 2>/dev/null; echo adain done
 python3 $R/bench.py --mode train --steps 4 --warmup 2 --train-batch 256 --chz 64 --train-storage bf16 > $out/bench_train_chz64_bf16.json 2>/dev/null
 python3 $R/bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline --layers > $out/bench_layers.json 2> $out/per_layer_table.txt
