@@ -306,33 +306,36 @@ __global__ __launch_bounds__(256) void norm_fuse_partial(const T* __restrict__ x
   if (c < Cp) {
     const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
     const long long nb = (long long)n * npix_per_n;
-    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {        // four rows per trip: all their loads are issued before the first use
-      egne_fv<N> xv[4], a1v[4], gqv[4];
-      bool okk[4];
+    const T* const tag = nullptr;
+    for (long long p = p0 + row; p < p1; p += 2 * ROWS) {        // two rows per trip, loads kept packed (16 bytes = 4 registers per tensor and row)
+      egne_u32x4 xv[2], a1v[2], gqv[2];
+      bool okk[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const long long q = p + ROWS * u;
         const bool ok = okk[u] = q < p1;
-        xv[u] = ok ? ldv(x + (nb + q) * xs + xo + c) : fv_fill<N>(0.f);
-        a1v[u] = (A.a1 && ok) ? ldv(A.a1 + (nb + q) * A.a1s + A.a1o + c) : fv_fill<N>(0.f);
+        xv[u] = ok ? ldraw(x + (nb + q) * xs + xo + c) : egne_u32x4{0u, 0u, 0u, 0u};
+        a1v[u] = (A.a1 && ok) ? ldraw(A.a1 + (nb + q) * A.a1s + A.a1o + c) : egne_u32x4{0u, 0u, 0u, 0u};
         if (A.gq && ok) {
           const unsigned uq = (unsigned)q, py = uq / (unsigned)A.poolW, px = uq - py * (unsigned)A.poolW;
-          gqv[u] = ldv(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
+          gqv[u] = ldraw(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
         } else {
-          gqv[u] = fv_fill<N>(0.f);
+          gqv[u] = egne_u32x4{0u, 0u, 0u, 0u};
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 2; ++u) {
+        const egne_fv<N> xf = unpackv(tag, xv[u]), af = unpackv(tag, a1v[u]), gf = unpackv(tag, gqv[u]);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-          const float xh = xv[u].v[e] * sc.v[e] + sh.v[e];
-          float ge = 0.25f * gqv[u].v[e];
+          const float xh = xf.v[e] * sc.v[e] + sh.v[e];
+          float ge = 0.25f * gf.v[e];
           if (A.act_q == EGNE_ACT_LEAKY) ge = xh > 0.f ? ge : 0.01f * ge;
           else if (A.act_q == EGNE_ACT_RELU) ge = xh > 0.f ? ge : 0.f;
-          const float G = okk[u] ? a1v[u].v[e] + ge : 0.f;
+          const float G = okk[u] ? af.v[e] + ge : 0.f;
           s1[e] += G; s2[e] += (double)G * xh;
         }
+      }
     }
   }
   __shared__ double sh_[ROWS][32][2];
@@ -369,44 +372,47 @@ __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, l
   for (int e = 0; e < N; ++e) s[e] = 0;
   if (c < Cp) {
     const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
-    float m1[N], m2[N];
+    float k1[N], k2[N];            // sc * mean(G), sc * mean(G xh): r = g + sc (a1 + ge) - k1 - xh k2
 #pragma unroll
-    for (int e = 0; e < N; ++e) { m1[e] = sums[2 * ((long long)n * Cp + c + e)] * invN; m2[e] = sums[2 * ((long long)n * Cp + c + e) + 1] * invN; }
+    for (int e = 0; e < N; ++e) { k1[e] = sc.v[e] * sums[2 * ((long long)n * Cp + c + e)] * invN; k2[e] = sc.v[e] * sums[2 * ((long long)n * Cp + c + e) + 1] * invN; }
     const long long nb = (long long)n * HW;
-    for (long long p = p0 + row; p < p1; p += 4 * ROWS) {
-      egne_fv<N> t[4], yy[4], a1v[4], gqv[4];
-      bool okk[4];
+    const T* const tag = nullptr;
+    for (long long p = p0 + row; p < p1; p += 2 * ROWS) {        // two rows per trip, loads kept packed
+      egne_u32x4 t[2], yy[2], a1v[2], gqv[2];
+      bool okk[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const long long q = p + ROWS * u;
         const bool ok = okk[u] = q < p1;
-        t[u] = ok ? ldv(g + (nb + q) * gs + go + c) : fv_fill<N>(0.f);
-        yy[u] = ok ? ldv(y + (nb + q) * ys + yo + c) : fv_fill<N>(0.f);
-        a1v[u] = (A.a1 && ok) ? ldv(A.a1 + (nb + q) * A.a1s + A.a1o + c) : fv_fill<N>(0.f);
+        t[u] = ok ? ldraw(g + (nb + q) * gs + go + c) : egne_u32x4{0u, 0u, 0u, 0u};
+        yy[u] = ok ? ldraw(y + (nb + q) * ys + yo + c) : egne_u32x4{0u, 0u, 0u, 0u};
+        a1v[u] = (A.a1 && ok) ? ldraw(A.a1 + (nb + q) * A.a1s + A.a1o + c) : egne_u32x4{0u, 0u, 0u, 0u};
         if (A.gq && ok) {
           const unsigned uq = (unsigned)q, py = uq / (unsigned)A.poolW, px = uq - py * (unsigned)A.poolW;
-          gqv[u] = ldv(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
+          gqv[u] = ldraw(A.gq + ((nb >> 2) + (long long)(py >> 1) * (A.poolW >> 1) + (px >> 1)) * A.gqs + A.gqo + c);
         } else {
-          gqv[u] = fv_fill<N>(0.f);
+          gqv[u] = egne_u32x4{0u, 0u, 0u, 0u};
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const long long q = p + ROWS * u;
+        const egne_fv<N> tf = unpackv(tag, t[u]), yf = unpackv(tag, yy[u]), af = unpackv(tag, a1v[u]), gf = unpackv(tag, gqv[u]);
+        egne_fv<N> o;
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-          const float xh = yy[u].v[e] * sc.v[e] + sh.v[e];
-          float ge = 0.25f * gqv[u].v[e];
+          const float xh = yf.v[e] * sc.v[e] + sh.v[e];
+          float ge = 0.25f * gf.v[e];
           if (A.act_q == EGNE_ACT_LEAKY) ge = xh > 0.f ? ge : 0.01f * ge;
           else if (A.act_q == EGNE_ACT_RELU) ge = xh > 0.f ? ge : 0.f;
-          float r = t[u].v[e] + sc.v[e] * (a1v[u].v[e] + ge - m1[e] - xh * m2[e]);
-          if (act == EGNE_ACT_LEAKY) r = yy[u].v[e] > 0.f ? r : 0.01f * r;
-          else if (act == EGNE_ACT_RELU) r = yy[u].v[e] > 0.f ? r : 0.f;
-          t[u].v[e] = okk[u] ? r : 0.f;
+          float r = tf.v[e] + sc.v[e] * (af.v[e] + ge) - k1[e] - xh * k2[e];
+          if (act == EGNE_ACT_LEAKY) r = yf.v[e] > 0.f ? r : 0.01f * r;
+          else if (act == EGNE_ACT_RELU) r = yf.v[e] > 0.f ? r : 0.f;
+          o.v[e] = okk[u] ? r : 0.f;
         }
-        if (okk[u]) stv(g + (nb + q) * gs + go + c, t[u]);
+        if (okk[u]) stv(g + (nb + q) * gs + go + c, o);
 #pragma unroll
-        for (int e = 0; e < N; ++e) s[e] += t[u].v[e];
+        for (int e = 0; e < N; ++e) s[e] += o.v[e];
       }
     }
   }

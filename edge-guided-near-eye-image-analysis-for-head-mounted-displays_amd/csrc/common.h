@@ -54,6 +54,22 @@ __device__ __forceinline__ void stv(egne_bf16* p, const egne_fv<8>& a) {
   const egne_bf16x4 l = __builtin_convertvector(lo, egne_bf16x4), h = __builtin_convertvector(hi, egne_bf16x4);
   *(egne_bf16x8*)p = egne_bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
 }
+// the same 16-byte vector kept PACKED (four dwords) until it is used: streaming kernels with several tensors and rows in flight hold
+// their loads this way (eight bf16 channels unpacked are eight registers)
+typedef unsigned egne_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ egne_u32x4 ldraw(const T* p) { return *(const egne_u32x4*)p; }
+__device__ __forceinline__ egne_fv<4> unpackv(const float*, egne_u32x4 w) {
+  return egne_fv<4>{{__builtin_bit_cast(float, w[0]), __builtin_bit_cast(float, w[1]), __builtin_bit_cast(float, w[2]), __builtin_bit_cast(float, w[3])}};
+}
+__device__ __forceinline__ egne_fv<8> unpackv(const egne_bf16*, egne_u32x4 w) {
+  egne_fv<8> r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+    r.v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+  }
+  return r;
+}
 template <int N> __device__ __forceinline__ egne_fv<N> ldf(const float* p) {      // N consecutive fp32 table entries
   egne_fv<N> r;
 #pragma unroll
