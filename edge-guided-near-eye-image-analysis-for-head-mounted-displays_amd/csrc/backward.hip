@@ -293,7 +293,8 @@ __device__ __forceinline__ egne_fv<N> norm_addend_G(const NormAddends<T>& A, con
 template <typename T>
 __global__ __launch_bounds__(256) void norm_fuse_partial(const T* __restrict__ x, long long xs, int xo, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, NormAddends<T> A, int Cp, long long npix_per_n,
-                                                         int nchunk, double* __restrict__ ws) {
+                                                         int nchunk, double* __restrict__ ws, int per_sample) {
+  // per_sample = 0: batch statistics (BatchNorm): one (scale, shift) row for all samples; the rows of ws are then summed over n too
   constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
   const int v = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void norm_fuse_partial(const T* __restrict__ x
 #pragma unroll
   for (int e = 0; e < N; ++e) { s1[e] = 0; s2[e] = 0; }
   if (c < Cp) {
-    const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
+    const long long tr = per_sample ? n : 0;
+    const egne_fv<N> sc = ldf<N>(scale + tr * Cp + c), sh = ldf<N>(shift + tr * Cp + c);
     const long long nb = (long long)n * npix_per_n;
     const T* const tag = nullptr;
     for (long long p = p0 + row; p < p1; p += 2 * ROWS) {        // two rows per trip, loads kept packed (16 bytes = 4 registers per tensor and row)
@@ -359,22 +361,28 @@ template <typename T>
 __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, long long gs, int go, const T* __restrict__ y, long long ys, int yo,
                                                             int act, const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ sums, NormAddends<T> A, int Cp, long long HW,
-                                                            int nps, double* __restrict__ ws) {
+                                                            int nps, double* __restrict__ ws, int per_sample, const float* __restrict__ gamma,
+                                                            float invN, int accumulate) {
+  // per_sample = 0 (BatchNorm): one row of scale / shift / sums for the whole batch, invN = 1 / (B HW), gamma scales the result;
+  // accumulate = 0: g is written, not read (the normalisation's backward is the only source of this gradient)
   constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
   const int v = threadIdx.x % CV, row = threadIdx.x / CV;
   const int c = cg * 32 + v * N;
   const long long per = (HW + nps - 1) / nps;
   const long long p0 = (long long)chunk * per, p1 = p0 + per < HW ? p0 + per : HW;
-  const float invN = 1.f / (float)HW;
   double s[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) s[e] = 0;
   if (c < Cp) {
-    const egne_fv<N> sc = ldf<N>(scale + (long long)n * Cp + c), sh = ldf<N>(shift + (long long)n * Cp + c);
-    float k1[N], k2[N];            // sc * mean(G), sc * mean(G xh): r = g + sc (a1 + ge) - k1 - xh k2
+    const long long tr = per_sample ? n : 0;
+    const egne_fv<N> sc = ldf<N>(scale + tr * Cp + c), sh = ldf<N>(shift + tr * Cp + c);
+    float k0[N], k1[N], k2[N];     // sc gamma, sc gamma mean(G), sc gamma mean(G xh): r = g + k0 (a1 + ge) - k1 - xh k2
 #pragma unroll
-    for (int e = 0; e < N; ++e) { k1[e] = sc.v[e] * sums[2 * ((long long)n * Cp + c + e)] * invN; k2[e] = sc.v[e] * sums[2 * ((long long)n * Cp + c + e) + 1] * invN; }
+    for (int e = 0; e < N; ++e) {
+      k0[e] = sc.v[e] * (gamma ? gamma[c + e] : 1.f);
+      k1[e] = k0[e] * sums[2 * (tr * Cp + c + e)] * invN; k2[e] = k0[e] * sums[2 * (tr * Cp + c + e) + 1] * invN;
+    }
     const long long nb = (long long)n * HW;
     const T* const tag = nullptr;
     for (long long p = p0 + row; p < p1; p += 2 * ROWS) {        // two rows per trip, loads kept packed
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, l
       for (int u = 0; u < 2; ++u) {
         const long long q = p + ROWS * u;
         const bool ok = okk[u] = q < p1;
-        t[u] = ok ? ldraw(g + (nb + q) * gs + go + c) : egne_u32x4{0u, 0u, 0u, 0u};
+        t[u] = (ok && accumulate) ? ldraw(g + (nb + q) * gs + go + c) : egne_u32x4{0u, 0u, 0u, 0u};
         yy[u] = ok ? ldraw(y + (nb + q) * ys + yo + c) : egne_u32x4{0u, 0u, 0u, 0u};
         a1v[u] = (A.a1 && ok) ? ldraw(A.a1 + (nb + q) * A.a1s + A.a1o + c) : egne_u32x4{0u, 0u, 0u, 0u};
         if (A.gq && ok) {
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, l
           float ge = 0.25f * gf.v[e];
           if (A.act_q == EGNE_ACT_LEAKY) ge = xh > 0.f ? ge : 0.01f * ge;
           else if (A.act_q == EGNE_ACT_RELU) ge = xh > 0.f ? ge : 0.f;
-          float r = tf.v[e] + sc.v[e] * (af.v[e] + ge) - k1[e] - xh * k2[e];
+          float r = tf.v[e] + k0[e] * (af.v[e] + ge) - k1[e] - xh * k2[e];
           if (act == EGNE_ACT_LEAKY) r = yf.v[e] > 0.f ? r : 0.01f * r;
           else if (act == EGNE_ACT_RELU) r = yf.v[e] > 0.f ? r : 0.f;
           o.v[e] = okk[u] ? r : 0.f;
@@ -1470,7 +1478,8 @@ extern "C" int egne_norm_pool2_bwd_bf16(const void* x, int64_t xs, int xo, const
 template <typename T>
 static int act_norm_bwd_impl(T* g, int64_t gs, int go, const T* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
                              const T* a1, int64_t a1s, int a1o, const T* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
-                             float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
+                             float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream,
+                             int per_sample = 1, const float* gamma = nullptr, float* dgamma = nullptr, float* dbeta = nullptr, int Cn = 0, int accumulate = 1) {
   EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && slice_ok(x, xs, xo, Cp) && scale && shift && sums && ws_norm && ws_bias && (a1 || gq), "act_norm_bwd: bad arguments");
   EGNE_REQUIRE(vec_ok<T>(gs, go, Cp) && vec_ok<T>(xs, xo, Cp) && (!a1 || vec_ok<T>(a1s, a1o, Cp)) && (!gq || vec_ok<T>(gqs, gqo, Cp)),
                "act_norm_bwd: slices must be 16-byte vectors (8 bf16 channels)");
@@ -1480,16 +1489,17 @@ static int act_norm_bwd_impl(T* g, int64_t gs, int go, const T* x, int64_t xs, i
   NormAddends<T> A{a1, (long long)a1s, a1o, gq, (long long)gqs, gqo, W, act_q};
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = chunks_for(HW, Cp, B);
-  hipLaunchKernelGGL(norm_fuse_partial<T>, dim3(nchunk, (Cp + 31) / 32, B), dim3(256), 0, st, x, (long long)xs, xo, scale, shift, A, Cp, HW, nchunk, (double*)ws_norm);
-  hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, B), dim3(1024), 0, st, (const double*)ws_norm, Cp, B, nchunk, sums,
-                     (float*)nullptr, (float*)nullptr, 0);
+  hipLaunchKernelGGL(norm_fuse_partial<T>, dim3(nchunk, (Cp + 31) / 32, B), dim3(256), 0, st, x, (long long)xs, xo, scale, shift, A, Cp, HW, nchunk, (double*)ws_norm, per_sample);
+  // batch statistics: the B x nchunk rows are one sample's worth of chunks for the second stage (which also adds dgamma / dbeta)
+  if (per_sample) hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, B), dim3(1024), 0, st, (const double*)ws_norm, Cp, B, nchunk, sums, (float*)nullptr, (float*)nullptr, 0);
+  else hipLaunchKernelGGL(norm_bwd_final, dim3((Cp + 31) / 32, 1), dim3(1024), 0, st, (const double*)ws_norm, Cp, 1, B * nchunk, sums, dgamma, dbeta, Cn);
   // ws_bias holds chunks_for(B H W) rows (egne_act_bwd_bias_workspace_bytes: what egne_pair_bias_bwd / the reduction below sum over): nps
   // chunks per sample fill the first B * nps of them, the rest stay zero (the caller's zero-filled allocation is never written there)
   const int nchb = chunks_for(npix, Cp, 1);
   EGNE_REQUIRE(B <= nchb, "act_norm_bwd: %d samples for %d partial-sum rows", B, nchb);
   const int nps = nchb / B;
   hipLaunchKernelGGL(act_norm_bwd_partial<T>, dim3(nps, (Cp + 31) / 32, B), dim3(256), 0, st, g, (long long)gs, go, x, (long long)xs, xo, act, scale, shift,
-                     (const float*)sums, A, Cp, HW, nps, (double*)ws_bias);
+                     (const float*)sums, A, Cp, HW, nps, (double*)ws_bias, per_sample, gamma, per_sample ? 1.f / (float)HW : 1.f / ((float)HW * (float)B), accumulate);
   if (dbias) hipLaunchKernelGGL(reduce_chunks_k, dim3((C + 31) / 32), dim3(1024), 0, st, (const double*)ws_bias, Cp, C, nchb, dbias, 1);
   return egne::check_launch("egne_act_norm_bwd");
 }
@@ -1503,6 +1513,30 @@ extern "C" int egne_act_norm_bwd_bf16(void* g, int64_t gs, int go, const void* x
                                       float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
   return act_norm_bwd_impl((egne_bf16*)g, gs, go, (const egne_bf16*)x, xs, xo, act, scale, shift, (const egne_bf16*)a1, a1s, a1o, (const egne_bf16*)gq, gqs, gqo,
                            act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream);
+}
+
+// BatchNorm backward (training-mode batch statistics over B samples: utils.py:1049) with the masking pass of the layer in front of it
+// (round 5): gz = act'(x) rstd gamma (gy - mean gy - xh mean(gy xh)) written over gx, x = that layer's activated output = the
+// BatchNorm's input; dgamma += sum gy xh, dbeta += sum gy; the layer's bias sums as egne_act_bwd_bias leaves them (ws_bias chunk
+// sums; dbias += their total when given).  Replaces egne_norm_bwd + egne_act_bwd_bias.
+template <typename T>
+static int bn_act_bwd_impl(const T* x, int64_t xs, int xo, int act, const float* scale, const float* shift, const float* gamma, const T* gy, int64_t gys, int gyo,
+                           int Cp, int B, int H, int W, T* gx, int64_t gxs, int gxo, float* sums, void* ws_norm, float* dgamma, float* dbeta, int Cn,
+                           float* dbias, int C, void* ws_bias, void* stream) {
+  EGNE_REQUIRE(gy && gx && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_bwd: bad arguments");
+  return act_norm_bwd_impl(gx, gxs, gxo, x, xs, xo, act, scale, shift, gy, gys, gyo, (const T*)nullptr, 0, 0, EGNE_ACT_NONE, Cp, B, H, W, sums, ws_norm, dbias, C,
+                           ws_bias, stream, 0, gamma, dgamma, dbeta, Cn, 0);
+}
+extern "C" int egne_bn_act_bwd(const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift, const float* gamma, const float* gy, int64_t gys,
+                               int gyo, int Cp, int B, int H, int W, float* gx, int64_t gxs, int gxo, float* sums, void* ws_norm, float* dgamma, float* dbeta,
+                               int Cn, float* dbias, int C, void* ws_bias, void* stream) {
+  return bn_act_bwd_impl(x, xs, xo, act, scale, shift, gamma, gy, gys, gyo, Cp, B, H, W, gx, gxs, gxo, sums, ws_norm, dgamma, dbeta, Cn, dbias, C, ws_bias, stream);
+}
+extern "C" int egne_bn_act_bwd_bf16(const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift, const float* gamma, const void* gy, int64_t gys,
+                                    int gyo, int Cp, int B, int H, int W, void* gx, int64_t gxs, int gxo, float* sums, void* ws_norm, float* dgamma, float* dbeta,
+                                    int Cn, float* dbias, int C, void* ws_bias, void* stream) {
+  return bn_act_bwd_impl((const egne_bf16*)x, xs, xo, act, scale, shift, gamma, (const egne_bf16*)gy, gys, gyo, Cp, B, H, W, (egne_bf16*)gx, gxs, gxo, sums, ws_norm,
+                         dgamma, dbeta, Cn, dbias, C, ws_bias, stream);
 }
 
 template <typename T>

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256)
 void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M, int sum_dst, int nks) {
   constexpr int LDP = 64 + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  egne_bf16* const lw = (egne_bf16*)smem;                               // [NKS][nbt][64 lanes][8]
-  float* const tile = (float*)(smem + (size_t)NKS * nbt * 1024) + (threadIdx.x >> 6) * 32 * LDP;
+  egne_bf16* const lw = (egne_bf16*)smem;                               // [nks][nbt][64 lanes][8]
+  // (behind the nks k-steps the launch allocated, not the NKS of the instantiation: NKS = 6 / 8 also serve 5 / 7 k-steps)
+  float* const tile = (float*)(smem + (size_t)nks * nbt * 1024) + (threadIdx.x >> 6) * 32 * LDP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int l15 = lane & 15, kg = lane >> 4;
   for (int d = 0; d < ndst; ++d) {

@@ -152,6 +152,96 @@ def test_conv1x1_bf16_streaming(G, chans, Cout, B, H, W, act, res):
     _check(got, want, "conv1x1_bf16")
 
 
+@pytest.mark.parametrize("Cs,dsts,B,H,W", [
+    (32, ((32, False, 0, False), (32, True, 2, True)), 2, 48, 64),                     # one k-step; second destination: residual + mask + sums
+    (64, ((38, False, 0, False), (64, False, 2, True), (64, True, 0, False)), 2, 61, 35),   # padded slice (40 of 64), pixel count not a multiple of 32
+    (104, ((102, True, 1, True), (100, False, 0, False)), 1, 60, 80),                  # four k-steps (the last one 8 channels), 128-channel destinations
+    (160, ((128, False, 2, False), (115, False, 0, False)), 64, 15, 20),               # FIVE k-steps on the six-step instantiation: b3.TD's data gradient (300 pixels per frame)
+    (192, ((64, False, 0, False), (32, True, 2, True)), 3, 30, 40),                    # six k-steps
+    (200, ((64, True, 2, True), (38, False, 0, False)), 2, 30, 40),                    # SEVEN k-steps on the eight-step instantiation
+    (256, ((32, False, 0, False), (32, False, 2, False)), 2, 30, 40),                  # eight k-steps
+])
+def test_conv1x1_bf16_multi_destinations(G, Cs, dsts, B, H, W):
+    """egne_conv1x1_bf16_multi_fwd (round 5): the per-member data gradients of a 1x1 over a would-be torch.cat (models/RITnet_v2.py:
+    59-61,85-86) as ONE launch over the same gz, with the accumulated residual, the activation mask of the destination's layer and
+    the per-wave channel sums, against float64 on the same bf16 tensors.  Every k-step count 1..8 the kernel serves is here: five
+    and seven run on the six- and eight-step instantiations (their LDS tile sits behind the k-steps the LAUNCH allocated)."""
+    import ctypes as C
+    from egne_amd import _lib
+    from egne_amd.engine import pad8, pad32
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    M = B * H * W
+    Csp = pad8(Cs)
+    gz = torch.zeros(M, Csp + 8, dtype=BF, device=DEV)
+    gzv = _q(_rand(G, M, Cs))
+    gz[:, 8:8 + Cs] = gzv.to(DEV).to(BF)
+    dm = _lib.ConvDesc()
+    dm.dtype = 1
+    dm.B, dm.H, dm.W, dm.Ho, dm.Wo = B, H, W, H, W
+    dm.kh = dm.kw = dm.stride = dm.ngroups = 1
+    for g_ in range(_lib.MAXGROUP):
+        dm.dil[g_] = 1
+    dm.nseg = 1
+    dm.seg[0].ptr, dm.seg[0].pix_stride, dm.seg[0].ch_off, dm.seg[0].Cp = gz.data_ptr(), Csp + 8, 8, Csp
+    dm.Ktot = Csp
+    arr = (_lib.Dst * len(dsts))()
+    keep, want, outs = [], [], []
+    for j, (Cd, res, act, sums) in enumerate(dsts):
+        Cp, CoutP = pad8(Cd), pad32(Cd)
+        w = _rand(G, Cd, Cs) / Cs ** 0.5
+        wflat = torch.zeros(CoutP, Csp)
+        wflat[:Cd, :Cs] = w
+        wflat = wflat.to(DEV)
+        dp = _lib.ConvDesc()
+        dp.nseg, dp.CoutP, dp.Ktot = 1, CoutP, Csp
+        dp.seg[0].Cp = Csp
+        n = int(L.egne_conv1x1_bf16_pack_elems(C.byref(dp)))
+        assert n > 0
+        frag = torch.empty(n, dtype=BF, device=DEV)
+        info = torch.tensor([0, Csp], dtype=torch.int32, device=DEV)
+        _lib.check(L.egne_pack_conv1x1_bf16(C.byref(dp), wflat.data_ptr(), info.data_ptr(), frag.data_ptr(), st), "pack")
+        out = torch.full((M, Cp + 16), 768.0, dtype=BF, device=DEV)
+        r0 = _q(_rand(G, M, Cp))
+        if res:
+            out[:, 8:8 + Cp] = r0.to(DEV).to(BF)
+        y = _q(_rand(G, M, Cp))
+        yb = y.to(DEV).to(BF)
+        q = arr[j]
+        q.out, q.out_pix_stride, q.out_ch_off, q.C, q.CoutP, q.wfrag = out.data_ptr(), Cp + 16, 8, Cp, CoutP, frag.data_ptr()
+        if res:
+            q.residual, q.res_pix_stride, q.res_ch_off = out.data_ptr(), Cp + 16, 8
+        if act:
+            q.mask_y, q.mask_pix_stride, q.mask_ch_off, q.act = yb.data_ptr(), Cp, 0, act
+        sm = None
+        if sums:
+            nrows = int(L.egne_conv1x1_bf16_multi_waves(C.byref(dm), len(dsts), arr))
+            assert nrows > 0
+            sm = torch.full((nrows, Cp), float("nan"), device=DEV)
+            q.sums = sm.data_ptr()
+        wd = torch.zeros(Cp, Cs, dtype=torch.float64)
+        wd[:Cd] = _q(w).double()
+        t = gzv.double() @ wd.t()
+        if res:
+            t = t + r0.double()
+        if act:
+            t = torch.where(y.double() > 0, t, t * (0.0 if act == 1 else 0.01))
+        want.append(t)
+        outs.append((out, Cp, sm))
+        keep += [wflat, frag, info, yb]
+    assert int(L.egne_conv1x1_bf16_multi_supported(C.byref(dm), len(dsts), arr))
+    _lib.check(L.egne_conv1x1_bf16_multi_fwd(C.byref(dm), len(dsts), arr, st), "multi")
+    torch.cuda.synchronize()
+    for j, ((out, Cp, sm), t) in enumerate(zip(outs, want)):
+        o = out.float().cpu()
+        assert (o[:, :8] == 768.0).all() and (o[:, 8 + Cp:] == 768.0).all(), "destination %d: wrote outside its slice" % j
+        _check(o[:, 8:8 + Cp], t, "multi destination %d" % j)
+        if sm is not None:      # sums of what was stored (bf16-rounded), one row per wave
+            tot = sm.double().sum(0).cpu()
+            ref = o[:, 8:8 + Cp].double().sum(0)
+            assert torch.isfinite(tot).all() and (tot - ref).abs().max().item() <= 1e-5 * o[:, 8:8 + Cp].double().abs().sum(0).max().item(), "channel sums of destination %d" % j
+
+
 def test_conv_generic_bf16_storage(G):
     """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
     slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
