@@ -44,7 +44,7 @@ class Dst(C.Structure):
     _fields_ = [("out", C.c_void_p), ("out_pix_stride", C.c_int64), ("out_ch_off", C.c_int32), ("C", C.c_int32), ("CoutP", C.c_int32),
                 ("wfrag", C.c_void_p), ("residual", C.c_void_p), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
                 ("mask_y", C.c_void_p), ("mask_pix_stride", C.c_int64), ("mask_ch_off", C.c_int32), ("act", C.c_int32),
-                ("sums", C.c_void_p)]
+                ("sums", C.c_void_p), ("res_pixels", C.c_int64)]
 
 
 MAXDST = 6
@@ -135,7 +135,8 @@ SIGNATURES = {
     "egne_act_bwd_bias_workspace_bytes": (i64, [i64, i32]),
     "egne_act_bwd_bias": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp]),
     "egne_act_bwd_bias_absmax": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i64, vp, i32, i32, vp, vp, vp]),
-    "egne_act_norm_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
+    "egne_act_norm_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, vp]),
+    "egne_bn_act_bwd": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp]),
     "egne_zero_many": (i32, [vp, i32, i64, vp]),
     "egne_pair_bias_bwd_workspace_bytes": (i64, [i32, i32]),
     "egne_pair_bias_bwd": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
@@ -171,7 +172,7 @@ SIGNATURES = {
 # the storage type in egne_conv_desc.dtype instead.
 BF16_TWINS = ["egne_upsample2x_nearest", "egne_upsample2x_nearest_bwd", "egne_norm_stats", "egne_affine", "egne_avgpool2", "egne_norm_act_pool2", "egne_upsample2x", "egne_nchw_to_nhwc",
               "egne_ellipse_head_act", "egne_selu_inplace", "egne_spatial_mean", "egne_softmax3", "egne_adain", "egne_conf_loss",
-              "egne_loss_bwd", "egne_act_bwd_bias", "egne_act_norm_bwd", "egne_pair_bias_bwd", "egne_norm_pool2_bwd", "egne_norm_bwd_store", "egne_norm_bwd",
+              "egne_loss_bwd", "egne_act_bwd_bias", "egne_act_norm_bwd", "egne_bn_act_bwd", "egne_pair_bias_bwd", "egne_norm_pool2_bwd", "egne_norm_bwd_store", "egne_norm_bwd",
               "egne_avgpool2_bwd", "egne_upsample2x_bwd", "egne_ellipse_head_act_bwd", "egne_selu_bwd", "egne_softmax3_bwd",
               "egne_adain_bwd", "egne_reflect_pad_bwd", "egne_spatial_mean_bwd", "egne_conf_loss_bwd"]
 for _n in BF16_TWINS:

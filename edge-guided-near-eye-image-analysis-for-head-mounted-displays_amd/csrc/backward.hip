@@ -362,9 +362,10 @@ __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, l
                                                             int act, const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ sums, NormAddends<T> A, int Cp, long long HW,
                                                             int nps, double* __restrict__ ws, int per_sample, const float* __restrict__ gamma,
-                                                            float invN, int accumulate) {
+                                                            float invN, int acc_n) {
   // per_sample = 0 (BatchNorm): one row of scale / shift / sums for the whole batch, invN = 1 / (B HW), gamma scales the result;
-  // accumulate = 0: g is written, not read (the normalisation's backward is the only source of this gradient)
+  // acc_n: g of samples n < acc_n is read and accumulated onto, g of the others is written only (the normalisation's backward is
+  // the only source of their gradient: 0 for a BatchNorm's input, the image half of the batch for an encoder tensor the decoder reads)
   constexpr int N = egne_vt<T>::N, CV = 32 / N, ROWS = 256 / CV;
   const int chunk = blockIdx.x, cg = blockIdx.y, n = blockIdx.z;
   const int v = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256) void act_norm_bwd_partial(T* __restrict__ g, l
   for (int e = 0; e < N; ++e) s[e] = 0;
   if (c < Cp) {
     const long long tr = per_sample ? n : 0;
+    const bool accumulate = n < acc_n;
     const egne_fv<N> sc = ldf<N>(scale + tr * Cp + c), sh = ldf<N>(shift + tr * Cp + c);
     float k0[N], k1[N], k2[N];     // sc gamma, sc gamma mean(G), sc gamma mean(G xh): r = g + k0 (a1 + ge) - k1 - xh k2
 #pragma unroll
@@ -1478,9 +1480,10 @@ extern "C" int egne_norm_pool2_bwd_bf16(const void* x, int64_t xs, int xo, const
 template <typename T>
 static int act_norm_bwd_impl(T* g, int64_t gs, int go, const T* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
                              const T* a1, int64_t a1s, int a1o, const T* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
-                             float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream,
-                             int per_sample = 1, const float* gamma = nullptr, float* dgamma = nullptr, float* dbeta = nullptr, int Cn = 0, int accumulate = 1) {
-  EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && slice_ok(x, xs, xo, Cp) && scale && shift && sums && ws_norm && ws_bias && (a1 || gq), "act_norm_bwd: bad arguments");
+                             float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream, int acc_samples,
+                             int per_sample = 1, const float* gamma = nullptr, float* dgamma = nullptr, float* dbeta = nullptr, int Cn = 0) {
+  EGNE_REQUIRE(slice_ok(g, gs, go, Cp) && slice_ok(x, xs, xo, Cp) && scale && shift && sums && ws_norm && ws_bias && (a1 || gq) && acc_samples >= 0 && acc_samples <= B,
+               "act_norm_bwd: bad arguments");
   EGNE_REQUIRE(vec_ok<T>(gs, go, Cp) && vec_ok<T>(xs, xo, Cp) && (!a1 || vec_ok<T>(a1s, a1o, Cp)) && (!gq || vec_ok<T>(gqs, gqo, Cp)),
                "act_norm_bwd: slices must be 16-byte vectors (8 bf16 channels)");
   EGNE_REQUIRE(B > 0 && H > 0 && W > 0 && (!gq || (H % 2 == 0 && W % 2 == 0)) && (long long)B * H * W < (1ll << 32) && B <= 65535 &&
@@ -1499,20 +1502,20 @@ static int act_norm_bwd_impl(T* g, int64_t gs, int go, const T* x, int64_t xs, i
   EGNE_REQUIRE(B <= nchb, "act_norm_bwd: %d samples for %d partial-sum rows", B, nchb);
   const int nps = nchb / B;
   hipLaunchKernelGGL(act_norm_bwd_partial<T>, dim3(nps, (Cp + 31) / 32, B), dim3(256), 0, st, g, (long long)gs, go, x, (long long)xs, xo, act, scale, shift,
-                     (const float*)sums, A, Cp, HW, nps, (double*)ws_bias, per_sample, gamma, per_sample ? 1.f / (float)HW : 1.f / ((float)HW * (float)B), accumulate);
+                     (const float*)sums, A, Cp, HW, nps, (double*)ws_bias, per_sample, gamma, per_sample ? 1.f / (float)HW : 1.f / ((float)HW * (float)B), acc_samples);
   if (dbias) hipLaunchKernelGGL(reduce_chunks_k, dim3((C + 31) / 32), dim3(1024), 0, st, (const double*)ws_bias, Cp, C, nchb, dbias, 1);
   return egne::check_launch("egne_act_norm_bwd");
 }
 extern "C" int egne_act_norm_bwd(float* g, int64_t gs, int go, const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
                                  const float* a1, int64_t a1s, int a1o, const float* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
-                                 float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
-  return act_norm_bwd_impl(g, gs, go, x, xs, xo, act, scale, shift, a1, a1s, a1o, gq, gqs, gqo, act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream);
+                                 float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, int acc_samples, void* stream) {
+  return act_norm_bwd_impl(g, gs, go, x, xs, xo, act, scale, shift, a1, a1s, a1o, gq, gqs, gqo, act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream, acc_samples);
 }
 extern "C" int egne_act_norm_bwd_bf16(void* g, int64_t gs, int go, const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
                                       const void* a1, int64_t a1s, int a1o, const void* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
-                                      float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream) {
+                                      float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, int acc_samples, void* stream) {
   return act_norm_bwd_impl((egne_bf16*)g, gs, go, (const egne_bf16*)x, xs, xo, act, scale, shift, (const egne_bf16*)a1, a1s, a1o, (const egne_bf16*)gq, gqs, gqo,
-                           act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream);
+                           act_q, Cp, B, H, W, sums, ws_norm, dbias, C, ws_bias, stream, acc_samples);
 }
 
 // BatchNorm backward (training-mode batch statistics over B samples: utils.py:1049) with the masking pass of the layer in front of it
@@ -1525,7 +1528,7 @@ static int bn_act_bwd_impl(const T* x, int64_t xs, int xo, int act, const float*
                            float* dbias, int C, void* ws_bias, void* stream) {
   EGNE_REQUIRE(gy && gx && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_bwd: bad arguments");
   return act_norm_bwd_impl(gx, gxs, gxo, x, xs, xo, act, scale, shift, gy, gys, gyo, (const T*)nullptr, 0, 0, EGNE_ACT_NONE, Cp, B, H, W, sums, ws_norm, dbias, C,
-                           ws_bias, stream, 0, gamma, dgamma, dbeta, Cn, 0);
+                           ws_bias, stream, 0, 0, gamma, dgamma, dbeta, Cn);
 }
 extern "C" int egne_bn_act_bwd(const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift, const float* gamma, const float* gy, int64_t gys,
                                int gyo, int Cp, int B, int H, int W, float* gx, int64_t gxs, int gxo, float* sums, void* ws_norm, float* dgamma, float* dbeta,

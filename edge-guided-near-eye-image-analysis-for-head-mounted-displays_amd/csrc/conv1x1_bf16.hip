@@ -152,6 +152,7 @@ struct DstTab {
   int stride[EGNE_MAXDST], off[EGNE_MAXDST], C[EGNE_MAXDST], nb16[EGNE_MAXDST], wofs[EGNE_MAXDST];       // wofs: first 1-KB fragment row of the destination in LDS (per k-step: + nbt * ks)
   int rstride[EGNE_MAXDST], roff[EGNE_MAXDST], mstride[EGNE_MAXDST], moff[EGNE_MAXDST], act[EGNE_MAXDST];
   const egne_bf16* wfrag[EGNE_MAXDST];
+  long long rpix[EGNE_MAXDST];        // pixels [0, rpix) accumulate onto the residual, the rest are stored (egne_dst.res_pixels; M: all)
 };
 
 template <int NKS>
@@ -196,7 +197,10 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
     for (int d = 0; d < ndst; ++d) {
       const int C = dt.C[d];
       const __amdgpu_buffer_rsrc_t rout = make_rsrc((egne_bf16*)dt.ptr[d] + m0 * dt.stride[d], (unsigned)rows * (unsigned)dt.stride[d] * 2u);
-      const __amdgpu_buffer_rsrc_t rres = make_rsrc(dt.res[d] ? (const egne_bf16*)dt.res[d] + m0 * dt.rstride[d] : nullptr, dt.res[d] ? (unsigned)rows * (unsigned)dt.rstride[d] * 2u : 0u);
+      // (rows of the group beyond the residual's pixel limit read out of bounds: zero)
+      const long long rleft = dt.rpix[d] - m0;
+      const int rrows = rleft < rows ? (rleft > 0 ? (int)rleft : 0) : rows;
+      const __amdgpu_buffer_rsrc_t rres = make_rsrc(dt.res[d] ? (const egne_bf16*)dt.res[d] + m0 * dt.rstride[d] : nullptr, dt.res[d] ? (unsigned)rrows * (unsigned)dt.rstride[d] * 2u : 0u);
       const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(dt.mask[d] ? (const egne_bf16*)dt.mask[d] + m0 * dt.mstride[d] : nullptr, dt.mask[d] ? (unsigned)rows * (unsigned)dt.mstride[d] * 2u : 0u);
       const float slope = dt.act[d] == EGNE_ACT_RELU ? 0.f : (dt.act[d] == EGNE_ACT_LEAKY ? 0.01f : 1.f);
       for (int b0 = 0; b0 < dt.nb16[d]; b0 += 4) {                     // 64 output channels at a time (nb16 is even)
@@ -482,6 +486,8 @@ extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, c
     dt.stride[i] = (int)q.out_pix_stride; dt.off[i] = q.out_ch_off; dt.C[i] = q.C; dt.nb16[i] = q.CoutP / 16; dt.wofs[i] = nbt;
     dt.rstride[i] = (int)q.res_pix_stride; dt.roff[i] = q.res_ch_off; dt.mstride[i] = (int)q.mask_pix_stride; dt.moff[i] = q.mask_ch_off; dt.act[i] = q.act;
     dt.wfrag[i] = (const egne_bf16*)q.wfrag;
+    EGNE_REQUIRE(q.res_pixels >= 0 && (q.residual || q.res_pixels == 0), "conv1x1_bf16_multi: res_pixels of destination %d", i);
+    dt.rpix[i] = q.res_pixels > 0 ? (long long)q.res_pixels : (long long)d.B * d.H * d.W;
     nbt += q.CoutP / 16;
   }
   const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);

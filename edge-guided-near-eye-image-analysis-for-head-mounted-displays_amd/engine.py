@@ -87,6 +87,8 @@ HALO_MAX_COUTP = int(os.environ.get("EGNE_HALO_MAX_COUTP", "128"))
 # (egne_conv1x1_bf16_multi_fwd), and -- where such a launch is the last writer of a gradient slice -- the activation mask and bias sums
 # of the layer that slice belongs to in its epilogue instead of a pass of their own (egne_act_bwd_bias)
 NORM_FUSE = os.environ.get("EGNE_NORM_FUSE", "1") != "0"         # ... and the InstanceNorm backward of a block's input / output inside that masking pass (egne_act_norm_bwd)
+PREFIX_ACC = os.environ.get("EGNE_PREFIX_ACC", "1") != "0"       # ... first encoder-side writer of a skip tensor's gradient: accumulates onto the decoder's half, stores the other (no zero pass)
+BN_ACT_FUSE = os.environ.get("EGNE_BN_ACT_FUSE", "1") != "0"     # ... and a training-mode BatchNorm's backward together with its producer's masking pass (egne_bn_act_bwd)
 MULTI_DGRAD = os.environ.get("EGNE_MULTI_DGRAD", "1") != "0"
 MASK_ON_WRITE = os.environ.get("EGNE_MASK_ON_WRITE", "1") != "0"
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
@@ -625,6 +627,7 @@ class Plan:
         # behind every run, the event that says the copy has landed
         self.ovf = self.ovf_host = self.ovf_event = None
         self.overflow_events = 0
+        self._premasked = {}                           # (buffer id, first channel) -> samples whose output gradient already is the masked gz, bias sums taken (esf_engine._train_bn)
         self._pending = {}                             # (buffer id, first channel, first sample) -> normalisation-backward addends waiting for the tensor's producer (_bw_conv)
         self._mask_cands = {}                          # (buffer id, first channel, channels, samples) -> multi-destination launch that wrote the slice last (_bw_conv)
         self.f16_products = 0                          # egne_conv_desc.f16_products of the plan's split-f16 launches (1: plain f16 operands; BDCN.f16_products)
@@ -651,28 +654,52 @@ class Plan:
             self.gtwins[id(buf)] = t
             self.keep.append(buf)
         if _whole and self._touching:
-            self._touched.setdefault(id(buf), []).append([0, int(buf.shape[-1]), False])
+            self._touched.setdefault(id(buf), []).append([0, int(buf.shape[-1]), False, 0, int(buf.shape[0])])
         return t
 
-    def gp(self, piece):
+    def gp(self, piece, B=None):
+        """Gradient twin of ``piece``.  While the backward plan is built the access is recorded as [first channel, end channel,
+        stored?, first sample, end sample): the samples [n0, n0 + B) when the caller says how many it touches, else the whole buffer."""
         if self._touching:
-            self._touched.setdefault(id(piece.buf), []).append([piece.off, piece.off + piece.Cp, False])
+            n0, n1 = (piece.n0, piece.n0 + int(B)) if B is not None else (0, int(piece.buf.shape[0]))
+            self._touched.setdefault(id(piece.buf), []).append([piece.off, piece.off + piece.Cp, False, n0, n1])
         return Piece(self.gbuf(piece.buf, False), piece.off, piece.C, piece.Cp, piece.n0)
 
-    def mark_stored(self, piece, B):
-        """The access just recorded for ``piece`` (the last gp call) is a STORE of every sample of the buffer: reads of these
-        channels later in the backward pass see this pass' values, whatever the twin held before (zero_grads can skip the
-        buffer if that holds for all of its accesses)."""
-        if self._touching and piece.n0 == 0 and B == piece.buf.shape[0]:
+    def mark_stored(self, piece, B, n0=None):
+        """The access just recorded for ``piece`` (the last gp call) is a STORE of the samples [n0, n0 + B) (n0: piece.n0): reads of
+        these channels and samples later in the backward pass see this pass' values, whatever the twin held before (zero_grads can
+        skip the buffer if that holds for all of its accesses)."""
+        if self._touching:
             ent = self._touched[id(piece.buf)][-1]
             assert ent[0] == piece.off and ent[1] == piece.off + piece.Cp
-            ent[2] = True
+            n0 = piece.n0 if n0 is None else n0
+            ent[2], ent[3], ent[4] = True, n0, n0 + int(B)
 
-    def first_touch(self, buf, off, Cp):
-        """While the backward plan is built: True if no emitter before this one has asked for any of the channels [off, off+Cp) of
-        ``buf``'s gradient twin (gp / gbuf are the only ways to reach a twin, and emitters run in execution order).  The twin was
-        zeroed before the backward pass, so the first writer may STORE instead of accumulate (no read of the slice)."""
-        return FIRST_WRITER and self._touching and all(b <= off or a >= off + Cp for a, b, _ in self._touched.get(id(buf), ()))
+    def first_touch(self, buf, off, Cp, n0=0, B=None):
+        """While the backward plan is built: True if no emitter before this one has asked for any of the channels [off, off+Cp) of the
+        samples [n0, n0+B) (B = None: all) of ``buf``'s gradient twin (gp / gbuf are the only ways to reach a twin, and emitters run
+        in execution order).  The twin was zeroed before the backward pass (or needs no zeroing at all if every access is covered by
+        stores), so the first writer may STORE instead of accumulate (no read of the slice)."""
+        m0, m1 = (n0, n0 + int(B)) if B is not None else (0, int(buf.shape[0]))
+        return FIRST_WRITER and self._touching and all(b <= off or a >= off + Cp or e1 <= m0 or e0 >= m1
+                                                       for a, b, _, e0, e1 in self._touched.get(id(buf), ()))
+
+    def touched_prefix(self, buf, off, Cp, n0, B):
+        """How many leading samples k of [n0, n0+B) earlier emitters have touched in the channels [off, off+Cp), if the touched samples
+        are exactly the prefix [n0, n0+k) -- the decoder's skip gradients reach the image half of an encoder tensor only, so the first
+        encoder-side writer accumulates onto k = B/2 samples and STORES the rest.  B when no such prefix exists (accumulate all)."""
+        if not (FIRST_WRITER and PREFIX_ACC and self._touching):
+            return int(B)
+        segs = sorted((max(e0, n0), min(e1, n0 + B)) for a, b, _, e0, e1 in self._touched.get(id(buf), ())
+                      if a < off + Cp and b > off and e0 < n0 + B and e1 > n0)
+        if not segs:
+            return 0
+        end = n0
+        for s0, s1 in segs:
+            if s0 > end:
+                return int(B)          # a gap: not a prefix
+            end = max(end, s1)
+        return int(end - n0)
 
     def norm_fusable(self, piece):
         """True if the InstanceNorm backward of ``piece``'s normalised readers is deferred to its producer's masking pass."""
@@ -708,7 +735,7 @@ class Plan:
         bw.raw(L.egne_act_norm_bwd, (g.ptr, g.stride, g.off, piece.ptr, piece.stride, piece.off, ACT_NONE, pend["scale"].data_ptr(), pend["shift"].data_ptr(),
                                      a1.ptr if a1 is not None else None, a1.stride if a1 is not None else 0, a1.off if a1 is not None else 0,
                                      gq.ptr if gq is not None else None, gq.stride if gq is not None else 0, gq.off if gq is not None else 0,
-                                     pend["act_q"], piece.Cp, B, H, W, sums.data_ptr(), wsn.data_ptr(), None, 0, wsb.data_ptr()), name + ".norm_bwd_fused")
+                                     pend["act_q"], piece.Cp, B, H, W, sums.data_ptr(), wsn.data_ptr(), None, 0, wsb.data_ptr(), B), name + ".norm_bwd_fused")
 
     def build_backward(self):
         """Replay the tape in reverse into a second plan that shares this plan's gradient buffers."""
@@ -725,16 +752,24 @@ class Plan:
         self._zero_free = set()
         if ZERO_SKIP:
             for bid, ents in self._touched.items():
-                cov, ok = [], True
-                for a, b_, st in ents:
-                    if st:
-                        cov.append((a, b_))
-                        continue
-                    need = [(a, b_)]
-                    for ca, cb in cov:       # subtract the covered ranges
-                        need = [r for x0, x1 in need for r in ((x0, min(x1, ca)), (max(x0, cb), x1)) if r[0] < r[1]]
-                    if need:
-                        ok = False
+                # per run of samples between two boundaries of the recorded accesses: the channel-range test
+                cuts = sorted({e for ent in ents for e in ent[3:5]})
+                ok = True
+                for s0, s1 in zip(cuts, cuts[1:]):
+                    cov = []
+                    for a, b_, st, e0, e1 in ents:
+                        if e1 <= s0 or e0 >= s1:
+                            continue
+                        if st:
+                            cov.append((a, b_))
+                            continue
+                        need = [(a, b_)]
+                        for ca, cb in cov:       # subtract the covered ranges
+                            need = [r for x0, x1 in need for r in ((x0, min(x1, ca)), (max(x0, cb), x1)) if r[0] < r[1]]
+                        if need:
+                            ok = False
+                            break
+                    if not ok:
                         break
                 if ok:
                     self._zero_free.add(bid)
@@ -1645,7 +1680,15 @@ class Plan:
             taken = any(q.sums for q in cand[1])              # a launch sums for ONE destination (<= 128 channels)
             if last == cand[0] and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and (not needs_sums or (not taken and pad32(Cs) <= 128)):
                 masked = cand
-        gy = self.gp(dst)
+        # (the fused InstanceNorm backward below is the one masking pass that can leave part of g unread: the samples no earlier writer touched)
+        acc_n = self.touched_prefix(dst.buf, dst.off, dst.Cp, dst.n0, B) if pend is not None else B
+        gy = self.gp(dst, B)
+        if acc_n < B:
+            ents = self._touched[id(dst.buf)]
+            ents[-1][4] = dst.n0 + acc_n                   # accumulates onto [n0, n0 + acc_n), stores the rest
+            ents.append([dst.off, dst.off + dst.Cp, True, dst.n0 + acc_n, dst.n0 + B])
+            if acc_n == 0:
+                del ents[-2]
         ws = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(npix, Cs)) + 7) // 8, dtype=torch.float64)
         bias = layer.biases[0] if layer.biases is not None else None
         split_dgrad = (bw.dyn_scales and F16X3_ENABLED and layer.kh == 3 and layer.kw == 3 and layer.pad == (1, 1) and layer.dils[0] == 1
@@ -1678,7 +1721,11 @@ class Plan:
             how = "side" if (peer is not None and PAIR_BIAS_SIDE) else "main"
             seen = bw.__dict__.setdefault("_bias_writers", {})
             assert seen.setdefault(id(bias), how) == how, "%s: its bias Parameter is also written from the other stream of the backward plan" % name
-        if pend is not None:
+        done = self._premasked.pop((id(dst.buf), dst.off), None)
+        if done is not None:
+            # a BatchNorm behind this layer has written gz = act'(y) * BatchNorm-backward(.) and added the bias sums (egne_bn_act_bwd)
+            assert done == set(range(dst.n0, dst.n0 + B)) and pend is None and masked is None and peer is None and not (split_dgrad or split_wgrad), name
+        elif pend is not None:
             # the InstanceNorm backward of this layer's output (its normalised readers left their upstream gradients in _pending) inside
             # the masking pass: gz = act'(y) (g + IN-backward(a1 + act_q' up(gq) / 4)), bias sums as egne_act_bwd_bias leaves them
             assert masked is None and not (peer is not None and not lead) and (pend["B"], pend["H"], pend["W"]) == (B, Ho, Wo), name
@@ -1688,7 +1735,7 @@ class Plan:
             bw.raw(L.egne_act_norm_bwd, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, pend["scale"].data_ptr(), pend["shift"].data_ptr(),
                                          a1.ptr if a1 is not None else None, a1.stride if a1 is not None else 0, a1.off if a1 is not None else 0,
                                          gq.ptr if gq is not None else None, gq.stride if gq is not None else 0, gq.off if gq is not None else 0,
-                                         pend["act_q"], Cs, B, Ho, Wo, sums.data_ptr(), wsn.data_ptr(), dbias, layer.Cout, ws.data_ptr()), name + ".act_norm_bwd")
+                                         pend["act_q"], Cs, B, Ho, Wo, sums.data_ptr(), wsn.data_ptr(), dbias, layer.Cout, ws.data_ptr(), acc_n), name + ".act_norm_bwd")
         elif peer is not None and not lead:
             pass                                             # the pair's 1x1: no activation to mask, bias gradient already taken (below)
         elif masked is not None:
@@ -1759,9 +1806,9 @@ class Plan:
                 n = merged[i]
                 ctot = sum(q.Cp for q in pieces[i:i + n])
                 dl = DgradLayer(layer, i, span=n)
-                first = self.first_touch(pc.buf, pc.off, ctot)
+                first = self.first_touch(pc.buf, pc.off, ctot, pc.n0, B)
                 mp = Piece(pc.buf, pc.off, ctot, ctot, pc.n0)
-                tgt = self.gp(mp)
+                tgt = self.gp(mp, B)
                 if first:
                     self.mark_stored(mp, B)
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d-%d" % (i, i + n - 1))
@@ -1798,8 +1845,8 @@ class Plan:
                 self.pre.append(dl.guard)
             else:
                 dl = DgradLayer(layer, i)
-            first = self.first_touch(pc.buf, pc.off, pc.Cp)
-            tgt = self.gp(pc)
+            first = self.first_touch(pc.buf, pc.off, pc.Cp, pc.n0, B)
+            tgt = self.gp(pc, B)
             if first and dl.Cout_store == pc.Cp:
                 self.mark_stored(pc, B)       # (both routes below store every channel of the slice when they come first)
             if pc.scale is None:
@@ -1860,16 +1907,22 @@ class Plan:
             if dl not in bw.layers:
                 bw.layers.append(dl)
             dl.ensure_packed(self.device)
-            first = self.first_touch(pc.buf, pc.off, pc.Cp)
-            tgt = self.gp(pc)
+            # samples of the slice with an earlier writer: none (store), all (accumulate), or a prefix (accumulate onto it, store the rest)
+            acc_n = self.touched_prefix(pc.buf, pc.off, pc.Cp, pc.n0, B) if dl.Cout_store == pc.Cp else (0 if self.first_touch(pc.buf, pc.off, pc.Cp, pc.n0, B) else B)
+            first = acc_n == 0
+            tgt = self.gp(pc, B)
+            if acc_n < B and dl.Cout_store == pc.Cp:
+                if acc_n:
+                    self._touched[id(pc.buf)][-1][4] = pc.n0 + acc_n
+                    self._touched[id(pc.buf)].append([pc.off, pc.off + pc.Cp, False, pc.n0 + acc_n, pc.n0 + B])
+                self.mark_stored(pc, B - acc_n, n0=pc.n0 + acc_n)
             ent = len(self._touched[id(pc.buf)]) - 1 if self._touching else -1
-            if first and dl.Cout_store == pc.Cp:
-                self.mark_stored(pc, B)
             q = arr[j]
             q.out, q.out_pix_stride, q.out_ch_off, q.C, q.CoutP = tgt.ptr, tgt.stride, tgt.off, pc.Cp, dl.CoutP
             q.wfrag = dl.b1frag.data_ptr()
             if not first:
                 q.residual, q.res_pix_stride, q.res_ch_off = tgt.ptr, tgt.stride, tgt.off
+                q.res_pixels = acc_n * H * W if acc_n < B else 0
             self._mask_cands[(id(pc.buf), pc.off, pc.Cp, pc.n0, B, H, W)] = (ent, arr, j, dm)
             flops += 2.0 * B * H * W * pc.C * layer.Cout
         self.keep += [dm, arr]

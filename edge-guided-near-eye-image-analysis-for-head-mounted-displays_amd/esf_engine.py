@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from . import engine as _eng
-from .engine import ACT_LEAKY, ACT_NONE, ConvLayer, Piece, PlanarPiece, Plan, VersionGuard, pad8, pad32
+from .engine import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvLayer, Piece, PlanarPiece, Plan, VersionGuard, pad8, pad32
 
 
 import os
@@ -106,10 +106,12 @@ class _BNFold:
         self.shift[:c].copy_(bn.bias.detach() - bn.running_mean * s)
 
 
-def _train_bn(pl, bn, pre, dst, n0, B, HW, name):
+def _train_bn(pl, bn, pre, dst, n0, B, HW, name, producer=None, hw=None):
     """Training-mode BatchNorm2d over samples [n0, n0+B) (utils.py:1049): batch statistics of ``pre``
     (the activated conv output, kept for backward) -> dst = (pre-mean)*rstd*gamma + beta; running
-    statistics updated as torch does (momentum 0.1, unbiased variance)."""
+    statistics updated as torch does (momentum 0.1, unbiased variance).  ``producer``: the convolution whose activated output
+    ``pre`` is -- bf16 plans then mask its output gradient and take its bias sums inside the BatchNorm's backward
+    (egne_bn_act_bwd: no pass of its own for either)."""
     p, q = pre.samples(n0), dst.samples(n0)
     rstd, nshift, mean, var = pl.norm_stats(p, B, HW, per_sample=False, eps=bn.eps, want_moments=True, name=name + ".stats")
     sc, sh, gpad = pl.vec(pre.Cp), pl.vec(pre.Cp), pl.vec(pre.Cp)
@@ -134,7 +136,24 @@ def _train_bn(pl, bn, pre, dst, n0, B, HW, name):
         def emit(bw):
             L = pl.L
             pl.flush_deferred_norm(bw, Piece(dst.buf, dst.off, dst.C, dst.Cp, 0), name)      # (block 0's input: its readers' InstanceNorm backward first)
-            gq, gpre = pl.gp(q), pl.gp(p)
+            gq, gpre = pl.gp(q, B), pl.gp(p, B)
+            bias = producer.biases[0] if (producer is not None and producer.biases is not None) else None
+            if (_eng.BN_ACT_FUSE and pl.bf16 and producer is not None and hw is not None and producer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
+                    and id(producer) not in pl._pair_links and pre.Cp % 8 == 0 and pre.off % 8 == 0 and q.Cp == pre.Cp):
+                # gz of the producer = act'(pre) * BatchNorm-backward(gy): the only source of pre's gradient, so it is stored
+                sums = bw.vec(pre.Cp * 2)
+                wsn = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, HW, pre.Cp, 1)) + 7) // 8, dtype=torch.float64)
+                wsb = bw.vec((int(L.egne_act_bwd_bias_workspace_bytes(B * HW, pre.Cp)) + 7) // 8, dtype=torch.float64)
+                bw.raw(L.egne_bn_act_bwd, (p.ptr, p.stride, p.off, producer.act, rstd.data_ptr(), nshift.data_ptr(), gpad.data_ptr(),
+                                           gq.ptr, gq.stride, gq.off, pre.Cp, B, hw[0], hw[1], gpre.ptr, gpre.stride, gpre.off,
+                                           sums.data_ptr(), wsn.data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), c,
+                                           bias.grad.data_ptr() if bias is not None else None, producer.Cout, wsb.data_ptr()), name + ".bn_act_bwd")
+                if bias is not None:
+                    seen = bw.__dict__.setdefault("_bias_writers", {})
+                    assert seen.setdefault(id(bias), "main") == "main", name
+                pl.mark_stored(p, B)
+                pl._premasked.setdefault((id(pre.buf), pre.off), set()).update(range(n0, n0 + B))
+                return
             sums = bw.vec(pre.Cp * 2)
             ws = bw.vec((int(L.egne_norm_bwd_workspace_bytes(B, HW, pre.Cp, 0)) + 7) // 8, dtype=torch.float64)
             bw.raw(L.egne_norm_bwd, (p.ptr, p.stride, p.off, rstd.data_ptr(), nshift.data_ptr(), gpad.data_ptr(),
@@ -257,9 +276,9 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
         pre = pl.buf(NB, H, W, pad8(chz))
         pl.conv(l, [Piece(t0, 0, chz)], Piece(pre, 0, chz), NB, H, W, name="enc.head.conv2")
         pl.dbg["head_pre"] = pre
-        _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn")
+        _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn", producer=l, hw=(H, W))
         if add_edge:
-            _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], B, B, H * W, "enc.head.bn.edge")
+            _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], B, B, H * W, "enc.head.bn.edge", producer=l, hw=(H, W))
 
     bott = pl.buf(NB, res[4][0], res[4][1], pad8(fc))
     pl.dbg.update(D=D, bott=bott, t0=t0)
@@ -443,7 +462,7 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     else:
         pre = pl.buf(B, H, W, 8)
         pl.conv(l, [Piece(tf, 0, chz)], Piece(pre, 0, 3), B, H, W, name="dec.final.conv2")
-        _train_bn(pl, dec.final.bn, Piece(pre, 0, 3), Piece(opb, 0, 3), 0, B, H * W, "dec.final.bn")
+        _train_bn(pl, dec.final.bn, Piece(pre, 0, 3), Piece(opb, 0, 3), 0, B, H * W, "dec.final.bn", producer=l, hw=(H, W))
 
     if variant == "v2" and st["add_seg"] == 1:
         # ---- AdaIN fusion (RITnet_v2.py:289-308): softmax(op) -> StyleEncoder -> MLP -> modulate bottleneck ----

@@ -551,13 +551,29 @@ int egne_conf_loss_bwd(const float* pred, int ld, const int64_t* gt, int B, int 
  * sums in ws_bias as egne_act_bwd_bias leaves them for egne_pair_bias_bwd).  Replaces egne_norm_bwd + egne_norm_pool2_bwd +
  * egne_act_bwd_bias: five passes over full-resolution tensors less.  B samples of H x W pixels (even for a pooled addend).
  * sums: [B][Cp][2] floats (scratch); ws_norm: egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1); ws_bias:
- * egne_act_bwd_bias_workspace_bytes(B*H*W, Cp). */
+ * egne_act_bwd_bias_workspace_bytes(B*H*W, Cp).  acc_samples: g of the first acc_samples samples is read (accumulated onto), the
+ * rest of g is written only (no earlier writer; B: plain read-modify-write of all of g). */
 int egne_act_norm_bwd(float* g, int64_t gs, int go, const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
                       const float* a1, int64_t a1s, int a1o, const float* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
-                      float* sums, void* ws_norm, float* dbias /* may be NULL */, int C, void* ws_bias, void* stream);
+                      float* sums, void* ws_norm, float* dbias /* may be NULL */, int C, void* ws_bias, int acc_samples, void* stream);
 int egne_act_norm_bwd_bf16(void* g, int64_t gs, int go, const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift,
                            const void* a1, int64_t a1s, int a1o, const void* gq, int64_t gqs, int gqo, int act_q, int Cp, int B, int H, int W,
-                           float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, void* stream);
+                           float* sums, void* ws_norm, float* dbias, int C, void* ws_bias, int acc_samples, void* stream);
+
+/* Training-mode BatchNorm backward (batch statistics over B samples, utils.py:1049) together with the masking pass of the layer in
+ * front of it (round 5): x = that layer's activated output = the BatchNorm's input, scale / shift = rstd / -mean rstd ([Cp], one row:
+ * egne_norm_stats with per_sample = 0), gamma [Cp], gy = gradient of the BatchNorm's output;
+ *   gx <- act'(x) rstd gamma (gy - mean gy - xh mean(gy xh))      (stored: the BatchNorm is the only reader of x)
+ *   dgamma += sum gy xh, dbeta += sum gy (first Cn channels), dbias += sum gx (first C channels; may be NULL), chunk sums of gx in
+ * ws_bias as egne_act_bwd_bias leaves them.  Replaces egne_norm_bwd + egne_act_bwd_bias: one statistics pass (reads gy, x) and one
+ * apply pass (reads gy, x, writes gx) instead of those two and a read-modify-write of gx.  sums: [Cp][2] floats (scratch); ws_norm:
+ * egne_norm_bwd_workspace_bytes(B, H*W, Cp, 1); ws_bias: egne_act_bwd_bias_workspace_bytes(B*H*W, Cp). */
+int egne_bn_act_bwd(const float* x, int64_t xs, int xo, int act, const float* scale, const float* shift, const float* gamma, const float* gy,
+                    int64_t gys, int gyo, int Cp, int B, int H, int W, float* gx, int64_t gxs, int gxo, float* sums, void* ws_norm,
+                    float* dgamma, float* dbeta, int Cn, float* dbias /* may be NULL */, int C, void* ws_bias, void* stream);
+int egne_bn_act_bwd_bf16(const void* x, int64_t xs, int xo, int act, const float* scale, const float* shift, const float* gamma, const void* gy,
+                         int64_t gys, int gyo, int Cp, int B, int H, int W, void* gx, int64_t gxs, int gxo, float* sums, void* ws_norm,
+                         float* dgamma, float* dbeta, int Cn, float* dbias, int C, void* ws_bias, void* stream);
 
 /* Weight gradient of the convolution described by `d` (same descriptor as the forward call):
  * gw[g][co][ci][kh][kw] += sum_pixels gz[pixel][co] * input[pixel + tap][ci], gz = gradient w.r.t. the
@@ -746,6 +762,8 @@ typedef struct {
   const void* mask_y; int64_t mask_pix_stride; int32_t mask_ch_off;      /* optional: activated output whose sign masks the result */
   int32_t act;                  /* egne_act of that layer */
   float* sums;                  /* optional [egne_conv1x1_bf16_multi_waves][C] */
+  int64_t res_pixels;           /* 0: the residual covers every pixel; k > 0: only the first k pixels accumulate (the rest of the slice has
+                                 * no earlier writer: the decoder's skip gradients reach the image half of the encoder's batch only) */
 } egne_dst;
 int egne_conv1x1_bf16_multi_supported(const egne_conv_desc* d, int ndst, const egne_dst* dsts);
 int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* d, int ndst, const egne_dst* dsts, void* stream);

@@ -160,6 +160,7 @@ def test_conv1x1_bf16_streaming(G, chans, Cout, B, H, W, act, res):
     (192, ((64, False, 0, False), (32, True, 2, True)), 3, 30, 40),                    # six k-steps
     (200, ((64, True, 2, True), (38, False, 0, False)), 2, 30, 40),                    # SEVEN k-steps on the eight-step instantiation
     (256, ((32, False, 0, False), (32, False, 2, False)), 2, 30, 40),                  # eight k-steps
+    (64, ((38, "half", 2, True), (64, "half", 0, False)), 3, 15, 20),                  # residual over the first 450 pixels only (egne_dst.res_pixels: 1.5 frames, mid-group)
 ])
 def test_conv1x1_bf16_multi_destinations(G, Cs, dsts, B, H, W):
     """egne_conv1x1_bf16_multi_fwd (round 5): the per-member data gradients of a 1x1 over a would-be torch.cat (models/RITnet_v2.py:
@@ -209,8 +210,10 @@ def test_conv1x1_bf16_multi_destinations(G, Cs, dsts, B, H, W):
         yb = y.to(DEV).to(BF)
         q = arr[j]
         q.out, q.out_pix_stride, q.out_ch_off, q.C, q.CoutP, q.wfrag = out.data_ptr(), Cp + 16, 8, Cp, CoutP, frag.data_ptr()
+        rp = M // 2 if res == "half" else M
         if res:
             q.residual, q.res_pix_stride, q.res_ch_off = out.data_ptr(), Cp + 16, 8
+            q.res_pixels = rp if res == "half" else 0
         if act:
             q.mask_y, q.mask_pix_stride, q.mask_ch_off, q.act = yb.data_ptr(), Cp, 0, act
         sm = None
@@ -223,7 +226,7 @@ def test_conv1x1_bf16_multi_destinations(G, Cs, dsts, B, H, W):
         wd[:Cd] = _q(w).double()
         t = gzv.double() @ wd.t()
         if res:
-            t = t + r0.double()
+            t[:rp] = t[:rp] + r0.double()[:rp]
         if act:
             t = torch.where(y.double() > 0, t, t * (0.0 if act == 1 else 0.01))
         want.append(t)
