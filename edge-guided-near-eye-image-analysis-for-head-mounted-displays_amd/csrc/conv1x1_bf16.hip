@@ -155,10 +155,112 @@ struct DstTab {
   long long rpix[EGNE_MAXDST];        // pixels [0, rpix) accumulate onto the residual, the rest are stored (egne_dst.res_pixels; M: all)
 };
 
+// One chunk of NBQ 16-channel blocks (32 or 64 output channels) of destination d for the wave's 32-pixel group: the residual and mask
+// vectors of all its pixels are requested BEFORE the MFMAs (their latency hides behind the products and the LDS round trip: with the
+// pixel loop's trip count a run-time value every load used to wait for its own reply, 2-4 serialised round trips per chunk -- the
+// kernel streamed at 2.6 TB/s), then the products, the wave's LDS tile, and out as 16-byte vectors of 8 channels.
+template <int NKS, int NBQ>
+__device__ __forceinline__ void multi_chunk(const DstTab& dt, int d, int b0, int nks, int nbt, const egne_bf16* lw, float* tile, const u32x4 (&xb)[NKS][2],
+                                            const __amdgpu_buffer_rsrc_t rout, const __amdgpu_buffer_rsrc_t rres, const __amdgpu_buffer_rsrc_t rmsk,
+                                            int rows, int lane, bool summing, double (&wsum)[8]) {
+  constexpr int LDP = 64 + 4;
+  constexpr int G = 2 * NBQ, PPI = 64 / G, IT = 32 / PPI;      // lanes per pixel on the way out (8 channels each), pixels per instruction
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int cg = lane % G, pl = lane / G;
+  const int C = dt.C[d];
+  const int n = 16 * b0 + 8 * cg;                              // first channel of the lane's vector inside the destination
+  const bool nok = n < C;
+  const bool has_res = dt.res[d] != nullptr, has_mask = dt.mask[d] != nullptr;
+  u32x4 rw[IT], yw[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int px = i * PPI + pl;
+    rw[i] = has_res ? __builtin_amdgcn_raw_buffer_load_b128(rres, nok ? (px * dt.rstride[d] + dt.roff[d] + n) * 2 : (int)OOB, 0, 0) : u32x4{0u, 0u, 0u, 0u};
+    yw[i] = has_mask ? __builtin_amdgcn_raw_buffer_load_b128(rmsk, nok ? (px * dt.mstride[d] + dt.moff[d] + n) * 2 : (int)OOB, 0, 0) : u32x4{0u, 0u, 0u, 0u};
+  }
+  f32x4 acc[2][NBQ];
+#pragma unroll
+  for (int a = 0; a < 2 * NBQ; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks >= nks) break;
+#pragma unroll
+    for (int j = 0; j < NBQ; ++j) {
+      const egne_bf16x8 a = *(const egne_bf16x8*)&lw[((long long)(ks * nbt + dt.wofs[d] + b0 + j) * 64 + lane) * 8];
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+        acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xb[ks][ph]), acc[ph][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int j = 0; j < NBQ; ++j) *(f32x4*)&tile[(16 * ph + l15) * LDP + 16 * j + 4 * kg] = acc[ph][j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
+  const float slope = dt.act[d] == EGNE_ACT_RELU ? 0.f : (dt.act[d] == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int px = i * PPI + pl;
+    float v[8];
+    const f32x4 t0 = *(const f32x4*)&tile[px * LDP + 8 * cg], t1 = *(const f32x4*)&tile[px * LDP + 8 * cg + 4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
+    if (has_res) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] += __builtin_bit_cast(float, rw[i][e] << 16);
+        v[2 * e + 1] += __builtin_bit_cast(float, rw[i][e] & 0xffff0000u);
+      }
+    }
+    if (has_mask) {         // gz = g * act'(y): the slice is the gradient of a layer's activated output y
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y0 = __builtin_bit_cast(float, yw[i][e] << 16), y1 = __builtin_bit_cast(float, yw[i][e] & 0xffff0000u);
+        v[2 * e] = y0 > 0.f ? v[2 * e] : slope * v[2 * e];
+        v[2 * e + 1] = y1 > 0.f ? v[2 * e + 1] : slope * v[2 * e + 1];
+      }
+    }
+    const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    const egne_bf16x4 l4 = __builtin_convertvector(lo, egne_bf16x4), h4 = __builtin_convertvector(hi, egne_bf16x4);
+    const egne_bf16x8 pk = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+    const bool pok = nok && px < rows;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rout, pok ? (px * dt.stride[d] + dt.off[d] + n) * 2 : (int)OOB, 0, 0);
+    if (summing) {            // sums of what was STORED (bf16-rounded), as a pass over the stored tensor would see it
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { csum[e] += pok ? (float)l4[e] : 0.f; csum[4 + e] += pok ? (float)h4[e] : 0.f; }
+    }
+  }
+  if (summing) {              // (the group's <= 16 values per lane and channel in fp32, the running sums in fp64)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wsum[e] += (double)csum[e];
+  }
+}
+
+template <int NKS>
+__device__ __forceinline__ void multi_load_x(const egne_conv_desc& p, const KTab& tab, int nks, long long m0, long long M, int l15, int kg, u32x4 (&xb)[NKS][2]) {
+  const int rows = (int)(M - m0 < 32 ? (M - m0 > 0 ? M - m0 : 0) : 32);      // (a group past the end: nothing in bounds, zeros)
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const bool on = ks < nks;                                   // (NKS = 6 / 8 also serve 5 / 7 k-steps)
+    const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
+    const int c = on ? tab.c0[ks] + 8 * kg : 1 << 20;
+    const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + (rows ? m0 : 0) * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int off = c < sg.Cp ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
+      xb[ks][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    }
+  }
+}
+
 template <int NKS>
 __global__ __launch_bounds__(256)
 void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int nbt, KTab tab, long long M, int sum_dst, int nks) {
   constexpr int LDP = 64 + 4;
+  constexpr bool PREFETCH = NKS <= 4;                                   // the next group's operands requested while this one is worked on
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   egne_bf16* const lw = (egne_bf16*)smem;                               // [nks][nbt][64 lanes][8]
   // (behind the nks k-steps the launch allocated, not the NKS of the instantiation: NKS = 6 / 8 also serve 5 / 7 k-steps)
@@ -178,106 +280,29 @@ void conv1x1_bf16_multi_kernel(const egne_conv_desc p, DstTab dt, int ndst, int 
   double wsum[2][8];                  // destination sum_dst: this wave's sums of the lane's 8 channels, first / second 64-channel chunk
 #pragma unroll
   for (int a = 0; a < 16; ++a) (&wsum[0][0])[a] = 0.;
+  u32x4 xb[NKS][2], xn[PREFETCH ? NKS : 1][2];
+  if (PREFETCH && wave_id < ngroups) multi_load_x<NKS>(p, tab, nks, wave_id * 32, M, l15, kg, xb);
   for (long long g = wave_id; g < ngroups; g += nwaves) {
     const long long m0 = g * 32;
     const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
-    u32x4 xb[NKS][2];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const bool on = ks < nks;                                   // (NKS = 6 / 8 also serve 5 / 7 k-steps)
-      const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
-      const int c = on ? tab.c0[ks] + 8 * kg : 1 << 20;
-      const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + m0 * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        const int off = c < sg.Cp ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
-        xb[ks][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-      }
-    }
+    if constexpr (PREFETCH) multi_load_x<NKS>(p, tab, nks, (g + nwaves) * 32, M, l15, kg, xn);
+    else multi_load_x<NKS>(p, tab, nks, m0, M, l15, kg, xb);
     for (int d = 0; d < ndst; ++d) {
-      const int C = dt.C[d];
       const __amdgpu_buffer_rsrc_t rout = make_rsrc((egne_bf16*)dt.ptr[d] + m0 * dt.stride[d], (unsigned)rows * (unsigned)dt.stride[d] * 2u);
       // (rows of the group beyond the residual's pixel limit read out of bounds: zero)
       const long long rleft = dt.rpix[d] - m0;
       const int rrows = rleft < rows ? (rleft > 0 ? (int)rleft : 0) : rows;
       const __amdgpu_buffer_rsrc_t rres = make_rsrc(dt.res[d] ? (const egne_bf16*)dt.res[d] + m0 * dt.rstride[d] : nullptr, dt.res[d] ? (unsigned)rrows * (unsigned)dt.rstride[d] * 2u : 0u);
       const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(dt.mask[d] ? (const egne_bf16*)dt.mask[d] + m0 * dt.mstride[d] : nullptr, dt.mask[d] ? (unsigned)rows * (unsigned)dt.mstride[d] * 2u : 0u);
-      const float slope = dt.act[d] == EGNE_ACT_RELU ? 0.f : (dt.act[d] == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+      const bool summing = d == sum_dst;
       for (int b0 = 0; b0 < dt.nb16[d]; b0 += 4) {                     // 64 output channels at a time (nb16 is even)
-        const int nbq = dt.nb16[d] - b0 < 4 ? dt.nb16[d] - b0 : 4;     // 2 or 4 blocks
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          if (ks >= nks) break;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < nbq) {
-              const egne_bf16x8 a = *(const egne_bf16x8*)&lw[((long long)(ks * nbt + dt.wofs[d] + b0 + j) * 64 + lane) * 8];
-#pragma unroll
-              for (int ph = 0; ph < 2; ++ph)
-                acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xb[ks][ph]), acc[ph][j], 0, 0, 0);
-            }
-          }
-        }
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < nbq) *(f32x4*)&tile[(16 * ph + l15) * LDP + 16 * j + 4 * kg] = acc[ph][j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
-        const int G = 2 * nbq, PPI = 64 / G;                     // lanes per pixel on the way out (8 channels each), pixels per instruction
-        const int cg = lane % G, pl = lane / G;
-        const int n = 16 * b0 + 8 * cg;                          // first channel of the lane's vector inside the destination
-        const bool nok = n < C;
-        const bool summing = d == sum_dst;
-        float csum[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-        for (int i = 0; i < 32 / PPI; ++i) {
-          const int px = i * PPI + pl;
-          egne_fv<8> v;
-          const f32x4 t0 = *(const f32x4*)&tile[px * LDP + 8 * cg], t1 = *(const f32x4*)&tile[px * LDP + 8 * cg + 4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v.v[e] = t0[e]; v.v[4 + e] = t1[e]; }
-          if (dt.res[d]) {
-            const u32x4 rw = __builtin_amdgcn_raw_buffer_load_b128(rres, nok ? (px * dt.rstride[d] + dt.roff[d] + n) * 2 : (int)OOB, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v.v[2 * e] += __builtin_bit_cast(float, rw[e] << 16);
-              v.v[2 * e + 1] += __builtin_bit_cast(float, rw[e] & 0xffff0000u);
-            }
-          }
-          if (dt.mask[d]) {         // gz = g * act'(y): the slice is the gradient of a layer's activated output y
-            const u32x4 yw = __builtin_amdgcn_raw_buffer_load_b128(rmsk, nok ? (px * dt.mstride[d] + dt.moff[d] + n) * 2 : (int)OOB, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float y0 = __builtin_bit_cast(float, yw[e] << 16), y1 = __builtin_bit_cast(float, yw[e] & 0xffff0000u);
-              v.v[2 * e] = y0 > 0.f ? v.v[2 * e] : slope * v.v[2 * e];
-              v.v[2 * e + 1] = y1 > 0.f ? v.v[2 * e + 1] : slope * v.v[2 * e + 1];
-            }
-          }
-          const f32x4 lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
-          const egne_bf16x4 l4 = __builtin_convertvector(lo, egne_bf16x4), h4 = __builtin_convertvector(hi, egne_bf16x4);
-          const egne_bf16x8 pk = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-          const bool pok = nok && px < rows;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rout, pok ? (px * dt.stride[d] + dt.off[d] + n) * 2 : (int)OOB, 0, 0);
-          if (summing) {            // sums of what was STORED (bf16-rounded), as a pass over the stored tensor would see it
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { csum[e] += pok ? (float)l4[e] : 0.f; csum[4 + e] += pok ? (float)h4[e] : 0.f; }
-          }
-        }
-        if (summing) {              // (the group's <= 16 values per lane and channel in fp32, the running sums in fp64)
-          if (b0 == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) wsum[0][e] += (double)csum[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) wsum[1][e] += (double)csum[e];
-          }
-        }
+        if (dt.nb16[d] - b0 >= 4) multi_chunk<NKS, 4>(dt, d, b0, nks, nbt, lw, tile, xb, rout, rres, rmsk, rows, lane, summing, wsum[b0 ? 1 : 0]);
+        else multi_chunk<NKS, 2>(dt, d, b0, nks, nbt, lw, tile, xb, rout, rres, rmsk, rows, lane, summing, wsum[b0 ? 1 : 0]);
       }
+    }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) { xb[ks][0] = xn[ks][0]; xb[ks][1] = xn[ks][1]; }
     }
   }
   if (sum_dst >= 0) {
