@@ -30,8 +30,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 struct KTab { unsigned char seg[MAXKS]; unsigned short c0[MAXKS]; };
 
 // NB16: 16-channel output blocks of this workgroup (CW = 16 NB16 channels; blockIdx.y selects the group)
-template <int NB16>
-__global__ __launch_bounds__(256)
+// NW: waves per workgroup (4; 8 where the resident weights leave room for one workgroup per compute unit only: twice the waves share them)
+template <int NB16, int NW = 4>
+__global__ __launch_bounds__(64 * NW)
 void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ wfrag, int nks, int nb16_total, KTab tab, long long M) {
   static_assert(NB16 == 2 || NB16 == 4, "the pixel-major store pattern needs 8 CW to divide 64 lanes");
   constexpr int CW = 16 * NB16, LDP = CW + 4;                           // result tile row pitch (floats)
@@ -41,7 +42,7 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
   const int tid = threadIdx.x, lane = tid & 63;
   const int l15 = lane & 15, kg = lane >> 4;
   const int b0 = blockIdx.y * NB16;
-  for (int it = tid; it < nks * NB16 * 64; it += 256) {                 // 16-byte items
+  for (int it = tid; it < nks * NB16 * 64; it += 64 * NW) {             // 16-byte items
     const int l = it & 63, r = it >> 6, j = r % NB16, ks = r / NB16;
     const bool ok = b0 + j < nb16_total;
     const u32x4 v = ok ? *(const u32x4*)(wfrag + (((long long)ks * nb16_total + b0 + j) * 64 + l) * 8) : u32x4{0u, 0u, 0u, 0u};
@@ -55,28 +56,46 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
   constexpr int G = CW / 8;                                              // lanes per pixel on the way out (8 channels each)
   constexpr int PPI = 64 / G;                                            // pixels per store instruction
   const long long ngroups = (M + 31) / 32;
-  const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+  const long long wave_id = (long long)blockIdx.x * NW + (tid >> 6), nwaves = (long long)gridDim.x * NW;
+  // KC k-steps of a group's operands: 2 x KC loads of 16 bytes per lane.  The NEXT chunk (of this group, or the first of the wave's next
+  // group) is requested before the products of the current one (round 5: one chunk at a time left every chunk's latency exposed --
+  // 1.0-1.6 TB/s on the 10-16 k-step layers of the wider model), the accumulated residual before the group's first product.
+  auto load_chunk = [&](long long gq, int k0, u32x4 (&xq)[KC][2]) {
+    const long long m0 = gq * 32;
+    const int rows = (int)(M - m0 < 32 ? (M - m0 > 0 ? M - m0 : 0) : 32);      // (past the last group: nothing in bounds, zeros)
+#pragma unroll
+    for (int u = 0; u < KC; ++u) {
+      const int ks = k0 + u;
+      const bool on = ks < nks;
+      const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
+      const int c = (on ? tab.c0[ks] : 0) + 8 * kg;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + (rows ? m0 : 0) * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {      // rows past M fall outside the resource and read zeros
+        const int off = (on && c < sg.Cp) ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
+        xq[u][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      }
+    }
+  };
+  u32x4 xa[KC][2], xn[KC][2];
+  if (wave_id < ngroups) load_chunk(wave_id, 0, xa);
   for (long long g = wave_id; g < ngroups; g += nwaves) {
     const long long m0 = g * 32;
     const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(outp + m0 * p.out_pix_stride, (unsigned)rows * (unsigned)p.out_pix_stride * 2u);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(resp ? resp + m0 * p.res_pix_stride : nullptr, resp ? (unsigned)rows * (unsigned)p.res_pix_stride * 2u : 0u);
+    u32x4 rw[32 / PPI];
+#pragma unroll
+    for (int i = 0; i < 32 / PPI; ++i) {
+      const int px = i * PPI + lane / G, n = cw0 + 8 * (lane % G);
+      rw[i] = resp ? __builtin_amdgcn_raw_buffer_load_b128(rres, n < p.Cout_store ? (px * (int)p.res_pix_stride + p.res_ch_off + n) * 2 : (int)OOB, 0, 0) : u32x4{0u, 0u, 0u, 0u};
+    }
     f32x4 acc[2][NB16];
 #pragma unroll
     for (int a = 0; a < 2 * NB16; ++a) (&acc[0][0])[a] = (f32x4)(0.f);
     for (int k0 = 0; k0 < nks; k0 += KC) {
-      u32x4 xb[KC][2];
-#pragma unroll
-      for (int u = 0; u < KC; ++u) {
-        const int ks = k0 + u;
-        const bool on = ks < nks;
-        const egne_seg& sg = p.seg[on ? tab.seg[ks] : 0];
-        const int c = (on ? tab.c0[ks] : 0) + 8 * kg;
-        const __amdgpu_buffer_rsrc_t r = make_rsrc((const egne_bf16*)sg.ptr + m0 * sg.pix_stride, (unsigned)rows * (unsigned)sg.pix_stride * 2u);
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {      // rows past M fall outside the resource and read zeros
-          const int off = (on && c < sg.Cp) ? ((16 * ph + l15) * (int)sg.pix_stride + sg.ch_off + c) * 2 : (int)OOB;
-          xb[u][ph] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-        }
-      }
+      if (k0 + KC < nks) load_chunk(g, k0 + KC, xn);
+      else load_chunk(g + nwaves, 0, xn);
 #pragma unroll
       for (int u = 0; u < KC; ++u) {
         if (k0 + u < nks) {
@@ -85,10 +104,12 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
             const egne_bf16x8 a = *(const egne_bf16x8*)&lw[(((k0 + u) * NB16 + j) * 64 + lane) * 8];
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
-              acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xb[u][ph]), acc[ph][j], 0, 0, 0);
+              acc[ph][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(egne_bf16x8, xa[u][ph]), acc[ph][j], 0, 0, 0);
           }
         }
       }
+#pragma unroll
+      for (int u = 0; u < KC; ++u) { xa[u][0] = xn[u][0]; xa[u][1] = xn[u][1]; }
     }
     // lane holds pixel 16 ph + l15, channels 16 j + 4 kg + r: through the wave's LDS tile into pixel-major 8-channel vectors
 #pragma unroll
@@ -106,8 +127,6 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
         *(f32x4*)&tile[(16 * ph + l15) * LDP + 16 * j + 4 * kg] = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(outp + m0 * p.out_pix_stride, (unsigned)rows * (unsigned)p.out_pix_stride * 2u);
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(resp ? resp + m0 * p.res_pix_stride : nullptr, resp ? (unsigned)rows * (unsigned)p.res_pix_stride * 2u : 0u);
 #pragma unroll
     for (int i = 0; i < 32 / PPI; ++i) {
       const int px = i * PPI + lane / G, cg = lane % G;
@@ -118,11 +137,10 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v.v[e] = t0[e]; v.v[4 + e] = t1[e]; }
       if (resp) {
-        const u32x4 rw = __builtin_amdgcn_raw_buffer_load_b128(rres, nok ? (px * (int)p.res_pix_stride + p.res_ch_off + n) * 2 : (int)OOB, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v.v[2 * e] += __builtin_bit_cast(float, rw[e] << 16);
-          v.v[2 * e + 1] += __builtin_bit_cast(float, rw[e] & 0xffff0000u);
+          v.v[2 * e] += __builtin_bit_cast(float, rw[i][e] << 16);
+          v.v[2 * e + 1] += __builtin_bit_cast(float, rw[i][e] & 0xffff0000u);
         }
       }
       const f32x4 lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
@@ -378,7 +396,9 @@ bool make_tab(const egne_conv_desc& d, KTab* tab, int* nks_) {
 // 16-channel output blocks per workgroup and the LDS bytes that takes: all of them up to 64 channels, else pieces of 64 or 32
 // (2 or 4: the pixel-major store pattern needs 8 CW to divide 64 lanes; CoutP is a multiple of 32, so nb16 is even)
 int blocks_per_wg(int nb16) { return nb16 <= 4 ? nb16 : (nb16 % 4 == 0 ? 4 : 2); }
-size_t lds_bytes(int nks, int nb) { return (size_t)nks * nb * 1024 + (size_t)4 * 32 * (16 * nb + 4) * sizeof(float); }
+size_t lds_bytes(int nks, int nb, int nw = 4) { return (size_t)nks * nb * 1024 + (size_t)nw * 32 * (16 * nb + 4) * sizeof(float); }
+// workgroups of `lds` bytes that fit the 160 KB of a compute unit (1-KB granules)
+int wgs_per_cu(size_t lds) { const int n = (int)(163840 / ((lds + 1023) / 1024 * 1024)); return n < 1 ? 1 : (n > 8 ? 8 : n); }
 
 }  // namespace
 
@@ -427,22 +447,29 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   KTab tab; int nks = 0;
   EGNE_REQUIRE(make_tab(d, &tab, &nks), "conv1x1_bf16: more than %d k-steps", MAXKS);
   const int nb16 = d.CoutP / 16, nb = blocks_per_wg(nb16);
-  const size_t lds = lds_bytes(nks, nb);
-  EGNE_REQUIRE(lds <= 120 * 1024, "conv1x1_bf16: %zu bytes of LDS per workgroup exceed the budget", lds);
+  EGNE_REQUIRE(lds_bytes(nks, nb) <= 120 * 1024, "conv1x1_bf16: %zu bytes of LDS per workgroup exceed the budget", lds_bytes(nks, nb));
+  // waves per compute unit: as many workgroups of four waves as fit its LDS next to each other, or -- where the resident weights leave
+  // room for one only -- eight waves around one copy of them (round 5: the 11-16 k-step layers of the wider model ran one wave per SIMD)
+  const int nw = (nb == 4 && 8 * wgs_per_cu(lds_bytes(nks, nb, 8)) > 4 * wgs_per_cu(lds_bytes(nks, nb, 4)) && lds_bytes(nks, nb, 8) <= 156 * 1024) ? 8 : 4;
+  const size_t lds = lds_bytes(nks, nb, nw);
   const long long M = (long long)d.B * d.H * d.W;
   const int gy = (nb16 + nb - 1) / nb;
-  long long gx = ((M + 31) / 32 + 3) / 4;
-  long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1)) / gy;     // workgroups: as many as stay resident
+  long long gx = ((M + 31) / 32 + nw - 1) / nw;
+  int per_cu = wgs_per_cu(lds);
+  const int max_waves = nb == 2 ? 12 : 8;                     // (142 / 170 registers: three / two waves per SIMD)
+  if (per_cu * nw > max_waves) per_cu = max_waves / nw;
+  long long cap = 256ll * per_cu / gy;                        // workgroups: as many as stay resident
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto kern) -> int {
-    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
     if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, d, (const egne_bf16*)wfrag, nks, nb16, tab, M);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(64 * nw), lds, st, d, (const egne_bf16*)wfrag, nks, nb16, tab, M);
     return egne::check_launch("egne_conv1x1_bf16_fwd");
   };
   if (nb == 2) return go(conv1x1_bf16_kernel<2>);
+  if (nw == 8) return go(conv1x1_bf16_kernel<4, 8>);
   return go(conv1x1_bf16_kernel<4>);
 }
 
@@ -466,7 +493,9 @@ static long long multi_grid(const egne_conv_desc& d, int nks, int nbt) {
   const size_t lds = (size_t)nks * nbt * 1024 + (size_t)4 * 32 * 68 * sizeof(float);
   const long long M = (long long)d.B * d.H * d.W;
   long long gx = ((M + 31) / 32 + 3) / 4;
-  const long long cap = 256ll * (lds <= 36 * 1024 ? 4 : (lds <= 76 * 1024 ? 2 : 1));
+  int per_cu = wgs_per_cu(lds);
+  if (per_cu > 2) per_cu = 2;                                 // (138-208 registers + accumulators: two waves per SIMD)
+  const long long cap = 256ll * per_cu;
   return gx > cap ? cap : gx;
 }
 

@@ -714,7 +714,25 @@ def test_bf16_gradients_vs_float64_truth(edge_exact):
           % ((name, ref_dev) + devs[torch.float32] + devs[torch.bfloat16]))
     print("   whole gradient vector (all parameters): relative L2 error / cosine to float64 -- fp32 storage %.2e / %.6f, bf16 storage %.2e / %.6f"
           % (whole[torch.float32] + whole[torch.bfloat16]))
-    assert whole[torch.bfloat16][0] < 3e-1 and whole[torch.bfloat16][1] > 0.95          # measured 0.21 / 0.978
+    # The comparator for a half-precision run is the reference's OWN half-precision mode (train.py:206 `model.to(args.prec)`, inputs cast
+    # alike :272-279): the oracle evaluated entirely in bf16 -- weights, activations and torch's bf16 kernels -- against the same float64
+    # gradient.  (torch.float16, what `--prec 16` selects in args.py:24, overflows to a NaN loss on this batch.)  Measured: the reference
+    # way 0.57 / 0.842, this library's bf16 STORAGE (fp32 master weights, fp32 accumulation, fp32 parameter gradients) 0.21 / 0.978.
+    # The error is the price of any 8-bit significand in front of LeakyReLU kinks: a relative perturbation d of an activation flips the
+    # sign test of ~d of the elements downstream, each flip changes that element's gradient by its full size, so the gradient moves by
+    # ~sqrt(d) per layer (fp32: 2e-3, bf16: 0.2 -- the ratio of the two is the square root of the ratio of their roundings to within
+    # 2.5x); rounding ONE head tensor of the fp32 plan to bf16 already costs 0.12-0.20 (profiles/r05_bf16_rounding_experiment.txt), so
+    # no choice of tensors kept in fp32 reaches the 0.10 the round-4 verdict asked for short of keeping all of them.
+    sdh = {k: (v.to(torch.bfloat16) if v.dtype.is_floating_point else v).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+           for k, v in m.state_dict().items()}
+    ah = [a.to(torch.bfloat16) if (torch.is_tensor(a) and a.dtype.is_floating_point) else a for a in batch_args(b, edge)]
+    oesf.esf_forward(sdh, setting(cfg), *ah, variant=variant, training=True)[3].sum().backward()
+    flat_r = torch.cat([sdh[n].grad.double().reshape(-1) for n in names])
+    flat_t = torch.cat([sd[n].grad.reshape(-1) for n in names])
+    ref_whole = (float((flat_r - flat_t).norm() / flat_t.norm()), float(torch.dot(flat_r, flat_t) / (flat_r.norm() * flat_t.norm())))
+    print("   the reference's own half-precision mode (oracle evaluated in torch.bfloat16 throughout): %.2e / %.6f" % ref_whole)
+    assert whole[torch.bfloat16][0] < 0.25 and whole[torch.bfloat16][1] > 0.97          # measured 0.21 / 0.978
+    assert whole[torch.bfloat16][0] < 0.5 * ref_whole[0] and 1 - whole[torch.bfloat16][1] < 0.25 * (1 - ref_whole[1])
     assert devs[torch.bfloat16][1] < 2e-2 and devs[torch.bfloat16][3] < 4e-1
     assert devs[torch.float32][0] < max(2 * ref_dev, 2e-3)
 
