@@ -148,6 +148,7 @@ SIGNATURES = {
                             i32, vp, vp]),
     "egne_avgpool2_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "egne_upsample2x_bwd_store": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_ellipse_head_act_bwd": (i32, [vp, vp, i32, i32, vp]),
     "egne_selu_bwd": (i32, [vp, vp, i64, vp]),
     "egne_softmax3_bwd": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i64, vp]),
@@ -173,7 +174,7 @@ SIGNATURES = {
 BF16_TWINS = ["egne_upsample2x_nearest", "egne_upsample2x_nearest_bwd", "egne_norm_stats", "egne_affine", "egne_avgpool2", "egne_norm_act_pool2", "egne_upsample2x", "egne_nchw_to_nhwc",
               "egne_ellipse_head_act", "egne_selu_inplace", "egne_spatial_mean", "egne_softmax3", "egne_adain", "egne_conf_loss",
               "egne_loss_bwd", "egne_act_bwd_bias", "egne_act_norm_bwd", "egne_bn_act_bwd", "egne_pair_bias_bwd", "egne_norm_pool2_bwd", "egne_norm_bwd_store", "egne_norm_bwd",
-              "egne_avgpool2_bwd", "egne_upsample2x_bwd", "egne_ellipse_head_act_bwd", "egne_selu_bwd", "egne_softmax3_bwd",
+              "egne_avgpool2_bwd", "egne_upsample2x_bwd", "egne_upsample2x_bwd_store", "egne_ellipse_head_act_bwd", "egne_selu_bwd", "egne_softmax3_bwd",
               "egne_adain_bwd", "egne_reflect_pad_bwd", "egne_spatial_mean_bwd", "egne_conf_loss_bwd"]
 for _n in BF16_TWINS:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]

@@ -538,7 +538,7 @@ __device__ __forceinline__ int up_taps(int y, int H, int* oy, float* w) {
 }
 // grid (tiles over W * Cp/N, H, B): one 16-byte channel vector of one input pixel per thread, no 64-bit division per element
 // (the flat-index form spent four of them per 8-byte vector: 459 us for the 120x160 -> 240x320 block)
-template <typename T>
+template <typename T, bool ACC = true>
 __global__ void upsample2x_bwd_k(const T* __restrict__ gy, long long gs, int go, T* __restrict__ gx, long long xs,
                                  int xo, int B, int H, int W, int Cp) {
   constexpr int N = egne_vt<T>::N;
@@ -558,9 +558,11 @@ __global__ void upsample2x_bwd_k(const T* __restrict__ gy, long long gs, int go,
       for (int e = 0; e < N; ++e) acc.v[e] += w * g.v[e];
     }
   T* dp = gx + (((long long)b * H + y) * W + x) * xs + xo + c;
-  const egne_fv<N> o = ldv(dp);
+  if constexpr (ACC) {
+    const egne_fv<N> o = ldv(dp);
 #pragma unroll
-  for (int e = 0; e < N; ++e) acc.v[e] += o.v[e];
+    for (int e = 0; e < N; ++e) acc.v[e] += o.v[e];
+  }
   stv(dp, acc);
 }
 
@@ -1558,13 +1560,22 @@ extern "C" int egne_avgpool2_bwd_bf16(const void* gy, int64_t gs, int go, void* 
   return avgpool2_bwd_impl((const egne_bf16*)gy, gs, go, (egne_bf16*)gx, xs, xo, B, H, W, Cp, stream);
 }
 
-template <typename T>
+template <typename T, bool ACC = true>
 static int upsample2x_bwd_impl(const T* gy, int64_t gs, int go, T* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream) {
   EGNE_REQUIRE(slice_ok(gy, gs, go, Cp) && slice_ok(gx, xs, xo, Cp) && B > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
   EGNE_REQUIRE(vec_ok<T>(gs, go, Cp) && vec_ok<T>(xs, xo, Cp) && H <= 65535 && B <= 65535, "upsample2x_bwd: slices must be 16-byte vectors; grid limits");
-  hipLaunchKernelGGL(upsample2x_bwd_k<T>, dim3((unsigned)((W * (Cp / egne_vt<T>::N) + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0,
+  hipLaunchKernelGGL((upsample2x_bwd_k<T, ACC>), dim3((unsigned)((W * (Cp / egne_vt<T>::N) + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0,
                      (hipStream_t)stream, gy, (long long)gs, go, gx, (long long)xs, xo, B, H, W, Cp);
   return egne::check_launch("egne_upsample2x_bwd");
+}
+// the same, STORED instead of accumulated (the first writer of a gradient slice: no zero pass, no read of gx)
+extern "C" int egne_upsample2x_bwd_store(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
+                                         int Cp, void* stream) {
+  return upsample2x_bwd_impl<float, false>(gy, gs, go, gx, xs, xo, B, H, W, Cp, stream);
+}
+extern "C" int egne_upsample2x_bwd_store_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W,
+                                              int Cp, void* stream) {
+  return upsample2x_bwd_impl<egne_bf16, false>((const egne_bf16*)gy, gs, go, (egne_bf16*)gx, xs, xo, B, H, W, Cp, stream);
 }
 extern "C" int egne_upsample2x_bwd(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W,
                                    int Cp, void* stream) {

@@ -31,7 +31,12 @@ struct KTab { unsigned char seg[MAXKS]; unsigned short c0[MAXKS]; };
 
 // NB16: 16-channel output blocks of this workgroup (CW = 16 NB16 channels; blockIdx.y selects the group)
 // NW: waves per workgroup (4; 8 where the resident weights leave room for one workgroup per compute unit only: twice the waves share them)
-template <int NB16, int NW = 4>
+// UP: the "residual" is a HALF-resolution tensor P [B][Ho = H/2][Wo = W/2] whose bilinear x2 up-sampling (F.interpolate(scale_factor=2,
+// mode='bilinear', align_corners=False): models/RITnet_v2.py:80-83) is added to the result -- conv11(cat(up(x), skip)) = up(W_up x) +
+// W_skip skip, the 1x1 and the interpolation commute -- so training plans never hold the up-sampled operand either (round 5; the
+// split-f16 inference kernel has done this since round 4, conv1x1_f16.hip).  Four 16-byte taps per output vector, requested before the
+// products like the plain residual; P is a quarter of the output's pixels and stays in L2.
+template <int NB16, int NW = 4, bool UP = false>
 __global__ __launch_bounds__(64 * NW)
 void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ wfrag, int nks, int nb16_total, KTab tab, long long M) {
   static_assert(NB16 == 2 || NB16 == 4, "the pixel-major store pattern needs 8 CW to divide 64 lanes");
@@ -77,6 +82,8 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       }
     }
   };
+  // (UP: the whole half-resolution tensor as one resource -- a group's pixels may straddle two frames; the host checks it is < 2 GB)
+  const __amdgpu_buffer_rsrc_t rup = make_rsrc(resp, UP ? (unsigned)((long long)p.B * p.Ho * p.Wo * p.res_pix_stride * 2) : 0u);
   u32x4 xa[KC][2], xn[KC][2];
   if (wave_id < ngroups) load_chunk(wave_id, 0, xa);
   for (long long g = wave_id; g < ngroups; g += nwaves) {
@@ -84,11 +91,31 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     const int rows = (int)(M - m0 < 32 ? M - m0 : 32);
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(outp + m0 * p.out_pix_stride, (unsigned)rows * (unsigned)p.out_pix_stride * 2u);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(resp ? resp + m0 * p.res_pix_stride : nullptr, resp ? (unsigned)rows * (unsigned)p.res_pix_stride * 2u : 0u);
-    u32x4 rw[32 / PPI];
+    u32x4 rw[UP ? 4 * (32 / PPI) : 32 / PPI];
+    float uly[32 / PPI], ulx[32 / PPI];
 #pragma unroll
     for (int i = 0; i < 32 / PPI; ++i) {
       const int px = i * PPI + lane / G, n = cw0 + 8 * (lane % G);
-      rw[i] = resp ? __builtin_amdgcn_raw_buffer_load_b128(rres, n < p.Cout_store ? (px * (int)p.res_pix_stride + p.res_ch_off + n) * 2 : (int)OOB, 0, 0) : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (UP) {
+        // pixel m0 + px = (b, oy, ox) of the H x W map; taps (y0 | y1) x (x0 | x1) of the Ho x Wo map (ATen area_pixel_compute_source_index,
+        // scale 0.5, align_corners = false: max(0.5 (d + 0.5) - 0.5, 0)), weights ly / lx towards the second tap
+        const unsigned m = (unsigned)(m0 + px), hw = (unsigned)(p.H * p.W);
+        const unsigned b = m / hw, r = m - b * hw, oy = r / (unsigned)p.W, ox = r - oy * (unsigned)p.W;
+        float sy = 0.5f * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+        float sx = 0.5f * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < p.Ho - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wo - 1 ? 1 : 0);
+        uly[i] = sy - (float)y0; ulx[i] = sx - (float)x0;
+        const bool ok = n < p.Cout_store && px < rows;
+        const int fb = (int)b * p.Ho * p.Wo, co = p.res_ch_off + n;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int yy = (t >> 1) ? y1 : y0, xx = (t & 1) ? x1 : x0;
+          rw[4 * i + t] = __builtin_amdgcn_raw_buffer_load_b128(rup, ok ? ((fb + yy * p.Wo + xx) * (int)p.res_pix_stride + co) * 2 : (int)OOB, 0, 0);
+        }
+      } else {
+        rw[i] = resp ? __builtin_amdgcn_raw_buffer_load_b128(rres, n < p.Cout_store ? (px * (int)p.res_pix_stride + p.res_ch_off + n) * 2 : (int)OOB, 0, 0) : u32x4{0u, 0u, 0u, 0u};
+      }
     }
     f32x4 acc[2][NB16];
 #pragma unroll
@@ -136,7 +163,19 @@ void conv1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       const f32x4 t0 = *(const f32x4*)&tile[px * LDP + 8 * cg], t1 = *(const f32x4*)&tile[px * LDP + 8 * cg + 4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v.v[e] = t0[e]; v.v[4 + e] = t1[e]; }
-      if (resp) {
+      if constexpr (UP) {
+        const float ly = uly[i], lx = ulx[i], hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a[2], bq[2], cq[2], dq[2];
+          a[0] = __builtin_bit_cast(float, rw[4 * i][e] << 16); a[1] = __builtin_bit_cast(float, rw[4 * i][e] & 0xffff0000u);
+          bq[0] = __builtin_bit_cast(float, rw[4 * i + 1][e] << 16); bq[1] = __builtin_bit_cast(float, rw[4 * i + 1][e] & 0xffff0000u);
+          cq[0] = __builtin_bit_cast(float, rw[4 * i + 2][e] << 16); cq[1] = __builtin_bit_cast(float, rw[4 * i + 2][e] & 0xffff0000u);
+          dq[0] = __builtin_bit_cast(float, rw[4 * i + 3][e] << 16); dq[1] = __builtin_bit_cast(float, rw[4 * i + 3][e] & 0xffff0000u);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) v.v[2 * e + h] += hy * (hx * a[h] + lx * bq[h]) + ly * (hx * cq[h] + lx * dq[h]);      // (the order of egne_upsample2x)
+        }
+      } else if (resp) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v.v[2 * e] += __builtin_bit_cast(float, rw[i][e] << 16);
@@ -429,9 +468,13 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   EGNE_REQUIRE(dp && wfrag, "conv1x1_bf16: null pointer");
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.dtype == 1, "conv1x1_bf16: the descriptor must say bf16 tensors (dtype 1)");
-  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && d.Ho == d.H && d.Wo == d.W &&
+  // Ho = H / 2, Wo = W / 2 with a residual: the residual is a half-resolution tensor to up-sample and add (as egne_conv1x1_f16x3_fwd)
+  const bool up = d.residual && 2 * d.Ho == d.H && 2 * d.Wo == d.W;
+  EGNE_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0 && d.ngroups == 1 && ((d.Ho == d.H && d.Wo == d.W) || up) &&
                d.nseg >= 1 && d.nseg <= EGNE_MAXSEG && !d.post_scale && !d.stats_ws && !d.pool_out && !d.dyn_scale && !d.absmax_out,
                "conv1x1_bf16: geometry / options not supported");
+  EGNE_REQUIRE(!up || (d.act == EGNE_ACT_NONE && (long long)d.B * d.Ho * d.Wo * d.res_pix_stride * 2 < (1ll << 31) && (long long)d.B * d.H * d.W < (1ll << 31)),
+               "conv1x1_bf16: up-sampled addend needs no activation and a half-resolution tensor below 2 GB");
   int ktot = 0;
   for (int s = 0; s < d.nseg; ++s) {
     const egne_seg& g = d.seg[s];
@@ -456,7 +499,7 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   const int gy = (nb16 + nb - 1) / nb;
   long long gx = ((M + 31) / 32 + nw - 1) / nw;
   int per_cu = wgs_per_cu(lds);
-  const int max_waves = nb == 2 ? 12 : 8;                     // (142 / 170 registers: three / two waves per SIMD)
+  const int max_waves = (nb == 2 && !up) ? 12 : 8;            // (142 / 170-240 registers: three / two waves per SIMD)
   if (per_cu * nw > max_waves) per_cu = max_waves / nw;
   long long cap = 256ll * per_cu / gy;                        // workgroups: as many as stay resident
   if (cap < 1) cap = 1;
@@ -468,6 +511,11 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(64 * nw), lds, st, d, (const egne_bf16*)wfrag, nks, nb16, tab, M);
     return egne::check_launch("egne_conv1x1_bf16_fwd");
   };
+  if (up) {
+    if (nb == 2) return go(conv1x1_bf16_kernel<2, 4, true>);
+    if (nw == 8) return go(conv1x1_bf16_kernel<4, 8, true>);
+    return go(conv1x1_bf16_kernel<4, 4, true>);
+  }
   if (nb == 2) return go(conv1x1_bf16_kernel<2>);
   if (nw == 8) return go(conv1x1_bf16_kernel<4, 8>);
   return go(conv1x1_bf16_kernel<4>);

@@ -1392,6 +1392,8 @@ class Plan:
             layer.need_b1 = True
         else:
             layer.need_flat = True
+        up_add = getattr(self, "_up_add", None)
+        assert up_add is None or (fast1 and residual is None and layer.act == ACT_NONE), "%s: an up-sampled addend needs the streaming bf16 1x1 kernel" % name
         if layer not in self.layers:
             self.layers.append(layer)
         layer.ensure_packed(self.device)
@@ -1424,6 +1426,18 @@ class Plan:
         assert dst.buf.dtype == torch.bfloat16 and all(p.buf.dtype == torch.bfloat16 for p in pieces), name
         self.keep.append(d)
         flops = 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.kh * layer.kw
+        db = None
+        if self.train:          # the backward descriptor: the plain convolution (an up-sampled addend has a backward of its own below)
+            db = _lib.ConvDesc()
+            C.memmove(C.byref(db), C.byref(d), C.sizeof(_lib.ConvDesc))
+            db.Ktot, db.CoutP = layer.Ktot, layer.CoutP
+            self.keep.append(db)
+        if up_add is not None:
+            # dst = conv1x1(pieces) + b + up2x(P): P [B][H/2][W/2] in bf16, egne_conv1x1_bf16_fwd's half-resolution "residual"
+            P, ph, pw = up_add
+            assert (2 * ph, 2 * pw) == (H, W) and P.Cp >= int(d.Cout_store) and tuple(P.buf.shape[:3]) == (B, ph, pw) and P.off % 8 == 0 and P.stride % 8 == 0, name
+            d.Ho, d.Wo = ph, pw
+            d.residual, d.res_pix_stride, d.res_ch_off = P.ptr, P.stride, P.off
         if smallcin:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif fast3:
@@ -1438,12 +1452,35 @@ class Plan:
         if stats:
             self.last_stats = self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2]
         if self.train:
-            db = _lib.ConvDesc()
-            C.memmove(C.byref(db), C.byref(d), C.sizeof(_lib.ConvDesc))
-            db.Ktot, db.CoutP = layer.Ktot, layer.CoutP
-            self.keep.append(db)
-            self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
+            def emit(bw, up_add=up_add):
+                self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name)
+                if up_add is not None:
+                    # gP (+)= up2x^T(gz): gz = the gradient of dst as _bw_conv left it (the layer has no activation); the first of P's
+                    # readers to come by stores (no zero pass for P's twin)
+                    P, ph, pw = up_add
+                    Pq = Piece(P.buf, P.off, min(P.C, int(db.Cout_store)), int(db.Cout_store), P.n0)
+                    first = self.first_touch(Pq.buf, Pq.off, Pq.Cp, Pq.n0, B)
+                    gz, gP = self.gp(dst, B), self.gp(Pq, B)
+                    if first:
+                        self.mark_stored(Pq, B)
+                    bw.raw(self.L.egne_upsample2x_bwd_store if first else self.L.egne_upsample2x_bwd,
+                           (gz.ptr, gz.stride, gz.off, gP.ptr, gP.stride, gP.off, B, ph, pw, Pq.Cp), name + ".up_add.bwd")
+            self.tape.append(emit)
         return Ho, Wo
+
+    def bf16_stream1x1_ok(self, layer, pieces, dst, B, H, W):
+        """True if _conv_bf16 runs this 1x1 on the streaming bf16-MFMA kernel (conv1x1_bf16.hip) -- the one that can add an
+        up-sampled half-resolution tensor in its epilogue (``up_add``)."""
+        if not (self.bf16 and BF16_FAST1X1 and layer.kh == 1 and layer.kw == 1 and layer.stride == 1 and layer.pad == (0, 0) and layer.post is None
+                and all(p.scale is None and p.Cp % 8 == 0 and p.off % 8 == 0 and p.stride % 8 == 0 for p in pieces)
+                and B * H * W >= 4096 and min(layer.Cout_store, dst.Cp) % 8 == 0 and dst.off % 8 == 0 and dst.stride % 8 == 0
+                and len(pieces) <= _lib.MAXSEG):
+            return False
+        dq = _lib.ConvDesc()
+        dq.nseg, dq.CoutP, dq.Ktot = len(pieces), layer.CoutP, layer.Ktot
+        for i, p in enumerate(pieces):
+            dq.seg[i].Cp = p.Cp
+        return int(self.L.egne_conv1x1_bf16_pack_elems(C.byref(dq))) > 0
 
     def pair_fusable(self, l1, pieces, l2, dst, H, W):
         """True if conv_pair will run l2(l1(cat(pieces))) as ONE launch (conv_fused_1x1_3x3_f16.hip)."""
@@ -1507,7 +1544,8 @@ class Plan:
         fused = self.pair_fusable(l1, pieces, l2, dst, H, W)
         # up_add = (P, ph, pw): a half-resolution tensor whose bilinear x2 upsampling is added to the 1x1 result (the up-sampled
         # operand of an up block folded through the 1x1; only the fused kernel does this -- callers check pair_fusable first)
-        assert up_add is None or (fused and l1.CoutP == 32 and l2.CoutP == 32 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 8), name
+        # (bf16-storage plans: the streaming bf16 1x1 adds it in its epilogue, conv1x1_bf16.hip, two launches)
+        assert up_add is None or self.bf16 or (fused and l1.CoutP == 32 and l2.CoutP == 32 and sum((pc.Cp + 15) // 16 for pc in pieces) <= 8), name
         # convBlock (utils.py:1047-1048): a 3x3 on <= 4 input channels in front of the 3x3 -- same kernel, taps folded into K
         fused_c4 = (FUSE_1X1 and FUSE_C4 and F16X3_ENABLED and not self.train and not self.bf16 and l1.split and l2.split and l1.kh == 3 and l1.kw == 3
                     and l1.stride == 1 and l1.G == 1 and l1.pad == (1, 1) and l1.pad_mode == 0 and l1.dils[0] == 1 and l1.Cin <= 4
@@ -1527,7 +1565,7 @@ class Plan:
                     and l2.pad_mode == 0 and l1.Cout <= 256 and pad8(l2.Cout) <= 256 and l2.Cin == l1.Cout):
                 self._pair_links[id(l1)] = l2         # _bw_conv: the 'a' bias gradient comes from b's output gradient
                 self._pair_links[id(l2)] = l1
-            self.conv(l1, pieces, tmp, B, H, W, name=name + ".a")
+            self.conv(l1, pieces, tmp, B, H, W, name=name + ".a", up_add=up_add)
             return self.conv(l2, [tmp], dst, B, H, W, residual=residual, name=name + ".b", stats=stats)
         for p, (c, cp) in zip(pieces, l1.in_layout):
             assert p.Cp == cp and p.C == c, (name, p.C, p.Cp, c, cp)
@@ -2110,8 +2148,11 @@ class Plan:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side if on_side else main)
-            assert not (on_side and getattr(fn, "python", False)), "%s: python calls queue torch work on the main stream" % name
-            rc = fn(*args, sp if on_side else st)
+            if on_side and getattr(fn, "python", False):
+                with torch.cuda.stream(side):       # a python call queues torch work on the current stream: behind the second stream's launches
+                    rc = fn(*args, sp)
+            else:
+                rc = fn(*args, sp if on_side else st)
             if timed:
                 e1.record(side if on_side else main)
                 events.append((kind, flops, e0, e1, name))

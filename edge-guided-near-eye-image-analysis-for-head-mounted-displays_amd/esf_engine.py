@@ -30,6 +30,7 @@ FOLD_UP = os.environ.get("EGNE_FOLD_UP", "1") != "0"     # up blocks: 1x1 of the
 # inference plans: the ellipse regression head (eight latency-bound launches on the 15x20 bottleneck) on the plan's second stream
 # next to the decoder, joined in front of the loss head
 ELREG_SIDE = os.environ.get("EGNE_ELREG_SIDE", "1") != "0"
+FOLD_UP_TRAIN = os.environ.get("EGNE_FOLD_UP_TRAIN", "1") != "0"       # ... and in bf16-storage TRAINING plans (backward: up2x^T of the 1x1's output gradient)
 FOLD_UP_STREAM = os.environ.get("EGNE_FOLD_UP_STREAM", "1") != "0"     # ... also where the pair is not fused (streaming 1x1 with the addend in its epilogue)
 
 
@@ -402,7 +403,55 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
         fold_up_s = (FOLD_UP and FOLD_UP_STREAM and not training and not fold_up and variant != "concat"
                      and pl.stream1x1_ok(l11s, skip, B, h, w, up_add=True) and pl.stream1x1_ok(l21s, skip + [x1], B, h, w, up_add=True)
                      and pl.stream1x1_ok(l11f, full, B, h, w) and pl.stream1x1_ok(l21f, full + [x1], B, h, w))
-        if fold_up_s:
+        # bf16-storage training plans (round 5): the same identity -- P = [W11_up; W21_up] x at half resolution, the two 1x1s read the skip
+        # slices (and x1) only and add up2x(P) in their epilogue (conv1x1_bf16.hip).  Backward: gP = up2x^T(gz) for either 1x1
+        # (egne_upsample2x_bwd), then P's own 1x1 gives W_up's weight gradient and x's data gradient at a quarter of the pixels.  The
+        # up-sampled operand (nine passes over a full-resolution tensor per block and step: written, read by two 1x1s and their two
+        # weight gradients, its gradient written, accumulated and read back) never exists.  The weight slices are derived tensors with
+        # gradient buffers of their own, added into conv11 / conv21's .grad behind the block's last weight gradient (on its stream).
+        x1p_ = Piece(x1.buf, x1.off, oc)
+        fold_train = (FOLD_UP and FOLD_UP_TRAIN and training and pl.bf16 and variant != "concat" and h == 2 * ph and w == 2 * pw
+                      and ub.conv11.bias is not None and ub.conv21.bias is not None
+                      and pl.bf16_stream1x1_ok(l11s, skip, Piece(y, 0, oc), B, h, w) and pl.bf16_stream1x1_ok(l21s, skip + [x1p_], Piece(y, 0, oc), B, h, w)
+                      and B * ph * pw * 2 * ocp * 2 < 2 ** 31)
+        if fold_train:
+            Ks = sum(p.C for p in skip)
+            wp = torch.zeros(2 * ocp, Cl, 1, 1, device=dev)
+            w11 = torch.zeros(oc, Ks, 1, 1, device=dev)
+            w21 = torch.zeros(oc, Ks + oc, 1, 1, device=dev)
+            for t in (wp, w11, w21):
+                t.grad = torch.zeros_like(t)
+
+            def refresh_wt(wp=wp, w11=w11, w21=w21, ub=ub, Cl=Cl, oc=oc, ocp=ocp):
+                with torch.no_grad():
+                    wp[:oc].copy_(ub.conv11.weight.detach()[:, :Cl])
+                    wp[ocp:ocp + oc].copy_(ub.conv21.weight.detach()[:, :Cl])
+                    w11.copy_(ub.conv11.weight.detach()[:, Cl:])
+                    w21.copy_(ub.conv21.weight.detach()[:, Cl:])
+            pl.pre.append(VersionGuard([ub.conv11.weight, ub.conv21.weight], refresh_wt))
+            refresh_wt()
+            lpw = ConvLayer([wp], None, _lay(prev))
+            l11t = ConvLayer([w11], [ub.conv11.bias], _lay(skip))
+            l21t = ConvLayer([w21], [ub.conv21.bias], _lay(skip + [x1]))
+
+            def emit_scatter(bw, wp=wp, w11=w11, w21=w21, ub=ub, Cl=Cl, oc=oc, ocp=ocp, nm=nm):
+                def scatter():
+                    with torch.no_grad():
+                        g11, g21 = ub.conv11.weight.grad, ub.conv21.weight.grad
+                        g11[:, :Cl].add_(wp.grad[:oc])
+                        g21[:, :Cl].add_(wp.grad[ocp:ocp + oc])
+                        g11[:, Cl:].add_(w11.grad)
+                        g21[:, Cl:].add_(w21.grad)
+                        for t in (wp, w11, w21):
+                            t.grad.zero_()
+                bw._add(_PyCall(scatter), (), nm + ".wgrad_scatter", kind="host", side=_eng.WGRAD_SIDE_STREAM)
+            pl.tape.append(emit_scatter)          # (replayed in reverse: behind the backward of everything below)
+            Pb = pl.buf(B, ph, pw, 2 * ocp)
+            pl.conv(lpw, prev, Piece(Pb, 0, 2 * ocp), B, ph, pw, name=nm + ".up_w")
+            P1, P2 = Piece(Pb, 0, oc, ocp), Piece(Pb, ocp, oc, ocp)
+            pl.conv_pair(l11t, skip, l12, x1, B, h, w, name=nm + ".conv1", up_add=(P1, ph, pw))
+            pl.conv_pair(l21t, skip + [x1], l22, Piece(y, 0, oc), B, h, w, name=nm + ".conv2", up_add=(P2, ph, pw))
+        elif fold_up_s:
             wp = torch.zeros(2 * ocp, Cl, 1, 1, device=dev)
 
             def refresh_wps(wp=wp, ub=ub, Cl=Cl, oc=oc, ocp=ocp):

@@ -681,6 +681,9 @@ int egne_norm_pool2_bwd_bf16(const void* x, int64_t xs, int xo, const float* sca
                              int accumulate, float* sums, void* ws, void* stream);
 int egne_avgpool2_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
 int egne_upsample2x_bwd_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
+/* egne_upsample2x_bwd with gx STORED instead of accumulated onto (round 5: the first writer of a gradient slice) */
+int egne_upsample2x_bwd_store(const float* gy, int64_t gs, int go, float* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
+int egne_upsample2x_bwd_store_bf16(const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo, int B, int H, int W, int Cp, void* stream);
 int egne_ellipse_head_act_bwd_bf16(void* g, const void* y, int B, int ld, void* stream);
 int egne_selu_bwd_bf16(void* g, const void* y, int64_t n, void* stream);
 int egne_softmax3_bwd_bf16(const void* y, int64_t ys, int yo, const void* gy, int64_t gs, int go, void* gx, int64_t xs, int xo,

@@ -245,6 +245,57 @@ def test_conv1x1_bf16_multi_destinations(G, Cs, dsts, B, H, W):
             assert torch.isfinite(tot).all() and (tot - ref).abs().max().item() <= 1e-5 * o[:, 8:8 + Cp].double().abs().sum(0).max().item(), "channel sums of destination %d" % j
 
 
+@pytest.mark.parametrize("B,ph,pw,Cl,Cs,oc", [(2, 30, 40, 64, 40, 32), (4, 15, 20, 100, 104, 62), (1, 60, 80, 32, 64, 100)])
+def test_conv1x1_bf16_upsampled_addend_forward_and_backward(G, B, ph, pw, Cl, Cs, oc):
+    """The up block's first 1x1 with the up-sampled operand folded through it (round 5, training plans with bf16 storage):
+    conv11(cat(up2x(x), skip)) = up2x(W_up x) + W_skip skip + b (models/RITnet_v2.py:80-86; the 1x1 and the bilinear interpolation
+    commute).  Forward: P = W_up x at half resolution (egne_conv1x1_bf16_fwd), then the 1x1 over the skip slice with up2x(P) added
+    in its epilogue, against F.interpolate + F.conv2d in float64 on the same bf16 tensors.  Backward: the plan's gradients of W_up,
+    W_skip, b, x and skip against float64 autograd of the UNFOLDED expression (weights rounded to bf16 as the packs do; P and its
+    gradient pass through bf16 storage, hence the storage tolerance on everything that flows through them)."""
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    H, W = 2 * ph, 2 * pw
+    x, skip = _q(_rand(G, B, Cl, ph, pw)), _q(_rand(G, B, Cs, H, W))
+    wu, wsk, b = _rand(G, oc, Cl, 1, 1) / Cl ** 0.5, _rand(G, oc, Cs, 1, 1) / Cs ** 0.5, _rand(G, oc) * 0.1
+    gy = _q(_rand(G, B, oc, H, W) * 1e-2)
+    pl = _plan()
+    pl.train = True
+    xp, = _pieces(pl, [x], B, ph, pw)
+    sp, = _pieces(pl, [skip], B, H, W)
+    ocp = pad8(oc)
+    wup, wsp, bp = torch.nn.Parameter(wu.to(DEV)), torch.nn.Parameter(wsk.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    for t in (wup, wsp, bp):
+        t.grad = torch.zeros_like(t)
+    lu = ConvLayer([wup], None, [(xp.C, xp.Cp)])
+    ls = ConvLayer([wsp], [bp], [(sp.C, sp.Cp)])
+    Pb = pl.buf(B, ph, pw, ocp)
+    out = pl.buf(B, H, W, ocp + 8)
+    out.fill_(768.0)
+    dst = Piece(out, 8, oc)
+    assert pl.bf16_stream1x1_ok(ls, [sp], dst, B, H, W)
+    pl.conv(lu, [xp], Piece(Pb, 0, oc), B, ph, pw, name="up_w")
+    pl.conv(ls, [sp], dst, B, H, W, name="c11", up_add=(Piece(Pb, 0, oc), ph, pw))
+    assert [m[0] for m in pl.meta][-1] == "conv_bf16:1x1"
+    bw = pl.build_backward()
+    pl.run()
+    pl.zero_grads()
+    pl.gbuf(out)[..., 8:8 + oc] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    assert (o[..., :8] == 768.0).all(), "wrote outside its output slice"
+    xd, sd = x.double().requires_grad_(True), skip.double().requires_grad_(True)
+    wud, wsd, bd = _q(wu).double().requires_grad_(True), _q(wsk).double().requires_grad_(True), b.double().requires_grad_(True)
+    want = F.conv2d(torch.cat([F.interpolate(xd, scale_factor=2, mode="bilinear", align_corners=False), sd], 1), torch.cat([wud, wsd], 1), bd)
+    _check(o[..., 8:8 + oc].permute(0, 3, 1, 2), want.detach(), "1x1 with the up-sampled addend")
+    want.backward(gy.double())
+    for name, got, ref, tol in (("W_up", wup.grad, wud.grad, EPS), ("W_skip", wsp.grad, wsd.grad, 2e-5), ("bias", bp.grad, bd.grad, 1e-5),
+                                ("x", pl.gbuf(xp.buf)[..., :Cl].permute(0, 3, 1, 2), xd.grad, 2 * EPS),
+                                ("skip", pl.gbuf(sp.buf)[..., :Cs].permute(0, 3, 1, 2), sd.grad, EPS)):
+        e = (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert e < tol, "gradient of %s: relative error %.2e" % (name, e)
+
+
 def test_conv_generic_bf16_storage(G):
     """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
     slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
