@@ -91,6 +91,7 @@ PREFIX_ACC = os.environ.get("EGNE_PREFIX_ACC", "1") != "0"       # ... first enc
 BN_ACT_FUSE = os.environ.get("EGNE_BN_ACT_FUSE", "1") != "0"     # ... and a training-mode BatchNorm's backward together with its producer's masking pass (egne_bn_act_bwd)
 MULTI_DGRAD = os.environ.get("EGNE_MULTI_DGRAD", "1") != "0"
 MASK_ON_WRITE = os.environ.get("EGNE_MASK_ON_WRITE", "1") != "0"
+MULTI_SINGLE = os.environ.get("EGNE_MULTI_SINGLE", "1") != "0"
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
 BF16_DGRAD_PACK = os.environ.get("EGNE_BF16_DGRAD_PACK", "1") != "0"   # bf16-storage plans: data-gradient fragments packed straight from the forward weight
 BF16_NARROW = os.environ.get("EGNE_BF16_NARROW", "1") != "0"       # bf16-storage plans: k x k convolutions onto <= 8 channels on the LDS-halo kernel (conv_narrow_bf16.hip)
@@ -1934,7 +1935,9 @@ class Plan:
             if not int(L.egne_conv1x1_bf16_multi_supported(C.byref(dm), len(best) + 1, probe)):
                 break
             best.append(i)
-        if len(best) < 2:
+        # (a layer with ONE input slice gains nothing from the shared read, but its launch may carry the mask and bias sums of the slice's
+        #  producer: the up blocks' half-resolution 1x1, whose data gradient is the only writer of the previous block's output gradient)
+        if len(best) < (1 if (MULTI_SINGLE and len(pieces) == 1) else 2):
             return set()
         arr = (_lib.Dst * len(best))()
         flops = 0.0
