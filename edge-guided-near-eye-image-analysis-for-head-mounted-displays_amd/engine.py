@@ -1789,6 +1789,8 @@ class Plan:
                 arr[j].sums = sums.data_ptr()
                 bw.raw(L.egne_group_sums_reduce, (sums.data_ptr(), nrows, Cs, layer.Cout if dbias is not None else Cs, dbias,
                                                   ws.data_ptr() if lead else None, 1), name + ".bias_sums")
+        elif self.bf16 and layer.act == ACT_NONE and bias is None and peer is None:
+            pass                                             # nothing to mask, nothing to sum (the up blocks' half-resolution 1x1)
         elif self.bf16:
             bw.raw(L.egne_act_bwd_bias, (gy.ptr, gy.stride, gy.off, dst.ptr, dst.stride, dst.off, layer.act, Cs, npix,
                                          dbias, layer.Cout, 1, ws.data_ptr()), name + ".act_bwd")
