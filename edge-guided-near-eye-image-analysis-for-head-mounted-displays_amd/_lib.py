@@ -36,7 +36,8 @@ class ConvDesc(C.Structure):
                 ("stats_ws", c_fp), ("stats_nchunk", C.c_int32),
                 ("pool_out", c_fp), ("pool_pix_stride", C.c_int64), ("pool_ch_off", C.c_int32),
                 ("dyn_scale", C.c_void_p), ("absmax_out", C.c_void_p), ("dtype", C.c_int32),
-                ("out_split", C.c_int32), ("out_split_scale", C.c_float), ("ovf_flag", C.c_void_p), ("f16_products", C.c_int32)]
+                ("out_split", C.c_int32), ("out_split_scale", C.c_float), ("ovf_flag", C.c_void_p), ("f16_products", C.c_int32),
+                ("mask_y", C.c_void_p), ("mask_pix_stride", C.c_int64), ("mask_ch_off", C.c_int32), ("mask_act", C.c_int32), ("mask_sums", C.c_void_p)]
 
 
 class Dst(C.Structure):
@@ -182,6 +183,7 @@ SIGNATURES.update({
     "egne_pack_conv_weight_bf16frag": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "egne_pack_conv_weight_bf16frag_dgrad": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "egne_conv3x3_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp, vp]),
+    "egne_conv3x3_bf16_sum_rows": (i32, []),
     "egne_conv_narrow_bf16_supported": (i32, [C.POINTER(ConvDesc)]),
     "egne_conv_narrow_bf16_fwd": (i32, [C.POINTER(ConvDesc), vp]),
     "egne_pack_conv3x3_narrow_weight": (i32, [vp, i32, i32, vp, vp]),

@@ -271,10 +271,23 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     f32x4 acc[2][2][2], prev[2][2][2];
 #pragma unroll
     for (int a = 0; a < 8; ++a) { (&acc[0][0][0])[a] = (f32x4)(0.f); (&prev[0][0][0])[a] = (f32x4)(0.f); }
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(outp, 0u), rres = make_rsrc(nullptr, 0u);
-    int tvo[2][2], tvr[2][2];
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(outp, 0u);
+    int tvo[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { (&tvo[0][0])[a] = (int)OOB; (&tvr[0][0])[a] = (int)OOB; }
+    for (int a = 0; a < 4; ++a) (&tvo[0][0])[a] = (int)OOB;
+    // mask-on-write (egne_conv_desc.mask_y): the launch is the last writer of a gradient slice -- the stored value is v * act'(y), and the
+    // wave keeps the sums of what it stores (fp64, all its tiles) for the producing layer's bias gradient
+    const egne_bf16* const mskp = (const egne_bf16*)p.mask_y;
+    const unsigned frame_msk = (unsigned)H * W * (unsigned)p.mask_pix_stride * 2u;
+    const float slope_m = p.mask_act == EGNE_ACT_RELU ? 0.f : (p.mask_act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
+    double msum[2][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) (&msum[0][0])[a] = 0.;
+    // residual and mask vectors of a tile are requested at the START of its last job (round 5: loaded at hand-over, every tile waited a
+    // memory round trip for them -- a masked data gradient took twice the time of a plain one)
+    u32x2 pre_r[2][2][2], pre_m[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { (&pre_r[0][0][0])[a] = u32x2{0u, 0u}; (&pre_m[0][0][0])[a] = u32x2{0u, 0u}; }
     // values are finished (bias, activation [, post affine, residual]) in place at hand-over; the deferred part is the bare store
     auto finish_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
@@ -285,9 +298,20 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
         v[e] = fmaxf(t, t * slope_out) * ps4[nh][e] + pt4[nh][e];
       }
       if (resp) {
-        const f32x4 rv = unpack_lo(__builtin_amdgcn_raw_buffer_load_b64(rres, jok[nh] ? tvr[tm][ph] : (int)OOB, nh * 32, 0));
+        const f32x4 rv = unpack_lo(pre_r[tm][ph][nh]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      }
+      if (mskp) {
+        const bool on = jok[nh] && tvo[tm][ph] != (int)OOB;
+        const f32x4 yv = unpack_lo(pre_m[tm][ph][nh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = yv[e] > 0.f ? v[e] : slope_m * v[e];
+        if (p.mask_sums) {       // sums of what is STORED (bf16-rounded), as a pass over the stored tensor would see it
+          const egne_bf16x4 r4 = __builtin_convertvector(v, egne_bf16x4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) msum[nh][e] += on ? (double)(float)r4[e] : 0.;
+        }
       }
       prev[tm][ph][nh] = v;
     };
@@ -307,6 +331,24 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
         if (ch == 0) {
 #pragma unroll
           for (int a = 0; a < 8; ++a) (&acc[0][0][0])[a] = (f32x4)(0.f);
+        }
+        if (ch == nk - 1 && (resp || mskp)) {
+          const __amdgpu_buffer_rsrc_t rr = make_rsrc(resp ? resp + (long long)tl.b * H * W * p.res_pix_stride : nullptr, resp ? frame_res : 0u);
+          const __amdgpu_buffer_rsrc_t rm = make_rsrc(mskp ? mskp + (long long)tl.b * H * W * p.mask_pix_stride : nullptr, mskp ? frame_msk : 0u);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+              const int yy = tl.y0 + row0 + tm, x = tl.x0 + ph * 16 + l15;
+              const bool okp = yy < H && x < W;
+              const int orr = okp ? ((yy * W + x) * (int)p.res_pix_stride + p.res_ch_off + cb * 32 + 4 * kg) * 2 : (int)OOB;
+              const int om = okp ? ((yy * W + x) * (int)p.mask_pix_stride + p.mask_ch_off + cb * 32 + 4 * kg) * 2 : (int)OOB;
+#pragma unroll
+              for (int nh = 0; nh < 2; ++nh) {
+                if (resp) pre_r[tm][ph][nh] = __builtin_amdgcn_raw_buffer_load_b64(rr, jok[nh] ? orr : (int)OOB, nh * 32, 0);
+                if (mskp) pre_m[tm][ph][nh] = __builtin_amdgcn_raw_buffer_load_b64(rm, jok[nh] ? om : (int)OOB, nh * 32, 0);
+              }
+            }
         }
         // operands of tap t + 1 are requested before the MFMAs of tap t (two register sets)
         b8 wh[2][2], ah[2][2][2];
@@ -344,7 +386,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 #pragma unroll
           for (int a = 0; a < 8; ++a) (&prev[0][0][0])[a] = (&acc[0][0][0])[a];
           rout = make_rsrc(outp + (long long)tl.b * H * W * p.out_pix_stride, frame_out);
-          rres = make_rsrc(resp ? resp + (long long)tl.b * H * W * p.res_pix_stride : nullptr, resp ? frame_res : 0u);
+
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -352,7 +394,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
               const int yy = y + tm, x = tl.x0 + ph * 16 + l15;
               const bool okp = yy < H && x < W;
               tvo[tm][ph] = okp ? ((yy * W + x) * (int)p.out_pix_stride + p.out_ch_off + cb * 32 + 4 * kg) * 2 : (int)OOB;
-              tvr[tm][ph] = okp ? ((yy * W + x) * (int)p.res_pix_stride + p.res_ch_off + cb * 32 + 4 * kg) * 2 : (int)OOB;
+
             }
           [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (finish_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
           have_prev = true;
@@ -362,8 +404,29 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     }
     if (have_prev)
       [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
+    if (mskp && p.mask_sums) {
+      // over the 16 pixel lanes that share the channel vector (fixed order), then row (workgroup, consumer wave) of mask_sums [rows][Cout_store]
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) (&msum[0][0])[a] += __shfl_xor((&msum[0][0])[a], o);
+      }
+      if (l15 == 0) {
+        float* row = p.mask_sums + ((long long)blockIdx.x * 4 + cw) * p.Cout_store;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+          if (jok[nh]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) row[cb * 32 + nh * 16 + 4 * kg + e] = (float)msum[nh][e];
+          }
+      }
+    }
   }
 }
+
+}  // namespace
+extern "C" int egne_conv3x3_bf16_sum_rows(void) { return 256 * 4; }
+namespace {
 
 template <int KCH>
 int launch_b3(const egne_conv_desc& d, const egne_bf16* wf, hipStream_t st) {
@@ -453,6 +516,11 @@ extern "C" int egne_conv3x3_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   EGNE_REQUIRE(!d.residual || (((uintptr_t)d.residual & 15) == 0 && d.res_pix_stride % 4 == 0 && d.res_ch_off % 4 == 0), "conv3x3_bf16: residual alignment");
   EGNE_REQUIRE((d.post_scale == nullptr) == (d.post_shift == nullptr) &&
                (!d.post_scale || (((uintptr_t)d.post_scale & 15) == 0 && ((uintptr_t)d.post_shift & 15) == 0)), "conv3x3_bf16: post affine");
+  EGNE_REQUIRE(!d.mask_y || (((uintptr_t)d.mask_y & 7) == 0 && d.mask_pix_stride % 4 == 0 && d.mask_ch_off % 4 == 0 &&
+                              (long long)d.H * d.W * d.mask_pix_stride * 2 < (1ll << 31) && !d.post_scale &&
+                              (d.mask_act == EGNE_ACT_NONE || d.mask_act == EGNE_ACT_RELU || d.mask_act == EGNE_ACT_LEAKY)),
+               "conv3x3_bf16: mask tensor (8-byte groups of 4 channels, no post affine)");
+  EGNE_REQUIRE(!d.mask_sums || (d.mask_y && ((uintptr_t)d.mask_sums & 3) == 0), "conv3x3_bf16: mask_sums needs mask_y");
   EGNE_REQUIRE(((uintptr_t)wfrag & 15) == 0, "conv3x3_bf16: weight alignment");
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 2 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 2 < (1ll << 31) &&
                (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 2 < (1ll << 31)), "conv3x3_bf16: frame too large for 32-bit byte offsets");

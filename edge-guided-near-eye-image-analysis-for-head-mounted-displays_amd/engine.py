@@ -92,6 +92,7 @@ BN_ACT_FUSE = os.environ.get("EGNE_BN_ACT_FUSE", "1") != "0"     # ... and a tra
 MULTI_DGRAD = os.environ.get("EGNE_MULTI_DGRAD", "1") != "0"
 MASK_ON_WRITE = os.environ.get("EGNE_MASK_ON_WRITE", "1") != "0"
 MULTI_SINGLE = os.environ.get("EGNE_MULTI_SINGLE", "1") != "0"
+MASK3_ON_WRITE = os.environ.get("EGNE_MASK3_ON_WRITE", "1") != "0"     # ... and on a bf16 3x3 data gradient that is a slice's last writer
 BF16_FAST1X1 = os.environ.get("EGNE_BF16_FAST1X1", "1") != "0"     # ... and the 1x1 convolutions over raw slices on the streaming bf16-MFMA kernel
 BF16_DGRAD_PACK = os.environ.get("EGNE_BF16_DGRAD_PACK", "1") != "0"   # bf16-storage plans: data-gradient fragments packed straight from the forward weight
 BF16_NARROW = os.environ.get("EGNE_BF16_NARROW", "1") != "0"       # bf16-storage plans: k x k convolutions onto <= 8 channels on the LDS-halo kernel (conv_narrow_bf16.hip)
@@ -628,6 +629,8 @@ class Plan:
         # behind every run, the event that says the copy has landed
         self.ovf = self.ovf_host = self.ovf_event = None
         self.overflow_events = 0
+        self._mask_cands3 = {}                         # as _mask_cands, for slices whose last writer is a bf16 3x3 data gradient (egne_conv_desc.mask_y)
+        self._last_b3_desc = None
         self._premasked = {}                           # (buffer id, first channel) -> samples whose output gradient already is the masked gz, bias sums taken (esf_engine._train_bn)
         self._pending = {}                             # (buffer id, first channel, first sample) -> normalisation-backward addends waiting for the tensor's producer (_bw_conv)
         self._mask_cands = {}                          # (buffer id, first channel, channels, samples) -> multi-destination launch that wrote the slice last (_bw_conv)
@@ -1443,6 +1446,7 @@ class Plan:
             self._add(self.L.egne_conv3x3_smallcin_fwd, (C.byref(d), layer.w40.data_ptr()), name, flops=flops, kind="conv3x3_smallcin")
         elif fast3:
             self._add(self.L.egne_conv3x3_bf16_fwd, (C.byref(d), layer.bfrag.data_ptr()), name, flops=flops, kind="conv_bf16:3x3")
+            self._last_b3_desc = d               # (a data gradient may get its slice's mask later: _bw_conv)
         elif fast1:
             self._add(self.L.egne_conv1x1_bf16_fwd, (C.byref(d), layer.b1frag.data_ptr()), name, flops=flops, kind="conv_bf16:1x1")
         elif BF16_NARROW and int(self.L.egne_conv_narrow_bf16_supported(C.byref(d))):
@@ -1719,6 +1723,13 @@ class Plan:
             taken = any(q.sums for q in cand[1])              # a launch sums for ONE destination (<= 128 channels)
             if last == cand[0] and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and (not needs_sums or (not taken and pad32(Cs) <= 128)):
                 masked = cand
+        masked3 = None
+        cand3 = self._mask_cands3.get((id(dst.buf), dst.off, Cs, dst.n0, B, Ho, Wo)) if (MASK3_ON_WRITE and self.bf16 and pend is None and masked is None) else None
+        if cand3 is not None and layer.act in (ACT_NONE, ACT_RELU, ACT_LEAKY):
+            ents = self._touched.get(id(dst.buf), [])
+            last = max((i for i, e in enumerate(ents) if e[0] < dst.off + dst.Cp and e[1] > dst.off), default=-1)
+            if last == cand3[0] and int(cand3[1].Cout_store) == Cs:
+                masked3 = cand3[1]
         # (the fused InstanceNorm backward below is the one masking pass that can leave part of g unread: the samples no earlier writer touched)
         acc_n = self.touched_prefix(dst.buf, dst.off, dst.Cp, dst.n0, B) if pend is not None else B
         gy = self.gp(dst, B)
@@ -1777,6 +1788,19 @@ class Plan:
                                          pend["act_q"], Cs, B, Ho, Wo, sums.data_ptr(), wsn.data_ptr(), dbias, layer.Cout, ws.data_ptr(), acc_n), name + ".act_norm_bwd")
         elif peer is not None and not lead:
             pass                                             # the pair's 1x1: no activation to mask, bias gradient already taken (below)
+        elif masked3 is not None and not (peer is not None and not lead):
+            # the bf16 3x3 data gradient that wrote this slice last masks it and leaves per-wave channel sums (egne_conv_desc.mask_y / mask_sums)
+            dm3 = masked3
+            if layer.act != ACT_NONE:
+                dm3.mask_y, dm3.mask_pix_stride, dm3.mask_ch_off, dm3.mask_act = dst.ptr, dst.stride, dst.off, layer.act
+            if dbias is not None or lead:
+                if layer.act == ACT_NONE:        # (sums need the masked epilogue: an identity mask on the gradient itself would do, but no layer asks)
+                    dm3.mask_y, dm3.mask_pix_stride, dm3.mask_ch_off, dm3.mask_act = dst.ptr, dst.stride, dst.off, ACT_NONE
+                nrows = int(L.egne_conv3x3_bf16_sum_rows())
+                sums = bw.vec(nrows * Cs)
+                dm3.mask_sums = sums.data_ptr()
+                bw.raw(L.egne_group_sums_reduce, (sums.data_ptr(), nrows, Cs, layer.Cout if dbias is not None else Cs, dbias,
+                                                  ws.data_ptr() if lead else None, 1), name + ".bias_sums")
         elif masked is not None:
             # mask and channel sums come out of the writer's epilogue; here only the sums' second stage (fixed order: deterministic).
             # A pair's 3x3 hands the totals to egne_pair_bias_bwd in the chunk-sum layout it reads (chunk 0 = the total, the rest stays zero)
@@ -1892,8 +1916,13 @@ class Plan:
                 self.mark_stored(pc, B)       # (both routes below store every channel of the slice when they come first)
             if pc.scale is None:
                 # the first writer of a gradient slice stores, later ones accumulate (the twin is zero before the backward pass)
+                ent3 = len(self._touched[id(pc.buf)]) - 1 if self._touching else -1
+                bw._last_b3_desc = None
                 bw.conv(dl, [gin], tgt, B, Ho, Wo, residual=None if first else tgt, name=name + ".dgrad%d" % i)
                 bw._dyn_hint = None
+                if MASK3_ON_WRITE and self.bf16 and bw._last_b3_desc is not None and dl.Cout_store == pc.Cp:
+                    # a bf16 3x3 data gradient: possibly the LAST writer of the slice -- its producer may hang mask and bias sums on it
+                    self._mask_cands3[(id(pc.buf), pc.off, pc.Cp, pc.n0, B, H, W)] = (ent3, bw._last_b3_desc)
             elif self.norm_fusable(pc) and pc.act_in == ACT_NONE and pc.scale.shape[0] == B:
                 # the data gradient w.r.t. IN(x) waits for x's producer (egne_act_norm_bwd): no normalisation-backward pass here
                 tmp = bw.buf(B, H, W, pc.Cp)

@@ -135,9 +135,18 @@ typedef struct {
    * to a training plan with BF16 activation storage (BASELINE.json configs[2..4]), whose input the edge map is rounded to bf16
    * (8-bit significand) anyway.  Entry points that do not know the field compute all three products. */
   int32_t f16_products;
+  /* Optional (egne_conv3x3_bf16_fwd used as a DATA GRADIENT, round 5): the launch is the last writer of a gradient slice and applies the
+   * activation mask of the layer whose OUTPUT the slice is the gradient of -- stored value = v * act'(y), y = that layer's activated
+   * output (bf16, same pixels and channels; mask_act = its egne_act) -- and leaves the channel sums of what it stored for that layer's
+   * bias gradient: mask_sums [egne_conv3x3_bf16_sum_rows()][Cout_store] floats, one row per consumer wave (zero-initialised by the caller:
+   * a wave writes the 32 channels of its output block only), added by egne_group_sums_reduce in a fixed order.  Replaces an
+   * egne_act_bwd_bias pass (read g, read y, write g) over the slice. */
+  const void* mask_y; int64_t mask_pix_stride; int32_t mask_ch_off; int32_t mask_act;
+  float* mask_sums;
 } egne_conv_desc;
 
 int egne_conv2d_fwd(const egne_conv_desc* d, void* stream);
+int egne_conv3x3_bf16_sum_rows(void);      /* rows of egne_conv_desc.mask_sums a launch of egne_conv3x3_bf16_fwd writes */
 
 /*
  * Fast path for the 3x3 / stride 1 / "same" / dilation<=2 / single-slice convolutions (most of

@@ -296,6 +296,58 @@ def test_conv1x1_bf16_upsampled_addend_forward_and_backward(G, B, ph, pw, Cl, Cs
         assert e < tol, "gradient of %s: relative error %.2e" % (name, e)
 
 
+@pytest.mark.parametrize("Cin,Cmid,Cout,B,H,W,act", [(32, 32, 32, 2, 24, 64, 2), (40, 64, 8, 1, 21, 35, 1), (32, 96, 32, 2, 16, 40, 2)])
+def test_mask_on_write_of_a_bf16_3x3_data_gradient(G, Cin, Cmid, Cout, B, H, W, act):
+    """Two 3x3 layers in a row (convBlock: utils.py:1047-1048; the up blocks' output into dec.final): the second layer's data gradient is
+    the LAST writer of the first layer's output gradient, so it applies that layer's activation mask and leaves the bias sums in its
+    epilogue (egne_conv_desc.mask_y / mask_sums, round 5) -- no egne_act_bwd_bias pass.  Weight, bias and data gradients of the FIRST
+    layer against float64 autograd on the stored tensors; the plan must hold no masking pass for it."""
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    x = _q(_rand(G, B, Cin, H, W))
+    wa, ba = _rand(G, Cmid, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cmid) * 0.1
+    wb, bb = _rand(G, Cout, Cmid, 3, 3) / (3 * Cmid ** 0.5), _rand(G, Cout) * 0.1
+    gy = _q(_rand(G, B, Cout, H, W) * 1e-2)
+    pl = _plan()
+    pl.train = True
+    xp, = _pieces(pl, [x], B, H, W)
+    pa = [torch.nn.Parameter(t.to(DEV)) for t in (wa, ba, wb, bb)]
+    for t in pa:
+        t.grad = torch.zeros_like(t)
+    la = ConvLayer([pa[0]], [pa[1]], [(xp.C, xp.Cp)], pad=(1, 1), act=act)
+    lb = ConvLayer([pa[2]], [pa[3]], [(Cmid, pad8(Cmid))], pad=(1, 1), act=2)
+    mid, out = pl.buf(B, H, W, pad8(Cmid)), pl.buf(B, H, W, pad8(Cout))
+    pl.conv(la, [xp], Piece(mid, 0, Cmid), B, H, W, name="a")
+    pl.conv(lb, [Piece(mid, 0, Cmid)], Piece(out, 0, Cout), B, H, W, name="b")
+    bw = pl.build_backward()
+    names = [c[2] for c in bw.calls]
+    assert "a.act_bwd" not in names and "a.bias_sums" in names, names
+    pl.run()
+    pl.zero_grads()
+    pl.gbuf(out)[..., :Cout] = gy.permute(0, 2, 3, 1).to(DEV).to(BF)
+    bw.run()
+    torch.cuda.synchronize()
+    slope = lambda a_: 0.0 if a_ == 1 else 0.01  # noqa: E731
+    ymid = mid.float().cpu()[..., :Cmid].permute(0, 3, 1, 2).double()            # as stored (bf16): decides the first layer's mask
+    yout = out.float().cpu()[..., :Cout].permute(0, 3, 1, 2).double()
+    gzb = _q((gy.double() * torch.where(yout > 0, 1.0, 0.01)).float()).double()   # second layer's masked gradient, stored as bf16
+    mid_d = ymid.clone().requires_grad_(True)
+    F.conv2d(mid_d, _q(wb).double(), bb.double(), padding=1).backward(gzb)
+    gza = mid_d.grad * torch.where(ymid > 0, 1.0, slope(act))                      # what the data gradient's epilogue must store
+    got_gza = pl.gbuf(mid).float().cpu()[..., :Cmid].permute(0, 3, 1, 2).double()
+    e = (got_gza - gza).abs().max().item() / gza.abs().max().item()
+    assert e < EPS, "masked data gradient: relative error %.2e" % e
+    gzaq = got_gza                                                                 # the stored (rounded) tensor feeds bias, weight and data gradients
+    eb = (pa[1].grad.double().cpu() - gzaq.sum((0, 2, 3))).abs().max().item() / gzaq.sum((0, 2, 3)).abs().max().item()
+    assert eb < 1e-5, "bias gradient from the epilogue's sums: relative error %.2e" % eb
+    xd, wad = x.double().requires_grad_(True), _q(wa).double().requires_grad_(True)
+    F.conv2d(xd, wad, None, padding=1).backward(gzaq)
+    ew = (pa[0].grad.double().cpu() - wad.grad).abs().max().item() / wad.grad.abs().max().item()
+    assert ew < 3e-3, "weight gradient: relative error %.2e" % ew
+    gx = pl.gbuf(xp.buf).float().cpu()[..., :Cin].permute(0, 3, 1, 2).double()
+    ex = (gx - xd.grad).abs().max().item() / xd.grad.abs().max().item()
+    assert ex < EPS, "data gradient of the first layer: relative error %.2e" % ex
+
+
 def test_conv_generic_bf16_storage(G):
     """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
     slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
