@@ -348,6 +348,49 @@ def test_mask_on_write_of_a_bf16_3x3_data_gradient(G, Cin, Cmid, Cout, B, H, W, 
     assert ex < EPS, "data gradient of the first layer: relative error %.2e" % ex
 
 
+@pytest.mark.parametrize("B,C,H,W,act", [(4, 32, 24, 40, 2), (3, 8, 17, 31, 1), (2, 64, 30, 40, 0)])
+def test_bn_act_bwd_kernel(G, B, C, H, W, act):
+    """egne_bn_act_bwd (round 5): training-mode BatchNorm backward (utils.py:1049: batch statistics over B samples) together with the
+    masking pass of the convolution in front of it, against float64: gx = act'(x) rstd gamma (gy - mean gy - xh mean(gy xh)) stored over
+    a poisoned buffer (the kernel must not read it), dgamma / dbeta / dbias ACCUMULATED onto what the parameters' gradients held."""
+    import ctypes as C_
+    from egne_amd import _lib
+    L = _lib.lib()
+    x = _q(_rand(G, B, H, W, C))                       # NHWC, the activated output of the producer = the BatchNorm's input
+    gy = _q(_rand(G, B, H, W, C) * 1e-2)
+    gamma = 0.5 + torch.rand(C, generator=G)
+    xd = x.double()
+    mean, var = xd.mean((0, 1, 2)), xd.var((0, 1, 2), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    xh = (xd - mean) * rstd
+    gd = gy.double()
+    n = B * H * W
+    core = gd - gd.mean((0, 1, 2)) - xh * (gd * xh).mean((0, 1, 2))
+    slope = {0: 1.0, 1: 0.0, 2: 0.01}[act]
+    want = torch.where(xd > 0, 1.0, slope) * rstd * gamma.double() * core
+    dev = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    xb, gyb = dev(x).to(BF), dev(gy).to(BF)
+    gx = torch.full((B, H, W, C + 8), 768.0, dtype=BF, device=DEV)
+    sc, sh, gm = dev(rstd.float()), dev((-mean * rstd).float()), dev(gamma)
+    dgamma, dbeta, dbias = torch.full((C,), 0.25, device=DEV), torch.full((C,), -0.5, device=DEV), torch.full((C,), 1.0, device=DEV)
+    sums = torch.zeros(C * 2, device=DEV)
+    wsn = torch.zeros((int(L.egne_norm_bwd_workspace_bytes(B, H * W, C, 1)) + 7) // 8, dtype=torch.float64, device=DEV)
+    wsb = torch.zeros((int(L.egne_act_bwd_bias_workspace_bytes(n, C)) + 7) // 8, dtype=torch.float64, device=DEV)
+    _lib.check(L.egne_bn_act_bwd_bf16(xb.data_ptr(), C, 0, act, sc.data_ptr(), sh.data_ptr(), gm.data_ptr(), gyb.data_ptr(), C, 0, C, B, H, W,
+                                      gx.data_ptr(), C + 8, 8, sums.data_ptr(), wsn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C,
+                                      dbias.data_ptr(), C, wsb.data_ptr(), _lib.stream_ptr()), "bn_act_bwd")
+    torch.cuda.synchronize()
+    o = gx.float().cpu()
+    assert (o[..., :8] == 768.0).all(), "wrote outside its slice"
+    _check(o[..., 8:], want, "gx")
+    # (the bias sums are taken of the fp32 values before they are rounded for storage: against the exact sum, on the scale of the summed
+    #  magnitudes -- the BatchNorm's backward leaves a zero-mean tensor, the sum itself is a small residual)
+    for name, got, ref, base, scale in (("dgamma", dgamma, (gd * xh).sum((0, 1, 2)), 0.25, None), ("dbeta", dbeta, gd.sum((0, 1, 2)), -0.5, None),
+                                        ("dbias", dbias, want.sum((0, 1, 2)), 1.0, want.abs().sum((0, 1, 2)).max().item())):
+        e = (got.double().cpu() - base - ref).abs().max().item() / (scale or max(ref.abs().max().item(), 1e-12))
+        assert e < 1e-4, "%s: relative error %.2e" % (name, e)
+
+
 def test_conv_generic_bf16_storage(G):
     """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
     slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
