@@ -391,6 +391,55 @@ def test_bn_act_bwd_kernel(G, B, C, H, W, act):
         assert e < 1e-4, "%s: relative error %.2e" % (name, e)
 
 
+@pytest.mark.parametrize("B,C,H,W,act,use_a1,use_gq,acc", [(4, 32, 24, 40, 2, True, True, 4), (3, 40, 18, 30, 0, True, True, 1),
+                                                        (2, 64, 30, 40, 2, True, False, 0), (4, 8, 16, 32, 1, False, True, 2)])
+def test_act_norm_bwd_kernel(G, B, C, H, W, act, use_a1, use_gq, acc):
+    """egne_act_norm_bwd (round 5): the InstanceNorm backward of a tensor normalised once for two readers (models/RITnet_v2.py:57 conv1
+    behind IN(x); :40-44 Transition_down behind avg_pool2d(leaky(IN(.)))) inside its producer's masking pass, against float64:
+    G = a1 + leaky'(xh) up(gq) / 4, g <- act'(x) (g + rstd (G - mean G - xh mean(G xh))), the first `acc` samples of g read, the rest
+    written only (poisoned here), bias sums accumulated."""
+    from egne_amd import _lib
+    L = _lib.lib()
+    x = _q(_rand(G, B, H, W, C))
+    xd = x.double()
+    mean, var = xd.mean((1, 2)), xd.var((1, 2), unbiased=False)              # per (sample, channel)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    sc, sh = rstd.float(), (-mean * rstd).float()
+    xh = xd * sc.double()[:, None, None, :] + sh.double()[:, None, None, :]
+    a1 = _q(_rand(G, B, H, W, C) * 1e-2)
+    gq = _q(_rand(G, B, H // 2, W // 2, C) * 1e-2)
+    g = _q(_rand(G, B, H, W, C) * 1e-2)
+    Gd = torch.zeros_like(xd)
+    if use_a1:
+        Gd = Gd + a1.double()
+    if use_gq:
+        up = gq.double().repeat_interleave(2, 1).repeat_interleave(2, 2)
+        Gd = Gd + torch.where(xh > 0, 1.0, 0.01) * up * 0.25
+    gx = sc.double()[:, None, None, :] * (Gd - Gd.mean((1, 2), keepdim=True) - xh * (Gd * xh).mean((1, 2), keepdim=True))
+    gacc = g.double().clone()
+    gacc[acc:] = 0
+    slope = {0: 1.0, 1: 0.0, 2: 0.01}[act]
+    want = torch.where(xd > 0, 1.0, slope) * (gacc + gx)
+    dev = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    xb, a1b, gqb = dev(x).to(BF), dev(a1).to(BF), dev(gq).to(BF)
+    gb = torch.full((B, H, W, C + 8), 768.0, dtype=BF, device=DEV)            # samples >= acc keep the poison: the kernel must not read them
+    gb[:acc, :, :, 8:] = g[:acc].to(DEV).to(BF)
+    scd, shd = dev(sc), dev(sh)
+    dbias = torch.full((C,), 2.0, device=DEV)
+    sums = torch.zeros(B * C * 2, device=DEV)
+    wsn = torch.zeros((int(L.egne_norm_bwd_workspace_bytes(B, H * W, C, 1)) + 7) // 8, dtype=torch.float64, device=DEV)
+    wsb = torch.zeros((int(L.egne_act_bwd_bias_workspace_bytes(B * H * W, C)) + 7) // 8, dtype=torch.float64, device=DEV)
+    _lib.check(L.egne_act_norm_bwd_bf16(gb.data_ptr(), C + 8, 8, xb.data_ptr(), C, 0, act, scd.data_ptr(), shd.data_ptr(),
+                                        a1b.data_ptr() if use_a1 else None, C, 0, gqb.data_ptr() if use_gq else None, C, 0, 2, C, B, H, W,
+                                        sums.data_ptr(), wsn.data_ptr(), dbias.data_ptr(), C, wsb.data_ptr(), acc, _lib.stream_ptr()), "act_norm_bwd")
+    torch.cuda.synchronize()
+    o = gb.float().cpu()
+    assert (o[..., :8] == 768.0).all(), "wrote outside its slice"
+    _check(o[..., 8:], want, "masked gradient with the normalisation's backward")
+    e = (dbias.double().cpu() - 2.0 - want.sum((0, 1, 2))).abs().max().item() / want.abs().sum((0, 1, 2)).max().item()
+    assert e < 1e-4, "bias sums: %.2e of the summed magnitudes" % e
+
+
 def test_conv_generic_bf16_storage(G):
     """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
     slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
