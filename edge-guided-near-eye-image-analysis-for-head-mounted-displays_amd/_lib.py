@@ -112,6 +112,7 @@ SIGNATURES = {
     "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "egne_norm_stats": (i32, [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "egne_norm_stats_finish": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "egne_norm_stats_finish_moments": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "egne_affine_inplace": (i32, [vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_affine": (i32, [vp, i64, i32, vp, i64, i32, i32, i64, vp, vp, vp]),
     "egne_avgpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),

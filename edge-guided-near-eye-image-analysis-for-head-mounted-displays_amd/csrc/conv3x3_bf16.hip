@@ -56,6 +56,11 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
                          int nrun) {
   extern __shared__ __attribute__((aligned(16))) egne_bf16 ldsb[];
   egne_bf16* const lw = ldsb + 2 * IMG;                  // weights behind the two images
+  // behind the weights: per consumer wave [16 values][64 lanes] DOUBLES -- the per-tile channel sums of egne_conv_desc.stats_ws on their
+  // way from "4 channels x 4 pixels per lane" to "one (channel, statistic) per lane" (fp64 throughout: E[x^2] - mean^2 of a nearly constant
+  // channel cancels seven digits, and float partial sums moved the decoder's gradients by 30 %), or -- a launch has one or the other --
+  // the running bias sums of a masked data gradient (mask_sums: [8][64] doubles per wave)
+  double* const lstat_all = (double*)(lw + (size_t)(KCH == 0 ? 2 : KCH) * WCH);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,9 +285,13 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     const egne_bf16* const mskp = (const egne_bf16*)p.mask_y;
     const unsigned frame_msk = (unsigned)H * W * (unsigned)p.mask_pix_stride * 2u;
     const float slope_m = p.mask_act == EGNE_ACT_RELU ? 0.f : (p.mask_act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
-    double msum[2][4];
+    // (the wave's running sums live in LDS, [8 values][64 lanes] doubles per consumer wave behind the statistics staging area: sixteen
+    //  registers the MFMA loop of the wider variants does not have)
+    double* const lms = lstat_all + cw * 16 * 64;
+    if (mskp && p.mask_sums) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) (&msum[0][0])[a] = 0.;
+      for (int a = 0; a < 8; ++a) lms[a * 64 + lane] = 0.;
+    }
     // residual and mask vectors of a tile are requested at the START of its last job (round 5: loaded at hand-over, every tile waited a
     // memory round trip for them -- a masked data gradient took twice the time of a plain one)
     u32x2 pre_r[2][2][2], pre_m[2][2][2];
@@ -310,7 +319,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
         if (p.mask_sums) {       // sums of what is STORED (bf16-rounded), as a pass over the stored tensor would see it
           const egne_bf16x4 r4 = __builtin_convertvector(v, egne_bf16x4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) msum[nh][e] += on ? (double)(float)r4[e] : 0.;
+          for (int e = 0; e < 4; ++e) lms[(nh * 4 + e) * 64 + lane] += on ? (double)(float)r4[e] : 0.;
         }
       }
       prev[tm][ph][nh] = v;
@@ -398,6 +407,50 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
             }
           [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (finish_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
           have_prev = true;
+          if (p.stats_ws) {
+            // InstanceNorm / BatchNorm statistics of the consumer without a pass over the tensor (round 5, training plans): sums and sums of
+            // squares of what this wave STORES of the tile (bf16-rounded), one chunk per (tile, consumer wave):
+            // stats_ws [b][tile * 4 + cw][Cout_store][2] doubles, finished by egne_norm_stats_finish in a fixed order
+            double* lst = lstat_all + cw * 16 * 64;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {            // (one half of the channels at a time: eight live sums instead of sixteen)
+              double ss[4], qq[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { ss[e] = 0.; qq[e] = 0.; }
+#pragma unroll
+              for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                  const bool okp = tvo[tm][ph] != (int)OOB;
+                  const egne_bf16x4 r4 = __builtin_convertvector(prev[tm][ph][nh], egne_bf16x4);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const double f = okp ? (double)(float)r4[e] : 0.;
+                    ss[e] += f; qq[e] += f * f;
+                  }
+                }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                lst[((nh * 4 + e) * 2 + 0) * 64 + lane] = ss[e];
+                lst[((nh * 4 + e) * 2 + 1) * 64 + lane] = qq[e];
+              }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible to its own reads after this)
+            // lane (kg' = lane >> 4, v = lane & 15): value v = (nh, e, statistic) of k-group kg' over its 16 pixel lanes
+            const int kgq = lane >> 4, vq = lane & 15;
+            double t = 0.;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const double2 q2 = *(const double2*)&lst[vq * 64 + kgq * 16 + 2 * j];
+              t += q2.x + q2.y;
+            }
+            const int nhq = vq >> 3, eq = (vq >> 1) & 3, stq = vq & 1;
+            const int n = cb * 32 + nhq * 16 + 4 * kgq + eq;
+            const long long chunk = (long long)(tl.y0 / TH) * tiles_x + tl.x0 / TW;
+            if (n < p.Cout_store)
+              p.stats_ws[((((long long)tl.b * p.stats_nchunk + chunk * 4 + cw) * p.Cout_store) + n) * 2 + stq] = t;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
         }
       }
       lds_barrier();
@@ -406,6 +459,10 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
     if (mskp && p.mask_sums) {
       // over the 16 pixel lanes that share the channel vector (fixed order), then row (workgroup, consumer wave) of mask_sums [rows][Cout_store]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double msum[2][4];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) (&msum[0][0])[a] = lms[a * 64 + lane];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
@@ -432,7 +489,10 @@ template <int KCH>
 int launch_b3(const egne_conv_desc& d, const egne_bf16* wf, hipStream_t st) {
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32, nrun = (d.Cout_store + 31) / 32;
-  constexpr size_t lds = ((size_t)2 * IMG + (size_t)(KCH == 0 ? 2 : KCH) * WCH) * sizeof(egne_bf16);
+  constexpr size_t lds = ((size_t)2 * IMG + (size_t)(KCH == 0 ? 2 : KCH) * WCH) * sizeof(egne_bf16) + 4 * 16 * 64 * sizeof(double);
+  if (d.stats_ws && d.mask_sums) return egne::fail(EGNE_ERR_ARG, "conv3x3_bf16: stats_ws and mask_sums share the waves' LDS scratch: one of them per launch");
+  if (d.stats_ws && d.stats_nchunk != tiles_x * tiles_y * 4)
+    return egne::fail(EGNE_ERR_ARG, "conv3x3_bf16: stats_nchunk %d, the launch has %d chunks per frame (tiles of 32 x 8 pixels x 4 waves)", d.stats_nchunk, tiles_x * tiles_y * 4);
   static_assert(lds <= 163840, "LDS budget");
   static bool once = hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_bf16: cannot raise the dynamic LDS limit to %zu", lds);
@@ -504,8 +564,8 @@ extern "C" int egne_conv3x3_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   const egne_conv_desc& d = *dp;
   EGNE_REQUIRE(d.dtype == 1, "conv3x3_bf16: the descriptor must say bf16 tensors (dtype 1)");
   EGNE_REQUIRE(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_mode == 0 && d.ngroups == 1 && d.nseg == 1 && d.pad_h == 1 &&
-               d.pad_w == 1 && d.dil[0] == 1 && d.Ho == d.H && d.Wo == d.W && !d.stats_ws && !d.pool_out && !d.dyn_scale && !d.absmax_out,
-               "conv3x3_bf16: geometry / options not supported");
+               d.pad_w == 1 && d.dil[0] == 1 && d.Ho == d.H && d.Wo == d.W && !d.pool_out && !d.dyn_scale && !d.absmax_out &&
+               (!d.stats_ws || ((uintptr_t)d.stats_ws & 15) == 0), "conv3x3_bf16: geometry / options not supported");
   const egne_seg& g = d.seg[0];
   EGNE_REQUIRE(g.ptr && g.Cp % 8 == 0 && (g.Cp + 31) / 32 * 32 == d.Ktot && d.Ktot >= 32 && d.Ktot <= 1024 && g.ch_off % 8 == 0 &&
                g.pix_stride % 8 == 0 && ((uintptr_t)g.ptr & 15) == 0 && (g.scale == nullptr) == (g.shift == nullptr) &&

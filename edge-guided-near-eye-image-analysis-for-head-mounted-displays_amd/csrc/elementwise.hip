@@ -110,13 +110,15 @@ __global__ __launch_bounds__(1024) void norm_stats_final(const double* __restric
 // Finish of the statistics whose partial sums came out of a convolution's epilogue: one block per (32 channels, frame),
 // 32 partial-sum streams per channel (independent loads in flight), fixed combination order.
 __global__ __launch_bounds__(1024) void norm_stats_finish_k(const double* __restrict__ ws, int Cp, int nchunk, long long npix_per_n,
-                                                           float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                                           float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ mean_out = nullptr, float* __restrict__ var_out = nullptr,
+                                                           long long row_stride = 1) {
   const int n = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), kg = threadIdx.x >> 5;       // 32 partial-sum streams
   double s = 0, q = 0;
   if (c < Cp) {
-    const double* w = ws + ((long long)n * nchunk * Cp + c) * 2;
+    const double* w = ws + ((long long)n * nchunk * row_stride * Cp + c) * 2;
     for (int k = kg; k < nchunk; k += 32) {
-      const double2 v = *(const double2*)(w + (long long)k * Cp * 2);
+      const double2 v = *(const double2*)(w + (long long)k * row_stride * Cp * 2);
       s += v.x; q += v.y;
     }
   }
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(1024) void norm_stats_finish_k(const double* __rest
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     scale[n * Cp + c] = rstd;
     shift[n * Cp + c] = (float)(-mean) * rstd;
+    if (mean_out) { mean_out[n * Cp + c] = (float)mean; var_out[n * Cp + c] = (float)var; }
   }
 }
 
@@ -446,6 +449,50 @@ extern "C" int egne_norm_stats_finish(const void* ws, int Cp, int B, int nchunk,
   hipLaunchKernelGGL(norm_stats_finish_k, dim3((Cp + 31) / 32, B), dim3(1024), 0, (hipStream_t)stream, (const double*)ws, Cp, nchunk,
                      (long long)HW, eps, scale, shift);
   return egne::check_launch("egne_norm_stats_finish");
+}
+
+// first level of a long reduction (batch statistics: one "sample" of B x nchunk rows): block (32 channels, group g) sums the rows
+// [g R, (g + 1) R) and leaves the sum IN row g R (every block touches its own rows only; fixed order: deterministic)
+__global__ __launch_bounds__(1024) void norm_stats_groups_k(double* __restrict__ ws, int Cp, int nrows, int R) {
+  const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), kg = threadIdx.x >> 5;
+  const int r0 = g * R, r1 = r0 + R < nrows ? r0 + R : nrows;
+  double s = 0, q = 0;
+  if (c < Cp) {
+    for (int k = r0 + kg; k < r1; k += 32) {
+      const double2 v = *(const double2*)(ws + ((long long)k * Cp + c) * 2);
+      s += v.x; q += v.y;
+    }
+  }
+  __shared__ double sh[32][32][2];
+  sh[kg][threadIdx.x & 31][0] = s; sh[kg][threadIdx.x & 31][1] = q;
+  __syncthreads();
+  if (kg == 0 && c < Cp) {
+    for (int j = 1; j < 32; ++j) { s += sh[j][threadIdx.x][0]; q += sh[j][threadIdx.x][1]; }
+    *(double2*)(ws + ((long long)r0 * Cp + c) * 2) = make_double2(s, q);
+  }
+}
+
+// the same with the moments themselves (biased variance) next to rstd / -mean rstd: a training-mode BatchNorm (utils.py:1049) whose batch
+// statistics come out of the producing convolution's epilogue -- its B samples' chunks are one "sample" of B nchunk chunks and B HW pixels
+extern "C" int egne_norm_stats_finish_moments(const void* ws, int Cp, int B, int nchunk, int HW, float eps, float* scale, float* shift,
+                                              float* mean_out, float* var_out, void* stream) {
+  EGNE_REQUIRE(ws && scale && shift && mean_out && var_out && Cp > 0 && B > 0 && nchunk > 0 && HW > 0 && ((uintptr_t)ws & 15) == 0,
+               "norm_stats_finish_moments: bad arguments");
+  // (ws is reduced IN PLACE when a sample has many rows -- one block per (32 channels, sample) would walk tens of megabytes alone: the
+  //  first row of every group of R rows then holds the group's sum; the partial sums are the producing launch's to rewrite next step)
+  constexpr int R = 256;
+  if (nchunk > 4 * R) {
+    const int G = (nchunk + R - 1) / R;
+    EGNE_REQUIRE(nchunk % R == 0 || B == 1, "norm_stats_finish_moments: %d rows per sample are not a multiple of %d (several samples)", nchunk, R);
+    for (int b = 0; b < B; ++b)
+      hipLaunchKernelGGL(norm_stats_groups_k, dim3((Cp + 31) / 32, G), dim3(1024), 0, (hipStream_t)stream, (double*)ws + (long long)b * nchunk * Cp * 2, Cp, nchunk, R);
+    hipLaunchKernelGGL(norm_stats_finish_k, dim3((Cp + 31) / 32, B), dim3(1024), 0, (hipStream_t)stream, (const double*)ws, Cp, G,
+                       (long long)HW, eps, scale, shift, mean_out, var_out, (long long)R);
+    return egne::check_launch("egne_norm_stats_finish_moments");
+  }
+  hipLaunchKernelGGL(norm_stats_finish_k, dim3((Cp + 31) / 32, B), dim3(1024), 0, (hipStream_t)stream, (const double*)ws, Cp, nchunk,
+                     (long long)HW, eps, scale, shift, mean_out, var_out);
+  return egne::check_launch("egne_norm_stats_finish_moments");
 }
 
 template <typename T>

@@ -67,6 +67,10 @@ WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans
 TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "1") != "0"     # training plans: split-f16 (22-bit products) 3x3 forward convolutions and data gradients, pre-scales taken on the device
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
 STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm statistics from the producing conv's epilogue
+# ... in bf16-storage training plans too (bf16 3x3 kernel; BatchNorm batch statistics likewise).  OFF by default: measured on the B=256 step it
+# takes 7 GB of HBM traffic off (the statistics passes over `out` of every down block and the head's pre-BatchNorm tensor) and 0.3-1 % of
+# frames/s with them -- the consumer waves of the 3x3 kernel are its only MFMA issuers and the per-tile reduction sits in their hand-over
+STATS_FUSED_BF16 = os.environ.get("EGNE_STATS_FUSED_BF16", "0") != "0"
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
 FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
 FUSE_C4 = os.environ.get("EGNE_FUSE_C4", "1") != "0"              # convBlock head (3x3 on <= 4 channels + 3x3) as one launch
@@ -629,6 +633,7 @@ class Plan:
         # behind every run, the event that says the copy has landed
         self.ovf = self.ovf_host = self.ovf_event = None
         self.overflow_events = 0
+        self._want_partials, self.last_partials = False, None      # _conv_bf16: the caller wants the statistics partials of the next 3x3 launch
         self._mask_cands3 = {}                         # as _mask_cands, for slices whose last writer is a bf16 3x3 data gradient (egne_conv_desc.mask_y)
         self._last_b3_desc = None
         self._premasked = {}                           # (buffer id, first channel) -> samples whose output gradient already is the masked gz, bias sums taken (esf_engine._train_bn)
@@ -1436,6 +1441,16 @@ class Plan:
             C.memmove(C.byref(db), C.byref(d), C.sizeof(_lib.ConvDesc))
             db.Ktot, db.CoutP = layer.Ktot, layer.CoutP
             self.keep.append(db)
+        # statistics of the consumer's normalisation from this launch's epilogue (bf16 3x3: per-(tile, consumer wave) partial sums of what is
+        # stored, egne_conv_desc.stats_ws): `stats` (InstanceNorm: finished per sample below) or the caller's `_want_partials` (BatchNorm:
+        # the caller finishes over its sample range, esf_engine._train_bn)
+        ws_stats, want_partials = None, bool(getattr(self, "_want_partials", False))
+        self._want_partials, self.last_partials = False, None
+        if (stats or want_partials) and fast3 and STATS_FUSED and STATS_FUSED_BF16 and self.train:
+            nchunk_s = ((W + 31) // 32) * ((H + 7) // 8) * 4
+            ws_stats = self._stats_ws(d, B, nchunk_s)
+            if want_partials:
+                self.last_partials = (ws_stats, nchunk_s, int(d.Cout_store))
         if up_add is not None:
             # dst = conv1x1(pieces) + b + up2x(P): P [B][H/2][W/2] in bf16, egne_conv1x1_bf16_fwd's half-resolution "residual"
             P, ph, pw = up_add
@@ -1455,7 +1470,8 @@ class Plan:
         else:
             self._add(self.L.egne_conv2d_fwd, (C.byref(d),), name, flops=flops, kind="conv_igemm")
         if stats:
-            self.last_stats = self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2]
+            self.last_stats = (self._stats_finish(ws_stats, d, B, Ho * Wo, nchunk_s, name) if ws_stats is not None
+                               else self.norm_stats(dst, B, Ho * Wo, name=name + ".stats")[:2])
         if self.train:
             def emit(bw, up_add=up_add):
                 self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name)

@@ -107,14 +107,22 @@ class _BNFold:
         self.shift[:c].copy_(bn.bias.detach() - bn.running_mean * s)
 
 
-def _train_bn(pl, bn, pre, dst, n0, B, HW, name, producer=None, hw=None):
+def _train_bn(pl, bn, pre, dst, n0, B, HW, name, producer=None, hw=None, partials=None):
     """Training-mode BatchNorm2d over samples [n0, n0+B) (utils.py:1049): batch statistics of ``pre``
     (the activated conv output, kept for backward) -> dst = (pre-mean)*rstd*gamma + beta; running
     statistics updated as torch does (momentum 0.1, unbiased variance).  ``producer``: the convolution whose activated output
     ``pre`` is -- bf16 plans then mask its output gradient and take its bias sums inside the BatchNorm's backward
     (egne_bn_act_bwd: no pass of its own for either)."""
     p, q = pre.samples(n0), dst.samples(n0)
-    rstd, nshift, mean, var = pl.norm_stats(p, B, HW, per_sample=False, eps=bn.eps, want_moments=True, name=name + ".stats")
+    if partials is not None and partials[2] == pre.Cp:
+        # batch statistics from the partial sums the producing convolution left (engine.Plan._conv_bf16, `_want_partials`): the chunks of
+        # samples [n0, n0 + B) as ONE sample of B * nchunk chunks -- no pass over `pre`
+        ws_, nch, Cs_ = partials
+        rstd, nshift, mean, var = pl.vec(1, pre.Cp), pl.vec(1, pre.Cp), pl.vec(1, pre.Cp), pl.vec(1, pre.Cp)
+        pl._add(pl.L.egne_norm_stats_finish_moments, (ws_.data_ptr() + 16 * n0 * nch * Cs_, Cs_, 1, B * nch, B * HW, bn.eps, rstd.data_ptr(), nshift.data_ptr(),
+                                                      mean.data_ptr(), var.data_ptr()), name + ".stats", kind="norm_stats")
+    else:
+        rstd, nshift, mean, var = pl.norm_stats(p, B, HW, per_sample=False, eps=bn.eps, want_moments=True, name=name + ".stats")
     sc, sh, gpad = pl.vec(pre.Cp), pl.vec(pre.Cp), pl.vec(pre.Cp)
     c = bn.num_features
     n = B * HW
@@ -275,11 +283,13 @@ def build_forward_plan(model, B, H, W, dev, training, dtype=torch.float32):
     else:
         pl.conv(l1, [xin_p], Piece(t0, 0, chz), NB, H, W, name="enc.head.conv1")
         pre = pl.buf(NB, H, W, pad8(chz))
+        pl._want_partials = True
         pl.conv(l, [Piece(t0, 0, chz)], Piece(pre, 0, chz), NB, H, W, name="enc.head.conv2")
+        head_partials, pl._want_partials = pl.last_partials, False
         pl.dbg["head_pre"] = pre
-        _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn", producer=l, hw=(H, W))
+        _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], 0, B, H * W, "enc.head.bn", producer=l, hw=(H, W), partials=head_partials)
         if add_edge:
-            _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], B, B, H * W, "enc.head.bn.edge", producer=l, hw=(H, W))
+            _train_bn(pl, enc.head.bn, Piece(pre, 0, chz), D[0]["x"], B, B, H * W, "enc.head.bn.edge", producer=l, hw=(H, W), partials=head_partials)
 
     bott = pl.buf(NB, res[4][0], res[4][1], pad8(fc))
     pl.dbg.update(D=D, bott=bott, t0=t0)

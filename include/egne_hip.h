@@ -85,7 +85,7 @@ typedef struct {
   int64_t out_pix_stride;
   int32_t out_ch_off;
   int32_t Cout_store;         /* channels written (logical Cout rounded up to the slice's padding) */
-  /* Optional (egne_conv3x3_halo_f16_fwd, egne_conv1x1_3x3_fused_f16_fwd): per-(frame, chunk, channel) partial sums of the
+  /* Optional (egne_conv3x3_halo_f16_fwd, egne_conv1x1_3x3_fused_f16_fwd; round 5: egne_conv3x3_bf16_fwd): per-(frame, chunk, channel) partial sums of the
    * STORED output values, [B][stats_nchunk][Cout_store][2] doubles (sum, sum of squares), for a following
    * egne_norm_stats_finish -- the InstanceNorm statistics of the consumer (models/RITnet_v2.py:40,57) without another
    * pass over the tensor.  A chunk is one wave's rows of one tile: stats_nchunk = ceil(W/32) * ceil(H/8) * 4. */
@@ -317,6 +317,10 @@ int egne_norm_stats(const float* x, int64_t pix_stride, int ch_off, int Cp, int 
  * ws [B][nchunk][Cp][2] doubles -> scale = rstd, shift = -mean*rstd ([B][Cp]); fixed summation order (deterministic). */
 int egne_norm_stats_finish(const void* ws, int Cp, int B, int nchunk, int HW, float eps, float* scale, float* shift,
                            void* stream);
+/* The same with mean / biased variance written too ([B][Cp]): batch statistics of a training-mode BatchNorm (utils.py:1049) from a
+ * convolution's epilogue (round 5) -- the B samples of the batch as ONE sample of B * nchunk chunks and B * HW pixels. */
+int egne_norm_stats_finish_moments(const void* ws, int Cp, int B, int nchunk, int HW, float eps, float* scale, float* shift,
+                                   float* mean_out, float* var_out, void* stream);
 
 /* y = x*scale[c] + shift[c] in place over an NHWC slice (training-mode BatchNorm apply). */
 int egne_affine_inplace(float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix,

@@ -440,6 +440,73 @@ def test_act_norm_bwd_kernel(G, B, C, H, W, act, use_a1, use_gq, acc):
     assert e < 1e-4, "bias sums: %.2e of the summed magnitudes" % e
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(3, 32, 32, 24, 64, 0.5), (2, 64, 40, 21, 70, 0.5), (2, 32, 128, 17, 33, 0.5), (4, 32, 32, 240, 320, 0.5),
+                                                 (2, 32, 32, 120, 160, 60.0)])      # nearly constant channels: E[x^2] - mean^2 cancels 3-4 digits
+def test_statistics_from_the_bf16_3x3_epilogue(G, B, Cin, Cout, H, W, bias, monkeypatch):
+    """Training plans with bf16 storage (round 5): the InstanceNorm statistics of a 3x3's consumer (models/RITnet_v2.py:40,57) and the
+    batch statistics of the BatchNorm behind it (utils.py:1049) come from per-(tile, consumer wave) partial sums the convolution leaves in
+    its epilogue (egne_conv_desc.stats_ws; egne_norm_stats_finish / _finish_moments) -- no pass over the tensor.  Against float64 over the
+    STORED (bf16) output; ragged tiles (H, W not multiples of 8 / 32) and padded channels included."""
+    from egne_amd import _lib, engine
+    from egne_amd.engine import ConvLayer, Piece, pad8
+    monkeypatch.setattr(engine, "STATS_FUSED_BF16", True)        # (EGNE_STATS_FUSED_BF16: off by default -- less traffic, no more frames/s)
+    x = _q(_rand(G, B, Cin, H, W))
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout) * bias + (bias if bias > 1 else 0.0)
+    pl = _plan()
+    pl.train = True
+    xp, = _pieces(pl, [x], B, H, W)
+    wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    wp.grad, bp.grad = torch.zeros_like(wp), torch.zeros_like(bp)
+    layer = ConvLayer([wp], [bp], [(xp.C, xp.Cp)], pad=(1, 1), act=2)
+    out = pl.buf(B, H, W, pad8(Cout))
+    pl._want_partials = True
+    pl.conv(layer, [xp], Piece(out, 0, Cout), B, H, W, name="c", stats=True)
+    sc, sh = pl.last_stats
+    ws, nchunk, Cs = pl.last_partials
+    kinds = [m[0] for m in pl.meta]
+    assert kinds == ["conv_bf16:3x3", "norm_stats"] and pl.calls[1][0] is pl.L.egne_norm_stats_finish, (kinds, [c[2] for c in pl.calls])
+    L = pl.L
+    rstd, nshift, mean, var = pl.vec(1, Cs), pl.vec(1, Cs), pl.vec(1, Cs), pl.vec(1, Cs)
+    n0, Bh = 1, B - 1                                       # batch statistics over samples [1, B): a BatchNorm over part of the launch's batch
+    pl._add(L.egne_norm_stats_finish_moments, (ws.data_ptr() + 16 * n0 * nchunk * Cs, Cs, 1, Bh * nchunk, Bh * H * W, 1e-5, rstd.data_ptr(), nshift.data_ptr(),
+                                               mean.data_ptr(), var.data_ptr()), "bn.stats", kind="norm_stats")
+    pl.run()
+    torch.cuda.synchronize()
+    y = out.float().cpu()[..., :Cout].double()               # as stored
+    m_, v_ = y.mean((1, 2)), y.var((1, 2), unbiased=False)
+    want_sc = 1.0 / torch.sqrt(v_ + 1e-5)
+    # PER (sample, channel): a channel whose variance is small against its mean must not borrow accuracy from the others
+    e1 = ((sc.cpu().double()[:, :Cout] - want_sc).abs() / want_sc).max().item()
+    e2 = ((sh.cpu().double()[:, :Cout] + m_ * want_sc).abs() / (m_ * want_sc).abs().clamp_min(1e-3)).max().item()
+    assert e1 < 2e-6 and e2 < 2e-6, "InstanceNorm rstd / shift from the epilogue: %.2e / %.2e" % (e1, e2)
+    yb = y[n0:]
+    mb, vb = yb.mean((0, 1, 2)), yb.var((0, 1, 2), unbiased=False)
+    e3 = ((mean.cpu().double()[0, :Cout] - mb).abs() / mb.abs().clamp_min(1e-3)).max().item()
+    e4 = ((var.cpu().double()[0, :Cout] - vb).abs() / vb).max().item()
+    e5 = ((rstd.cpu().double()[0, :Cout] - 1.0 / torch.sqrt(vb + 1e-5)).abs() * torch.sqrt(vb + 1e-5)).max().item()
+    assert e3 < 2e-6 and e4 < 2e-6 and e5 < 2e-6, "batch moments from the epilogue: mean %.2e var %.2e rstd %.2e" % (e3, e4, e5)
+
+
+def test_training_step_with_statistics_from_the_epilogue_changes_no_bit(edge_exact, monkeypatch):
+    """EGNE_STATS_FUSED_BF16=1: InstanceNorm / BatchNorm statistics of a bf16-storage training plan from the 3x3 epilogues.  The partial
+    sums are fp64 sums of bf16 values -- exact -- so loss, running statistics and every gradient equal the plain plan's bit for bit."""
+    from common import batch_args, esf_module
+    from egne_amd import engine
+    b, edge = edge_exact(B=2, seed=4321)
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(engine, "STATS_FUSED_BF16", flag)
+        m = esf_module("baseline_edge", seed=3).to(DEV).to(torch.bfloat16).train()
+        loss = m(*[a.to(DEV) if torch.is_tensor(a) else a for a in batch_args(b, edge)])[3]
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        names = [c[2] for c in m._last_plan.calls]
+        assert ("enc.b0.conv3.b.stats" in names) and (flag == any(c[0] is m._last_plan.L.egne_norm_stats_finish for c in m._last_plan.calls))
+        res.append((loss.detach().clone(), m._grad_flat.clone(), m.enc.head.bn.running_var.clone()))
+        del m
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_conv_generic_bf16_storage(G):
     """egne_conv2d_fwd with egne_conv_desc.dtype = 1: exact fp32 products on bf16 tensors -- the concat-free 1x1 over several
     slices with a fused affine (RITnet_v2.py:59-61,38-41), a reflect-padded stride-2 4x4 (StyleEncoder, :96-103), a "valid" 2x3
