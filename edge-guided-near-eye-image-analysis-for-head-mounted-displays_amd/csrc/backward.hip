@@ -1761,7 +1761,7 @@ static int wgrad_impl(const egne_conv_desc* dp, const TS* gz, int64_t gzs, int g
     const int ppw = (nco * nkc + 3) / 4;
     const size_t lds = (size_t)(nco + nkc) * ch * W1LD * sizeof(float);
     auto go = [&](auto kern) -> int {
-      static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+      const bool raised = egne::raise_lds((const void*)kern, 120 * 1024);
       if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "wgrad 1x1: cannot raise the dynamic LDS limit");
       hipLaunchKernelGGL(kern, dim3(nsplit), dim3(256), lds, st, d, gz, (long long)gzs, gzo, nsplit, nco, nkc, tab, (float*)ws);
       return EGNE_OK;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <unordered_map>
 #include "../../include/egne_hip.h"
 
 // 256 bytes of zeros in device memory: invalid (out-of-image / padded-channel) lanes load from here with
@@ -125,6 +127,24 @@ inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(EGNE_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
   return EGNE_OK;
+}
+
+// Dynamic-LDS limit of ONE kernel (hipFuncAttributeMaxDynamicSharedMemorySize), raised once per kernel address and again if a later
+// launch needs more.  Launch helpers that take the kernel as a generic-lambda / template argument share one function-pointer TYPE
+// between all instantiations of a kernel template: a `static bool once` inside them is one flag for all of them, and only the
+// first variant launched in the process would get its limit raised (round-5 advisor finding).
+inline bool raise_lds(const void* kern, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> have;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = have.find(kern);
+  if (it != have.end() && it->second >= bytes) return true;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  have[kern] = bytes;
+  return true;
 }
 
 #define EGNE_REQUIRE(cond, ...) \

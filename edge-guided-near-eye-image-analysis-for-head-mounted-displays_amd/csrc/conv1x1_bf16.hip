@@ -506,7 +506,7 @@ extern "C" int egne_conv1x1_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   if (gx > cap) gx = cap;
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto kern) -> int {
-    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+    const bool raised = egne::raise_lds((const void*)kern, 156 * 1024);
     if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(64 * nw), lds, st, d, (const egne_bf16*)wfrag, nks, nb16, tab, M);
     return egne::check_launch("egne_conv1x1_bf16_fwd");
@@ -597,7 +597,7 @@ extern "C" int egne_conv1x1_bf16_multi_fwd(const egne_conv_desc* dp, int ndst, c
   const long long gx = multi_grid(d, nks, nbt);
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto kern) -> int {
-    static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    const bool raised = egne::raise_lds((const void*)kern, 120 * 1024);
     if (!raised) return egne::fail(EGNE_ERR_LAUNCH, "conv1x1_bf16_multi: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, d, dt, ndst, nbt, tab, M, sum_dst, nks);
     return egne::check_launch("egne_conv1x1_bf16_multi_fwd");

@@ -362,7 +362,7 @@ int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long
     for (int i = 0; i < nk; ++i) { tab.seg[nco + i] = tseg[k0 + i]; tab.c0[nco + i] = tc0[k0 + i]; tab.kofs[nco + i] = tk[k0 + i]; }
     const size_t lds = (size_t)(nco + nk) * ch * 32 * sizeof(egne_bf16);
     auto go = [&](auto kern) -> int {
-      static const bool raised = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
+      const bool raised = egne::raise_lds((const void*)kern, 64 * 1024);
       if (!raised) return fail(EGNE_ERR_LAUNCH, "wgrad1x1_bf16: cannot raise the dynamic LDS limit");
       hipLaunchKernelGGL(kern, dim3(nsplit), dim3(512), lds, st, d, gz, gzs, gzo, nsplit, nco, nk, tab, ws);
       return check_launch("egne_conv2d_wgrad (1x1, bf16)");

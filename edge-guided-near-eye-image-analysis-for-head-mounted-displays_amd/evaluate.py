@@ -347,6 +347,7 @@ def evaluate_ellseg_per_video(path_vid, args, model, edge_model, device):
             # invalid results (engine.Plan.overflowed): this batch again, back to back, on the re-calibrated plans -- and the batch
             # queued behind it too, whose edge maps were computed with the old scales
             redo[0] = not redo[0]
+            torch.cuda.synchronize()    # the edge network of the NEXT batch is in flight on the pipeline's stream and owns the same plan buffers
             x = torch.stack([e[0] for _, _, fe in frames_of_batch for e in fe]).to(device)
             edge, seg, pup, iri = evaluate_ellseg_on_image(x, model, edge_model)
         k = 0

@@ -159,8 +159,16 @@ class GradOverlap:
         return n if seen_other else None
 
     def tail_ready(self):
-        if not (self.enabled and active()) or self.work is not None:
+        """Called by the backward plan.  Contract: exactly ONE backward pass per ``allreduce_grads``.  A second pass while the tail
+        bucket of the first is still out (gradient accumulation, a step abandoned after an exception) would write into the arena
+        slice the collective is reducing and ``finish`` would then mix summed and local gradients -- so it fails loudly; ``abandon``
+        waits the collective out when a step is given up."""
+        if not (self.enabled and active()):
             return
+        if self.work is not None:
+            raise RuntimeError("GradOverlap: a second backward pass started while the early all-reduce bucket of the previous one is still "
+                               "pending -- call parallel.allreduce_grads(model) after every backward (or model.grad_comm.abandon() "
+                               "to give a step up; EGNE_OVERLAP_ALLREDUCE=0 for gradient accumulation)")
         s = self.split()
         if not s:
             return
@@ -173,6 +181,13 @@ class GradOverlap:
     @property
     def pending(self):
         return self.work is not None
+
+    def abandon(self):
+        """Give the current step up (an exception between backward and the reduce): wait for the early bucket, forget it.  The arena
+        then holds a partly reduced gradient -- the next backward overwrites it."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
 
     def finish(self):
         flat, _ = grad_arena(self.model)

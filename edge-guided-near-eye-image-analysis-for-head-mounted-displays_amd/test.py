@@ -47,15 +47,19 @@ def calc_acc(args, testloader, model, edge_model, device):
     def metrics(batch, r):
         (mask, elPred, elOut, loss, flags), done = r
         done.synchronize()
-        if redo[0] or model.overflowed() or edge_model.overflowed():
+        # both words are read (and cleared) before they are combined: an edge-network overflow puts NaNs into the edge map, so the
+        # model's plan flags too, and a short-circuit `or` would leave the edge plan's word set and its stale scales in place
+        ov = bool(model.overflowed()) | bool(edge_model.overflowed())
+        if redo[0] or ov:
             # a frame beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): the results of this batch are
             # invalid; both plans re-calibrate on their next call, so the batch runs again, back to back -- and so does the batch
             # queued behind it, whose edge maps were computed with the old scales
             redo[0] = not redo[0]
+            torch.cuda.synchronize()    # the edge network of the NEXT batch is in flight on the pipeline's stream and owns the same plan buffers
             with torch.no_grad():
                 mask, elPred, elOut, loss, flags = second(batch)(calc_edge(args, batch[0].to(device), edge_model, device))
             torch.cuda.synchronize()
-            if model.overflowed() or edge_model.overflowed():
+            if bool(model.overflowed()) | bool(edge_model.overflowed()):
                 raise RuntimeError("non-finite activations after re-calibration: the input frames themselves are not finite")
         model.raise_on_loss_flags(flags)           # two absent classes: loss.py:132 raises in the reference
         img, labels, spatialWeights, distMap, pupil_center, iris_center, elNorm, cond, imInfo = batch

@@ -46,31 +46,38 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
     ranks feed the same numbers to the LR scheduler / early stopping."""
     model.eval()
     lsum = nsamp = isum = icnt = 0.0
-    train_products, edge_model.f16_products = getattr(edge_model, "f16_products", 0), 0      # validation: the 22-bit split products, as test.py
-    for bt, batch in enumerate(loader):
-        if args.test_normal and bt > 20:
-            break
-        img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
-        for attempt in (0, 1):
-            with torch.no_grad():
-                edge = calc_edge(args, img.to(device), edge_model, device)
-                out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
-                            dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
-            # a batch beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): both plans re-calibrate on their
-            # next call, so the batch runs once more
-            if not (bool(model.overflowed()) | bool(edge_model.overflowed())):
+    train_products = getattr(edge_model, "f16_products", 0)
+    edge_model.f16_products = 0          # validation: the 22-bit split products, as test.py
+    try:
+        for bt, batch in enumerate(loader):
+            if args.test_normal and bt > 20:
                 break
-        # batches are weighted by their sample count: under torchrun the shards (and their last batches) differ in size
-        n = float(img.shape[0])
-        model.raise_on_loss_flags(model.loss_flags())       # two absent classes: loss.py:132 raises in the reference
-        lsum += out[3].mean().item() * n
-        nsamp += n
-        iou = getSeg_metrics(labels.numpy(), model.predictions().cpu().numpy(), cond.numpy().astype(np.float32)[:, 1])[0]
-        if iou == iou:
-            isum += float(iou) * n
-            icnt += n
-    model.train()
-    edge_model.f16_products = train_products
+            img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
+            for attempt in (0, 1):
+                with torch.no_grad():
+                    edge = calc_edge(args, img.to(device), edge_model, device)
+                    out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
+                                dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
+                # a batch beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): both plans re-calibrate on their
+                # next call, so the batch runs once more
+                if not (bool(model.overflowed()) | bool(edge_model.overflowed())):
+                    break
+            else:
+                # (test.py / evaluate.py raise here too: a NaN validation loss would steer the LR scheduler, early stopping and the
+                # checkpoint choice)
+                raise RuntimeError("validation batch %d: non-finite activations after re-calibration: the input frames themselves are not finite" % bt)
+            # batches are weighted by their sample count: under torchrun the shards (and their last batches) differ in size
+            n = float(img.shape[0])
+            model.raise_on_loss_flags(model.loss_flags())       # two absent classes: loss.py:132 raises in the reference
+            lsum += out[3].mean().item() * n
+            nsamp += n
+            iou = getSeg_metrics(labels.numpy(), model.predictions().cpu().numpy(), cond.numpy().astype(np.float32)[:, 1])[0]
+            if iou == iou:
+                isum += float(iou) * n
+                icnt += n
+    finally:
+        model.train()
+        edge_model.f16_products = train_products
     if nsamp == 0:
         raise RuntimeError("rank %d validated no batch (validation set too small for %d ranks?)" % (parallel.rank(), parallel.world_size()))
     sums = parallel.sum_over_ranks([lsum, nsamp, isum, icnt], device)
@@ -132,6 +139,9 @@ def main(argv=None):
     # validation keeps its partial last batch (nothing is dropped, parallel.samplers); one process: as train.py:110-121
     validloader = DataLoader(validObj, batch_size=args.batchsize, shuffle=False, sampler=vsamp, num_workers=args.workers,
                              drop_last=vsamp is None and len(validObj) >= args.batchsize)
+    # one 4-byte read of the edge plan's sticky overflow word per step, where the step's stream has the edge map (EGNE_TRAIN_OVF_CHECK=0: off)
+    check_edge = os.environ.get("EGNE_TRAIN_OVF_CHECK", "1") != "0" and hasattr(edge_net, "overflowed")
+    redo_edge = [False]
     pipe = None
     if getattr(args, "pipeline", 0):
         from egne_amd.pipeline import TwoStagePipeline
@@ -148,6 +158,19 @@ def main(argv=None):
             img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
 
             def rest(edge, img=img, labels=labels, sw=sw, dm=dm, pc=pc, eln=eln, cond=cond, imInfo=imInfo):
+                if check_edge and (redo_edge[0] or bool(edge_net.overflowed())):
+                    # the frozen edge network left the f16 range of its calibrated pre-scales (engine.Plan.overflowed): this edge map holds
+                    # NaNs, and a step on it would put them into the BatchNorm statistics, the Adam state and the weights.  The plan is
+                    # marked for re-calibration, so the map is computed again, here, behind everything in flight (under the pipeline the
+                    # edge network of the NEXT batch is running on the other stream in the same plan buffers, with the old scales: that
+                    # batch computes its map again too)
+                    redo_edge[0] = pipe is not None and not redo_edge[0]
+                    torch.cuda.synchronize()
+                    edge = calc_edge(args, img.to(device), edge_net, device).clone()
+                    if edge_net.overflowed():
+                        raise RuntimeError("non-finite edge maps after re-calibration: the input frames themselves are not finite")
+                    if pipe is not None:
+                        pipe.sa.wait_stream(torch.cuda.current_stream())
                 optimizer.zero_grad()
                 if args.device_prep:    # bit-identical to the Dataset's one_hot2dist maps, 54k frames/s instead of 123 per host core
                     from egne_amd import dataprep

@@ -11,6 +11,10 @@ host memory per frame).  Here every one of the 256 frames differs, and three siz
   permutation of the batch -- logits follow their frames, the loss and every parameter gradient stay (sums in another order).  A
   kernel that reads or writes the wrong frame's data breaks this unless the mistake itself commutes with an arbitrary permutation;
 * bf16 against fp32 storage on the same 256 frames: per-frame logits and per-tensor gradient cosines.
+* the frozen edge network (round-5 verdict, "What's weak" 1): bench.py and train.py call ``calc_edge`` on the whole 256-frame shard
+  (utils.py:645-656 has no chunking), so its B=256 plan -- other rounds of the deep trunk kernel, other ``.tail`` splits, stage-1
+  tensors of 5 GB -- runs here in ONE call, in both product modes, against four B=64 calls (that plan is the oracle-checked one)
+  and against the live oracle on the first and last frames, all 11 outputs.
 """
 import types
 
@@ -155,3 +159,53 @@ def test_training_b256_distinct_frames_bf16_vs_fp32_storage(steps256):
     assert abs(rh["loss"] - rf["loss"]) < 1e-2 * abs(rf["loss"])
     assert per.median().item() < 8e-2 and per.max().item() < 2.5e-1
     assert cs[len(cs) // 10] > 0.93 and np.median(cs) > 0.975 and whole < 0.15 and cos > 0.99        # measured 0.963 / 0.986 / 0.108 / 0.9949
+
+
+def _kinds(pl):
+    return {k for k, _ in pl.meta}
+
+
+@pytest.mark.parametrize("products", [0, 1], ids=["split3", "plain_f16"])
+def test_bdcn_b256_distinct_frames_one_call(products):
+    """``BDCN.forward_fuse`` / ``forward`` on 256 DISTINCT frames in ONE call (what utils.calc_edge does with a configs[2..4] shard),
+    with the 22-bit split products and with plain f16 operands (``f16_products = 1``: the plan next to a bf16-storage training step).
+    (1) every frame of the fused map against the B=64 call that holds it (1e-5: the plans choose tiles / frame tails by B, products
+    are summed in another order); (2) the live oracle on frames 0, 1, 254, 255: the fused map and the 10 side outputs at 1e-3
+    (split) / 2^-9 (plain f16: the bound of test_bdcn_plain_f16_operands_next_to_a_bf16_training_plan); (3) the plan's kernel kinds."""
+    from common import bdcn_module
+    from egne_amd import synth
+    from oracle import bdcn as obdcn
+    _free()
+    b = synth.make_batch(B, seed=2025)
+    x = torch.cat((b["img"],) * 3, 1)
+    assert len({bytes(f.numpy().tobytes()[:4096]) for f in b["img"]}) == B
+    bd = bdcn_module().to(DEV)
+    bd.f16_products = products
+    xd = x.to(DEV)
+    got = bd.forward_fuse(xd)
+    pl = bd._last_plan
+    assert pl.x_in.shape[0] == B and pl.f16_products == products
+    assert not bd.overflowed()
+    kinds, names = _kinds(pl), [n for _, _, n in pl.calls]
+    assert {"conv_f16x3:big", "conv_f16x3:msdil", "conv_f16x3:first"} <= kinds and kinds & {"conv_f16x3:rs", "conv_f16x3:rw"}, kinds
+    tails = [n for n in names if n.endswith(".tail")]
+    worst = 0.0
+    for i in range(0, B, 64):
+        g4 = bd.forward_fuse(xd[i:i + 64])
+        per = (got[i:i + 64] - g4).abs().flatten(1).max(1)[0]
+        worst = max(worst, per.max().item())
+        assert per.max().item() < 1e-5, "frame %d of the B=256 call differs from its B=64 call by %.2e" % (i + int(per.argmax()), per.max())
+    assert bd._last_plan is not pl and bd._last_plan.x_in.shape[0] == 64
+    sub = [0, 1, B - 2, B - 1]
+    outs = [o[sub].cpu() for o in bd(xd)]                      # all 11 maps of the B=256 plan (only_fuse=False: a third plan)
+    assert bd._last_plan.x_in.shape[0] == B
+    with torch.no_grad():
+        ref = obdcn.bdcn_forward(bdcn_module().state_dict(), x[sub])
+    tol = 2.0 ** -9 if products else 1e-3
+    errs = [float((o - r).abs().max()) for o, r in zip(outs, ref)]
+    print("BDCN B=256 distinct frames, %s: worst frame vs its B=64 call %.2e; vs the oracle on frames %s: fused %.2e, side outputs max %.2e; "
+          "tail launches %s" % ("plain f16 operands" if products else "split products", worst, sub, errs[10], max(errs[:10]), tails or "none"))
+    assert max(errs) < tol, errs
+    assert float((outs[10] - got[sub].cpu()).abs().max()) < 1e-6            # forward()[-1] and forward_fuse agree
+    del bd, got, xd
+    _free()

@@ -289,6 +289,119 @@ def test_data_parallel_collectives_gloo_world4(tmp_path):
         assert p.returncode == 0 and "ok" in o, "rank %d failed:\n%s" % (r, o[-3000:])
 
 
+_DP8_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import torch, torch.distributed as dist
+torch.set_num_threads(1)
+from common import esf_module, setting, batch_args
+from egne_amd import parallel, synth, _entry
+from egne_amd.models.RITnet_v2 import DenseNet2D
+from oracle import esfnet as oesf
+rank, world = parallel.init('gloo')
+assert world == 8
+# -- (1) one data-parallel step of train.py's loop with REAL gradients: every rank owns one frame of a global batch of 8 (its
+#    shard of one shared permutation), computes loss and gradients on it with its own BatchNorm statistics and its own loss
+#    normalisation (oracle autograd: the HIP path needs a GPU), the arena is averaged over the ranks, Adam steps
+cfg = 'baseline_edge'
+m = esf_module(cfg, seed=rank, disentangle=True)          # ranks start different on purpose
+parallel.broadcast_state(m)
+parallel.overlap_grads(m)
+params = [p for n, p in m.named_parameters() if 'dsIdentify' not in n]
+opt = torch.optim.Adam(params, lr=5e-4)
+ts, vs = parallel.samplers(_entry.SyntheticEyes(16, seed=1), _entry.SyntheticEyes(9, seed=2), rank, world)
+ts.set_epoch(0)
+mine = list(ts)
+assert len(mine) == 2
+idx = torch.tensor(mine); allidx = [torch.zeros_like(idx) for _ in range(8)]
+dist.all_gather(allidx, idx)
+assert len(set(sum((a.tolist() for a in allidx), []))) == 16           # disjoint shards of one permutation
+assert list(vs) == list(range(rank, 9, 8))                               # rank 0 validates two frames, the others one: nothing dropped
+H, W = 240, 320                                                          # (the regression head's Linear layer fixes the frame size)
+b = synth.make_batch(1, H=H, W=W, seed=1000 + mine[0], mask_absent_every=8)
+sd = {k: (v.detach().clone().requires_grad_(v.dtype.is_floating_point and k in dict(m.named_parameters())) if torch.is_tensor(v) else v)
+      for k, v in m.state_dict().items()}
+edge = torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(rank))
+out = oesf.esf_forward(sd, setting(cfg), *batch_args(b, edge), training=True, disentangle=True)
+out[3].mean().backward()
+flat = m._ensure_grad_arena()
+flat.zero_()
+for n, p in m.named_parameters():
+    if sd[n].grad is not None:
+        p.grad.copy_(sd[n].grad)
+local = flat.clone()
+assert local.abs().sum() > 0 and torch.isfinite(local).all()
+every = [torch.zeros_like(local) for _ in range(8)]
+dist.all_gather(every, local)
+want = torch.stack(every).double().sum(0).div(8).float()
+# the backward plan's hook issues the tail bucket (everything behind the encoder's block), allreduce_grads the rest
+gc = m.grad_comm
+gc.tail_ready()
+assert gc.pending
+try:
+    gc.tail_ready()                                   # a second backward pass before the reduce must fail loudly (round-5 advisor finding)
+    raise SystemExit('a second tail_ready with the first bucket pending must raise')
+except RuntimeError:
+    pass
+parallel.allreduce_grads(m)
+assert not gc.pending
+err = (flat - want).abs().max().item() / want.abs().max().item()
+assert err < 1e-6, err
+opt.step()
+chk = torch.stack([p.detach().double().sum() for p in m.parameters()] + [p.detach().double().abs().sum() for p in m.parameters()]).reshape(-1)
+allchk = [torch.zeros_like(chk) for _ in range(8)]
+dist.all_gather(allchk, chk)
+assert all(torch.equal(allchk[0], c) for c in allchk), 'replicas diverged after one data-parallel Adam step'
+ref0 = esf_module(cfg, seed=0, disentangle=True)
+moved = sum(float((p - q).abs().sum()) for (n, p), (_, q) in zip(m.named_parameters(), ref0.named_parameters()) if 'dsIdentify' not in n)
+assert moved > 0
+# -- (2) the two-bucket split on the arenas of configs[3] (AdaIN modules) and configs[4] (64-channel model)
+for cfg2, chz in (('baseline_adain_edge', 32), ('baseline_edge', 64)):
+    m2 = DenseNet2D(dict(setting(cfg2)), chz=chz)
+    parallel.overlap_grads(m2)
+    f2 = m2._ensure_grad_arena()
+    s = m2.grad_comm.split()
+    nenc = sum(p.numel() for n, p in m2.named_parameters() if n.startswith('enc.'))
+    assert s == nenc and 0 < s < f2.numel(), (cfg2, chz, s, nenc, f2.numel())
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(f2.numel(), generator=g)
+    f2.copy_(base * (rank + 1))
+    m2.grad_comm.tail_ready()
+    assert m2.grad_comm.pending
+    parallel.allreduce_grads(m2)
+    assert torch.allclose(f2, base * 4.5, rtol=1e-5, atol=1e-6), (cfg2, chz)
+    if rank == 0:
+        print('arena', cfg2, chz, f2.numel() * 4 // 1024, 'KiB, early bucket %%.0f %%%%' %% (100.0 * (f2.numel() - s) / f2.numel()))
+lo, hi = parallel.shard(2048)
+assert (lo, hi) == (rank * 256, rank * 256 + 256)                        # configs[4]: global batch 2048 = 8 x 256
+assert parallel.sum_over_ranks([float(rank), 1.0]) == [28.0, 8.0]
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok')
+"""
+
+
+def test_data_parallel_step_gloo_world8(tmp_path):
+    """Eight ranks over gloo (BASELINE.json configs[4]: DP over 8 GPUs; replaces nn.DataParallel, train.py:205,285): a data-parallel
+    Adam step with real per-rank gradients (one frame per rank, local BatchNorm / loss normalisation, oracle autograd standing in for
+    the HIP backward, which needs a GPU), identical replicas afterwards; the two-bucket all-reduce on the AdaIN and 64-channel
+    arenas; shards of the global batch of 2048."""
+    script = tmp_path / "dp8_worker.py"
+    script.write_text(_DP8_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29651", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(8)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "ok" in o, "rank %d failed:\n%s" % (r, o[-3000:])
+
+
+def test_bench_refuses_eight_gpus_in_a_world_of_four():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--mode", "train"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode != 0 and b"--gpus 8 but WORLD_SIZE=4" in p.stdout
+
+
 def test_ellipse_transform_matches_reference():
     from egne_amd import ellipse
     g = gold("ellipse_transform")
