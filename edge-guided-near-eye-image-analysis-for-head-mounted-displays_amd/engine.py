@@ -1374,7 +1374,7 @@ class Plan:
             and layer.pad == (1, 1)
         smallcin = (one and SMALLCIN_ENABLED and layer.Cin <= 4 and pad8(layer.Cout) <= 64 and pieces[0].scale is None and residual is None
                     and not isinstance(layer, (DgradLayer, SplitDgradLayer, BfDgradLayer)) and layer.post is None)
-        fast3 = (one and not smallcin and BF16_FAST3X3 and pieces[0].Cp % 8 == 0 and pieces[0].off % 8 == 0 and pieces[0].stride % 8 == 0
+        fast3 = (one and not smallcin and BF16_FAST3X3 and layer.post is None and pieces[0].Cp % 8 == 0 and pieces[0].off % 8 == 0 and pieces[0].stride % 8 == 0
                  and layer.CoutP <= 256 and min(layer.Cout_store, dst.Cp) % 4 == 0 and min(layer.Cout_store, dst.Cp) >= 8
                  and H * W * max(pieces[0].stride, dst.stride) < 2 ** 30
                  and (residual is None or H * W * residual.stride < 2 ** 30))

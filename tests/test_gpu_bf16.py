@@ -107,6 +107,11 @@ def _check(got, want, what=""):
     (1, 180, 180, 30, 40, 2, False, False),    # streamed weights (192 padded input channels), six output blocks
     (3, 32, 3, 16, 96, 2, False, False),       # 3 output channels stored as 8
     (1, 256, 64, 9, 11, 1, False, False),      # deep K, tiny map
+    (2, 32, 64, 24, 40, 2, False, False),      # round 6: one chunk, a 64-channel block per workgroup (two 32-channel blocks per consumer wave)
+    (2, 32, 64, 19, 33, 0, False, True),       # ... with a residual, ragged tiles
+    (1, 64, 100, 20, 36, 2, True, True),       # 104 stored channels of a 128-channel pack: blocks of 64 + 64, the second partly stored
+    (1, 96, 160, 12, 40, 1, False, False),     # streamed weights, blocks 64 + 64 + 32: the last workgroup computes ONE 32-channel block
+    (2, 64, 64, 33, 70, 2, True, False),       # two resident chunks, fused affine, several tiles per worker
 ])
 def test_conv3x3_bf16_kernel(G, B, Cin, Cout, H, W, act, norm, res):
     """egne_conv3x3_bf16_fwd (models/RITnet_v2.py:57-62,85-87 in a bf16-storage plan) against float64 on the same
