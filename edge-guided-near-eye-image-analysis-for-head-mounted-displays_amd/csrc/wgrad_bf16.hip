@@ -179,6 +179,159 @@ void wgrad3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ 
 
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient for layers of 64+ channels on both sides (round 6).  With one (32 co, 32 ci) pair per workgroup a 64 -> 64
+// layer staged every gz tile and every x halo twice (four workgroups per tile), an eight-wave workgroup spent a tile's time on 18 MFMAs
+// per wave between two barriers and a single-buffered image, and the mid-resolution layers ran at 300-570 TFLOP/s.  Here a workgroup owns a
+// (64 co, 64 ci) QUAD of pairs for all nine taps:
+//   * both 32-channel halves of the gz tile and of the x halo are staged ONCE per tile, by LDS-DMA (buffer_load_dwordx4 ... lds: a wave
+//     instruction writes 16 pixels x 64 bytes of one image, no staging registers, no vector ALU), into one of TWO image sets -- tile
+//     t + 1 lands while tile t is contracted, one barrier per tile;
+//   * wave w contracts pair (w & 3) over four tile rows (w >> 2): the x fragment of halo row r serves the taps (dy, tile row) with
+//     row + 1 + dy = r, so it is read once for up to three MFMAs -- 36 x-fragment reads + 8 resident gz fragments per tile and wave for
+//     72 MFMAs (the pair-per-workgroup form: 18 + 2 for 18);
+//   * the two waves of a pair add their blocks through LDS at the end.
+// Layers whose input is normalised on load (egne_seg.scale: conv1 of the down blocks) keep the form above (the DMA cannot apply the affine).
+constexpr int WX = 352;                                   // halo pixels rounded up to whole DMA pieces of 16
+constexpr int WSET = (2 * GPX + 2 * WX) * 32;             // bf16 elements of one image set: [gz half 0 | gz half 1 | x half 0 | x half 1]
+constexpr int WNP = 2 * (GPX / 16) + 2 * (WX / 16);       // 76 DMA pieces per tile
+constexpr int WPI = (WNP + 7) / 8;                        // pieces per wave (10; the last round is partial)
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+__global__ __launch_bounds__(NT)
+void wgrad3x3_bf16_wide_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ gz, long long gzs, int gzo, int nsplit, int nqco,
+                               int nco, int nkc, int tiles_x, int tiles_y, int ntiles, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) egne_bf16 wlds[];      // two image sets; reused for the final cross-wave sum
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W;
+  const egne_seg sg = p.seg[0];
+  const egne_bf16* const xin = (const egne_bf16*)sg.ptr;
+  const int qc = blockIdx.y % nqco, qk = blockIdx.y / nqco;
+  const int co0 = qc * 64, ci0 = qk * 64;
+  const unsigned frame_g = (unsigned)H * W * (unsigned)gzs * 2u, frame_x = (unsigned)H * W * (unsigned)sg.pix_stride * 2u;
+
+  struct Tile { int b, y0, x0; };
+  auto decode = [&](int t) {
+    Tile r;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    r.b = t; r.y0 = ty * TH; r.x0 = tx * TW;
+    return r;
+  };
+  // this wave's DMA pieces j = wave + 8 I: tile-invariant byte offset relative to the tile's first pixel, and the column it reads
+  // (the only coordinate that needs a test: rows outside the frame fall outside the buffer resource, channels past the tensor are baked in)
+  int rel[WPI], col[WPI];
+#pragma unroll
+  for (int I = 0; I < WPI; ++I) {
+    const int j = wave + 8 * I, pc = lane & 3;
+    if (j < 2 * (GPX / 16)) {
+      const int half = j / (GPX / 16), px = (j % (GPX / 16)) * 16 + (lane >> 2);
+      const int c = co0 + half * 32 + pc * 8;
+      col[I] = px & 31;
+      rel[I] = c < p.Cout_store ? (int)((((long long)(px >> 5) * W + (px & 31)) * gzs + gzo + c) * 2) : (int)OOB;
+    } else if (j < WNP) {
+      const int jj = j - 2 * (GPX / 16), half = jj / (WX / 16), q = (jj % (WX / 16)) * 16 + (lane >> 2);
+      const int hy = q / HWd, hx = q - hy * HWd, c = ci0 + half * 32 + pc * 8;
+      col[I] = hx - 1;
+      rel[I] = (q < NPX && c < sg.Cp) ? (int)((((long long)(hy - 1) * W + (hx - 1)) * sg.pix_stride + sg.ch_off + c) * 2) : (int)OOB;
+    } else {
+      col[I] = 0; rel[I] = (int)OOB;
+    }
+  }
+  auto issue = [&](int t, int set) {
+    const Tile tl = decode(t);
+    const __amdgpu_buffer_rsrc_t rgz = make_rsrc(gz + (long long)tl.b * H * W * gzs, frame_g);
+    const __amdgpu_buffer_rsrc_t rxi = make_rsrc(xin + (long long)tl.b * H * W * sg.pix_stride, frame_x);
+    const int bg = (int)(((long long)tl.y0 * W + tl.x0) * gzs * 2), bx = (int)(((long long)tl.y0 * W + tl.x0) * sg.pix_stride * 2);
+    char* const base = (char*)(wlds + set * WSET);
+#pragma unroll
+    for (int I = 0; I < WPI; ++I) {
+      const int j = wave + 8 * I;
+      if (j < WNP) {                                                     // (wave-uniform)
+        const bool isg = j < 2 * (GPX / 16);
+        const bool ok = rel[I] != (int)OOB && (unsigned)(tl.x0 + col[I]) < (unsigned)W;
+        const int off = ok ? rel[I] + (isg ? bg : bx) : (int)OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isg ? rgz : rxi, (lds_vptr)(base + j * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  // pair of this wave and its four tile rows
+  const int pr = wave & 3, hh = wave >> 2;
+  const int ch_c = pr & 1, ch_k = pr >> 1;
+  const bool pair_ok = qc * 2 + ch_c < nco && qk * 2 + ch_k < nkc;     // (wave-uniform: the transposing reads run with all lanes enabled)
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int lbase = ((8 * (g16 >> 1) + (i16 >> 2)) * 32 + 16 * (g16 & 1) + 4 * (i16 & 3));      // elements (transposing read, see above)
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16)(0.f);
+
+  int t = blockIdx.x, set = 0;
+  if (t < ntiles) issue(t, 0);
+  for (; t < ntiles; t += nsplit, set ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t have landed ...
+    __syncthreads();                                       // ... and so have everyone's; every wave is done with the other set
+    if (t + nsplit < ntiles) issue(t + nsplit, set ^ 1);
+    if (pair_ok) {
+      const egne_bf16* const Gi = wlds + set * WSET + ch_c * (GPX * 32) + lbase;
+      const egne_bf16* const Xi = wlds + set * WSET + 2 * GPX * 32 + ch_k * (WX * 32) + lbase;
+      // the wave's eight gz fragments (four rows x two 16-pixel k-steps) stay in registers for the tile
+      egne_bf16x8 af[4][2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const egne_bf16* ga = Gi + ((hh * 4 + r) * 32 + 16 * s2) * 32;
+          const egne_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)ga);
+          const egne_bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(ga + 4 * 32));
+          af[r][s2] = egne_bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        }
+      // 36 x fragments: halo row hr (six per wave) x kernel column x k-step, each for the taps dy with tile row r = hr - 1 - dy in 0..3
+      auto loadx = [&](int hr, int dx, int s2) {
+        const egne_bf16* xa = Xi + ((hh * 4 + hr) * HWd + 16 * s2 + 1 + dx) * 32;
+        const egne_bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)xa);
+        const egne_bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(xa + 4 * 32));
+        return egne_bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      };
+      egne_bf16x8 bq = loadx(0, -1, 0);
+#pragma unroll
+      for (int it = 0; it < 36; ++it) {
+        const int hr = it / 6, dx = (it % 6) / 2 - 1, s2 = it & 1;
+        const egne_bf16x8 bcur = bq;
+        if (it + 1 < 36) bq = loadx((it + 1) / 6, ((it + 1) % 6) / 2 - 1, (it + 1) & 1);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int r = hr - 1 - dy;
+          if (r >= 0 && r < 4) acc[(dy + 1) * 3 + dx + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r][s2], bcur, acc[(dy + 1) * 3 + dx + 1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // the two waves of a pair (rows 0-3 / 4-7) add their blocks through LDS, one tap at a time; the pair's 32 x 32 block of every tap goes to
+  // the workgroup's partial: lane holds column k = lane & 31 of rows co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* const red = (float*)wlds;         // [8 waves][16][64]
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();
+    if (hh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(pr * 16 + r) * 64 + lane] = acc[tap][r];
+    }
+    __syncthreads();
+    if (hh == 0 && pair_ok) {
+      float* dst = ws + ((long long)blockIdx.x * 9 + tap) * (long long)p.CoutP * p.Ktot;
+      const int k = ci0 + ch_k * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + ch_c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (k < p.Ktot && co < p.CoutP) dst[(long long)co * p.Ktot + k] = acc[tap][r] + red[(pr * 16 + r) * 64 + lane];
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
 // 1x1 / stride 1 weight gradient over raw bf16 slices with every (32 co, 32 k) block pair of the layer in ONE workgroup (the bf16
 // form of conv1x1_wgrad_allpairs_kernel, backward.hip): a workgroup walks its pixel range in chunks of CH pixels (64 with up to 16
 // tiles, 128 up to 8, 256 up to 4: always 64 KB of loads in flight per workgroup -- with 64-pixel chunks the 4-tile layers of the
@@ -295,9 +448,16 @@ bool wgrad3x3_bf16_supported(const egne_conv_desc& d, long long gzs) {
 
 static int npairs_of(const egne_conv_desc& d) { return (d.CoutP / 32) * ((d.Ktot + 31) / 32); }
 
+// the quad-per-workgroup form: layers with two or more 32-channel blocks on BOTH sides whose input is read raw (no affine on load)
+static bool wgrad3x3_wide(const egne_conv_desc& d) {
+  static const bool off = [] { const char* e = getenv("EGNE_WGRAD3_WIDE"); return e && e[0] == '0'; }();
+  return !off && d.CoutP >= 64 && d.Ktot > 32 && !d.seg[0].scale;
+}
+static int nquads_of(const egne_conv_desc& d) { return ((d.CoutP / 32 + 1) / 2) * (((d.Ktot + 31) / 32 + 1) / 2); }
+
 int wgrad3x3_bf16_splits(const egne_conv_desc& d) {
   const long long tiles = (long long)((d.W + TW - 1) / TW) * ((d.H + TH - 1) / TH) * d.B;
-  long long ns = 256 / npairs_of(d);          // one 8-wave workgroup per CU
+  long long ns = 256 / (wgrad3x3_wide(d) ? nquads_of(d) : npairs_of(d));          // one 8-wave workgroup per CU
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   return (int)ns;
@@ -380,6 +540,14 @@ int wgrad3x3_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long
   if (gzo % 8 || ((uintptr_t)gz & 15)) return fail(EGNE_ERR_ARG, "wgrad3x3_bf16: gz slice must start on a multiple of 8 channels (offset %d)", gzo);
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH, ntiles = tiles_x * tiles_y * d.B;
   const int nsplit = wgrad3x3_bf16_splits(d), nco = d.CoutP / 32;
+  if (wgrad3x3_wide(d)) {
+    const int nkc = (d.Ktot + 31) / 32, nqco = (nco + 1) / 2;
+    const size_t lds = (size_t)2 * WSET * sizeof(egne_bf16);
+    if (!raise_lds((const void*)wgrad3x3_bf16_wide_kernel, lds)) return fail(EGNE_ERR_LAUNCH, "wgrad3x3_bf16 (wide): cannot raise the dynamic LDS limit to %zu", lds);
+    hipLaunchKernelGGL(wgrad3x3_bf16_wide_kernel, dim3(nsplit, nquads_of(d)), dim3(NT), lds, st, d, gz, gzs, gzo, nsplit, nqco, nco, nkc, tiles_x, tiles_y,
+                       ntiles, ws);
+    return check_launch("egne_conv2d_wgrad (3x3, bf16, wide)");
+  }
   hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(nsplit, npairs_of(d)), dim3(NT), 0, st, d, gz, gzs, gzo, nsplit, nco, tiles_x, tiles_y, ntiles, ws);
   return check_launch("egne_conv2d_wgrad (3x3, bf16)");
 }

@@ -542,6 +542,9 @@ def test_conv_generic_bf16_storage(G):
 
 
 @pytest.mark.parametrize("kind,Cin,Cout,H,W", [("3x3", 32, 32, 24, 40), ("3x3", 38, 64, 21, 35), ("3x3n", 64, 64, 30, 40),
+                                              # round 6, the quad-per-workgroup weight gradient: one full quad; 3 x 3 blocks (quads with missing pairs);
+                                              # 4 x 4 blocks with a partly stored last block, several tiles per workgroup and ragged columns
+                                              ("3x3", 64, 64, 30, 40), ("3x3", 96, 96, 17, 33), ("3x3", 128, 100, 24, 70),
                                               ("1x1", 166, 64, 48, 64), ("1x1big", 352, 100, 60, 40),
                                               ("1x1wide", 459, 153, 60, 40)])      # 15 input x 5 output tiles: two launches over groups of input tiles
 def test_weight_and_data_gradients_bf16_storage(G, kind, Cin, Cout, H, W):
