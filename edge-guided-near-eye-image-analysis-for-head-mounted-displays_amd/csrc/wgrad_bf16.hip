@@ -356,30 +356,48 @@ void wgrad1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ 
   const long long per = ((M + nsplit - 1) / nsplit + W1_CH - 1) / W1_CH * W1_CH;
   const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
   const int piece = tid & 3;                                            // item I of a thread: linear index tid + 512 I over (tile, pixel, 8-channel group)
+  // Everything about an item but the chunk it is read from is fixed for the launch: its tensor, channel group and pixel within the chunk.
+  // Round 5 derived all of it again per item and chunk -- a dynamically indexed egne_seg out of the kernel arguments (scalar loads), a
+  // 64-bit product for the chunk's base, a buffer resource -- 16-38 scalar instructions per MFMA (profiles/r05_pmc_kernels_train.txt).
+  // Now: one 64-bit address per item, advanced by a constant per chunk; lanes past the range or the tensor read a zero page.
   u32x4 rv[W1_NI];
+  const char* ia[W1_NI];          // address of the item in the chunk being requested next
+  int istep[W1_NI];               // bytes per chunk of W1_CH pixels (0: the item reads nothing)
+#pragma unroll
+  for (int I = 0; I < W1_NI; ++I) {
+    const int lin = tid + 512 * I, j = lin / (4 * W1_CH), px = (lin % (4 * W1_CH)) >> 2;
+    const bool isg = j < nco, on = j < nt;
+    const egne_seg& sg = p.seg[(isg || !on) ? 0 : tab.seg[j]];
+    const int c = (isg ? 32 * j : (on ? tab.c0[j] : 0)) + 8 * piece;
+    const bool cok = on && (isg ? c < p.Cout_store : c < sg.Cp);
+    const long long stride = isg ? gzs : sg.pix_stride;
+    const egne_bf16* base = isg ? gz : (const egne_bf16*)sg.ptr;
+    ia[I] = (const char*)(base + (m_begin + px) * stride + (isg ? gzo : sg.ch_off) + c);
+    istep[I] = cok ? (int)(W1_CH * stride * 2) : 0;
+  }
   auto issue = [&](long long mc) {
     const int rows = (int)(m_end - mc < W1_CH ? m_end - mc : W1_CH);
 #pragma unroll
     for (int I = 0; I < W1_NI; ++I) {
-      const int lin = tid + 512 * I, j = lin / (4 * W1_CH), px = (lin % (4 * W1_CH)) >> 2;
       if (512 * I < nt * 4 * W1_CH) {                 // (uniform; the lanes past the last tile read nothing)
-        const bool isg = j < nco, on = j < nt;
-        const egne_seg& sg = p.seg[(isg || !on) ? 0 : tab.seg[j]];
-        const int c = (isg ? 32 * j : (on ? tab.c0[j] : 0)) + 8 * piece;
-        const bool cok = on && (isg ? c < p.Cout_store : c < sg.Cp);
-        const long long stride = isg ? gzs : sg.pix_stride;
-        const egne_bf16* base = (isg ? gz : (const egne_bf16*)sg.ptr) + mc * stride;
-        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, (unsigned)rows * (unsigned)stride * 2u);       // pixels past the range read zeros
-        const int off = cok ? (int)((px * stride + (isg ? gzo : sg.ch_off) + c) * 2) : (int)OOB;
-        rv[I] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        const int px = ((tid + 512 * I) % (4 * W1_CH)) >> 2;
+        const bool ok = istep[I] != 0 && px < rows;   // pixels past the range read zeros
+        rv[I] = *(const u32x4*)(ok ? ia[I] : (const char*)egne_zero_page);
+        ia[I] += istep[I];
       }
     }
   };
   const int g16 = lane >> 4, i16 = lane & 15;
   const int lbase = ((8 * (g16 >> 1) + (i16 >> 2)) * 32 + 16 * (g16 & 1) + 4 * (i16 & 3));      // elements (transposing read, see above)
   f32x16 acc[PPW];
+  int aofs[PPW], bofs[PPW];       // LDS images of this wave's pairs (no division per pair and chunk)
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) acc[i] = (f32x16)(0.f);
+  for (int i = 0; i < PPW; ++i) {
+    acc[i] = (f32x16)(0.f);
+    const int q = wave + 8 * i, kc = q / nco, ct = q - kc * nco;
+    aofs[i] = (ct * W1_CH) * 32 + lbase;
+    bofs[i] = ((nco + kc) * W1_CH) * 32 + lbase;
+  }
   if (m_begin < m_end) issue(m_begin);
   for (long long mc = m_begin; mc < m_end; mc += W1_CH) {
     __syncthreads();                 // every wave is done with the previous chunk's tiles
@@ -392,11 +410,9 @@ void wgrad1x1_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ 
     if (mc + W1_CH < m_end) issue(mc + W1_CH);       // next chunk's loads fly during this chunk's MFMAs
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int q = wave + 8 * i;
-      if (q < npairs) {               // (wave-uniform: the transposing reads below run with all lanes enabled)
-        const int kc = q / nco, ct = q - kc * nco;
-        const egne_bf16* As = w1lds + (ct * W1_CH) * 32 + lbase;
-        const egne_bf16* Bs = w1lds + ((nco + kc) * W1_CH) * 32 + lbase;
+      if (wave + 8 * i < npairs) {    // (wave-uniform: the transposing reads below run with all lanes enabled)
+        const egne_bf16* As = w1lds + aofs[i];
+        const egne_bf16* Bs = w1lds + bofs[i];
 #pragma unroll
         for (int s = 0; s < W1_CH / 16; ++s) {
           const egne_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(As + 16 * s * 32));

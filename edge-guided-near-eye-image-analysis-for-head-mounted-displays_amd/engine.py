@@ -67,10 +67,11 @@ WSCALE_EVERY = int(os.environ.get("EGNE_WSCALE_EVERY", "16"))   # training plans
 TRAIN_SPLIT = os.environ.get("EGNE_TRAIN_SPLIT", "1") != "0"     # training plans: split-f16 (22-bit products) 3x3 forward convolutions and data gradients, pre-scales taken on the device
 F16X3_ASCALE = float(os.environ.get("EGNE_F16X3_ASCALE", "16"))   # pre-scale of inputs that are normalised on load (|z| <= sqrt(H*W))
 STATS_FUSED = os.environ.get("EGNE_STATS_FUSED", "1") != "0"      # InstanceNorm statistics from the producing conv's epilogue
-# ... in bf16-storage training plans too (bf16 3x3 kernel; BatchNorm batch statistics likewise).  OFF by default: measured on the B=256 step it
-# takes 7 GB of HBM traffic off (the statistics passes over `out` of every down block and the head's pre-BatchNorm tensor) and 0.3-1 % of
-# frames/s with them -- the consumer waves of the 3x3 kernel are its only MFMA issuers and the per-tile reduction sits in their hand-over
-STATS_FUSED_BF16 = os.environ.get("EGNE_STATS_FUSED_BF16", "0") != "0"
+# ... in bf16-storage training plans too (bf16 3x3 kernel; BatchNorm batch statistics likewise): the statistics passes over `out` of every
+# down block and the head's pre-BatchNorm tensor go (7 GB of HBM traffic per B=256 step).  Round 5 measured 0.3-1 % FEWER frames/s with it and
+# left it off; with round 6's 3x3 kernel the A/B is level (1552 / 1540 without, 1544 / 1547 with, scratch/r06_env_ab.sh) and the traffic
+# decides: ON (EGNE_STATS_FUSED_BF16=0: separate passes; bit-identical either way, tests/test_gpu_bf16.py)
+STATS_FUSED_BF16 = os.environ.get("EGNE_STATS_FUSED_BF16", "1") != "0"
 FUSE_1X1 = os.environ.get("EGNE_FUSE_1X1", "1") != "0"            # 1x1 + its consuming 3x3 as one launch (inference plans)
 FUSE_1X1_MIN_W = int(os.environ.get("EGNE_FUSE_1X1_MIN_W", "60"))
 FUSE_C4 = os.environ.get("EGNE_FUSE_C4", "1") != "0"              # convBlock head (3x3 on <= 4 channels + 3x3) as one launch

@@ -454,7 +454,7 @@ def test_statistics_from_the_bf16_3x3_epilogue(G, B, Cin, Cout, H, W, bias, monk
     STORED (bf16) output; ragged tiles (H, W not multiples of 8 / 32) and padded channels included."""
     from egne_amd import _lib, engine
     from egne_amd.engine import ConvLayer, Piece, pad8
-    monkeypatch.setattr(engine, "STATS_FUSED_BF16", True)        # (EGNE_STATS_FUSED_BF16: off by default -- less traffic, no more frames/s)
+    monkeypatch.setattr(engine, "STATS_FUSED_BF16", True)        # (EGNE_STATS_FUSED_BF16: on by default since round 6)
     x = _q(_rand(G, B, Cin, H, W))
     w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout) * bias + (bias if bias > 1 else 0.0)
     pl = _plan()
