@@ -57,6 +57,17 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Output-channel order of a 32-channel block inside the LDS weight images (round 6).  The consumer's two fragments nh = 0 / 1 of a block
+// are the LDS lane positions 16 nh + i (i = MFMA row), and the transposed product leaves rows 4 kg .. 4 kg + 3 of a fragment in lane
+// group kg.  With channel 8 (i >> 2) + 4 nh + (i & 3) at position 16 nh + i a lane ends with the EIGHT CONSECUTIVE channels 8 kg .. 8 kg + 7
+// of its pixel in its two accumulators: one 16-byte store per pixel, block and lane instead of two of 8 bytes (a consumer wave's 16
+// stores per tile were 800-1000 of its 8 300 cycles, scratch/b3_stamps.py; the reads keep their conflict-free lane order).
+// pack lane (k-half h, channel c) = 32 h + c  <-  LDS lane position l = 32 h + m:
+__device__ __forceinline__ int chan_lane(int l) {
+  const int m = l & 31;
+  return (l & 32) + 8 * ((m & 15) >> 2) + 4 * (m >> 4) + (m & 3);
+}
+
 __device__ __forceinline__ f32x4 unpack_lo(u32x2 v) {     // 4 bf16 -> 4 floats
   const u32x4 w = {v[0] << 16, v[0] & 0xffff0000u, v[1] << 16, v[1] & 0xffff0000u};
   return __builtin_bit_cast(f32x4, w);
@@ -123,7 +134,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
   if constexpr (!STREAM) {
     for (int it = tid; it < KCH * 9 * MB * 2 * 64; it += 512) {       // 16-byte items, LDS order [chunk][tap][mb][ks][lane]
       const int l = it & 63, ks = (it >> 6) & 1, r0 = it >> 7, mb = r0 % MB, r = r0 / MB, tap = r % 9, ch = r / 9;
-      const long long src = (((long long)tap * KT16 + ch * 2 + ks) * ncb + cb * MB + mb) * 512 + l * 8;
+      const long long src = (((long long)tap * KT16 + ch * 2 + ks) * ncb + cb * MB + mb) * 512 + chan_lane(l) * 8;
       *(u32x4*)&lw[(long long)it * 8] = mb < mbn ? *(const u32x4*)(wfrag + src) : u32x4{0u, 0u, 0u, 0u};
     }
   }
@@ -224,7 +235,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 #pragma unroll
       for (int i = 0; i < (STREAM ? NWI : 0); ++i) {
         const int it = tid + 256 * i, l = it & 63, ks = (it >> 6) & 1, r0 = it >> 7, mb = r0 % MB, tap = r0 / MB;
-        const int off = (on && it < NWP && mb < mbn) ? ((((tap * KT16 + ch * 2 + ks) * ncb + cb * MB + mb) * 512 + l * 8) * 2) : (int)OOB;
+        const int off = (on && it < NWP && mb < mbn) ? ((((tap * KT16 + ch * 2 + ks) * ncb + cb * MB + mb) * 512 + chan_lane(l) * 8) * 2) : (int)OOB;
         wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rwf, off, 0, 0);
       }
     };
@@ -302,8 +313,8 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 2u;
     const unsigned frame_res = (unsigned)H * W * (unsigned)p.res_pix_stride * 2u;
     const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
-    // transposed product (weights as the A operand): the lane holds channels n = 32 (cb MB + mb) + 16 nh + 4 kg + r of pixel 16 ph + l15
-    const int nbase = cb * MB * 32 + 4 * kg;             // + mb * 32 + nh * 16
+    // transposed product (weights as the A operand): the lane holds channels n = 32 (cb MB + mb) + 8 kg + 4 nh + r of pixel 16 ph + l15
+    const int nbase = cb * MB * 32 + 8 * kg;             // + mb * 32 + nh * 4 (chan_lane: eight consecutive channels per lane and block)
     // Activation operands: pixel q = (row0 + r) * 34 + 16 ph + kx + l15 (r = tm + ky), 8-channel group kg at group kg ^ ((q >> 1) & 3).
     // With c = r * 34 + 16 ph + kx (compile time) and row0 * 34 = 68 cw even: (q >> 1) = ((l15 + (c & 1)) >> 1) + (c >> 1) + 34 cw, so the
     // lane-dependent part of the address takes EIGHT values (parity of c, (c >> 1) & 3) and the rest is the instruction's offset
@@ -347,7 +358,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     // waited a memory round trip for them -- a masked data gradient took twice the time of a plain one)
     // (declared per job below: values that live from tap 5 of a tile's last job to its hand-over only -- as loop-carried variables they
     //  held 32 MB registers through every tap)
-    auto jok = [&](int mb, int nh) { return nbase + mb * 32 + nh * 16 < p.Cout_store; };      // Cout_store is a multiple of 4
+    auto jok = [&](int mb, int nh) { return nbase + mb * 32 + nh * 4 < p.Cout_store; };       // Cout_store is a multiple of 4
     // values are finished (activation [, residual, mask]) and rounded at hand-over, behind the barrier that releases the tile's last image
     // to the producers; the deferred part is the bare store.  (Round 6 measured the 16 groups at 2 450 cycles per tile next to 4 600 of MFMA
     // issue, scratch/b3_stamps.py, and tried them BETWEEN the MFMAs of the tile's last tap: the same total -- the wave's vector work does
@@ -379,11 +390,20 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       const u32x2 pk = __builtin_bit_cast(u32x2, __builtin_convertvector(v, egne_bf16x4));
       if (PP == 1 || tpar == 0) prevp[0][tm][ph][mb][nh] = pk; else prevp[PP - 1][tm][ph][mb][nh] = pk;
     };
+    // store group Gs = (tm, ph, mb): both halves nh of a block as ONE 16-byte store (8-byte stores where the slice ends or starts on a multiple of 4
+    // that is not one of 8 -- uniform per launch)
+    const bool narrow = ((p.Cout_store | p.out_ch_off | (int)p.out_pix_stride) & 4) != 0;
     auto store_group = [&](auto gc) {
-      constexpr int Gi = decltype(gc)::value, nh = Gi & 1, mb = (Gi >> 1) % MB, ph = ((Gi >> 1) / MB) & 1, tm = (Gi >> 1) / MB / 2;
+      constexpr int Gi = decltype(gc)::value, mb = Gi % MB, ph = (Gi / MB) & 1, tm = Gi / MB / 2;
       // (the tile being stored is the PREVIOUS one: the other parity; after the last tile tpar has flipped once more)
-      const u32x2 pk = (PP == 1 || tpar == 1) ? prevp[0][tm][ph][mb][nh] : prevp[PP - 1][tm][ph][mb][nh];
-      __builtin_amdgcn_raw_buffer_store_b64(pk, rout, jok(mb, nh) ? tvo[tm][ph] : (int)OOB, (mb * 32 + nh * 16) * 2, 0);
+      const u32x2 p0 = (PP == 1 || tpar == 1) ? prevp[0][tm][ph][mb][0] : prevp[PP - 1][tm][ph][mb][0];
+      const u32x2 p1 = (PP == 1 || tpar == 1) ? prevp[0][tm][ph][mb][1] : prevp[PP - 1][tm][ph][mb][1];
+      if (narrow) {
+        __builtin_amdgcn_raw_buffer_store_b64(p0, rout, jok(mb, 0) ? tvo[tm][ph] : (int)OOB, (mb * 32) * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(p1, rout, jok(mb, 1) ? tvo[tm][ph] : (int)OOB, (mb * 32 + 4) * 2, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{p0[0], p0[1], p1[0], p1[1]}, rout, jok(mb, 1) ? tvo[tm][ph] : (int)OOB, (mb * 32) * 2, 0);
+      }
     };
     bool have_prev = false;
     // The jobs of a tile as straight-line code per position -- FIRST job (the previous tile's stores ride on its first four taps), middle
@@ -409,8 +429,8 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
               for (int nh = 0; nh < 2; ++nh) {
-                if (resp) pre_r[tm][ph][mb][nh] = __builtin_amdgcn_raw_buffer_load_b64(rr, jok(mb, nh) ? orr : (int)OOB, (mb * 32 + nh * 16) * 2, 0);
-                if (mskp) pre_m[tm][ph][mb][nh] = __builtin_amdgcn_raw_buffer_load_b64(rm, jok(mb, nh) ? om : (int)OOB, (mb * 32 + nh * 16) * 2, 0);
+                if (resp) pre_r[tm][ph][mb][nh] = __builtin_amdgcn_raw_buffer_load_b64(rr, jok(mb, nh) ? orr : (int)OOB, (mb * 32 + nh * 4) * 2, 0);
+                if (mskp) pre_m[tm][ph][mb][nh] = __builtin_amdgcn_raw_buffer_load_b64(rm, jok(mb, nh) ? om : (int)OOB, (mb * 32 + nh * 4) * 2, 0);
               }
           }
       };
@@ -440,13 +460,13 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
           (([&] {
             constexpr int S = Ss, Bq = S & 1;
             if constexpr (S + 1 < 9) fetch(std::integral_constant<int, S + 1>{});
-            // the previous tile's results leave between the MFMAs of the first four taps of this tile's first job (2 MB stores of 8 bytes
+            // the previous tile's results leave between the MFMAs of the first four taps of this tile's first job (MB stores of 16 bytes
             // per tap); the residual / mask vectors of the tile are requested at tap 5 of its last job
             if constexpr (FIRST && S < 4) {
               if (have_prev) {
                 [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
-                  (store_group(std::integral_constant<int, 2 * MB * S + Gs>{}), ...);
-                }(std::make_integer_sequence<int, 2 * MB>{});
+                  (store_group(std::integral_constant<int, MB * S + Gs>{}), ...);
+                }(std::make_integer_sequence<int, MB>{});
               }
             }
             if constexpr (RM && LAST && S == 5) prefetch_rm();
@@ -521,7 +541,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
             t += q2.x + q2.y;
           }
           const int nhq = vq >> 3, eq = (vq >> 1) & 3, stq = vq & 1;
-          const int n = (cb * MB + mb) * 32 + nhq * 16 + 4 * kgq + eq;
+          const int n = (cb * MB + mb) * 32 + 8 * kgq + 4 * nhq + eq;
           const long long chunk = (long long)(tl.y0 / TH) * tiles_x + tl.x0 / TW;
           if (n < p.Cout_store)
             p.stats_ws[((((long long)tl.b * p.stats_nchunk + chunk * 4 + cw) * p.Cout_store) + n) * 2 + stq] = t;
@@ -542,12 +562,12 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-          int lo = 4 * kg;
+          int lo = 8 * kg;
           asm volatile("" : "+v"(lo));                    // (opaque OFFSET: an opaque pointer would lose its LDS address space -- flat loads)
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) acc[tm][ph][mb][nh] = *(const f32x4*)&lepi[lo + mb * 32 + nh * 16];
+            for (int nh = 0; nh < 2; ++nh) acc[tm][ph][mb][nh] = *(const f32x4*)&lepi[lo + mb * 32 + nh * 4];
         }
       u32x2 pre_r[2][2][MB][2], pre_m[2][2][MB][2];      // (assigned at tap 5 of the tile's last job, read at its hand-over)
       if constexpr (KCH == 1) {
@@ -578,7 +598,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     B3_OUT();
     for (; s < nloop; ++s) lds_barrier();                // (the producers run an even number of steps)
     if (have_prev)
-      [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NG>{});
+      [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 4 * MB>{});
     if (mskp && p.mask_sums) {
       // over the 16 pixel lanes that share the channel vector (fixed order), then row (workgroup, consumer wave) of mask_sums [rows][Cout_store]
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -598,7 +618,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
           for (int nh = 0; nh < 2; ++nh)
             if (jok(mb, nh)) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) row[nbase + mb * 32 + nh * 16 + e] = (float)msum[mb * 2 + nh][e];
+              for (int e = 0; e < 4; ++e) row[nbase + mb * 32 + nh * 4 + e] = (float)msum[mb * 2 + nh][e];
             }
       }
     }

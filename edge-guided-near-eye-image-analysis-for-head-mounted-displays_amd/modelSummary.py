@@ -1,6 +1,6 @@
 """Model registry (reference: modelSummary.py:18-26, which instantiates classes that do not exist and
 calls DenseNet2D() without its required ``setting``).  Here the dictionary holds factories.  'ritnet_v1' is the comparator of
-models/RITnet_v1.py and 'deepvog' the one of models/deepvog_pytorch.py (evaluation only); neither takes a ``setting``: the edge options
+models/RITnet_v1.py and 'deepvog' the one of models/deepvog_pytorch.py (evaluation and training; fp32 storage only, bf16 storage refused); neither takes a ``setting``: the edge options
 do not apply to them."""
 from .models.RITnet_concat import DenseNet2D as DN_concat
 from .models.RITnet_v1 import DenseNet2D as DN_v1
