@@ -86,8 +86,12 @@ __device__ __forceinline__ f32x4 unpack_lo(u32x2 v) {     // 4 bf16 -> 4 floats
 // RM: 0 = neither residual nor mask; 1 = a residual (accumulating data gradients); 2 = a mask, with or without a residual (the last writer of
 // a gradient slice).  Their vectors are prefetched into 8 MB register pairs each -- compiled out of the launches that have none: the
 // 64-channel form has registers for ONE of the two sets (masked launches of 64+ channels take the MB = 1 form).
-template <int KCH, int MB, int RM>
-__global__ __launch_bounds__(512)
+// RW: tile rows per consumer wave.  2: four consumer waves (one MFMA-issuing wave per SIMD).  1 (round 6, MB = 2 without statistics or mask):
+// EIGHT consumer waves of one row each next to the four producers -- two MFMA-issuing waves per SIMD, so that one wave's operand waits,
+// hand-over and stores run under the other's MFMAs (stamps: a consumer wave of the four-wave form spends 4 600 of 10 300 cycles per tile
+// issuing MFMAs and nobody else on its SIMD issues any).
+template <int KCH, int MB, int RM, int RW>
+__global__ __launch_bounds__(64 * (4 + 8 / RW))
 void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ wfrag, int tiles_x, int tiles_y, int ntiles, int ncb,
                          int nrun) {
   extern __shared__ __attribute__((aligned(16))) egne_bf16 ldsb[];
@@ -132,7 +136,8 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
   // the block's weights: fragments (tap, k16, nt = cb MB + mb) of the pack [tap][Ktot/16][CoutP/32][lane][8]
   const int KT16 = nk * 2;
   if constexpr (!STREAM) {
-    for (int it = tid; it < KCH * 9 * MB * 2 * 64; it += 512) {       // 16-byte items, LDS order [chunk][tap][mb][ks][lane]
+    constexpr int NTHR = 64 * (4 + 8 / RW);
+    for (int it = tid; it < KCH * 9 * MB * 2 * 64; it += NTHR) {       // 16-byte items, LDS order [chunk][tap][mb][ks][lane]
       const int l = it & 63, ks = (it >> 6) & 1, r0 = it >> 7, mb = r0 % MB, r = r0 / MB, tap = r % 9, ch = r / 9;
       const long long src = (((long long)tap * KT16 + ch * 2 + ks) * ncb + cb * MB + mb) * 512 + chan_lane(l) * 8;
       *(u32x4*)&lw[(long long)it * 8] = mb < mbn ? *(const u32x4*)(wfrag + src) : u32x4{0u, 0u, 0u, 0u};
@@ -306,7 +311,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     // =================================================================== consumers: 9 taps per job from LDS only
     // v_mfma_f32_16x16x32_bf16: one instruction per (16 channels, 16 pixels, 32 input channels of a tap); a wave's two rows x 32
     // pixels x 32 MB channels are 8 MB independent accumulators
-    const int cw = wave - 4, row0 = cw * 2;
+    const int cw = wave - 4, row0 = cw * RW;
     const int l15 = lane & 15, kg = lane >> 4;
     egne_bf16* const outp = (egne_bf16*)p.out;
     const egne_bf16* const resp = RM ? (const egne_bf16*)p.residual : nullptr;       // (RM = 2: may be null)
@@ -324,25 +329,25 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     for (int par = 0; par < 2; ++par)
 #pragma unroll
       for (int mm = 0; mm < 4; ++mm)
-        atab[par][mm] = (l15 + cw * 68) * 64 + ((kg ^ ((((l15 + par) >> 1) + mm + 2 * cw) & 3)) << 4);
+        atab[par][mm] = (l15 + cw * RW * 34) * 64 + ((kg ^ ((((l15 + par) >> 1) + mm + cw * RW * 17) & 3)) << 4);
     // weights: k-group kg of output channel m = fragment k16 = kg >> 1, lane position (kg & 1) * 32 + m
     const int wl = (kg >> 1) * 512 + ((kg & 1) * 32 + l15) * 8;       // + (tap * MB + mb) * 1024 + nh * 128 (elements)
-    f32x4 acc[2][2][MB][2];
+    f32x4 acc[RW][2][MB][2];
     // the finished tile as it will be stored (bf16 x 4 per group).  MB = 1: TWO sets, by tile parity -- a set is rewritten two tiles after
     // its stores went out; with one set the rounding at the tile's last tap waited for the acknowledgements of the previous tile's stores
     // (the compiler guards the data registers of a store in flight with s_waitcnt vmcnt(0))
     constexpr int PP = 1;       // (PP = 2 for MB = 1 measured: the parity branches per group cost more than the wait they avoid)
-    u32x2 prevp[PP][2][2][MB][2];
+    u32x2 prevp[PP][RW][2][MB][2];
     int tpar = 0;                                         // parity of the tile being computed
-    constexpr int NG = 8 * MB;
+    constexpr int NG = 4 * RW * MB;
 #pragma unroll
     for (int a = 0; a < NG; ++a) (&acc[0][0][0][0])[a] = (f32x4)(0.f);
 #pragma unroll
     for (int a = 0; a < NG * PP; ++a) (&prevp[0][0][0][0][0])[a] = u32x2{0u, 0u};
     __amdgpu_buffer_rsrc_t rout = make_rsrc(outp, 0u);
-    int tvo[2][2];
+    int tvo[RW][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) (&tvo[0][0])[a] = (int)OOB;
+    for (int a = 0; a < 2 * RW; ++a) (&tvo[0][0])[a] = (int)OOB;
     // mask-on-write (egne_conv_desc.mask_y): the launch is the last writer of a gradient slice -- the stored value is v * act'(y), and the
     // wave keeps the sums of what it stores (fp64, all its tiles) for the producing layer's bias gradient
     const egne_bf16* const mskp = RM == 2 ? (const egne_bf16*)p.mask_y : nullptr;
@@ -364,7 +369,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     // issue, scratch/b3_stamps.py, and tried them BETWEEN the MFMAs of the tile's last tap: the same total -- the wave's vector work does
     // not hide behind its own matrix work -- and 45 spilled registers in the residual form; the bias now enters as the accumulators'
     // initial value and the activation is branch-free.)
-    auto finish_group = [&](auto gc, const u32x2 (&pre_r)[2][2][MB][2], const u32x2 (&pre_m)[2][2][MB][2]) {
+    auto finish_group = [&](auto gc, const u32x2 (&pre_r)[RW][2][MB][2], const u32x2 (&pre_m)[RW][2][MB][2]) {
       constexpr int Gi = decltype(gc)::value, nh = Gi & 1, mb = (Gi >> 1) % MB, ph = ((Gi >> 1) / MB) & 1, tm = (Gi >> 1) / MB / 2;
       f32x4 v = acc[tm][ph][mb][nh];                       // (the bias went in with the accumulator's initial value)
       // branch-free: none / ReLU / LeakyReLU are max(v, v * slope) with slope 1 / 0 / 0.01 -- a taken scalar branch between two MFMAs
@@ -410,7 +415,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     // jobs, LAST job (residual / mask vectors requested at tap 5, hand-over behind it) -- so that the compiler sees where the packed
     // results of the previous tile and the prefetched vectors are live: as conditions inside one loop body both sets stayed allocated
     // through every tap and the 64-channel form spilled 250 registers.
-    auto run_job = [&](auto firstc, auto lastc, const Tile& tl, int ch, int s, u32x2 (&pre_r)[2][2][MB][2], u32x2 (&pre_m)[2][2][MB][2]) {
+    auto run_job = [&](auto firstc, auto lastc, const Tile& tl, int ch, int s, u32x2 (&pre_r)[RW][2][MB][2], u32x2 (&pre_m)[RW][2][MB][2]) {
       constexpr bool FIRST = decltype(firstc)::value, LAST = decltype(lastc)::value;
       const char* Timg = (const char*)(ldsb + (s & 1) * IMG);
       const egne_bf16* wb = lw + (STREAM ? (s & 1) : ch) * WCHM + wl;
@@ -418,7 +423,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
         const __amdgpu_buffer_rsrc_t rr = make_rsrc(resp ? resp + (long long)tl.b * H * W * p.res_pix_stride : nullptr, resp ? frame_res : 0u);
         const __amdgpu_buffer_rsrc_t rm = make_rsrc(mskp ? mskp + (long long)tl.b * H * W * p.mask_pix_stride : nullptr, mskp ? frame_msk : 0u);
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < RW; ++tm)
 #pragma unroll
           for (int ph = 0; ph < 2; ++ph) {
             const int yy = tl.y0 + row0 + tm, x = tl.x0 + ph * 16 + l15;
@@ -448,7 +453,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) wh[Bq][mb][nh] = *(const b8*)&wb[(T * MB + mb) * 1024 + nh * 128];
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
+          for (int tm = 0; tm < RW; ++tm)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
               const int c = (tm + T / 3) * HWd + ph * 16 + T % 3;
@@ -465,14 +470,14 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
             if constexpr (FIRST && S < 4) {
               if (have_prev) {
                 [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
-                  (store_group(std::integral_constant<int, MB * S + Gs>{}), ...);
-                }(std::make_integer_sequence<int, MB>{});
+                  (store_group(std::integral_constant<int, (RW * MB / 2) * S + Gs>{}), ...);
+                }(std::make_integer_sequence<int, RW * MB / 2>{});
               }
             }
             if constexpr (RM && LAST && S == 5) prefetch_rm();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < RW; ++tm)
 #pragma unroll
               for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -489,10 +494,10 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       if constexpr (MB == 1) job(std::integral_constant<int, 1>{});
       else { if (mbn == 2) job(std::integral_constant<int, 2>{}); else job(std::integral_constant<int, 1>{}); }
     };
-    auto hand_over = [&](const Tile& tl, const u32x2 (&pre_r)[2][2][MB][2], const u32x2 (&pre_m)[2][2][MB][2]) {
+    auto hand_over = [&](const Tile& tl, const u32x2 (&pre_r)[RW][2][MB][2], const u32x2 (&pre_m)[RW][2][MB][2]) {
       rout = make_rsrc(outp + (long long)tl.b * H * W * p.out_pix_stride, frame_out);
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < RW; ++tm)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
           const int yy = tl.y0 + row0 + tm, x = tl.x0 + ph * 16 + l15;
@@ -514,7 +519,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ss[e] = 0.; qq[e] = 0.; }
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < RW; ++tm)
 #pragma unroll
               for (int ph = 0; ph < 2; ++ph) {
                 const bool okp = tvo[tm][ph] != (int)OOB;
@@ -559,7 +564,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
       // accumulators start from the bias: sixteen LDS reads straight into their registers (zero fill + bias add at the end were 130 vector
       // instructions per tile and 32-channel block); the opaque offset keeps the compiler from turning them into four reads + copies
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < RW; ++tm)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
           int lo = 8 * kg;
@@ -569,7 +574,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) acc[tm][ph][mb][nh] = *(const f32x4*)&lepi[lo + mb * 32 + nh * 4];
         }
-      u32x2 pre_r[2][2][MB][2], pre_m[2][2][MB][2];      // (assigned at tap 5 of the tile's last job, read at its hand-over)
+      u32x2 pre_r[RW][2][MB][2], pre_m[RW][2][MB][2];      // (assigned at tap 5 of the tile's last job, read at its hand-over)
       if constexpr (KCH == 1) {
         run_job(TT{}, TT{}, tl, 0, s, pre_r, pre_m);
         B3_ADD(0);
@@ -598,11 +603,11 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
     B3_OUT();
     for (; s < nloop; ++s) lds_barrier();                // (the producers run an even number of steps)
     if (have_prev)
-      [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 4 * MB>{});
+      [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (store_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 2 * RW * MB>{});
     if (mskp && p.mask_sums) {
       // over the 16 pixel lanes that share the channel vector (fixed order), then row (workgroup, consumer wave) of mask_sums [rows][Cout_store]
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      double msum[MB * 2][4];
+      double msum[MB * RW][4];
 #pragma unroll
       for (int a = 0; a < NG; ++a) (&msum[0][0])[a] = lms[a * 64 + lane];
 #pragma unroll
@@ -629,7 +634,7 @@ void conv3x3_bf16_kernel(const egne_conv_desc p, const egne_bf16* __restrict__ w
 extern "C" int egne_conv3x3_bf16_sum_rows(void) { return 256 * 4; }
 namespace {
 
-template <int KCH, int MB, int RM>
+template <int KCH, int MB, int RM, int RW = 2>
 int launch_b3(const egne_conv_desc& d, const egne_bf16* wf, hipStream_t st) {
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32, nrun = (d.Cout_store + 32 * MB - 1) / (32 * MB);
@@ -639,10 +644,10 @@ int launch_b3(const egne_conv_desc& d, const egne_bf16* wf, hipStream_t st) {
   if (d.stats_ws && d.stats_nchunk != tiles_x * tiles_y * 4)
     return egne::fail(EGNE_ERR_ARG, "conv3x3_bf16: stats_nchunk %d, the launch has %d chunks per frame (tiles of 32 x 8 pixels x 4 waves)", d.stats_nchunk, tiles_x * tiles_y * 4);
   static_assert(lds <= 163840, "LDS budget");
-  const bool once = egne::raise_lds((const void*)conv3x3_bf16_kernel<KCH, MB, RM>, lds);
+  const bool once = egne::raise_lds((const void*)conv3x3_bf16_kernel<KCH, MB, RM, RW>, lds);
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_bf16: cannot raise the dynamic LDS limit to %zu", lds);
   // 256 workgroups = 8 XCDs x 32; the nrun blocks of a worker sit on one XCD: 32 / nrun workers per XCD
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<KCH, MB, RM>), dim3(256), dim3(512), lds, st, d, wf, tiles_x, tiles_y, ntiles, ncb, nrun);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<KCH, MB, RM, RW>), dim3(256), dim3(64 * (4 + 8 / RW)), lds, st, d, wf, tiles_x, tiles_y, ntiles, ncb, nrun);
   return egne::check_launch("egne_conv3x3_bf16_fwd");
 }
 
@@ -733,6 +738,18 @@ extern "C" int egne_conv3x3_bf16_fwd(const egne_conv_desc* dp, const void* wfrag
   // two 32-channel output blocks per workgroup wherever the pack has them (EGNE_B3_MB=1: the round-5 form, one block per workgroup)
   static const int mb_env = [] { const char* e = getenv("EGNE_B3_MB"); return e ? atoi(e) : 2; }();
   const int rm = d.mask_y ? 2 : (d.residual ? 1 : 0);
+  // EGNE_B3_RW=1: eight consumer waves of one row each where the launch writes neither statistics nor mask sums.  Measured (round 6,
+  // scratch/b3_bench.py, 128 frames): 64 -> 64 at 120x160 0.193 -> 0.177 ms, at 240x320 0.841 -> 0.819, with a residual 1.047 -> 0.987,
+  // streamed-weights layers (128+ channels) level; on the training step level within the boxes' noise (1607 / 1613 vs 1608 / 1604 frames/s,
+  // chz 64: 688 / 694 vs 693 / 692) -- the launches that carry statistics keep the four-wave form anyway.  OFF by default.
+  static const int rw_env = [] { const char* e = getenv("EGNE_B3_RW"); return e ? atoi(e) : 2; }();
+  if (d.CoutP >= 64 && mb_env >= 2 && rm < 2 && rw_env == 1 && !d.stats_ws) {
+    switch (d.Ktot) {
+      case 32: return rm ? launch_b3<1, 2, 1, 1>(d, wf, st) : launch_b3<1, 2, 0, 1>(d, wf, st);
+      case 64: return rm ? launch_b3<2, 2, 1, 1>(d, wf, st) : launch_b3<2, 2, 0, 1>(d, wf, st);
+      default: return rm ? launch_b3<0, 2, 1, 1>(d, wf, st) : launch_b3<0, 2, 0, 1>(d, wf, st);
+    }
+  }
   if (d.CoutP >= 64 && mb_env >= 2 && rm < 2) {
     switch (d.Ktot) {
       case 32: return rm ? launch_b3<1, 2, 1>(d, wf, st) : launch_b3<1, 2, 0>(d, wf, st);
