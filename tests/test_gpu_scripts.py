@@ -22,6 +22,72 @@ def test_test_py_synthetic(capsys):
     assert "mIoU" in capsys.readouterr().out
 
 
+def _amplified_eyes(first, factor=3000.0):
+    """_entry.SyntheticEyes whose frames are multiplied by ``factor`` from the ``first``-th FETCHED sample on (whatever its index: the
+    training loader shuffles): far beyond the 32x head-room of pre-scales calibrated on the first batch (engine.Plan: the split-f16
+    kernels then produce non-finite values and flag it)."""
+    from egne_amd import _entry
+    base = _entry.SyntheticEyes
+
+    class Amplified(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.fetched = 0
+
+        def __getitem__(self, i):
+            t = super().__getitem__(i)
+            self.fetched += 1
+            return ((t[0] * factor,) + tuple(t[1:])) if self.fetched > first else t
+    return Amplified
+
+
+def _count_overflows(monkeypatch):
+    """Counts the True answers of BDCN.overflowed (each one clears the word and marks the plan for re-calibration)."""
+    from egne_amd.bdcn_new import BDCN
+    seen = []
+    orig = BDCN.overflowed
+
+    def spy(self):
+        r = orig(self)
+        if r:
+            seen.append(1)
+        return r
+    monkeypatch.setattr(BDCN, "overflowed", spy)
+    return seen
+
+
+def test_test_py_redoes_batches_beyond_the_calibrated_prescales(monkeypatch, capsys):
+    """test.py's loop (calc_acc, test.py:31-252 of the reference) on a set whose later frames are 3000x the calibration batch: the edge
+    network's plan overflows its f16 pre-scales, BOTH plans' words are read (round-5 advisor finding: a short-circuit `or` left the edge
+    plan's word set and its stale scales in place, and the rerun raised the false "input frames are not finite"), the batch and the one
+    queued behind it run again, the metrics are finite."""
+    from egne_amd import _entry
+    from egne_amd import test as T
+    monkeypatch.setattr(_entry, "SyntheticEyes", _amplified_eyes(first=4))
+    seen = _count_overflows(monkeypatch)
+    miou, pd, idist, loss = T.main(["--synthetic", "8", "--batchsize", "2", "--setting", "configs/baseline_edge.yaml"])
+    assert seen, "no overflow was reported: the amplified frames went through on the first batch's scales"
+    assert np.isfinite(miou) and 0 <= miou <= 1 and np.isfinite(loss)
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_train_py_recomputes_an_overflowed_edge_map(tmp_path, monkeypatch, pipeline):
+    """train.py's loop with frames beyond the calibrated pre-scales of the frozen edge network (round-5 advisor finding: the loop never
+    looked at the edge plan's overflow word -- up to 16 optimizer steps on NaN edge maps, NaN BatchNorm statistics, Adam state and
+    weights): the step reads the word where it has the edge map, recomputes the map on the re-calibrated plan (and the next batch's under
+    the pipeline), and every parameter and BatchNorm statistic is finite after the epoch."""
+    monkeypatch.chdir(tmp_path)
+    from egne_amd import _entry
+    from egne_amd import train as TR
+    monkeypatch.setattr(_entry, "SyntheticEyes", _amplified_eyes(first=2))
+    seen = _count_overflows(monkeypatch)
+    m = TR.main(["--synthetic", "8", "--batchsize", "2", "--epochs", "1", "--setting", "configs/baseline_edge.yaml", "--expname", "o" + pipeline,
+                 "--pipeline", pipeline])
+    assert seen, "no overflow was reported"
+    bad = [k for k, v in m.state_dict().items() if v.dtype.is_floating_point and not torch.isfinite(v).all()]
+    assert not bad, "non-finite parameters / statistics after an overflowed edge map: %s" % bad[:5]
+
+
 def test_train_py_synthetic_loss_decreases(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from egne_amd import train as TR
