@@ -114,13 +114,16 @@ def evaluate_ellseg_on_image(frames, model, edge_model, args=None):
     from egne_amd.utils import calc_edge
     assert frames.dim() == 4, 'Frame must be [N,1,H,W]'
     ns = argparse.Namespace(prec=torch.float32, edge_thres=0)
-    for attempt in (0, 1):
+    for attempt in (0, 1, 2):
         with torch.no_grad():
             edge = calc_edge(ns, frames, edge_model, frames.device)
+        # a frame beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): a plan re-calibrates on its next call, so
+        # the frames simply run again.  The edge network's word is read BEFORE its map is fed on (a NaN map must not reach the model plan's
+        # own calibration pass)
+        if _overflowed(edge_model):
+            continue
         res = _to_host(_seg_and_fit(frames, model)(edge))
-        # a frame beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): both plans re-calibrate on their
-        # next call, so the frames simply run again
-        if not (_overflowed(model) | _overflowed(edge_model)):
+        if not _overflowed(model):
             return res
     raise RuntimeError("non-finite activations after re-calibration: the input frames themselves are not finite")
 

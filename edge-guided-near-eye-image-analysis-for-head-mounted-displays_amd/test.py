@@ -52,15 +52,26 @@ def calc_acc(args, testloader, model, edge_model, device):
         ov = bool(model.overflowed()) | bool(edge_model.overflowed())
         if redo[0] or ov:
             # a frame beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): the results of this batch are
-            # invalid; both plans re-calibrate on their next call, so the batch runs again, back to back -- and so does the batch
-            # queued behind it, whose edge maps were computed with the old scales
-            redo[0] = not redo[0]
+            # invalid; a plan re-calibrates on its next call, so the batch runs again, back to back.  The batch queued behind it ran its
+            # edge network with the old scales, and its flag went with the words cleared here: whenever a batch cleared a word, the next
+            # one runs again as well.  Up to three attempts: the word may have been set by the NEXT batch's edge network (already running), in
+            # which case this batch re-calibrates the plans on ITS frames and the next one overflows them once more
+            cleared = ov
             torch.cuda.synchronize()    # the edge network of the NEXT batch is in flight on the pipeline's stream and owns the same plan buffers
-            with torch.no_grad():
-                mask, elPred, elOut, loss, flags = second(batch)(calc_edge(args, batch[0].to(device), edge_model, device))
-            torch.cuda.synchronize()
-            if bool(model.overflowed()) | bool(edge_model.overflowed()):
+            for attempt in (0, 1, 2):
+                with torch.no_grad():
+                    edge = calc_edge(args, batch[0].to(device), edge_model, device)
+                    again = bool(edge_model.overflowed())
+                    if not again:           # (a NaN edge map must not reach the model plan's own calibration pass)
+                        mask, elPred, elOut, loss, flags = second(batch)(edge)
+                        torch.cuda.synchronize()
+                        again = bool(model.overflowed())
+                if not again:
+                    break
+                cleared = True
+            else:
                 raise RuntimeError("non-finite activations after re-calibration: the input frames themselves are not finite")
+            redo[0] = cleared
         model.raise_on_loss_flags(flags)           # two absent classes: loss.py:132 raises in the reference
         img, labels, spatialWeights, distMap, pupil_center, iris_center, elNorm, cond, imInfo = batch
         predict = mask.cpu().numpy()

@@ -53,14 +53,18 @@ def lossandaccuracy(args, loader, model, edge_model, alpha, device):
             if args.test_normal and bt > 20:
                 break
             img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
-            for attempt in (0, 1):
+            for attempt in (0, 1, 2):
                 with torch.no_grad():
                     edge = calc_edge(args, img.to(device), edge_model, device)
+                # a batch beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): a plan re-calibrates on its next
+                # call, so the batch runs once more.  The edge network's word is read BEFORE its map is fed on: a NaN map would reach the
+                # model plan's own calibration pass
+                if bool(edge_model.overflowed()):
+                    continue
+                with torch.no_grad():
                     out = model(img.to(device), edge, labels.to(device).long(), pc.to(device), eln.to(device), sw.to(device),
                                 dm.to(device), cond.to(device).float(), imInfo[:, 2].to(device), alpha)
-                # a batch beyond the head-room of the calibrated f16 pre-scales (engine.Plan.overflowed): both plans re-calibrate on their
-                # next call, so the batch runs once more
-                if not (bool(model.overflowed()) | bool(edge_model.overflowed())):
+                if not bool(model.overflowed()):
                     break
             else:
                 # (test.py / evaluate.py raise here too: a NaN validation loss would steer the LR scheduler, early stopping and the
@@ -158,17 +162,24 @@ def main(argv=None):
             img, labels, sw, dm, pc, ic, eln, cond, imInfo = batch
 
             def rest(edge, img=img, labels=labels, sw=sw, dm=dm, pc=pc, eln=eln, cond=cond, imInfo=imInfo):
-                if check_edge and (redo_edge[0] or bool(edge_net.overflowed())):
+                ov = check_edge and bool(edge_net.overflowed())          # (reads AND clears the plan's sticky word)
+                if check_edge and (redo_edge[0] or ov):
                     # the frozen edge network left the f16 range of its calibrated pre-scales (engine.Plan.overflowed): this edge map holds
                     # NaNs, and a step on it would put them into the BatchNorm statistics, the Adam state and the weights.  The plan is
-                    # marked for re-calibration, so the map is computed again, here, behind everything in flight (under the pipeline the
-                    # edge network of the NEXT batch is running on the other stream in the same plan buffers, with the old scales: that
-                    # batch computes its map again too)
-                    redo_edge[0] = pipe is not None and not redo_edge[0]
+                    # marked for re-calibration, so the map is computed again, here, behind everything in flight.  Under the pipeline the
+                    # edge network of the NEXT batch is already queued on the other stream, in the same plan buffers and with the old scales,
+                    # and its flag went with the word this step cleared: whenever a step cleared the word, the next step computes its map
+                    # again as well (two attempts each: the plan may first have to re-calibrate on this batch's frames)
+                    cleared = ov
                     torch.cuda.synchronize()
-                    edge = calc_edge(args, img.to(device), edge_net, device).clone()
-                    if edge_net.overflowed():
+                    for attempt in (0, 1):
+                        edge = calc_edge(args, img.to(device), edge_net, device).clone()
+                        if not edge_net.overflowed():
+                            break
+                        cleared = True
+                    else:
                         raise RuntimeError("non-finite edge maps after re-calibration: the input frames themselves are not finite")
+                    redo_edge[0] = pipe is not None and cleared
                     if pipe is not None:
                         pipe.sa.wait_stream(torch.cuda.current_stream())
                 optimizer.zero_grad()
