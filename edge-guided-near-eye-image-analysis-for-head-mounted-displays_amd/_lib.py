@@ -51,6 +51,26 @@ class Dst(C.Structure):
 MAXDST = 6
 
 
+class ConvQuery(C.Structure):
+    """egne_conv_query: a layer described to egne_conv2d_auto_kind (csrc/dispatch.hip)."""
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("pad_mode", C.c_int32),
+                ("ngroups", C.c_int32), ("dil", C.c_int32 * MAXGROUP), ("nseg", C.c_int32),
+                ("seg_C", C.c_int32 * MAXSEG), ("seg_Cp", C.c_int32 * MAXSEG), ("seg_ch_off", C.c_int32 * MAXSEG), ("seg_pix_stride", C.c_int64 * MAXSEG),
+                ("seg_affine", C.c_int32 * MAXSEG), ("seg_planar", C.c_int32), ("seg_presplit", C.c_int32),
+                ("Cout", C.c_int32), ("Cout_store", C.c_int32), ("dst_Cp", C.c_int32), ("dst_ch_off", C.c_int32), ("dst_pix_stride", C.c_int64),
+                ("act", C.c_int32), ("has_post", C.c_int32), ("has_residual", C.c_int32), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
+                ("split", C.c_int32), ("split1", C.c_int32), ("split_c4", C.c_int32), ("train", C.c_int32), ("dyn_scales", C.c_int32),
+                ("is_dgrad", C.c_int32), ("want_stats", C.c_int32), ("want_pool", C.c_int32), ("pool_Cp", C.c_int32), ("pool_pix_stride", C.c_int64),
+                ("want_scores", C.c_int32), ("up_add", C.c_int32), ("narrow_bf16_ok", C.c_int32)]
+
+
+class ConvChoice(C.Structure):
+    """egne_conv_choice: the entry point egne_conv2d_auto_kind picked and what its epilogue takes along."""
+    _fields_ = [("kind", C.c_int32), ("name", C.c_char * 32), ("tail_frames", C.c_int32), ("fused_stats", C.c_int32), ("fused_pool", C.c_int32),
+                ("small_ws_floats", C.c_int64)]
+
+
 class BdcnTailDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("s", c_fp * 5), ("s1", c_fp * 5), ("h", C.c_int32 * 5), ("w", C.c_int32 * 5),
@@ -168,6 +188,7 @@ SIGNATURES = {
     "egne_last_error": (C.c_char_p, []),
     "egne_version": (i32, []),
     "egne_sizeof": (i32, [i32]),
+    "egne_conv2d_auto_kind": (i32, [C.POINTER(ConvQuery), C.POINTER(ConvChoice)]),
 }
 
 # Entry points with a bf16-storage twin (same arguments, activation pointers are bf16; suffix _bf16): training plans that keep

@@ -16,6 +16,8 @@ extern "C" int egne_sizeof(int which) {
     case 1: return (int)sizeof(egne_loss_desc);
     case 2: return (int)sizeof(egne_bdcn_tail_desc);
     case 3: return (int)sizeof(egne_dst);
+    case 4: return (int)sizeof(egne_conv_query);
+    case 5: return (int)sizeof(egne_conv_choice);
     default: return -1;
   }
 }

@@ -81,6 +81,10 @@ RECAL_EVERY = int(os.environ.get("EGNE_RECAL_EVERY", "1024"))     # inference pl
 #   leave 32x of head-room over the calibration batch and are re-measured on a schedule (one short sync per split launch, ~0.1 % of the
 #   runs in between).  A batch beyond the head-room turns f16 operands into inf: every split-f16 epilogue tests what it stores and sets
 #   the plan's sticky overflow word (round 5, OVF_CHECK); Plan.overflowed() / check_overflow() read it, the next run refuses to go on
+# every convolution the planner plans is also put to the C-side chooser (egne_conv2d_auto_kind, csrc/dispatch.hip) and the two must agree
+# (tests/test_gpu_nets.py turns it on for the plans of both networks at B = 64 and B = 2 and for the training plans)
+CHECK_DISPATCH = os.environ.get("EGNE_CHECK_DISPATCH", "0") != "0"
+DISPATCH_LOG = []          # (name, planner's kind, C side's kind) of every convolution checked
 OVF_CHECK = os.environ.get("EGNE_OVF_CHECK", "1") != "0"          # inference plans: split-f16 epilogues report non-finite results (egne_conv_desc.ovf_flag, Plan.overflowed)
 SMALLCIN_ENABLED = os.environ.get("EGNE_SMALLCIN", "1") != "0"   # first layers: taps folded into K (conv3x3_c4_kernel)
 HALO_MIN_W = int(os.environ.get("EGNE_HALO_MIN_W", "30"))
@@ -972,12 +976,60 @@ class Plan:
                 + (4 * 18 * (32 * (1 if layer.CoutP == 32 else 2) + 8) * 4 if up_add else 0) <= 80 * 1024       # (+ the addend patch of each wave)
                 and B * H * W >= S1X1_MIN_PIX)
 
+    def _check_dispatch(self, n0, layer, pieces, dst, B, H, W, residual, name, stats, scores, pool, up_add):
+        """EGNE_CHECK_DISPATCH=1: describe the layer to egne_conv2d_auto_kind and demand the kind this planner just recorded (the first
+        launch the convolution added to Plan.meta), the frames it handed to the flat kernel behind the deep trunk kernel and what its
+        epilogue took along."""
+        conv_kinds = [k for k, _ in self.meta[n0:] if k.startswith("conv")]
+        if not conv_kinds:
+            return
+        mine = conv_kinds[0]
+        q = _lib.ConvQuery()
+        q.dtype = 1 if self.bf16 else 0
+        q.B, q.H, q.W = B, H, W
+        q.kh, q.kw, q.stride, q.pad_h, q.pad_w, q.pad_mode, q.ngroups = layer.kh, layer.kw, layer.stride, layer.pad[0], layer.pad[1], layer.pad_mode, layer.G
+        for g in range(_lib.MAXGROUP):
+            q.dil[g] = layer.dils[g] if g < layer.G else 1
+        q.nseg = len(pieces)
+        for i, p in enumerate(pieces):
+            q.seg_C[i], q.seg_Cp[i], q.seg_ch_off[i], q.seg_pix_stride[i] = p.C, p.Cp, p.off, p.stride
+            q.seg_affine[i] = int(p.scale is not None)
+        p0 = pieces[0]
+        q.seg_planar, q.seg_presplit = int(isinstance(p0, PlanarPiece)), int(getattr(p0, "presplit", None) is not None)
+        q.Cout, q.Cout_store = layer.Cout, layer.Cout_store
+        q.dst_Cp, q.dst_ch_off, q.dst_pix_stride = dst.Cp, dst.off, dst.stride
+        q.act, q.has_post, q.has_residual = layer.act, int(layer.post is not None), int(residual is not None)
+        if residual is not None:
+            q.res_pix_stride, q.res_ch_off = residual.stride, residual.off
+        q.split, q.split1, q.split_c4 = int(bool(layer.split)), int(bool(layer.split1)), int(bool(getattr(layer, "split_c4", False)))
+        q.train, q.dyn_scales = int(bool(self.train)), int(bool(self.dyn_scales))
+        q.is_dgrad = int(isinstance(layer, (DgradLayer, SplitDgradLayer, BfDgradLayer)))
+        q.want_stats = int(bool(stats) and STATS_FUSED)
+        q.want_scores = int(scores is not None)
+        if pool is not None and POOL_FUSED:
+            q.want_pool, q.pool_Cp, q.pool_pix_stride = 1, pool.Cp, pool.stride
+        q.up_add = int(up_add is not None)
+        q.narrow_bf16_ok = int(mine == "conv_bf16:narrow")
+        ch = _lib.ConvChoice()
+        _lib.check(self.L.egne_conv2d_auto_kind(C.byref(q), C.byref(ch)), "conv2d_auto_kind")
+        theirs = ch.name.decode()
+        DISPATCH_LOG.append((name, mine, theirs))
+        assert theirs == mine, "%s: the planner chose %s, egne_conv2d_auto_kind %s" % (name, mine, theirs)
+        if mine == "conv_f16x3:big":
+            tails = [k for k, _ in self.meta[n0:] if k == "conv_f16x3:flat"]
+            assert bool(ch.tail_frames) == bool(tails), "%s: frame tail %d against %s" % (name, ch.tail_frames, tails)
+        if mine in ("conv_f16x3:rw", "conv_f16x3:rs", "conv_f16x3:halo") and not self.bf16:
+            assert bool(ch.fused_pool) == bool(self.last_pooled), "%s: pooled output %d against %s" % (name, ch.fused_pool, self.last_pooled)
+
     def conv(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None, pool=None, up_add=None):
         """``pool``: a Piece for the 2x2 / stride-2 ceil-mode max pooling of the result; ``self.last_pooled`` tells the caller
         whether the convolution kernel wrote it (otherwise the caller runs maxpool2).  ``up_add`` = (P, ph, pw): a half-resolution
         tensor whose bilinear x2 up-sampling is added to the result of a streaming 1x1 (callers check ``stream1x1_ok`` first)."""
         self._pool_req, self.last_pooled, self.last_presplit, self._up_add = pool, False, False, up_add
+        n0 = len(self.meta)
         r = self._conv_impl(layer, pieces, dst, B, H, W, residual, name, stats, scores)
+        if CHECK_DISPATCH:
+            self._check_dispatch(n0, layer, pieces, dst, B, H, W, residual, name, stats, scores, pool, up_add)
         self._pool_req = self._up_add = None
         LAYER_BYTES[name] = float(self.esz) * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
         return r

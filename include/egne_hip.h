@@ -788,9 +788,80 @@ int egne_group_sums_reduce(const float* sums, int64_t nrows, int ld, int C, floa
                            int accumulate, void* stream);
 int egne_conv1x1_bf16_fwd(const egne_conv_desc* d, const void* wfrag, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------------------------------
+ * Which forward entry point serves a convolution (round 6, csrc/dispatch.hip).  The reference leaves the choice of a kernel to ATen
+ * (F.conv2d at models/RITnet_v2.py:57-62,85-87, bdcn_new.py:49-55, vgg16_c.py:65-88); here the engine's planner makes it
+ * (engine.Plan._conv_impl / _conv_bf16) and this function restates its predicates, in its order, with its default thresholds, for
+ * callers that bind this header directly: describe the layer, get the entry point (egne_conv_kind + the `kind` string the planner
+ * records in Plan.meta) and what its epilogue takes along (statistics, pooled output, frames handed to the flat kernel behind the
+ * deep trunk kernel, workspace of the small-problem form).  The planner checks every convolution it plans against this function
+ * under EGNE_CHECK_DISPATCH=1.  Pair fusions (1x1 into the 3x3 that consumes it, Transition_down with its pooling) are decided
+ * by the plan builder before a layer gets here. */
+typedef enum {
+  EGNE_KIND_IGEMM = 0,            /* egne_conv2d_fwd (exact fp32 implicit GEMM; bf16 tensors too) */
+  EGNE_KIND_HALO_F32 = 1,         /* egne_conv3x3_halo_fwd */
+  EGNE_KIND_SMALLCIN = 2,         /* egne_conv3x3_smallcin_fwd */
+  EGNE_KIND_NARROW_F32 = 3,       /* egne_conv3x3_narrow_fwd */
+  EGNE_KIND_F16X3_FLAT = 4,       /* egne_conv2d_f16x3_fwd */
+  EGNE_KIND_F16X3_SMALL = 5,      /* egne_conv2d_f16x3_small_fwd */
+  EGNE_KIND_F16X3_BIG = 6,        /* egne_conv2d_f16x3_big_fwd (+ egne_conv2d_f16x3_fwd for tail_frames) */
+  EGNE_KIND_F16X3_HALO = 7,       /* egne_conv3x3_halo_f16_fwd */
+  EGNE_KIND_F16X3_RS = 8,         /* egne_conv3x3_rs_f16_fwd */
+  EGNE_KIND_F16X3_RW = 9,         /* egne_conv3x3_rw_f16_fwd */
+  EGNE_KIND_F16X3_LATTICE = 10,   /* three egne_conv3x3_halo_f16_fwd launches on dilation lattices */
+  EGNE_KIND_F16X3_MSDIL = 11,     /* egne_msblock_dil(_scores)_f16_fwd */
+  EGNE_KIND_F16X3_STREAM1X1 = 12, /* egne_conv1x1_f16x3_fwd */
+  EGNE_KIND_F16X3_GEMM1X1 = 13,   /* egne_conv1x1_ms_f16x3_fwd */
+  EGNE_KIND_F16X3_FIRST = 14,     /* egne_conv3x3_smallcin_f16_fwd */
+  EGNE_KIND_BF16_3X3 = 15,        /* egne_conv3x3_bf16_fwd */
+  EGNE_KIND_BF16_1X1 = 16,        /* egne_conv1x1_bf16_fwd */
+  EGNE_KIND_BF16_NARROW = 17      /* egne_conv_narrow_bf16_fwd */
+} egne_conv_kind;
+
+typedef struct {
+  int32_t dtype;                  /* storage of the activation tensors: 0 fp32, 1 bf16 (egne_conv_desc.dtype) */
+  int32_t B, H, W;                /* frames and INPUT map */
+  int32_t kh, kw, stride, pad_h, pad_w, pad_mode, ngroups;     /* padding in TAPS, as in egne_conv_desc (a dilated "same" 3x3: 1) */
+  int32_t dil[EGNE_MAXGROUP];
+  int32_t nseg;                   /* input slices in concat order */
+  int32_t seg_C[EGNE_MAXSEG];     /* logical channels */
+  int32_t seg_Cp[EGNE_MAXSEG];    /* stored channels (padded to 8) */
+  int32_t seg_ch_off[EGNE_MAXSEG];
+  int64_t seg_pix_stride[EGNE_MAXSEG];
+  int32_t seg_affine[EGNE_MAXSEG];/* 1: per-(n, c) affine (+ activation) applied on load (egne_seg.scale) */
+  int32_t seg_planar;             /* the one slice is an NCHW tensor read in place (first layer) */
+  int32_t seg_presplit;           /* the one slice is in split-pair storage (egne_seg.presplit) */
+  int32_t Cout;                   /* logical output channels of ONE group */
+  int32_t Cout_store;             /* channels the layer stores (0: Cout rounded up to 8) */
+  int32_t dst_Cp, dst_ch_off; int64_t dst_pix_stride;
+  int32_t act, has_post, has_residual; int64_t res_pix_stride; int32_t res_ch_off;
+  int32_t split;                  /* k x k products may be split-f16 (22-bit significand; ConvLayer.split) */
+  int32_t split1;                 /* the same for a 1x1 over raw slices (ConvLayer.split1) */
+  int32_t split_c4;               /* ... for a first layer on <= 4 channels (ConvLayer.split_c4) */
+  int32_t train;                  /* the plan records a backward pass */
+  int32_t dyn_scales;             /* split-f16 pre-scales are taken on the device (training plans with fp32 storage) */
+  int32_t is_dgrad;               /* the layer is a data gradient (derived weights) */
+  int32_t want_stats;             /* the consumer needs InstanceNorm statistics of the output */
+  int32_t want_pool; int32_t pool_Cp; int64_t pool_pix_stride;   /* a 2x2 ceil-mode max pooling of the result is wanted */
+  int32_t want_scores;            /* MSBlock: the block's share of the stage's score maps instead of its output */
+  int32_t up_add;                 /* a half-resolution addend is up-sampled into the result (streaming 1x1) */
+  int32_t narrow_bf16_ok;         /* dtype 1: egne_conv_narrow_bf16_supported said yes on the finished descriptor */
+} egne_conv_query;
+
+typedef struct {
+  int32_t kind;                   /* egne_conv_kind */
+  char name[32];                  /* the planner's name for it ("conv_f16x3:rw", "conv_bf16:3x3", ...) */
+  int32_t tail_frames;            /* EGNE_KIND_F16X3_BIG: trailing frames that go to egne_conv2d_f16x3_fwd (whole rounds of 256 workgroups for the rest) */
+  int32_t fused_stats;            /* the launch writes the statistics partial sums (egne_conv_desc.stats_ws) */
+  int32_t fused_pool;             /* ... and the pooled output (egne_conv_desc.pool_out) */
+  int64_t small_ws_floats;        /* EGNE_KIND_F16X3_SMALL: workspace of egne_conv2d_f16x3_small_fwd */
+} egne_conv_choice;
+
+int egne_conv2d_auto_kind(const egne_conv_query* q, egne_conv_choice* out);
+
 const char* egne_last_error(void);
 int egne_version(void);
-int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc, 3 egne_dst */
+int egne_sizeof(int which);   /* 0 egne_conv_desc, 1 egne_loss_desc, 2 egne_bdcn_tail_desc, 3 egne_dst, 4 egne_conv_query, 5 egne_conv_choice */
 
 #ifdef __cplusplus
 }

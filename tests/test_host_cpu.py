@@ -75,6 +75,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.egne_sizeof(1) == __import__("ctypes").sizeof(_lib.LossDesc)
     assert L.egne_sizeof(2) == __import__("ctypes").sizeof(_lib.BdcnTailDesc)
     assert L.egne_sizeof(3) == __import__("ctypes").sizeof(_lib.Dst)
+    assert L.egne_sizeof(4) == __import__("ctypes").sizeof(_lib.ConvQuery)
+    assert L.egne_sizeof(5) == __import__("ctypes").sizeof(_lib.ConvChoice)
 
 
 def test_no_cpu_fallback_and_loud_failure():
