@@ -127,6 +127,9 @@ SIGNATURES = {
     "egne_pack_conv1x1_weight_f16x2_map": (i32, [vp, i32, i32, vp, i32, i32, f32, vp, vp, vp]),
     "egne_conv2d_f16x3_big_fwd": (i32, [C.POINTER(ConvDesc), vp, f32, f32, vp]),
     "egne_pack_conv_weight_f16img": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "egne_conv2d_f16_big1_fwd": (i32, [C.POINTER(ConvDesc), vp, f32, f32, vp]),
+    "egne_conv2d_f16_big1_supported": (i32, [C.POINTER(ConvDesc)]),
+    "egne_pack_conv_weight_f16img1": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "egne_pack_conv1x1_weight_f16": (i32, [vp, i32, i32, vp, i32, i32, f32, vp, vp, vp]),
     "egne_absmax": (i32, [vp, i64, i32, i32, i64, vp, vp]),
     "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),

@@ -43,6 +43,7 @@ BIG_MIN_COUT = int(os.environ.get("EGNE_BIG_MIN_COUT", "256"))
 BIG_MIN_CIN = int(os.environ.get("EGNE_BIG_MIN_CIN", "64"))
 BIG_SPLIT_TAIL = os.environ.get("EGNE_BIG_SPLIT_TAIL", "1") != "0"
 BIG_CUS = 256
+BIG1_ENABLED = os.environ.get("EGNE_BIG1", "1") != "0"    # plain-f16 plans (f16_products = 1): the four-stage form of the deep trunk kernel (conv_f16_big1.hip)
 WINDOW_NAME = os.environ.get("EGNE_FIT_WINDOW", "enc.b3.conv1")      # launch in front of which pending WINDOW_HOOKS are released ("none": never)
 WINDOW_HOOKS = []     # callables waiting for a plan's launch window (Plan.window_at): run on the host where the plan queues that launch
 EVENT_KINDS = None   # bench.py: restrict the per-launch HIP events of Plan.run(events) to these kernel families
@@ -205,6 +206,8 @@ class ConvLayer:
         self.m1hi = self.m1lo = None
         self.need_big = False    # LDS-image pack for the deep 256-wide split-f16 kernel
         self.wimg = None
+        self.need_big1 = False   # hi-only LDS-image pack of the plain-f16 form of that kernel (conv_f16_big1.hip; plans with f16_products = 1)
+        self.wimg1 = None
         self.need_bfrag = False  # bf16 fragment pack of the bf16-storage 3x3 kernel (conv3x3_bf16.hip)
         self.bfrag = None
         self.split1 = False      # allow the streaming split-f16 kernel for this 1x1 layer (frozen nets only)
@@ -232,7 +235,7 @@ class ConvLayer:
             (b._version if b is not None else -1) for b in (self.biases or [])) + (id(getattr(self, "k_perm", None)),)
         have = (getattr(self, "w40", None) is not None or not getattr(self, "need_c4", False)) and ((self.wp is not None or not self.need_flat) and (self.wf is not None or not self.need_frag)
                 and (self.whi is not None or not self.need_split) and (self.fhi is not None or not self.need_sfrag)
-                and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big)
+                and (self.s1hi is not None or not self.need_s1) and (self.wimg is not None or not self.need_big) and (self.wimg1 is not None or not self.need_big1)
                 and (self.m1hi is not None or not self.need_m1) and (self.c4hi is not None or not self.need_c4h)
                 and (self.bfrag is not None or not self.need_bfrag)
                 and (getattr(self, "b1frag", None) is not None or not getattr(self, "need_b1", False)))
@@ -331,6 +334,11 @@ class ConvLayer:
                 self.wimg = torch.empty(self.big_coutp * kts * T * 2, dtype=torch.float16, device=dev)
             _lib.check(L.egne_pack_conv_weight_f16img(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, bn, kts, self.w_scale_big,
                                                       self.wimg.data_ptr(), st), "pack_f16img")
+            if self.need_big1:
+                if self.wimg1 is None:
+                    self.wimg1 = torch.empty(self.big_coutp * kts * T, dtype=torch.float16, device=dev)
+                _lib.check(L.egne_pack_conv_weight_f16img1(wd.data_ptr(), self.Cout, self.Cin, self.kh, self.kw, bn, kts, self.w_scale_big,
+                                                           self.wimg1.data_ptr(), st), "pack_f16img1")
         if getattr(self, "need_b1", False):
             _pack_b1(self, dev, st)
         if self.need_bfrag:
@@ -461,6 +469,7 @@ class DgradLayer(ConvLayer):
         self.split1 = self.need_s1 = False
         self.s1hi = self.s1lo = None
         self.need_big, self.wimg = False, None
+        self.need_big1, self.wimg1 = False, None
         self.need_m1, self.m1hi, self.m1lo = False, None, None
         self.need_c4h, self.c4hi, self.c4lo = False, None, None
         self.need_bfrag, self.bfrag = False, None
@@ -1176,6 +1185,9 @@ class Plan:
             smallcin = shalo = halo = lattice = s1x1 = False
             layer.need_big = True
             layer.need_flat = True
+            big1 = BIG1_ENABLED and self.f16_products == 1 and (pad32(layer.Ktot) // 32 * layer.kh * layer.kw) % 2 == 0
+            if big1:
+                layer.need_big1 = True
             bn = 256 if layer.Cout % 256 == 0 else 128
             ny = (layer.Cout + bn - 1) // bn
             wgs = lambda nb: (nb * Ho * Wo + 255) // 256 * ny      # noqa: E731
@@ -1269,12 +1281,14 @@ class Plan:
             d2.out = dst.ptr + 4 * b1 * Ho * Wo * dst.stride
             d2.Ktot, d2.CoutP = pad32(layer.Ktot), layer.split_coutp()
             self.keep.append(d2)
-            self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
+            self._add(self.L.egne_conv2d_f16_big1_fwd if big1 else self.L.egne_conv2d_f16x3_big_fwd,
+                      (C.byref(d), (layer.wimg1 if big1 else layer.wimg).data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
                       flops=flops * b1 / B, kind="conv_f16x3:big", cal=cal2, ws=[(3, layer, "w_scale_big")])
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d2), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE, layer.w_scale),
                       name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat", cal=cal3, ws=[(4, layer, "w_scale")])
         elif big:
-            self._add(self.L.egne_conv2d_f16x3_big_fwd, (C.byref(d), layer.wimg.data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
+            self._add(self.L.egne_conv2d_f16_big1_fwd if big1 else self.L.egne_conv2d_f16x3_big_fwd,
+                      (C.byref(d), (layer.wimg1 if big1 else layer.wimg).data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
                       flops=flops, kind="conv_f16x3:big", cal=cal2, ws=[(3, layer, "w_scale_big")])
         elif ms1x1:
             d.Ktot, d.CoutP = layer.m1_ktot, layer.m1_coutp

@@ -188,6 +188,15 @@ int egne_conv2d_f16x3_small_fwd(const egne_conv_desc* d, const void* whi, const 
 int egne_pack_conv_weight_f16img(const float* w_oihw, int Cout, int Cin, int kh, int kw, int BN, int Ktot, float wscale,
                                  void* wimg, void* stream);
 int egne_conv2d_f16x3_big_fwd(const egne_conv_desc* d, const void* wimg, float a_scale, float w_scale, void* stream);
+/* The deep variant on PLAIN f16 operands (d->f16_products = 1: the frozen edge network next to a bf16-storage training plan; vgg16_c.py:70-78
+ * under utils.py:646): same tile, same accumulation order (bit-identical to egne_conv2d_f16x3_big_fwd with f16_products = 1), but 64-byte LDS
+ * rows (hi halves only) in a FOUR-stage ring: activations written two K steps ahead, weight images requested three ahead, the next step's
+ * fragments read during the current one.  Needs an even number of K steps (Cp / 32 * kh * kw: egne_conv2d_f16_big1_supported) and weight
+ * images without lo granules ([Cout tile][step][BN rows][64 B], egne_pack_conv_weight_f16img1: half the bytes of the f16img pack). */
+int egne_pack_conv_weight_f16img1(const float* w_oihw, int Cout, int Cin, int kh, int kw, int BN, int Ktot, float wscale,
+                                  void* wimg, void* stream);
+int egne_conv2d_f16_big1_supported(const egne_conv_desc* d);
+int egne_conv2d_f16_big1_fwd(const egne_conv_desc* d, const void* wimg, float a_scale, float w_scale, void* stream);
 
 /* Split-f16 variant of the LDS-halo 3x3 kernel (narrow full-resolution layers: Cout 32 / 64, dilation <= 2, one
  * input slice, fused affine allowed).  Weights: hi / lo f16 in MFMA-fragment order

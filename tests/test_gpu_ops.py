@@ -703,6 +703,53 @@ def test_deep_trunk_kernel_with_frame_tail(G):
     assert err < 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,d", [
+    (28, 128, 256, 30, 40, 1),     # conv3_1 class: four chunks, 36 K steps (the planner takes the deep kernel from 32 768 pixels on)
+    (47, 256, 512, 23, 31, 1),     # conv4_1 class, ragged last tile (33 511 pixels), two output tiles
+    (110, 512, 512, 15, 20, 2),    # conv5 class: dilation 2, 144 K steps
+    (102, 256, 384, 17, 19, 1),    # 128-wide output tiles (Cout % 256 != 0), ragged last tile
+])
+def test_deep_trunk_kernel_plain_f16_four_stage_form(G, B, Cin, Cout, H, W, d):
+    """egne_conv2d_f16_big1_fwd (the frozen edge network's wide layers next to a bf16-storage training plan, vgg16_c.py:70-88): same
+    operands, same accumulation order as egne_conv2d_f16x3_big_fwd with f16_products = 1 -> BIT-identical; and against float64 on
+    the f16-rounded operands (what "plain f16 products, fp32 accumulate" means) to 2e-6 of the output scale."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd import engine
+    from egne_amd.engine import ConvLayer, Piece, Plan
+    x = F.relu(_rand(G, B, Cin, H, W))
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    outs = []
+    for big1 in (True, False):
+        old = engine.BIG1_ENABLED
+        engine.BIG1_ENABLED = big1
+        try:
+            pl = Plan(torch.device(DEV))
+            pl.f16_products = 1
+            (px,) = to_nhwc_buf(pl, [x], B, H, W)
+            layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, Cin)], pad=(1, 1), dils=(d,), act=1)      # (padding counts taps)
+            layer.split = True
+            out = pl.buf(B, H, W, Cout + 8)
+            out.fill_(777.0)
+            pl.conv(layer, [px], Piece(out, 8, Cout), B, H, W)
+            want = pl.L.egne_conv2d_f16_big1_fwd if big1 else pl.L.egne_conv2d_f16x3_big_fwd
+            assert pl.calls[0][0] == want, "expected the %s launch" % ("four-stage" if big1 else "two-stage")
+            pl.run()
+            pl.run()
+            torch.cuda.synchronize()
+            assert (out[..., :8] == 777.0).all(), "wrote outside its output slice"
+            outs.append((out[..., 8:].clone(), pl.calls[0][1][2], layer.w_scale_big))
+        finally:
+            engine.BIG1_ENABLED = old
+    (o1, a_s, w_s), (o0, _, _) = outs
+    assert torch.equal(o1, o0), "four-stage and two-stage forms differ: max %.3e" % (o1 - o0).abs().max().item()
+    xh = (x.to(DEV) * a_s).half().double() / a_s
+    wh = (w.to(DEV) * w_s).half().double() / w_s
+    ref = F.relu(F.conv2d(xh, wh, b.to(DEV).double(), padding=d, dilation=d))
+    err = (o1.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    print("big1 vs float64 on f16 operands %.2e" % err)
+    assert err < 2e-6
+
+
 @pytest.mark.parametrize("chans,C1,C2,B,H,W,res,post", [
     ((32, 32), 32, 32, 2, 61, 83, False, False),            # ESF block 0 conv21 + conv22 class: ragged tiles in x and y
     ((32, 32, 32), 32, 32, 3, 24, 64, True, False),         # conv31 + conv32 class, residual add in the epilogue
