@@ -168,6 +168,10 @@ int wgrad1x1_bf16_launch(const egne_conv_desc& d, const egne_bf16* gz, long long
 int msdil_ps_launch(const egne_conv_desc& d, const void* fhi, const void* flo, float a_scale, float w_scale, const float* score_w,
                     const float* score_c, float* s0, float* s1, int accumulate, hipStream_t st);   // msblock_dil_ps_f16.hip
 
+bool msdil1_wanted(const egne_conv_desc& d);      // msblock_dil1_f16.hip: plain f16 operands, ring-of-rows form
+int msdil1_launch(const egne_conv_desc& d, const void* fhi, float a_scale, float w_scale, const float* score_w, const float* score_c,
+                  float* s0, float* s1, int accumulate, hipStream_t st);
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace egne

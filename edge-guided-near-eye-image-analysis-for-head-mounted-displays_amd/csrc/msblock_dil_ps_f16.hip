@@ -362,6 +362,7 @@ namespace egne {
 // descriptor has been validated there.
 int msdil_ps_launch(const egne_conv_desc& d, const void* fhi, const void* flo, float a_scale, float w_scale, const float* score_w,
                     const float* score_c, float* s0, float* s1, int accumulate, hipStream_t st) {
+  if (msdil1_wanted(d)) return msdil1_launch(d, fhi, a_scale, w_scale, score_w, score_c, s0, s1, accumulate, st);
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B;
   constexpr size_t lds = ((size_t)2 * BUFH + 2 * WBUFH) * sizeof(_Float16) + 162 * sizeof(float) + 18 * 64 * sizeof(int) + WBUFH * sizeof(_Float16);

@@ -1006,6 +1006,67 @@ def test_msblock_with_split_pair_storage(G, B, H, W, Cin, mag):
     print("MSBlock %dx%dx%d Cin %d mag %g: err %.2e, split-pair storage %s (%s)" % (B, H, W, Cin, mag, err, split, kinds[0]))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,scores", [(2, 240, 320, 64, False), (3, 120, 160, 128, True), (2, 75, 101, 64, True), (5, 60, 80, 64, False),
+                                               (40, 64, 96, 64, True)])
+def test_msblock_plain_f16_ring_form(G, B, H, W, Cin, scores, monkeypatch):
+    """msblock_dil1_f16.hip (the dilated group of an MSBlock on plain f16 operands, a ring of 32 rows in LDS; bdcn_new.py:49-55 under
+    utils.py:646 next to a bf16-storage training plan): BIT-identical to the strip form of msblock_dil_ps_f16.hip with one product --
+    block output or fused score maps, ragged maps, several segments per column, more work items than workgroups -- and within the
+    plain-f16 rounding of float64."""
+    from gpu_util import DEV, to_nhwc_buf
+    from egne_amd.engine import ConvLayer, Piece, Plan, SplitScale, pad8
+    x = F.relu(_rand(G, B, Cin, H, W)) * 2
+    w0, b0 = _rand(G, 32, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, 32)
+    ws = [_rand(G, 32, 32, 3, 3) / 17 for _ in range(3)]
+    bs = [_rand(G, 32) for _ in range(3)]
+    cw, cc = _rand(G, 2, 32) / 6, torch.tensor([0.7, -1.3])
+    o = F.relu(F.conv2d(x.double().to(DEV), w0.double().to(DEV), b0.double().to(DEV), padding=1))
+    truth = o.clone()
+    for w, b, d in zip(ws, bs, (4, 8, 12)):
+        truth = truth + F.relu(F.conv2d(o, w.double().to(DEV), b.double().to(DEV), padding=d, dilation=d))
+    if scores:
+        truth = torch.stack([(truth * cw[h].double().to(DEV)[None, :, None, None]).sum(1) + float(cc[h]) for h in range(2)], 1)
+    res = []
+    for ring in ("1", "0"):
+        monkeypatch.setenv("EGNE_MSDIL1", ring)
+        pl = Plan(torch.device(DEV))
+        pl.f16_products = 1
+        (px,) = to_nhwc_buf(pl, [x], B, H, W)
+        l0 = ConvLayer([torch.nn.Parameter(w0.to(DEV))], [torch.nn.Parameter(b0.to(DEV))], [(Cin, pad8(Cin))], pad=(1, 1), act=1)
+        lg = ConvLayer([torch.nn.Parameter(w.to(DEV)) for w in ws], [torch.nn.Parameter(b.to(DEV)) for b in bs], [(32, 32)],
+                       pad=(1, 1), dils=(4, 8, 12), act=1)
+        l0.split = lg.split = True
+        obuf = pl.buf(B, H, W, 32)
+        po = Piece(obuf, 0, 32)
+        assert pl.msdil_ok(lg, po, H, W)
+        po.presplit = SplitScale()
+        pl.conv(l0, [px], po, B, H, W)
+        assert pl.last_presplit, "the resident-weights 3x3 writes split-pair storage"
+        if scores:
+            s0, s1 = pl.vec(B, H, W), pl.vec(B, H, W)
+            s0.fill_(123.0); s1.fill_(-5.0)
+            cwd, ccd = cw.to(DEV), cc.to(DEV)
+            pl.keep += [cwd, ccd]
+            pl.conv(lg, [po], po, B, H, W, residual=po, scores=(cwd, ccd, s0, s1, False))
+        else:
+            out = pl.buf(B, H, W, 40)
+            out.fill_(777.0)
+            pl.conv(lg, [po], Piece(out, 8, 32), B, H, W, residual=po)
+        assert [k for k, _ in pl.meta][-1] == "conv_f16x3:msdil"
+        for _ in range(2):
+            pl.run()
+        torch.cuda.synchronize()
+        if scores:
+            res.append(torch.stack([s0, s1], 1).clone())
+        else:
+            assert (out[..., :8] == 777.0).all(), "stores outside the output slice"
+            res.append(out[..., 8:].permute(0, 3, 1, 2).clone())
+    assert torch.equal(res[0], res[1]), "ring and strip forms differ: max %.3e" % (res[0] - res[1]).abs().max().item()
+    err = (res[0].double() - truth).abs().max().item() / truth.abs().max().item()
+    print("MSBlock plain f16, ring form, %dx%dx%d scores %s: err %.2e vs float64" % (B, H, W, scores, err))
+    assert err < 3e-3          # operands rounded to 11 bits, twice (o itself, then the dilated taps)
+
+
 @pytest.mark.parametrize("kind,B,H,W,C1,C2", [("halo", 3, 61, 83, 32, 32), ("halo", 2, 120, 160, 64, 96), ("pair", 3, 61, 83, 32, 32),
                                               ("pair", 2, 37, 70, 64, 64), ("halo", 2, 60, 80, 32, 32), ("halo", 2, 64, 96, 32, 64)])
 def test_instance_norm_statistics_from_the_conv_epilogue(G, kind, B, H, W, C1, C2):
