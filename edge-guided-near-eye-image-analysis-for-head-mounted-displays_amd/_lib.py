@@ -132,6 +132,7 @@ SIGNATURES = {
     "egne_pack_conv_weight_f16img1": (i32, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "egne_pack_conv1x1_weight_f16": (i32, [vp, i32, i32, vp, i32, i32, f32, vp, vp, vp]),
     "egne_absmax": (i32, [vp, i64, i32, i32, i64, vp, vp]),
+    "egne_absmax_f16": (i32, [vp, i64, i32, i32, i64, vp, vp]),
     "egne_norm_stats_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "egne_norm_stats": (i32, [vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "egne_norm_stats_finish": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -127,8 +127,18 @@ class BDCN(nn.Module):
                     p.normal_(0, 0.01)
 
     # ------------------------------------------------------------------------------------------
-    def _build(self, B, H, W, dev, only_fuse, edge_thres):
+    def _build(self, B, H, W, dev, only_fuse, edge_thres, f16_storage=None):
+        if f16_storage is None:
+            # plain-f16 plans: conv1_1 / conv1_2 / pool1 as F16 tensors (egne_conv_desc.out_split = 2) -- their consumers round every operand
+            # to exactly the stored value anyway, so nothing changes but the bytes; fp32 tensors where a chosen kernel does not know the storage
+            if engine.F16_STORAGE and getattr(self, "_plan_products", 0) == 1:
+                try:
+                    return self._build(B, H, W, dev, only_fuse, edge_thres, True)
+                except engine.NeedsFp32Storage:
+                    pass
+            return self._build(B, H, W, dev, only_fuse, edge_thres, False)
         pl = Plan(dev)
+        pl.f16_storage = bool(f16_storage)
         # BDCN.f16_products = 1: plain f16 operands (one MFMA per product instead of the split's three) in the kernels that know
         # egne_conv_desc.f16_products -- the frozen edge network next to a training plan with bf16 activation storage, which rounds
         # the edge map to bf16 on entry (train.py / bench.py set it for --prec 16 only; inference and fp32 storage keep the split)
@@ -269,13 +279,19 @@ class BDCN(nn.Module):
             layer = ConvLayer([conv.weight], [conv.bias], [(cin, pad8(cin))], pad=(1, 1), dils=(d,), act=ACT_RELU)
             layer.split = cin % 32 == 0      # frozen trunk: split-f16 MFMA (conv_f16x3.hip), edge map tolerance 1e-3
             layer.split_c4 = cin <= 4        # conv1_1: streaming split-f16 first-layer kernel (conv3x3_c4_f16.hip)
-            ob = pl.buf(B, hh, ww, cout)
+            h16 = f16_storage and name in ("conv1_1", "conv1_2")
+            ob = (pl.buf16 if h16 else pl.buf)(B, hh, ww, cout)
             dst = Piece(ob, 0, cout)
+            if h16:
+                dst.f16s = engine.SplitScale()
             nxt = _VGG[idx + 1] if idx + 1 < len(_VGG) else None
             pq = None
             if nxt is not None and nxt[0] == "P" and nxt[1] == 2:         # vgg16_c.py:70: pooling right behind this convolution
-                pq = Piece(pl.buf(B, maxpool_out(hh, 2), maxpool_out(ww, 2), pad8(cout)), 0, cout)
+                pq = Piece((pl.buf16 if h16 else pl.buf)(B, maxpool_out(hh, 2), maxpool_out(ww, 2), pad8(cout)), 0, cout)
+                pq.f16s = dst.f16s
             pl.conv(layer, [cur], dst, B, hh, ww, name="vgg." + name, pool=pq)
+            if h16 and pq is not None and not pl.last_pooled:
+                raise engine.NeedsFp32Storage("vgg.pool behind " + name)      # (the stand-alone pooling kernel reads fp32)
             pooled = pq if pl.last_pooled else None
             cur = dst
             si, bi = block_of[name]

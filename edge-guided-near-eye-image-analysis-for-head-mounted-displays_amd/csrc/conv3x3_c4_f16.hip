@@ -13,6 +13,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -118,7 +119,11 @@ __global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(const egne_conv_des
     }
     const long long m0 = (long long)blk * 32;
     const long long rows = M - m0 < 32 ? M - m0 : 32;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)(rows * p.out_pix_stride * 4));
+    // out_split = 2: the output is stored as f16 halves of v * out_split_scale (channel order kept): the input format of
+    // conv3x3_rw_f16.hip's F16IN form -- the edge network's conv1_1 next to a bf16-storage training plan
+    const bool o16 = p.out_split == 2;
+    const int oesz = o16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)p.out + m0 * p.out_pix_stride * oesz, (unsigned)(rows * p.out_pix_stride * oesz));
     bool bad = false;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -132,6 +137,13 @@ __global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(const egne_conv_des
           v[e] = fmaxf(t, t * slope) * ps[tn][j][e] + pt[tn][j][e];
         }
         if (tn == 0 && j == 0) bad |= egne_nonfinite(v[0]);       // lane = pixel: one channel per pixel (common.h)
+        if (o16) {
+          const f32x2 u0 = {v[0] * p.out_split_scale, v[1] * p.out_split_scale}, u1 = {v[2] * p.out_split_scale, v[3] * p.out_split_scale};
+          const h2 h0 = __builtin_convertvector(u0, h2), h1 = __builtin_convertvector(u1, h2);
+          if (tn == 0 && j == 0) bad |= egne_nonfinite((float)h0[0]);
+          const u32x2 two = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+          __builtin_amdgcn_raw_buffer_store_b64(two, ro, n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 2 : (int)OOB, 0, 0);
+        } else
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
                                                n < p.Cout_store ? (li * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
       }
@@ -185,6 +197,7 @@ extern "C" int egne_conv3x3_smallcin_f16_fwd(const egne_conv_desc* dp, const voi
                d.out_pix_stride * 128 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
                (!d.post_scale || (((uintptr_t)d.post_scale & 15) == 0 && ((uintptr_t)d.post_shift & 15) == 0)), "conv_smallcin_f16: output");
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv_smallcin_f16: weights / scales");
+  EGNE_REQUIRE(d.out_split == 0 || (d.out_split == 2 && d.out_split_scale > 0.f && !d.post_scale), "conv_smallcin_f16: f16 output (out_split = 2) needs a positive scale and no post affine");
   const long long M = (long long)d.B * d.H * d.W;
   const long long nb = (M + 31) / 32;
   EGNE_REQUIRE(nb < (1ll << 31), "conv_smallcin_f16: too many pixels");

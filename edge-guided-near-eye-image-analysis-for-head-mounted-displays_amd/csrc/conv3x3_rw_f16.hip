@@ -30,6 +30,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 __device__ int g_wdbg = 0;
@@ -57,7 +58,9 @@ __device__ __forceinline__ void lds_barrier() {
 // ncb = output blocks of 32 channels; tiles_x / tiles_y / ntiles as usual.
 // NP: products per multiply (egne_conv_desc.f16_products): 3 = hi hi + hi lo + lo hi, 1 = hi hi only (plain f16 operands: the lo
 // halves are neither derived, stored nor read; the frozen edge network next to a bf16-storage training plan)
-template <int KCH, int NP = 3>
+// F16IN: the input slice is held as f16 (egne_seg.presplit = 2: plain halves of x * a_scale in channel order, written by a producer with
+// egne_conv_desc.out_split = 2): a producer item is a 16-byte copy of eight channels, no conversion (NP = 1 only)
+template <int KCH, int NP = 3, bool F16IN = false>
 __global__ __launch_bounds__(512)
 void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi, const _Float16* __restrict__ flo, float a_scale,
                        float out_scale, int tiles_x, int tiles_y, int ntiles, int ncb, int nrun) {
@@ -116,38 +119,40 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
 
   if (wave < 4) {
     // =================================================================== producers: halo chunk -> hi / lo image
-    const int piece = tid & 7, pg = tid >> 3;            // 16-byte piece of the pixel's 32-channel chunk, pixel group (32 per round)
+    // 16-byte piece of the pixel's 32-channel chunk (4 fp32 or 8 f16 channels), pixel group (32 or 64 per round of 256 lanes)
+    constexpr int NPC = F16IN ? 4 : 8, PGS = 256 / NPC, CPP = 32 / NPC, ESZ = F16IN ? 2 : 4, NQ = (NPX * NPC + 255) / 256;
+    const int piece = tid & (NPC - 1), pg = tid / NPC;
     const float slope_in = sg.act_in == EGNE_ACT_RELU ? 0.f : (sg.act_in == EGNE_ACT_LEAKY ? 0.01f : 1.f);
-    // LDS slot of item I: pixel pg + 32 I; (pixel >> 1) & 3 = (pg >> 1) & 3 for every I: lane constant + 64 B * 32 * I
-    const int lofs = pg * 32 + (((piece >> 1) ^ ((pg >> 1) & 3)) << 3) + ((piece & 1) << 2);
-    u32x4 st[2][NI];
+    // LDS slot of item I: pixel pg + PGS I; (pixel >> 1) & 3 = (pg >> 1) & 3 for every I: lane constant + 64 B * PGS * I
+    const int lofs = F16IN ? pg * 32 + ((piece ^ ((pg >> 1) & 3)) << 3) : pg * 32 + (((piece >> 1) ^ ((pg >> 1) & 3)) << 3) + ((piece & 1) << 2);
+    u32x4 st[2][NQ];
     // byte offset of item I relative to the tile's first pixel (tile- and chunk-invariant): with it an item's address is one add
     // for tiles whose halo columns lie inside the image (rows outside it fall outside the per-frame resource and read zeros)
-    int rel[NI];
+    int rel[NQ];
 #pragma unroll
-    for (int I = 0; I < NI; ++I) {
-      const int px = pg + 32 * I, hy = px / HWd, hx = px - hy * HWd;
-      rel[I] = px < NPX ? (((hy - 1) * W + hx - 1) * (int)sg.pix_stride + sg.ch_off + piece * 4) * 4 : (int)OOB;
+    for (int I = 0; I < NQ; ++I) {
+      const int px = pg + PGS * I, hy = px / HWd, hx = px - hy * HWd;
+      rel[I] = px < NPX ? (((hy - 1) * W + hx - 1) * (int)sg.pix_stride + sg.ch_off + piece * CPP) * ESZ : (int)OOB;
     }
     struct Job { Tile t; int ch; };
     auto job_at = [&](int j) { Job r; r.t = decode(tile_at(j / nk)); r.ch = j % nk; return r; };
     auto issue1 = [&](const Job& jb, bool on, auto bc, auto ic) {
       constexpr int BUF = decltype(bc)::value, I = decltype(ic)::value;
       const Tile& tl = jb.t;
-      const __amdgpu_buffer_rsrc_t r = make_rsrc(sg.ptr + (long long)tl.b * H * W * sg.pix_stride, (unsigned)H * W * (unsigned)sg.pix_stride * 4u);
-      const int c0 = jb.ch * 32 + piece * 4;            // channels past the slice (padding up to 32 * KCH) read zeros
+      const __amdgpu_buffer_rsrc_t r = make_rsrc((const char*)sg.ptr + (long long)tl.b * H * W * sg.pix_stride * ESZ, (unsigned)H * W * (unsigned)sg.pix_stride * (unsigned)ESZ);
+      const int c0 = jb.ch * 32 + piece * CPP;          // channels past the slice (padding up to 32 * KCH) read zeros
       int off;
       if (tl.x0 >= 1 && tl.x0 + TW + 1 <= W) {          // wave-uniform: interior columns
-        const int sbase = ((tl.y0 * W + tl.x0) * (int)sg.pix_stride + jb.ch * 32) * 4;
+        const int sbase = ((tl.y0 * W + tl.x0) * (int)sg.pix_stride + jb.ch * 32) * ESZ;
         off = (on && c0 < sg.Cp && rel[I] != (int)OOB) ? rel[I] + sbase : (int)OOB;
       } else {
         int pq = pg;
         asm volatile("" : "+v"(pq));                    // opaque: no hoisting of the per-item coordinates out of the job loop
-        const int px = pq + 32 * I;
+        const int px = pq + PGS * I;
         const int hy = px / HWd, hx = px - hy * HWd;
         const int y = tl.y0 - 1 + hy, x = tl.x0 - 1 + hx;
         const bool ok = on && c0 < sg.Cp && px < NPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        off = ok ? ((y * W + x) * (int)sg.pix_stride + sg.ch_off + c0) * 4 : (int)OOB;
+        off = ok ? ((y * W + x) * (int)sg.pix_stride + sg.ch_off + c0) * ESZ : (int)OOB;
       }
       st[BUF][I] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
     };
@@ -165,8 +170,12 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     };
     auto convert1 = [&](const Job& jb, _Float16* img, auto bc, auto ic) {
       constexpr int BUF = decltype(bc)::value, I = decltype(ic)::value;
-      const int px = pg + 32 * I;
-      if (I < NI - 1 || px < NPX) {
+      const int px = pg + PGS * I;
+      if constexpr (F16IN) {
+        if (I < NQ - 1 || px < NPX) *(u32x4*)&img[lofs + 32 * PGS * I] = st[BUF][I];     // already f16(x * a_scale): a copy
+        return;
+      }
+      if (I < NQ - 1 || px < NPX) {
         f32x4 v = __builtin_bit_cast(f32x4, st[BUF][I]);
         if (sg.scale) {      // fused InstanceNorm affine (+ activation) of the consumer; zero padding applied after it
           const int hy = px / HWd, hx = px - hy * HWd;
@@ -178,7 +187,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           }
           if (!((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) v = (f32x4)(0.f);
         }
-        const int o = lofs + 32 * 32 * I;
+        const int o = lofs + 32 * PGS * I;
         if constexpr (NP == 1) {
           float t0, t1, t2, t3;                   // (one-lane-value multiplies, as split_f16.h: no packed f32 next to the MFMAs)
           asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t0) : "s"(a_scale), "v"(v[0]));
@@ -232,7 +241,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           if (c_on) convert1(jc, img, bc, std::integral_constant<int, Is>{});
           issue1(ji, i_on, bc, std::integral_constant<int, Is>{});
         }()), ...);
-      }(std::make_integer_sequence<int, NI>{});
+      }(std::make_integer_sequence<int, NQ>{});
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
@@ -248,13 +257,13 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
         (issue1(j0, nmine > 0, B0{}, std::integral_constant<int, Is>{}), ...);
         (issue1(j1, nmine > 1, B1{}, std::integral_constant<int, Is>{}), ...);
-      }(std::make_integer_sequence<int, NI>{});
+      }(std::make_integer_sequence<int, NQ>{});
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
         (([&] {
           if (nmine > 0) convert1(j0, ldsh, B0{}, std::integral_constant<int, Is>{});
           issue1(j2, nmine > 2, B0{}, std::integral_constant<int, Is>{});
         }()), ...);
-      }(std::make_integer_sequence<int, NI>{});
+      }(std::make_integer_sequence<int, NQ>{});
     }
     lds_barrier();
     t_last = __builtin_amdgcn_s_memtime();
@@ -271,7 +280,11 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     // which issued at ~42 cycles per MFMA instead of 32 (and the chip holds a higher clock on this shape).
     const int cw = wave - 4, row0 = cw * 2;
     const int l15 = lane & 15, kg = lane >> 4;
-    const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * 4u;
+    // out_split = 2: the output (and the pooled second output) is stored as f16 halves of v * out_split_scale, channel order kept -- the
+    // input format of this kernel's F16IN form (the frozen edge network's stage-1 tensors next to a bf16-storage training plan)
+    const bool o16 = NP == 1 && p.out_split == 2;          // (plain-f16 plans only: nothing of it in the three-product kernels)
+    const int oesz = o16 ? 2 : 4;
+    const unsigned frame_out = (unsigned)H * W * (unsigned)p.out_pix_stride * (unsigned)oesz;
     const unsigned frame_res = (unsigned)H * W * (unsigned)p.res_pix_stride * 4u;
     const float slope_out = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
     const bool full_epi = p.post_scale != nullptr || p.residual != nullptr;
@@ -331,7 +344,13 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
         }
       }
       if constexpr (nh == 0) ovf_bad |= egne_nonfinite(v[0]);      // lane = pixel: one channel per pixel (common.h)
-      if (p.out_split) {
+      if (o16) {
+        const egne::sp_f32x2 u0 = {v[0] * p.out_split_scale, v[1] * p.out_split_scale}, u1 = {v[2] * p.out_split_scale, v[3] * p.out_split_scale};
+        const h2 h0 = __builtin_convertvector(u0, h2), h1 = __builtin_convertvector(u1, h2);
+        if constexpr (nh == 0) ovf_bad |= egne_nonfinite((float)h0[0]);      // (a value beyond the f16 range under the calibrated scale)
+        v[0] = __builtin_bit_cast(float, h0);
+        v[1] = __builtin_bit_cast(float, h1);
+      } else if (p.out_split) {
         // split-pair storage (egne_conv_desc.out_split): the consumer's hi / lo f16 halves of v * out_split_scale, written here ONCE
         // instead of being derived by every consumer workgroup that stages the element (the dilated group stages it 13.5 times)
         h2 h0, h1, l0, l1;
@@ -344,7 +363,11 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
     };
     auto store_group = [&](auto gc) {
       constexpr int Gi = decltype(gc)::value, nh = Gi & 1, ph = (Gi >> 1) & 1, tm = Gi >> 2;
-      if (p.out_split) {
+      if (o16) {
+        const u32x4 pk = __builtin_bit_cast(u32x4, prev[tm][ph][nh]);
+        const u32x2 two = {pk[0], pk[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(two, rout, jok[nh] ? tvo[tm][ph] : (int)OOB, nh * 32, 0);
+      } else if (p.out_split) {
         // split-pair storage: per pixel and 32-channel block [hi x 32 | lo x 32] halves, the lane's channels {4 kg ..} and {16 + 4 kg ..}
         // side by side at positions 8 kg .. 8 kg + 7 of either plane (the consumer's weights are packed in that channel order): one
         // 16-byte store per plane, 64 contiguous bytes per pixel and store instruction as with plain fp32
@@ -417,14 +440,14 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           const int y = tl.y0 + row0;
           if (p.pool_out) {      // second output: 2x2 / stride 2 / ceil-mode max pooling (act(max) = max(act): monotonic activation)
             const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
-            const __amdgpu_buffer_rsrc_t rpo = make_rsrc(p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride,
-                                                         (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * 4u);
+            const __amdgpu_buffer_rsrc_t rpo = make_rsrc((char*)p.pool_out + (long long)tl.b * Hp * Wp * p.pool_pix_stride * oesz,
+                                                         (unsigned)Hp * Wp * (unsigned)p.pool_pix_stride * (unsigned)oesz);
             const bool y1 = y + 1 < H;
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
               const int x = tl.x0 + ph * 16 + l15;
               const bool x1 = x + 1 < W;
-              const int poff = (!(l15 & 1) && x < W && y < H) ? (((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + cb * 32 + 4 * kg) * 4 : (int)OOB;
+              const int poff = (!(l15 & 1) && x < W && y < H) ? (((y >> 1) * Wp + (x >> 1)) * (int)p.pool_pix_stride + p.pool_ch_off + cb * 32 + 4 * kg) * oesz : (int)OOB;
 #pragma unroll
               for (int nh = 0; nh < 2; ++nh) {
                 f32x4 v;
@@ -437,13 +460,20 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
                   const float t = m * out_scale + b4[nh][e];
                   v[e] = fmaxf(t, t * slope_out);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rpo, jok[nh] ? poff : (int)OOB, nh * 64, 0);
+                if (o16) {
+                  const egne::sp_f32x2 u0 = {v[0] * p.out_split_scale, v[1] * p.out_split_scale}, u1 = {v[2] * p.out_split_scale, v[3] * p.out_split_scale};
+                  const h2 h0 = __builtin_convertvector(u0, h2), h1 = __builtin_convertvector(u1, h2);
+                  const u32x2 two = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                  __builtin_amdgcn_raw_buffer_store_b64(two, rpo, jok[nh] ? poff : (int)OOB, nh * 32, 0);
+                } else {
+                  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rpo, jok[nh] ? poff : (int)OOB, nh * 64, 0);
+                }
               }
             }
           }
 #pragma unroll
           for (int a = 0; a < 8; ++a) (&prev[0][0][0])[a] = (&acc[0][0][0])[a];
-          rout = make_rsrc(p.out + (long long)tl.b * H * W * p.out_pix_stride, frame_out);
+          rout = make_rsrc((char*)p.out + (long long)tl.b * H * W * p.out_pix_stride * oesz, frame_out);
           rres = make_rsrc(p.residual ? p.residual + (long long)tl.b * H * W * p.res_pix_stride : nullptr, p.residual ? frame_res : 0u);
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
@@ -451,7 +481,7 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
             for (int ph = 0; ph < 2; ++ph) {
               const int yy = y + tm, x = tl.x0 + ph * 16 + l15;
               const bool okp = yy < H && x < W;
-              tvo[tm][ph] = okp ? ((yy * W + x) * (int)p.out_pix_stride + p.out_ch_off + cb * 32 + 4 * kg) * 4 : (int)OOB;
+              tvo[tm][ph] = okp ? ((yy * W + x) * (int)p.out_pix_stride + p.out_ch_off + cb * 32 + 4 * kg) * oesz : (int)OOB;
               tvr[tm][ph] = okp ? ((yy * W + x) * (int)p.res_pix_stride + p.res_ch_off + cb * 32 + 4 * kg) * 4 : (int)OOB;
             }
           [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (finish_group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, 8>{});
@@ -470,16 +500,16 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
   }
 }
 
-template <int KCH, int NP = 3>
+template <int KCH, int NP = 3, bool F16IN = false>
 int launch_rw(const egne_conv_desc& d, const _Float16* fhi, const _Float16* flo, float a_scale, float os, hipStream_t st) {
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * d.B, ncb = d.CoutP / 32, nrun = (d.Cout_store + 31) / 32;
   constexpr size_t lds = ((size_t)2 * IMGH + (size_t)(KCH == 0 ? 2 : KCH) * WCH) * sizeof(_Float16);
   static_assert(lds <= 163840, "LDS budget");
-  static bool once = hipFuncSetAttribute((const void*)conv3x3_rw_kernel<KCH, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  static bool once = hipFuncSetAttribute((const void*)conv3x3_rw_kernel<KCH, NP, F16IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!once) return egne::fail(EGNE_ERR_LAUNCH, "conv3x3_rw: cannot raise the dynamic LDS limit to %zu", lds);
   // 256 workgroups = 8 XCDs x 32; the ncb blocks of a worker sit on one XCD: 32 / ncb workers per XCD
-  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH, NP>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb, nrun);
+  hipLaunchKernelGGL((conv3x3_rw_kernel<KCH, NP, F16IN>), dim3(256), dim3(512), lds, st, d, fhi, flo, a_scale, os, tiles_x, tiles_y, ntiles, ncb, nrun);
   return egne::check_launch("egne_conv3x3_rw_f16_fwd");
 }
 
@@ -508,13 +538,24 @@ extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi
                                 d.pool_ch_off + d.Cout_store <= d.pool_pix_stride &&
                                 (long long)((d.H + 1) / 2) * ((d.W + 1) / 2) * d.pool_pix_stride * 4 < (1ll << 31)), "conv3x3_rw: pooled output");
   EGNE_REQUIRE(((uintptr_t)fhi & 15) == 0 && ((uintptr_t)flo & 15) == 0 && a_scale > 0.f && w_scale > 0.f, "conv3x3_rw: weights / scales");
-  EGNE_REQUIRE(!d.out_split || (d.out_split_scale > 0.f && d.Cout_store % 32 == 0 && d.out_ch_off % 32 == 0 && !d.pool_out && !d.post_scale && !d.residual),
+  EGNE_REQUIRE(d.out_split != 1 || (d.out_split_scale > 0.f && d.Cout_store % 32 == 0 && d.out_ch_off % 32 == 0 && !d.pool_out && !d.post_scale && !d.residual),
                "conv3x3_rw: split-pair output needs whole 32-channel blocks, a positive scale and no pooled / post-affine / residual options");
+  EGNE_REQUIRE(d.out_split == 0 || d.out_split == 1 || (d.out_split == 2 && d.f16_products == 1 && d.out_split_scale > 0.f && !d.post_scale && !d.residual),
+               "conv3x3_rw: f16 output (out_split = 2) needs f16_products = 1, a positive scale and no post-affine / residual options");
+  const bool in16 = g.presplit == 2;
+  EGNE_REQUIRE(g.presplit == 0 || (in16 && d.f16_products == 1 && !g.scale && g.ch_off % 8 == 0 && g.pix_stride % 8 == 0 &&
+                                   (long long)d.H * d.W * g.pix_stride * 2 < (1ll << 31)),
+               "conv3x3_rw: an f16 input slice (presplit = 2) needs f16_products = 1, no fused affine and 16-byte aligned pixels");
   EGNE_REQUIRE((long long)d.H * d.W * g.pix_stride * 4 < (1ll << 31) && (long long)d.H * d.W * d.out_pix_stride * 4 < (1ll << 31) &&
                (!d.residual || (long long)d.H * d.W * d.res_pix_stride * 4 < (1ll << 31)), "conv3x3_rw: frame too large for 32-bit byte offsets");
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *h = (const _Float16*)fhi, *l = (const _Float16*)flo;
+  if (d.f16_products == 1 && in16) {       // ... read from f16 storage
+    if (d.Ktot == 32) return launch_rw<1, 1, true>(d, h, l, a_scale, os, st);
+    if (d.Ktot == 64) return launch_rw<2, 1, true>(d, h, l, a_scale, os, st);
+    return launch_rw<0, 1, true>(d, h, l, a_scale, os, st);
+  }
   if (d.f16_products == 1) {       // plain f16 operands (egne_conv_desc.f16_products; a split-pair OUTPUT is still written as both halves)
     if (d.Ktot == 32) return launch_rw<1, 1>(d, h, l, a_scale, os, st);
     if (d.Ktot == 64) return launch_rw<2, 1>(d, h, l, a_scale, os, st);

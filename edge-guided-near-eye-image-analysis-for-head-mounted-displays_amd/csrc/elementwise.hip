@@ -31,6 +31,30 @@ __global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, lon
   if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_bits, m);
 }
 
+// the same over a slice held as f16 (egne_conv_desc.out_split = 2): the pattern written is that of the value AS A FLOAT
+__global__ __launch_bounds__(256) void absmax_f16_k(const _Float16* __restrict__ x, long long pix_stride, int ch_off, int Cp,
+                                                    long long npix, unsigned* __restrict__ out_bits) {
+  typedef _Float16 h8_ __attribute__((ext_vector_type(8)));
+  const int nv = Cp >> 3;
+  const long long total = npix * nv;
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / nv;
+    const int c = (int)(i - p * nv) * 8;
+    const h8_ v = *(const h8_*)(x + p * pix_stride + ch_off + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned b = __float_as_uint((float)v[e]) & 0x7fffffffu;
+      m = b > m ? b : m;
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_bits, m);
+}
+
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm / BatchNorm statistics: two deterministic stages, fp64 accumulation.
 //   stage 1: grid (nchunk, ceil(Cp/32), Bn); block = 8 channel-vectors x 32 pixel rows
@@ -384,6 +408,16 @@ extern "C" int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int C
   hipLaunchKernelGGL(absmax_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)pix_stride, ch_off, Cp,
                      (long long)npix, (unsigned*)out_bits);
   return egne::check_launch("egne_absmax");
+}
+
+extern "C" int egne_absmax_f16(const void* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, void* out_bits, void* stream) {
+  EGNE_REQUIRE(x && out_bits && Cp > 0 && Cp % 8 == 0 && ch_off % 8 == 0 && pix_stride % 8 == 0 && npix > 0 && ((uintptr_t)x & 15) == 0,
+               "absmax_f16: bad arguments");
+  long long total = npix * (Cp >> 3), g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(absmax_f16_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (long long)pix_stride, ch_off, Cp,
+                     (long long)npix, (unsigned*)out_bits);
+  return egne::check_launch("egne_absmax_f16");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -124,7 +124,7 @@ def _ptr(t, elem_off=0):
 class Piece:
     """A channel slice [off, off+Cp) of an NHWC fp32 buffer (optionally starting at sample n0)."""
 
-    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd", "presplit", "norm_fuse")
+    __slots__ = ("buf", "off", "C", "Cp", "n0", "scale", "shift", "act_in", "nograd", "presplit", "norm_fuse", "f16s")
 
     def __init__(self, buf, off, C_, Cp=None, n0=0):
         self.buf, self.off, self.C, self.Cp, self.n0 = buf, int(off), int(C_), int(Cp or pad8(C_)), int(n0)
@@ -132,6 +132,7 @@ class Piece:
         self.act_in = ACT_NONE
         self.nograd = False
         self.presplit = None    # a SplitScale: the slice is held in split-pair storage (egne_conv_desc.out_split), see Plan.conv
+        self.f16s = None        # a SplitScale: the slice is held as F16 halves of x * value (egne_conv_desc.out_split = 2; Plan.buf16)
         # training plans: the InstanceNorm backward of this tensor's normalised readers joins its gradient where its PRODUCING convolution
         # masks it (egne_act_norm_bwd; set by the plan builder on tensors whose producer is a convolution of the plan, Plan._pending)
         self.norm_fuse = False
@@ -166,6 +167,12 @@ class SplitScale:
         self.value = F16X3_ASCALE
 
 
+class NeedsFp32Storage(Exception):
+    """Plan.conv: a slice held as f16 (Piece.f16s) met a kernel that neither writes nor reads that storage -- the plan builder falls
+    back to fp32 tensors (bdcn_new.BDCN._build)."""
+
+
+F16_STORAGE = os.environ.get("EGNE_F16_STORAGE", "1") != "0"   # plain-f16 plans (f16_products = 1): conv1_1 / conv1_2 / pool1 of the edge network as f16 tensors
 PRESPLIT = os.environ.get("EGNE_PRESPLIT", "1") != "0"    # MSBlock: `o` written in split-pair storage by its producer (resident-weights 3x3)
 # Position p of a 32-channel block in split-pair storage holds channel 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3): the producer's
 # lanes end with channels {4 kg .. 4 kg + 3} and {16 + 4 kg .. 16 + 4 kg + 3} of a pixel (transposed 16x16x32 product) and store them as
@@ -630,6 +637,7 @@ class Plan:
         self.pre = []       # python callables run before the launches (BN folding etc.)
         self.meta = []      # per call: (kernel family, algorithmic FLOPs) for bench.py's roofline
         self.wscale_refs = []   # (call index, argument index, layer, attribute): weight-pack scales baked into launch arguments
+        self.post_cal = {}  # call index -> (descriptor, f16 output Piece, its SplitScale, pixels): scale of an f16 output re-measured behind the calibrating launch
         self.cal = {}       # call index -> (index of the a_scale argument, raw input Pieces, pixels): split-f16 pre-scale calibration
         self.calibrated = False
         self.dyn_scales = bool(train) and TRAIN_SPLIT and not self.bf16     # split-f16 pre-scales taken on the device (egne_conv_desc.dyn_scale)
@@ -661,6 +669,12 @@ class Plan:
     # ---- memory ------------------------------------------------------------------------------
     def buf(self, B, H, W, Ctot):
         t = torch.zeros((B, H, W, int(Ctot)), dtype=self.dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def buf16(self, B, H, W, Ctot):
+        """An NHWC activation buffer of f16 elements (Piece.f16s: egne_conv_desc.out_split = 2 of its producer)."""
+        t = torch.zeros((B, H, W, int(Ctot)), dtype=torch.float16, device=self.device)
         self.keep.append(t)
         return t
 
@@ -1269,6 +1283,9 @@ class Plan:
         if self.dyn_scales and raw and split and not (smallcin and c4h):
             self._dyn_slot(d, pieces, B, B * H * W, name)
             cal3 = cal2 = None
+        if (getattr(pieces[0], "f16s", None) is not None or dst.f16s is not None) and not ((shalo and rs and not (big or ms1x1 or s1x1 or msdil or lattice))
+                                                                                          or (smallcin and c4h and not big)):
+            raise NeedsFp32Storage(name)      # only the resident-weights 3x3 and the first-layer kernel know f16 storage
         if big and big_tail:
             # two launches over disjoint frame ranges: [0, B - tail) on the 256-wide kernel, the rest on the 128x128 kernel
             layer.ensure_packed(self.device)
@@ -1362,6 +1379,25 @@ class Plan:
                     ps.value = d.out_split_scale = _a_scale_for(bound)
                     return args[:3] + (_a_scale_for(vmax),) + args[4:]
                 cal3 = (cal_ps, list(pieces), B * H * W)
+            fin, fout = pieces[0].f16s, dst.f16s
+            if fin is not None or fout is not None:
+                if not (rw and self.f16_products == 1 and CALIBRATE and not self.dyn_scales and layer.post is None and residual is None and raw):
+                    raise NeedsFp32Storage(name)
+                if fout is not None:
+                    if d.pool_out:
+                        assert pq.f16s is fout, "%s: the pooled second output shares the main output's storage scale" % name
+                    cal3 = self._f16_out(d, layer, dst, B * Ho * Wo, cal3, fin)
+                elif d.pool_out:
+                    raise NeedsFp32Storage(name)
+                if fin is not None:
+                    d.seg[0].presplit = 2
+                    inner = cal3[0] if (cal3 is not None and callable(cal3[0])) else None
+
+                    def cal_in(args, vmax, fin=fin, inner=inner):       # the storage scale IS the operand scale: nothing to measure
+                        if inner is not None:
+                            args = inner(args, 2047.0 / fin.value)      # (a bound on max |x|: what the output's bound starts from)
+                        return args[:3] + (fin.value,) + args[4:]
+                    cal3 = (cal_in, [], 0)
             self._add(self.L.egne_conv3x3_rw_f16_fwd if rw else self.L.egne_conv3x3_rs_f16_fwd,
                       (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE, layer.w_scale), name, flops=flops,
                       kind="conv_f16x3:rw" if rw else "conv_f16x3:rs", cal=cal3, ws=[(4, layer, "w_scale")])
@@ -1397,6 +1433,8 @@ class Plan:
                                                      layer.w_scale), name, flops=flops, kind="conv_f16x3:flat", cal=cal3, ws=[(4, layer, "w_scale")])
         elif smallcin and c4h:
             d.CoutP = layer.c4_coutp
+            if dst.f16s is not None:
+                cal3 = self._f16_out(d, layer, dst, B * Ho * Wo, cal3, None)
             self._add(self.L.egne_conv3x3_smallcin_f16_fwd, (C.byref(d), layer.c4hi.data_ptr(), layer.c4lo.data_ptr(), F16X3_ASCALE,
                                                              layer.w_scale_c4), name, flops=flops, kind="conv_f16x3:first", cal=cal3, ws=[(4, layer, "w_scale_c4")])
         elif smallcin:
@@ -1419,6 +1457,27 @@ class Plan:
             self.keep.append(db)
             self.tape.append(lambda bw: self._bw_conv(bw, layer, list(pieces), dst, db, B, H, W, Ho, Wo, name))
         return Ho, Wo
+
+    def _f16_out(self, d, layer, dst, npix, cal, fin):
+        """dst is held as f16 (Piece.f16s): out_split = 2.  The calibrating run first stores with a scale from a BOUND on |out| (max |in|
+        * max_co sum |w| + max |b|: nothing can overflow), then Plan._run_calibrating measures the stored tensor, sets the scale that
+        puts its maximum in [1024, 2048) and runs the launch again (post_cal)."""
+        fs = dst.f16s
+        assert self.f16_products == 1 and CALIBRATE and not self.dyn_scales and cal is not None, "f16 storage needs a calibrated plain-f16 plan"
+        d.out_split, d.out_split_scale = 2, fs.value
+        ai, pcs, npx = cal
+
+        def cal_out(args, vmax, d=d, layer=layer, fs=fs, ai=ai, fin=fin):
+            if fin is not None:
+                vmax = 2047.0 / fin.value
+            with torch.no_grad():
+                bound = vmax * float(layer.weights[0].detach().abs().sum(dim=(1, 2, 3)).max())
+                if layer.biases is not None and layer.biases[0] is not None:
+                    bound += float(layer.biases[0].detach().abs().max())
+            fs.value = d.out_split_scale = _a_scale_for(bound)
+            return ai(args, vmax) if callable(ai) else args[:ai] + (_a_scale_for(vmax),) + args[ai + 1:]
+        self.post_cal[len(self.calls)] = (d, dst, fs, npix)
+        return (cal_out, pcs, npx)
 
     def _presplit_in(self, d, pieces, residual, cal):
         """One-launch dilated group whose input was written in split-pair storage: flag the slice and take the launch's pre-scale
@@ -2313,6 +2372,18 @@ def _run_calibrating(self, st):
         rc = fn(*args, st)
         if rc != 0:
             _lib.check(rc, name)
+        pc = self.post_cal.get(i)
+        if pc is not None:        # an f16 output: stored under a bound's scale -- measure it, take the scale of its maximum, store again
+            d, dst, fs, npix = pc
+            mx.zero_()
+            _lib.check(self.L.egne_absmax_f16(dst.ptr, dst.stride, dst.off, dst.Cp, npix, mx.data_ptr(), st), "absmax_f16")
+            v = float(mx.view(torch.float32).item())
+            if not math.isfinite(v):
+                raise RuntimeError("non-finite activations leave %s (max |x s| = %r)" % (name, v))
+            new = _a_scale_for(v / fs.value)
+            if new != fs.value:
+                fs.value = d.out_split_scale = new
+                _lib.check(fn(*args, st), name)
     self.calibrated = True
 
 

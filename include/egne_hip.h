@@ -49,7 +49,9 @@ typedef struct {
   const float* shift;   /*   ([B][Cp], used to fuse InstanceNorm / BatchNorm into the consumer) */
   int32_t act_in;       /* egne_act applied after the affine (LeakyReLU of Transition_down) */
   int32_t presplit;     /* 1: the slice is held in SPLIT-PAIR storage (see egne_conv_desc.out_split), written with the scale that is
-                         * passed as this launch's a_scale; honoured by egne_msblock_dil(_scores)_f16_fwd only, 0 everywhere else */
+                         * passed as this launch's a_scale; honoured by egne_msblock_dil(_scores)_f16_fwd only, 0 everywhere else.
+                         * 2: the slice is held as F16 (out_split = 2 of its producer; ptr at halfs, pix_stride / ch_off in halfs, multiples
+                         * of 8), written with this launch's a_scale: egne_conv3x3_rw_f16_fwd with f16_products = 1 only */
 } egne_seg;
 
 /*
@@ -122,7 +124,13 @@ typedef struct {
    * either plane holds channel 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3) of the block (the order the producer's lanes end
    * with, so that a lane stores 16 contiguous bytes per plane) and the consumer's weights are packed in that order.  The consumer
    * (seg.presplit = 1) copies 16-byte pieces straight into its LDS operand image and recovers x = (hi + lo) / s where it needs
-   * the value itself (the 4-way sum of bdcn_new.py:54), exact to 2^-22 |x|. */
+   * the value itself (the 4-way sum of bdcn_new.py:54), exact to 2^-22 |x|.
+   * out_split = 2 (egne_conv3x3_rw_f16_fwd and egne_conv3x3_smallcin_f16_fwd with f16_products = 1; round 6): F16 storage -- the output
+   * (and egne_conv3x3_rw_f16_fwd's pooled second output) is written as f16(v s), one half per element in CHANNEL order; `out` /
+   * `pool_out` then point at halfs, strides and offsets count halfs (slices on multiples of 8).  A plain-f16 consumer rounds its operand to
+   * exactly this value while staging it (f16(x a_scale), a_scale = s), so the stored tensor carries everything the consumer would have
+   * kept at half the bytes: conv1_1 / conv1_2 / pool1 of the frozen edge network next to a bf16-storage training plan
+   * (vgg16_c.py:66-70 under utils.py:646).  Consumers read it through seg.presplit = 2 with a_scale = s. */
   int32_t out_split;
   float out_split_scale;      /* s > 0, a power of two */
   /* Optional (every split-f16 entry point): sticky overflow word.  The kernel sets bit 0 when a value it stores is not finite --
@@ -311,6 +319,9 @@ int egne_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw
  * choose the power-of-two pre-scale of the split-f16 kernels (a_scale): |x| * a_scale must stay below the f16 range,
  * which the fixed scale of round 1 did not guarantee for arbitrary checkpoints. */
 int egne_absmax(const float* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, void* out_bits, void* stream);
+/* The same over a slice held as F16 (egne_conv_desc.out_split = 2; pix_stride / ch_off in halfs, multiples of 8): the word receives the
+ * bit pattern of max |x| as a FLOAT, so the host derives scales from either measurement alike. */
+int egne_absmax_f16(const void* x, int64_t pix_stride, int ch_off, int Cp, int64_t npix, void* out_bits, void* stream);
 
 /* Per-(n,c) mean / inverse std over H*W of an NHWC slice -> scale = rstd, shift = -mean*rstd
  * ([B][Cp]).  F.instance_norm at models/RITnet_v2.py:40,57 (eps 1e-5, biased variance).  With

@@ -78,6 +78,46 @@ def test_bdcn_plain_f16_operands_next_to_a_bf16_training_plan():
     assert np.abs(got1 - got3).max() > 0, "the single-product plan ran the split kernels"
 
 
+@pytest.mark.parametrize("B", [64, 6])
+def test_bdcn_plain_f16_plan_keeps_its_stage1_tensors_as_f16(B):
+    """Round 6: in a plain-f16 plan conv1_1, conv1_2 and pool1 are STORED as f16 (egne_conv_desc.out_split = 2, egne_seg.presplit = 2;
+    vgg16_c.py:66-70 under utils.py:646).  Their consumers round every operand to exactly the stored value while staging it, so the plan
+    must reproduce the fp32-storage plan of the same arithmetic BIT for bit -- all 11 outputs, distinct frames -- at half the bytes; the
+    storage scales come out of the calibration (bound first, measured maximum second) with the usual 32x of head-room."""
+    from common import bdcn_module
+    from egne_amd import engine, synth
+    bd = bdcn_module().to(DEV)
+    bd.f16_products = 1
+    x = torch.cat((synth.make_batch(B, seed=77)["img"],) * 3, 1).to(DEV)
+    outs, plans = [], []
+    for on in (True, False):
+        old = engine.F16_STORAGE
+        engine.F16_STORAGE = on
+        try:
+            bd._plans.clear()
+            o = bd(x)
+            torch.cuda.synchronize()
+            o2 = bd(x)          # replay with the stored scales
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(o, o2))
+            outs.append([t.clone() for t in o])
+            plans.append(bd._last_plan)
+        finally:
+            engine.F16_STORAGE = old
+    p16, p32 = plans
+    assert p16.f16_storage and not p32.f16_storage and len(p16.post_cal) == 2 and not p32.post_cal
+    for (d, dst, fs, npix) in p16.post_cal.values():
+        m = float(dst.buf.float().abs().max())
+        assert dst.buf.dtype == torch.float16 and 1024.0 <= m < 2048.0 and d.out_split == 2 and d.out_split_scale == fs.value, (m, fs.value)
+    assert [k for k, _ in p16.meta] == [k for k, _ in p32.meta]
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), "output %d differs between f16 and fp32 storage: %.3e" % (k, (a - b).abs().max().item())
+    bytes16 = sum(t.numel() * t.element_size() for t in p16.keep if torch.is_tensor(t))
+    bytes32 = sum(t.numel() * t.element_size() for t in p32.keep if torch.is_tensor(t))
+    print("B=%d: f16 storage of conv1_1 / conv1_2 / pool1: plan buffers %.2f -> %.2f GB, all 11 outputs bit-identical" % (B, bytes32 / 1e9, bytes16 / 1e9))
+    bd._plans.clear()
+
+
 def test_bdcn_side_outputs_big_batch():
     """All 11 maps at B=64 (the 10 side outputs only at the fixture's 8x8 sub-grid)."""
     from common import bdcn_module, gold
