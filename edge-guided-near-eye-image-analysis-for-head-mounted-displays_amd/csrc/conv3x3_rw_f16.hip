@@ -375,7 +375,8 @@ void conv3x3_rw_kernel(const egne_conv_desc p, const _Float16* __restrict__ fhi,
           const u32x4 p0 = __builtin_bit_cast(u32x4, prev[tm][ph][0]), p1 = __builtin_bit_cast(u32x4, prev[tm][ph][1]);
           const u32x4 hi = {p0[0], p0[1], p1[0], p1[1]}, lo = {p0[2], p0[3], p1[2], p1[3]};
           __builtin_amdgcn_raw_buffer_store_b128(hi, rout, tvo[tm][ph], 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(lo, rout, tvo[tm][ph], 64, 0);
+          // (a plain-f16 plan never reads the lo plane: its one consumer takes the hi halves as operands AND as the residual)
+          if constexpr (NP == 3) __builtin_amdgcn_raw_buffer_store_b128(lo, rout, tvo[tm][ph], 64, 0);
         }
       } else {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, prev[tm][ph][nh]), rout, jok[nh] ? tvo[tm][ph] : (int)OOB, nh * 64, 0);
@@ -556,7 +557,7 @@ extern "C" int egne_conv3x3_rw_f16_fwd(const egne_conv_desc* dp, const void* fhi
     if (d.Ktot == 64) return launch_rw<2, 1, true>(d, h, l, a_scale, os, st);
     return launch_rw<0, 1, true>(d, h, l, a_scale, os, st);
   }
-  if (d.f16_products == 1) {       // plain f16 operands (egne_conv_desc.f16_products; a split-pair OUTPUT is still written as both halves)
+  if (d.f16_products == 1) {       // plain f16 operands (egne_conv_desc.f16_products; of a split-pair OUTPUT only the hi plane is written: no plain-f16 consumer reads the other)
     if (d.Ktot == 32) return launch_rw<1, 1>(d, h, l, a_scale, os, st);
     if (d.Ktot == 64) return launch_rw<2, 1>(d, h, l, a_scale, os, st);
     return launch_rw<0, 1>(d, h, l, a_scale, os, st);
