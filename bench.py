@@ -509,13 +509,13 @@ class Bench:
                   "algorithmic_bytes_per_step": int(conv_b / max(steps, 1))}
         sp_ach = sp_f / sp_t / 1e12 if sp_t > 0 else 0.0
         r_split = {"bound": "mfma", "kernel": "split-f16 conv family (fp32 tensors, %d x v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 per product, fp32 " % products +
-                   "accumulate): conv_f16x3_big_kernel, conv3x3_rw_kernel, conv3x3_rs_kernel, fused_1x1_3x3_kernel, msblock_dil_kernel, "
+                   "accumulate): conv_f16x3_big_kernel (plain f16: conv_f16_big1_kernel), conv3x3_rw_kernel, conv3x3_rs_kernel, fused_1x1_3x3_kernel, msblock_dil_kernel (plain f16: msdil1_kernel), "
                    "conv3x3_halo_f16_kernel, conv_f16x3_kernel, conv1x1 kernels; inference plans of BDCN and ESF-Net, 3x3 forward convolutions "
                    "data and weight gradients of training plans",
                    "achieved": round(sp_ach, 2), "peak": round(PEAK_F16_MFMA_TFLOPS / products, 1), "mfmas_per_product": products,
                    "unit": "TFLOP/s (algorithmic, fp32-equivalent; peak = 2500 dense f16 MFMA / %d MFMA%s per product%s)"
                            % (products, "s" if products > 1 else "", "" if products == 3 else
-                              ": plain f16 operands in the deep trunk, resident-weights, halo, flat and dilated-group kernels; conv1_1 / conv1_2 keep three"),
+                              ": plain f16 operands in the deep trunk, resident-weights, halo, flat and dilated-group kernels, conv1_1 / conv1_2 / pool1 stored as f16; conv1_1 keeps three"),
                    "frac": round(sp_ach / (PEAK_F16_MFMA_TFLOPS / products), 4), "traffic": None,
                    "launches_per_step": sp_n // max(steps, 1), "avg_launch_ms": round(1e3 * sp_t / max(sp_n, 1), 4),
                    "algorithmic_gflop_per_frame": round(sp_f / steps / B / 1e9, 2), "time_share": round(sp_t / dt, 4),

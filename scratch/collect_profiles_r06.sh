@@ -45,7 +45,7 @@ python3 - "$out" <<'PY'
 import csv, glob, json, re, sys, collections
 out = sys.argv[1]
 SPLIT = ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel",
-         "fused_1x1_3x3_kernel", "msblock_dil_kernel", "msdil_ps_kernel", "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel", "conv3x3_rw_kernel", "conv1x1_pool_f16x3_kernel", "conv3x3_wgrad_halo_f16_kernel")
+         "fused_1x1_3x3_kernel", "msblock_dil_kernel", "msdil_ps_kernel", "msdil1_kernel", "conv_f16_big1_kernel", "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel", "conv3x3_rw_kernel", "conv1x1_pool_f16x3_kernel", "conv3x3_wgrad_halo_f16_kernel")
 FP32 = ("conv3x3_narrow_f32_kernel", "conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_c4_kernel", "conv_wgrad", "conv3x3_wgrad_halo_kernel", "conv1x1_wgrad_allpairs_kernel")
 BF16 = ("conv3x3_bf16_kernel", "conv1x1_bf16_kernel", "conv1x1_bf16_multi_kernel", "wgrad3x3_bf16_kernel", "wgrad3x3_bf16_wide_kernel", "wgrad1x1_bf16_kernel", "conv_wgrad_wide_kernel", "conv_narrow_bf16_kernel")
 def fam(k):
@@ -63,7 +63,7 @@ def collect(prefix, steps):
                 if "absmax_k" in r["Kernel_Name"] and prefix == "pmc":      # calibration pass of the first run only: not steady state
                     continue
                 k = fam(r["Kernel_Name"])
-                m = re.search(r"(fused_1x1_3x3_kernel|msblock_dil_kernel|msdil_ps_kernel|conv[a-z0-9_]*kernel|wgrad[a-z0-9_]*kernel|[a-z0-9_]+_k(?![a-z0-9_]))", r["Kernel_Name"])
+                m = re.search(r"(fused_1x1_3x3_kernel|msblock_dil_kernel|msdil_ps_kernel|msdil1_kernel|conv[a-z0-9_]*kernel|wgrad[a-z0-9_]*kernel|[a-z0-9_]+_k(?![a-z0-9_]))", r["Kernel_Name"])
                 short = m.group(1) if m else r["Kernel_Name"].split("(")[0][-48:]
                 tot[c][k] += float(r["Counter_Value"]); per[c][short] += float(r["Counter_Value"])
                 if c == "FETCH_SIZE": cnt[k] += 1; pcnt[short] += 1

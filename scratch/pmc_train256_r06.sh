@@ -19,7 +19,7 @@ python3 - "$out" "$*" <<'PY'
 import csv, glob, json, sys, collections
 out, extra = sys.argv[1], sys.argv[2]
 BF16 = ("conv3x3_bf16_kernel", "conv1x1_bf16_kernel", "conv1x1_bf16_multi_kernel", "wgrad3x3_bf16_kernel", "wgrad3x3_bf16_wide_kernel", "wgrad1x1_bf16_kernel", "conv_wgrad_wide_kernel", "conv_narrow_bf16_kernel")
-EDGE = ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel", "msblock_dil_kernel", "msdil_ps_kernel",
+EDGE = ("conv_f16x3_kernel", "conv_f16x3_big_kernel", "conv3x3_halo_f16_kernel", "conv1x1_f16x3_kernel", "conv1x1_ms_f16x3_kernel", "msblock_dil_kernel", "msdil_ps_kernel", "msdil1_kernel", "conv_f16_big1_kernel",
         "conv3x3_c4_f16_kernel", "conv3x3_rs_kernel", "conv3x3_rw_kernel", "bdcn_", "maxpool")
 def fam(k):
     if any(s in k for s in BF16): return "bf16_conv"
