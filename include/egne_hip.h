@@ -824,7 +824,7 @@ typedef enum {
   EGNE_KIND_NARROW_F32 = 3,       /* egne_conv3x3_narrow_fwd */
   EGNE_KIND_F16X3_FLAT = 4,       /* egne_conv2d_f16x3_fwd */
   EGNE_KIND_F16X3_SMALL = 5,      /* egne_conv2d_f16x3_small_fwd */
-  EGNE_KIND_F16X3_BIG = 6,        /* egne_conv2d_f16x3_big_fwd (+ egne_conv2d_f16x3_fwd for tail_frames) */
+  EGNE_KIND_F16X3_BIG = 6,        /* egne_conv2d_f16x3_big_fwd (+ egne_conv2d_f16x3_fwd for tail_frames); with f16_products = 1 and egne_conv2d_f16_big1_supported(): egne_conv2d_f16_big1_fwd */
   EGNE_KIND_F16X3_HALO = 7,       /* egne_conv3x3_halo_f16_fwd */
   EGNE_KIND_F16X3_RS = 8,         /* egne_conv3x3_rs_f16_fwd */
   EGNE_KIND_F16X3_RW = 9,         /* egne_conv3x3_rw_f16_fwd */
