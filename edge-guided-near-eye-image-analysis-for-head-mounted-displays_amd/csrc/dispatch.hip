@@ -23,6 +23,7 @@ inline int cdivi(int a, int b) { return (a + b - 1) / b; }
 // engine.py defaults
 constexpr int HALO_MIN_W = 30, HALO_MAX_COUTP = 128, HALO_F16_MIN_W = 30, HALO_F16_MIN_W_NARROW = 30, HALO_F16_MAX_COUTP = 256;
 constexpr int LATTICE_MIN_W = 20, RS_MIN_W = 60, RW_MIN_W = 120, RW_MAX_COUTP = 32, RW_MAX_CP = 512;
+constexpr int RS_MIN_W_F16 = 30, RW_MIN_W_F16 = 30;      // plain-f16 plans (egne_conv_query.f16_products = 1): engine.RS_MIN_W_F16 / RW_MIN_W_F16
 constexpr int BIG_MIN_COUT = 256, BIG_MIN_CIN = 64, BIG_CUS = 256;
 constexpr long long MS1X1_MIN_PIX = 30000, S1X1_MIN_PIX = 100000;
 
@@ -115,9 +116,9 @@ extern "C" int egne_conv2d_auto_kind(const egne_conv_query* qp, egne_conv_choice
   const int sfrag_coutp = CoutP <= 64 ? CoutP : (CoutP + 63) / 64 * 64;
   const int split_coutp = (Cout > 64 && G == 1) ? (Cout + 127) / 128 * 128 : CoutP;
   const long long mx_stride = st0 > q.dst_pix_stride ? st0 : q.dst_pix_stride;
-  bool rs = split && !lattice && !msdil && k3 && G == 1 && same1 && q.stride == 1 && q.pad_mode == 0 && d0 == 1 && q.nseg == 1 && W >= RS_MIN_W &&
+  bool rs = split && !lattice && !msdil && k3 && G == 1 && same1 && q.stride == 1 && q.pad_mode == 0 && d0 == 1 && q.nseg == 1 && W >= (q.f16_products == 1 ? RS_MIN_W_F16 : RS_MIN_W) &&
             (long long)H * W * mx_stride < (1ll << 29) && (!q.has_residual || (long long)H * W * q.res_pix_stride < (1ll << 29));
-  const bool rw_wide = rs && Cp0 > 64 && Cp0 <= RW_MAX_CP && sfrag_coutp <= RW_MAX_COUTP && !q.want_stats && W >= RW_MIN_W && cstore % 8 == 0 &&
+  const bool rw_wide = rs && Cp0 > 64 && Cp0 <= RW_MAX_CP && sfrag_coutp <= RW_MAX_COUTP && !q.want_stats && W >= (q.f16_products == 1 ? RW_MIN_W_F16 : RW_MIN_W) && cstore % 8 == 0 &&
                        q.dst_pix_stride % 4 == 0 && q.dst_ch_off % 4 == 0 && (!q.has_residual || (q.res_pix_stride % 4 == 0 && q.res_ch_off % 4 == 0));
   rs = rw_wide || (rs && Cp0 >= 8 && Cp0 <= 64 && (sfrag_coutp == 32 || sfrag_coutp == 64 || sfrag_coutp == 128) && !(Cp0 <= 32 && sfrag_coutp == 128));
   if (rs && !rw_wide && Cp0 > 32 && Cp0 <= 64 && Cp0 % 32 > 0 && Cp0 % 32 <= 16) rs = false;          // a short tail chunk: the halo kernel skips its zero half

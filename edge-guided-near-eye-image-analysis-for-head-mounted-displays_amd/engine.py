@@ -29,6 +29,12 @@ RW_MAX_CP = int(os.environ.get("EGNE_RW_MAX_CP", "512"))        # ... and widest
 RW_ENABLED = os.environ.get("EGNE_RW", "1") != "0"             # resident-weights form of the role-split 3x3 (no consumer loads)
 RS_ENABLED = os.environ.get("EGNE_RS", "1") != "0"             # role-split (producer / consumer waves) 3x3 kernel for narrow inputs
 RS_MIN_W = int(os.environ.get("EGNE_RS_MIN_W", "60"))
+# plain-f16 plans (f16_products = 1): narrowest map of the role-split / streamed-weights forms.  With one product per multiply the halo kernel's
+# load -> convert -> barrier -> multiply sequence per 32-channel chunk is pure latency (256 -> 32 at 60x80: 163 us against 144 on the streamed-weights
+# kernel), and a resident-weights producer writes `o` in split-pair storage, which puts the dilated group on the ring-of-rows / strip kernels
+# (121 -> 41 us at 60x80, 47 -> 33 us at 30x40)
+RS_MIN_W_F16 = int(os.environ.get("EGNE_RS_MIN_W_F16", "30"))
+RW_MIN_W_F16 = int(os.environ.get("EGNE_RW_MIN_W_F16", "30"))
 NARROW_F32 = os.environ.get("EGNE_NARROW_F32", "1") != "0"          # <= 4 output channels: exact-fp32 vector-ALU kernel (conv_narrow_f32.hip)
 TAIL16_HALO = os.environ.get("EGNE_TAIL16_HALO", "1") != "0"      # 33..48-channel slices: halo kernel (skips the zero half k-step) instead of role-split
 MSDIL_ENABLED = os.environ.get("EGNE_MSDIL", "1") != "0"       # dilated MSBlock groups as one launch (sum in registers)
@@ -1033,6 +1039,7 @@ class Plan:
             q.want_pool, q.pool_Cp, q.pool_pix_stride = 1, pool.Cp, pool.stride
         q.up_add = int(up_add is not None)
         q.narrow_bf16_ok = int(mine == "conv_bf16:narrow")
+        q.f16_products = int(self.f16_products)
         ch = _lib.ConvChoice()
         _lib.check(self.L.egne_conv2d_auto_kind(C.byref(q), C.byref(ch)), "conv2d_auto_kind")
         theirs = ch.name.decode()
@@ -1157,13 +1164,13 @@ class Plan:
         # narrow-input 3x3 layers on wide maps: producer / consumer waves (conv3x3_rs_f16.hip) instead of the all-in-one halo kernel
         rs = (split and RS_ENABLED and HALO_F16_ENABLED and not lattice and not msdil and layer.kh == 3 and layer.kw == 3
               and layer.G == 1 and layer.pad == (1, 1) and layer.stride == 1 and layer.pad_mode == 0 and layer.dils[0] == 1
-              and len(pieces) == 1 and W >= RS_MIN_W and H * W * max(pieces[0].stride, dst.stride) < 2 ** 29
+              and len(pieces) == 1 and W >= (RS_MIN_W_F16 if self.f16_products == 1 else RS_MIN_W) and H * W * max(pieces[0].stride, dst.stride) < 2 ** 29
               and (residual is None or H * W * residual.stride < 2 ** 29))
         # wider inputs: the resident-weights kernel with its weights streamed chunk by chunk (no statistics from its epilogue)
         # (measured against the halo kernel: ahead for 128 -> 32 at 120x160 (290 vs 318 us), level or behind at 60x80 and for wide
         #  outputs -- every output block stages the input again --, so only single-block layers on wide maps take it by default)
         rw_wide = (rs and RW_ENABLED and 64 < pieces[0].Cp <= RW_MAX_CP and layer.sfrag_coutp() <= RW_MAX_COUTP and not stats
-                   and W >= RW_MIN_W and min(layer.Cout_store, dst.Cp) % 8 == 0 and dst.stride % 4 == 0 and dst.off % 4 == 0
+                   and W >= (RW_MIN_W_F16 if self.f16_products == 1 else RW_MIN_W) and min(layer.Cout_store, dst.Cp) % 8 == 0 and dst.stride % 4 == 0 and dst.off % 4 == 0
                    and (residual is None or (residual.stride % 4 == 0 and residual.off % 4 == 0)))
         rs = rw_wide or (rs and 8 <= pieces[0].Cp <= 64 and layer.sfrag_coutp() in (32, 64, 128)
                          and not (pieces[0].Cp <= 32 and layer.sfrag_coutp() == 128))

@@ -866,6 +866,8 @@ typedef struct {
   int32_t want_scores;            /* MSBlock: the block's share of the stage's score maps instead of its output */
   int32_t up_add;                 /* a half-resolution addend is up-sampled into the result (streaming 1x1) */
   int32_t narrow_bf16_ok;         /* dtype 1: egne_conv_narrow_bf16_supported said yes on the finished descriptor */
+  int32_t f16_products;           /* egne_conv_desc.f16_products of the plan's split-f16 launches (1: plain f16 operands -- the role-split / streamed-weights
+                                   * 3x3 forms then take maps from 30 pixels of width on) */
 } egne_conv_query;
 
 typedef struct {
