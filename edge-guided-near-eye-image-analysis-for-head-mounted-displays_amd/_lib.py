@@ -62,7 +62,7 @@ class ConvQuery(C.Structure):
                 ("act", C.c_int32), ("has_post", C.c_int32), ("has_residual", C.c_int32), ("res_pix_stride", C.c_int64), ("res_ch_off", C.c_int32),
                 ("split", C.c_int32), ("split1", C.c_int32), ("split_c4", C.c_int32), ("train", C.c_int32), ("dyn_scales", C.c_int32),
                 ("is_dgrad", C.c_int32), ("want_stats", C.c_int32), ("want_pool", C.c_int32), ("pool_Cp", C.c_int32), ("pool_pix_stride", C.c_int64),
-                ("want_scores", C.c_int32), ("up_add", C.c_int32), ("narrow_bf16_ok", C.c_int32), ("f16_products", C.c_int32)]
+                ("want_scores", C.c_int32), ("up_add", C.c_int32), ("narrow_bf16_ok", C.c_int32), ("f16_products", C.c_int32), ("f16_storage", C.c_int32)]
 
 
 class ConvChoice(C.Structure):
@@ -142,6 +142,7 @@ SIGNATURES = {
     "egne_avgpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_norm_act_pool2": (i32, [vp, i64, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_maxpool2": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "egne_maxpool2_f16": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x_nearest": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
     "egne_upsample2x_nearest_bwd": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp]),

@@ -131,14 +131,16 @@ class BDCN(nn.Module):
         if f16_storage is None:
             # plain-f16 plans: conv1_1 / conv1_2 / pool1 as F16 tensors (egne_conv_desc.out_split = 2) -- their consumers round every operand
             # to exactly the stored value anyway, so nothing changes but the bytes; fp32 tensors where a chosen kernel does not know the storage
+            # (level 2: also the outputs of conv3_1 .. conv5_3 and pool3 / pool4 -- deep trunk kernel, streamed-weights 3x3 and pooling read them)
             if engine.F16_STORAGE and getattr(self, "_plan_products", 0) == 1:
-                try:
-                    return self._build(B, H, W, dev, only_fuse, edge_thres, True)
-                except engine.NeedsFp32Storage:
-                    pass
-            return self._build(B, H, W, dev, only_fuse, edge_thres, False)
+                for level in ((2, 1) if engine.F16_STORAGE_DEEP else (1,)):
+                    try:
+                        return self._build(B, H, W, dev, only_fuse, edge_thres, level)
+                    except engine.NeedsFp32Storage:
+                        pass
+            return self._build(B, H, W, dev, only_fuse, edge_thres, 0)
         pl = Plan(dev)
-        pl.f16_storage = bool(f16_storage)
+        pl.f16_storage = int(f16_storage)
         # BDCN.f16_products = 1: plain f16 operands (one MFMA per product instead of the split's three) in the kernels that know
         # egne_conv_desc.f16_products -- the frozen edge network next to a training plan with bf16 activation storage, which rounds
         # the edge map to bf16 on entry (train.py / bench.py set it for --prec 16 only; inference and fp32 storage keep the split)
@@ -269,8 +271,10 @@ class BDCN(nn.Module):
                 if pooled is not None:
                     dst = pooled
                 else:
-                    ob = pl.buf(B, ho, wo, cur.Cp)
+                    c16 = getattr(cur, "f16s", None)
+                    ob = (pl.buf16 if c16 is not None else pl.buf)(B, ho, wo, cur.Cp)
                     dst = Piece(ob, 0, cur.C)
+                    dst.f16s = c16
                     pl.maxpool2(cur, dst, B, hh, ww, s, "vgg.pool")
                 cur, hh, ww, pooled = dst, ho, wo, None
                 continue
@@ -279,7 +283,7 @@ class BDCN(nn.Module):
             layer = ConvLayer([conv.weight], [conv.bias], [(cin, pad8(cin))], pad=(1, 1), dils=(d,), act=ACT_RELU)
             layer.split = cin % 32 == 0      # frozen trunk: split-f16 MFMA (conv_f16x3.hip), edge map tolerance 1e-3
             layer.split_c4 = cin <= 4        # conv1_1: streaming split-f16 first-layer kernel (conv3x3_c4_f16.hip)
-            h16 = f16_storage and name in ("conv1_1", "conv1_2")
+            h16 = (f16_storage >= 1 and name in ("conv1_1", "conv1_2")) or (f16_storage >= 2 and name[4] in "345")
             ob = (pl.buf16 if h16 else pl.buf)(B, hh, ww, cout)
             dst = Piece(ob, 0, cout)
             if h16:
@@ -290,8 +294,6 @@ class BDCN(nn.Module):
                 pq = Piece((pl.buf16 if h16 else pl.buf)(B, maxpool_out(hh, 2), maxpool_out(ww, 2), pad8(cout)), 0, cout)
                 pq.f16s = dst.f16s
             pl.conv(layer, [cur], dst, B, hh, ww, name="vgg." + name, pool=pq)
-            if h16 and pq is not None and not pl.last_pooled:
-                raise engine.NeedsFp32Storage("vgg.pool behind " + name)      # (the stand-alone pooling kernel reads fp32)
             pooled = pq if pl.last_pooled else None
             cur = dst
             si, bi = block_of[name]

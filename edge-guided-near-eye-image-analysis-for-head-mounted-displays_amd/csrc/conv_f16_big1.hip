@@ -23,6 +23,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 namespace {
@@ -41,13 +42,18 @@ __host__ __device__ __forceinline__ constexpr int swz(int r) {
 }
 
 // NB = 32-channel blocks per wave along N (2 -> BN = 256 with 4 waves along N, 1 -> BN = 128)
-template <int NB>
-__global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc p, const char* __restrict__ wimg, float a_scale,
-                                                            float out_scale) {
+// F16IN: the input slice is held as f16 (egne_seg.presplit = 2: halves of x * a_scale in channel order): the activations are staged like the
+// weights -- by LDS-DMA, three steps ahead, no registers, no conversion (lane l of a 16-row instruction: row l >> 2, LDS chunk l & 3 <- the row's
+// chunk (l & 3) ^ key(row); taps outside the image and rows past the batch carry the out-of-range offset and land as zeros)
+// (the body is a __device__ function behind two thin kernels: with F16IN as a parameter of the KERNEL template hipcc's host pass dropped the
+//  stubs of the F16IN = true instantiations without a diagnostic)
+template <int NB, bool F16IN>
+__device__ __forceinline__ void conv_f16_big1_body(const egne_conv_desc& p, const char* __restrict__ wimg, float a_scale, float out_scale) {
   constexpr int BN = 128 * NB;
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int NTN = 2 * NB;                            // 16-channel blocks per wave
-  constexpr int NVM = 4 + NB;                            // vector-memory instructions a wave issues per step
+  constexpr int NVM = (F16IN ? 2 : 4) + NB;              // vector-memory instructions a wave issues per step
+  constexpr int ESZ = F16IN ? 2 : 4;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform: the LDS-DMA's base goes through M0 without a loop)
@@ -59,27 +65,31 @@ __global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc
   const egne_seg sg = p.seg[0];
   const int hw = p.Ho * p.Wo, frame_px = p.H * p.W;
   const int b0 = (int)(m0 / hw);
-  const long long in_left = ((long long)p.B - b0) * frame_px * sg.pix_stride * 4;
-  const __amdgpu_buffer_rsrc_t rin = make_rsrc(sg.ptr + (long long)b0 * frame_px * sg.pix_stride,
+  const long long in_left = ((long long)p.B - b0) * frame_px * sg.pix_stride * ESZ;
+  const __amdgpu_buffer_rsrc_t rin = make_rsrc((const char*)sg.ptr + (long long)b0 * frame_px * sg.pix_stride * ESZ,
                                                (unsigned)(in_left < 0x7fffffffll ? in_left : 0x7fffffffll));
   const int nchunk = sg.Cp >> 5;
   const int nsteps = T * nchunk;                         // even (launcher)
   // weight images: [ntile][step = chunk*T + tap][BN rows x 64 B]
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(wimg + (long long)ntile * nsteps * (BN * ROWB), (unsigned)(nsteps * BN * ROWB));
 
-  // ---- activation staging: thread -> 4 items (row = (tid>>3) + 64*i, float4 column c4 = tid&7) ----
+  // ---- activation staging.  fp32 input: thread -> 4 items (row = (tid>>3) + 64*i, float4 column c4 = tid&7); f16 input: lane -> 2 DMA
+  //      pieces (row = 32 wave + 16 i + (lane >> 2), source chunk (lane & 3) ^ key(row)) ----
+  constexpr int NIT = F16IN ? 2 : 4;
   const int c4 = tid & 7;
-  int roff[4];
-  unsigned tapmask[4];
+  int roff[NIT];
+  unsigned tapmask[NIT];
   {
     const int dil = p.dil[0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long long m = m0 + (tid >> 3) + 64 * i;
+    for (int i = 0; i < NIT; ++i) {
+      const int row_i = F16IN ? 32 * wave + 16 * i + (lane >> 2) : (tid >> 3) + 64 * i;
+      const long long m = m0 + row_i;
       const int b = (int)(m / hw);
       const int r = (int)(m - (long long)b * hw);
       const int oy = r / p.Wo, ox = r - oy * p.Wo;
-      roff[i] = ((((b - b0) * p.H + oy) * p.W + ox) * (int)sg.pix_stride + sg.ch_off + c4 * 4) * 4;
+      roff[i] = F16IN ? ((((b - b0) * p.H + oy) * p.W + ox) * (int)sg.pix_stride + sg.ch_off + (((lane & 3) ^ swz(row_i)) << 3)) * 2
+                      : ((((b - b0) * p.H + oy) * p.W + ox) * (int)sg.pix_stride + sg.ch_off + c4 * 4) * 4;
       unsigned mk = 0;
       for (int ky = 0; ky < p.kh; ++ky)
         for (int kx = 0; kx < p.kw; ++kx) {
@@ -93,19 +103,34 @@ __global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc
   const int ldst0 = (tid >> 3) * ROWB + ((((c4 >> 1) ^ swz(tid >> 3))) << 4) + (c4 & 1) * 8;
   const int wvoff = lane * 16;
 
-  u32x4 ra[2][4];
-  int ky_n = 0, kx_n = 0, c0_n = 0, tap_n = 0;          // coordinates of the step load_a requests next
+  u32x4 ra[2][F16IN ? 1 : 4];
+  int ky_n = 0, kx_n = 0, c0_n = 0, tap_n = 0;          // coordinates of the step load_a / dma_a requests next
+  auto advance = [&]() {
+    if (++kx_n == p.kw) { kx_n = 0; ++ky_n; }
+    if (ky_n == p.kh) { ky_n = 0; c0_n += 32; }
+    tap_n = tap_n + 1 == T ? 0 : tap_n + 1;
+  };
   auto load_a = [&](u32x4* dst, bool on) {
     const int dil = p.dil[0];
     const int tapoff = (((ky_n - p.pad_h) * p.W + (kx_n - p.pad_w)) * dil * (int)sg.pix_stride + c0_n) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (F16IN ? 0 : 4); ++i) {
       const bool ok = on && ((tapmask[i] >> tap_n) & 1u);
       dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? roff[i] + tapoff : (int)OOB, 0, 0);
     }
-    if (++kx_n == p.kw) { kx_n = 0; ++ky_n; }
-    if (ky_n == p.kh) { ky_n = 0; c0_n += 32; }
-    tap_n = tap_n + 1 == T ? 0 : tap_n + 1;
+    advance();
+  };
+  // f16 input: the step's 256 rows x 64 B straight into ring slot `slot` (16 instructions of 1 KB, two per wave)
+  auto dma_a = [&](int slot, bool on) {
+    const int dil = p.dil[0];
+    const int tapoff = (((ky_n - p.pad_h) * p.W + (kx_n - p.pad_w)) * dil * (int)sg.pix_stride + c0_n) * 2;
+    char* base = lds + slot * STAGE + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < (F16IN ? 2 : 0); ++i) {
+      const bool ok = on && ((tapmask[i] >> tap_n) & 1u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(base + i * 1024), 16, ok ? roff[i] + tapoff : (int)OOB, 0, 0, 0);
+    }
+    advance();
   };
   // weight image of `step` into ring slot `slot`: BN rows x 64 B = BN / 16 wave instructions of 1 KB, NB per wave; already swizzled
   auto dma_b = [&](int slot, int step) {
@@ -157,6 +182,37 @@ __global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc
         acc[half * 4 + t][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[tn], a[t], acc[half * 4 + t][tn], 0, 0, 0);
   };
 
+  h8 a0[4], a1[4], bf[2][NTN];
+  if constexpr (F16IN) {
+    // ---- prologue: steps 0, 1 and 2 requested; 0 and 1 have landed ----
+    dma_a(0, true);
+    dma_b(0, 0);
+    dma_a(1, nsteps > 1);
+    dma_b(1, 1);
+    dma_a(2, nsteps > 2);
+    dma_b(2, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(a0, 0, 0);
+    read_b(bf[0], 0);
+    auto step_body = [&](int step, auto pc) {
+      constexpr int P = decltype(pc)::value;
+      const int cur = step & 3, nxt = (step + 1) & 3;
+      read_a(a1, cur, 1);
+      mfma_half(a0, bf[P], 0);
+      dma_a((step + 3) & 3, step + 3 < nsteps);          // slot last read in step - 1: every wave has passed the barrier since
+      dma_b((step + 3) & 3, step + 3);
+      read_a(a0, nxt, 0);                                // slot nxt is complete since the barrier in front of this step
+      read_b(bf[P ^ 1], nxt);
+      mfma_half(a1, bf[P], 1);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NVM) : "memory");      // step + 2 has landed
+      __builtin_amdgcn_s_barrier();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+      step_body(step, std::integral_constant<int, 0>{});
+      step_body(step + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
   // ---- prologue: steps 0 and 1 into slots 0 and 1, step 2 requested ----
   load_a(ra[0], true);
   dma_b(0, 0);
@@ -169,7 +225,6 @@ __global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc
   dma_b(2, 2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  h8 a0[4], a1[4], bf[2][NTN];
   read_a(a0, 0, 0);
   read_b(bf[0], 0);
 
@@ -195,12 +250,16 @@ __global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc
     step_body(step, std::integral_constant<int, 0>{});
     step_body(step + 1, std::integral_constant<int, 1>{});
   }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (requests past the end: nothing may land in LDS after the workgroup has gone)
 
   // ---- epilogue: transposed product, lane = pixel lr of the block, channels n = 16 * blk + 4 * kg + e (register e) ----
   const float slope = p.act == EGNE_ACT_RELU ? 0.f : (p.act == EGNE_ACT_LEAKY ? 0.01f : 1.f);
   const long long left = M - m0;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + m0 * p.out_pix_stride, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * 4));
+  // out_split = 2: the output is stored as f16 halves of v * out_split_scale in channel order (the F16IN form's input format)
+  const bool o16 = p.out_split == 2;
+  const int oesz = o16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc((char*)p.out + m0 * p.out_pix_stride * oesz, (unsigned)((left < BM ? left : BM) * p.out_pix_stride * oesz));
   bool bad = false;
 #pragma unroll
   for (int tn = 0; tn < NTN; ++tn) {
@@ -217,11 +276,28 @@ __global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc
       }
       if (tn == 0) bad |= egne_nonfinite(v[0]);          // lane = pixel: one channel per pixel (common.h)
       const int row = wm * 128 + tm * 16 + lr;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
-                                             nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
+      if (o16) {
+        const f32x2 u0 = {v[0] * p.out_split_scale, v[1] * p.out_split_scale}, u1 = {v[2] * p.out_split_scale, v[3] * p.out_split_scale};
+        const h2 h0 = __builtin_convertvector(u0, h2), h1 = __builtin_convertvector(u1, h2);
+        if (tn == 0) bad |= egne_nonfinite((float)h0[0]);
+        const u32x2 two = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+        __builtin_amdgcn_raw_buffer_store_b64(two, rout, nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 2 : (int)OOB, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout,
+                                               nok ? (row * (int)p.out_pix_stride + p.out_ch_off + n) * 4 : (int)OOB, 0, 0);
+      }
     }
   }
   egne_ovf_commit(bad, p.ovf_flag);
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void conv_f16_big1_kernel(const egne_conv_desc p, const char* __restrict__ wimg, float a_scale, float out_scale) {
+  conv_f16_big1_body<NB, false>(p, wimg, a_scale, out_scale);
+}
+template <int NB>
+__global__ __launch_bounds__(512) void conv_f16_big1_h_kernel(const egne_conv_desc p, const char* __restrict__ wimg, float a_scale, float out_scale) {
+  conv_f16_big1_body<NB, true>(p, wimg, a_scale, out_scale);
 }
 
 // OIHW fp32 -> LDS images [ntile][step = chunk*T + tap][BN rows][64 B]: row j = output channel ntile*BN + j, its 16-byte chunk c
@@ -272,6 +348,9 @@ extern "C" int egne_conv2d_f16_big1_fwd(const egne_conv_desc* dp, const void* wi
   const egne_seg& g = d.seg[0];
   EGNE_REQUIRE(g.ptr && g.Cp % 32 == 0 && g.Cp == d.Ktot && ((uintptr_t)g.ptr & 15) == 0 && g.ch_off % 4 == 0 && g.pix_stride % 4 == 0 &&
                ((g.Cp / 32) * d.kh * d.kw) % 2 == 0, "conv_f16_big1: input slice (Cp %d Ktot %d, an even number of K steps)", g.Cp, d.Ktot);
+  const bool in16 = g.presplit == 2;
+  EGNE_REQUIRE(g.presplit == 0 || (in16 && g.ch_off % 8 == 0 && g.pix_stride % 8 == 0), "conv_f16_big1: an f16 input slice (presplit = 2) starts on multiples of 8 halfs");
+  EGNE_REQUIRE(d.out_split == 0 || (d.out_split == 2 && d.out_split_scale > 0.f), "conv_f16_big1: out_split is 0 or 2 (f16 output) with a positive scale");
   EGNE_REQUIRE(d.CoutP % 128 == 0 && d.Cout_store <= d.CoutP && d.Cout_store % 4 == 0 && d.out && ((uintptr_t)d.out & 15) == 0 &&
                d.out_ch_off % 4 == 0 && d.out_pix_stride % 4 == 0 && d.out_ch_off + d.Cout_store <= d.out_pix_stride &&
                d.out_pix_stride * 1024 < (1ll << 31) && (!d.bias || ((uintptr_t)d.bias & 15) == 0), "conv_f16_big1: output");
@@ -282,16 +361,15 @@ extern "C" int egne_conv2d_f16_big1_fwd(const egne_conv_desc* dp, const void* wi
   const long long M = (long long)d.B * d.Ho * d.Wo;
   const float os = 1.0f / (a_scale * w_scale);
   hipStream_t st = (hipStream_t)stream;
-  if (d.CoutP % 256 == 0) {
-    if (!egne::raise_lds((const void*)conv_f16_big1_kernel<2>, NSTG * (BM + 256) * ROWB))
-      return egne::fail(EGNE_ERR_LAUNCH, "conv_f16_big1: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL((conv_f16_big1_kernel<2>), dim3((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 256)), dim3(512),
-                       NSTG * (BM + 256) * ROWB, st, d, (const char*)wimg, a_scale, os);
-  } else {
-    if (!egne::raise_lds((const void*)conv_f16_big1_kernel<1>, NSTG * (BM + 128) * ROWB))
-      return egne::fail(EGNE_ERR_LAUNCH, "conv_f16_big1: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL((conv_f16_big1_kernel<1>), dim3((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / 128)), dim3(512),
-                       NSTG * (BM + 128) * ROWB, st, d, (const char*)wimg, a_scale, os);
-  }
+#define EGNE_BIG1_GO(KERN, BNV)                                                                                                          \
+  do {                                                                                                                                  \
+    if (!egne::raise_lds((const void*)KERN, NSTG * (BM + BNV) * ROWB))                                                                  \
+      return egne::fail(EGNE_ERR_LAUNCH, "conv_f16_big1: cannot raise the dynamic LDS limit");                                          \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)((M + BM - 1) / BM), (unsigned)(d.CoutP / BNV)), dim3(512), NSTG * (BM + BNV) * ROWB, st,   \
+                       d, (const char*)wimg, a_scale, os);                                                                              \
+  } while (0)
+  if (d.CoutP % 256 == 0) { if (in16) EGNE_BIG1_GO(conv_f16_big1_h_kernel<2>, 256); else EGNE_BIG1_GO(conv_f16_big1_kernel<2>, 256); }
+  else { if (in16) EGNE_BIG1_GO(conv_f16_big1_h_kernel<1>, 128); else EGNE_BIG1_GO(conv_f16_big1_kernel<1>, 128); }
+#undef EGNE_BIG1_GO
   return egne::check_launch("egne_conv2d_f16_big1_fwd");
 }

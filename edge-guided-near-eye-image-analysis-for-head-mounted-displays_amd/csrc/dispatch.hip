@@ -147,7 +147,7 @@ extern "C" int egne_conv2d_auto_kind(const egne_conv_query* qp, egne_conv_choice
     auto wgs = [&](long long nbf) { return (nbf * Ho * Wo + 255) / 256 * ny; };
     const long long full = wgs(B) / BIG_CUS;
     const double frac = (double)wgs(B) / BIG_CUS - (double)full;
-    if (full >= 1 && frac > 0.04 && frac < 0.65) {
+    if (full >= 1 && frac > 0.04 && frac < 0.65 && !q.f16_storage) {      // (f16 tensors: the flat kernel behind a ragged round reads and writes fp32)
       long long b1 = B;
       while (b1 > 1 && wgs(b1) > full * BIG_CUS) --b1;
       if ((double)wgs(b1) >= 0.9 * (double)(full * BIG_CUS)) out->tail_frames = (int)(B - b1);

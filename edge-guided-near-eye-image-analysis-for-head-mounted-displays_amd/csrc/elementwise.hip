@@ -276,6 +276,43 @@ __global__ void maxpool2_k(const float* __restrict__ x, long long xs, int xo, fl
   }
 }
 
+// the same pooling over a slice held as f16 (egne_conv_desc.out_split = 2 of its producer; the maximum commutes with the storage scale):
+// eight channels (16 bytes) per thread
+__global__ void maxpool2_f16_k(const _Float16* __restrict__ x, long long xs, int xo, _Float16* __restrict__ y, long long ys,
+                               int yo, int B, int H, int W, int Ho, int Wo, int stride, int Cp) {
+  typedef _Float16 h8_ __attribute__((ext_vector_type(8)));
+  const unsigned nv = Cp >> 3;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)Wo * nv) return;
+  const int ox = (int)(t / nv), c = (int)(t - ox * nv) * 8;
+  const int b = blockIdx.z;
+  const int x0 = ox * stride, x1 = x0 + 1 < W ? x0 + 1 : x0;
+  const _Float16* s = x + ((long long)b * H * W) * xs + xo + c;
+  h8_ v[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = blockIdx.y * 4 + j;
+    const int y0 = oy < Ho ? oy * stride : 0, y1 = y0 + 1 < H ? y0 + 1 : y0;
+    v[j][0] = *(const h8_*)(s + ((long long)y0 * W + x0) * xs);
+    v[j][1] = *(const h8_*)(s + ((long long)y0 * W + x1) * xs);
+    v[j][2] = *(const h8_*)(s + ((long long)y1 * W + x0) * xs);
+    v[j][3] = *(const h8_*)(s + ((long long)y1 * W + x1) * xs);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = blockIdx.y * 4 + j;
+    if (oy < Ho) {
+      h8_ r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float m = fmaxf(fmaxf((float)v[j][0][e], (float)v[j][1][e]), fmaxf((float)v[j][2][e], (float)v[j][3][e]));
+        r[e] = (_Float16)m;
+      }
+      *(h8_*)(y + (((long long)b * Ho + oy) * Wo + ox) * ys + yo + c) = r;
+    }
+  }
+}
+
 template <typename T>
 __global__ void upsample2x_k(const T* __restrict__ x, long long xs, int xo, T* __restrict__ y, long long ys,
                              int yo, int B, int H, int W, int Cp) {
@@ -593,6 +630,19 @@ extern "C" int egne_norm_act_pool2(const float* x, int64_t xs, int xo, const flo
 extern "C" int egne_norm_act_pool2_bf16(const void* x, int64_t xs, int xo, const float* scale, const float* shift, int act,
                                         void* y, int64_t ys, int yo, int B, int H, int W, int Cp, void* stream) {
   return norm_act_pool2_impl((const egne_bf16*)x, xs, xo, scale, shift, act, (egne_bf16*)y, ys, yo, B, H, W, Cp, stream);
+}
+
+extern "C" int egne_maxpool2_f16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W,
+                                 int Ho, int Wo, int stride, int Cp, void* stream) {
+  EGNE_REQUIRE(x && y && Cp > 0 && Cp % 8 == 0 && xo % 8 == 0 && yo % 8 == 0 && xs % 8 == 0 && ys % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+               ((uintptr_t)y & 15) == 0 && xo + Cp <= xs && yo + Cp <= ys, "maxpool2_f16: bad slices");
+  EGNE_REQUIRE(stride == 1 || stride == 2, "maxpool2_f16: stride %d", stride);
+  auto osz = [&](int n) { int o = (n - 2 + stride - 1) / stride + 1; if ((o - 1) * stride >= n) --o; return o; };
+  EGNE_REQUIRE(B > 0 && H >= 2 && W >= 2 && Ho == osz(H) && Wo == osz(W), "maxpool2_f16: output %dx%d != %dx%d", Ho, Wo, osz(H), osz(W));
+  EGNE_REQUIRE(Ho <= 65535 && B <= 65535, "maxpool2_f16: grid limits");
+  hipLaunchKernelGGL(maxpool2_f16_k, dim3((Wo * (Cp / 8) + 255) / 256, (Ho + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
+                     (long long)xs, xo, (_Float16*)y, (long long)ys, yo, B, H, W, Ho, Wo, stride, Cp);
+  return egne::check_launch("egne_maxpool2_f16");
 }
 
 extern "C" int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo, int B, int H, int W,

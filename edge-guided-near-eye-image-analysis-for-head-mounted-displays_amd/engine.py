@@ -179,6 +179,7 @@ class NeedsFp32Storage(Exception):
 
 
 F16_STORAGE = os.environ.get("EGNE_F16_STORAGE", "1") != "0"   # plain-f16 plans (f16_products = 1): conv1_1 / conv1_2 / pool1 of the edge network as f16 tensors
+F16_STORAGE_DEEP = os.environ.get("EGNE_F16_STORAGE_DEEP", "1") != "0"   # ... and conv3_1 .. conv5_3, pool3 / pool4 (the deep trunk kernel stages both operands by LDS-DMA)
 PRESPLIT = os.environ.get("EGNE_PRESPLIT", "1") != "0"    # MSBlock: `o` written in split-pair storage by its producer (resident-weights 3x3)
 # Position p of a 32-channel block in split-pair storage holds channel 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3): the producer's
 # lanes end with channels {4 kg .. 4 kg + 3} and {16 + 4 kg .. 16 + 4 kg + 3} of a pixel (transposed 16x16x32 product) and store them as
@@ -1040,6 +1041,7 @@ class Plan:
         q.up_add = int(up_add is not None)
         q.narrow_bf16_ok = int(mine == "conv_bf16:narrow")
         q.f16_products = int(self.f16_products)
+        q.f16_storage = int(getattr(p0, "f16s", None) is not None or dst.f16s is not None)
         ch = _lib.ConvChoice()
         _lib.check(self.L.egne_conv2d_auto_kind(C.byref(q), C.byref(ch)), "conv2d_auto_kind")
         theirs = ch.name.decode()
@@ -1290,9 +1292,11 @@ class Plan:
         if self.dyn_scales and raw and split and not (smallcin and c4h):
             self._dyn_slot(d, pieces, B, B * H * W, name)
             cal3 = cal2 = None
-        if (getattr(pieces[0], "f16s", None) is not None or dst.f16s is not None) and not ((shalo and rs and not (big or ms1x1 or s1x1 or msdil or lattice))
-                                                                                          or (smallcin and c4h and not big)):
-            raise NeedsFp32Storage(name)      # only the resident-weights 3x3 and the first-layer kernel know f16 storage
+        any16 = getattr(pieces[0], "f16s", None) is not None or dst.f16s is not None
+        if any16 and big and big1:
+            big_tail = 0                      # (the flat kernel behind a ragged last round reads and writes fp32)
+        if any16 and not ((shalo and rs and not (big or ms1x1 or s1x1 or msdil or lattice)) or (smallcin and c4h and not big) or (big and big1)):
+            raise NeedsFp32Storage(name)      # only the resident-weights 3x3, the first-layer kernel and the plain-f16 deep trunk kernel know f16 storage
         if big and big_tail:
             # two launches over disjoint frame ranges: [0, B - tail) on the 256-wide kernel, the rest on the 128x128 kernel
             layer.ensure_packed(self.device)
@@ -1311,6 +1315,13 @@ class Plan:
             self._add(self.L.egne_conv2d_f16x3_fwd, (C.byref(d2), layer.whi.data_ptr(), layer.wlo.data_ptr(), F16X3_ASCALE, layer.w_scale),
                       name + ".tail", flops=flops * big_tail / B, kind="conv_f16x3:flat", cal=cal3, ws=[(4, layer, "w_scale")])
         elif big:
+            if any16:
+                if not (CALIBRATE and not self.dyn_scales and raw):
+                    raise NeedsFp32Storage(name)
+                if dst.f16s is not None:
+                    cal2 = self._f16_out(d, layer, dst, B * Ho * Wo, cal2, pieces[0].f16s)
+                if pieces[0].f16s is not None:
+                    cal2 = self._f16_in(d, pieces[0].f16s, cal2, 2)
             self._add(self.L.egne_conv2d_f16_big1_fwd if big1 else self.L.egne_conv2d_f16x3_big_fwd,
                       (C.byref(d), (layer.wimg1 if big1 else layer.wimg).data_ptr(), F16X3_ASCALE, layer.w_scale_big), name,
                       flops=flops, kind="conv_f16x3:big", cal=cal2, ws=[(3, layer, "w_scale_big")])
@@ -1397,14 +1408,7 @@ class Plan:
                 elif d.pool_out:
                     raise NeedsFp32Storage(name)
                 if fin is not None:
-                    d.seg[0].presplit = 2
-                    inner = cal3[0] if (cal3 is not None and callable(cal3[0])) else None
-
-                    def cal_in(args, vmax, fin=fin, inner=inner):       # the storage scale IS the operand scale: nothing to measure
-                        if inner is not None:
-                            args = inner(args, 2047.0 / fin.value)      # (a bound on max |x|: what the output's bound starts from)
-                        return args[:3] + (fin.value,) + args[4:]
-                    cal3 = (cal_in, [], 0)
+                    cal3 = self._f16_in(d, fin, cal3, 3)
             self._add(self.L.egne_conv3x3_rw_f16_fwd if rw else self.L.egne_conv3x3_rs_f16_fwd,
                       (C.byref(d), layer.fhi.data_ptr(), layer.flo.data_ptr(), F16X3_ASCALE, layer.w_scale), name, flops=flops,
                       kind="conv_f16x3:rw" if rw else "conv_f16x3:rs", cal=cal3, ws=[(4, layer, "w_scale")])
@@ -1475,8 +1479,8 @@ class Plan:
         ai, pcs, npx = cal
 
         def cal_out(args, vmax, d=d, layer=layer, fs=fs, ai=ai, fin=fin):
-            if fin is not None:
-                vmax = 2047.0 / fin.value
+            if fin is not None and not vmax:
+                vmax = getattr(fin, "vmax", None) or 2047.0 / fin.value
             with torch.no_grad():
                 bound = vmax * float(layer.weights[0].detach().abs().sum(dim=(1, 2, 3)).max())
                 if layer.biases is not None and layer.biases[0] is not None:
@@ -1485,6 +1489,19 @@ class Plan:
             return ai(args, vmax) if callable(ai) else args[:ai] + (_a_scale_for(vmax),) + args[ai + 1:]
         self.post_cal[len(self.calls)] = (d, dst, fs, npix)
         return (cal_out, pcs, npx)
+
+    def _f16_in(self, d, fin, cal, ai):
+        """pieces[0] is held as f16 (Piece.f16s = fin): presplit = 2 and the launch's a_scale argument (index ``ai``) IS the storage scale --
+        nothing is measured; an inner calibration callback (the output's bound) starts from the maximum measured when the tensor's own scale
+        was calibrated (SplitScale.vmax)."""
+        d.seg[0].presplit = 2
+        inner = cal[0] if (cal is not None and callable(cal[0])) else None
+
+        def cal_in(args, vmax, fin=fin, inner=inner, ai=ai):
+            if inner is not None:
+                args = inner(args, getattr(fin, "vmax", None) or 2047.0 / fin.value)
+            return args[:ai] + (fin.value,) + args[ai + 1:]
+        return (cal_in, [], 0)
 
     def _presplit_in(self, d, pieces, residual, cal):
         """One-launch dilated group whose input was written in split-pair storage: flag the slice and take the launch's pre-scale
@@ -2183,8 +2200,10 @@ class Plan:
         o = lambda n: min((n - 2 + stride - 1) // stride + 1, (n - 1) // stride + 1)  # noqa: E731
         Ho, Wo = o(H), o(W)
         assert src.Cp == dst.Cp
-        self._add(self.L.egne_maxpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, Ho, Wo,
-                                         stride, src.Cp), name, kind="maxpool2")
+        f16 = getattr(src, "f16s", None) is not None
+        assert (not f16 and dst.f16s is None) or dst.f16s is src.f16s, "%s: a pooled f16 slice keeps its input's storage scale" % name
+        self._add(self.L.egne_maxpool2_f16 if f16 else self.L.egne_maxpool2, (src.ptr, src.stride, src.off, dst.ptr, dst.stride, dst.off, B, H, W, Ho, Wo,
+                                                                            stride, src.Cp), name, kind="maxpool2")
         return Ho, Wo
 
     def upsample2x(self, src, dst, B, H, W, name="upsample"):
@@ -2387,7 +2406,8 @@ def _run_calibrating(self, st):
             v = float(mx.view(torch.float32).item())
             if not math.isfinite(v):
                 raise RuntimeError("non-finite activations leave %s (max |x s| = %r)" % (name, v))
-            new = _a_scale_for(v / fs.value)
+            fs.vmax = v / fs.value          # max |x| of the tensor (as stored: f16-rounded): what a consumer's own bounds start from
+            new = _a_scale_for(fs.vmax)
             if new != fs.value:
                 fs.value = d.out_split_scale = new
                 _lib.check(fn(*args, st), name)

@@ -362,6 +362,10 @@ int egne_norm_act_pool2(const float* x, int64_t xs, int xo, const float* scale, 
 /* nn.MaxPool2d(2, stride, ceil_mode=True) (vgg16_c.py:15,20,27,34) on an NHWC slice. */
 int egne_maxpool2(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
                   int B, int H, int W, int Ho, int Wo, int stride, int Cp, void* stream);
+/* The same pooling over a slice held as F16 (egne_conv_desc.out_split = 2; strides / offsets in halfs, multiples of 8): the maximum commutes with
+ * the storage scale, so the output is held under the input's scale (pool3 / pool4 of vgg16_c.py:76-82 in a plain-f16 plan). */
+int egne_maxpool2_f16(const void* x, int64_t xs, int xo, void* y, int64_t ys, int yo, int B, int H, int W, int Ho, int Wo, int stride,
+                      int Cp, void* stream);
 
 /* F.interpolate(bilinear, scale_factor=2, align_corners=False) (models/RITnet_v2.py:80-83). */
 int egne_upsample2x(const float* x, int64_t xs, int xo, float* y, int64_t ys, int yo,
@@ -868,6 +872,7 @@ typedef struct {
   int32_t narrow_bf16_ok;         /* dtype 1: egne_conv_narrow_bf16_supported said yes on the finished descriptor */
   int32_t f16_products;           /* egne_conv_desc.f16_products of the plan's split-f16 launches (1: plain f16 operands -- the role-split / streamed-weights
                                    * 3x3 forms then take maps from 30 pixels of width on) */
+  int32_t f16_storage;            /* the input slice or the destination is held as f16 (egne_seg.presplit = 2 / egne_conv_desc.out_split = 2) */
 } egne_conv_query;
 
 typedef struct {
