@@ -1063,7 +1063,15 @@ class Plan:
         if CHECK_DISPATCH:
             self._check_dispatch(n0, layer, pieces, dst, B, H, W, residual, name, stats, scores, pool, up_add)
         self._pool_req = self._up_add = None
-        LAYER_BYTES[name] = float(self.esz) * B * (H * W * sum(p.Cp for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) + (residual.Cp if residual is not None else 0)))
+        # algorithmic bytes of the layer: every input slice read once, the output written once -- in the storage the plan holds them in (a plain-f16
+        # plan keeps some tensors as f16: Piece.f16s; of a split-pair slice it reads and writes the hi plane only)
+        def esz_of(p):
+            if getattr(p, "f16s", None) is not None:
+                return 2.0
+            if self.f16_products == 1 and getattr(p, "presplit", None) is not None:
+                return 2.0
+            return float(self.esz)
+        LAYER_BYTES[name] = B * (H * W * sum(p.Cp * esz_of(p) for p in pieces) + r[0] * r[1] * (min(layer.Cout_store, dst.Cp) * esz_of(dst) + (residual.Cp * esz_of(residual) if residual is not None else 0)))
         return r
 
     def _conv_impl(self, layer, pieces, dst, B, H, W, residual=None, name="conv", stats=False, scores=None):
