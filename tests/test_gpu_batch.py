@@ -78,8 +78,8 @@ def test_bdcn_plain_f16_operands_next_to_a_bf16_training_plan():
     assert np.abs(got1 - got3).max() > 0, "the single-product plan ran the split kernels"
 
 
-@pytest.mark.parametrize("B", [64, 6])
-def test_bdcn_plain_f16_plan_keeps_its_stage1_tensors_as_f16(B):
+@pytest.mark.parametrize("B,H,W", [(64, 240, 320), (6, 240, 320), (8, 101, 150)])
+def test_bdcn_plain_f16_plan_keeps_its_stage1_tensors_as_f16(B, H, W):
     """Round 6: in a plain-f16 plan conv1_1, conv1_2, pool1 and every trunk tensor from conv3_1 on (with pool3 / pool4) are STORED as f16 (egne_conv_desc.out_split = 2, egne_seg.presplit = 2;
     vgg16_c.py:66-70 under utils.py:646).  Their consumers round every operand to exactly the stored value while staging it, so the plan
     must reproduce the fp32-storage plan of the same arithmetic BIT for bit -- all 11 outputs, distinct frames -- at half the bytes; the
@@ -89,6 +89,8 @@ def test_bdcn_plain_f16_plan_keeps_its_stage1_tensors_as_f16(B):
     bd = bdcn_module().to(DEV)
     bd.f16_products = 1
     x = torch.cat((synth.make_batch(B, seed=77)["img"],) * 3, 1).to(DEV)
+    if (H, W) != (240, 320):           # ragged tiles / columns in every kernel of the plan
+        x = x[:, :, :H, :W].contiguous()
     outs, plans = [], []
     for on in (True, False):
         old, old_tail = engine.F16_STORAGE, engine.BIG_SPLIT_TAIL
