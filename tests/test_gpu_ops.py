@@ -750,6 +750,61 @@ def test_deep_trunk_kernel_plain_f16_four_stage_form(G, B, Cin, Cout, H, W, d):
     assert err < 2e-6
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,d", [
+    (47, 256, 512, 23, 31, 1),     # ragged last tile (33 511 pixels), two output tiles
+    (110, 512, 512, 15, 20, 2),    # dilation 2, 144 K steps
+    (102, 256, 384, 17, 19, 1),    # 128-wide output tiles, ragged last tile
+])
+def test_deep_trunk_kernel_f16_storage_both_operands_by_dma(G, B, Cin, Cout, H, W, d):
+    """conv_f16_big1_h_kernel (egne_seg.presplit = 2, egne_conv_desc.out_split = 2; the frozen edge network's conv3_2 .. conv5_3 in a
+    plain-f16 plan, vgg16_c.py:72-88 under utils.py:646): input held as f16 halves of x s, activations staged by LDS-DMA like the weights,
+    output stored as halves -- against the fp32-tensor form of the same kernel on the de-quantised input: the stored halves must be
+    exactly f16(out s_out) of that result, with the output's scale calibrated to put its maximum in [1024, 2048), and nothing outside
+    the slice is touched."""
+    from gpu_util import DEV
+    from egne_amd.engine import ConvLayer, Piece, Plan, SplitScale
+    s_in = 64.0
+    xh = (F.relu(_rand(G, B, Cin, H, W)) * s_in).half()                 # the tensor AS STORED
+    x = xh.float() / s_in
+    w, b = _rand(G, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), _rand(G, Cout)
+    layer = ConvLayer([torch.nn.Parameter(w.to(DEV))], [torch.nn.Parameter(b.to(DEV))], [(Cin, Cin)], pad=(1, 1), dils=(d,), act=1)
+    layer.split = True
+    # fp32 tensors in and out
+    pl0 = Plan(torch.device(DEV))
+    pl0.f16_products = 1
+    xb = pl0.buf(B, H, W, Cin)
+    xb.copy_(x.permute(0, 2, 3, 1).to(DEV))
+    o0 = pl0.buf(B, H, W, Cout)
+    pl0.conv(layer, [Piece(xb, 0, Cin)], Piece(o0, 0, Cout), B, H, W)
+    assert pl0.calls[0][0] == pl0.L.egne_conv2d_f16_big1_fwd
+    pl0.run()
+    # f16 tensors in and out
+    pl1 = Plan(torch.device(DEV))
+    pl1.f16_products = 1
+    xb16 = pl1.buf16(B, H, W, Cin + 8)
+    xb16.fill_(777.0)
+    xb16[..., 8:].copy_(xh.permute(0, 2, 3, 1).to(DEV))
+    pin = Piece(xb16, 8, Cin)
+    pin.f16s = SplitScale()
+    pin.f16s.value, pin.f16s.vmax = s_in, float(x.abs().max())
+    o1 = pl1.buf16(B, H, W, Cout + 8)
+    o1.fill_(777.0)
+    pout = Piece(o1, 8, Cout)
+    pout.f16s = SplitScale()
+    pl1.conv(layer, [pin], pout, B, H, W)
+    assert pl1.calls[0][0] == pl1.L.egne_conv2d_f16_big1_fwd and len(pl1.calls) == 1 and len(pl1.post_cal) == 1
+    pl1.run()
+    pl1.run()
+    torch.cuda.synchronize()
+    s_out = pout.f16s.value
+    m = float(o1[..., 8:].float().abs().max())
+    assert 1024.0 <= m < 2048.0, (m, s_out)
+    assert (o1[..., :8] == 777.0).all(), "stores outside the output slice"
+    want = (o0 * s_out).half()
+    assert torch.equal(o1[..., 8:], want), "stored halves differ from f16(fp32 result * scale): %d elements" % (o1[..., 8:] != want).sum().item()
+    print("big1 f16 in / out: %dx%dx%dx%d -> %d, scale %g, max stored %.1f" % (B, Cin, H, W, Cout, s_out, m))
+
+
 @pytest.mark.parametrize("chans,C1,C2,B,H,W,res,post", [
     ((32, 32), 32, 32, 2, 61, 83, False, False),            # ESF block 0 conv21 + conv22 class: ragged tiles in x and y
     ((32, 32, 32), 32, 32, 3, 24, 64, True, False),         # conv31 + conv32 class, residual add in the epilogue
