@@ -78,6 +78,38 @@ def test_bdcn_plain_f16_operands_next_to_a_bf16_training_plan():
     assert np.abs(got1 - got3).max() > 0, "the single-product plan ran the split kernels"
 
 
+def test_bdcn_f16_storage_recalibrates_after_an_overflow_and_a_weight_update():
+    """The storage scales of a plain-f16 plan (egne_conv_desc.out_split = 2) are calibrated like every operand scale, with 32x of head-room.
+    Frames 3000x the calibration batch push stored halves beyond the f16 range: the sticky word must be set (BDCN.overflowed), the next call
+    re-calibrates -- bound first, measured maximum second (engine.Plan.post_cal) -- and then reproduces a FRESH module's plan bit for bit;
+    weights changed in place (the plan's version guards) likewise, without a rerun."""
+    from common import bdcn_module
+    from egne_amd import synth
+    x = torch.cat((synth.make_batch(64, seed=5)["img"],) * 3, 1).to(DEV)
+    bd = bdcn_module().to(DEV)
+    bd.f16_products = 1
+    bd.forward_fuse(x)
+    assert not bd.overflowed() and bd._last_plan.f16_storage == 2
+    xl = x * 3000.0
+    bd.forward_fuse(xl)
+    assert bd.overflowed(), "stored halves beyond the f16 range went unnoticed"
+    o1 = bd.forward_fuse(xl)
+    assert not bd.overflowed() and bool(torch.isfinite(o1).all())
+    fresh = bdcn_module().to(DEV)
+    fresh.f16_products = 1
+    assert torch.equal(o1, fresh.forward_fuse(xl)), "re-calibrated plan differs from a fresh one"
+    with torch.no_grad():
+        for m in (bd, fresh):
+            m.features.conv1_1.weight.mul_(200.0)
+            m.features.conv1_1.bias.mul_(200.0)
+    o2 = bd.forward_fuse(x)
+    assert not bd.overflowed() and bool(torch.isfinite(o2).all())
+    fresh2 = bdcn_module().to(DEV)
+    fresh2.f16_products = 1
+    fresh2.load_state_dict(bd.state_dict())
+    assert torch.equal(o2, fresh2.forward_fuse(x)), "plan after a weight update differs from a fresh one"
+
+
 @pytest.mark.parametrize("B,H,W", [(64, 240, 320), (6, 240, 320), (8, 101, 150)])
 def test_bdcn_plain_f16_plan_keeps_its_stage1_tensors_as_f16(B, H, W):
     """Round 6: in a plain-f16 plan conv1_1, conv1_2, pool1 and every trunk tensor from conv3_1 on (with pool3 / pool4) are STORED as f16 (egne_conv_desc.out_split = 2, egne_seg.presplit = 2;
